@@ -1,0 +1,121 @@
+/* mcvc.h -- C ABI of the MI355X-native MaskCycleGAN-VC hot path (libmcvc_hip.so, gfx950 only).
+ *
+ * The reference (GANtastic3/MaskCycleGAN-VC) has no FFI: its hot path is Python calling torch.nn
+ * ops.  This ABI is the drop-in boundary *below* the Python nn.Module mirror in
+ * maskcyclegan-vc_amd/mask_cyclegan_vc/: every entry point names the reference interface it
+ * replaces (file:line relative to the reference repo root).
+ *
+ * Conventions
+ *   - plain pointers and sizes; every pointer is a DEVICE pointer to contiguous fp32 unless noted;
+ *   - `stream` is a hipStream_t passed as void* (0 = null stream); all calls are asynchronous w.r.t.
+ *     the host, allocate nothing, keep no global state, and are re-entrant;
+ *   - return value 0 = success, otherwise a hipError_t value or MCVC_ERR_* (>= 1000); the Python
+ *     wrapper raises RuntimeError;
+ *   - parameter tables are arrays of device pointers in the reference's `named_parameters()` order
+ *     (Generator: 110 tensors, Discriminator: 20 tensors); gradient tables use
+ *     the same order, entries may be NULL (skipped); gradients are ACCUMULATED (+=);
+ *   - `packed` buffers hold the K-major re-packed weights the MFMA kernels read; they must be
+ *     zero-initialised once by the caller and refreshed with mcvc_*_pack after every parameter update;
+ *   - `stash` keeps what backward needs (conv outputs, InstanceNorm statistics, activations);
+ *     `scratch` is transient (split-K slabs, gradient ping-pong buffers).
+ */
+#ifndef MCVC_H
+#define MCVC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCVC_ABI_VERSION 1
+#define MCVC_GEN_NPARAMS 110
+#define MCVC_DISC_NPARAMS 20
+#define MCVC_N_MEL 80
+
+int mcvc_version(void);
+
+/* ---- sizes (floats) -------------------------------------------------------------------------- */
+long long mcvc_gen_packed_floats(void);
+long long mcvc_disc_packed_floats(void);
+long long mcvc_gen_stash_floats(int B, int T);
+long long mcvc_gen_scratch_floats(int B, int T);
+long long mcvc_disc_stash_floats(int B, int T);
+long long mcvc_disc_scratch_floats(int B, int T);
+int mcvc_gen_out_frames(int T);          /* T' of Generator.forward (== T when T % 4 == 0) */
+int mcvc_disc_out_frames(int T);         /* last dim of Discriminator.forward (T/8 when T % 8 == 0) */
+
+/* ---- weight packing (after every optimizer step / load_state_dict) --------------------------- */
+int mcvc_gen_pack(const float* const* params, float* packed, void* stream);
+int mcvc_disc_pack(const float* const* params, float* packed, void* stream);
+
+/* ---- Generator: replaces Generator.forward (mask_cyclegan_vc/model.py:239-280) and its autograd
+ *      x, mask: [B,80,T] (mask NULL = all ones, test.py:92); out: [B,80,T']                        */
+int mcvc_gen_forward(const float* const* params, const float* packed, const float* x, const float* mask,
+                     float* out, float* stash, float* scratch, long long scratch_floats, int B, int T, void* stream);
+/*      dout: [B,80,T'] ; dx (nullable): [B,80,T], written or accumulated (accumulate_dx != 0)      */
+int mcvc_gen_backward(const float* const* params, const float* packed, float* const* grads, const float* mask,
+                      const float* dout, float* dx, int accumulate_dx, const float* stash,
+                      float* scratch, long long scratch_floats, int B, int T, void* stream);
+
+/* ---- Discriminator: replaces Discriminator.forward (model.py:340-349) and its autograd
+ *      x: [B,80,T]; out: [B,1,10,T8] sigmoid probabilities                                          */
+int mcvc_disc_forward(const float* const* params, const float* packed, const float* x, float* out,
+                      float* stash, float* scratch, long long scratch_floats, int B, int T, void* stream);
+/*      dout: [B,1,10,T8]; grad wrt the sigmoid OUTPUT (dout_is_logit_grad == 0) or wrt the pre-sigmoid
+ *      logits (!= 0, what mcvc_lsgan_loss emits).  grads NULL = data-gradient only (generator phase,
+ *      train.py:211-216 -- the reference computes D weight grads there and discards them).          */
+int mcvc_disc_backward(const float* const* params, const float* packed, float* const* grads,
+                       const float* dout, int dout_is_logit_grad, float* dx, int accumulate_dx,
+                       const float* stash, float* scratch, long long scratch_floats, int B, int T, void* stream);
+
+/* ---- losses (train.py:219-237, 276-294). loss_slot/term_slot: device floats, accumulated (+=) -- */
+/* loss_slot += weight*mean|a-b|, term_slot += mean|a-b|, grad_a (=|+=) weight*sign(a-b)/n           */
+int mcvc_l1_loss(const float* a, const float* b, long long n, float weight, float* loss_slot, float* term_slot,
+                 float* grad_a, int accumulate_grad, void* stream);
+/* d = discriminator sigmoid output; loss_slot += weight*mean((target-d)^2);
+ * grad_logit = d(loss)/d(pre-sigmoid logit)                                                         */
+int mcvc_lsgan_loss(const float* d, long long n, float target, float weight, float* loss_slot, float* term_slot,
+                    float* grad_logit, void* stream);
+
+/* ---- optimizer: torch.optim.Adam(betas, eps, weight_decay=0) on a flat buffer (train.py:119-122) */
+int mcvc_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                   float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+int mcvc_axpy(float* y, const float* x, float alpha, long long n, void* stream);
+
+/* ---- single-op entry points (kernel parity tests; same kernels the network calls use) ---------- */
+/* y[N,Cout,OH,OW] = conv2d(x[N,Cin,H,W], w[Cout,Cin,KH,KW]) + bias ; stride 1 or 2.
+ * wpack: scratch of mcvc_conv2d_pack_floats() floats, zero-initialised by the caller.
+ * slabs: optional split-K scratch (max_slabs-1)*N*Cout*OH*OW floats; the reduced result is in y.     */
+long long mcvc_conv2d_pack_floats(int Cout, int Cin, int KH, int KW);
+int mcvc_conv2d_forward(const float* x, const float* w, const float* bias, float* y, float* wpack,
+                        float* slabs, int max_slabs, int N, int Cin, int H, int W, int Cout, int KH, int KW,
+                        int stride, int pad_h, int pad_w, int pixel_shuffle, void* stream);
+/* dx[N,Cin,H,W] = conv2d_backward_data(dy[N,Cout,OH,OW], w) */
+int mcvc_conv2d_dgrad(const float* dy, const float* w, float* dx, float* wpack, float* slabs, int max_slabs,
+                      int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
+                      void* stream);
+/* dw[Cout,Cin,KH,KW] += conv2d_backward_weight(x, dy) */
+int mcvc_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout,
+                      int KH, int KW, int stride, int pad_h, int pad_w, void* stream);
+/* InstanceNorm(affine) + activation.  act: 0 none, 1 gated GLU (x has 2C channels: value|gate), 2 SiLU.
+ * x[N,Cx,H,W] -> y[N,C,H,W]; stats[N,Cx,2] (mean, rstd)                                              */
+int mcvc_instnorm_act_forward(float* x, const float* gamma, const float* beta, const float* gamma_gate,
+                              const float* beta_gate, const float* residual, float* y, float* stats,
+                              int N, int C, int H, int W, int act, void* stream);
+int mcvc_instnorm_act_backward(const float* x, const float* gamma, const float* beta, const float* gamma_gate,
+                               const float* beta_gate, const float* stats, float* dy, float* dx,
+                               float* dgamma, float* dbeta, float* dgamma_gate, float* dbeta_gate,
+                               int N, int C, int H, int W, int act, void* stream);
+
+/* db[C] += sum over (n, h, w) of dy[N,C,P] */
+int mcvc_bias_grad(const float* dy, float* db, int N, int C, int P, void* stream);
+/* norm-less activations: act 1 gated GLU (x[N,2C,P] -> y[N,C,P]), 2 x*sigmoid(x), 3 sigmoid */
+int mcvc_act_forward(float* x, float* y, int N, int C, int P, int act, void* stream);
+int mcvc_act_backward(const float* x, float* dy, float* dx, int N, int C, int P, int act, void* stream);
+/* xin[N,2,P] = (x*mask, mask)   (model.py:241) ; dx (=|+=) dxin[:,0]*mask */
+int mcvc_fif_input(const float* x, const float* mask, float* xin, int N, int P, void* stream);
+int mcvc_fif_input_grad(const float* dxin, const float* mask, float* dx, int N, int P, int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCVC_H */

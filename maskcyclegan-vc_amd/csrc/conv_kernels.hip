@@ -1,0 +1,538 @@
+// Direct (im2col-free) convolution kernels for gfx950 on the exact-fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32: lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+//  D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31] for accumulator register r).
+//
+// Replaces the reference's nn.Conv2d / nn.Conv1d call sites (mask_cyclegan_vc/model.py:47-69, 86-99,
+// 116-126, 142-146, 183-187, 227-231, 207-211, 290-327) -- forward, data-gradient (same kernel on dY with
+// re-packed weights, see pack_kernels.hip) and weight-gradient.
+#include "mcvc_common.h"
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// =================================================================================================
+// forward / data-gradient kernel
+// =================================================================================================
+// Block = 4 waves arranged BMW x BNW; each wave owns WM x WN accumulators of 32(co) x 32(pixel).
+// LDS per channel chunk:  Xs[cic][PH][PWp]  (input patch incl. halo, zero padded)
+//                         Ws[cic*KH*KW][COT] (K-major weight slice, straight copy of the packed rows)
+// The two k-slots of the 32x32x2 MFMA are the even / odd channel of a channel pair, so both
+// operand addresses are  lane_const + uniform_tap_offset  -> one v_add per ds_read_b32.
+// Stride-2 patches are stored column-de-interleaved (even cols then odd cols) so the 32 lanes of a
+// pixel row read consecutive banks; PWp is chosen on the host so that the rows of one 32-pixel
+// sub-tile start in disjoint bank groups.
+template <int WM, int WN, int BMW, int BNW>
+__global__ void __launch_bounds__(256) conv_direct_kernel(const ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int COT = 32 * WM * BMW;
+    constexpr int NSUB = WN * BNW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm_id = wave / BNW, wn_id = wave % BNW;
+    const int KHKW = a.KH * a.KW;
+
+    const int tile_x = blockIdx.x % a.tiles_w;
+    const int tile_y = blockIdx.x / a.tiles_w;
+    const int co0 = blockIdx.y * COT;
+    const int n = blockIdx.z / a.nsplit;
+    const int split = blockIdx.z - n * a.nsplit;
+
+    const int tow = 1 << a.tow_log2;
+    const int rps = 32 >> a.tow_log2;              // output rows per 32-pixel sub-tile
+    const int toh = NSUB * rps;
+    const int oh0 = tile_y * toh, ow0 = tile_x * tow;
+    const int ih0 = oh0 * a.stride - a.pad_h;
+    const int iw0 = ow0 * a.stride - a.pad_w;
+    const bool s2 = (a.stride == 2);
+
+    float* Xs = smem;
+    float* Ws = smem + a.xs_floats;
+
+    const int r_j = l31 >> a.tow_log2, c_j = l31 & (tow - 1);
+    int b_lane[WN];
+#pragma unroll
+    for (int wn = 0; wn < WN; ++wn) {
+        const int sub = wn_id * WN + wn;
+        b_lane[wn] = half * a.plane + (sub * rps + r_j) * a.stride * a.PWp + c_j;
+    }
+    const int a_lane = half * KHKW * COT + wm_id * (WM * 32) + l31;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ch_begin = split * a.chunks_per_split;
+    int ch_end = ch_begin + a.chunks_per_split;
+    if (ch_end > a.nchunks) ch_end = a.nchunks;
+
+    const float* xn = a.x + (long long)n * a.x_sb;
+
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        const int c0 = ch * a.cic;
+        __syncthreads();
+        // ---- stage the input patch (half-wave per patch row, coalesced along w)
+        {
+            const int rows = a.cic * a.PH;
+            for (int row = tid >> 5; row < rows; row += 8) {
+                const int ci = row / a.PH;
+                const int r = row - ci * a.PH;
+                const int ih = ih0 + r;
+                const int cg = c0 + ci;
+                const bool rok = (cg < a.Cin) && (ih >= 0) && (ih < a.H);
+                const float* src = xn + (long long)cg * a.x_sc + (long long)ih * a.x_sh;
+                float* dst = Xs + ci * a.plane + r * a.PWp;
+                for (int c = l31; c < a.PW; c += 32) {
+                    const int iw = iw0 + c;
+                    float v = 0.f;
+                    if (rok && iw >= 0 && iw < a.W) v = src[iw];
+                    const int cm = s2 ? ((c & 1) * a.PWh + (c >> 1)) : c;
+                    dst[cm] = v;
+                }
+            }
+        }
+        // ---- stage the weight slice (rows are contiguous in the packed layout)
+        {
+            constexpr int V = COT / 4;
+            const int rows = a.cic * KHKW;
+            const long long grow0 = (long long)c0 * KHKW;
+            for (int idx = tid; idx < rows * V; idx += 256) {
+                const int row = idx / V, v4 = idx - row * V;
+                const long long grow = grow0 + row;
+                const int co = co0 + v4 * 4;
+                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (grow < a.w_rows && co < a.w_cout)
+                    val = *reinterpret_cast<const float4*>(a.w + grow * a.w_cout + co);
+                *reinterpret_cast<float4*>(Ws + row * COT + v4 * 4) = val;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA main loop over (channel pair, kh, kw)
+        const int npairs = a.cic >> 1;
+        for (int cp = 0; cp < npairs; ++cp) {
+            const float* xs = Xs + cp * 2 * a.plane;
+            const float* ws = Ws + cp * 2 * KHKW * COT + a_lane;
+            for (int kh = 0; kh < a.KH; ++kh) {
+                const int xrow = kh * a.PWp;
+                for (int kw = 0; kw < a.KW; ++kw) {
+                    const int xoff = xrow + (s2 ? ((kw & 1) * a.PWh + (kw >> 1)) : kw);
+                    float av[WM], bv[WN];
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) av[i] = ws[i * 32];
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) bv[j] = xs[b_lane[j] + xoff];
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) acc[i][j] = MFMA32(av[i], bv[j], acc[i][j]);
+                    ws += COT;
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias, (shuffled) store / slab store / accumulate
+    float* ybase = (split == 0 || a.out_mode == CONV_OUT_ACCUM) ? a.y : (a.y_slabs + (long long)(split - 1) * a.slab_stride);
+    ybase += (long long)n * a.y_sb;
+    const bool add_bias = (a.bias != nullptr) && (split == 0);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int sub = wn_id * WN + j;
+        const int oh = oh0 + sub * rps + r_j;
+        const int ow = ow0 + c_j;
+        const bool pok = (oh < a.OH) && (ow < a.OW);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wm_id * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (pok && co < a.Cout) {
+                    float v = acc[i][j][r];
+                    if (add_bias) v += a.bias[co];
+                    long long off;
+                    if (a.shuffle)
+                        off = (long long)(co >> 2) * a.y_sc + (long long)(2 * oh + ((co >> 1) & 1)) * a.y_sh + (2 * ow + (co & 1));
+                    else
+                        off = (long long)co * a.y_sc + (long long)oh * a.y_sh + (long long)ow * a.y_sw;
+                    if (a.out_mode == CONV_OUT_ACCUM) {
+                        if (a.nsplit > 1) atomicAdd(ybase + off, v);
+                        else ybase[off] += v;
+                    } else {
+                        ybase[off] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- host planner --------------------------------------------------------------------------------
+namespace {
+
+enum ConvCfg { CFG_L = 0, CFG_M, CFG_N, CFG_T, CFG_S, CFG_COUNT };
+struct CfgDesc { int cot, npix; };
+static const CfgDesc kCfg[CFG_COUNT] = {
+    {128, 128},   // L: 2x2 waves of 2x2 accumulators
+    {128, 64},    // M: 2x2 waves of 2x1
+    {64, 128},    // N: 2x2 waves of 1x2
+    {256, 32},    // T: 4x1 waves of 2x1   (1-D trunk: few pixels, many channels)
+    {32, 256},    // S: 1x4 waves of 1x2   (Cout <= 32)
+};
+
+constexpr int kLdsBudgetFloats = 15 * 1024;   // 60 KiB per workgroup -> 2 workgroups per CU
+
+struct ConvPlan {
+    ConvArgs a;
+    dim3 grid;
+    int cfg;
+    size_t lds_bytes;
+};
+
+static int pick_tow_log2(int OW) { return OW > 16 ? 5 : (OW > 8 ? 4 : 3); }
+
+static void patch_geometry(const ConvProblem& p, int npix, int tow_log2, int* PH, int* PW, int* PWp, int* PWh)
+{
+    const int tow = 1 << tow_log2, rps = 32 >> tow_log2, toh = (npix / 32) * rps;
+    *PH = (toh - 1) * p.stride + p.KH;
+    *PW = (tow - 1) * p.stride + p.KW;
+    *PWh = (*PW + 1) / 2;
+    int need = (p.stride == 2) ? 2 * (*PWh) : *PW;
+    int pwp = need;
+    if (rps > 1) {
+        // rows of one sub-tile must start in disjoint bank groups: (stride*PWp) % 32 == tow (or 32-tow when tow==8)
+        for (;; ++pwp) {
+            const int m = (p.stride * pwp) % 32;
+            if (m == tow || (tow == 8 && m == 24)) break;
+        }
+    }
+    *PWp = pwp;
+}
+
+static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_nsplit, ConvPlan* out)
+{
+    if (p.stride != 1 && p.stride != 2) return false;
+    ConvPlan pl;
+    ConvArgs& a = pl.a;
+    a = ConvArgs{};
+    const int tow_log2 = pick_tow_log2(p.OW);
+    const int tow = 1 << tow_log2, rps = 32 >> tow_log2;
+    const int npix_img = p.OH * p.OW;
+    int cfg;
+    if (p.Cout <= 32) cfg = CFG_S;
+    else if (npix_img * 1 <= 48 && p.Cout >= 256) cfg = CFG_T;
+    else if (p.KH * p.KW > 25 || p.Cout <= 64) cfg = CFG_N;
+    else {
+        // prefer the big tile only when it still yields enough workgroups
+        const int toh_l = (kCfg[CFG_L].npix / 32) * rps;
+        const long long blocks_l = (long long)cdiv_i(p.OW, tow) * cdiv_i(p.OH, toh_l) * cdiv_i(p.Cout, 128) * NB;
+        cfg = (blocks_l >= 512) ? CFG_L : CFG_M;
+    }
+    const int cot = kCfg[cfg].cot, npix = kCfg[cfg].npix;
+    const int toh = (npix / 32) * rps;
+    patch_geometry(p, npix, tow_log2, &a.PH, &a.PW, &a.PWp, &a.PWh);
+    a.plane = a.PH * a.PWp;
+    const int khkw = p.KH * p.KW;
+    const int cin_pad = round_up_i(p.Cin, 2);
+    // channels per chunk: as many pairs as fit the LDS budget, capped so a chunk is ~<=256 k-steps
+    int cic = 2;
+    while (cic + 2 <= cin_pad && (cic + 2) * (a.plane + khkw * cot) + 8 <= kLdsBudgetFloats && (cic + 2) * khkw <= 256) cic += 2;
+    if (cic * (a.plane + khkw * cot) + 8 > 40 * 1024) return false;   // would not fit 160 KiB
+    a.cic = cic;
+    a.xs_floats = round_up_i(cic * a.plane, 4);
+    a.nchunks = cdiv_i(cin_pad, cic);
+    a.tow_log2 = tow_log2;
+    a.tiles_w = cdiv_i(p.OW, tow);
+    const int tiles_h = cdiv_i(p.OH, toh);
+    const int cotiles = cdiv_i(p.Cout, cot);
+    const long long blocks = (long long)a.tiles_w * tiles_h * cotiles * NB;
+    int nsplit = 1;
+    if (force_nsplit > 0) {
+        // exact count requested: trailing splits may own no chunk and then only write zeros (+bias)
+        a.nsplit = force_nsplit;
+        a.chunks_per_split = cdiv_i(a.nchunks, force_nsplit);
+    } else {
+        if (allow_split && blocks < 256 && a.nchunks > 1) {
+            nsplit = (int)cdiv_ll(512, blocks);
+            if (nsplit > a.nchunks) nsplit = a.nchunks;
+            if (nsplit > 64) nsplit = 64;
+            if (nsplit < 1) nsplit = 1;
+        }
+        a.chunks_per_split = cdiv_i(a.nchunks, nsplit);
+        a.nsplit = cdiv_i(a.nchunks, a.chunks_per_split);
+    }
+    a.Cin = p.Cin; a.H = p.H; a.W = p.W;
+    a.Cout = p.Cout; a.OH = p.OH; a.OW = p.OW;
+    a.KH = p.KH; a.KW = p.KW; a.stride = p.stride; a.pad_h = p.pad_h; a.pad_w = p.pad_w;
+    pl.cfg = cfg;
+    pl.grid = dim3((unsigned)(a.tiles_w * tiles_h), (unsigned)cotiles, (unsigned)(NB * a.nsplit));
+    pl.lds_bytes = (size_t)(a.xs_floats + cic * khkw * cot) * sizeof(float);
+    *out = pl;
+    return true;
+}
+
+template <int WM, int WN, int BMW, int BNW>
+static hipError_t launch_cfg(const ConvPlan& pl, hipStream_t s)
+{
+    auto kern = conv_direct_kernel<WM, WN, BMW, BNW>;
+    if (pl.lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, pl.grid, dim3(256), pl.lds_bytes, s, pl.a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+int mcvc_conv_plan_nsplit(const ConvProblem& p, int NB, int allow_split)
+{
+    ConvPlan pl;
+    if (!make_plan(p, NB, allow_split, 0, &pl)) return -1;
+    return pl.a.nsplit;
+}
+
+int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float* wpk, int w_rows, int w_cout,
+                     const float* bias, hipStream_t s, int* nsplit_out)
+{
+    ConvPlan pl;
+    if (io.nsplit < 1) return MCVC_ERR_INVALID;
+    if (io.nsplit > 1 && !io.accumulate && io.slabs == nullptr) return MCVC_ERR_WORKSPACE;
+    if (!make_plan(p, NB, 0, io.nsplit, &pl)) return MCVC_ERR_INVALID;
+    ConvArgs& a = pl.a;
+    if ((w_cout & 3) != 0) return MCVC_ERR_INVALID;
+    a.x = io.x; a.x_sb = io.x_sb; a.x_sc = io.x_sc; a.x_sh = io.x_sh;
+    a.y = io.y; a.y_sb = io.y_sb; a.y_sc = io.y_sc; a.y_sh = io.y_sh; a.y_sw = io.y_sw;
+    a.y_slabs = io.slabs; a.slab_stride = io.slab_stride;
+    a.w = wpk; a.w_rows = w_rows; a.w_cout = w_cout; a.bias = bias;
+    a.out_mode = io.accumulate ? CONV_OUT_ACCUM : CONV_OUT_SLAB;
+    a.shuffle = io.shuffle;
+    if (nsplit_out) *nsplit_out = a.nsplit;
+    hipError_t e;
+    switch (pl.cfg) {
+        case CFG_L: e = launch_cfg<2, 2, 2, 2>(pl, s); break;
+        case CFG_M: e = launch_cfg<2, 1, 2, 2>(pl, s); break;
+        case CFG_N: e = launch_cfg<1, 2, 2, 2>(pl, s); break;
+        case CFG_T: e = launch_cfg<2, 1, 4, 1>(pl, s); break;
+        default:    e = launch_cfg<1, 2, 1, 4>(pl, s); break;
+    }
+    return (int)e;
+}
+
+// =================================================================================================
+// weight-gradient kernel
+// =================================================================================================
+// Block = nwaves waves; wave t owns task (co group, kh, kw group) = MS x KWT accumulators of
+// 32(co) x 32(ci).  Per pixel chunk the block stages dYs[cot][pitch_a] and Xs[32][PH][PWp] (odd
+// pitches -> conflict-free lane strides) and every wave walks the chunk's pixel pairs.
+template <int MS, int KWT, int MAXT>
+__global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int tasks_per_group = a.KH * a.nkwg;
+    const int cgrp = wave / tasks_per_group;
+    const int trem = wave - cgrp * tasks_per_group;
+    const int kh = trem / a.nkwg;
+    const int kw0 = (trem - kh * a.nkwg) * KWT;
+    const int ms_base = cgrp * MS * 32;
+
+    const int ci0 = blockIdx.x * 32;
+    const int co0 = blockIdx.y * a.cot;
+
+    float* As = smem;                           // [cot][pitch_a]
+    float* Xs = smem + a.cot * a.pitch_a;       // [32][plane]
+
+    int lane_off, lane_ci, lane_kw;
+    bool lane_ok;
+    if (a.lane_mode == 0) {
+        lane_ci = ci0 + l31; lane_kw = 0; lane_ok = lane_ci < a.Cin;
+        lane_off = l31 * a.plane;
+    } else {
+        lane_ci = l31 / a.KW; lane_kw = l31 - lane_ci * a.KW; lane_ok = lane_ci < a.Cin;
+        lane_off = lane_ok ? (lane_ci * a.plane + lane_kw) : 0;
+    }
+    lane_off += half * a.stride;                // odd pixel of the pair
+
+    f32x16 acc[MS][KWT];
+#pragma unroll
+    for (int i = 0; i < MS; ++i)
+#pragma unroll
+        for (int t = 0; t < KWT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+
+    const int tiles = a.tiles_h * a.tiles_w;
+    const int items = a.NB * tiles;
+    const int nci = (a.lane_mode == 0) ? 32 : a.Cin;
+    const int tw2 = a.tow >> 1;
+
+    for (int item = blockIdx.z; item < items; item += a.ksplit) {
+        const int n = item / tiles;
+        const int t = item - n * tiles;
+        const int ty = t / a.tiles_w, tx = t - ty * a.tiles_w;
+        const int oh0 = ty * a.toh, ow0 = tx * a.tow;
+        const int ih0 = oh0 * a.stride - a.pad_h, iw0 = ow0 * a.stride - a.pad_w;
+        __syncthreads();
+        // stage dY chunk: As[co][r*tow + c]
+        {
+            const int per_co = a.toh * a.tow;
+            const int total = a.cot * per_co;
+            const float* dyn = a.dy + (long long)n * a.dy_sb;
+            for (int idx = tid; idx < total; idx += nthreads) {
+                const int co = idx / per_co;
+                const int rem = idx - co * per_co;
+                const int r = rem / a.tow, c = rem - r * a.tow;
+                const int oh = oh0 + r, ow = ow0 + c, cg = co0 + co;
+                float v = 0.f;
+                if (cg < a.Cout && oh < a.OH && ow < a.OW) v = dyn[(long long)cg * a.dy_sc + (long long)oh * a.dy_sh + ow];
+                As[co * a.pitch_a + rem] = v;
+            }
+        }
+        // stage X patch: Xs[ci][r][c]
+        {
+            const int per_ci = a.PH * a.PW;
+            const int total = nci * per_ci;
+            const float* xn = a.x + (long long)n * a.x_sb;
+            for (int idx = tid; idx < total; idx += nthreads) {
+                const int ci = idx / per_ci;
+                const int rem = idx - ci * per_ci;
+                const int r = rem / a.PW, c = rem - r * a.PW;
+                const int ih = ih0 + r, iw = iw0 + c;
+                const int cg = ((a.lane_mode == 0) ? ci0 : 0) + ci;
+                float v = 0.f;
+                if (cg < a.Cin && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = xn[(long long)cg * a.x_sc + (long long)ih * a.x_sh + iw];
+                Xs[ci * a.plane + r * a.PWp + c] = v;
+            }
+        }
+        __syncthreads();
+        const float* ap = As + (ms_base + l31) * a.pitch_a + half;
+        for (int r = 0; r < a.toh; ++r) {
+            const float* xr = Xs + lane_off + (r * a.stride + kh) * a.PWp + ((a.lane_mode == 0) ? kw0 : 0);
+            const float* ar = ap + r * a.tow;
+            for (int cp = 0; cp < tw2; ++cp) {
+                float av[MS], bv[KWT];
+#pragma unroll
+                for (int i = 0; i < MS; ++i) av[i] = ar[i * 32 * a.pitch_a + 2 * cp];
+#pragma unroll
+                for (int t2 = 0; t2 < KWT; ++t2) bv[t2] = xr[2 * cp * a.stride + t2];
+#pragma unroll
+                for (int i = 0; i < MS; ++i)
+#pragma unroll
+                    for (int t2 = 0; t2 < KWT; ++t2) acc[i][t2] = MFMA32(av[i], bv[t2], acc[i][t2]);
+            }
+        }
+    }
+
+    // write-out: dW[co][ci][kh][kw]
+#pragma unroll
+    for (int i = 0; i < MS; ++i) {
+#pragma unroll
+        for (int t2 = 0; t2 < KWT; ++t2) {
+            const int kw = (a.lane_mode == 0) ? (kw0 + t2) : lane_kw;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + ms_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (lane_ok && co < a.Cout && (ms_base + i * 32) < a.cot && kw < a.KW) {
+                    const long long idx = (((long long)co * a.Cin + lane_ci) * a.KH + kh) * a.KW + kw;
+                    const float v = acc[i][t2][r];
+                    if (a.atomic) atomicAdd(a.dw + idx, v);
+                    else a.dw[idx] += v;
+                }
+            }
+        }
+    }
+}
+
+namespace {
+template <int MS, int KWT, int MAXT>
+static hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, int nwaves, size_t lds, hipStream_t s)
+{
+    if (64 * nwaves > MAXT) return hipErrorInvalidValue;
+    auto kern = conv_wgrad_kernel<MS, KWT, MAXT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(64 * nwaves), lds, s, a);
+    return hipGetLastError();
+}
+}  // namespace
+
+int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, hipStream_t s)
+{
+    WgradArgs a{};
+    a.x = io.x; a.x_sb = io.x_sb; a.x_sc = io.x_sc; a.x_sh = io.x_sh;
+    a.dy = io.dy; a.dy_sb = io.dy_sb; a.dy_sc = io.dy_sc; a.dy_sh = io.dy_sh;
+    a.dw = dw;
+    a.NB = NB; a.Cin = p.Cin; a.H = p.H; a.W = p.W; a.Cout = p.Cout; a.OH = p.OH; a.OW = p.OW;
+    a.KH = p.KH; a.KW = p.KW; a.stride = p.stride; a.pad_h = p.pad_h; a.pad_w = p.pad_w;
+
+    // ---- choose the lane mapping and the per-wave task shape
+    int MS, KWT;
+    a.lane_mode = (p.Cin * p.KW <= 32 && p.Cin <= 4) ? 1 : 0;
+    if (a.lane_mode == 1) { MS = (p.Cout >= 128) ? 4 : 1; KWT = 1; a.nkwg = 1; }
+    else if (p.KW % 5 == 0) { KWT = 5; a.nkwg = p.KW / 5; MS = (p.Cout >= 64) ? 2 : 1; }
+    else if (p.KW == 3) { KWT = 3; a.nkwg = 1; MS = (p.Cout >= 64) ? 2 : 1; }
+    else if (p.KW == 1) { KWT = 1; a.nkwg = 1; MS = (p.Cout >= 128) ? 4 : 1; }
+    else return MCVC_ERR_INVALID;
+    const int tasks = p.KH * a.nkwg;
+    if (tasks > 16) return MCVC_ERR_INVALID;
+    // waves per block: co groups so that 4 <= nwaves <= 16 where possible
+    int groups = 1;
+    const int max_groups = cdiv_i(p.Cout, 32 * MS);
+    while (groups * 2 * tasks <= 8 && groups * 2 <= max_groups && groups * 2 * MS * 32 <= 512) groups *= 2;
+    const int nwaves = groups * tasks;
+    a.cot = groups * MS * 32;
+
+    // ---- pixel chunk geometry (LDS budget 60 KiB)
+    int tow = 32;
+    while (tow > 2 && tow / 2 >= p.OW) tow /= 2;      // smallest power of two >= OW, capped at 32
+    a.tow = tow;
+    const int nci = (a.lane_mode == 0) ? 32 : p.Cin;
+    int toh = 1;
+    for (int cand = 1; cand <= p.OH && cand <= 16; ++cand) {
+        const int PH = (cand - 1) * p.stride + p.KH, PW = (tow - 1) * p.stride + p.KW;
+        const int plane = (PH * PW) | 1;
+        const int pitch_a = (cand * tow) | 1;
+        if (a.cot * pitch_a + nci * plane + 64 <= kLdsBudgetFloats) toh = cand; else break;
+    }
+    a.toh = toh;
+    a.PH = (toh - 1) * p.stride + p.KH;
+    a.PW = (tow - 1) * p.stride + p.KW;
+    a.PWp = a.PW;
+    a.plane = (a.PH * a.PWp) | 1;
+    a.pitch_a = (toh * tow) | 1;
+    a.tiles_h = cdiv_i(p.OH, toh);
+    a.tiles_w = cdiv_i(p.OW, tow);
+    const size_t lds = (size_t)(a.cot * a.pitch_a + nci * a.plane + 64) * sizeof(float);
+    if (lds > 160 * 1024) return MCVC_ERR_INVALID;
+
+    const int ci_tiles = (a.lane_mode == 0) ? cdiv_i(p.Cin, 32) : 1;
+    const int co_tiles = cdiv_i(p.Cout, a.cot);
+    const int items = NB * a.tiles_h * a.tiles_w;
+    int ksplit = 1;
+    const int blocks = ci_tiles * co_tiles;
+    if (blocks < 256) ksplit = cdiv_i(512, blocks);
+    if (ksplit > items) ksplit = items;
+    a.ksplit = ksplit;
+    a.atomic = ksplit > 1;
+    dim3 grid((unsigned)ci_tiles, (unsigned)co_tiles, (unsigned)ksplit);
+    hipError_t e;
+    // MAXT bounds the register allocator: 512 threads -> up to 256 VGPRs (accumulator-heavy shapes)
+    if (MS == 2 && KWT == 5) e = launch_wgrad<2, 5, 512>(a, grid, nwaves, lds, s);
+    else if (MS == 1 && KWT == 5) e = launch_wgrad<1, 5, 1024>(a, grid, nwaves, lds, s);
+    else if (MS == 2 && KWT == 3) e = launch_wgrad<2, 3, 512>(a, grid, nwaves, lds, s);
+    else if (MS == 1 && KWT == 3) e = launch_wgrad<1, 3, 1024>(a, grid, nwaves, lds, s);
+    else if (MS == 4 && KWT == 1) e = launch_wgrad<4, 1, 512>(a, grid, nwaves, lds, s);
+    else e = launch_wgrad<1, 1, 1024>(a, grid, nwaves, lds, s);
+    return (int)e;
+}

@@ -1,0 +1,175 @@
+// Shared declarations for the MaskCycleGAN-VC gfx950 (MI355X / CDNA4) kernel library.
+// Everything here is internal; the exported C ABI is include/mcvc.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MCVC_OK 0
+#define MCVC_ERR_INVALID 1001
+#define MCVC_ERR_WORKSPACE 1002
+
+static inline int cdiv_i(int a, int b) { return (a + b - 1) / b; }
+static inline long long cdiv_ll(long long a, long long b) { return (a + b - 1) / b; }
+static inline int round_up_i(int a, int b) { return cdiv_i(a, b) * b; }
+
+// ------------------------------------------------------------------------------------------------
+// Direct convolution (forward and data-gradient share one kernel; the data-gradient is a
+// convolution of dY with re-packed weights).  Implicit GEMM on v_mfma_f32_32x32x2_f32:
+//   M = output channel (co), N = output pixel, K = (input channel, kh, kw).
+// The input patch of a pixel tile is staged ONCE in LDS per channel chunk and every tap reads a
+// shifted window of it -- no im2col buffer exists anywhere.
+// ------------------------------------------------------------------------------------------------
+enum ConvOutMode { CONV_OUT_SLAB = 0, CONV_OUT_ACCUM = 1 };
+
+struct ConvArgs {
+    const float* x;        // input, element (n, c, h, w) at x + n*x_sb + c*x_sc + h*x_sh + w
+    const float* w;        // packed weights [w_rows = Cin_pad*KH*KW][w_cout], row = (ci*KH+kh)*KW+kw
+    const float* bias;     // [Cout] or nullptr
+    float* y;              // split 0 destination
+    float* y_slabs;        // destination of split s>=1: y_slabs + (s-1)*slab_stride
+    long long x_sb;
+    long long x_sc;
+    long long y_sb;
+    long long y_sc;
+    long long slab_stride;
+    int x_sh;
+    int y_sh, y_sw;
+    int Cin, H, W;         // logical input dims
+    int Cout, OH, OW;      // logical output grid
+    int KH, KW, stride, pad_h, pad_w;
+    int w_rows, w_cout;
+    int cic;               // input channels per LDS chunk (even)
+    int nchunks, chunks_per_split, nsplit;
+    int tow_log2;          // pixel tile width = 1 << tow_log2 (8, 16 or 32)
+    int tiles_w;
+    int PH, PW, PWp, PWh, plane, xs_floats;   // LDS patch geometry
+    int out_mode;          // ConvOutMode
+    int shuffle;           // 1: PixelShuffle(2) store  y[c=co>>2][2oh+((co>>1)&1)][2ow+(co&1)]
+};
+
+struct ConvProblem {
+    int Cin, H, W;         // input
+    int Cout, OH, OW;      // output grid
+    int KH, KW, stride, pad_h, pad_w;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient:  dW[co][ci][kh][kw] += sum_{n,oh,ow} dY[n][co][oh][ow] * X[n][ci][oh*s+kh-p][ow*s+kw-p]
+//   M = co, N = ci (or (ci,kw) for tiny Cin), K = pixel; one accumulator per tap.
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* dw;
+    long long x_sb, x_sc;
+    long long dy_sb, dy_sc;
+    int x_sh, dy_sh;
+    int NB, Cin, H, W, Cout, OH, OW, KH, KW, stride, pad_h, pad_w;
+    int toh, tow, tiles_h, tiles_w;
+    int PH, PW, PWp, plane;
+    int pitch_a;
+    int ksplit;
+    int lane_mode;         // 0: N lane = ci ; 1: N lane = ci*KW + kw  (Cin*KW <= 32)
+    int nkwg;              // kw groups per kh (lane_mode 0)
+    int cot;               // output channels per block
+    int atomic;
+};
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm (+ activation) forward / backward
+// ------------------------------------------------------------------------------------------------
+enum ActKind { ACT_NONE = 0, ACT_GLU = 1, ACT_SILU = 2, ACT_SIGMOID = 3 };
+
+struct NormArgs {
+    // conv output (pre-norm), dense planes: plane (n,cx) at x + n*x_sn + cx*x_sc, P = H*W contiguous floats.
+    // For ACT_GLU the value plane is channel c and the gate plane channel C + c.
+    float* x;                 // slab 0 (also receives the slab-reduced sum)
+    const float* x_slabs;     // slabs 1..nslab-1 (same layout), slab_stride floats apart
+    long long x_sn, x_sc, slab_stride;
+    int nslab;
+    const float* gamma[2];    // [C] affine weight of the value / gate branch
+    const float* beta[2];
+    float* stats;             // [N][Cx][2] = mean, rstd  (Cx = C or 2C)
+    float* y;                 // output, plane (n,c) at y + n*y_sn + c*y_sc, element (h,w) at + h*y_sh + w
+    const float* res;         // optional residual, same addressing as y
+    long long y_sn, y_sc;
+    int y_sh;
+    int N, C, H, W;
+    int act;
+    float eps;
+};
+
+struct NormBwdArgs {
+    const float* x;           // reduced conv output (dense planes)
+    long long x_sn, x_sc;
+    const float* gamma[2];
+    const float* beta[2];
+    const float* stats;
+    float* dy;                // grad wrt y (slab 0; receives slab-reduced sum when nslab>1), addressed like y
+    const float* dy_slabs;
+    long long y_sn, y_sc, slab_stride;
+    int y_sh;
+    int nslab;
+    float* dx;                // grad wrt conv output: plane (n,cx) at dx + n*dx_sn + cx*dx_sc (dense) unless unshuffle
+    long long dx_sn, dx_sc;
+    int dx_sh;
+    int unshuffle;            // 1: plane (n,c) element (h,w) -> conv channel 4c+2(h&1)+(w&1), pixel (h>>1, w>>1), row pitch dx_sh
+    float* dgamma[2];         // accumulated (+=); may be null
+    float* dbeta[2];
+    int N, C, H, W;
+    int act;
+};
+
+// element-wise activation without a norm (conv1 GLU, D convLayer1 SiLU, D output sigmoid, plain slab reduce)
+struct ActArgs {
+    float* x;                 // [N][Cx][P] dense; slab 0, receives reduced sum
+    const float* x_slabs;
+    long long slab_stride;
+    int nslab;
+    float* y;                 // [N][C][P] dense
+    int N, C, P;
+    int act;
+};
+
+struct ActBwdArgs {
+    const float* x;           // reduced pre-activation [N][Cx][P]
+    float* dy;                // [N][C][P] slab 0
+    const float* dy_slabs;
+    long long slab_stride;
+    int nslab;
+    float* dx;                // [N][Cx][P]
+    int N, C, P;
+    int act;
+};
+
+// ------------------------------------------------------------------------------------------------
+// host-side launch helpers (defined in the .hip files)
+// ------------------------------------------------------------------------------------------------
+struct ConvIO {
+    const float* x; long long x_sb, x_sc; int x_sh;
+    float* y; long long y_sb, y_sc; int y_sh, y_sw;
+    float* slabs; long long slab_stride;                  // scratch for split-K partial slabs (s >= 1)
+    int nsplit;                                            // exact K-split count (>=1); planned by the caller
+    int accumulate;                                        // 1: y += conv (atomic when nsplit > 1)
+    int shuffle;
+};
+
+int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float* wpk, int w_rows, int w_cout,
+                     const float* bias, hipStream_t s, int* nsplit_out);
+// number of split-K slabs the planner would use (for workspace sizing)
+int mcvc_conv_plan_nsplit(const ConvProblem& p, int NB, int allow_split);
+
+struct WgradIO {
+    const float* x; long long x_sb, x_sc; int x_sh;
+    const float* dy; long long dy_sb, dy_sc; int dy_sh;
+};
+int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, hipStream_t s);
+
+int mcvc_norm_fwd_launch(const NormArgs& a, hipStream_t s);
+int mcvc_norm_bwd_launch(const NormBwdArgs& a, hipStream_t s);
+int mcvc_act_fwd_launch(const ActArgs& a, hipStream_t s);
+int mcvc_act_bwd_launch(const ActBwdArgs& a, hipStream_t s);

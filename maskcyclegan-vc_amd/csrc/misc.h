@@ -1,0 +1,14 @@
+#pragma once
+#include <hip/hip_runtime.h>
+
+int mcvc_prep_input_launch(const float* x, const float* mask, float* xin, int N, int P, hipStream_t s);
+int mcvc_mask_grad_launch(const float* dxin, const float* slabs, long long slab_stride, int nslab, const float* mask, float* dx,
+                          int N, int P, int C, int accumulate, hipStream_t s);
+int mcvc_bias_grad_launch(const float* dy, long long sn, long long sc, int N, int C, int P, float* db, hipStream_t s);
+int mcvc_l1_loss_launch(const float* a, const float* b, long long n, float weight, float* loss_slot, float* term_slot,
+                        float* grad_a, int accumulate, hipStream_t s);
+int mcvc_lsgan_loss_launch(const float* d, long long n, float target, float weight, float* loss_slot, float* term_slot,
+                           float* grad_logit, hipStream_t s);
+int mcvc_adam_launch(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                     int step, float grad_scale, hipStream_t s);
+int mcvc_axpy_launch(float* y, const float* x, float alpha, long long n, hipStream_t s);

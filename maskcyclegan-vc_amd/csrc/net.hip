@@ -1,0 +1,909 @@
+// Network-level schedule of the MaskCycleGAN-VC Generator / Discriminator on the gfx950 kernels and
+// the exported C ABI (include/mcvc.h).  The library owns the layer schedule so that one host call
+// launches a whole forward or backward pass back-to-back on the caller's HIP stream (graph-capturable:
+// no allocation, no synchronisation, no host-side state).
+//
+// Layer walk follows mask_cyclegan_vc/model.py:239-280 (Generator.forward) and :340-349
+// (Discriminator.forward); parameter indices follow named_parameters() order.
+//
+// Internal layouts (all fp32):
+//   2-D activations  NCHW  [B][C][H][W]
+//   1-D trunk        [C][B][T4]  -- channel-major with the batch inside, so every Conv1d is a
+//                    single-image KHx1 convolution over an image of B rows; the reference's
+//                    view(B, 5120, 1, -1) (model.py:249-251, channel = c*20 + h) and view(B,256,20,-1)
+//                    (:270-271) become pure stride changes folded into the producing kernels.
+//   value|gate pairs are one convolution with concatenated output channels [value C | gate C].
+#include "mcvc_common.h"
+#include "pack.h"
+#include "misc.h"
+#include "../../include/mcvc.h"
+#include <string.h>
+
+namespace {
+
+constexpr float kInEps = 1e-5f;
+
+struct View { float* p; long long sb, sc; int sh; };
+struct CView { const float* p; long long sb, sc; int sh; };
+static inline CView cv(const View& v) { return CView{v.p, v.sb, v.sc, v.sh}; }
+
+struct Exec {
+    hipStream_t s;
+    bool dry;
+    int err;
+    float* slabs;
+    long long slab_cap;
+    long long slab_need;
+    int max_split;                 // 0 = planner default (<= 64)
+    void fail(int e) { if (!err && e) err = e; }
+};
+
+// -------------------------------------------------------------------------------------------------
+struct ConvSpec {
+    int Cin, Cout, nbr, KH, KW, stride, ph, pw;
+    int wi[2], bi[2];
+    int has_bias_grad;
+    // derived
+    int cout_tot, cout_pk, cin_pad, w_rows, cin_pk, dg_rows_co;
+    long long off_fwd, off_bias, off_dgrad;
+    int ncls;
+    DgradClass cls[4];
+};
+
+static void spec_finalize(ConvSpec& c, long long& cur)
+{
+    c.cout_tot = c.Cout * c.nbr;
+    c.cout_pk = round_up_i(c.cout_tot, 32);
+    c.cin_pad = round_up_i(c.Cin, 2);
+    c.w_rows = c.cin_pad * c.KH * c.KW;
+    c.off_fwd = cur; cur += (long long)c.w_rows * c.cout_pk;
+    c.off_bias = cur; cur += c.cout_pk;
+    c.cin_pk = round_up_i(c.Cin, 32);
+    c.dg_rows_co = round_up_i(c.cout_tot, 2);
+    c.off_dgrad = cur;
+    c.ncls = 0;
+    const int st = c.stride;
+    for (int qh = 0; qh < st; ++qh) {
+        for (int qw = 0; qw < st; ++qw) {
+            DgradClass k{};
+            const int khmin = (qh + c.ph) % st, kwmin = (qw + c.pw) % st;
+            if (khmin > c.KH - 1 || kwmin > c.KW - 1) continue;
+            k.khmax = khmin + st * ((c.KH - 1 - khmin) / st);
+            k.kwmax = kwmin + st * ((c.KW - 1 - kwmin) / st);
+            k.nth = (k.khmax - khmin) / st + 1;
+            k.ntw = (k.kwmax - kwmin) / st + 1;
+            k.pad_h = (k.khmax - qh - c.ph) / st;
+            k.pad_w = (k.kwmax - qw - c.pw) / st;
+            k.qh = qh; k.qw = qw;
+            k.offset = cur - c.off_dgrad;
+            cur += (long long)c.dg_rows_co * k.nth * k.ntw * c.cin_pk;
+            c.cls[c.ncls++] = k;
+        }
+    }
+    cur = (cur + 3) & ~3LL;
+}
+
+static ConvSpec mk(int Cin, int Cout, int nbr, int KH, int KW, int stride, int ph, int pw, int w0, int b0, int w1, int b1, int bias_grad)
+{
+    ConvSpec c{};
+    c.Cin = Cin; c.Cout = Cout; c.nbr = nbr; c.KH = KH; c.KW = KW; c.stride = stride; c.ph = ph; c.pw = pw;
+    c.wi[0] = w0; c.bi[0] = b0; c.wi[1] = w1; c.bi[1] = b1; c.has_bias_grad = bias_grad;
+    return c;
+}
+
+static inline int conv_out(int H, int K, int s, int p) { return (H + 2 * p - K) / s + 1; }
+
+// ---- conv wrappers ---------------------------------------------------------------------------------
+static void run_conv(Exec& ex, const ConvProblem& p, int NB, ConvIO io, long long y_total, const float* w, int w_rows, int w_cout,
+                     const float* bias, int allow_split, int force_nsplit, int* nsplit_out)
+{
+    int ns = 1;
+    if (force_nsplit > 0) ns = force_nsplit;
+    else if (allow_split) ns = mcvc_conv_plan_nsplit(p, NB, 1);
+    if (ns < 1) { ex.fail(MCVC_ERR_INVALID); ns = 1; }
+    if (ex.max_split > 0 && ns > ex.max_split) ns = ex.max_split;
+    if (!io.accumulate) {
+        const long long need = (long long)(ns - 1) * y_total;
+        if (need > ex.slab_need) ex.slab_need = need;
+        if (!ex.dry && need > ex.slab_cap) { ex.fail(MCVC_ERR_WORKSPACE); return; }
+    }
+    if (nsplit_out) *nsplit_out = io.accumulate ? 1 : ns;
+    if (ex.dry) return;
+    io.slabs = ex.slabs; io.slab_stride = y_total; io.nsplit = ns;
+    ex.fail(mcvc_conv_launch(p, NB, io, w, w_rows, w_cout, bias, ex.s, nullptr));
+}
+
+static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, int H, int W, CView x, View y, long long y_total,
+                     int shuffle, int allow_split, int* nsplit)
+{
+    ConvProblem p{c.Cin, H, W, c.cout_tot, conv_out(H, c.KH, c.stride, c.ph), conv_out(W, c.KW, c.stride, c.pw),
+                  c.KH, c.KW, c.stride, c.ph, c.pw};
+    ConvIO io{};
+    io.x = x.p; io.x_sb = x.sb; io.x_sc = x.sc; io.x_sh = x.sh;
+    io.y = y.p; io.y_sb = y.sb; io.y_sc = y.sc; io.y_sh = y.sh; io.y_sw = 1;
+    io.shuffle = shuffle;
+    run_conv(ex, p, NB, io, y_total, packed + c.off_fwd, c.w_rows, c.cout_pk, packed + c.off_bias, allow_split, 0, nsplit);
+}
+
+// dX = conv-backward-data.  dy: conv-output layout (cout_tot channels, OHxOW); dx: input layout.
+static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB, int H, int W, CView dy, View dx, long long dx_total,
+                       int accumulate, int allow_split, int* nsplit)
+{
+    const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
+    const int st = c.stride;
+    ConvProblem ps[4];
+    int force = 0;
+    for (int k = 0; k < c.ncls; ++k) {
+        const DgradClass& d = c.cls[k];
+        ps[k] = ConvProblem{c.cout_tot, OH, OW, c.Cin, (H - d.qh + st - 1) / st, (W - d.qw + st - 1) / st,
+                            d.nth, d.ntw, 1, d.pad_h, d.pad_w};
+    }
+    if (c.ncls > 1 && allow_split) {          // all parity classes must agree on the slab count
+        force = 1 << 30;
+        for (int k = 0; k < c.ncls; ++k) { const int n = mcvc_conv_plan_nsplit(ps[k], NB, 1); if (n < force) force = n; }
+        if (force < 1) force = 1;
+        if (ex.max_split > 0 && force > ex.max_split) force = ex.max_split;
+    }
+    int ns_all = 1;
+    for (int k = 0; k < c.ncls; ++k) {
+        const DgradClass& d = c.cls[k];
+        if (ps[k].OH <= 0 || ps[k].OW <= 0) continue;
+        ConvIO io{};
+        io.x = dy.p; io.x_sb = dy.sb; io.x_sc = dy.sc; io.x_sh = dy.sh;
+        io.y = dx.p + (long long)d.qh * dx.sh + d.qw; io.y_sb = dx.sb; io.y_sc = dx.sc; io.y_sh = dx.sh * st; io.y_sw = st;
+        io.accumulate = accumulate;
+        int ns = 1;
+        // slabs of class k live at the same slab base + the class's element offset
+        Exec sub = ex;
+        if (!ex.dry) sub.slabs = ex.slabs + (long long)d.qh * dx.sh + d.qw;
+        run_conv(sub, ps[k], NB, io, dx_total, packed + c.off_dgrad + d.offset, c.dg_rows_co * d.nth * d.ntw, c.cin_pk, nullptr,
+                 allow_split, force, &ns);
+        ex.err = sub.err; ex.slab_need = sub.slab_need;
+        if (ns > ns_all) ns_all = ns;
+    }
+    if (nsplit) *nsplit = ns_all;
+}
+
+static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB, int H, int W, CView x, CView dy)
+{
+    if (ex.dry || !grads) return;
+    const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
+    ConvProblem p{c.Cin, H, W, c.Cout, OH, OW, c.KH, c.KW, c.stride, c.ph, c.pw};
+    for (int br = 0; br < c.nbr; ++br) {
+        float* dw = grads[c.wi[br]];
+        if (!dw) continue;
+        WgradIO io{x.p, x.sb, x.sc, x.sh, dy.p + (long long)br * c.Cout * dy.sc, dy.sb, dy.sc, dy.sh};
+        ex.fail(mcvc_wgrad_launch(p, NB, io, dw, ex.s));
+    }
+}
+
+static void conv_bias_grad(Exec& ex, const ConvSpec& c, float* const* grads, int NB, CView dy, int P)
+{
+    if (ex.dry || !grads || !c.has_bias_grad) return;
+    for (int br = 0; br < c.nbr; ++br) {
+        float* db = grads[c.bi[br]];
+        if (!db) continue;
+        ex.fail(mcvc_bias_grad_launch(dy.p + (long long)br * c.Cout * dy.sc, dy.sb, dy.sc, NB, c.Cout, P, db, ex.s));
+    }
+}
+
+static void pack_spec(Exec& ex, const ConvSpec& c, const float* const* params, float* packed)
+{
+    const int K = c.Cin * c.KH * c.KW;
+    for (int br = 0; br < c.nbr; ++br) {
+        const float* w = params[c.wi[br]];
+        ex.fail(mcvc_pack_fwd_launch(w, packed + c.off_fwd, c.Cout, K, c.cout_pk, br * c.Cout, ex.s));
+        ex.fail(mcvc_copy_launch(params[c.bi[br]], packed + c.off_bias + br * c.Cout, c.Cout, ex.s));
+        PackDgradArgs a{};
+        a.Cin = c.Cin; a.KH = c.KH; a.KW = c.KW; a.step = c.stride; a.ld = c.cin_pk; a.co_off = br * c.Cout; a.ncls = c.ncls;
+        for (int k = 0; k < c.ncls; ++k) a.cls[k] = c.cls[k];
+        ex.fail(mcvc_pack_dgrad_launch(w, packed + c.off_dgrad, a, c.Cout, ex.s));
+    }
+}
+
+// ---- norm wrappers -------------------------------------------------------------------------------------
+struct NormP { const float* g[2]; const float* b[2]; float* dg[2]; float* db[2]; };
+
+static NormP normp(const float* const* params, float* const* grads, int g0, int b0, int g1 = -1, int b1 = -1)
+{
+    NormP n{};
+    if (!params) return n;                       // dry (sizing) run
+    n.g[0] = params[g0]; n.b[0] = params[b0];
+    if (g1 >= 0) { n.g[1] = params[g1]; n.b[1] = params[b1]; }
+    if (grads) {
+        n.dg[0] = grads[g0]; n.db[0] = grads[b0];
+        if (g1 >= 0) { n.dg[1] = grads[g1]; n.db[1] = grads[b1]; }
+    }
+    return n;
+}
+
+static void norm_fwd(Exec& ex, float* x, long long x_sn, long long x_sc, long long x_total, int nslab, const NormP& np, float* stats,
+                     float* y, long long y_sn, long long y_sc, int y_sh, const float* res, int N, int C, int H, int W, int act)
+{
+    if (ex.dry) return;
+    NormArgs a{};
+    a.x = x; a.x_slabs = ex.slabs; a.x_sn = x_sn; a.x_sc = x_sc; a.slab_stride = x_total; a.nslab = nslab;
+    a.gamma[0] = np.g[0]; a.gamma[1] = np.g[1]; a.beta[0] = np.b[0]; a.beta[1] = np.b[1];
+    a.stats = stats; a.y = y; a.res = res; a.y_sn = y_sn; a.y_sc = y_sc; a.y_sh = y_sh;
+    a.N = N; a.C = C; a.H = H; a.W = W; a.act = act; a.eps = kInEps;
+    ex.fail(mcvc_norm_fwd_launch(a, ex.s));
+}
+
+static void norm_bwd(Exec& ex, const float* x, long long x_sn, long long x_sc, const NormP& np, const float* stats,
+                     float* dy, long long y_sn, long long y_sc, int y_sh, long long dy_total, int nslab,
+                     float* dx, long long dx_sn, long long dx_sc, int dx_sh, int unshuffle, int N, int C, int H, int W, int act)
+{
+    if (ex.dry) return;
+    NormBwdArgs a{};
+    a.x = x; a.x_sn = x_sn; a.x_sc = x_sc;
+    a.gamma[0] = np.g[0]; a.gamma[1] = np.g[1]; a.beta[0] = np.b[0]; a.beta[1] = np.b[1];
+    a.stats = stats; a.dy = dy; a.dy_slabs = ex.slabs; a.y_sn = y_sn; a.y_sc = y_sc; a.y_sh = y_sh; a.slab_stride = dy_total; a.nslab = nslab;
+    a.dx = dx; a.dx_sn = dx_sn; a.dx_sc = dx_sc; a.dx_sh = dx_sh; a.unshuffle = unshuffle;
+    a.dgamma[0] = np.dg[0]; a.dgamma[1] = np.dg[1]; a.dbeta[0] = np.db[0]; a.dbeta[1] = np.db[1];
+    a.N = N; a.C = C; a.H = H; a.W = W; a.act = act;
+    ex.fail(mcvc_norm_bwd_launch(a, ex.s));
+}
+
+static void act_fwd(Exec& ex, float* x, long long x_total, int nslab, float* y, int N, int C, int P, int act)
+{
+    if (ex.dry) return;
+    ActArgs a{}; a.x = x; a.x_slabs = ex.slabs; a.slab_stride = x_total; a.nslab = nslab; a.y = y; a.N = N; a.C = C; a.P = P; a.act = act;
+    ex.fail(mcvc_act_fwd_launch(a, ex.s));
+}
+
+static void act_bwd(Exec& ex, const float* x, float* dy, long long dy_total, int nslab, float* dx, int N, int C, int P, int act)
+{
+    if (ex.dry) return;
+    ActBwdArgs a{}; a.x = x; a.dy = dy; a.dy_slabs = ex.slabs; a.slab_stride = dy_total; a.nslab = nslab; a.dx = dx; a.N = N; a.C = C; a.P = P; a.act = act;
+    ex.fail(mcvc_act_bwd_launch(a, ex.s));
+}
+
+// =================================================================================================
+// Generator
+// =================================================================================================
+struct GenNet {
+    ConvSpec conv1, ds1, ds2, c2d1d, res_vg[6], res_out[6], c1d2d, up1, up2, last;
+    long long packed_floats;
+};
+
+static GenNet build_gen()
+{
+    GenNet g{};
+    long long cur = 0;
+    g.conv1 = mk(2, 128, 2, 5, 15, 1, 2, 7, 0, 1, 2, 3, 1);            // model.py:116-126 (no norm -> bias grads live)
+    g.ds1 = mk(128, 256, 2, 5, 5, 2, 2, 2, 4, 5, 8, 9, 0);              // :129-133
+    g.ds2 = mk(256, 256, 2, 5, 5, 2, 2, 2, 12, 13, 16, 17, 0);          // :135-139
+    g.c2d1d = mk(5120, 256, 1, 1, 1, 1, 0, 0, 20, 21, -1, -1, 0);       // :142-146
+    for (int i = 0; i < 6; ++i) {                                       // :151-180
+        const int b = 24 + 12 * i;
+        g.res_vg[i] = mk(256, 512, 2, 1, 3, 1, 0, 1, b + 0, b + 1, b + 4, b + 5, 0);
+        g.res_out[i] = mk(512, 256, 1, 1, 3, 1, 0, 1, b + 8, b + 9, -1, -1, 0);
+    }
+    g.c1d2d = mk(256, 5120, 1, 1, 1, 1, 0, 0, 96, 97, -1, -1, 0);       // :183-187
+    g.up1 = mk(256, 1024, 1, 5, 5, 1, 2, 2, 104, 105, -1, -1, 1);       // :192-196 (PixelShuffle before the norm -> bias grad live)
+    g.up2 = mk(256, 512, 1, 5, 5, 1, 2, 2, 100, 101, -1, -1, 1);        // :200-204 (named convLayer.* in named_parameters)
+    g.last = mk(128, 1, 1, 5, 15, 1, 2, 7, 108, 109, -1, -1, 1);        // :207-211
+    ConvSpec* all[] = {&g.conv1, &g.ds1, &g.ds2, &g.c2d1d, &g.c1d2d, &g.up1, &g.up2, &g.last};
+    for (ConvSpec* c : all) spec_finalize(*c, cur);
+    for (int i = 0; i < 6; ++i) { spec_finalize(g.res_vg[i], cur); spec_finalize(g.res_out[i], cur); }
+    g.packed_floats = cur;
+    return g;
+}
+static const GenNet& gen_net() { static const GenNet g = build_gen(); return g; }
+
+struct GenDims {
+    int B, T, W2, W4, Wu1, Wu2;
+    long long big;       // largest activation / conv-output tensor (floats)
+};
+static GenDims gen_dims(int B, int T)
+{
+    GenDims d{};
+    d.B = B; d.T = T;
+    d.W2 = conv_out(T, 5, 2, 2);
+    d.W4 = conv_out(d.W2, 5, 2, 2);
+    d.Wu1 = 2 * d.W4; d.Wu2 = 4 * d.W4;
+    const int wmax = d.T > d.Wu2 ? d.T : d.Wu2;
+    d.big = (long long)B * 256 * 80 * wmax;
+    return d;
+}
+
+struct GenStash {
+    long long xin, c1, y1, c2, s2, y2, c3, s3, y3, c4, s4, y4;
+    struct { long long ca, sa, ya, cb, sb, y; } r[6];
+    long long c6, s6, y6, c7, s7, y7, c8, s8, y8, total;
+};
+static GenStash gen_stash(const GenDims& d)
+{
+    GenStash s{};
+    long long cur = 0;
+    auto take = [&](long long n) { const long long o = cur; cur += (n + 3) & ~3LL; return o; };
+    const long long B = d.B;
+    s.xin = take(B * 2 * 80 * d.T);
+    s.c1 = take(B * 256 * 80 * d.T);   s.y1 = take(B * 128 * 80 * d.T);
+    s.c2 = take(B * 512 * 40 * d.W2);  s.s2 = take(B * 512 * 2);  s.y2 = take(B * 256 * 40 * d.W2);
+    s.c3 = take(B * 512 * 20 * d.W4);  s.s3 = take(B * 512 * 2);  s.y3 = take(B * 5120 * d.W4);
+    s.c4 = take(B * 256 * d.W4);       s.s4 = take(B * 256 * 2);  s.y4 = take(B * 256 * d.W4);
+    for (int i = 0; i < 6; ++i) {
+        s.r[i].ca = take(B * 1024 * d.W4); s.r[i].sa = take(B * 1024 * 2); s.r[i].ya = take(B * 512 * d.W4);
+        s.r[i].cb = take(B * 256 * d.W4);  s.r[i].sb = take(B * 256 * 2);  s.r[i].y = take(B * 256 * d.W4);
+    }
+    s.c6 = take(B * 5120 * d.W4);      s.s6 = take(B * 5120 * 2); s.y6 = take(B * 5120 * d.W4);
+    s.c7 = take(B * 256 * 40 * d.Wu1); s.s7 = take(B * 256 * 2);  s.y7 = take(B * 256 * 40 * d.Wu1);
+    s.c8 = take(B * 128 * 80 * d.Wu2); s.s8 = take(B * 128 * 2);  s.y8 = take(B * 128 * 80 * d.Wu2);
+    s.total = cur;
+    return s;
+}
+
+struct GenScratch { long long ga, gb, dh, dt1, dt2, dt3, slabs; };
+static GenScratch gen_scratch(const GenDims& d)
+{
+    GenScratch s{};
+    long long cur = 0;
+    auto take = [&](long long n) { const long long o = cur; cur += (n + 3) & ~3LL; return o; };
+    s.ga = take(d.big); s.gb = take(d.big);
+    s.dh = take((long long)256 * d.B * d.W4); s.dt1 = take((long long)1024 * d.B * d.W4);
+    s.dt2 = take((long long)512 * d.B * d.W4); s.dt3 = take((long long)256 * d.B * d.W4);
+    s.slabs = cur;
+    return s;
+}
+
+static void gen_forward_impl(Exec& ex, const float* const* P, const float* packed, const float* x, const float* mask, float* out,
+                             float* st, const GenDims& d)
+{
+    const GenNet& g = gen_net();
+    const GenStash o = gen_stash(d);
+    const int B = d.B, T = d.T, W2 = d.W2, W4 = d.W4, Wu1 = d.Wu1, Wu2 = d.Wu2;
+    const long long BT4 = (long long)B * W4;
+    int ns = 1;
+    // ---- model.py:241-242  stack(x*mask, mask) -> gated 5x15 conv (value|gate in one launch)
+    if (!ex.dry) ex.fail(mcvc_prep_input_launch(x, mask, st + o.xin, B, 80 * T, ex.s));
+    conv_fwd(ex, g.conv1, packed, B, 80, T, CView{st + o.xin, 2LL * 80 * T, 80LL * T, T}, View{st + o.c1, 256LL * 80 * T, 80LL * T, T},
+             (long long)B * 256 * 80 * T, 0, 1, &ns);
+    act_fwd(ex, st + o.c1, (long long)B * 256 * 80 * T, ns, st + o.y1, B, 128, 80 * T, ACT_GLU);
+    // ---- :245  downSample1 (5x5 s2, IN, GLU)
+    conv_fwd(ex, g.ds1, packed, B, 80, T, CView{st + o.y1, 128LL * 80 * T, 80LL * T, T}, View{st + o.c2, 512LL * 40 * W2, 40LL * W2, W2},
+             (long long)B * 512 * 40 * W2, 0, 1, &ns);
+    norm_fwd(ex, st + o.c2, 512LL * 40 * W2, 40LL * W2, (long long)B * 512 * 40 * W2, ns, normp(P, nullptr, 6, 7, 10, 11), st + o.s2,
+             st + o.y2, 256LL * 40 * W2, 40LL * W2, W2, nullptr, B, 256, 40, W2, ACT_GLU);
+    // ---- :246  downSample2; output written straight in trunk layout [c*20+h][b][w]  (:249-251)
+    conv_fwd(ex, g.ds2, packed, B, 40, W2, CView{st + o.y2, 256LL * 40 * W2, 40LL * W2, W2}, View{st + o.c3, 512LL * 20 * W4, 20LL * W4, W4},
+             (long long)B * 512 * 20 * W4, 0, 1, &ns);
+    norm_fwd(ex, st + o.c3, 512LL * 20 * W4, 20LL * W4, (long long)B * 512 * 20 * W4, ns, normp(P, nullptr, 14, 15, 18, 19), st + o.s3,
+             st + o.y3, W4, 20LL * BT4, (int)BT4, nullptr, B, 256, 20, W4, ACT_GLU);
+    // ---- :254-255  1x1 5120->256 + IN ; image = [5120][B rows][W4]
+    conv_fwd(ex, g.c2d1d, packed, 1, B, W4, CView{st + o.y3, 0, BT4, W4}, View{st + o.c4, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
+    norm_fwd(ex, st + o.c4, W4, BT4, 256 * BT4, ns, normp(P, nullptr, 22, 23), st + o.s4, st + o.y4, W4, BT4, W4, nullptr, B, 256, 1, W4, ACT_NONE);
+    // ---- :258-263  six residual GLU blocks
+    const float* h = st + o.y4;
+    for (int i = 0; i < 6; ++i) {
+        const int b = 24 + 12 * i;
+        conv_fwd(ex, g.res_vg[i], packed, 1, B, W4, CView{h, 0, BT4, W4}, View{st + o.r[i].ca, 0, BT4, W4}, 1024 * BT4, 0, 1, &ns);
+        norm_fwd(ex, st + o.r[i].ca, W4, BT4, 1024 * BT4, ns, normp(P, nullptr, b + 2, b + 3, b + 6, b + 7), st + o.r[i].sa,
+                 st + o.r[i].ya, W4, BT4, W4, nullptr, B, 512, 1, W4, ACT_GLU);
+        conv_fwd(ex, g.res_out[i], packed, 1, B, W4, CView{st + o.r[i].ya, 0, BT4, W4}, View{st + o.r[i].cb, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
+        norm_fwd(ex, st + o.r[i].cb, W4, BT4, 256 * BT4, ns, normp(P, nullptr, b + 10, b + 11), st + o.r[i].sb,
+                 st + o.r[i].y, W4, BT4, W4, h, B, 256, 1, W4, ACT_NONE);
+        h = st + o.r[i].y;
+    }
+    // ---- :266-271  1x1 256->5120 + IN, written as NCHW [B][256][20][W4] (5120 = c*20 + h)
+    conv_fwd(ex, g.c1d2d, packed, 1, B, W4, CView{h, 0, BT4, W4}, View{st + o.c6, 0, BT4, W4}, 5120 * BT4, 0, 1, &ns);
+    norm_fwd(ex, st + o.c6, W4, BT4, 5120 * BT4, ns, normp(P, nullptr, 98, 99), st + o.s6, st + o.y6, 5120LL * W4, W4, W4, nullptr,
+             B, 5120, 1, W4, ACT_NONE);
+    // ---- :274  upSample1: conv 5x5 -> PixelShuffle(2) (fused into the store) -> IN -> x*sigmoid(x)
+    conv_fwd(ex, g.up1, packed, B, 20, W4, CView{st + o.y6, 256LL * 20 * W4, 20LL * W4, W4}, View{st + o.c7, 256LL * 40 * Wu1, 40LL * Wu1, Wu1},
+             (long long)B * 256 * 40 * Wu1, 1, 1, &ns);
+    norm_fwd(ex, st + o.c7, 256LL * 40 * Wu1, 40LL * Wu1, (long long)B * 256 * 40 * Wu1, ns, normp(P, nullptr, 106, 107), st + o.s7,
+             st + o.y7, 256LL * 40 * Wu1, 40LL * Wu1, Wu1, nullptr, B, 256, 40, Wu1, ACT_SILU);
+    // ---- :275  upSample2
+    conv_fwd(ex, g.up2, packed, B, 40, Wu1, CView{st + o.y7, 256LL * 40 * Wu1, 40LL * Wu1, Wu1}, View{st + o.c8, 128LL * 80 * Wu2, 80LL * Wu2, Wu2},
+             (long long)B * 128 * 80 * Wu2, 1, 1, &ns);
+    norm_fwd(ex, st + o.c8, 128LL * 80 * Wu2, 80LL * Wu2, (long long)B * 128 * 80 * Wu2, ns, normp(P, nullptr, 102, 103), st + o.s8,
+             st + o.y8, 128LL * 80 * Wu2, 80LL * Wu2, Wu2, nullptr, B, 128, 80, Wu2, ACT_SILU);
+    // ---- :278-279  last 5x15 conv to one channel
+    conv_fwd(ex, g.last, packed, B, 80, Wu2, CView{st + o.y8, 128LL * 80 * Wu2, 80LL * Wu2, Wu2}, View{out, 80LL * Wu2, 80LL * Wu2, Wu2},
+             (long long)B * 80 * Wu2, 0, 1, &ns);
+    if (ns > 1) act_fwd(ex, out, (long long)B * 80 * Wu2, ns, nullptr, B, 1, 80 * Wu2, ACT_NONE);
+}
+
+static void gen_backward_impl(Exec& ex, const float* const* P, const float* packed, float* const* G, const float* mask, const float* dout,
+                              float* dx, int accumulate_dx, const float* stc, float* sc, const GenDims& d)
+{
+    const GenNet& g = gen_net();
+    const GenStash o = gen_stash(d);
+    const GenScratch q = gen_scratch(d);
+    float* st = const_cast<float*>(stc);     // stash is read-only here; kernels take non-const for slab-reduce paths that are not used on it
+    const int B = d.B, T = d.T, W2 = d.W2, W4 = d.W4, Wu1 = d.Wu1, Wu2 = d.Wu2;
+    const long long BT4 = (long long)B * W4;
+    float* GA = sc + q.ga; float* GB = sc + q.gb;
+    float* DH = sc + q.dh; float* DT1 = sc + q.dt1; float* DT2 = sc + q.dt2; float* DT3 = sc + q.dt3;
+    int ns = 1;
+    // ---- last conv (model.py:278)
+    {
+        CView dyv{dout, 80LL * Wu2, 80LL * Wu2, Wu2};
+        CView xv{st + o.y8, 128LL * 80 * Wu2, 80LL * Wu2, Wu2};
+        conv_wgrad(ex, g.last, G, B, 80, Wu2, xv, dyv);
+        conv_bias_grad(ex, g.last, G, B, dyv, 80 * Wu2);
+        conv_dgrad(ex, g.last, packed, B, 80, Wu2, dyv, View{GA, 128LL * 80 * Wu2, 80LL * Wu2, Wu2}, (long long)B * 128 * 80 * Wu2, 0, 1, &ns);
+    }
+    // ---- upSample2 (:275): IN+SiLU backward, un-shuffled into conv-output coordinates [B][512][40][Wu1]
+    norm_bwd(ex, st + o.c8, 128LL * 80 * Wu2, 80LL * Wu2, normp(P, G, 102, 103), st + o.s8, GA, 128LL * 80 * Wu2, 80LL * Wu2, Wu2,
+             (long long)B * 128 * 80 * Wu2, ns, GB, 512LL * 40 * Wu1, 40LL * Wu1, Wu1, 1, B, 128, 80, Wu2, ACT_SILU);
+    {
+        CView dyv{GB, 512LL * 40 * Wu1, 40LL * Wu1, Wu1};
+        CView xv{st + o.y7, 256LL * 40 * Wu1, 40LL * Wu1, Wu1};
+        conv_wgrad(ex, g.up2, G, B, 40, Wu1, xv, dyv);
+        conv_bias_grad(ex, g.up2, G, B, dyv, 40 * Wu1);
+        conv_dgrad(ex, g.up2, packed, B, 40, Wu1, dyv, View{GA, 256LL * 40 * Wu1, 40LL * Wu1, Wu1}, (long long)B * 256 * 40 * Wu1, 0, 1, &ns);
+    }
+    // ---- upSample1 (:274)
+    norm_bwd(ex, st + o.c7, 256LL * 40 * Wu1, 40LL * Wu1, normp(P, G, 106, 107), st + o.s7, GA, 256LL * 40 * Wu1, 40LL * Wu1, Wu1,
+             (long long)B * 256 * 40 * Wu1, ns, GB, 1024LL * 20 * W4, 20LL * W4, W4, 1, B, 256, 40, Wu1, ACT_SILU);
+    {
+        CView dyv{GB, 1024LL * 20 * W4, 20LL * W4, W4};
+        CView xv{st + o.y6, 256LL * 20 * W4, 20LL * W4, W4};
+        conv_wgrad(ex, g.up1, G, B, 20, W4, xv, dyv);
+        conv_bias_grad(ex, g.up1, G, B, dyv, 20 * W4);
+        conv_dgrad(ex, g.up1, packed, B, 20, W4, dyv, View{GA, 256LL * 20 * W4, 20LL * W4, W4}, (long long)B * 5120 * W4, 0, 1, &ns);
+    }
+    // ---- conv1dto2d + IN (:266-271): dy arrives NCHW, dx leaves in trunk layout
+    norm_bwd(ex, st + o.c6, W4, BT4, normp(P, G, 98, 99), st + o.s6, GA, 5120LL * W4, W4, W4, 5120 * BT4, ns,
+             GB, W4, BT4, W4, 0, B, 5120, 1, W4, ACT_NONE);
+    {
+        const float* hin = st + o.r[5].y;
+        CView dyv{GB, 0, BT4, W4};
+        conv_wgrad(ex, g.c1d2d, G, 1, B, W4, CView{hin, 0, BT4, W4}, dyv);
+        conv_dgrad(ex, g.c1d2d, packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
+    }
+    // ---- residual blocks (:258-263), last to first.  DH carries d(h) and is updated in place.
+    for (int i = 5; i >= 0; --i) {
+        const int b = 24 + 12 * i;
+        const float* hin = (i == 0) ? (st + o.y4) : (st + o.r[i - 1].y);
+        norm_bwd(ex, st + o.r[i].cb, W4, BT4, normp(P, G, b + 10, b + 11), st + o.r[i].sb, DH, W4, BT4, W4, 256 * BT4, ns,
+                 DT3, W4, BT4, W4, 0, B, 256, 1, W4, ACT_NONE);
+        int ns2 = 1;
+        {
+            CView dyv{DT3, 0, BT4, W4};
+            conv_wgrad(ex, g.res_out[i], G, 1, B, W4, CView{st + o.r[i].ya, 0, BT4, W4}, dyv);
+            conv_dgrad(ex, g.res_out[i], packed, 1, B, W4, dyv, View{DT2, 0, BT4, W4}, 512 * BT4, 0, 1, &ns2);
+        }
+        norm_bwd(ex, st + o.r[i].ca, W4, BT4, normp(P, G, b + 2, b + 3, b + 6, b + 7), st + o.r[i].sa, DT2, W4, BT4, W4, 512 * BT4, ns2,
+                 DT1, W4, BT4, W4, 0, B, 512, 1, W4, ACT_GLU);
+        {
+            CView dyv{DT1, 0, BT4, W4};
+            conv_wgrad(ex, g.res_vg[i], G, 1, B, W4, CView{hin, 0, BT4, W4}, dyv);
+            conv_dgrad(ex, g.res_vg[i], packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 1 /*accumulate: skip path*/, 1, nullptr);
+        }
+        ns = 1;
+    }
+    // ---- conv2dto1d + IN (:254-255)
+    norm_bwd(ex, st + o.c4, W4, BT4, normp(P, G, 22, 23), st + o.s4, DH, W4, BT4, W4, 256 * BT4, 1, DT3, W4, BT4, W4, 0, B, 256, 1, W4, ACT_NONE);
+    {
+        CView dyv{DT3, 0, BT4, W4};
+        conv_wgrad(ex, g.c2d1d, G, 1, B, W4, CView{st + o.y3, 0, BT4, W4}, dyv);
+        conv_dgrad(ex, g.c2d1d, packed, 1, B, W4, dyv, View{GA, 0, BT4, W4}, 5120 * BT4, 0, 1, &ns);
+    }
+    // ---- downSample2 (:246): dy is in trunk layout
+    norm_bwd(ex, st + o.c3, 512LL * 20 * W4, 20LL * W4, normp(P, G, 14, 15, 18, 19), st + o.s3, GA, W4, 20LL * BT4, (int)BT4, 5120 * BT4, ns,
+             GB, 512LL * 20 * W4, 20LL * W4, W4, 0, B, 256, 20, W4, ACT_GLU);
+    {
+        CView dyv{GB, 512LL * 20 * W4, 20LL * W4, W4};
+        conv_wgrad(ex, g.ds2, G, B, 40, W2, CView{st + o.y2, 256LL * 40 * W2, 40LL * W2, W2}, dyv);
+        conv_dgrad(ex, g.ds2, packed, B, 40, W2, dyv, View{GA, 256LL * 40 * W2, 40LL * W2, W2}, (long long)B * 256 * 40 * W2, 0, 1, &ns);
+    }
+    // ---- downSample1 (:245)
+    norm_bwd(ex, st + o.c2, 512LL * 40 * W2, 40LL * W2, normp(P, G, 6, 7, 10, 11), st + o.s2, GA, 256LL * 40 * W2, 40LL * W2, W2,
+             (long long)B * 256 * 40 * W2, ns, GB, 512LL * 40 * W2, 40LL * W2, W2, 0, B, 256, 40, W2, ACT_GLU);
+    {
+        CView dyv{GB, 512LL * 40 * W2, 40LL * W2, W2};
+        conv_wgrad(ex, g.ds1, G, B, 80, T, CView{st + o.y1, 128LL * 80 * T, 80LL * T, T}, dyv);
+        conv_dgrad(ex, g.ds1, packed, B, 80, T, dyv, View{GA, 128LL * 80 * T, 80LL * T, T}, (long long)B * 128 * 80 * T, 0, 1, &ns);
+    }
+    // ---- conv1 gated GLU (:242)
+    act_bwd(ex, st + o.c1, GA, (long long)B * 128 * 80 * T, ns, GB, B, 128, 80 * T, ACT_GLU);
+    {
+        CView dyv{GB, 256LL * 80 * T, 80LL * T, T};
+        conv_wgrad(ex, g.conv1, G, B, 80, T, CView{st + o.xin, 2LL * 80 * T, 80LL * T, T}, dyv);
+        conv_bias_grad(ex, g.conv1, G, B, dyv, 80 * T);
+        if (dx) {
+            conv_dgrad(ex, g.conv1, packed, B, 80, T, dyv, View{GA, 2LL * 80 * T, 80LL * T, T}, (long long)B * 2 * 80 * T, 0, 1, &ns);
+            if (!ex.dry) ex.fail(mcvc_mask_grad_launch(GA, ex.slabs, (long long)B * 2 * 80 * T, ns, mask, dx, B, 80 * T, 2, accumulate_dx, ex.s));
+        }
+    }
+}
+
+// =================================================================================================
+// Discriminator
+// =================================================================================================
+struct DiscNet { ConvSpec conv1, ds[3], outc; long long packed_floats; };
+static DiscNet build_disc()
+{
+    DiscNet n{};
+    long long cur = 0;
+    n.conv1 = mk(1, 128, 1, 3, 3, 1, 1, 1, 0, 1, -1, -1, 1);             // model.py:290-295
+    n.ds[0] = mk(128, 256, 1, 3, 3, 2, 1, 1, 2, 3, -1, -1, 0);           // :298-302
+    n.ds[1] = mk(256, 512, 1, 3, 3, 2, 1, 1, 6, 7, -1, -1, 0);           // :304-308
+    n.ds[2] = mk(512, 1024, 1, 3, 3, 2, 1, 1, 10, 11, -1, -1, 0);        // :310-314
+    n.outc = mk(1024, 1, 1, 1, 3, 1, 0, 1, 18, 19, -1, -1, 1);           // :323-327   (downSample4, params 14-17, is dead: :316-320 never called)
+    spec_finalize(n.conv1, cur);
+    for (int i = 0; i < 3; ++i) spec_finalize(n.ds[i], cur);
+    spec_finalize(n.outc, cur);
+    n.packed_floats = cur;
+    return n;
+}
+static const DiscNet& disc_net() { static const DiscNet n = build_disc(); return n; }
+
+struct DiscDims { int B, T, H[4], W[4]; long long big; };
+static DiscDims disc_dims(int B, int T)
+{
+    DiscDims d{};
+    d.B = B; d.T = T; d.H[0] = 80; d.W[0] = T;
+    for (int i = 1; i < 4; ++i) { d.H[i] = conv_out(d.H[i - 1], 3, 2, 1); d.W[i] = conv_out(d.W[i - 1], 3, 2, 1); }
+    d.big = (long long)B * 128 * 80 * T;
+    return d;
+}
+static const int kDC[4] = {128, 256, 512, 1024};
+
+struct DiscStash { long long c0, y0, c[3], s[3], y[3], logit, total; };
+static DiscStash disc_stash(const DiscDims& d)
+{
+    DiscStash s{};
+    long long cur = 0;
+    auto take = [&](long long n) { const long long o = cur; cur += (n + 3) & ~3LL; return o; };
+    const long long B = d.B;
+    s.c0 = take(B * 128 * 80 * d.T); s.y0 = take(B * 128 * 80 * d.T);
+    for (int i = 0; i < 3; ++i) {
+        const long long n = B * kDC[i + 1] * d.H[i + 1] * d.W[i + 1];
+        s.c[i] = take(n); s.s[i] = take(B * kDC[i + 1] * 2); s.y[i] = take(n);
+    }
+    s.logit = take(B * d.H[3] * d.W[3]);
+    s.total = cur;
+    return s;
+}
+struct DiscScratch { long long ga, gb, slabs; };
+static DiscScratch disc_scratch(const DiscDims& d)
+{
+    DiscScratch s{};
+    s.ga = 0; s.gb = (d.big + 3) & ~3LL; s.slabs = 2 * s.gb;
+    return s;
+}
+
+static void disc_forward_impl(Exec& ex, const float* const* P, const float* packed, const float* x, float* out, float* st, const DiscDims& d)
+{
+    const DiscNet& n = disc_net();
+    const DiscStash o = disc_stash(d);
+    const int B = d.B, T = d.T;
+    int ns = 1;
+    // model.py:343-344  unsqueeze(1) -> conv 3x3 -> x*sigmoid(x)
+    conv_fwd(ex, n.conv1, packed, B, 80, T, CView{x, 80LL * T, 80LL * T, T}, View{st + o.c0, 128LL * 80 * T, 80LL * T, T},
+             (long long)B * 128 * 80 * T, 0, 1, &ns);
+    act_fwd(ex, st + o.c0, (long long)B * 128 * 80 * T, ns, st + o.y0, B, 128, 80 * T, ACT_SILU);
+    const float* h = st + o.y0;
+    for (int i = 0; i < 3; ++i) {                       // :345-347
+        const int Ci = kDC[i], Co = kDC[i + 1], Hi = d.H[i], Wi = d.W[i], Ho = d.H[i + 1], Wo = d.W[i + 1];
+        conv_fwd(ex, n.ds[i], packed, B, Hi, Wi, CView{h, (long long)Ci * Hi * Wi, (long long)Hi * Wi, Wi},
+                 View{st + o.c[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo}, (long long)B * Co * Ho * Wo, 0, 1, &ns);
+        norm_fwd(ex, st + o.c[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, (long long)B * Co * Ho * Wo, ns, normp(P, nullptr, 4 + 4 * i, 5 + 4 * i),
+                 st + o.s[i], st + o.y[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo, nullptr, B, Co, Ho, Wo, ACT_SILU);
+        h = st + o.y[i];
+    }
+    // :348  1x3 conv to one channel + sigmoid
+    const int H3 = d.H[3], W3 = d.W[3];
+    conv_fwd(ex, n.outc, packed, B, H3, W3, CView{h, 1024LL * H3 * W3, (long long)H3 * W3, W3}, View{st + o.logit, (long long)H3 * W3, (long long)H3 * W3, W3},
+             (long long)B * H3 * W3, 0, 1, &ns);
+    act_fwd(ex, st + o.logit, (long long)B * H3 * W3, ns, out, B, 1, H3 * W3, ACT_SIGMOID);
+}
+
+static void disc_backward_impl(Exec& ex, const float* const* P, const float* packed, float* const* G, const float* dout, int is_logit_grad,
+                               float* dx, int accumulate_dx, const float* stc, float* sc, const DiscDims& d)
+{
+    const DiscNet& n = disc_net();
+    const DiscStash o = disc_stash(d);
+    const DiscScratch q = disc_scratch(d);
+    float* st = const_cast<float*>(stc);
+    const int B = d.B, T = d.T;
+    float* GA = sc + q.ga; float* GB = sc + q.gb;
+    const int H3 = d.H[3], W3 = d.W[3];
+    int ns = 1;
+    const float* dlogit = dout;
+    if (!is_logit_grad) {                         // sigmoid backward (model.py:348)
+        if (!ex.dry) {
+            ex.fail(mcvc_copy_launch(dout, GA, B * H3 * W3, ex.s));
+        }
+        act_bwd(ex, st + o.logit, GA, 0, 1, GB, B, 1, H3 * W3, ACT_SIGMOID);
+        dlogit = GB;
+    }
+    {
+        CView dyv{dlogit, (long long)H3 * W3, (long long)H3 * W3, W3};
+        CView xv{st + o.y[2], 1024LL * H3 * W3, (long long)H3 * W3, W3};
+        conv_wgrad(ex, n.outc, G, B, H3, W3, xv, dyv);
+        conv_bias_grad(ex, n.outc, G, B, dyv, H3 * W3);
+        conv_dgrad(ex, n.outc, packed, B, H3, W3, dyv, View{GA, 1024LL * H3 * W3, (long long)H3 * W3, W3}, (long long)B * 1024 * H3 * W3, 0, 1, &ns);
+    }
+    for (int i = 2; i >= 0; --i) {
+        const int Ci = kDC[i], Co = kDC[i + 1], Hi = d.H[i], Wi = d.W[i], Ho = d.H[i + 1], Wo = d.W[i + 1];
+        norm_bwd(ex, st + o.c[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, normp(P, G, 4 + 4 * i, 5 + 4 * i), st + o.s[i],
+                 GA, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo, (long long)B * Co * Ho * Wo, ns,
+                 GB, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo, 0, B, Co, Ho, Wo, ACT_SILU);
+        const float* hin = (i == 0) ? (st + o.y0) : (st + o.y[i - 1]);
+        CView dyv{GB, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo};
+        conv_wgrad(ex, n.ds[i], G, B, Hi, Wi, CView{hin, (long long)Ci * Hi * Wi, (long long)Hi * Wi, Wi}, dyv);
+        conv_dgrad(ex, n.ds[i], packed, B, Hi, Wi, dyv, View{GA, (long long)Ci * Hi * Wi, (long long)Hi * Wi, Wi}, (long long)B * Ci * Hi * Wi, 0, 1, &ns);
+    }
+    act_bwd(ex, st + o.c0, GA, (long long)B * 128 * 80 * T, ns, GB, B, 128, 80 * T, ACT_SILU);
+    {
+        CView dyv{GB, 128LL * 80 * T, 80LL * T, T};
+        // the forward input x is not in the stash; its weight gradient needs it -> caller passes it via stash? no: keep a copy
+        conv_wgrad(ex, n.conv1, G, B, 80, T, CView{st + o.total, 80LL * T, 80LL * T, T}, dyv);
+        conv_bias_grad(ex, n.conv1, G, B, dyv, 80 * T);
+        if (dx) {
+            conv_dgrad(ex, n.conv1, packed, B, 80, T, dyv, View{GA, 80LL * T, 80LL * T, T}, (long long)B * 80 * T, 0, 1, &ns);
+            if (!ex.dry) ex.fail(mcvc_mask_grad_launch(GA, ex.slabs, (long long)B * 80 * T, ns, nullptr, dx, B, 80 * T, 1, accumulate_dx, ex.s));
+        }
+    }
+}
+
+static Exec make_exec(void* stream, float* scratch, long long scratch_floats, long long slab_off)
+{
+    Exec ex{};
+    ex.s = (hipStream_t)stream; ex.dry = false; ex.err = 0;
+    ex.slabs = scratch ? scratch + slab_off : nullptr;
+    ex.slab_cap = scratch_floats - slab_off;
+    return ex;
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int mcvc_version(void) { return MCVC_ABI_VERSION; }
+
+long long mcvc_gen_packed_floats(void) { return gen_net().packed_floats; }
+long long mcvc_disc_packed_floats(void) { return disc_net().packed_floats; }
+int mcvc_gen_out_frames(int T) { return gen_dims(1, T).Wu2; }
+int mcvc_disc_out_frames(int T) { return disc_dims(1, T).W[3]; }
+
+long long mcvc_gen_stash_floats(int B, int T) { return gen_stash(gen_dims(B, T)).total; }
+
+long long mcvc_gen_scratch_floats(int B, int T)
+{
+    const GenDims d = gen_dims(B, T);
+    Exec ex{}; ex.dry = true;
+    gen_forward_impl(ex, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d);
+    float dummy = 0.f;
+    gen_backward_impl(ex, nullptr, nullptr, nullptr, nullptr, nullptr, &dummy, 0, nullptr, nullptr, d);
+    return gen_scratch(d).slabs + ex.slab_need + 64;
+}
+
+long long mcvc_disc_stash_floats(int B, int T)
+{
+    const DiscDims d = disc_dims(B, T);
+    return disc_stash(d).total + (((long long)B * 80 * T + 3) & ~3LL);   // + a copy of the input for the first layer's weight gradient
+}
+
+long long mcvc_disc_scratch_floats(int B, int T)
+{
+    const DiscDims d = disc_dims(B, T);
+    Exec ex{}; ex.dry = true;
+    disc_forward_impl(ex, nullptr, nullptr, nullptr, nullptr, nullptr, d);
+    float dummy = 0.f;
+    disc_backward_impl(ex, nullptr, nullptr, nullptr, nullptr, 1, &dummy, 0, nullptr, nullptr, d);
+    return disc_scratch(d).slabs + ex.slab_need + 64;
+}
+
+int mcvc_gen_pack(const float* const* params, float* packed, void* stream)
+{
+    const GenNet& g = gen_net();
+    Exec ex{}; ex.s = (hipStream_t)stream;
+    const ConvSpec* all[] = {&g.conv1, &g.ds1, &g.ds2, &g.c2d1d, &g.c1d2d, &g.up1, &g.up2, &g.last};
+    for (const ConvSpec* c : all) pack_spec(ex, *c, params, packed);
+    for (int i = 0; i < 6; ++i) { pack_spec(ex, g.res_vg[i], params, packed); pack_spec(ex, g.res_out[i], params, packed); }
+    return ex.err;
+}
+
+int mcvc_disc_pack(const float* const* params, float* packed, void* stream)
+{
+    const DiscNet& n = disc_net();
+    Exec ex{}; ex.s = (hipStream_t)stream;
+    pack_spec(ex, n.conv1, params, packed);
+    for (int i = 0; i < 3; ++i) pack_spec(ex, n.ds[i], params, packed);
+    pack_spec(ex, n.outc, params, packed);
+    return ex.err;
+}
+
+int mcvc_gen_forward(const float* const* params, const float* packed, const float* x, const float* mask, float* out, float* stash,
+                     float* scratch, long long scratch_floats, int B, int T, void* stream)
+{
+    if (B < 1 || T < 1 || !params || !packed || !x || !out || !stash || !scratch) return MCVC_ERR_INVALID;
+    const GenDims d = gen_dims(B, T);
+    Exec ex = make_exec(stream, scratch, scratch_floats, gen_scratch(d).slabs);
+    if (ex.slab_cap < 0) return MCVC_ERR_WORKSPACE;
+    gen_forward_impl(ex, params, packed, x, mask, out, stash, d);
+    return ex.err;
+}
+
+int mcvc_gen_backward(const float* const* params, const float* packed, float* const* grads, const float* mask, const float* dout,
+                      float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T, void* stream)
+{
+    if (B < 1 || T < 1 || !params || !packed || !dout || !stash || !scratch) return MCVC_ERR_INVALID;
+    const GenDims d = gen_dims(B, T);
+    Exec ex = make_exec(stream, scratch, scratch_floats, gen_scratch(d).slabs);
+    if (ex.slab_cap < 0) return MCVC_ERR_WORKSPACE;
+    gen_backward_impl(ex, params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, d);
+    return ex.err;
+}
+
+int mcvc_disc_forward(const float* const* params, const float* packed, const float* x, float* out, float* stash, float* scratch,
+                      long long scratch_floats, int B, int T, void* stream)
+{
+    if (B < 1 || T < 1 || !params || !packed || !x || !out || !stash || !scratch) return MCVC_ERR_INVALID;
+    const DiscDims d = disc_dims(B, T);
+    Exec ex = make_exec(stream, scratch, scratch_floats, disc_scratch(d).slabs);
+    if (ex.slab_cap < 0) return MCVC_ERR_WORKSPACE;
+    // keep the input for the first layer's weight gradient
+    ex.fail(mcvc_copy_launch(x, stash + disc_stash(d).total, B * 80 * T, ex.s));
+    disc_forward_impl(ex, params, packed, x, out, stash, d);
+    return ex.err;
+}
+
+int mcvc_disc_backward(const float* const* params, const float* packed, float* const* grads, const float* dout, int dout_is_logit_grad,
+                       float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T, void* stream)
+{
+    if (B < 1 || T < 1 || !params || !packed || !dout || !stash || !scratch) return MCVC_ERR_INVALID;
+    const DiscDims d = disc_dims(B, T);
+    Exec ex = make_exec(stream, scratch, scratch_floats, disc_scratch(d).slabs);
+    if (ex.slab_cap < 0) return MCVC_ERR_WORKSPACE;
+    disc_backward_impl(ex, params, packed, grads, dout, dout_is_logit_grad, dx, accumulate_dx, stash, scratch, d);
+    return ex.err;
+}
+
+int mcvc_l1_loss(const float* a, const float* b, long long n, float weight, float* loss_slot, float* term_slot, float* grad_a,
+                 int accumulate_grad, void* stream)
+{
+    return mcvc_l1_loss_launch(a, b, n, weight, loss_slot, term_slot, grad_a, accumulate_grad, (hipStream_t)stream);
+}
+
+int mcvc_lsgan_loss(const float* d, long long n, float target, float weight, float* loss_slot, float* term_slot, float* grad_logit, void* stream)
+{
+    return mcvc_lsgan_loss_launch(d, n, target, weight, loss_slot, term_slot, grad_logit, (hipStream_t)stream);
+}
+
+int mcvc_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
+                   float eps, int step, float grad_scale, void* stream)
+{
+    return mcvc_adam_launch(p, g, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream);
+}
+
+int mcvc_axpy(float* y, const float* x, float alpha, long long n, void* stream)
+{
+    return mcvc_axpy_launch(y, x, alpha, n, (hipStream_t)stream);
+}
+
+// ---- single-op entry points ----------------------------------------------------------------------------
+static ConvSpec single_spec(int Cout, int Cin, int KH, int KW, int stride, int ph, int pw)
+{
+    ConvSpec c = mk(Cin, Cout, 1, KH, KW, stride, ph, pw, 0, 1, -1, -1, 1);
+    long long cur = 0;
+    spec_finalize(c, cur);
+    return c;
+}
+
+long long mcvc_conv2d_pack_floats(int Cout, int Cin, int KH, int KW)
+{
+    // stride-2 classes partition the taps, so the stride-1 layout is the upper bound
+    ConvSpec c = mk(Cin, Cout, 1, KH, KW, 1, 0, 0, 0, 1, -1, -1, 1);
+    long long cur = 0;
+    spec_finalize(c, cur);
+    return cur + 64;
+}
+
+int mcvc_conv2d_forward(const float* x, const float* w, const float* bias, float* y, float* wpack, float* slabs, int max_slabs,
+                        int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_h, int pad_w, int pixel_shuffle, void* stream)
+{
+    if (stride != 1 && stride != 2) return MCVC_ERR_INVALID;
+    const ConvSpec c = single_spec(Cout, Cin, KH, KW, stride, pad_h, pad_w);
+    Exec ex{}; ex.s = (hipStream_t)stream;
+    ex.fail(mcvc_pack_fwd_launch(w, wpack + c.off_fwd, Cout, Cin * KH * KW, c.cout_pk, 0, ex.s));
+    if (bias) ex.fail(mcvc_copy_launch(bias, wpack + c.off_bias, Cout, ex.s));
+    const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
+    const long long y_total = (long long)N * Cout * OH * OW;
+    ex.slabs = slabs; ex.slab_cap = slabs ? (long long)(max_slabs - 1) * y_total : 0; ex.max_split = max_slabs > 0 ? max_slabs : 1;
+    int ns = 1;
+    View yv = pixel_shuffle ? View{y, (long long)Cout * OH * OW, 4LL * OH * OW, 2 * OW} : View{y, (long long)Cout * OH * OW, (long long)OH * OW, OW};
+    ConvProblem p{Cin, H, W, Cout, OH, OW, KH, KW, stride, pad_h, pad_w};
+    ConvIO io{};
+    io.x = x; io.x_sb = (long long)Cin * H * W; io.x_sc = (long long)H * W; io.x_sh = W;
+    io.y = yv.p; io.y_sb = yv.sb; io.y_sc = yv.sc; io.y_sh = yv.sh; io.y_sw = 1; io.shuffle = pixel_shuffle;
+    int want = (slabs && max_slabs > 1) ? mcvc_conv_plan_nsplit(p, N, 1) : 1;
+    if (want > max_slabs) want = max_slabs;
+    run_conv(ex, p, N, io, y_total, wpack + c.off_fwd, c.w_rows, c.cout_pk, bias ? wpack + c.off_bias : nullptr, 0, want, &ns);
+    if (ns > 1) act_fwd(ex, y, y_total, ns, nullptr, 1, 1, (int)y_total, ACT_NONE);
+    return ex.err;
+}
+
+int mcvc_conv2d_dgrad(const float* dy, const float* w, float* dx, float* wpack, float* slabs, int max_slabs, int N, int Cin, int H, int W,
+                      int Cout, int KH, int KW, int stride, int pad_h, int pad_w, void* stream)
+{
+    if (stride != 1 && stride != 2) return MCVC_ERR_INVALID;
+    const ConvSpec c = single_spec(Cout, Cin, KH, KW, stride, pad_h, pad_w);
+    Exec ex{}; ex.s = (hipStream_t)stream;
+    PackDgradArgs a{};
+    a.Cin = Cin; a.KH = KH; a.KW = KW; a.step = stride; a.ld = c.cin_pk; a.co_off = 0; a.ncls = c.ncls;
+    for (int k = 0; k < c.ncls; ++k) a.cls[k] = c.cls[k];
+    ex.fail(mcvc_pack_dgrad_launch(w, wpack + c.off_dgrad, a, Cout, ex.s));
+    const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
+    const long long dx_total = (long long)N * Cin * H * W;
+    ex.slabs = slabs; ex.slab_cap = slabs ? (long long)(max_slabs - 1) * dx_total : 0; ex.max_split = max_slabs > 0 ? max_slabs : 1;
+    int ns = 1;
+    // positions of dx never written by any parity class do not exist: classes tile the whole input grid
+    conv_dgrad(ex, c, wpack, N, H, W, CView{dy, (long long)Cout * OH * OW, (long long)OH * OW, OW},
+               View{dx, (long long)Cin * H * W, (long long)H * W, W}, dx_total, 0, (slabs && max_slabs > 1) ? 1 : 0, &ns);
+    if (ns > max_slabs && !ex.err) return MCVC_ERR_WORKSPACE;
+    if (ns > 1) act_fwd(ex, dx, dx_total, ns, nullptr, 1, 1, (int)dx_total, ACT_NONE);
+    return ex.err;
+}
+
+int mcvc_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride,
+                      int pad_h, int pad_w, void* stream)
+{
+    const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
+    ConvProblem p{Cin, H, W, Cout, OH, OW, KH, KW, stride, pad_h, pad_w};
+    WgradIO io{x, (long long)Cin * H * W, (long long)H * W, W, dy, (long long)Cout * OH * OW, (long long)OH * OW, OW};
+    return mcvc_wgrad_launch(p, N, io, dw, (hipStream_t)stream);
+}
+
+int mcvc_instnorm_act_forward(float* x, const float* gamma, const float* beta, const float* gamma_gate, const float* beta_gate,
+                              const float* residual, float* y, float* stats, int N, int C, int H, int W, int act, void* stream)
+{
+    Exec ex{}; ex.s = (hipStream_t)stream;
+    NormP np{}; np.g[0] = gamma; np.b[0] = beta; np.g[1] = gamma_gate; np.b[1] = beta_gate;
+    const int Cx = (act == ACT_GLU) ? 2 * C : C;
+    norm_fwd(ex, x, (long long)Cx * H * W, (long long)H * W, 0, 1, np, stats, y, (long long)C * H * W, (long long)H * W, W, residual, N, C, H, W, act);
+    return ex.err;
+}
+
+int mcvc_instnorm_act_backward(const float* x, const float* gamma, const float* beta, const float* gamma_gate, const float* beta_gate,
+                               const float* stats, float* dy, float* dx, float* dgamma, float* dbeta, float* dgamma_gate, float* dbeta_gate,
+                               int N, int C, int H, int W, int act, void* stream)
+{
+    Exec ex{}; ex.s = (hipStream_t)stream;
+    NormP np{}; np.g[0] = gamma; np.b[0] = beta; np.g[1] = gamma_gate; np.b[1] = beta_gate;
+    np.dg[0] = dgamma; np.db[0] = dbeta; np.dg[1] = dgamma_gate; np.db[1] = dbeta_gate;
+    const int Cx = (act == ACT_GLU) ? 2 * C : C;
+    norm_bwd(ex, x, (long long)Cx * H * W, (long long)H * W, np, stats, dy, (long long)C * H * W, (long long)H * W, W, 0, 1,
+             dx, (long long)Cx * H * W, (long long)H * W, W, 0, N, C, H, W, act);
+    return ex.err;
+}
+
+int mcvc_bias_grad(const float* dy, float* db, int N, int C, int P, void* stream)
+{
+    return mcvc_bias_grad_launch(dy, (long long)C * P, (long long)P, N, C, P, db, (hipStream_t)stream);
+}
+
+int mcvc_act_forward(float* x, float* y, int N, int C, int P, int act, void* stream)
+{
+    Exec ex{}; ex.s = (hipStream_t)stream;
+    act_fwd(ex, x, 0, 1, y, N, C, P, act);
+    return ex.err;
+}
+
+int mcvc_act_backward(const float* x, float* dy, float* dx, int N, int C, int P, int act, void* stream)
+{
+    Exec ex{}; ex.s = (hipStream_t)stream;
+    act_bwd(ex, x, dy, 0, 1, dx, N, C, P, act);
+    return ex.err;
+}
+
+int mcvc_fif_input(const float* x, const float* mask, float* xin, int N, int P, void* stream)
+{
+    return mcvc_prep_input_launch(x, mask, xin, N, P, (hipStream_t)stream);
+}
+
+int mcvc_fif_input_grad(const float* dxin, const float* mask, float* dx, int N, int P, int accumulate, void* stream)
+{
+    return mcvc_mask_grad_launch(dxin, nullptr, 0, 1, mask, dx, N, P, 2, accumulate, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,305 @@
+// InstanceNorm(affine, eps=1e-5, biased variance) fused with the activation that follows it in the
+// reference, forward and backward, plus the norm-less activations.
+//
+// Reference call sites (mask_cyclegan_vc/model.py): nn.InstanceNorm{1,2}d + gated GLU
+// `a * sigmoid(g)` (:71-76, :101-103), + `x*sigmoid(x)` (:20-21 used at :236, :337), plain IN
+// (:147-148, :188-189, :68-69 followed by the residual add of :76).
+//
+// A group of G lanes (16 / 64 / 256) owns one (n, c) plane; reductions are wavefront shuffles
+// (plus one LDS hop for G = 256).  Statistics are two-pass (mean, then centred second moment) in
+// fp32 -- planes are as small as 16 elements in the 1-D trunk, where a one-pass E[x^2]-E[x]^2
+// would lose the parity budget.  Split-K partial slabs written by the conv kernel are summed here
+// (the "launch-boundary reduce"), so the conv never needs atomics for its K split.
+#include "mcvc_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+template <int G>
+__device__ __forceinline__ float gsum(float v, float* red)
+{
+    if constexpr (G <= 64) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    } else {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) norm_fwd_kernel(const NormArgs a)
+{
+    __shared__ float red[4];
+    constexpr int GPB = 256 / G;
+    const int g = threadIdx.x / G, l = threadIdx.x % G;
+    const long long plane_id = (long long)blockIdx.x * GPB + g;
+    if (plane_id >= (long long)a.N * a.C) return;      // whole groups leave together (G<=64); G=256: never taken
+    const int n = (int)(plane_id / a.C), c = (int)(plane_id - (long long)n * a.C);
+    const int P = a.H * a.W;
+    const float invP = 1.0f / (float)P;
+    const int nbr = (a.act == ACT_GLU) ? 2 : 1;
+    const int Cx = a.C * nbr;
+    float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
+    float* xp[2];
+    for (int br = 0; br < nbr; ++br) {
+        const int cx = c + br * a.C;
+        const long long poff = (long long)n * a.x_sn + (long long)cx * a.x_sc;
+        float* x = a.x + poff;
+        xp[br] = x;
+        float s = 0.f;
+        for (int i = l; i < P; i += G) {
+            float v = x[i];
+            if (a.nslab > 1) {
+                for (int sl = 1; sl < a.nslab; ++sl) v += a.x_slabs[(long long)(sl - 1) * a.slab_stride + poff + i];
+                x[i] = v;
+            }
+            s += v;
+        }
+        s = gsum<G>(s, red);
+        const float m = s * invP;
+        float q = 0.f;
+        for (int i = l; i < P; i += G) { const float d = x[i] - m; q += d * d; }
+        q = gsum<G>(q, red);
+        const float r = 1.0f / sqrtf(q * invP + a.eps);
+        mean[br] = m; rstd[br] = r;
+        if (l == 0) {
+            float* st = a.stats + ((long long)n * Cx + cx) * 2;
+            st[0] = m; st[1] = r;
+        }
+    }
+    const float g0 = a.gamma[0][c], b0 = a.beta[0][c];
+    float g1 = 0.f, b1 = 0.f;
+    if (nbr == 2) { g1 = a.gamma[1][c]; b1 = a.beta[1][c]; }
+    const long long yoff0 = (long long)n * a.y_sn + (long long)c * a.y_sc;
+    for (int i = l; i < P; i += G) {
+        const int h = i / a.W, w = i - h * a.W;
+        const float z0 = (xp[0][i] - mean[0]) * rstd[0] * g0 + b0;
+        float y;
+        if (a.act == ACT_GLU) {
+            const float z1 = (xp[1][i] - mean[1]) * rstd[1] * g1 + b1;
+            y = z0 * sigmoidf_(z1);
+        } else if (a.act == ACT_SILU) {
+            y = z0 * sigmoidf_(z0);
+        } else {
+            y = z0;
+        }
+        const long long yo = yoff0 + (long long)h * a.y_sh + w;
+        if (a.res) y += a.res[yo];
+        a.y[yo] = y;
+    }
+}
+
+// one group per channel c, looping over n: d(gamma), d(beta) are owned by the group -> no atomics,
+// deterministic accumulation order.
+template <int G>
+__global__ void __launch_bounds__(256) norm_bwd_kernel(const NormBwdArgs a)
+{
+    __shared__ float red[4];
+    constexpr int GPB = 256 / G;
+    const int g = threadIdx.x / G, l = threadIdx.x % G;
+    const int c = blockIdx.x * GPB + g;
+    if (c >= a.C) return;
+    const int P = a.H * a.W;
+    const float invP = 1.0f / (float)P;
+    const int nbr = (a.act == ACT_GLU) ? 2 : 1;
+    const int Cx = a.C * nbr;
+    float gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f};
+    for (int br = 0; br < nbr; ++br) { gam[br] = a.gamma[br][c]; bet[br] = a.beta[br][c]; }
+    float dgam[2] = {0.f, 0.f}, dbet[2] = {0.f, 0.f};
+    const int oh_w = a.W >> 1;   // conv-grid width when un-shuffling
+    (void)oh_w;
+    for (int n = 0; n < a.N; ++n) {
+        float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
+        const float* xp[2] = {nullptr, nullptr};
+        for (int br = 0; br < nbr; ++br) {
+            const int cx = c + br * a.C;
+            const float* st = a.stats + ((long long)n * Cx + cx) * 2;
+            mean[br] = st[0]; rstd[br] = st[1];
+            xp[br] = a.x + (long long)n * a.x_sn + (long long)cx * a.x_sc;
+        }
+        const long long yoff0 = (long long)n * a.y_sn + (long long)c * a.y_sc;
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+        for (int i = l; i < P; i += G) {
+            const int h = i / a.W, w = i - h * a.W;
+            const long long yo = yoff0 + (long long)h * a.y_sh + w;
+            float dyv = a.dy[yo];
+            if (a.nslab > 1) {
+                for (int sl = 1; sl < a.nslab; ++sl) dyv += a.dy_slabs[(long long)(sl - 1) * a.slab_stride + yo];
+                a.dy[yo] = dyv;
+            }
+            const float xh0 = (xp[0][i] - mean[0]) * rstd[0];
+            const float z0 = xh0 * gam[0] + bet[0];
+            float dz0, dz1 = 0.f, xh1 = 0.f;
+            if (a.act == ACT_GLU) {
+                xh1 = (xp[1][i] - mean[1]) * rstd[1];
+                const float sg = sigmoidf_(xh1 * gam[1] + bet[1]);
+                dz0 = dyv * sg;
+                dz1 = dyv * z0 * sg * (1.0f - sg);
+            } else if (a.act == ACT_SILU) {
+                const float sg = sigmoidf_(z0);
+                dz0 = dyv * (sg * (1.0f + z0 * (1.0f - sg)));
+            } else {
+                dz0 = dyv;
+            }
+            s1[0] += dz0; s2[0] += dz0 * xh0;
+            s1[1] += dz1; s2[1] += dz1 * xh1;
+        }
+        for (int br = 0; br < nbr; ++br) {
+            s1[br] = gsum<G>(s1[br], red);
+            s2[br] = gsum<G>(s2[br], red);
+            dbet[br] += s1[br];
+            dgam[br] += s2[br];
+        }
+        for (int i = l; i < P; i += G) {
+            const int h = i / a.W, w = i - h * a.W;
+            const long long yo = yoff0 + (long long)h * a.y_sh + w;
+            const float dyv = a.dy[yo];
+            const float xh0 = (xp[0][i] - mean[0]) * rstd[0];
+            const float z0 = xh0 * gam[0] + bet[0];
+            float dz0, dz1 = 0.f, xh1 = 0.f;
+            if (a.act == ACT_GLU) {
+                xh1 = (xp[1][i] - mean[1]) * rstd[1];
+                const float sg = sigmoidf_(xh1 * gam[1] + bet[1]);
+                dz0 = dyv * sg;
+                dz1 = dyv * z0 * sg * (1.0f - sg);
+            } else if (a.act == ACT_SILU) {
+                const float sg = sigmoidf_(z0);
+                dz0 = dyv * (sg * (1.0f + z0 * (1.0f - sg)));
+            } else {
+                dz0 = dyv;
+            }
+            const float dx0 = gam[0] * rstd[0] * (dz0 - s1[0] * invP - xh0 * (s2[0] * invP));
+            if (a.unshuffle) {
+                const int co = 4 * c + 2 * (h & 1) + (w & 1);
+                a.dx[(long long)n * a.dx_sn + (long long)co * a.dx_sc + (long long)(h >> 1) * a.dx_sh + (w >> 1)] = dx0;
+            } else {
+                a.dx[(long long)n * a.dx_sn + (long long)c * a.dx_sc + i] = dx0;
+                if (nbr == 2) {
+                    const float dx1 = gam[1] * rstd[1] * (dz1 - s1[1] * invP - xh1 * (s2[1] * invP));
+                    a.dx[(long long)n * a.dx_sn + (long long)(c + a.C) * a.dx_sc + i] = dx1;
+                }
+            }
+        }
+    }
+    if (l == 0) {
+        for (int br = 0; br < nbr; ++br) {
+            if (a.dgamma[br]) a.dgamma[br][c] += dgam[br];
+            if (a.dbeta[br]) a.dbeta[br][c] += dbet[br];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) act_fwd_kernel(const ActArgs a)
+{
+    const long long total = (long long)a.N * a.C * a.P;
+    const int nbr = (a.act == ACT_GLU) ? 2 : 1;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int i = (int)(idx % a.P);
+        const long long nc = idx / a.P;
+        const int c = (int)(nc % a.C);
+        const long long n = nc / a.C;
+        float v[2] = {0.f, 0.f};
+        for (int br = 0; br < nbr; ++br) {
+            const long long xo = ((n * nbr * a.C) + c + br * a.C) * a.P + i;
+            float t = a.x[xo];
+            if (a.nslab > 1) {
+                for (int sl = 1; sl < a.nslab; ++sl) t += a.x_slabs[(long long)(sl - 1) * a.slab_stride + xo];
+                a.x[xo] = t;
+            }
+            v[br] = t;
+        }
+        float y;
+        if (a.act == ACT_GLU) y = v[0] * sigmoidf_(v[1]);
+        else if (a.act == ACT_SILU) y = v[0] * sigmoidf_(v[0]);
+        else if (a.act == ACT_SIGMOID) y = sigmoidf_(v[0]);
+        else y = v[0];
+        if (a.y) a.y[idx] = y;
+    }
+}
+
+__global__ void __launch_bounds__(256) act_bwd_kernel(const ActBwdArgs a)
+{
+    const long long total = (long long)a.N * a.C * a.P;
+    const int nbr = (a.act == ACT_GLU) ? 2 : 1;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int i = (int)(idx % a.P);
+        const long long nc = idx / a.P;
+        const int c = (int)(nc % a.C);
+        const long long n = nc / a.C;
+        float dyv = a.dy[idx];
+        if (a.nslab > 1) {
+            for (int sl = 1; sl < a.nslab; ++sl) dyv += a.dy_slabs[(long long)(sl - 1) * a.slab_stride + idx];
+            a.dy[idx] = dyv;
+        }
+        const long long xo0 = ((n * nbr * a.C) + c) * a.P + i;
+        const float x0 = a.x[xo0];
+        if (a.act == ACT_GLU) {
+            const long long xo1 = xo0 + (long long)a.C * a.P;
+            const float sg = sigmoidf_(a.x[xo1]);
+            a.dx[xo0] = dyv * sg;
+            a.dx[xo1] = dyv * x0 * sg * (1.0f - sg);
+        } else if (a.act == ACT_SILU) {
+            const float sg = sigmoidf_(x0);
+            a.dx[xo0] = dyv * (sg * (1.0f + x0 * (1.0f - sg)));
+        } else if (a.act == ACT_SIGMOID) {
+            const float sg = sigmoidf_(x0);
+            a.dx[xo0] = dyv * sg * (1.0f - sg);
+        } else {
+            a.dx[xo0] = dyv;
+        }
+    }
+}
+
+static int pick_group(int P) { return P <= 32 ? 16 : (P <= 640 ? 64 : 256); }
+
+}  // namespace
+
+int mcvc_norm_fwd_launch(const NormArgs& a, hipStream_t s)
+{
+    const int P = a.H * a.W;
+    const long long planes = (long long)a.N * a.C;
+    const int G = pick_group(P);
+    const unsigned blocks = (unsigned)cdiv_ll(planes, 256 / G);
+    if (G == 16) hipLaunchKernelGGL(norm_fwd_kernel<16>, dim3(blocks), dim3(256), 0, s, a);
+    else if (G == 64) hipLaunchKernelGGL(norm_fwd_kernel<64>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(norm_fwd_kernel<256>, dim3(blocks), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_norm_bwd_launch(const NormBwdArgs& a, hipStream_t s)
+{
+    const int P = a.H * a.W;
+    const int G = pick_group(P);
+    const unsigned blocks = (unsigned)cdiv_i(a.C, 256 / G);
+    if (G == 16) hipLaunchKernelGGL(norm_bwd_kernel<16>, dim3(blocks), dim3(256), 0, s, a);
+    else if (G == 64) hipLaunchKernelGGL(norm_bwd_kernel<64>, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(norm_bwd_kernel<256>, dim3(blocks), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+static unsigned ew_blocks(long long total)
+{
+    long long b = cdiv_ll(total, 256);
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+int mcvc_act_fwd_launch(const ActArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks((long long)a.N * a.C * a.P)), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_act_bwd_launch(const ActBwdArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks((long long)a.N * a.C * a.P)), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,24 @@
+// Data-gradient class descriptors shared by the packer and the network planner.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct DgradClass {
+    int nth, ntw;          // taps of this output-parity class
+    int khmax, kwmax;      // tap u -> kh = khmax - step*u
+    int pad_h, pad_w;      // padding of the equivalent stride-1 conv over dY
+    int qh, qw;            // output parity (0 for stride 1)
+    long long offset;      // float offset of this class inside the layer's dgrad pack
+};
+
+struct PackDgradArgs {
+    int Cin, KH, KW;
+    int step;              // = conv stride (1 or 2)
+    int ld;                // row length (Cin rounded up to 32)
+    int co_off;            // channel offset of this branch inside the concatenated (value|gate) conv
+    int ncls;
+    DgradClass cls[4];
+};
+
+int mcvc_pack_fwd_launch(const float* w, float* dst, int Cout, int K, int ld, int co_off, hipStream_t s);
+int mcvc_pack_dgrad_launch(const float* w, float* dst, const PackDgradArgs& a, int Cout, hipStream_t s);
+int mcvc_copy_launch(const float* src, float* dst, int n, hipStream_t s);

@@ -1,0 +1,81 @@
+// Weight re-packing for the direct-conv kernels (conv_kernels.hip).
+//
+// The nn.Module boundary keeps the reference's OIHW / OIW parameter tensors (state_dict drop-in,
+// SURVEY.md Appendix B).  The MFMA kernels want K-major operands so that the 32 lanes of an A
+// fragment read 32 consecutive output channels:
+//   forward : Wf[(ci*KH+kh)*KW+kw][co]                       = W[co][ci][kh][kw]
+//   dgrad   : Wd[cls][((co*NTH+u)*NTW+v)][ci]                = W[co][ci][kh(u)][kw(v)]
+// where for stride 1 the single class is the 180-degree flipped kernel and for stride 2 the four
+// output-parity classes (ih%2, iw%2) each keep the taps with matching parity -- so the
+// data-gradient of a strided conv runs as four dense stride-1 convs with no zero-insertion.
+// Packed buffers are zero-initialised once by the owner; the kernels only write valid entries, so
+// channel/row padding stays zero.
+#include "mcvc_common.h"
+#include "pack.h"
+
+// [R=Cout][K] -> dst[k*ld + co_off + co], 32x32 LDS tiles, both sides coalesced
+__global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ dst,
+                                                       int Cout, int K, int ld, int co_off)
+{
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int co = c0 + r, k = k0 + tx;
+        tile[r][tx] = (co < Cout && k < K) ? w[(long long)co * K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, co = c0 + tx;
+        if (k < K && co < Cout) dst[(long long)k * ld + co_off + co] = tile[tx][r];
+    }
+}
+
+// one block per (ci tile of 32, co): load W[co][ci0..ci0+32)[taps] (contiguous) and scatter rows of 32 ci
+__global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ dst, PackDgradArgs a)
+{
+    extern __shared__ float lds[];
+    const int ci0 = blockIdx.x * 32, co = blockIdx.y;
+    const int khkw = a.KH * a.KW;
+    int nci = a.Cin - ci0; if (nci > 32) nci = 32;
+    const float* src = w + ((long long)co * a.Cin + ci0) * khkw;
+    for (int i = threadIdx.x; i < nci * khkw; i += 256) lds[i] = src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    for (int c = 0; c < a.ncls; ++c) {
+        const int nt = a.cls[c].nth * a.cls[c].ntw;
+        for (int t = grp; t < nt; t += 8) {
+            const int u = t / a.cls[c].ntw, v = t - u * a.cls[c].ntw;
+            const int kh = a.cls[c].khmax - a.step * u, kw = a.cls[c].kwmax - a.step * v;
+            if (lane < nci)
+                dst[a.cls[c].offset + ((long long)(a.co_off + co) * nt + t) * a.ld + ci0 + lane] = lds[lane * khkw + kh * a.KW + kw];
+        }
+    }
+}
+
+__global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+int mcvc_pack_fwd_launch(const float* w, float* dst, int Cout, int K, int ld, int co_off, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv_i(K, 32), (unsigned)cdiv_i(Cout, 32));
+    hipLaunchKernelGGL(pack_fwd_kernel, grid, dim3(256), 0, s, w, dst, Cout, K, ld, co_off);
+    return (int)hipGetLastError();
+}
+
+int mcvc_pack_dgrad_launch(const float* w, float* dst, const PackDgradArgs& a, int Cout, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv_i(a.Cin, 32), (unsigned)Cout);
+    const size_t lds = (size_t)32 * a.KH * a.KW * sizeof(float);
+    hipLaunchKernelGGL(pack_dgrad_kernel, grid, dim3(256), lds, s, w, dst, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_copy_launch(const float* src, float* dst, int n, hipStream_t s)
+{
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)cdiv_i(n, 256)), dim3(256), 0, s, src, dst, n);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,110 @@
+"""ctypes binding of ``libmcvc_hip.so`` (the C ABI declared in ``include/mcvc.h``).
+
+PyTorch is used only as the owner of device memory and HIP streams: every call below hands raw
+device pointers and the current stream to the library.  There is NO fallback -- if the library is
+missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_longlong, c_void_p
+
+import torch  # noqa: F401  (must be imported first so libamdhip64.so.7 is already resident)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmcvc_hip.so")
+
+GEN_NPARAMS = 110
+DISC_NPARAMS = 20
+N_MEL = 80
+
+_lib = None
+
+_PP = ctypes.POINTER(c_void_p)
+
+_SIGS = {
+    "mcvc_version": (c_int, []),
+    "mcvc_gen_packed_floats": (c_longlong, []),
+    "mcvc_disc_packed_floats": (c_longlong, []),
+    "mcvc_gen_stash_floats": (c_longlong, [c_int, c_int]),
+    "mcvc_gen_scratch_floats": (c_longlong, [c_int, c_int]),
+    "mcvc_disc_stash_floats": (c_longlong, [c_int, c_int]),
+    "mcvc_disc_scratch_floats": (c_longlong, [c_int, c_int]),
+    "mcvc_gen_out_frames": (c_int, [c_int]),
+    "mcvc_disc_out_frames": (c_int, [c_int]),
+    "mcvc_gen_pack": (c_int, [_PP, c_void_p, c_void_p]),
+    "mcvc_disc_pack": (c_int, [_PP, c_void_p, c_void_p]),
+    "mcvc_gen_forward": (c_int, [_PP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
+    "mcvc_gen_backward": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
+    "mcvc_disc_forward": (c_int, [_PP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
+    "mcvc_disc_backward": (c_int, [_PP, c_void_p, _PP, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
+    "mcvc_l1_loss": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "mcvc_lsgan_loss": (c_int, [c_void_p, c_longlong, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mcvc_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
+    "mcvc_axpy": (c_int, [c_void_p, c_void_p, c_float, c_longlong, c_void_p]),
+    "mcvc_conv2d_pack_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
+    "mcvc_conv2d_forward": (c_int, [c_void_p] * 6 + [c_int] * 12 + [c_void_p]),
+    "mcvc_conv2d_dgrad": (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p]),
+    "mcvc_conv2d_wgrad": (c_int, [c_void_p] * 3 + [c_int] * 10 + [c_void_p]),
+    "mcvc_instnorm_act_forward": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
+    "mcvc_instnorm_act_backward": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p]),
+    "mcvc_bias_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mcvc_act_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mcvc_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mcvc_fif_input": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mcvc_fif_input_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+
+
+def lib():
+    """Load (once) and return the HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmcvc_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)          # AttributeError if the ABI and the header ever diverge
+            fn.restype = res
+            fn.argtypes = args
+        if L.mcvc_version() != 1:
+            raise RuntimeError("libmcvc_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "mcvc call"):
+    if rc != 0:
+        raise RuntimeError("%s failed with code %d" % (what, rc))
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr_table(tensors):
+    """Host array of device pointers (NULL for None entries)."""
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def require_cuda_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("mask_cyclegan_vc (MI355X build): tensors must live on a HIP device; "
+                               "there is no CPU path in this package")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise RuntimeError("expected contiguous float32 tensors")

@@ -1,0 +1,152 @@
+"""GPU parity of the whole-network HIP path against (a) golden vectors produced by the reference and
+(b) the CPU oracle on identical seeded inputs.  Bar: relative L2 <= 1e-3 (north star); observed ~1e-6."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import mcvc_oracle as orc  # noqa: E402  (checker only)
+from mask_cyclegan_vc.model import Discriminator, DownSampleGenerator, Generator, ResidualLayer  # noqa: E402
+
+TOL = 1e-3
+
+
+def rel_l2(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def seeded_inputs(seed, B, T, max_mask_len=25):
+    rs = np.random.RandomState(seed)
+    x = rs.randn(B, 80, T).astype(np.float32)
+    m = orc.fif_mask(rs, B, 80, T, min(max_mask_len, T))
+    return torch.from_numpy(x), torch.from_numpy(m)
+
+
+@pytest.fixture(scope="module")
+def meta(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "meta.json")))
+
+
+@pytest.fixture(scope="module")
+def nets(meta):
+    g = Generator()
+    g.load_state_dict(orc.filler_params("G", meta["filler_seeds"]["G"]), strict=True)
+    d = Discriminator()
+    d.load_state_dict(orc.filler_params("D", meta["filler_seeds"]["D"]), strict=True)
+    return g.cuda(), d.cuda()
+
+
+def test_forward_matches_reference_goldens(golden_dir, meta, nets):
+    gold = np.load(os.path.join(golden_dir, "forward.npz"))
+    g, d = nets
+    worst = 0.0
+    with torch.no_grad():
+        for case in meta["forward_cases"]:
+            B, T = case["B"], case["T"]
+            x, m = seeded_inputs(case["seed"], B, T)
+            y = g(x.cuda(), m.cuda())
+            tag = "%dx%d" % (B, T)
+            assert tuple(y.shape) == gold["g_out_" + tag].shape
+            e = [rel_l2(y, gold["g_out_" + tag]), rel_l2(d(x.cuda()), gold["d_out_" + tag]), rel_l2(d(y), gold["dg_out_" + tag])]
+            worst = max(worst, *e)
+            assert max(e) < TOL, (tag, e)
+    print("worst forward rel-L2 vs reference goldens: %.3e" % worst)
+
+
+def test_gradients_match_reference_goldens(golden_dir, meta, nets):
+    gold = np.load(os.path.join(golden_dir, "grads.npz"))
+    norms = json.load(open(os.path.join(golden_dir, "grad_norms.json")))
+    g, d = nets
+    c = meta["grad_case"]
+    x, m = seeded_inputs(c["seed"], c["B"], c["T"])
+    x = x.cuda().requires_grad_(True)
+    for p in list(g.parameters()) + list(d.parameters()):
+        p.grad = None
+    y = g(x, m.cuda())
+    loss = torch.mean((1 - d(y)) ** 2) + 10.0 * torch.mean(torch.abs(x.detach() - y))
+    loss.backward()
+    assert abs(float(loss) - float(gold["loss"])) < 1e-4 * abs(float(gold["loss"]))
+    assert rel_l2(x.grad, gold["dx"]) < TOL
+    checked = 0
+    for tag, net in (("G", g), ("D", d)):
+        for n, p in net.named_parameters():
+            ref = norms[tag + ":" + n]
+            if ref is None:
+                assert p.grad is None, n                  # dead downSample4: no grad, like the reference
+                continue
+            if ref < 1e-6:
+                # conv bias in front of an InstanceNorm: mathematically zero; the reference carries ~1e-8 noise
+                assert float(p.grad.norm()) < 1e-5, n
+                continue
+            assert abs(float(p.grad.double().norm()) - ref) < TOL * ref, (n, float(p.grad.norm()), ref)
+            assert rel_l2(p.grad.flatten()[:32], gold[tag + ":" + n]) < 5e-3, n
+            checked += 1
+    assert checked > 80
+
+
+@pytest.mark.parametrize("B,T", [(1, 64), (3, 64), (2, 24), (1, 68)])
+def test_full_tensor_parity_vs_oracle(B, T, nets, meta):
+    """Every parameter gradient and the input gradient, full tensors, vs the CPU oracle."""
+    g, d = nets
+    gp = orc.filler_params("G", meta["filler_seeds"]["G"])
+    dp = orc.filler_params("D", meta["filler_seeds"]["D"])
+    x, m = seeded_inputs(77 + B + T, B, T)
+    gn, dn = orc.generator_param_names(), orc.discriminator_param_names()
+    live_d = [k for k in dn if not k.startswith(orc.DISC_DEAD_PREFIX)]
+    xr = x.clone().requires_grad_(True)
+    leaves = [xr] + [gp[k].requires_grad_(True) for k in gn] + [dp[k].requires_grad_(True) for k in live_d]
+    yr = orc.generator_forward(gp, xr, m)
+    dr = orc.discriminator_forward(dp, yr)
+    wy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(5))
+    loss_r = torch.mean((1 - dr) ** 2) + (yr * wy).mean()
+    ref = torch.autograd.grad(loss_r, leaves)
+
+    xd = x.cuda().requires_grad_(True)
+    for p in list(g.parameters()) + list(d.parameters()):
+        p.grad = None
+    y = g(xd, m.cuda())
+    dd = d(y)
+    assert rel_l2(y, yr) < TOL and rel_l2(dd, dr) < TOL
+    loss = torch.mean((1 - dd) ** 2) + (y * wy.cuda()).mean()
+    loss.backward()
+    assert rel_l2(xd.grad, ref[0]) < TOL
+    gd = dict(g.named_parameters()); ddict = dict(d.named_parameters())
+    worst = 0.0
+    for k, r in zip(gn, ref[1:1 + len(gn)]):
+        if float(r.norm()) < 1e-6:
+            continue
+        e = rel_l2(gd[k].grad, r); worst = max(worst, e)
+        assert e < TOL, (k, e)
+    for k, r in zip(live_d, ref[1 + len(gn):]):
+        if float(r.norm()) < 1e-6:
+            continue
+        e = rel_l2(ddict[k].grad, r); worst = max(worst, e)
+        assert e < TOL, (k, e)
+    print("B=%d T=%d worst parameter-gradient rel-L2 vs oracle: %.3e" % (B, T, worst))
+
+
+def test_building_blocks_match_torch():
+    import torch.nn.functional as F
+    torch.manual_seed(3)
+    r = ResidualLayer(256, 512, 3, 1, 1)
+    x = torch.randn(2, 256, 16)
+    p = {k: v.detach() for k, v in r.state_dict().items()}
+
+    def inorm(t, n):
+        return F.instance_norm(t, None, None, p[n + ".1.weight"], p[n + ".1.bias"], True, 0.0, 1e-5)
+    a = inorm(F.conv1d(x, p["conv1d_layer.0.weight"], p["conv1d_layer.0.bias"], 1, 1), "conv1d_layer")
+    gt = inorm(F.conv1d(x, p["conv_layer_gates.0.weight"], p["conv_layer_gates.0.bias"], 1, 1), "conv_layer_gates")
+    ref = x + inorm(F.conv1d(a * torch.sigmoid(gt), p["conv1d_out_layer.0.weight"], p["conv1d_out_layer.0.bias"], 1, 1), "conv1d_out_layer")
+    assert rel_l2(r.cuda()(x.cuda()), ref) < TOL
+    ds = DownSampleGenerator(128, 256, 5, 2, 2)
+    x2 = torch.randn(1, 128, 20, 16)
+    q = {k: v.detach() for k, v in ds.state_dict().items()}
+    a = F.instance_norm(F.conv2d(x2, q["convLayer.0.weight"], q["convLayer.0.bias"], 2, 2), None, None, q["convLayer.1.weight"], q["convLayer.1.bias"], True, 0.0, 1e-5)
+    gt = F.instance_norm(F.conv2d(x2, q["convLayer_gates.0.weight"], q["convLayer_gates.0.bias"], 2, 2), None, None, q["convLayer_gates.1.weight"], q["convLayer_gates.1.bias"], True, 0.0, 1e-5)
+    assert rel_l2(ds.cuda()(x2.cuda()), a * torch.sigmoid(gt)) < TOL
