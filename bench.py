@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- MaskCycleGAN-VC full G+D training step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one full iteration of the reference's inner loop (train.py:195-299: 10 generator forwards,
+12 discriminator forwards, both backward passes, both Adam steps) on one synthetic minibatch per GPU
+(bs=1, 80 mel x 64 frames, fp32 -- BASELINE.json configs[1]); inputs are resident in HBM before the
+timed region.  Prints ONE JSON line on rank 0.  `value` is the whole-job rate: per-GPU bs=1 iterations
+per second summed over the N data-parallel ranks (weak scaling).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "maskcyclegan-vc_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+ALG_GFLOP_PER_SAMPLE_ITER = 504.1      # necessary conv MAC*2 work of one bs=1 iteration
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_batches(n_batches, B, T, rank, device, max_mask_len=25):
+    """real ~ N(0,1) (the dataset is per-bin standardised); masks follow dataset/vc_dataset.py:51-55."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    rs = np.random.RandomState(1234 + rank)
+    out = []
+    for _ in range(n_batches):
+        ra = torch.randn(B, 80, T, generator=g)
+        rb = torch.randn(B, 80, T, generator=g)
+        ms = []
+        for _k in range(2):
+            m = np.ones((B, 80, T), dtype=np.float32)
+            for b in range(B):
+                size = rs.randint(0, max_mask_len)
+                start = rs.randint(0, T - size)
+                m[b, :, start:start + size] = 0.0
+            ms.append(torch.from_numpy(m))
+        out.append(tuple(t.to(device) for t in (ra, ms[0], rb, ms[1])))
+    return out
+
+
+def build_nets(device):
+    from mask_cyclegan_vc.model import Discriminator, Generator
+    torch.manual_seed(0)                   # reference construction order (train.py:103-110)
+    names = ("generator_A2B", "generator_B2A", "discriminator_A", "discriminator_B", "discriminator_A2", "discriminator_B2")
+    nets = {}
+    for i, n in enumerate(names):
+        nets[n] = (Generator() if i < 2 else Discriminator()).to(device)
+    return nets
+
+
+def trace_one_step(engine, batch):
+    from mask_cyclegan_vc import _hip
+    L = _hip.lib()
+    nk = L.mcvc_trace_kinds()
+    buf = (ctypes.c_double * (4 * nk))()
+    torch.cuda.synchronize()
+    L.mcvc_trace_enable(1)
+    engine.step(*batch)
+    L.mcvc_trace_collect(buf)
+    L.mcvc_trace_enable(0)
+    rows = []
+    for k in range(nk):
+        n, ms, fl, by = buf[4 * k:4 * k + 4]
+        if n > 0:
+            rows.append({"kernel": L.mcvc_trace_kind_name(k).decode(), "launches": int(n), "ms": ms, "gflop": fl / 1e9, "mbytes": by / 1e6})
+    rows.sort(key=lambda r: -r["ms"])
+    return rows
+
+
+def cpu_baseline(B, T, n_timed, first_losses, threads=0):
+    """The oracle (CPU restatement pinned to the reference, tests/test_oracle_golden.py) on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mcvc_oracle as orc
+    # mkldnn oversubscribes badly on a 256-core host (one iteration did not finish in 10 minutes);
+    # 32 threads is where the reference's CPU path runs fastest on these boxes
+    torch.set_num_threads(threads if threads > 0 else min(os.cpu_count() or 1, 32))
+    log("cpu baseline: %d threads" % torch.get_num_threads())
+    nets = orc.default_init_nets(0)
+    so = orc.StepOracle(nets)
+    batches = synthetic_batches(1 + n_timed, B, T, 0, "cpu")
+    t0 = time.perf_counter()
+    g0, d0 = so.step(*batches[0])                     # warm-up iteration (also the parity probe)
+    t_first = time.perf_counter() - t0
+    log("cpu warm-up iteration %.1f s" % t_first)
+    t0 = time.perf_counter()
+    for b in batches[1:]:
+        so.step(*b)
+    dt = time.perf_counter() - t0
+    parity = None
+    if first_losses is not None:
+        parity = {"g_loss_rel": abs(first_losses[0] - g0) / abs(g0), "d_loss_rel": abs(first_losses[1] - d0) / abs(d0)}
+    return {"value": n_timed / dt, "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d timed full G+D iterations at bs=%d 80x%d after 1 warm-up (%.1f s); oracle/mcvc_oracle.StepOracle, "
+                      "reference autograd semantics incl. its discarded work" % (n_timed, B, T, t_first),
+            "host_cpus": os.cpu_count()}, parity
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-size", type=int, default=1, help="per-GPU minibatch (BASELINE metric: 1)")
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--cpu-iters", type=int, default=4, help="timed CPU-baseline iterations (0 = skip)")
+    ap.add_argument("--no-trace", action="store_true")
+    ap.add_argument("--dump-trace", default=None, help="write one traced step's per-launch records (launch order) to this file")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")
+    args = ap.parse_args()
+
+    from mask_cyclegan_vc.engine import TrainEngine
+    from mask_cyclegan_vc.parallel import FlatGradReducer, init_from_env
+    from mask_cyclegan_vc.schedule import StepSchedule
+
+    rank, world, local_rank = init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    B, T = args.batch_size, args.frames
+
+    log("building nets")
+    nets = build_nets(device)
+    sched = StepSchedule(generator_lr=2e-4, discriminator_lr=1e-4, num_epochs=6172, n_samples=81, batch_size=B,
+                         decay_after=2e5, stop_identity_after=1e4, world_size=world)     # bash_scripts/mask_cyclegan_train.sh
+    engine = TrainEngine(nets, B, T, schedule=sched, reducer=FlatGradReducer())
+    batches = synthetic_batches(16, B, T, rank, device)
+    log("engine ready; warm-up")
+
+    first = None
+    for i in range(args.warmup):
+        engine.step(*batches[i % len(batches)])
+        if i == 0:
+            lo = engine.losses()
+            first = (lo["g_loss"], lo["d_loss"])
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    log("timing %d steps" % args.steps)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        engine.step(*batches[(args.warmup + i) % len(batches)])
+        engine.losses()                    # the reference reads both losses every iteration (train.py:303)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    log("timed region done: %.2f ms/step" % (1e3 * dt / args.steps))
+    final = engine.losses()
+    finite = all(np.isfinite(v) for v in final.values())
+    rows = [] if args.no_trace else trace_one_step(engine, batches[0])
+    if args.dump_trace and rank == 0:
+        from mask_cyclegan_vc import _hip
+        L = _hip.lib()
+        buf = (ctypes.c_double * (4 * 8192))()
+        torch.cuda.synchronize()
+        L.mcvc_trace_enable(1)
+        engine.step(*batches[0])
+        n = L.mcvc_trace_collect_raw(buf, 8192)
+        L.mcvc_trace_enable(0)
+        with open(args.dump_trace, "w") as fh:
+            for i in range(n):
+                k, ms, fl, by = buf[4 * i:4 * i + 4]
+                fh.write("%4d %-24s %9.4f ms %10.4f GF %9.3f MB %8.2f TF/s %8.1f GB/s\n" % (
+                    i, L.mcvc_trace_kind_name(int(k)).decode(), ms, fl / 1e9, by / 1e6, fl / 1e9 / max(ms, 1e-6), by / 1e6 / max(ms, 1e-6)))
+
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        value = world * args.steps / dt
+        sample_iters = world * B * args.steps / dt
+        res = {
+            "metric": "train iters/s (full G+D step), 80x64 mel bs=1",
+            "value": value, "unit": "iters/s (per-GPU bs=%d iterations, summed over GPUs)" % B,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MaskCycleGAN-VC full G+D iteration, VCC2018-shaped synthetic mels, bs=%d/GPU, 80 mel x %d frames, fp32, "
+                                   "default-init weights (seed 0)" % (B, T),
+                       "global_batch": world * B, "parallelism": "dp%d" % world},
+            "mel_frames_per_s": sample_iters * T,
+            "step_mfma_fraction": sample_iters * ALG_GFLOP_PER_SAMPLE_ITER / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world),
+            "losses_finite": finite, "last_losses": final,
+        }
+        if rows:
+            conv = [r for r in rows if r["gflop"] > 0]
+            dom = max(conv, key=lambda r: r["ms"])
+            total_ms = sum(r["ms"] for r in rows)
+            ach = dom["gflop"] / dom["ms"]          # GFLOP/ms == TFLOP/s
+            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "kernel": dom["kernel"],
+                               "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
+                               "share_of_kernel_time": dom["ms"] / total_ms}
+            res["kernel_time_ms_per_step"] = {r["kernel"]: round(r["ms"], 4) for r in rows}
+            res["kernel_launches_per_step"] = int(sum(r["launches"] for r in rows))
+            res["all_conv_tflops"] = sum(r["gflop"] for r in conv) / sum(r["ms"] for r in conv)
+        log("trace done")
+        if world == 1 and args.cpu_iters > 0:
+            cb, parity = cpu_baseline(B, T, args.cpu_iters, first, args.cpu_threads)
+            res["cpu_baseline"] = cb
+            res["parity_first_iteration_vs_cpu"] = parity
+            res["speedup_vs_cpu"] = value / cb["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -93,9 +93,11 @@ int mcvc_conv2d_forward(const float* x, const float* w, const float* bias, float
 int mcvc_conv2d_dgrad(const float* dy, const float* w, float* dx, float* wpack, float* slabs, int max_slabs,
                       int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
                       void* stream);
-/* dw[Cout,Cin,KH,KW] += conv2d_backward_weight(x, dy) */
-int mcvc_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout,
-                      int KH, int KW, int stride, int pad_h, int pad_w, void* stream);
+/* dw[Cout,Cin,KH,KW] += conv2d_backward_weight(x, dy).  slabs: K-split scratch of
+ * mcvc_conv2d_wgrad_slab_floats() floats (may be NULL: no split)                                      */
+long long mcvc_conv2d_wgrad_slab_floats(int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_h, int pad_w);
+int mcvc_conv2d_wgrad(const float* x, const float* dy, float* dw, float* slabs, long long slab_floats, int N, int Cin, int H, int W,
+                      int Cout, int KH, int KW, int stride, int pad_h, int pad_w, void* stream);
 /* InstanceNorm(affine) + activation.  act: 0 none, 1 gated GLU (x has 2C channels: value|gate), 2 SiLU.
  * x[N,Cx,H,W] -> y[N,C,H,W]; stats[N,Cx,2] (mean, rstd)                                              */
 int mcvc_instnorm_act_forward(float* x, const float* gamma, const float* beta, const float* gamma_gate,
@@ -114,6 +116,15 @@ int mcvc_act_backward(const float* x, float* dy, float* dx, int N, int C, int P,
 /* xin[N,2,P] = (x*mask, mask)   (model.py:241) ; dx (=|+=) dxin[:,0]*mask */
 int mcvc_fif_input(const float* x, const float* mask, float* xin, int N, int P, void* stream);
 int mcvc_fif_input_grad(const float* dxin, const float* mask, float* dx, int N, int P, int accumulate, void* stream);
+
+/* ---- opt-in measurement (bench.py `roofline`): HIP events around every kernel launch ----------- */
+int mcvc_trace_enable(int on);
+int mcvc_trace_kinds(void);
+const char* mcvc_trace_kind_name(int kind);
+/* out[kind][4] = {launches, total_ms, algorithmic_flops, algorithmic_bytes}; clears the log; syncs  */
+int mcvc_trace_collect(double* out);
+/* raw records in launch order: out[i][4] = {kind, ms, flops, bytes}; returns the record count           */
+int mcvc_trace_collect_raw(double* out, int max_records);
 
 #ifdef __cplusplus
 }

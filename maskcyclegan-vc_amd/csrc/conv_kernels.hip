@@ -6,6 +6,7 @@
 // 116-126, 142-146, 183-187, 227-231, 207-211, 290-327) -- forward, data-gradient (same kernel on dY with
 // re-packed weights, see pack_kernels.hip) and weight-gradient.
 #include "mcvc_common.h"
+#include "trace.h"
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -20,16 +21,33 @@
 // Stride-2 patches are stored column-de-interleaved (even cols then odd cols) so the 32 lanes of a
 // pixel row read consecutive banks; PWp is chosen on the host so that the rows of one 32-pixel
 // sub-tile start in disjoint bank groups.
+// Software pipeline, ONE barrier per channel chunk, everything double-buffered in LDS:
+//   * the weight slice of chunk c+1 streams HBM/L2 -> LDS by direct DMA (global_load_lds, 16 B/lane, no
+//     VGPRs); rows past the end of the packed matrix are redirected to its all-zero pad row;
+//   * the (small) input patch of chunk c+1 is fetched into registers before the MFMA loop of chunk c and
+//     written to the other LDS buffer after it (zero fill / stride-2 de-interleave happen on that write);
+//   * __syncthreads() drains the DMA (hipcc emits vmcnt(0) in front of the barrier) and flips buffers.
+constexpr int kMaxPR = 8;    // patch rows per half-wave            (cic*PH <= 64)
+constexpr int kMaxPC = 3;    // 32-column groups per patch row      (PW <= 96)
+
+__device__ __forceinline__ void glds16(const float* g, float* l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
 template <int WM, int WN, int BMW, int BNW>
-__global__ void __launch_bounds__(256) conv_direct_kernel(const ConvArgs a)
+__global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int COT = 32 * WM * BMW;
     constexpr int NSUB = WN * BNW;
+    constexpr int V = COT / 4;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
+    const int hw = tid >> 5;                         // half-wave id 0..7
     const int wm_id = wave / BNW, wn_id = wave % BNW;
     const int KHKW = a.KH * a.KW;
 
@@ -47,8 +65,9 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(const ConvArgs a)
     const int iw0 = ow0 * a.stride - a.pad_w;
     const bool s2 = (a.stride == 2);
 
-    float* Xs = smem;
-    float* Ws = smem + a.xs_floats;
+    const int ws_floats = a.cic * KHKW * COT;
+    float* Xbuf[2] = {smem, smem + a.xs_floats};
+    float* Wbuf[2] = {smem + 2 * a.xs_floats, smem + 2 * a.xs_floats + ws_floats};
 
     const int r_j = l31 >> a.tow_log2, c_j = l31 & (tow - 1);
     int b_lane[WN];
@@ -72,47 +91,80 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(const ConvArgs a)
     if (ch_end > a.nchunks) ch_end = a.nchunks;
 
     const float* xn = a.x + (long long)n * a.x_sb;
+    const int prow_n = a.cic * a.PH;               // patch rows per chunk
+    const int w4_n = a.cic * KHKW * V;             // weight float4 per chunk
+    // a column tile past the packed row length reads (finite) neighbouring weights; those outputs are discarded
+    const int co_lim = a.w_cout - 4;
 
-    for (int ch = ch_begin; ch < ch_end; ++ch) {
+    float preg[kMaxPR][kMaxPC];
+
+    auto dma_weights = [&](int ch, float* wdst) {
+        const long long grow0 = (long long)ch * a.cic * KHKW;
+        for (int base = wave * 64; base < w4_n; base += 256) {     // wave-uniform LDS base, lane*16 B added by HW
+            const int idx = base + lane;
+            if (idx < w4_n) {
+                const int row = idx / V, v4 = idx - row * V;
+                long long grow = grow0 + row;
+                if (grow > a.w_rows) grow = a.w_rows;              // zero pad row
+                int co = co0 + v4 * 4;
+                if (co > co_lim) co = co_lim;
+                glds16(a.w + grow * a.w_cout + co, wdst + (long long)base * 4);
+            }
+        }
+    };
+    auto fetch_patch = [&](int ch) {
         const int c0 = ch * a.cic;
-        __syncthreads();
-        // ---- stage the input patch (half-wave per patch row, coalesced along w)
-        {
-            const int rows = a.cic * a.PH;
-            for (int row = tid >> 5; row < rows; row += 8) {
+#pragma unroll
+        for (int k = 0; k < kMaxPR; ++k) {
+            const int row = hw + 8 * k;
+            const int ci = row / a.PH;
+            const int r = row - ci * a.PH;
+            const int ih = ih0 + r;
+            const int cg = c0 + ci;
+            const bool rok = (row < prow_n) && (cg < a.Cin) && (ih >= 0) && (ih < a.H);
+            const float* src = xn + (long long)cg * a.x_sc + (long long)ih * a.x_sh;
+#pragma unroll
+            for (int j = 0; j < kMaxPC; ++j) {
+                const int iw = iw0 + l31 + 32 * j;
+                float v = 0.f;
+                if (rok && (l31 + 32 * j) < a.PW && iw >= 0 && iw < a.W) v = src[iw];
+                preg[k][j] = v;
+            }
+        }
+    };
+    auto commit_patch = [&](float* xdst) {
+#pragma unroll
+        for (int k = 0; k < kMaxPR; ++k) {
+            const int row = hw + 8 * k;
+            if (row < prow_n) {
                 const int ci = row / a.PH;
                 const int r = row - ci * a.PH;
-                const int ih = ih0 + r;
-                const int cg = c0 + ci;
-                const bool rok = (cg < a.Cin) && (ih >= 0) && (ih < a.H);
-                const float* src = xn + (long long)cg * a.x_sc + (long long)ih * a.x_sh;
-                float* dst = Xs + ci * a.plane + r * a.PWp;
-                for (int c = l31; c < a.PW; c += 32) {
-                    const int iw = iw0 + c;
-                    float v = 0.f;
-                    if (rok && iw >= 0 && iw < a.W) v = src[iw];
-                    const int cm = s2 ? ((c & 1) * a.PWh + (c >> 1)) : c;
-                    dst[cm] = v;
+                float* dst = xdst + ci * a.plane + r * a.PWp;
+#pragma unroll
+                for (int j = 0; j < kMaxPC; ++j) {
+                    const int c = l31 + 32 * j;
+                    if (c < a.PW) dst[s2 ? ((c & 1) * a.PWh + (c >> 1)) : c] = preg[k][j];
                 }
             }
         }
-        // ---- stage the weight slice (rows are contiguous in the packed layout)
-        {
-            constexpr int V = COT / 4;
-            const int rows = a.cic * KHKW;
-            const long long grow0 = (long long)c0 * KHKW;
-            for (int idx = tid; idx < rows * V; idx += 256) {
-                const int row = idx / V, v4 = idx - row * V;
-                const long long grow = grow0 + row;
-                const int co = co0 + v4 * 4;
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (grow < a.w_rows && co < a.w_cout)
-                    val = *reinterpret_cast<const float4*>(a.w + grow * a.w_cout + co);
-                *reinterpret_cast<float4*>(Ws + row * COT + v4 * 4) = val;
-            }
+    };
+
+    if (ch_begin < ch_end) {
+        dma_weights(ch_begin, Wbuf[0]);
+        fetch_patch(ch_begin);
+        commit_patch(Xbuf[0]);
+    }
+    __syncthreads();
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        const int cur = (ch - ch_begin) & 1;
+        const bool more = (ch + 1 < ch_end);
+        if (more) {
+            dma_weights(ch + 1, Wbuf[cur ^ 1]);
+            fetch_patch(ch + 1);
         }
-        __syncthreads();
         // ---- MFMA main loop over (channel pair, kh, kw)
+        const float* Xs = Xbuf[cur];
+        const float* Ws = Wbuf[cur];
         const int npairs = a.cic >> 1;
         for (int cp = 0; cp < npairs; ++cp) {
             const float* xs = Xs + cp * 2 * a.plane;
@@ -134,6 +186,8 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(const ConvArgs a)
                 }
             }
         }
+        if (more) commit_patch(Xbuf[cur ^ 1]);
+        __syncthreads();
     }
 
     // ---- epilogue: bias, (shuffled) store / slab store / accumulate
@@ -160,7 +214,7 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(const ConvArgs a)
                     else
                         off = (long long)co * a.y_sc + (long long)oh * a.y_sh + (long long)ow * a.y_sw;
                     if (a.out_mode == CONV_OUT_ACCUM) {
-                        if (a.nsplit > 1) atomicAdd(ybase + off, v);
+                        if (a.nsplit > 1) unsafeAtomicAdd(ybase + off, v);   // global_atomic_add_f32 (no CAS loop)
                         else ybase[off] += v;
                     } else {
                         ybase[off] = v;
@@ -174,17 +228,18 @@ __global__ void __launch_bounds__(256) conv_direct_kernel(const ConvArgs a)
 // ---- host planner --------------------------------------------------------------------------------
 namespace {
 
-enum ConvCfg { CFG_L = 0, CFG_M, CFG_N, CFG_T, CFG_S, CFG_COUNT };
-struct CfgDesc { int cot, npix; };
+enum ConvCfg { CFG_L = 0, CFG_M, CFG_N, CFG_T, CFG_S, CFG_S2, CFG_COUNT };
+struct CfgDesc { int cot, npix, kind; };
 static const CfgDesc kCfg[CFG_COUNT] = {
-    {128, 128},   // L: 2x2 waves of 2x2 accumulators
-    {128, 64},    // M: 2x2 waves of 2x1
-    {64, 128},    // N: 2x2 waves of 1x2
-    {256, 32},    // T: 4x1 waves of 2x1   (1-D trunk: few pixels, many channels)
-    {32, 256},    // S: 1x4 waves of 1x2   (Cout <= 32)
+    {128, 128, K_CONV_L},   // L: 2x2 waves of 2x2 accumulators
+    {128, 64, K_CONV_M},    // M: 2x2 waves of 2x1
+    {64, 128, K_CONV_N},    // N: 2x2 waves of 1x2
+    {256, 32, K_CONV_T},    // T: 4x1 waves of 2x1   (1-D trunk: few pixels, many channels)
+    {32, 256, K_CONV_S},    // S: 1x4 waves of 1x2   (Cout <= 32)
+    {32, 128, K_CONV_S2},   // S2: 1x4 waves of 1x1  (Cout <= 32, small images)
 };
 
-constexpr int kLdsBudgetFloats = 15 * 1024;   // 60 KiB per workgroup -> 2 workgroups per CU
+constexpr int kLdsBudgetFloats = 19 * 1024 + 512;   // 78 KiB per workgroup -> 2 workgroups per CU (160 KiB LDS)
 
 struct ConvPlan {
     ConvArgs a;
@@ -216,73 +271,96 @@ static void patch_geometry(const ConvProblem& p, int npix, int tow_log2, int* PH
 static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_nsplit, ConvPlan* out)
 {
     if (p.stride != 1 && p.stride != 2) return false;
-    ConvPlan pl;
-    ConvArgs& a = pl.a;
-    a = ConvArgs{};
     const int tow_log2 = pick_tow_log2(p.OW);
     const int tow = 1 << tow_log2, rps = 32 >> tow_log2;
     const int npix_img = p.OH * p.OW;
-    int cfg;
-    if (p.Cout <= 32) cfg = CFG_S;
-    else if (npix_img * 1 <= 48 && p.Cout >= 256) cfg = CFG_T;
-    else if (p.KH * p.KW > 25 || p.Cout <= 64) cfg = CFG_N;
-    else {
-        // prefer the big tile only when it still yields enough workgroups
+    // candidate tile configurations in order of preference; the first one whose LDS / register-prefetch
+    // geometry fits is used
+    int cand[4], ncand = 0;
+    if (p.Cout <= 32) {
+        if (npix_img > 160) cand[ncand++] = CFG_S;
+        cand[ncand++] = CFG_S2; cand[ncand++] = CFG_S;
+    } else if (npix_img <= 48 && p.Cout >= 256) {
+        cand[ncand++] = CFG_T; cand[ncand++] = CFG_M; cand[ncand++] = CFG_N;
+    } else if (p.KH * p.KW > 25 || p.Cout <= 64) {
+        cand[ncand++] = CFG_N; cand[ncand++] = CFG_M;
+    } else {
         const int toh_l = (kCfg[CFG_L].npix / 32) * rps;
         const long long blocks_l = (long long)cdiv_i(p.OW, tow) * cdiv_i(p.OH, toh_l) * cdiv_i(p.Cout, 128) * NB;
-        cfg = (blocks_l >= 512) ? CFG_L : CFG_M;
+        if (blocks_l >= 512) cand[ncand++] = CFG_L;      // the big tile only when it still fills the chip
+        cand[ncand++] = CFG_M; cand[ncand++] = CFG_N;
     }
-    const int cot = kCfg[cfg].cot, npix = kCfg[cfg].npix;
-    const int toh = (npix / 32) * rps;
-    patch_geometry(p, npix, tow_log2, &a.PH, &a.PW, &a.PWp, &a.PWh);
-    a.plane = a.PH * a.PWp;
     const int khkw = p.KH * p.KW;
     const int cin_pad = round_up_i(p.Cin, 2);
-    // channels per chunk: as many pairs as fit the LDS budget, capped so a chunk is ~<=256 k-steps
-    int cic = 2;
-    while (cic + 2 <= cin_pad && (cic + 2) * (a.plane + khkw * cot) + 8 <= kLdsBudgetFloats && (cic + 2) * khkw <= 256) cic += 2;
-    if (cic * (a.plane + khkw * cot) + 8 > 40 * 1024) return false;   // would not fit 160 KiB
-    a.cic = cic;
-    a.xs_floats = round_up_i(cic * a.plane, 4);
-    a.nchunks = cdiv_i(cin_pad, cic);
-    a.tow_log2 = tow_log2;
-    a.tiles_w = cdiv_i(p.OW, tow);
-    const int tiles_h = cdiv_i(p.OH, toh);
-    const int cotiles = cdiv_i(p.Cout, cot);
-    const long long blocks = (long long)a.tiles_w * tiles_h * cotiles * NB;
-    int nsplit = 1;
-    if (force_nsplit > 0) {
-        // exact count requested: trailing splits may own no chunk and then only write zeros (+bias)
-        a.nsplit = force_nsplit;
-        a.chunks_per_split = cdiv_i(a.nchunks, force_nsplit);
-    } else {
-        if (allow_split && blocks < 256 && a.nchunks > 1) {
-            nsplit = (int)cdiv_ll(512, blocks);
-            if (nsplit > a.nchunks) nsplit = a.nchunks;
-            if (nsplit > 64) nsplit = 64;
-            if (nsplit < 1) nsplit = 1;
+    for (int t = 0; t < ncand; ++t) {
+        ConvPlan pl;
+        ConvArgs& a = pl.a;
+        a = ConvArgs{};
+        const int cfg = cand[t];
+        const int cot = kCfg[cfg].cot, npix = kCfg[cfg].npix;
+        const int toh = (npix / 32) * rps;
+        patch_geometry(p, npix, tow_log2, &a.PH, &a.PW, &a.PWp, &a.PWh);
+        a.plane = a.PH * a.PWp;
+        if (a.PW > 32 * kMaxPC) continue;
+        // both operands are double-buffered: 2 * (patch + weights) floats
+        auto fits = [&](int c) {
+            return c <= cin_pad && 2 * (round_up_i(c * a.plane, 4) + c * khkw * cot) <= kLdsBudgetFloats && c * khkw <= 256 &&
+                   c * a.PH <= 8 * kMaxPR;
+        };
+        int cic = 2;
+        while (fits(cic + 2)) cic += 2;
+        if (2 * (round_up_i(cic * a.plane, 4) + cic * khkw * cot) > 40 * 1024) continue;   // would not fit 160 KiB
+        if (cic * a.PH > 8 * kMaxPR) continue;
+        a.cic = cic;
+        a.xs_floats = round_up_i(cic * a.plane, 4);
+        a.nchunks = cdiv_i(cin_pad, cic);
+        a.tow_log2 = tow_log2;
+        a.tiles_w = cdiv_i(p.OW, tow);
+        const int tiles_h = cdiv_i(p.OH, toh);
+        const int cotiles = cdiv_i(p.Cout, cot);
+        const long long blocks = (long long)a.tiles_w * tiles_h * cotiles * NB;
+        int nsplit = 1;
+        if (force_nsplit > 0) {
+            // exact count requested: trailing splits may own no chunk and then only write zeros (+bias)
+            a.nsplit = force_nsplit;
+            a.chunks_per_split = cdiv_i(a.nchunks, force_nsplit);
+        } else {
+            if (allow_split && blocks < 256 && a.nchunks > 1) {
+                nsplit = (int)(512 / blocks);             // one resident round: 2 workgroups per CU x 256 CUs
+                if (nsplit > a.nchunks) nsplit = a.nchunks;
+                if (nsplit > 64) nsplit = 64;
+                if (nsplit < 1) nsplit = 1;
+            }
+            a.chunks_per_split = cdiv_i(a.nchunks, nsplit);
+            a.nsplit = cdiv_i(a.nchunks, a.chunks_per_split);
         }
-        a.chunks_per_split = cdiv_i(a.nchunks, nsplit);
-        a.nsplit = cdiv_i(a.nchunks, a.chunks_per_split);
+        a.Cin = p.Cin; a.H = p.H; a.W = p.W;
+        a.Cout = p.Cout; a.OH = p.OH; a.OW = p.OW;
+        a.KH = p.KH; a.KW = p.KW; a.stride = p.stride; a.pad_h = p.pad_h; a.pad_w = p.pad_w;
+        pl.cfg = cfg;
+        pl.grid = dim3((unsigned)(a.tiles_w * tiles_h), (unsigned)cotiles, (unsigned)(NB * a.nsplit));
+        pl.lds_bytes = (size_t)2 * (a.xs_floats + cic * khkw * cot) * sizeof(float);
+        *out = pl;
+        return true;
     }
-    a.Cin = p.Cin; a.H = p.H; a.W = p.W;
-    a.Cout = p.Cout; a.OH = p.OH; a.OW = p.OW;
-    a.KH = p.KH; a.KW = p.KW; a.stride = p.stride; a.pad_h = p.pad_h; a.pad_w = p.pad_w;
-    pl.cfg = cfg;
-    pl.grid = dim3((unsigned)(a.tiles_w * tiles_h), (unsigned)cotiles, (unsigned)(NB * a.nsplit));
-    pl.lds_bytes = (size_t)(a.xs_floats + cic * khkw * cot) * sizeof(float);
-    *out = pl;
-    return true;
+    return false;
 }
 
 template <int WM, int WN, int BMW, int BNW>
 static hipError_t launch_cfg(const ConvPlan& pl, hipStream_t s)
 {
     auto kern = conv_direct_kernel<WM, WN, BMW, BNW>;
-    if (pl.lds_bytes > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
+    static bool attr_done = false;             // once per instantiation (benign race: idempotent)
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
+        attr_done = true;
     }
+    const ConvArgs& a = pl.a;
+    const int nb = (int)pl.grid.z / a.nsplit;
+    const double px = (double)nb * a.OH * a.OW;
+    TraceScope ts(kCfg[pl.cfg].kind, s, 2.0 * px * a.Cout * a.Cin * a.KH * a.KW,
+                  4.0 * ((double)nb * a.Cin * a.H * a.W + (double)a.Cin * a.KH * a.KW * a.Cout + px * a.Cout * a.nsplit));
     hipLaunchKernelGGL(kern, pl.grid, dim3(256), pl.lds_bytes, s, pl.a);
     return hipGetLastError();
 }
@@ -318,6 +396,7 @@ int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float
         case CFG_M: e = launch_cfg<2, 1, 2, 2>(pl, s); break;
         case CFG_N: e = launch_cfg<1, 2, 2, 2>(pl, s); break;
         case CFG_T: e = launch_cfg<2, 1, 4, 1>(pl, s); break;
+        case CFG_S2: e = launch_cfg<1, 1, 1, 4>(pl, s); break;
         default:    e = launch_cfg<1, 2, 1, 4>(pl, s); break;
     }
     return (int)e;
@@ -329,6 +408,10 @@ int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float
 // Block = nwaves waves; wave t owns task (co group, kh, kw group) = MS x KWT accumulators of
 // 32(co) x 32(ci).  Per pixel chunk the block stages dYs[cot][pitch_a] and Xs[32][PH][PWp] (odd
 // pitches -> conflict-free lane strides) and every wave walks the chunk's pixel pairs.
+// Write-out: accumulators are transposed through LDS 8 output channels at a time so that every
+// output channel's [ci][kh][kw] run (contiguous in OIHW) is written with coalesced stores -- either
+// `dw +=` directly (ksplit == 1, deterministic) or to this K-split's private slab, which
+// wgrad_reduce_kernel then folds into dw (no atomics anywhere).
 template <int MS, int KWT, int MAXT>
 __global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
 {
@@ -337,6 +420,7 @@ __global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
+    const int hw = tid >> 5, nhw = nthreads >> 5;
 
     const int tasks_per_group = a.KH * a.nkwg;
     const int cgrp = wave / tasks_per_group;
@@ -344,17 +428,18 @@ __global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
     const int kh = trem / a.nkwg;
     const int kw0 = (trem - kh * a.nkwg) * KWT;
     const int ms_base = cgrp * MS * 32;
+    const int KHKW = a.KH * a.KW;
 
     const int ci0 = blockIdx.x * 32;
     const int co0 = blockIdx.y * a.cot;
 
     float* As = smem;                           // [cot][pitch_a]
-    float* Xs = smem + a.cot * a.pitch_a;       // [32][plane]
+    float* Xs = smem + a.cot * a.pitch_a;       // [nci][plane]
 
     int lane_off, lane_ci, lane_kw;
     bool lane_ok;
     if (a.lane_mode == 0) {
-        lane_ci = ci0 + l31; lane_kw = 0; lane_ok = lane_ci < a.Cin;
+        lane_ci = l31; lane_kw = 0; lane_ok = (ci0 + l31) < a.Cin;
         lane_off = l31 * a.plane;
     } else {
         lane_ci = l31 / a.KW; lane_kw = l31 - lane_ci * a.KW; lane_ok = lane_ci < a.Cin;
@@ -373,7 +458,9 @@ __global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
     const int tiles = a.tiles_h * a.tiles_w;
     const int items = a.NB * tiles;
     const int nci = (a.lane_mode == 0) ? 32 : a.Cin;
+    const int ci_base = (a.lane_mode == 0) ? ci0 : 0;
     const int tw2 = a.tow >> 1;
+    const int rows_a = a.cot * a.toh, rows_x = nci * a.PH;
 
     for (int item = blockIdx.z; item < items; item += a.ksplit) {
         const int n = item / tiles;
@@ -382,35 +469,36 @@ __global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
         const int oh0 = ty * a.toh, ow0 = tx * a.tow;
         const int ih0 = oh0 * a.stride - a.pad_h, iw0 = ow0 * a.stride - a.pad_w;
         __syncthreads();
-        // stage dY chunk: As[co][r*tow + c]
+        // stage dY chunk rows (co, r): tow <= 32 contiguous floats each, one half-wave per row
         {
-            const int per_co = a.toh * a.tow;
-            const int total = a.cot * per_co;
             const float* dyn = a.dy + (long long)n * a.dy_sb;
-            for (int idx = tid; idx < total; idx += nthreads) {
-                const int co = idx / per_co;
-                const int rem = idx - co * per_co;
-                const int r = rem / a.tow, c = rem - r * a.tow;
-                const int oh = oh0 + r, ow = ow0 + c, cg = co0 + co;
+            const int ow = ow0 + l31;
+            const bool cok = (l31 < a.tow) && (ow < a.OW);
+#pragma unroll 4
+            for (int row = hw; row < rows_a; row += nhw) {
+                const int co = row / a.toh, r = row - co * a.toh;
+                const int oh = oh0 + r, cg = co0 + co;
                 float v = 0.f;
-                if (cg < a.Cout && oh < a.OH && ow < a.OW) v = dyn[(long long)cg * a.dy_sc + (long long)oh * a.dy_sh + ow];
-                As[co * a.pitch_a + rem] = v;
+                if (cok && cg < a.Cout && oh < a.OH) v = dyn[(long long)cg * a.dy_sc + (long long)oh * a.dy_sh + ow];
+                if (l31 < a.tow) As[co * a.pitch_a + r * a.tow + l31] = v;
             }
         }
-        // stage X patch: Xs[ci][r][c]
+        // stage X patch rows (ci, r): PW floats each
         {
-            const int per_ci = a.PH * a.PW;
-            const int total = nci * per_ci;
             const float* xn = a.x + (long long)n * a.x_sb;
-            for (int idx = tid; idx < total; idx += nthreads) {
-                const int ci = idx / per_ci;
-                const int rem = idx - ci * per_ci;
-                const int r = rem / a.PW, c = rem - r * a.PW;
-                const int ih = ih0 + r, iw = iw0 + c;
-                const int cg = ((a.lane_mode == 0) ? ci0 : 0) + ci;
-                float v = 0.f;
-                if (cg < a.Cin && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = xn[(long long)cg * a.x_sc + (long long)ih * a.x_sh + iw];
-                Xs[ci * a.plane + r * a.PWp + c] = v;
+#pragma unroll 2
+            for (int row = hw; row < rows_x; row += nhw) {
+                const int ci = row / a.PH, r = row - ci * a.PH;
+                const int ih = ih0 + r, cg = ci_base + ci;
+                const bool rok = (cg < a.Cin) && (ih >= 0) && (ih < a.H);
+                const float* src = xn + (long long)cg * a.x_sc + (long long)ih * a.x_sh;
+                float* dst = Xs + ci * a.plane + r * a.PWp;
+                for (int c = l31; c < a.PW; c += 32) {
+                    const int iw = iw0 + c;
+                    float v = 0.f;
+                    if (rok && iw >= 0 && iw < a.W) v = src[iw];
+                    dst[c] = v;
+                }
             }
         }
         __syncthreads();
@@ -432,23 +520,71 @@ __global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
         }
     }
 
-    // write-out: dW[co][ci][kh][kw]
+    // ---- write-out through LDS: per pass 8 output channels x [nci][KH][KW] per co-group
+    int nci_valid = a.Cin - ci_base; if (nci_valid > nci) nci_valid = nci;
+    const int RL = nci * KHKW;                  // LDS row pitch
+    const int RLv = nci_valid * KHKW;           // valid (contiguous in OIHW) run per output channel
+    const int ngroups = a.cot / (MS * 32);
+    float* out = (a.ksplit > 1) ? (a.slabs + (long long)blockIdx.z * a.slab_stride) : a.dw;
+    float* Tt = smem;
 #pragma unroll
     for (int i = 0; i < MS; ++i) {
 #pragma unroll
-        for (int t2 = 0; t2 < KWT; ++t2) {
-            const int kw = (a.lane_mode == 0) ? (kw0 + t2) : lane_kw;
+        for (int q = 0; q < 4; ++q) {
+            __syncthreads();
+            if (lane_ok) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + ms_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (lane_ok && co < a.Cout && (ms_base + i * 32) < a.cot && kw < a.KW) {
-                    const long long idx = (((long long)co * a.Cin + lane_ci) * a.KH + kh) * a.KW + kw;
-                    const float v = acc[i][t2][r];
-                    if (a.atomic) atomicAdd(a.dw + idx, v);
-                    else a.dw[idx] += v;
+                for (int t2 = 0; t2 < KWT; ++t2) {
+                    const int kw = (a.lane_mode == 0) ? (kw0 + t2) : lane_kw;
+                    if (kw < a.KW) {
+                        const int e = lane_ci * KHKW + kh * a.KW + kw;
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) Tt[(cgrp * 8 + rr + 4 * half) * RL + e] = acc[i][t2][4 * q + rr];
+                    }
+                }
+            }
+            __syncthreads();
+            const int total = ngroups * 8 * RLv;
+            for (int idx = tid; idx < total; idx += nthreads) {
+                const int grow = idx / RLv, e = idx - grow * RLv;       // grow = g*8 + row
+                const int g = grow >> 3, row = grow & 7;
+                const int co = co0 + g * (MS * 32) + i * 32 + q * 8 + row;
+                if (co < a.Cout) {
+                    const long long o = ((long long)co * a.Cin + ci_base) * KHKW + e;
+                    const float v = Tt[grow * RL + e];
+                    if (a.ksplit > 1) out[o] = v; else out[o] += v;
                 }
             }
         }
+    }
+}
+
+// dw[i] += sum_z slabs[z][i]   (slab z starts at z*stride; stride % 4 == 0; vec: dw is 16-byte aligned)
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slabs, long long n,
+                                                           long long stride, int ksplit, int vec)
+{
+    if (!vec) {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+            float acc = dw[i];
+            for (int z = 0; z < ksplit; ++z) acc += slabs[(long long)z * stride + i];
+            dw[i] = acc;
+        }
+        return;
+    }
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 acc = reinterpret_cast<float4*>(dw)[i];
+        for (int z = 0; z < ksplit; ++z) {
+            const float4 v = reinterpret_cast<const float4*>(slabs + (long long)z * stride)[i];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4*>(dw)[i] = acc;
+    }
+    const long long t = (n4 << 2) + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && t < n) {
+        float acc = dw[t];
+        for (int z = 0; z < ksplit; ++z) acc += slabs[(long long)z * stride + t];
+        dw[t] = acc;
     }
 }
 
@@ -458,46 +594,53 @@ static hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, int nwaves, size_t
 {
     if (64 * nwaves > MAXT) return hipErrorInvalidValue;
     auto kern = conv_wgrad_kernel<MS, KWT, MAXT>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
+        attr_done = true;
     }
+    const int kind = (MS == 2 && KWT == 5) ? K_WGRAD_2x5 : (MS == 1 && KWT == 5) ? K_WGRAD_1x5 : (MS == 2 && KWT == 3) ? K_WGRAD_2x3
+                   : (MS == 1 && KWT == 3) ? K_WGRAD_1x3 : (MS == 4) ? K_WGRAD_4x1 : K_WGRAD_1x1;
+    const double px = (double)a.NB * a.OH * a.OW;
+    TraceScope ts(kind, s, 2.0 * px * a.Cout * a.Cin * a.KH * a.KW,
+                  4.0 * ((double)a.NB * a.Cin * a.H * a.W + px * a.Cout + (double)a.Cout * a.Cin * a.KH * a.KW * (a.ksplit > 1 ? a.ksplit : 2)));
     hipLaunchKernelGGL(kern, grid, dim3(64 * nwaves), lds, s, a);
     return hipGetLastError();
 }
-}  // namespace
 
-int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, hipStream_t s)
+struct WgradPlan { WgradArgs a; dim3 grid; int MS, KWT, nwaves; size_t lds; };
+
+static bool plan_wgrad(const ConvProblem& p, int NB, long long slab_cap_floats, WgradPlan* out)
 {
-    WgradArgs a{};
-    a.x = io.x; a.x_sb = io.x_sb; a.x_sc = io.x_sc; a.x_sh = io.x_sh;
-    a.dy = io.dy; a.dy_sb = io.dy_sb; a.dy_sc = io.dy_sc; a.dy_sh = io.dy_sh;
-    a.dw = dw;
+    WgradPlan pl{};
+    WgradArgs& a = pl.a;
     a.NB = NB; a.Cin = p.Cin; a.H = p.H; a.W = p.W; a.Cout = p.Cout; a.OH = p.OH; a.OW = p.OW;
     a.KH = p.KH; a.KW = p.KW; a.stride = p.stride; a.pad_h = p.pad_h; a.pad_w = p.pad_w;
-
-    // ---- choose the lane mapping and the per-wave task shape
+    a.dw_floats = (long long)p.Cout * p.Cin * p.KH * p.KW;
+    a.slab_stride = (a.dw_floats + 3) & ~3LL;
     int MS, KWT;
     a.lane_mode = (p.Cin * p.KW <= 32 && p.Cin <= 4) ? 1 : 0;
     if (a.lane_mode == 1) { MS = (p.Cout >= 128) ? 4 : 1; KWT = 1; a.nkwg = 1; }
     else if (p.KW % 5 == 0) { KWT = 5; a.nkwg = p.KW / 5; MS = (p.Cout >= 64) ? 2 : 1; }
     else if (p.KW == 3) { KWT = 3; a.nkwg = 1; MS = (p.Cout >= 64) ? 2 : 1; }
     else if (p.KW == 1) { KWT = 1; a.nkwg = 1; MS = (p.Cout >= 128) ? 4 : 1; }
-    else return MCVC_ERR_INVALID;
+    else return false;
     const int tasks = p.KH * a.nkwg;
-    if (tasks > 16) return MCVC_ERR_INVALID;
-    // waves per block: co groups so that 4 <= nwaves <= 16 where possible
+    if (tasks > 16) return false;
     int groups = 1;
     const int max_groups = cdiv_i(p.Cout, 32 * MS);
-    while (groups * 2 * tasks <= 8 && groups * 2 <= max_groups && groups * 2 * MS * 32 <= 512) groups *= 2;
-    const int nwaves = groups * tasks;
+    while (groups * 2 * tasks <= 8 && groups * 2 <= max_groups && groups * 2 * MS * 32 <= 256) groups *= 2;
+    pl.nwaves = groups * tasks;
+    pl.MS = MS; pl.KWT = KWT;
     a.cot = groups * MS * 32;
 
-    // ---- pixel chunk geometry (LDS budget 60 KiB)
     int tow = 32;
     while (tow > 2 && tow / 2 >= p.OW) tow /= 2;      // smallest power of two >= OW, capped at 32
     a.tow = tow;
     const int nci = (a.lane_mode == 0) ? 32 : p.Cin;
+    const int khkw = p.KH * p.KW;
+    const int tfloats = groups * 8 * nci * khkw;      // write-out transpose tile
     int toh = 1;
     for (int cand = 1; cand <= p.OH && cand <= 16; ++cand) {
         const int PH = (cand - 1) * p.stride + p.KH, PW = (tow - 1) * p.stride + p.KW;
@@ -513,26 +656,64 @@ int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw
     a.pitch_a = (toh * tow) | 1;
     a.tiles_h = cdiv_i(p.OH, toh);
     a.tiles_w = cdiv_i(p.OW, tow);
-    const size_t lds = (size_t)(a.cot * a.pitch_a + nci * a.plane + 64) * sizeof(float);
-    if (lds > 160 * 1024) return MCVC_ERR_INVALID;
+    int lds_floats = a.cot * a.pitch_a + nci * a.plane + 64;
+    if (tfloats > lds_floats) lds_floats = tfloats;
+    pl.lds = (size_t)lds_floats * sizeof(float);
+    if (pl.lds > 160 * 1024) return false;
 
     const int ci_tiles = (a.lane_mode == 0) ? cdiv_i(p.Cin, 32) : 1;
     const int co_tiles = cdiv_i(p.Cout, a.cot);
     const int items = NB * a.tiles_h * a.tiles_w;
+    const int waves = ci_tiles * co_tiles * pl.nwaves;
     int ksplit = 1;
-    const int blocks = ci_tiles * co_tiles;
-    if (blocks < 256) ksplit = cdiv_i(512, blocks);
+    if (waves < 1024) ksplit = cdiv_i(1536, waves);   // ~1.5 waves per SIMD chip-wide
     if (ksplit > items) ksplit = items;
+    if (ksplit > 1) {
+        long long cap = slab_cap_floats / a.slab_stride;
+        if (cap > 32) cap = 32;
+        if (ksplit > cap) ksplit = (int)cap;
+        if (ksplit < 2) ksplit = 1;
+    }
     a.ksplit = ksplit;
-    a.atomic = ksplit > 1;
-    dim3 grid((unsigned)ci_tiles, (unsigned)co_tiles, (unsigned)ksplit);
+    pl.grid = dim3((unsigned)ci_tiles, (unsigned)co_tiles, (unsigned)ksplit);
+    *out = pl;
+    return true;
+}
+}  // namespace
+
+long long mcvc_wgrad_plan_slab_floats(const ConvProblem& p, int NB)
+{
+    WgradPlan pl;
+    if (!plan_wgrad(p, NB, 1LL << 40, &pl)) return -1;
+    return pl.a.ksplit > 1 ? (long long)pl.a.ksplit * pl.a.slab_stride : 0;
+}
+
+int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, float* slabs, long long slab_cap_floats, hipStream_t s)
+{
+    WgradPlan pl;
+    if (!plan_wgrad(p, NB, slabs ? slab_cap_floats : 0, &pl)) return MCVC_ERR_INVALID;
+    WgradArgs& a = pl.a;
+    a.x = io.x; a.x_sb = io.x_sb; a.x_sc = io.x_sc; a.x_sh = io.x_sh;
+    a.dy = io.dy; a.dy_sb = io.dy_sb; a.dy_sc = io.dy_sc; a.dy_sh = io.dy_sh;
+    a.dw = dw; a.slabs = slabs;
     hipError_t e;
+    const int MS = pl.MS, KWT = pl.KWT;
     // MAXT bounds the register allocator: 512 threads -> up to 256 VGPRs (accumulator-heavy shapes)
-    if (MS == 2 && KWT == 5) e = launch_wgrad<2, 5, 512>(a, grid, nwaves, lds, s);
-    else if (MS == 1 && KWT == 5) e = launch_wgrad<1, 5, 1024>(a, grid, nwaves, lds, s);
-    else if (MS == 2 && KWT == 3) e = launch_wgrad<2, 3, 512>(a, grid, nwaves, lds, s);
-    else if (MS == 1 && KWT == 3) e = launch_wgrad<1, 3, 1024>(a, grid, nwaves, lds, s);
-    else if (MS == 4 && KWT == 1) e = launch_wgrad<4, 1, 512>(a, grid, nwaves, lds, s);
-    else e = launch_wgrad<1, 1, 1024>(a, grid, nwaves, lds, s);
+    if (MS == 2 && KWT == 5) e = launch_wgrad<2, 5, 512>(a, pl.grid, pl.nwaves, pl.lds, s);
+    else if (MS == 1 && KWT == 5) e = launch_wgrad<1, 5, 1024>(a, pl.grid, pl.nwaves, pl.lds, s);
+    else if (MS == 2 && KWT == 3) e = launch_wgrad<2, 3, 512>(a, pl.grid, pl.nwaves, pl.lds, s);
+    else if (MS == 1 && KWT == 3) e = launch_wgrad<1, 3, 1024>(a, pl.grid, pl.nwaves, pl.lds, s);
+    else if (MS == 4 && KWT == 1) e = launch_wgrad<4, 1, 512>(a, pl.grid, pl.nwaves, pl.lds, s);
+    else e = launch_wgrad<1, 1, 1024>(a, pl.grid, pl.nwaves, pl.lds, s);
+    if (e != hipSuccess) return (int)e;
+    if (a.ksplit > 1) {
+        long long b = cdiv_ll(a.dw_floats >> 2, 256);
+        if (b > 2048) b = 2048;
+        if (b < 1) b = 1;
+        TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (double)a.dw_floats * (a.ksplit + 2));
+        const int vec = (((uintptr_t)dw | (uintptr_t)slabs) & 15) == 0;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, s, dw, slabs, a.dw_floats, a.slab_stride, a.ksplit, vec);
+        e = hipGetLastError();
+    }
     return (int)e;
 }

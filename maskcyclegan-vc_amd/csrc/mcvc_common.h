@@ -65,6 +65,8 @@ struct WgradArgs {
     const float* x;
     const float* dy;
     float* dw;
+    float* slabs;          // ksplit private partial-dW slabs (ksplit > 1)
+    long long dw_floats, slab_stride;
     long long x_sb, x_sc;
     long long dy_sb, dy_sc;
     int x_sh, dy_sh;
@@ -76,7 +78,6 @@ struct WgradArgs {
     int lane_mode;         // 0: N lane = ci ; 1: N lane = ci*KW + kw  (Cin*KW <= 32)
     int nkwg;              // kw groups per kh (lane_mode 0)
     int cot;               // output channels per block
-    int atomic;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -167,7 +168,9 @@ struct WgradIO {
     const float* x; long long x_sb, x_sc; int x_sh;
     const float* dy; long long dy_sb, dy_sc; int dy_sh;
 };
-int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, hipStream_t s);
+int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, float* slabs, long long slab_cap_floats, hipStream_t s);
+// scratch floats the K-split of this weight gradient wants (0 = no split)
+long long mcvc_wgrad_plan_slab_floats(const ConvProblem& p, int NB);
 
 int mcvc_norm_fwd_launch(const NormArgs& a, hipStream_t s);
 int mcvc_norm_bwd_launch(const NormBwdArgs& a, hipStream_t s);

@@ -5,6 +5,7 @@
 // LSGAN means); train.py:119-122, 242, 299 (torch.optim.Adam, betas (0.5, 0.999), eps 1e-8).
 #include "mcvc_common.h"
 #include "misc.h"
+#include "trace.h"
 
 namespace {
 
@@ -169,6 +170,7 @@ static unsigned ew_blocks(long long total, int bs)
 
 int mcvc_prep_input_launch(const float* x, const float* mask, float* xin, int N, int P, hipStream_t s)
 {
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 16.0 * N * P);
     hipLaunchKernelGGL(prep_input_kernel, dim3(ew_blocks((long long)N * P, 256)), dim3(256), 0, s, x, mask, xin, N, P);
     return (int)hipGetLastError();
 }
@@ -176,12 +178,14 @@ int mcvc_prep_input_launch(const float* x, const float* mask, float* xin, int N,
 int mcvc_mask_grad_launch(const float* dxin, const float* slabs, long long slab_stride, int nslab, const float* mask, float* dx,
                           int N, int P, int C, int accumulate, hipStream_t s)
 {
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * N * P * (nslab + 2));
     hipLaunchKernelGGL(mask_grad_kernel, dim3(ew_blocks((long long)N * P, 256)), dim3(256), 0, s, dxin, slabs, slab_stride, nslab, mask, dx, N, P, C, accumulate);
     return (int)hipGetLastError();
 }
 
 int mcvc_bias_grad_launch(const float* dy, long long sn, long long sc, int N, int C, int P, float* db, hipStream_t s)
 {
+    TraceScope ts(K_BIAS_GRAD, s, 0.0, 4.0 * (double)N * C * P);
     hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)C), dim3(256), 0, s, dy, sn, sc, N, P, db);
     return (int)hipGetLastError();
 }
@@ -189,6 +193,7 @@ int mcvc_bias_grad_launch(const float* dy, long long sn, long long sc, int N, in
 int mcvc_l1_loss_launch(const float* a, const float* b, long long n, float weight, float* loss_slot, float* term_slot,
                         float* grad_a, int accumulate, hipStream_t s)
 {
+    TraceScope ts(K_LOSS, s, 0.0, 12.0 * n);
     hipLaunchKernelGGL(l1_loss_kernel, dim3(1), dim3(1024), 0, s, a, b, n, weight, loss_slot, term_slot, grad_a, accumulate);
     return (int)hipGetLastError();
 }
@@ -196,6 +201,7 @@ int mcvc_l1_loss_launch(const float* a, const float* b, long long n, float weigh
 int mcvc_lsgan_loss_launch(const float* d, long long n, float target, float weight, float* loss_slot, float* term_slot,
                            float* grad_logit, hipStream_t s)
 {
+    TraceScope ts(K_LOSS, s, 0.0, 8.0 * n);
     hipLaunchKernelGGL(lsgan_loss_kernel, dim3(1), dim3(1024), 0, s, d, n, target, weight, loss_slot, term_slot, grad_logit);
     return (int)hipGetLastError();
 }
@@ -204,14 +210,17 @@ int mcvc_adam_launch(float* p, const float* g, float* m, float* v, long long n, 
                      int step, float grad_scale, hipStream_t s)
 {
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return MCVC_ERR_INVALID;
-    const float bc1 = 1.0f - powf(b1, (float)step);
+    // bias corrections in double like torch.optim.Adam's python scalars, then rounded once
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
     const double bc2 = 1.0 - pow((double)b2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n >> 2, 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps, bc1, (float)sqrt(bc2), grad_scale);
+    TraceScope ts(K_ADAM, s, 0.0, 28.0 * n);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n >> 2, 256)), dim3(256), 0, s, p, g, m, v, n, (float)((double)lr / bc1), b1, b2, eps, 1.0f, (float)sqrt(bc2), grad_scale);
     return (int)hipGetLastError();
 }
 
 int mcvc_axpy_launch(float* y, const float* x, float alpha, long long n, hipStream_t s)
 {
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 12.0 * n);
     hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n, 256)), dim3(256), 0, s, y, x, alpha, n);
     return (int)hipGetLastError();
 }

@@ -56,7 +56,7 @@ static void spec_finalize(ConvSpec& c, long long& cur)
     c.cout_pk = round_up_i(c.cout_tot, 32);
     c.cin_pad = round_up_i(c.Cin, 2);
     c.w_rows = c.cin_pad * c.KH * c.KW;
-    c.off_fwd = cur; cur += (long long)c.w_rows * c.cout_pk;
+    c.off_fwd = cur; cur += (long long)(c.w_rows + 1) * c.cout_pk;      // + one all-zero pad row (DMA target for k >= K)
     c.off_bias = cur; cur += c.cout_pk;
     c.cin_pk = round_up_i(c.Cin, 32);
     c.dg_rows_co = round_up_i(c.cout_tot, 2);
@@ -76,7 +76,7 @@ static void spec_finalize(ConvSpec& c, long long& cur)
             k.pad_w = (k.kwmax - qw - c.pw) / st;
             k.qh = qh; k.qw = qw;
             k.offset = cur - c.off_dgrad;
-            cur += (long long)c.dg_rows_co * k.nth * k.ntw * c.cin_pk;
+            cur += ((long long)c.dg_rows_co * k.nth * k.ntw + 1) * c.cin_pk;   // + zero pad row
             c.cls[c.ncls++] = k;
         }
     }
@@ -166,14 +166,19 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
 
 static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB, int H, int W, CView x, CView dy)
 {
-    if (ex.dry || !grads) return;
     const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
     ConvProblem p{c.Cin, H, W, c.Cout, OH, OW, c.KH, c.KW, c.stride, c.ph, c.pw};
+    if (ex.dry) {          // the K-split slabs share the conv slab scratch (never live at the same time)
+        const long long need = mcvc_wgrad_plan_slab_floats(p, NB);
+        if (need > ex.slab_need) ex.slab_need = need;
+        return;
+    }
+    if (!grads) return;
     for (int br = 0; br < c.nbr; ++br) {
         float* dw = grads[c.wi[br]];
         if (!dw) continue;
         WgradIO io{x.p, x.sb, x.sc, x.sh, dy.p + (long long)br * c.Cout * dy.sc, dy.sb, dy.sc, dy.sh};
-        ex.fail(mcvc_wgrad_launch(p, NB, io, dw, ex.s));
+        ex.fail(mcvc_wgrad_launch(p, NB, io, dw, ex.slabs, ex.slab_cap, ex.s));
     }
 }
 
@@ -792,11 +797,11 @@ static ConvSpec single_spec(int Cout, int Cin, int KH, int KW, int stride, int p
 
 long long mcvc_conv2d_pack_floats(int Cout, int Cin, int KH, int KW)
 {
-    // stride-2 classes partition the taps, so the stride-1 layout is the upper bound
+    // stride-2 classes partition the taps (same rows in total) but each class carries its own zero pad row
     ConvSpec c = mk(Cin, Cout, 1, KH, KW, 1, 0, 0, 0, 1, -1, -1, 1);
     long long cur = 0;
     spec_finalize(c, cur);
-    return cur + 64;
+    return cur + 4LL * c.cin_pk + 64;
 }
 
 int mcvc_conv2d_forward(const float* x, const float* w, const float* bias, float* y, float* wpack, float* slabs, int max_slabs,
@@ -845,13 +850,20 @@ int mcvc_conv2d_dgrad(const float* dy, const float* w, float* dx, float* wpack, 
     return ex.err;
 }
 
-int mcvc_conv2d_wgrad(const float* x, const float* dy, float* dw, int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride,
-                      int pad_h, int pad_w, void* stream)
+long long mcvc_conv2d_wgrad_slab_floats(int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_h, int pad_w)
+{
+    const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
+    ConvProblem p{Cin, H, W, Cout, OH, OW, KH, KW, stride, pad_h, pad_w};
+    return mcvc_wgrad_plan_slab_floats(p, N);
+}
+
+int mcvc_conv2d_wgrad(const float* x, const float* dy, float* dw, float* slabs, long long slab_floats, int N, int Cin, int H, int W, int Cout,
+                      int KH, int KW, int stride, int pad_h, int pad_w, void* stream)
 {
     const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
     ConvProblem p{Cin, H, W, Cout, OH, OW, KH, KW, stride, pad_h, pad_w};
     WgradIO io{x, (long long)Cin * H * W, (long long)H * W, W, dy, (long long)Cout * OH * OW, (long long)OH * OW, OW};
-    return mcvc_wgrad_launch(p, N, io, dw, (hipStream_t)stream);
+    return mcvc_wgrad_launch(p, N, io, dw, slabs, slab_floats, (hipStream_t)stream);
 }
 
 int mcvc_instnorm_act_forward(float* x, const float* gamma, const float* beta, const float* gamma_gate, const float* beta_gate,

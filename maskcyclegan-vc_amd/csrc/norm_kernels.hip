@@ -11,6 +11,7 @@
 // would lose the parity budget.  Split-K partial slabs written by the conv kernel are summed here
 // (the "launch-boundary reduce"), so the conv never needs atomics for its K split.
 #include "mcvc_common.h"
+#include "trace.h"
 
 namespace {
 
@@ -267,6 +268,8 @@ int mcvc_norm_fwd_launch(const NormArgs& a, hipStream_t s)
     const long long planes = (long long)a.N * a.C;
     const int G = pick_group(P);
     const unsigned blocks = (unsigned)cdiv_ll(planes, 256 / G);
+    const double el = (double)planes * P * (a.act == ACT_GLU ? 2 : 1);
+    TraceScope ts(K_NORM_FWD, s, 0.0, 4.0 * (el * (a.nslab + 1) + (double)planes * P));
     if (G == 16) hipLaunchKernelGGL(norm_fwd_kernel<16>, dim3(blocks), dim3(256), 0, s, a);
     else if (G == 64) hipLaunchKernelGGL(norm_fwd_kernel<64>, dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(norm_fwd_kernel<256>, dim3(blocks), dim3(256), 0, s, a);
@@ -278,6 +281,8 @@ int mcvc_norm_bwd_launch(const NormBwdArgs& a, hipStream_t s)
     const int P = a.H * a.W;
     const int G = pick_group(P);
     const unsigned blocks = (unsigned)cdiv_i(a.C, 256 / G);
+    const double el = (double)a.N * a.C * P;
+    TraceScope ts(K_NORM_BWD, s, 0.0, 4.0 * el * ((a.act == ACT_GLU ? 4 : 2) + a.nslab));
     if (G == 16) hipLaunchKernelGGL(norm_bwd_kernel<16>, dim3(blocks), dim3(256), 0, s, a);
     else if (G == 64) hipLaunchKernelGGL(norm_bwd_kernel<64>, dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(norm_bwd_kernel<256>, dim3(blocks), dim3(256), 0, s, a);
@@ -294,12 +299,14 @@ static unsigned ew_blocks(long long total)
 
 int mcvc_act_fwd_launch(const ActArgs& a, hipStream_t s)
 {
+    TraceScope ts(K_ACT_FWD, s, 0.0, 4.0 * (double)a.N * a.C * a.P * ((a.act == ACT_GLU ? 2 : 1) * a.nslab + 1));
     hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks((long long)a.N * a.C * a.P)), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
 int mcvc_act_bwd_launch(const ActBwdArgs& a, hipStream_t s)
 {
+    TraceScope ts(K_ACT_BWD, s, 0.0, 4.0 * (double)a.N * a.C * a.P * ((a.act == ACT_GLU ? 4 : 2) + a.nslab));
     hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks((long long)a.N * a.C * a.P)), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }

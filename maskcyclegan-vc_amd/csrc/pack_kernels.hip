@@ -12,6 +12,7 @@
 // channel/row padding stays zero.
 #include "mcvc_common.h"
 #include "pack.h"
+#include "trace.h"
 
 // [R=Cout][K] -> dst[k*ld + co_off + co], 32x32 LDS tiles, both sides coalesced
 __global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ dst,
@@ -62,6 +63,7 @@ __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ d
 int mcvc_pack_fwd_launch(const float* w, float* dst, int Cout, int K, int ld, int co_off, hipStream_t s)
 {
     dim3 grid((unsigned)cdiv_i(K, 32), (unsigned)cdiv_i(Cout, 32));
+    TraceScope ts(K_PACK, s, 0.0, 8.0 * (double)Cout * K);
     hipLaunchKernelGGL(pack_fwd_kernel, grid, dim3(256), 0, s, w, dst, Cout, K, ld, co_off);
     return (int)hipGetLastError();
 }
@@ -70,12 +72,14 @@ int mcvc_pack_dgrad_launch(const float* w, float* dst, const PackDgradArgs& a, i
 {
     dim3 grid((unsigned)cdiv_i(a.Cin, 32), (unsigned)Cout);
     const size_t lds = (size_t)32 * a.KH * a.KW * sizeof(float);
+    TraceScope ts(K_PACK, s, 0.0, 8.0 * (double)Cout * a.Cin * a.KH * a.KW);
     hipLaunchKernelGGL(pack_dgrad_kernel, grid, dim3(256), lds, s, w, dst, a);
     return (int)hipGetLastError();
 }
 
 int mcvc_copy_launch(const float* src, float* dst, int n, hipStream_t s)
 {
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 8.0 * n);
     hipLaunchKernelGGL(copy_kernel, dim3((unsigned)cdiv_i(n, 256)), dim3(256), 0, s, src, dst, n);
     return (int)hipGetLastError();
 }

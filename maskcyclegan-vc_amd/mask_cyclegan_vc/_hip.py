@@ -46,7 +46,8 @@ _SIGS = {
     "mcvc_conv2d_pack_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "mcvc_conv2d_forward": (c_int, [c_void_p] * 6 + [c_int] * 12 + [c_void_p]),
     "mcvc_conv2d_dgrad": (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p]),
-    "mcvc_conv2d_wgrad": (c_int, [c_void_p] * 3 + [c_int] * 10 + [c_void_p]),
+    "mcvc_conv2d_wgrad_slab_floats": (c_longlong, [c_int] * 10),
+    "mcvc_conv2d_wgrad": (c_int, [c_void_p] * 4 + [c_longlong] + [c_int] * 10 + [c_void_p]),
     "mcvc_instnorm_act_forward": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
     "mcvc_instnorm_act_backward": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p]),
     "mcvc_bias_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -54,6 +55,11 @@ _SIGS = {
     "mcvc_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mcvc_fif_input": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mcvc_fif_input_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mcvc_trace_enable": (c_int, [c_int]),
+    "mcvc_trace_kinds": (c_int, []),
+    "mcvc_trace_kind_name": (ctypes.c_char_p, [c_int]),
+    "mcvc_trace_collect": (c_int, [ctypes.POINTER(ctypes.c_double)]),
+    "mcvc_trace_collect_raw": (c_int, [ctypes.POINTER(ctypes.c_double), c_int]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

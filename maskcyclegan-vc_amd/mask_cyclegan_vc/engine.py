@@ -1,0 +1,291 @@
+"""Hand-scheduled MaskCycleGAN-VC training step on the HIP library (the product's fast path).
+
+Semantics = reference ``MaskCycleGANVCTraining.train()`` inner loop (train.py:195-299): 6 generator
+and 4 discriminator forwards + backward + Adam(G), then 4+8 discriminator forwards on real /
+generated data (generators run with their *updated* weights) + backward + Adam(D).
+
+What differs from running the reference loop on autograd -- all mathematically invisible:
+  * no autograd graph: the step's dataflow is fixed, so forward/backward library calls are issued
+    directly in dependency order with pre-allocated buffers (graph-capturable, no allocation);
+  * work whose result the reference throws away is not computed: discriminator weight gradients in
+    the generator phase (zeroed by ``reset_grad`` at train.py:297 before use) and the backward
+    through the generators in the discriminator phase (zeroed at :240 of the next iteration);
+  * parameters, gradients and Adam moments live in flat buffers (generator: both nets; discriminator:
+    the live tensors of all four nets -- ``downSample4`` never receives a gradient, so like
+    torch.optim.Adam we never touch it), giving one Adam launch and one all-reduce per phase.
+The modules' ``nn.Parameter``s are re-pointed at views of the flat buffers, so ``state_dict()``,
+checkpoints and the autograd API keep working on the same storage.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _hip
+from ._hip import check, lib, ptr, ptr_table, stream
+from .parallel import FlatGradReducer
+from .schedule import StepSchedule
+
+G_NAMES = ("generator_A2B", "generator_B2A")
+D_NAMES = ("discriminator_A", "discriminator_B", "discriminator_A2", "discriminator_B2")
+_DEAD = range(14, 18)          # discriminator downSample4.* slots in named_parameters() order
+
+# loss slots (device float32[16])
+SLOT_G, SLOT_D, SLOT_CYCLE, SLOT_IDENT, SLOT_ADV_G, SLOT_D_REAL, SLOT_D_FAKE = range(7)
+
+
+def _align4(n):
+    return (n + 3) & ~3
+
+
+class _FlatGroup:
+    """Parameters of several modules re-homed into one flat buffer (+ gradient and Adam buffers)."""
+
+    def __init__(self, param_lists, device):
+        sizes = [[p.numel() for p in ps] for ps in param_lists]
+        total = sum(_align4(n) for ss in sizes for n in ss)
+        self.flat = torch.zeros(total, device=device)
+        self.grad = torch.zeros(total, device=device)
+        self.exp_avg = torch.zeros(total, device=device)
+        self.exp_avg_sq = torch.zeros(total, device=device)
+        self.step = 0
+        self.views, self.grad_views = [], []
+        off = 0
+        for ps in param_lists:
+            vs, gs = [], []
+            for p in ps:
+                n = p.numel()
+                v = self.flat[off:off + n].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                g = self.grad[off:off + n].view(p.shape)
+                p.grad = g
+                vs.append(v); gs.append(g)
+                off += _align4(n)
+            self.views.append(vs); self.grad_views.append(gs)
+        self.numel = total
+
+
+class TrainEngine:
+    def __init__(self, nets, batch_size, n_frames=64, schedule: StepSchedule | None = None, reducer: FlatGradReducer | None = None,
+                 betas=(0.5, 0.999), eps=1e-8):
+        self.nets = nets
+        dev = next(nets[G_NAMES[0]].parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("TrainEngine needs the networks on a HIP device (no CPU path)")
+        self.device = dev
+        self.B, self.T = batch_size, n_frames
+        self.sched = schedule or StepSchedule(batch_size=batch_size)
+        self.reducer = reducer or FlatGradReducer()
+        self.betas, self.eps = betas, eps
+        L = self.L = lib()
+        B, T = self.B, self.T
+        # ---- flat parameter groups
+        g_lists = [list(nets[n].parameters()) for n in G_NAMES]
+        d_all = [list(nets[n].parameters()) for n in D_NAMES]
+        d_live = [[p for i, p in enumerate(ps) if i not in _DEAD] for ps in d_all]
+        self.g_group = _FlatGroup(g_lists, dev)
+        self.d_group = _FlatGroup(d_live, dev)
+        self._p_tab, self._g_tab = {}, {}
+        for n, ps, gv in zip(G_NAMES, g_lists, self.g_group.grad_views):
+            self._p_tab[n] = ptr_table(ps)
+            self._g_tab[n] = ptr_table(gv)
+        for n, ps, gv in zip(D_NAMES, d_all, self.d_group.grad_views):
+            self._p_tab[n] = ptr_table(ps)
+            it = iter(gv)
+            self._g_tab[n] = ptr_table([None if i in _DEAD else next(it) for i in range(len(ps))])
+        # ---- packed weights
+        self.packed = {n: torch.zeros(L.mcvc_gen_packed_floats(), device=dev) for n in G_NAMES}
+        self.packed.update({n: torch.zeros(L.mcvc_disc_packed_floats(), device=dev) for n in D_NAMES})
+        # ---- activations / workspaces (static shapes -> graph-capturable)
+        Tg = L.mcvc_gen_out_frames(T)
+        if Tg != T:
+            raise ValueError("training needs n_frames to be a multiple of 4 (the cycle must return the input length)")
+        T8 = L.mcvc_disc_out_frames(T)
+        f = lambda *s: torch.empty(s, device=dev)   # noqa: E731
+        self.g_stash = [f(L.mcvc_gen_stash_floats(B, T)) for _ in range(6)]
+        self.d_stash = [f(L.mcvc_disc_stash_floats(B, T)) for _ in range(8)]
+        self.g_scratch = f(L.mcvc_gen_scratch_floats(B, T))
+        self.d_scratch = f(L.mcvc_disc_scratch_floats(B, T))
+        self.mel = {k: f(B, 80, T) for k in ("fake_A", "fake_B", "cycle_A", "cycle_B", "identity_A", "identity_B",
+                                             "g_fake_A", "g_fake_B", "g_cycle_A", "g_cycle_B", "g_identity_A", "g_identity_B")}
+        self.dout = [f(B, 1, 10, T8) for _ in range(8)]
+        self.dlogit = [f(B, 1, 10, T8) for _ in range(8)]
+        self.slots = torch.zeros(16, device=dev)
+        self.reducer.broadcast_(self.g_group.flat)
+        self.reducer.broadcast_(self.d_group.flat)
+        self.repack(G_NAMES + D_NAMES)
+
+    # ---- thin call helpers ------------------------------------------------------------------------
+    def repack(self, names):
+        for n in names:
+            fn = self.L.mcvc_gen_pack if n in G_NAMES else self.L.mcvc_disc_pack
+            check(fn(self._p_tab[n], ptr(self.packed[n]), stream()), "pack " + n)
+
+    def _G(self, name, x, mask, out, stash):
+        check(self.L.mcvc_gen_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(mask), ptr(out), ptr(stash),
+                                      ptr(self.g_scratch), self.g_scratch.numel(), self.B, self.T, stream()), "gen_forward")
+
+    def _G_bwd(self, name, mask, dout, dx, acc, stash):
+        check(self.L.mcvc_gen_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name], ptr(mask), ptr(dout), ptr(dx), acc,
+                                       ptr(stash), ptr(self.g_scratch), self.g_scratch.numel(), self.B, self.T, stream()), "gen_backward")
+
+    def _D(self, name, x, out, stash):
+        check(self.L.mcvc_disc_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(out), ptr(stash), ptr(self.d_scratch),
+                                       self.d_scratch.numel(), self.B, self.T, stream()), "disc_forward")
+
+    def _D_bwd(self, name, dlogit, dx, acc, stash, with_weight_grads):
+        check(self.L.mcvc_disc_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name] if with_weight_grads else None,
+                                        ptr(dlogit), 1, ptr(dx), acc, ptr(stash), ptr(self.d_scratch), self.d_scratch.numel(),
+                                        self.B, self.T, stream()), "disc_backward")
+
+    def _slot(self, i):
+        return self.slots[i:i + 1]
+
+    def _l1(self, a, b, weight, grad, term_slot):
+        check(self.L.mcvc_l1_loss(ptr(a), ptr(b), a.numel(), float(weight), ptr(self._slot(SLOT_G)), ptr(self._slot(term_slot)), ptr(grad), 0,
+                                  stream()), "l1_loss")
+
+    def _lsgan(self, d, target, weight, loss_slot, term_slot, dlogit):
+        check(self.L.mcvc_lsgan_loss(ptr(d), d.numel(), float(target), float(weight), ptr(self._slot(loss_slot)), ptr(self._slot(term_slot)),
+                                     ptr(dlogit), stream()), "lsgan_loss")
+
+    def _adam(self, grp, lr):
+        grp.step += 1
+        check(self.L.mcvc_adam_step(ptr(grp.flat), ptr(grp.grad), ptr(grp.exp_avg), ptr(grp.exp_avg_sq), grp.numel, float(lr),
+                                    self.betas[0], self.betas[1], self.eps, grp.step, self.reducer.grad_scale, stream()), "adam_step")
+
+    # ---- the two phases -------------------------------------------------------------------------------
+    def generator_phase(self, real_A, mask_A, real_B, mask_B):
+        """train.py:195-242."""
+        m, s = self.mel, self.g_stash
+        sc = self.sched
+        self.slots.zero_()
+        self.g_group.grad.zero_()
+        self._G("generator_A2B", real_A, mask_A, m["fake_B"], s[0])        # :203
+        self._G("generator_B2A", m["fake_B"], None, m["cycle_A"], s[1])     # :204 (mask of ones)
+        self._G("generator_B2A", real_B, mask_B, m["fake_A"], s[2])        # :205
+        self._G("generator_A2B", m["fake_A"], None, m["cycle_B"], s[3])     # :206
+        self._G("generator_B2A", real_A, None, m["identity_A"], s[4])       # :207-208
+        self._G("generator_A2B", real_B, None, m["identity_B"], s[5])       # :209-210
+        self._D("discriminator_A", m["fake_A"], self.dout[0], self.d_stash[0])      # :211
+        self._D("discriminator_B", m["fake_B"], self.dout[1], self.d_stash[1])      # :212
+        self._D("discriminator_A2", m["cycle_A"], self.dout[2], self.d_stash[2])    # :215
+        self._D("discriminator_B2", m["cycle_B"], self.dout[3], self.d_stash[3])    # :216
+        # losses (:219-237) and their gradients
+        self._l1(m["cycle_A"], real_A, sc.cycle_loss_lambda, m["g_cycle_A"], SLOT_CYCLE)
+        self._l1(m["cycle_B"], real_B, sc.cycle_loss_lambda, m["g_cycle_B"], SLOT_CYCLE)
+        self._l1(m["identity_A"], real_A, sc.identity_loss_lambda, m["g_identity_A"], SLOT_IDENT)
+        self._l1(m["identity_B"], real_B, sc.identity_loss_lambda, m["g_identity_B"], SLOT_IDENT)
+        for i in range(4):
+            self._lsgan(self.dout[i], 1.0, 1.0, SLOT_G, SLOT_ADV_G, self.dlogit[i])
+        # backward, in dependency order; discriminators contribute data-gradients only
+        self._D_bwd("discriminator_A2", self.dlogit[2], m["g_cycle_A"], 1, self.d_stash[2], False)
+        self._D_bwd("discriminator_B2", self.dlogit[3], m["g_cycle_B"], 1, self.d_stash[3], False)
+        self._D_bwd("discriminator_A", self.dlogit[0], m["g_fake_A"], 0, self.d_stash[0], False)
+        self._D_bwd("discriminator_B", self.dlogit[1], m["g_fake_B"], 0, self.d_stash[1], False)
+        self._G_bwd("generator_B2A", None, m["g_cycle_A"], m["g_fake_B"], 1, s[1])     # cycle_A = G_B2A(fake_B)
+        self._G_bwd("generator_A2B", None, m["g_cycle_B"], m["g_fake_A"], 1, s[3])     # cycle_B = G_A2B(fake_A)
+        self._G_bwd("generator_A2B", mask_A, m["g_fake_B"], None, 0, s[0])
+        self._G_bwd("generator_B2A", mask_B, m["g_fake_A"], None, 0, s[2])
+        self._G_bwd("generator_B2A", None, m["g_identity_A"], None, 0, s[4])
+        self._G_bwd("generator_A2B", None, m["g_identity_B"], None, 0, s[5])
+        self.reducer.reduce_(self.g_group.grad)
+        self._adam(self.g_group, sc.g_opt_lr)                                             # :242
+        self.repack(G_NAMES)
+
+    def discriminator_phase(self, real_A, mask_A, real_B, mask_B):
+        """train.py:247-299."""
+        m, s = self.mel, self.g_stash
+        sc = self.sched
+        self.d_group.grad.zero_()
+        ds, do, dl = self.d_stash, self.dout, self.dlogit
+        self._D("discriminator_A", real_A, do[0], ds[0])                 # :255
+        self._D("discriminator_B", real_B, do[1], ds[1])                 # :256
+        self._D("discriminator_A2", real_A, do[2], ds[2])                # :257
+        self._D("discriminator_B2", real_B, do[3], ds[3])                # :258
+        self._G("generator_B2A", real_B, mask_B, m["fake_A"], s[0])      # :259 generated_A
+        self._D("discriminator_A", m["fake_A"], do[4], ds[4])            # :260
+        self._G("generator_A2B", m["fake_A"], None, m["cycle_B"], s[1])  # :263 cycled_B
+        self._D("discriminator_B2", m["cycle_B"], do[5], ds[5])          # :265
+        self._G("generator_A2B", real_A, mask_A, m["fake_B"], s[2])      # :267 generated_B
+        self._D("discriminator_B", m["fake_B"], do[6], ds[6])            # :268
+        self._G("generator_B2A", m["fake_B"], None, m["cycle_A"], s[3])  # :271 cycled_A
+        self._D("discriminator_A2", m["cycle_A"], do[7], ds[7])          # :273
+        # d_loss = (A + B)/2 + (A_2nd + B_2nd)/2 with each = (real + fake)/2  -> every term weighs 1/4  (:276-294)
+        for i in range(4):
+            self._lsgan(do[i], 1.0, 0.25, SLOT_D, SLOT_D_REAL, dl[i])
+        for i in range(4, 8):
+            self._lsgan(do[i], 0.0, 0.25, SLOT_D, SLOT_D_FAKE, dl[i])
+        order = ("discriminator_A", "discriminator_B", "discriminator_A2", "discriminator_B2",
+                 "discriminator_A", "discriminator_B2", "discriminator_B", "discriminator_A2")
+        for i, n in enumerate(order):
+            self._D_bwd(n, dl[i], None, 0, ds[i], True)
+        self.reducer.reduce_(self.d_group.grad)
+        self._adam(self.d_group, sc.d_opt_lr)                                            # :299
+        self.repack(D_NAMES)
+
+    def step(self, real_A, mask_A, real_B, mask_B):
+        """One full iteration.  Inputs: float32 [B,80,T] on the engine's device.  Returns the loss-slot
+        tensor (device); ``losses()`` does the host read the reference does with ``.item()`` (train.py:303)."""
+        _hip.require_cuda_f32(real_A, mask_A, real_B, mask_B)
+        if tuple(real_A.shape) != (self.B, 80, self.T):
+            raise ValueError("batch shape %s does not match the engine (%d, 80, %d)" % (tuple(real_A.shape), self.B, self.T))
+        self.generator_phase(real_A, mask_A, real_B, mask_B)
+        self.discriminator_phase(real_A, mask_A, real_B, mask_B)
+        self.sched.end_iteration()
+        return self.slots
+
+    def losses(self):
+        v = self.slots.tolist()      # device sync, like the reference's .item()
+        return {"g_loss": v[SLOT_G], "d_loss": v[SLOT_D], "cycle_loss": v[SLOT_CYCLE], "identity_loss": v[SLOT_IDENT],
+                "adv_loss": v[SLOT_ADV_G]}
+
+    # ---- torch.optim.Adam-compatible optimizer state (checkpoint layout of the reference) -----------------
+    def optimizer_state_dict(self, which):
+        """``torch.optim.Adam.state_dict()``-shaped dict: per-parameter ``step/exp_avg/exp_avg_sq`` keyed by the
+        position in the concatenated parameter list (G: 0..219; D: 0..79 with the dead 14-17,34-37,... absent)."""
+        grp = self.g_group if which == "G" else self.d_group
+        names = G_NAMES if which == "G" else D_NAMES
+        lr = self.sched.g_opt_lr if which == "G" else self.sched.d_opt_lr
+        state, idx, off = {}, 0, 0
+        for n in names:
+            ps = list(self.nets[n].parameters())
+            for i, p in enumerate(ps):
+                if which == "D" and i in _DEAD:
+                    idx += 1
+                    continue
+                k = p.numel()
+                if grp.step > 0:
+                    state[idx] = {"step": torch.tensor(float(grp.step)),
+                                  "exp_avg": grp.exp_avg[off:off + k].view(p.shape).detach().cpu().clone(),
+                                  "exp_avg_sq": grp.exp_avg_sq[off:off + k].view(p.shape).detach().cpu().clone()}
+                off += _align4(k)
+                idx += 1
+        group = {"lr": lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(idx))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, which, sd):
+        grp = self.g_group if which == "G" else self.d_group
+        names = G_NAMES if which == "G" else D_NAMES
+        idx, off, step = 0, 0, 0
+        for n in names:
+            for i, p in enumerate(self.nets[n].parameters()):
+                if which == "D" and i in _DEAD:
+                    idx += 1
+                    continue
+                k = p.numel()
+                st = sd["state"].get(idx)
+                if st is not None:
+                    grp.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                    grp.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                    step = max(step, int(float(st["step"])))
+                off += _align4(k)
+                idx += 1
+        grp.step = step
+        lr = sd["param_groups"][0]["lr"]
+        if which == "G":
+            self.sched.g_opt_lr = lr
+        else:
+            self.sched.d_opt_lr = lr

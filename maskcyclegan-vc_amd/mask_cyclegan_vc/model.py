@@ -174,11 +174,11 @@ class _GeneratorFn(torch.autograd.Function):
         _, scratch = ctx.net.workspace(B, T, dout.device)
         need = ctx.needs_input_grad
         sizes = [p.numel() if need[3 + i] else 0 for i, p in enumerate(params)]
-        flat = torch.zeros(sum(sizes), device=dout.device)
+        flat = torch.zeros(sum((n + 3) & ~3 for n in sizes), device=dout.device)
         grads, off = [], 0
         for p, n in zip(params, sizes):
             grads.append(flat[off:off + n].view_as(p) if n else None)
-            off += n
+            off += (n + 3) & ~3          # 16-byte aligned views
         dx = torch.empty((B, _hip.N_MEL, T), device=dout.device) if need[1] else None
         check(L.mcvc_gen_backward(ptr_table(params), ptr(packed), ptr_table(grads) if any(sizes) else None, ptr(mask), ptr(dout), ptr(dx), 0,
                                   ptr(stash), ptr(scratch), scratch.numel(), B, T, stream()), "mcvc_gen_backward")
@@ -215,11 +215,11 @@ class _DiscriminatorFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         # downSample4 (parameter slots 14..17) takes no part in forward: its grads stay None, like the reference
         sizes = [p.numel() if (need[2 + i] and not 14 <= i <= 17) else 0 for i, p in enumerate(params)]
-        flat = torch.zeros(sum(sizes), device=dout.device)
+        flat = torch.zeros(sum((n + 3) & ~3 for n in sizes), device=dout.device)
         grads, off = [], 0
         for p, n in zip(params, sizes):
             grads.append(flat[off:off + n].view_as(p) if n else None)
-            off += n
+            off += (n + 3) & ~3
         dx = torch.empty((B, _hip.N_MEL, T), device=dout.device) if need[1] else None
         check(L.mcvc_disc_backward(ptr_table(params), ptr(packed), ptr_table(grads) if any(sizes) else None, ptr(dout), 0, ptr(dx), 0,
                                    ptr(stash), ptr(scratch), scratch.numel(), B, T, stream()), "mcvc_disc_backward")

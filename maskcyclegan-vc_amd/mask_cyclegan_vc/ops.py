@@ -52,7 +52,10 @@ def conv2d_wgrad(x, dy, w_shape, stride, padding):
     N, Cin, H, W = x.shape
     Cout, _, KH, KW = w_shape
     dw = torch.zeros(w_shape, device=x.device)
-    check(lib().mcvc_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), N, Cin, H, W, Cout, KH, KW, stride, padding[0], padding[1], stream()),
+    L = lib()
+    n_slab = L.mcvc_conv2d_wgrad_slab_floats(N, Cin, H, W, Cout, KH, KW, stride, padding[0], padding[1])
+    slabs = torch.empty(n_slab, device=x.device) if n_slab > 0 else None
+    check(L.mcvc_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(slabs), n_slab, N, Cin, H, W, Cout, KH, KW, stride, padding[0], padding[1], stream()),
           "mcvc_conv2d_wgrad")
     return dw
 
