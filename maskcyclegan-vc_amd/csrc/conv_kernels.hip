@@ -328,7 +328,7 @@ static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_n
             if (allow_split && blocks < 256 && a.nchunks > 1) {
                 nsplit = (int)(512 / blocks);             // one resident round: 2 workgroups per CU x 256 CUs
                 if (nsplit > a.nchunks) nsplit = a.nchunks;
-                if (nsplit > 64) nsplit = 64;
+                if (nsplit > 16) nsplit = 16;             // every slab is re-read by the consumer kernel
                 if (nsplit < 1) nsplit = 1;
             }
             a.chunks_per_split = cdiv_i(a.nchunks, nsplit);
@@ -545,6 +545,7 @@ __global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
             }
             __syncthreads();
             const int total = ngroups * 8 * RLv;
+#pragma unroll 4
             for (int idx = tid; idx < total; idx += nthreads) {
                 const int grow = idx / RLv, e = idx - grow * RLv;       // grow = g*8 + row
                 const int g = grow >> 3, row = grow & 7;
@@ -586,6 +587,71 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(float* __restrict__ d
         for (int z = 0; z < ksplit; ++z) acc += slabs[(long long)z * stride + t];
         dw[t] = acc;
     }
+}
+
+// ---- small-K weight gradient (1-D trunk at small batch) ---------------------------------------------------
+// dW[co][ci][kw] += sum_{row, ow} dY[row][co][ow] * X[row][ci][ow + kw - pw]     (KH == 1, stride 1)
+// With only tens of pixels this is an outer-product, bound by the dW read-modify-write (1.5 MB per trunk conv),
+// not by FLOPs: one thread per input channel, COB output channels per block, dY broadcast from LDS, dW written
+// with coalesced accesses.  Three dependent memory round trips in total (dY stage, X rows, dW RMW).
+struct SmallKArgs {
+    const float* x; const float* dy; float* dw;
+    long long x_sb, x_sc, dy_sb, dy_sc;
+    int x_sh, dy_sh;
+    int NB, Cin, Cout, OH, OW, pw;
+};
+
+template <int KW, int COB>
+__global__ void __launch_bounds__(256) wgrad_smallk_kernel(const SmallKArgs a)
+{
+    __shared__ float dys[COB * 128];
+    const int tid = threadIdx.x;
+    const int co0 = blockIdx.x * COB;
+    const int ci = blockIdx.y * 256 + tid;
+    const int rows = a.NB * a.OH;
+    const int npix = rows * a.OW;
+    for (int i = tid; i < COB * npix; i += 256) {
+        const int co = i / npix, p = i - co * npix;
+        const int row = p / a.OW, ow = p - row * a.OW;
+        const int n = row / a.OH, oh = row - n * a.OH;
+        const int cg = co0 + co;
+        dys[co * npix + p] = (cg < a.Cout) ? a.dy[(long long)n * a.dy_sb + (long long)cg * a.dy_sc + (long long)oh * a.dy_sh + ow] : 0.f;
+    }
+    __syncthreads();
+    if (ci >= a.Cin) return;
+    float acc[COB][KW];
+#pragma unroll
+    for (int c = 0; c < COB; ++c)
+#pragma unroll
+        for (int k = 0; k < KW; ++k) acc[c][k] = 0.f;
+    for (int row = 0; row < rows; ++row) {
+        const int n = row / a.OH, oh = row - n * a.OH;
+        const float* xr = a.x + (long long)n * a.x_sb + (long long)ci * a.x_sc + (long long)oh * a.x_sh;
+        const float* dr = dys + row * a.OW;
+#pragma unroll 4
+        for (int q = 0; q < a.OW; ++q) {
+            const float xv = xr[q];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int ow = q - k + a.pw;
+                if (ow >= 0 && ow < a.OW) {
+#pragma unroll
+                    for (int c = 0; c < COB; ++c) acc[c][k] += dr[c * npix + ow] * xv;
+                }
+            }
+        }
+    }
+    float old[COB][KW];
+#pragma unroll
+    for (int c = 0; c < COB; ++c)
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            old[c][k] = (co0 + c < a.Cout) ? a.dw[((long long)(co0 + c) * a.Cin + ci) * KW + k] : 0.f;
+#pragma unroll
+    for (int c = 0; c < COB; ++c)
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            if (co0 + c < a.Cout) a.dw[((long long)(co0 + c) * a.Cin + ci) * KW + k] = old[c][k] + acc[c][k];
 }
 
 namespace {
@@ -668,9 +734,14 @@ static bool plan_wgrad(const ConvProblem& p, int NB, long long slab_cap_floats, 
     int ksplit = 1;
     if (waves < 1024) ksplit = cdiv_i(1536, waves);   // ~1.5 waves per SIMD chip-wide
     if (ksplit > items) ksplit = items;
+    if (a.dw_floats <= 65536 && items > ksplit) {     // tiny dW (edge layers): slabs are free, the dY stream is the cost
+        ksplit = cdiv_i(4096, waves);
+        if (ksplit > items) ksplit = items;
+    }
     if (ksplit > 1) {
         long long cap = slab_cap_floats / a.slab_stride;
-        if (cap > 32) cap = 32;
+        const long long hard = (a.dw_floats <= 65536) ? 512 : 32;
+        if (cap > hard) cap = hard;
         if (ksplit > cap) ksplit = (int)cap;
         if (ksplit < 2) ksplit = 1;
     }
@@ -681,15 +752,36 @@ static bool plan_wgrad(const ConvProblem& p, int NB, long long slab_cap_floats, 
 }
 }  // namespace
 
+static bool smallk_applies(const ConvProblem& p, int NB);
 long long mcvc_wgrad_plan_slab_floats(const ConvProblem& p, int NB)
 {
+    if (smallk_applies(p, NB)) return 0;
     WgradPlan pl;
     if (!plan_wgrad(p, NB, 1LL << 40, &pl)) return -1;
     return pl.a.ksplit > 1 ? (long long)pl.a.ksplit * pl.a.slab_stride : 0;
 }
 
+static bool smallk_applies(const ConvProblem& p, int NB)
+{
+    return p.KH == 1 && p.stride == 1 && (p.KW == 1 || p.KW == 3) && p.pad_h == 0 && (long long)NB * p.OH * p.OW <= 128 && p.OW == p.W;
+}
+
 int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, float* slabs, long long slab_cap_floats, hipStream_t s)
 {
+    if (smallk_applies(p, NB)) {
+        SmallKArgs k{};
+        k.x = io.x; k.dy = io.dy; k.dw = dw;
+        k.x_sb = io.x_sb; k.x_sc = io.x_sc; k.x_sh = io.x_sh;
+        k.dy_sb = io.dy_sb; k.dy_sc = io.dy_sc; k.dy_sh = io.dy_sh;
+        k.NB = NB; k.Cin = p.Cin; k.Cout = p.Cout; k.OH = p.OH; k.OW = p.OW; k.pw = p.pad_w;
+        constexpr int COB = 4;
+        dim3 grid((unsigned)cdiv_i(p.Cout, COB), (unsigned)cdiv_i(p.Cin, 256));
+        const double px = (double)NB * p.OH * p.OW;
+        TraceScope ts(K_WGRAD_SMALLK, s, 2.0 * px * p.Cout * p.Cin * p.KW, 4.0 * (2.0 * p.Cout * p.Cin * p.KW + px * (p.Cin + p.Cout)));
+        if (p.KW == 3) hipLaunchKernelGGL((wgrad_smallk_kernel<3, COB>), grid, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((wgrad_smallk_kernel<1, COB>), grid, dim3(256), 0, s, k);
+        return (int)hipGetLastError();
+    }
     WgradPlan pl;
     if (!plan_wgrad(p, NB, slabs ? slab_cap_floats : 0, &pl)) return MCVC_ERR_INVALID;
     WgradArgs& a = pl.a;

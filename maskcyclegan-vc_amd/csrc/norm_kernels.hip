@@ -197,6 +197,199 @@ __global__ void __launch_bounds__(256) norm_bwd_kernel(const NormBwdArgs a)
     }
 }
 
+// ---- register-cached variants -----------------------------------------------------------------------
+// Each lane keeps its <= E plane elements in registers: ONE global read of the plane (all loads issued
+// back-to-back), statistics by shuffles, one write.  At bs=1 these kernels are pure latency, so the number
+// of dependent memory round trips (1 here vs 5-6 in the streaming kernels above) is what matters.
+template <int G, int E>
+__global__ void __launch_bounds__(256) norm_fwd_reg_kernel(const NormArgs a)
+{
+    __shared__ float red[4];
+    constexpr int GPB = 256 / G;
+    const int g = threadIdx.x / G, l = threadIdx.x % G;
+    const long long plane_id = (long long)blockIdx.x * GPB + g;
+    if (plane_id >= (long long)a.N * a.C) return;
+    const int n = (int)(plane_id / a.C), c = (int)(plane_id - (long long)n * a.C);
+    const int P = a.H * a.W;
+    const float invP = 1.0f / (float)P;
+    const int nbr = (a.act == ACT_GLU) ? 2 : 1;
+    const int Cx = a.C * nbr;
+    float xv[2][E];
+    float rv[E];
+    long long yo[E];
+    // ---- issue every load first
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+        if (br < nbr) {
+            const long long poff = (long long)n * a.x_sn + (long long)(c + br * a.C) * a.x_sc;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = l + e * G;
+                float v = 0.f;
+                if (i < P) {
+                    v = a.x[poff + i];
+#pragma unroll 8
+                    for (int sl = 1; sl < a.nslab; ++sl) v += a.x_slabs[(long long)(sl - 1) * a.slab_stride + poff + i];
+                }
+                xv[br][e] = v;
+            }
+        }
+    }
+    const long long yoff0 = (long long)n * a.y_sn + (long long)c * a.y_sc;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = l + e * G;
+        const int h = i / a.W, w = i - h * a.W;
+        yo[e] = yoff0 + (long long)h * a.y_sh + w;
+        rv[e] = (a.res != nullptr && i < P) ? a.res[yo[e]] : 0.f;
+    }
+    const float g0 = a.gamma[0][c], b0 = a.beta[0][c];
+    float g1 = 0.f, b1 = 0.f;
+    if (nbr == 2) { g1 = a.gamma[1][c]; b1 = a.beta[1][c]; }
+    // ---- statistics
+    float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+        if (br < nbr) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) s += xv[br][e];          // padding lanes hold 0
+            s = gsum<G>(s, red);
+            const float m = s * invP;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const float d = xv[br][e] - m; q += (l + e * G < P) ? d * d : 0.f; }
+            q = gsum<G>(q, red);
+            const float r = 1.0f / sqrtf(q * invP + a.eps);
+            mean[br] = m; rstd[br] = r;
+            if (l == 0) {
+                float* st = a.stats + ((long long)n * Cx + c + br * a.C) * 2;
+                st[0] = m; st[1] = r;
+            }
+            if (a.nslab > 1) {                                    // backward needs the reduced conv output
+                const long long poff = (long long)n * a.x_sn + (long long)(c + br * a.C) * a.x_sc;
+#pragma unroll
+                for (int e = 0; e < E; ++e) if (l + e * G < P) a.x[poff + l + e * G] = xv[br][e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (l + e * G < P) {
+            const float z0 = (xv[0][e] - mean[0]) * rstd[0] * g0 + b0;
+            float y;
+            if (a.act == ACT_GLU) y = z0 * sigmoidf_((xv[1][e] - mean[1]) * rstd[1] * g1 + b1);
+            else if (a.act == ACT_SILU) y = z0 * sigmoidf_(z0);
+            else y = z0;
+            a.y[yo[e]] = y + rv[e];
+        }
+    }
+}
+
+template <int G, int E>
+__global__ void __launch_bounds__(256) norm_bwd_reg_kernel(const NormBwdArgs a)
+{
+    __shared__ float red[4];
+    constexpr int GPB = 256 / G;
+    const int g = threadIdx.x / G, l = threadIdx.x % G;
+    const int c = blockIdx.x * GPB + g;
+    if (c >= a.C) return;
+    const int P = a.H * a.W;
+    const float invP = 1.0f / (float)P;
+    const int nbr = (a.act == ACT_GLU) ? 2 : 1;
+    const int Cx = a.C * nbr;
+    float gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f};
+    for (int br = 0; br < nbr; ++br) { gam[br] = a.gamma[br][c]; bet[br] = a.beta[br][c]; }
+    float dgam[2] = {0.f, 0.f}, dbet[2] = {0.f, 0.f};
+    for (int n = 0; n < a.N; ++n) {
+        float xh[2][E], dz[2][E], dyv[E];
+        int hh[E], ww[E];
+        const long long yoff0 = (long long)n * a.y_sn + (long long)c * a.y_sc;
+        float mean[2] = {0.f, 0.f}, rstd[2] = {1.f, 1.f};
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+            if (br < nbr) {
+                const float* st = a.stats + ((long long)n * Cx + c + br * a.C) * 2;
+                mean[br] = st[0]; rstd[br] = st[1];
+                const float* xp = a.x + (long long)n * a.x_sn + (long long)(c + br * a.C) * a.x_sc;
+#pragma unroll
+                for (int e = 0; e < E; ++e) { const int i = l + e * G; xh[br][e] = (i < P) ? xp[i] : 0.f; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = l + e * G;
+            const int h = i / a.W, w = i - h * a.W;
+            hh[e] = h; ww[e] = w;
+            float v = 0.f;
+            if (i < P) {
+                const long long yo = yoff0 + (long long)h * a.y_sh + w;
+                v = a.dy[yo];
+                if (a.nslab > 1) {
+#pragma unroll 8
+                    for (int sl = 1; sl < a.nslab; ++sl) v += a.dy_slabs[(long long)(sl - 1) * a.slab_stride + yo];
+                    a.dy[yo] = v;                  // the residual path re-reads the reduced gradient
+                }
+            }
+            dyv[e] = v;
+        }
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const bool ok = (l + e * G) < P;
+            const float x0 = (xh[0][e] - mean[0]) * rstd[0];
+            const float z0 = x0 * gam[0] + bet[0];
+            float d0, d1 = 0.f, x1 = 0.f;
+            if (a.act == ACT_GLU) {
+                x1 = (xh[1][e] - mean[1]) * rstd[1];
+                const float sg = sigmoidf_(x1 * gam[1] + bet[1]);
+                d0 = dyv[e] * sg;
+                d1 = dyv[e] * z0 * sg * (1.0f - sg);
+            } else if (a.act == ACT_SILU) {
+                const float sg = sigmoidf_(z0);
+                d0 = dyv[e] * (sg * (1.0f + z0 * (1.0f - sg)));
+            } else {
+                d0 = dyv[e];
+            }
+            if (!ok) { d0 = 0.f; d1 = 0.f; }
+            xh[0][e] = ok ? x0 : 0.f; xh[1][e] = ok ? x1 : 0.f;
+            dz[0][e] = d0; dz[1][e] = d1;
+            s1[0] += d0; s2[0] += d0 * xh[0][e];
+            s1[1] += d1; s2[1] += d1 * xh[1][e];
+        }
+        for (int br = 0; br < nbr; ++br) {
+            s1[br] = gsum<G>(s1[br], red);
+            s2[br] = gsum<G>(s2[br], red);
+            dbet[br] += s1[br];
+            dgam[br] += s2[br];
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = l + e * G;
+            if (i < P) {
+                const float dx0 = gam[0] * rstd[0] * (dz[0][e] - s1[0] * invP - xh[0][e] * (s2[0] * invP));
+                if (a.unshuffle) {
+                    const int h = hh[e], w = ww[e];
+                    const int co = 4 * c + 2 * (h & 1) + (w & 1);
+                    a.dx[(long long)n * a.dx_sn + (long long)co * a.dx_sc + (long long)(h >> 1) * a.dx_sh + (w >> 1)] = dx0;
+                } else {
+                    a.dx[(long long)n * a.dx_sn + (long long)c * a.dx_sc + i] = dx0;
+                    if (nbr == 2) {
+                        const float dx1 = gam[1] * rstd[1] * (dz[1][e] - s1[1] * invP - xh[1][e] * (s2[1] * invP));
+                        a.dx[(long long)n * a.dx_sn + (long long)(c + a.C) * a.dx_sc + i] = dx1;
+                    }
+                }
+            }
+        }
+    }
+    if (l == 0) {
+        for (int br = 0; br < nbr; ++br) {
+            if (a.dgamma[br]) a.dgamma[br][c] += dgam[br];
+            if (a.dbeta[br]) a.dbeta[br][c] += dbet[br];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) act_fwd_kernel(const ActArgs a)
 {
     const long long total = (long long)a.N * a.C * a.P;
@@ -270,6 +463,14 @@ int mcvc_norm_fwd_launch(const NormArgs& a, hipStream_t s)
     const unsigned blocks = (unsigned)cdiv_ll(planes, 256 / G);
     const double el = (double)planes * P * (a.act == ACT_GLU ? 2 : 1);
     TraceScope ts(K_NORM_FWD, s, 0.0, 4.0 * (el * (a.nslab + 1) + (double)planes * P));
+#define MCVC_FWD_REG(GG, EE) { hipLaunchKernelGGL((norm_fwd_reg_kernel<GG, EE>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, a); return (int)hipGetLastError(); }
+    if (P <= 16) MCVC_FWD_REG(16, 1)
+    if (P <= 64) MCVC_FWD_REG(16, 4)
+    if (P <= 128) MCVC_FWD_REG(64, 2)
+    if (P <= 320) MCVC_FWD_REG(64, 5)
+    if (P <= 1280) MCVC_FWD_REG(256, 5)
+    if (P <= 5120) MCVC_FWD_REG(256, 20)
+#undef MCVC_FWD_REG
     if (G == 16) hipLaunchKernelGGL(norm_fwd_kernel<16>, dim3(blocks), dim3(256), 0, s, a);
     else if (G == 64) hipLaunchKernelGGL(norm_fwd_kernel<64>, dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(norm_fwd_kernel<256>, dim3(blocks), dim3(256), 0, s, a);
@@ -283,6 +484,14 @@ int mcvc_norm_bwd_launch(const NormBwdArgs& a, hipStream_t s)
     const unsigned blocks = (unsigned)cdiv_i(a.C, 256 / G);
     const double el = (double)a.N * a.C * P;
     TraceScope ts(K_NORM_BWD, s, 0.0, 4.0 * el * ((a.act == ACT_GLU ? 4 : 2) + a.nslab));
+#define MCVC_BWD_REG(GG, EE) { hipLaunchKernelGGL((norm_bwd_reg_kernel<GG, EE>), dim3((unsigned)cdiv_i(a.C, 256 / GG)), dim3(256), 0, s, a); return (int)hipGetLastError(); }
+    if (P <= 16) MCVC_BWD_REG(16, 1)
+    if (P <= 64) MCVC_BWD_REG(16, 4)
+    if (P <= 128) MCVC_BWD_REG(64, 2)
+    if (P <= 320) MCVC_BWD_REG(64, 5)
+    if (P <= 1280) MCVC_BWD_REG(256, 5)
+    if (P <= 5120) MCVC_BWD_REG(256, 20)
+#undef MCVC_BWD_REG
     if (G == 16) hipLaunchKernelGGL(norm_bwd_kernel<16>, dim3(blocks), dim3(256), 0, s, a);
     else if (G == 64) hipLaunchKernelGGL(norm_bwd_kernel<64>, dim3(blocks), dim3(256), 0, s, a);
     else hipLaunchKernelGGL(norm_bwd_kernel<256>, dim3(blocks), dim3(256), 0, s, a);

@@ -97,19 +97,34 @@ class TrainEngine:
         self.packed = {n: torch.zeros(L.mcvc_gen_packed_floats(), device=dev) for n in G_NAMES}
         self.packed.update({n: torch.zeros(L.mcvc_disc_packed_floats(), device=dev) for n in D_NAMES})
         # ---- activations / workspaces (static shapes -> graph-capturable)
+        # Passes that share weights and do not depend on each other run as ONE batched pass (mathematically
+        # identical: every op is per-sample).  Generator phase: G_A2B on [real_A|mask_A ; real_B|ones] and
+        # G_B2A on [real_B|mask_B ; real_A|ones] (translation + identity), then the two cycle passes.
+        # Discriminator phase: each discriminator sees [real ; generated] in one pass.
         Tg = L.mcvc_gen_out_frames(T)
         if Tg != T:
             raise ValueError("training needs n_frames to be a multiple of 4 (the cycle must return the input length)")
         T8 = L.mcvc_disc_out_frames(T)
+        B2 = 2 * B
         f = lambda *s: torch.empty(s, device=dev)   # noqa: E731
-        self.g_stash = [f(L.mcvc_gen_stash_floats(B, T)) for _ in range(6)]
-        self.d_stash = [f(L.mcvc_disc_stash_floats(B, T)) for _ in range(8)]
-        self.g_scratch = f(L.mcvc_gen_scratch_floats(B, T))
-        self.d_scratch = f(L.mcvc_disc_scratch_floats(B, T))
-        self.mel = {k: f(B, 80, T) for k in ("fake_A", "fake_B", "cycle_A", "cycle_B", "identity_A", "identity_B",
-                                             "g_fake_A", "g_fake_B", "g_cycle_A", "g_cycle_B", "g_identity_A", "g_identity_B")}
-        self.dout = [f(B, 1, 10, T8) for _ in range(8)]
-        self.dlogit = [f(B, 1, 10, T8) for _ in range(8)]
+        self.g_stash2 = [f(L.mcvc_gen_stash_floats(B2, T)) for _ in range(2)]      # translation+identity passes
+        self.g_stash1 = [f(L.mcvc_gen_stash_floats(B, T)) for _ in range(2)]       # cycle passes
+        self.d_stash1 = [f(L.mcvc_disc_stash_floats(B, T)) for _ in range(4)]
+        self.d_stash2 = [f(L.mcvc_disc_stash_floats(B2, T)) for _ in range(4)]
+        self.g_scratch = f(max(L.mcvc_gen_scratch_floats(B, T), L.mcvc_gen_scratch_floats(B2, T)))
+        self.d_scratch = f(max(L.mcvc_disc_scratch_floats(B, T), L.mcvc_disc_scratch_floats(B2, T)))
+        mel2 = lambda: f(B2, 80, T)                  # noqa: E731
+        self.in_A2B, self.in_B2A = mel2(), mel2()              # [real_A ; real_B] and [real_B ; real_A]
+        self.mask_A2B = torch.ones(B2, 80, T, device=dev)      # [mask_A ; ones]
+        self.mask_B2A = torch.ones(B2, 80, T, device=dev)      # [mask_B ; ones]
+        self.out_A2B, self.out_B2A = mel2(), mel2()            # [fake_B ; identity_B] and [fake_A ; identity_A]
+        self.gout_A2B, self.gout_B2A = mel2(), mel2()          # gradients w.r.t. those outputs
+        self.mel = {k: f(B, 80, T) for k in ("cycle_A", "cycle_B", "g_cycle_A", "g_cycle_B", "gen_A", "gen_B", "cyc_A", "cyc_B")}
+        self.d_in = {n: mel2() for n in D_NAMES}               # discriminator phase: [real ; generated]
+        self.dout1 = [f(B, 1, 10, T8) for _ in range(4)]
+        self.dlogit1 = [f(B, 1, 10, T8) for _ in range(4)]
+        self.dout2 = [f(B2, 1, 10, T8) for _ in range(4)]
+        self.dlogit2 = [f(B2, 1, 10, T8) for _ in range(4)]
         self.slots = torch.zeros(16, device=dev)
         self.reducer.broadcast_(self.g_group.flat)
         self.reducer.broadcast_(self.d_group.flat)
@@ -121,22 +136,22 @@ class TrainEngine:
             fn = self.L.mcvc_gen_pack if n in G_NAMES else self.L.mcvc_disc_pack
             check(fn(self._p_tab[n], ptr(self.packed[n]), stream()), "pack " + n)
 
-    def _G(self, name, x, mask, out, stash):
+    def _G(self, name, x, mask, out, stash, nb):
         check(self.L.mcvc_gen_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(mask), ptr(out), ptr(stash),
-                                      ptr(self.g_scratch), self.g_scratch.numel(), self.B, self.T, stream()), "gen_forward")
+                                      ptr(self.g_scratch), self.g_scratch.numel(), nb, self.T, stream()), "gen_forward")
 
-    def _G_bwd(self, name, mask, dout, dx, acc, stash):
+    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb):
         check(self.L.mcvc_gen_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name], ptr(mask), ptr(dout), ptr(dx), acc,
-                                       ptr(stash), ptr(self.g_scratch), self.g_scratch.numel(), self.B, self.T, stream()), "gen_backward")
+                                       ptr(stash), ptr(self.g_scratch), self.g_scratch.numel(), nb, self.T, stream()), "gen_backward")
 
-    def _D(self, name, x, out, stash):
+    def _D(self, name, x, out, stash, nb):
         check(self.L.mcvc_disc_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(out), ptr(stash), ptr(self.d_scratch),
-                                       self.d_scratch.numel(), self.B, self.T, stream()), "disc_forward")
+                                       self.d_scratch.numel(), nb, self.T, stream()), "disc_forward")
 
-    def _D_bwd(self, name, dlogit, dx, acc, stash, with_weight_grads):
+    def _D_bwd(self, name, dlogit, dx, acc, stash, with_weight_grads, nb):
         check(self.L.mcvc_disc_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name] if with_weight_grads else None,
                                         ptr(dlogit), 1, ptr(dx), acc, ptr(stash), ptr(self.d_scratch), self.d_scratch.numel(),
-                                        self.B, self.T, stream()), "disc_backward")
+                                        nb, self.T, stream()), "disc_backward")
 
     def _slot(self, i):
         return self.slots[i:i + 1]
@@ -157,69 +172,73 @@ class TrainEngine:
     # ---- the two phases -------------------------------------------------------------------------------
     def generator_phase(self, real_A, mask_A, real_B, mask_B):
         """train.py:195-242."""
-        m, s = self.mel, self.g_stash
+        B, B2 = self.B, 2 * self.B
+        m = self.mel
         sc = self.sched
         self.slots.zero_()
         self.g_group.grad.zero_()
-        self._G("generator_A2B", real_A, mask_A, m["fake_B"], s[0])        # :203
-        self._G("generator_B2A", m["fake_B"], None, m["cycle_A"], s[1])     # :204 (mask of ones)
-        self._G("generator_B2A", real_B, mask_B, m["fake_A"], s[2])        # :205
-        self._G("generator_A2B", m["fake_A"], None, m["cycle_B"], s[3])     # :206
-        self._G("generator_B2A", real_A, None, m["identity_A"], s[4])       # :207-208
-        self._G("generator_A2B", real_B, None, m["identity_B"], s[5])       # :209-210
-        self._D("discriminator_A", m["fake_A"], self.dout[0], self.d_stash[0])      # :211
-        self._D("discriminator_B", m["fake_B"], self.dout[1], self.d_stash[1])      # :212
-        self._D("discriminator_A2", m["cycle_A"], self.dout[2], self.d_stash[2])    # :215
-        self._D("discriminator_B2", m["cycle_B"], self.dout[3], self.d_stash[3])    # :216
+        # batched inputs (device-to-device copies; the batch dimension is outermost, so halves are contiguous views)
+        self.in_A2B[:B].copy_(real_A); self.in_A2B[B:].copy_(real_B)
+        self.in_B2A[:B].copy_(real_B); self.in_B2A[B:].copy_(real_A)
+        self.mask_A2B[:B].copy_(mask_A); self.mask_B2A[:B].copy_(mask_B)       # second halves stay all-ones
+        fake_B, identity_B = self.out_A2B[:B], self.out_A2B[B:]
+        fake_A, identity_A = self.out_B2A[:B], self.out_B2A[B:]
+        g_fake_B, g_identity_B = self.gout_A2B[:B], self.gout_A2B[B:]
+        g_fake_A, g_identity_A = self.gout_B2A[:B], self.gout_B2A[B:]
+        self._G("generator_A2B", self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], B2)   # :203 fake_B  + :209-210 identity_B
+        self._G("generator_B2A", self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], B2)   # :205 fake_A  + :207-208 identity_A
+        self._G("generator_B2A", fake_B, None, m["cycle_A"], self.g_stash1[0], B)                  # :204 (mask of ones)
+        self._G("generator_A2B", fake_A, None, m["cycle_B"], self.g_stash1[1], B)                  # :206
+        do, dl, ds = self.dout1, self.dlogit1, self.d_stash1
+        self._D("discriminator_A", fake_A, do[0], ds[0], B)              # :211
+        self._D("discriminator_B", fake_B, do[1], ds[1], B)              # :212
+        self._D("discriminator_A2", m["cycle_A"], do[2], ds[2], B)       # :215
+        self._D("discriminator_B2", m["cycle_B"], do[3], ds[3], B)       # :216
         # losses (:219-237) and their gradients
         self._l1(m["cycle_A"], real_A, sc.cycle_loss_lambda, m["g_cycle_A"], SLOT_CYCLE)
         self._l1(m["cycle_B"], real_B, sc.cycle_loss_lambda, m["g_cycle_B"], SLOT_CYCLE)
-        self._l1(m["identity_A"], real_A, sc.identity_loss_lambda, m["g_identity_A"], SLOT_IDENT)
-        self._l1(m["identity_B"], real_B, sc.identity_loss_lambda, m["g_identity_B"], SLOT_IDENT)
+        self._l1(identity_A, real_A, sc.identity_loss_lambda, g_identity_A, SLOT_IDENT)
+        self._l1(identity_B, real_B, sc.identity_loss_lambda, g_identity_B, SLOT_IDENT)
         for i in range(4):
-            self._lsgan(self.dout[i], 1.0, 1.0, SLOT_G, SLOT_ADV_G, self.dlogit[i])
+            self._lsgan(do[i], 1.0, 1.0, SLOT_G, SLOT_ADV_G, dl[i])
         # backward, in dependency order; discriminators contribute data-gradients only
-        self._D_bwd("discriminator_A2", self.dlogit[2], m["g_cycle_A"], 1, self.d_stash[2], False)
-        self._D_bwd("discriminator_B2", self.dlogit[3], m["g_cycle_B"], 1, self.d_stash[3], False)
-        self._D_bwd("discriminator_A", self.dlogit[0], m["g_fake_A"], 0, self.d_stash[0], False)
-        self._D_bwd("discriminator_B", self.dlogit[1], m["g_fake_B"], 0, self.d_stash[1], False)
-        self._G_bwd("generator_B2A", None, m["g_cycle_A"], m["g_fake_B"], 1, s[1])     # cycle_A = G_B2A(fake_B)
-        self._G_bwd("generator_A2B", None, m["g_cycle_B"], m["g_fake_A"], 1, s[3])     # cycle_B = G_A2B(fake_A)
-        self._G_bwd("generator_A2B", mask_A, m["g_fake_B"], None, 0, s[0])
-        self._G_bwd("generator_B2A", mask_B, m["g_fake_A"], None, 0, s[2])
-        self._G_bwd("generator_B2A", None, m["g_identity_A"], None, 0, s[4])
-        self._G_bwd("generator_A2B", None, m["g_identity_B"], None, 0, s[5])
+        self._D_bwd("discriminator_A2", dl[2], m["g_cycle_A"], 1, ds[2], False, B)
+        self._D_bwd("discriminator_B2", dl[3], m["g_cycle_B"], 1, ds[3], False, B)
+        self._D_bwd("discriminator_A", dl[0], g_fake_A, 0, ds[0], False, B)
+        self._D_bwd("discriminator_B", dl[1], g_fake_B, 0, ds[1], False, B)
+        self._G_bwd("generator_B2A", None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B)       # cycle_A = G_B2A(fake_B)
+        self._G_bwd("generator_A2B", None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B)       # cycle_B = G_A2B(fake_A)
+        self._G_bwd("generator_A2B", self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2)
+        self._G_bwd("generator_B2A", self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2)
         self.reducer.reduce_(self.g_group.grad)
         self._adam(self.g_group, sc.g_opt_lr)                                             # :242
         self.repack(G_NAMES)
 
     def discriminator_phase(self, real_A, mask_A, real_B, mask_B):
         """train.py:247-299."""
-        m, s = self.mel, self.g_stash
+        B, B2 = self.B, 2 * self.B
+        m = self.mel
         sc = self.sched
         self.d_group.grad.zero_()
-        ds, do, dl = self.d_stash, self.dout, self.dlogit
-        self._D("discriminator_A", real_A, do[0], ds[0])                 # :255
-        self._D("discriminator_B", real_B, do[1], ds[1])                 # :256
-        self._D("discriminator_A2", real_A, do[2], ds[2])                # :257
-        self._D("discriminator_B2", real_B, do[3], ds[3])                # :258
-        self._G("generator_B2A", real_B, mask_B, m["fake_A"], s[0])      # :259 generated_A
-        self._D("discriminator_A", m["fake_A"], do[4], ds[4])            # :260
-        self._G("generator_A2B", m["fake_A"], None, m["cycle_B"], s[1])  # :263 cycled_B
-        self._D("discriminator_B2", m["cycle_B"], do[5], ds[5])          # :265
-        self._G("generator_A2B", real_A, mask_A, m["fake_B"], s[2])      # :267 generated_B
-        self._D("discriminator_B", m["fake_B"], do[6], ds[6])            # :268
-        self._G("generator_B2A", m["fake_B"], None, m["cycle_A"], s[3])  # :271 cycled_A
-        self._D("discriminator_A2", m["cycle_A"], do[7], ds[7])          # :273
+        di = self.d_in
+        # generators run with their UPDATED weights and no gradient (train.py:259-273); outputs land directly in the
+        # second half of the discriminators' batched inputs
+        gen_A, gen_B = di["discriminator_A"][B:], di["discriminator_B"][B:]
+        cyc_A, cyc_B = di["discriminator_A2"][B:], di["discriminator_B2"][B:]
+        di["discriminator_A"][:B].copy_(real_A); di["discriminator_A2"][:B].copy_(real_A)
+        di["discriminator_B"][:B].copy_(real_B); di["discriminator_B2"][:B].copy_(real_B)
+        self._G("generator_B2A", real_B, mask_B, gen_A, self.g_stash1[0], B)     # :259 generated_A
+        self._G("generator_A2B", gen_A, None, cyc_B, self.g_stash1[1], B)        # :263 cycled_B
+        self._G("generator_A2B", real_A, mask_A, gen_B, self.g_stash1[0], B)     # :267 generated_B
+        self._G("generator_B2A", gen_B, None, cyc_A, self.g_stash1[1], B)        # :271 cycled_A
+        do, dl, ds = self.dout2, self.dlogit2, self.d_stash2
         # d_loss = (A + B)/2 + (A_2nd + B_2nd)/2 with each = (real + fake)/2  -> every term weighs 1/4  (:276-294)
-        for i in range(4):
-            self._lsgan(do[i], 1.0, 0.25, SLOT_D, SLOT_D_REAL, dl[i])
-        for i in range(4, 8):
-            self._lsgan(do[i], 0.0, 0.25, SLOT_D, SLOT_D_FAKE, dl[i])
-        order = ("discriminator_A", "discriminator_B", "discriminator_A2", "discriminator_B2",
-                 "discriminator_A", "discriminator_B2", "discriminator_B", "discriminator_A2")
-        for i, n in enumerate(order):
-            self._D_bwd(n, dl[i], None, 0, ds[i], True)
+        for i, n in enumerate(D_NAMES):
+            self._D(n, di[n], do[i], ds[i], B2)                                  # :255-258 real half, :260-273 generated half
+            self._lsgan(do[i][:B], 1.0, 0.25, SLOT_D, SLOT_D_REAL, dl[i][:B])
+            self._lsgan(do[i][B:], 0.0, 0.25, SLOT_D, SLOT_D_FAKE, dl[i][B:])
+        for i, n in enumerate(D_NAMES):
+            self._D_bwd(n, dl[i], None, 0, ds[i], True, B2)
         self.reducer.reduce_(self.d_group.grad)
         self._adam(self.d_group, sc.d_opt_lr)                                            # :299
         self.repack(D_NAMES)
