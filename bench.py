@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-size", type=int, default=1, help="per-GPU minibatch (BASELINE metric: 1)")
     ap.add_argument("--frames", type=int, default=64)
-    ap.add_argument("--cpu-iters", type=int, default=4, help="timed CPU-baseline iterations (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=12, help="timed CPU-baseline iterations (0 = skip)")
     ap.add_argument("--no-trace", action="store_true")
     ap.add_argument("--dump-trace", default=None, help="write one traced step's per-launch records (launch order) to this file")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")

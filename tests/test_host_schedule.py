@@ -1,0 +1,33 @@
+"""Host-side step bookkeeping (mask_cyclegan_vc/schedule.py) against the reference's unmodified train() trace:
+global_step advances by batch size, the LR-decay call-site bug, identity-loss cut-off."""
+import json
+import os
+
+from mask_cyclegan_vc.schedule import StepSchedule
+
+
+def test_schedule_replays_reference_decay_trace(golden_dir):
+    js = json.load(open(os.path.join(golden_dir, "step_decay.json")))
+    cfg = js["config"]
+    s = StepSchedule(generator_lr=cfg["g_lr"], discriminator_lr=cfg["d_lr"], num_epochs=cfg["num_epochs"], n_samples=cfg["n_utt"],
+                     batch_size=cfg["batch_size"], decay_after=cfg["decay_after"], stop_identity_after=cfg["stop_identity_after"])
+    for tr in js["trace"]:
+        # the fixture is taken inside logger.end_iter(), before this iteration's lr adjustment
+        assert abs(s.g_opt_lr - tr["g_opt_lr"]) < 1e-15 and abs(s.d_opt_lr - tr["d_opt_lr"]) < 1e-15
+        assert s.identity_loss_lambda == tr["identity_lambda_before_check"]
+        s.end_iteration()
+        assert s.global_step == tr["global_step"]
+    fin = js["final"]
+    assert abs(s.g_opt_lr - fin["g_opt_lr"]) < 1e-15            # generator optimizer holds the decayed DISCRIMINATOR lr
+    assert abs(s.d_opt_lr - fin["d_opt_lr"]) < 1e-15            # discriminator optimizer never decays
+    assert abs(s.generator_lr - fin["generator_lr_attr"]) < 1e-15
+    assert abs(s.discriminator_lr - fin["discriminator_lr_attr"]) < 1e-15
+    assert s.identity_loss_lambda == fin["identity_loss_lambda"] == 0
+    assert fin["g_opt_lr"] != cfg["g_lr"] and fin["d_opt_lr"] == cfg["d_lr"]
+
+
+def test_schedule_resume_and_world_size():
+    s = StepSchedule(n_samples=81, batch_size=1, start_epoch=3, dataset_len=81, world_size=8)
+    assert s.global_step == 162                                  # base_logger.py:55-56
+    s.end_iteration()
+    assert s.global_step == 170                                  # every rank consumed batch_size samples
