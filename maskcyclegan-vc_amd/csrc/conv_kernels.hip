@@ -7,6 +7,7 @@
 // re-packed weights, see pack_kernels.hip) and weight-gradient.
 #include "mcvc_common.h"
 #include "trace.h"
+#include <stdlib.h>
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -36,20 +37,24 @@ __device__ __forceinline__ void glds16(const float* g, float* l)
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int WM, int WN, int BMW, int BNW>
+// KW is a template parameter: the kw taps of a kernel row are fully unrolled and their LDS offsets are
+// ds_read immediates.  (With runtime kh/kw/stride arithmetic each tap cost ~30 SALU instructions; the scalar unit
+// is shared by the CU's 8 resident waves, which made the loop SALU-bound at ~2x the MFMA time.)
+template <int WM, int WN, int BMW, int BNW, int KW>
 __global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int COT = 32 * WM * BMW;
     constexpr int NSUB = WN * BNW;
     constexpr int V = COT / 4;
+    constexpr int RPI = 256 / V;                     // packed-weight rows covered by one 256-thread DMA sweep
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int hw = tid >> 5;                         // half-wave id 0..7
     const int wm_id = wave / BNW, wn_id = wave % BNW;
-    const int KHKW = a.KH * a.KW;
+    const int KHKW = a.KH * KW;
 
     const int tile_x = blockIdx.x % a.tiles_w;
     const int tile_y = blockIdx.x / a.tiles_w;
@@ -65,9 +70,11 @@ __global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
     const int iw0 = ow0 * a.stride - a.pad_w;
     const bool s2 = (a.stride == 2);
 
+    // LDS map (float offsets into smem): [X buf0][X buf1][W buf0][W buf1].  Buffers are addressed as
+    // smem[offset] -- never through a selected pointer, which would decay to a flat pointer and turn every
+    // operand read into flat_load_dword + vmcnt(0).
     const int ws_floats = a.cic * KHKW * COT;
-    float* Xbuf[2] = {smem, smem + a.xs_floats};
-    float* Wbuf[2] = {smem + 2 * a.xs_floats, smem + 2 * a.xs_floats + ws_floats};
+    const int wbase = 2 * a.xs_floats;
 
     const int r_j = l31 >> a.tow_log2, c_j = l31 & (tow - 1);
     int b_lane[WN];
@@ -92,101 +99,118 @@ __global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
 
     const float* xn = a.x + (long long)n * a.x_sb;
     const int prow_n = a.cic * a.PH;               // patch rows per chunk
-    const int w4_n = a.cic * KHKW * V;             // weight float4 per chunk
-    // a column tile past the packed row length reads (finite) neighbouring weights; those outputs are discarded
-    const int co_lim = a.w_cout - 4;
+    const int prow_it = (prow_n + 7) >> 3;         // row sweeps actually needed (<= kMaxPR)
+    const int pcol_it = (a.PW + 31) >> 5;          // column groups actually needed (<= kMaxPC)
+    const int wrows = a.cic * KHKW;                // packed-weight rows per chunk
+    // DMA lane constants: thread t moves float4 #(t % V) of row (t / V) + i*RPI on sweep i
+    const int d_row0 = tid / V;
+    int d_co = co0 + (tid % V) * 4;
+    if (d_co > a.w_cout - 4) d_co = a.w_cout - 4;  // column tile past the row end: finite neighbours, outputs discarded
+    const float* d_src0 = a.w + d_co;
 
     float preg[kMaxPR][kMaxPC];
 
-    auto dma_weights = [&](int ch, float* wdst) {
-        const long long grow0 = (long long)ch * a.cic * KHKW;
-        for (int base = wave * 64; base < w4_n; base += 256) {     // wave-uniform LDS base, lane*16 B added by HW
-            const int idx = base + lane;
-            if (idx < w4_n) {
-                const int row = idx / V, v4 = idx - row * V;
-                long long grow = grow0 + row;
-                if (grow > a.w_rows) grow = a.w_rows;              // zero pad row
-                int co = co0 + v4 * 4;
-                if (co > co_lim) co = co_lim;
-                glds16(a.w + grow * a.w_cout + co, wdst + (long long)base * 4);
-            }
+    auto dma_weights = [&](int ch, int wdst_off) {
+        const long long grow0 = (long long)ch * wrows;
+        int row = d_row0;
+        int lds = wdst_off + (wave * 64) * 4;                       // wave-uniform LDS base (float index)
+        for (; row < wrows; row += RPI, lds += 1024) {
+            long long grow = grow0 + row;
+            if (grow > a.w_rows) grow = a.w_rows;                    // all-zero pad row
+            glds16(d_src0 + grow * a.w_cout, smem + lds);
         }
     };
     auto fetch_patch = [&](int ch) {
         const int c0 = ch * a.cic;
 #pragma unroll
         for (int k = 0; k < kMaxPR; ++k) {
-            const int row = hw + 8 * k;
-            const int ci = row / a.PH;
-            const int r = row - ci * a.PH;
-            const int ih = ih0 + r;
-            const int cg = c0 + ci;
-            const bool rok = (row < prow_n) && (cg < a.Cin) && (ih >= 0) && (ih < a.H);
-            const float* src = xn + (long long)cg * a.x_sc + (long long)ih * a.x_sh;
+            if (k < prow_it) {
+                const int row = hw + 8 * k;
+                const int ci = row / a.PH;
+                const int r = row - ci * a.PH;
+                const int ih = ih0 + r;
+                const int cg = c0 + ci;
+                const bool rok = (row < prow_n) && (cg < a.Cin) && (ih >= 0) && (ih < a.H);
+                const float* src = xn + (long long)cg * a.x_sc + (long long)ih * a.x_sh + iw0 + l31;
 #pragma unroll
-            for (int j = 0; j < kMaxPC; ++j) {
-                const int iw = iw0 + l31 + 32 * j;
-                float v = 0.f;
-                if (rok && (l31 + 32 * j) < a.PW && iw >= 0 && iw < a.W) v = src[iw];
-                preg[k][j] = v;
+                for (int j = 0; j < kMaxPC; ++j) {
+                    if (j < pcol_it) {
+                        const int iw = iw0 + l31 + 32 * j;
+                        float v = 0.f;
+                        if (rok && (l31 + 32 * j) < a.PW && iw >= 0 && iw < a.W) v = src[32 * j];
+                        preg[k][j] = v;
+                    }
+                }
             }
         }
     };
-    auto commit_patch = [&](float* xdst) {
+    auto commit_patch = [&](int xdst_off) {
 #pragma unroll
         for (int k = 0; k < kMaxPR; ++k) {
-            const int row = hw + 8 * k;
-            if (row < prow_n) {
-                const int ci = row / a.PH;
-                const int r = row - ci * a.PH;
-                float* dst = xdst + ci * a.plane + r * a.PWp;
+            if (k < prow_it) {
+                const int row = hw + 8 * k;
+                if (row < prow_n) {
+                    const int ci = row / a.PH;
+                    const int r = row - ci * a.PH;
+                    const int dst = xdst_off + ci * a.plane + r * a.PWp;
 #pragma unroll
-                for (int j = 0; j < kMaxPC; ++j) {
-                    const int c = l31 + 32 * j;
-                    if (c < a.PW) dst[s2 ? ((c & 1) * a.PWh + (c >> 1)) : c] = preg[k][j];
+                    for (int j = 0; j < kMaxPC; ++j) {
+                        if (j < pcol_it) {
+                            const int c = l31 + 32 * j;
+                            if (c < a.PW) smem[dst + (s2 ? ((c & 1) * a.PWh + (c >> 1)) : c)] = preg[k][j];
+                        }
+                    }
                 }
             }
         }
     };
 
     if (ch_begin < ch_end) {
-        dma_weights(ch_begin, Wbuf[0]);
+        dma_weights(ch_begin, wbase);
         fetch_patch(ch_begin);
-        commit_patch(Xbuf[0]);
+        commit_patch(0);
     }
     __syncthreads();
+    const int npairs = a.cic >> 1;
+    const int odd_off = s2 ? a.PWh : 0;            // stride 2: odd patch columns live PWh floats after the even ones
     for (int ch = ch_begin; ch < ch_end; ++ch) {
         const int cur = (ch - ch_begin) & 1;
         const bool more = (ch + 1 < ch_end);
         if (more) {
-            dma_weights(ch + 1, Wbuf[cur ^ 1]);
+            dma_weights(ch + 1, wbase + (cur ^ 1) * ws_floats);
             fetch_patch(ch + 1);
         }
-        // ---- MFMA main loop over (channel pair, kh, kw)
-        const float* Xs = Xbuf[cur];
-        const float* Ws = Wbuf[cur];
-        const int npairs = a.cic >> 1;
+        // ---- MFMA main loop: (channel pair, kh) at run time, the KW taps of a row unrolled with immediate offsets
+        int a_off = wbase + cur * ws_floats + a_lane;
+        int x_pair = cur * a.xs_floats;
         for (int cp = 0; cp < npairs; ++cp) {
-            const float* xs = Xs + cp * 2 * a.plane;
-            const float* ws = Ws + cp * 2 * KHKW * COT + a_lane;
+            int x_row = x_pair;
             for (int kh = 0; kh < a.KH; ++kh) {
-                const int xrow = kh * a.PWp;
-                for (int kw = 0; kw < a.KW; ++kw) {
-                    const int xoff = xrow + (s2 ? ((kw & 1) * a.PWh + (kw >> 1)) : kw);
+                int xe[WN], xo[WN];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) { xe[j] = x_row + b_lane[j]; xo[j] = xe[j] + odd_off; }
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
                     float av[WM], bv[WN];
 #pragma unroll
-                    for (int i = 0; i < WM; ++i) av[i] = ws[i * 32];
+                    for (int i = 0; i < WM; ++i) av[i] = smem[a_off + kw * COT + i * 32];
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) bv[j] = xs[b_lane[j] + xoff];
+                    for (int j = 0; j < WN; ++j) {
+                        // stride 1: column kw.  stride 2 (de-interleaved): even kw -> kw/2, odd kw -> PWh + kw/2
+                        bv[j] = s2 ? ((kw & 1) ? smem[xo[j] + (kw >> 1)] : smem[xe[j] + (kw >> 1)]) : smem[xe[j] + kw];
+                    }
 #pragma unroll
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
                         for (int j = 0; j < WN; ++j) acc[i][j] = MFMA32(av[i], bv[j], acc[i][j]);
-                    ws += COT;
                 }
+                a_off += KW * COT;
+                x_row += a.PWp;
             }
+            a_off += KHKW * COT;                    // skip the odd channel's rows (read by the upper half-wave)
+            x_pair += 2 * a.plane;
         }
-        if (more) commit_patch(Xbuf[cur ^ 1]);
+        if (more) commit_patch((cur ^ 1) * a.xs_floats);
         __syncthreads();
     }
 
@@ -228,7 +252,16 @@ __global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
 // ---- host planner --------------------------------------------------------------------------------
 namespace {
 
-enum ConvCfg { CFG_L = 0, CFG_M, CFG_N, CFG_T, CFG_S, CFG_S2, CFG_COUNT };
+// tuning knobs (read once from the environment; defaults are the shipped configuration)
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static int conv_lds_budget_floats() { static const int v = env_int("MCVC_CONV_LDS_KB", 78) * 256; return v; }
+static int conv_small_tile_below() { static const int v = env_int("MCVC_CONV_Q_BELOW", 0); return v; }
+
+enum ConvCfg { CFG_L = 0, CFG_M, CFG_N, CFG_T, CFG_S, CFG_S2, CFG_Q, CFG_COUNT };
 struct CfgDesc { int cot, npix, kind; };
 static const CfgDesc kCfg[CFG_COUNT] = {
     {128, 128, K_CONV_L},   // L: 2x2 waves of 2x2 accumulators
@@ -237,6 +270,7 @@ static const CfgDesc kCfg[CFG_COUNT] = {
     {256, 32, K_CONV_T},    // T: 4x1 waves of 2x1   (1-D trunk: few pixels, many channels)
     {32, 256, K_CONV_S},    // S: 1x4 waves of 1x2   (Cout <= 32)
     {32, 128, K_CONV_S2},   // S2: 1x4 waves of 1x1  (Cout <= 32, small images)
+    {64, 64, K_CONV_Q},     // Q: 2x2 waves of 1x1   (small batch: twice the workgroups of M, half the LDS)
 };
 
 constexpr int kLdsBudgetFloats = 19 * 1024 + 512;   // 78 KiB per workgroup -> 2 workgroups per CU (160 KiB LDS)
@@ -271,6 +305,7 @@ static void patch_geometry(const ConvProblem& p, int npix, int tow_log2, int* PH
 static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_nsplit, ConvPlan* out)
 {
     if (p.stride != 1 && p.stride != 2) return false;
+    if (p.KW != 1 && p.KW != 2 && p.KW != 3 && p.KW != 5 && p.KW != 15) return false;
     const int tow_log2 = pick_tow_log2(p.OW);
     const int tow = 1 << tow_log2, rps = 32 >> tow_log2;
     const int npix_img = p.OH * p.OW;
@@ -288,6 +323,9 @@ static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_n
         const int toh_l = (kCfg[CFG_L].npix / 32) * rps;
         const long long blocks_l = (long long)cdiv_i(p.OW, tow) * cdiv_i(p.OH, toh_l) * cdiv_i(p.Cout, 128) * NB;
         if (blocks_l >= 512) cand[ncand++] = CFG_L;      // the big tile only when it still fills the chip
+        const int toh_m = (kCfg[CFG_M].npix / 32) * rps;
+        const long long blocks_m = (long long)cdiv_i(p.OW, tow) * cdiv_i(p.OH, toh_m) * cdiv_i(p.Cout, 128) * NB;
+        if (blocks_m < conv_small_tile_below()) cand[ncand++] = CFG_Q;
         cand[ncand++] = CFG_M; cand[ncand++] = CFG_N;
     }
     const int khkw = p.KH * p.KW;
@@ -303,8 +341,9 @@ static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_n
         a.plane = a.PH * a.PWp;
         if (a.PW > 32 * kMaxPC) continue;
         // both operands are double-buffered: 2 * (patch + weights) floats
+        const int budget = conv_lds_budget_floats();
         auto fits = [&](int c) {
-            return c <= cin_pad && 2 * (round_up_i(c * a.plane, 4) + c * khkw * cot) <= kLdsBudgetFloats && c * khkw <= 256 &&
+            return c <= cin_pad && 2 * (round_up_i(c * a.plane, 4) + c * khkw * cot) <= budget && c * khkw <= 256 &&
                    c * a.PH <= 8 * kMaxPR;
         };
         int cic = 2;
@@ -346,10 +385,10 @@ static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_n
     return false;
 }
 
-template <int WM, int WN, int BMW, int BNW>
-static hipError_t launch_cfg(const ConvPlan& pl, hipStream_t s)
+template <int WM, int WN, int BMW, int BNW, int KW>
+static hipError_t launch_cfg_kw(const ConvPlan& pl, hipStream_t s)
 {
-    auto kern = conv_direct_kernel<WM, WN, BMW, BNW>;
+    auto kern = conv_direct_kernel<WM, WN, BMW, BNW, KW>;
     static bool attr_done = false;             // once per instantiation (benign race: idempotent)
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -363,6 +402,19 @@ static hipError_t launch_cfg(const ConvPlan& pl, hipStream_t s)
                   4.0 * ((double)nb * a.Cin * a.H * a.W + (double)a.Cin * a.KH * a.KW * a.Cout + px * a.Cout * a.nsplit));
     hipLaunchKernelGGL(kern, pl.grid, dim3(256), pl.lds_bytes, s, pl.a);
     return hipGetLastError();
+}
+
+template <int WM, int WN, int BMW, int BNW>
+static hipError_t launch_cfg(const ConvPlan& pl, hipStream_t s)
+{
+    switch (pl.a.KW) {
+        case 1: return launch_cfg_kw<WM, WN, BMW, BNW, 1>(pl, s);
+        case 2: return launch_cfg_kw<WM, WN, BMW, BNW, 2>(pl, s);
+        case 3: return launch_cfg_kw<WM, WN, BMW, BNW, 3>(pl, s);
+        case 5: return launch_cfg_kw<WM, WN, BMW, BNW, 5>(pl, s);
+        case 15: return launch_cfg_kw<WM, WN, BMW, BNW, 15>(pl, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace
@@ -397,6 +449,7 @@ int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float
         case CFG_N: e = launch_cfg<1, 2, 2, 2>(pl, s); break;
         case CFG_T: e = launch_cfg<2, 1, 4, 1>(pl, s); break;
         case CFG_S2: e = launch_cfg<1, 1, 1, 4>(pl, s); break;
+        case CFG_Q: e = launch_cfg<1, 1, 2, 2>(pl, s); break;
         default:    e = launch_cfg<1, 2, 1, 4>(pl, s); break;
     }
     return (int)e;
