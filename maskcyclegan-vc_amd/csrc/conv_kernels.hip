@@ -31,6 +31,16 @@
 constexpr int kMaxPR = 8;    // patch rows per half-wave            (cic*PH <= 64)
 constexpr int kMaxPC = 3;    // 32-column groups per patch row      (PW <= 96)
 
+// XCD-aware block remap (MI355X: 8 XCDs, private 4 MiB L2 each; hardware hands consecutive workgroup ids to
+// consecutive XCDs).  Returns a logical id such that each XCD owns one contiguous range of logical ids, so
+// workgroups that share an operand slice (same weights / same dY rows) hit the same L2.  Bijective for any total.
+__device__ __forceinline__ int xcd_logical_id(int linear, int total)
+{
+    const int q = total >> 3, r = total & 7;
+    const int xcd = linear & 7, k = linear >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 __device__ __forceinline__ void glds16(const float* g, float* l)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -56,11 +66,15 @@ __global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
     const int wm_id = wave / BNW, wn_id = wave % BNW;
     const int KHKW = a.KH * KW;
 
-    const int tile_x = blockIdx.x % a.tiles_w;
-    const int tile_y = blockIdx.x / a.tiles_w;
-    const int co0 = blockIdx.y * COT;
-    const int n = blockIdx.z / a.nsplit;
-    const int split = blockIdx.z - n * a.nsplit;
+    // logical order: pixel tile fastest, then image, then K-split, then co-tile -> the workgroups of one XCD
+    // share (co-tile, split), i.e. the same weight slice, which then stays resident in that XCD's L2
+    int lid = xcd_logical_id((int)blockIdx.x, (int)gridDim.x);
+    const int tile = lid % a.tiles_total; lid /= a.tiles_total;
+    const int n = lid % a.nb; lid /= a.nb;
+    const int split = lid % a.nsplit;
+    const int co0 = (lid / a.nsplit) * COT;
+    const int tile_x = tile % a.tiles_w;
+    const int tile_y = tile / a.tiles_w;
 
     const int tow = 1 << a.tow_log2;
     const int rps = 32 >> a.tow_log2;              // output rows per 32-pixel sub-tile
@@ -177,13 +191,13 @@ __global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
         const int cur = (ch - ch_begin) & 1;
         const bool more = (ch + 1 < ch_end);
         if (more) {
-            dma_weights(ch + 1, wbase + (cur ^ 1) * ws_floats);
-            fetch_patch(ch + 1);
+            if (!(a.dbg & 1)) dma_weights(ch + 1, wbase + (cur ^ 1) * ws_floats);
+            if (!(a.dbg & 2)) fetch_patch(ch + 1);
         }
         // ---- MFMA main loop: (channel pair, kh) at run time, the KW taps of a row unrolled with immediate offsets
         int a_off = wbase + cur * ws_floats + a_lane;
         int x_pair = cur * a.xs_floats;
-        for (int cp = 0; cp < npairs; ++cp) {
+        for (int cp = 0; cp < ((a.dbg & 4) ? 0 : npairs); ++cp) {
             int x_row = x_pair;
             for (int kh = 0; kh < a.KH; ++kh) {
                 int xe[WN], xo[WN];
@@ -210,7 +224,7 @@ __global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
             a_off += KHKW * COT;                    // skip the odd channel's rows (read by the upper half-wave)
             x_pair += 2 * a.plane;
         }
-        if (more) commit_patch((cur ^ 1) * a.xs_floats);
+        if (more && !(a.dbg & 2)) commit_patch((cur ^ 1) * a.xs_floats);
         __syncthreads();
     }
 
@@ -218,6 +232,7 @@ __global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
     float* ybase = (split == 0 || a.out_mode == CONV_OUT_ACCUM) ? a.y : (a.y_slabs + (long long)(split - 1) * a.slab_stride);
     ybase += (long long)n * a.y_sb;
     const bool add_bias = (a.bias != nullptr) && (split == 0);
+    if (a.dbg & 8) return;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int sub = wn_id * WN + j;
@@ -260,6 +275,7 @@ static int env_int(const char* name, int dflt)
 }
 static int conv_lds_budget_floats() { static const int v = env_int("MCVC_CONV_LDS_KB", 78) * 256; return v; }
 static int conv_small_tile_below() { static const int v = env_int("MCVC_CONV_Q_BELOW", 0); return v; }
+static int conv_debug_bits() { static const int v = env_int("MCVC_CONV_DEBUG", 0); return v; }   // timing ablations only (wrong results)
 
 enum ConvCfg { CFG_L = 0, CFG_M, CFG_N, CFG_T, CFG_S, CFG_S2, CFG_Q, CFG_COUNT };
 struct CfgDesc { int cot, npix, kind; };
@@ -377,7 +393,8 @@ static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_n
         a.Cout = p.Cout; a.OH = p.OH; a.OW = p.OW;
         a.KH = p.KH; a.KW = p.KW; a.stride = p.stride; a.pad_h = p.pad_h; a.pad_w = p.pad_w;
         pl.cfg = cfg;
-        pl.grid = dim3((unsigned)(a.tiles_w * tiles_h), (unsigned)cotiles, (unsigned)(NB * a.nsplit));
+        a.tiles_total = a.tiles_w * tiles_h; a.nb = NB;
+        pl.grid = dim3((unsigned)(a.tiles_total * cotiles * NB * a.nsplit));
         pl.lds_bytes = (size_t)2 * (a.xs_floats + cic * khkw * cot) * sizeof(float);
         *out = pl;
         return true;
@@ -396,7 +413,7 @@ static hipError_t launch_cfg_kw(const ConvPlan& pl, hipStream_t s)
         attr_done = true;
     }
     const ConvArgs& a = pl.a;
-    const int nb = (int)pl.grid.z / a.nsplit;
+    const int nb = a.nb;
     const double px = (double)nb * a.OH * a.OW;
     TraceScope ts(kCfg[pl.cfg].kind, s, 2.0 * px * a.Cout * a.Cin * a.KH * a.KW,
                   4.0 * ((double)nb * a.Cin * a.H * a.W + (double)a.Cin * a.KH * a.KW * a.Cout + px * a.Cout * a.nsplit));
@@ -440,6 +457,7 @@ int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float
     a.y_slabs = io.slabs; a.slab_stride = io.slab_stride;
     a.w = wpk; a.w_rows = w_rows; a.w_cout = w_cout; a.bias = bias;
     a.out_mode = io.accumulate ? CONV_OUT_ACCUM : CONV_OUT_SLAB;
+    a.dbg = conv_debug_bits();
     a.shuffle = io.shuffle;
     if (nsplit_out) *nsplit_out = a.nsplit;
     hipError_t e;
@@ -483,8 +501,11 @@ __global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
     const int ms_base = cgrp * MS * 32;
     const int KHKW = a.KH * a.KW;
 
-    const int ci0 = blockIdx.x * 32;
-    const int co0 = blockIdx.y * a.cot;
+    // logical order: ci tile fastest, then K-split, then co tile -> an XCD's workgroups share dY rows
+    int lid = xcd_logical_id((int)blockIdx.x, (int)gridDim.x);
+    const int ci0 = (lid % a.ci_tiles) * 32; lid /= a.ci_tiles;
+    const int zsplit = lid % a.ksplit;
+    const int co0 = (lid / a.ksplit) * a.cot;
 
     float* As = smem;                           // [cot][pitch_a]
     float* Xs = smem + a.cot * a.pitch_a;       // [nci][plane]
@@ -515,7 +536,7 @@ __global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
     const int tw2 = a.tow >> 1;
     const int rows_a = a.cot * a.toh, rows_x = nci * a.PH;
 
-    for (int item = blockIdx.z; item < items; item += a.ksplit) {
+    for (int item = zsplit; item < items; item += a.ksplit) {
         const int n = item / tiles;
         const int t = item - n * tiles;
         const int ty = t / a.tiles_w, tx = t - ty * a.tiles_w;
@@ -578,7 +599,7 @@ __global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
     const int RL = nci * KHKW;                  // LDS row pitch
     const int RLv = nci_valid * KHKW;           // valid (contiguous in OIHW) run per output channel
     const int ngroups = a.cot / (MS * 32);
-    float* out = (a.ksplit > 1) ? (a.slabs + (long long)blockIdx.z * a.slab_stride) : a.dw;
+    float* out = (a.ksplit > 1) ? (a.slabs + (long long)zsplit * a.slab_stride) : a.dw;
     float* Tt = smem;
 #pragma unroll
     for (int i = 0; i < MS; ++i) {
@@ -798,8 +819,8 @@ static bool plan_wgrad(const ConvProblem& p, int NB, long long slab_cap_floats, 
         if (ksplit > cap) ksplit = (int)cap;
         if (ksplit < 2) ksplit = 1;
     }
-    a.ksplit = ksplit;
-    pl.grid = dim3((unsigned)ci_tiles, (unsigned)co_tiles, (unsigned)ksplit);
+    a.ksplit = ksplit; a.ci_tiles = ci_tiles;
+    pl.grid = dim3((unsigned)(ci_tiles * co_tiles * ksplit));
     *out = pl;
     return true;
 }

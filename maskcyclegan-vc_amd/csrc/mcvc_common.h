@@ -45,10 +45,11 @@ struct ConvArgs {
     int cic;               // input channels per LDS chunk (even)
     int nchunks, chunks_per_split, nsplit;
     int tow_log2;          // pixel tile width = 1 << tow_log2 (8, 16 or 32)
-    int tiles_w;
+    int tiles_w, tiles_total, nb;
     int PH, PW, PWp, PWh, plane, xs_floats;   // LDS patch geometry
     int out_mode;          // ConvOutMode
     int shuffle;           // 1: PixelShuffle(2) store  y[c=co>>2][2oh+((co>>1)&1)][2ow+(co&1)]
+    int dbg;               // timing-ablation bits (MCVC_CONV_DEBUG); 0 in production
 };
 
 struct ConvProblem {
@@ -74,7 +75,7 @@ struct WgradArgs {
     int toh, tow, tiles_h, tiles_w;
     int PH, PW, PWp, plane;
     int pitch_a;
-    int ksplit;
+    int ksplit, ci_tiles;
     int lane_mode;         // 0: N lane = ci ; 1: N lane = ci*KW + kw  (Cin*KW <= 32)
     int nkwg;              // kw groups per kh (lane_mode 0)
     int cot;               // output channels per block
