@@ -1,0 +1,14 @@
+"""MaskCycleGAN-VC inference flags (reference args/cycleGAN_test_arg_parser.py:16-26)."""
+from .base_arg_parser import BaseArgParser
+
+
+class CycleGANTestArgParser(BaseArgParser):
+    isTrain = False
+    FLAGS = [
+        ("--sample_rate", dict(type=int, default=22050, help="Sampling rate of mel-spectrograms.")),
+        ("--speaker_A_id", dict(type=str, default="VCC2SF3", help="Source speaker id (From VOC dataset).")),
+        ("--speaker_B_id", dict(type=str, default="VCC2TF1", help="Source speaker id (From VOC dataset).")),
+        ("--preprocessed_data_dir", dict(type=str, default="vcc2018_training_preprocessed/", help="Directory containing preprocessed dataset files.")),
+        ("--ckpt_dir", dict(type=str, default=None, help="Path to model ckpt.")),
+        ("--model_name", dict(type=str, choices=("generator_A2B", "generator_B2A"), default="generator_A2B", help="Name of model to load.")),
+    ]

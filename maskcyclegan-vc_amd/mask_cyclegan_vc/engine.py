@@ -96,39 +96,51 @@ class TrainEngine:
         # ---- packed weights
         self.packed = {n: torch.zeros(L.mcvc_gen_packed_floats(), device=dev) for n in G_NAMES}
         self.packed.update({n: torch.zeros(L.mcvc_disc_packed_floats(), device=dev) for n in D_NAMES})
-        # ---- activations / workspaces (static shapes -> graph-capturable)
-        # Passes that share weights and do not depend on each other run as ONE batched pass (mathematically
-        # identical: every op is per-sample).  Generator phase: G_A2B on [real_A|mask_A ; real_B|ones] and
-        # G_B2A on [real_B|mask_B ; real_A|ones] (translation + identity), then the two cycle passes.
-        # Discriminator phase: each discriminator sees [real ; generated] in one pass.
-        Tg = L.mcvc_gen_out_frames(T)
-        if Tg != T:
-            raise ValueError("training needs n_frames to be a multiple of 4 (the cycle must return the input length)")
-        T8 = L.mcvc_disc_out_frames(T)
-        B2 = 2 * B
-        f = lambda *s: torch.empty(s, device=dev)   # noqa: E731
-        self.g_stash2 = [f(L.mcvc_gen_stash_floats(B2, T)) for _ in range(2)]      # translation+identity passes
-        self.g_stash1 = [f(L.mcvc_gen_stash_floats(B, T)) for _ in range(2)]       # cycle passes
-        self.d_stash1 = [f(L.mcvc_disc_stash_floats(B, T)) for _ in range(4)]
-        self.d_stash2 = [f(L.mcvc_disc_stash_floats(B2, T)) for _ in range(4)]
-        self.g_scratch = f(max(L.mcvc_gen_scratch_floats(B, T), L.mcvc_gen_scratch_floats(B2, T)))
-        self.d_scratch = f(max(L.mcvc_disc_scratch_floats(B, T), L.mcvc_disc_scratch_floats(B2, T)))
-        mel2 = lambda: f(B2, 80, T)                  # noqa: E731
-        self.in_A2B, self.in_B2A = mel2(), mel2()              # [real_A ; real_B] and [real_B ; real_A]
-        self.mask_A2B = torch.ones(B2, 80, T, device=dev)      # [mask_A ; ones]
-        self.mask_B2A = torch.ones(B2, 80, T, device=dev)      # [mask_B ; ones]
-        self.out_A2B, self.out_B2A = mel2(), mel2()            # [fake_B ; identity_B] and [fake_A ; identity_A]
-        self.gout_A2B, self.gout_B2A = mel2(), mel2()          # gradients w.r.t. those outputs
-        self.mel = {k: f(B, 80, T) for k in ("cycle_A", "cycle_B", "g_cycle_A", "g_cycle_B", "gen_A", "gen_B", "cyc_A", "cyc_B")}
-        self.d_in = {n: mel2() for n in D_NAMES}               # discriminator phase: [real ; generated]
-        self.dout1 = [f(B, 1, 10, T8) for _ in range(4)]
-        self.dlogit1 = [f(B, 1, 10, T8) for _ in range(4)]
-        self.dout2 = [f(B2, 1, 10, T8) for _ in range(4)]
-        self.dlogit2 = [f(B2, 1, 10, T8) for _ in range(4)]
         self.slots = torch.zeros(16, device=dev)
+        self._workspaces = {}
+        self._use(batch_size)
         self.reducer.broadcast_(self.g_group.flat)
         self.reducer.broadcast_(self.d_group.flat)
         self.repack(G_NAMES + D_NAMES)
+
+    # ---- activations / workspaces: static shapes per batch size (graph-capturable), created on first use -----------
+    def _use(self, B):
+        """Bind the workspace set for per-GPU batch size ``B`` (the reference's DataLoader has drop_last=False, so the
+        last batch of an epoch may be smaller).
+
+        Passes that share weights and do not depend on each other run as ONE batched pass (mathematically identical:
+        every op is per-sample).  Generator phase: G_A2B on [real_A|mask_A ; real_B|ones] and G_B2A on
+        [real_B|mask_B ; real_A|ones] (translation + identity), then the two cycle passes.  Discriminator phase:
+        each discriminator sees [real ; generated] in one pass."""
+        ws = self._workspaces.get(B)
+        if ws is None:
+            L, T, dev = self.L, self.T, self.device
+            if L.mcvc_gen_out_frames(T) != T:
+                raise ValueError("training needs n_frames to be a multiple of 4 (the cycle must return the input length)")
+            T8 = L.mcvc_disc_out_frames(T)
+            B2 = 2 * B
+            f = lambda *s: torch.empty(s, device=dev)   # noqa: E731
+            mel2 = lambda: f(B2, 80, T)                  # noqa: E731
+            ws = dict(
+                g_stash2=[f(L.mcvc_gen_stash_floats(B2, T)) for _ in range(2)],      # translation+identity passes
+                g_stash1=[f(L.mcvc_gen_stash_floats(B, T)) for _ in range(2)],       # cycle passes
+                d_stash1=[f(L.mcvc_disc_stash_floats(B, T)) for _ in range(4)],
+                d_stash2=[f(L.mcvc_disc_stash_floats(B2, T)) for _ in range(4)],
+                g_scratch=f(max(L.mcvc_gen_scratch_floats(B, T), L.mcvc_gen_scratch_floats(B2, T))),
+                d_scratch=f(max(L.mcvc_disc_scratch_floats(B, T), L.mcvc_disc_scratch_floats(B2, T))),
+                in_A2B=mel2(), in_B2A=mel2(),                                          # [real_A ; real_B] and [real_B ; real_A]
+                mask_A2B=torch.ones(B2, 80, T, device=dev), mask_B2A=torch.ones(B2, 80, T, device=dev),   # [mask ; ones]
+                out_A2B=mel2(), out_B2A=mel2(),                                        # [fake_B ; identity_B], [fake_A ; identity_A]
+                gout_A2B=mel2(), gout_B2A=mel2(),                                      # gradients w.r.t. those outputs
+                mel={k: f(B, 80, T) for k in ("cycle_A", "cycle_B", "g_cycle_A", "g_cycle_B")},
+                d_in={n: mel2() for n in D_NAMES},                                     # discriminator phase: [real ; generated]
+                dout1=[f(B, 1, 10, T8) for _ in range(4)], dlogit1=[f(B, 1, 10, T8) for _ in range(4)],
+                dout2=[f(B2, 1, 10, T8) for _ in range(4)], dlogit2=[f(B2, 1, 10, T8) for _ in range(4)],
+            )
+            self._workspaces[B] = ws
+        self.B = B
+        for k, v in ws.items():
+            setattr(self, k, v)
 
     # ---- thin call helpers ------------------------------------------------------------------------
     def repack(self, names):
@@ -247,8 +259,10 @@ class TrainEngine:
         """One full iteration.  Inputs: float32 [B,80,T] on the engine's device.  Returns the loss-slot
         tensor (device); ``losses()`` does the host read the reference does with ``.item()`` (train.py:303)."""
         _hip.require_cuda_f32(real_A, mask_A, real_B, mask_B)
-        if tuple(real_A.shape) != (self.B, 80, self.T):
-            raise ValueError("batch shape %s does not match the engine (%d, 80, %d)" % (tuple(real_A.shape), self.B, self.T))
+        if tuple(real_A.shape[1:]) != (80, self.T):
+            raise ValueError("batch shape %s does not match the engine (B, 80, %d)" % (tuple(real_A.shape), self.T))
+        if real_A.shape[0] != self.B:
+            self._use(int(real_A.shape[0]))
         self.generator_phase(real_A, mask_A, real_B, mask_B)
         self.discriminator_phase(real_A, mask_A, real_B, mask_B)
         self.sched.end_iteration()
@@ -258,6 +272,18 @@ class TrainEngine:
         v = self.slots.tolist()      # device sync, like the reference's .item()
         return {"g_loss": v[SLOT_G], "d_loss": v[SLOT_D], "cycle_loss": v[SLOT_CYCLE], "identity_loss": v[SLOT_IDENT],
                 "adv_loss": v[SLOT_ADV_G]}
+
+    def optimizer(self, which):
+        """Adapter with ``state_dict()`` / ``load_state_dict()`` in torch.optim.Adam layout (for saver.ModelSaver)."""
+        eng = self
+
+        class _Adapter(object):
+            def state_dict(self):
+                return eng.optimizer_state_dict(which)
+
+            def load_state_dict(self, sd):
+                eng.load_optimizer_state_dict(which, sd)
+        return _Adapter()
 
     # ---- torch.optim.Adam-compatible optimizer state (checkpoint layout of the reference) -----------------
     def optimizer_state_dict(self, which):

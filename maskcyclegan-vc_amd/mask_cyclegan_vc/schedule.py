@@ -32,7 +32,8 @@ class StepSchedule:
         self.g_opt_lr = generator_lr
         self.d_opt_lr = discriminator_lr
         dataset_len = n_samples if dataset_len is None else dataset_len
-        self.global_step = (start_epoch - 1) * dataset_len                   # base_logger.py:55-56
+        # base_logger.py:53-56: round_down((epoch-1)*dataset_len, batch_size), python round()
+        self.global_step = int(batch_size * round(float((start_epoch - 1) * dataset_len) / batch_size))
 
     def end_iteration(self):
         """Call once per iteration after the optimizer steps (train.py:302-315)."""

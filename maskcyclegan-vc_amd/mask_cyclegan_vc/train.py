@@ -1,0 +1,122 @@
+"""``python -m mask_cyclegan_vc.train`` -- drop-in for the reference trainer (mask_cyclegan_vc/train.py).
+
+Same CLI (args/), same dataset files, same checkpoint layout, same per-iteration semantics (train.py:175-315); the
+arithmetic runs in the HIP engine (engine.py).  Launch one process per GPU with torchrun for data-parallel training
+(RCCL gradient all-reduce, parallel.py); a single process behaves exactly like the reference's single-device loop.
+
+Not built: the MelGAN vocoder load, validation figures and audio dumps of
+train.py:46-48, 317-358 -- they need network access and audio packages and are not on the step path."""
+import os
+import pickle
+
+import numpy as np
+import torch
+import torch.utils.data as data
+
+from args.cycleGAN_train_arg_parser import CycleGANTrainArgParser
+from dataset.vc_dataset import VCDataset
+from logger.train_logger import TrainLogger
+from saver.model_saver import ModelSaver
+
+from .engine import D_NAMES, G_NAMES, TrainEngine
+from .model import Discriminator, Generator
+from .parallel import FlatGradReducer, init_from_env
+from .schedule import StepSchedule
+
+NET_NAMES = G_NAMES + D_NAMES          # construction order of the reference (train.py:103-110)
+
+
+def load_speaker(preprocessed_dir, speaker_id):
+    """<dir>/<spk>/<spk>_normalized.pickle (list of float32 [80,T]) and <spk>_norm_stat.npz (reference train.py:51-64)."""
+    base = os.path.join(preprocessed_dir, speaker_id)
+    with open(os.path.join(base, "%s_normalized.pickle" % speaker_id), "rb") as fh:
+        mels = pickle.load(fh)
+    stat = np.load(os.path.join(base, "%s_norm_stat.npz" % speaker_id))
+    return mels, stat["mean"], stat["std"]
+
+
+class MaskCycleGANVCTraining(object):
+    def __init__(self, args):
+        self.args = args
+        self.rank, self.world, self.local_rank = init_from_env()
+        if not torch.cuda.is_available():
+            raise RuntimeError("mask_cyclegan_vc.train (MI355X build) needs a HIP device; there is no CPU path")
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank)
+        self.num_epochs = args.num_epochs
+        self.start_epoch = args.start_epoch
+        self.mini_batch_size = args.batch_size
+        self.epochs_per_save = args.epochs_per_save
+        self.dataset_A, self.dataset_A_mean, self.dataset_A_std = load_speaker(args.preprocessed_data_dir, args.speaker_A_id)
+        self.dataset_B, self.dataset_B_mean, self.dataset_B_std = load_speaker(args.preprocessed_data_dir, args.speaker_B_id)
+        self.n_samples = len(self.dataset_A)
+        print("n_samples = %d" % self.n_samples)
+        if self.world > 1:                       # every rank draws its own minibatches
+            np.random.seed(args.seed + self.rank)
+        self.dataset = VCDataset(datasetA=self.dataset_A, datasetB=self.dataset_B, n_frames=args.num_frames, max_mask_len=args.max_mask_len)
+        self.train_dataloader = data.DataLoader(dataset=self.dataset, batch_size=self.mini_batch_size, shuffle=True, drop_last=False)
+        self.logger = TrainLogger(args, len(self.train_dataloader.dataset), world_size=self.world)
+        self.saver = ModelSaver(args)            # like the reference, max_ckpts is not passed: nothing is pruned
+        # six networks in the reference's construction order; parse_args() seeded torch, so default init matches
+        torch.manual_seed(args.seed)
+        nets = {}
+        for n in NET_NAMES:
+            nets[n] = (Generator() if n in G_NAMES else Discriminator()).to(self.device)
+            setattr(self, n, nets[n])
+        self.nets = nets
+        sched = StepSchedule(generator_lr=args.generator_lr, discriminator_lr=args.discriminator_lr, num_epochs=args.num_epochs,
+                             n_samples=self.n_samples, batch_size=self.mini_batch_size, decay_after=args.decay_after,
+                             stop_identity_after=args.stop_identity_after, cycle_loss_lambda=args.cycle_loss_lambda,
+                             identity_loss_lambda=args.identity_loss_lambda, start_epoch=args.start_epoch,
+                             dataset_len=len(self.dataset), world_size=self.world)
+        sched.global_step = self.logger.global_step
+        self.engine = TrainEngine(nets, self.mini_batch_size, args.num_frames, schedule=sched,
+                                  reducer=FlatGradReducer(bucket_bytes=args.allreduce_bucket_mb << 20))
+        self.generator_optimizer = self.engine.optimizer("G")
+        self.discriminator_optimizer = self.engine.optimizer("D")
+        if args.continue_train:                  # reference train.py:125-137
+            self.saver.load_model(self.generator_A2B, "generator_A2B", None, self.generator_optimizer)
+            self.saver.load_model(self.generator_B2A, "generator_B2A", None, None)
+            self.saver.load_model(self.discriminator_A, "discriminator_A", None, self.discriminator_optimizer)
+            self.saver.load_model(self.discriminator_B, "discriminator_B", None, None)
+            self.saver.load_model(self.discriminator_A2, "discriminator_A2", None, None)
+            self.saver.load_model(self.discriminator_B2, "discriminator_B2", None, None)
+            self.engine.repack(NET_NAMES)
+
+    def save_all(self, epoch):
+        """Six files per epoch; the G optimizer state rides in both generator files and the D state in all four
+        discriminator files (reference train.py:361-373)."""
+        if self.rank != 0:
+            return
+        for n in NET_NAMES:
+            opt = self.generator_optimizer if n in G_NAMES else self.discriminator_optimizer
+            self.saver.save(epoch, self.nets[n], opt, None, self.device, n)
+
+    def train(self):
+        done = 0
+        for epoch in range(self.start_epoch, self.num_epochs + 1):
+            self.logger.start_epoch()
+            for real_A, mask_A, real_B, mask_B in self.train_dataloader:
+                self.logger.start_iter()
+                batch = [t.to(self.device, dtype=torch.float).contiguous() for t in (real_A, mask_A, real_B, mask_B)]
+                self.engine.step(*batch)                                   # G phase, D phase, lr / lambda bookkeeping
+                lo = self.engine.losses()                                  # host read, like .item() in train.py:303
+                self.logger.log_iter(loss_dict={"g_loss": lo["g_loss"], "d_loss": lo["d_loss"]})
+                self.logger.end_iter()
+                done += 1
+                if self.args.max_iters and done >= self.args.max_iters:
+                    break
+            if epoch % self.epochs_per_save == 0:
+                self.save_all(epoch)
+            self.logger.end_epoch()
+            if self.args.max_iters and done >= self.args.max_iters:
+                break
+
+
+def main(argv=None):
+    args = CycleGANTrainArgParser().parse_args(argv)
+    MaskCycleGANVCTraining(args).train()
+
+
+if __name__ == "__main__":
+    main()
