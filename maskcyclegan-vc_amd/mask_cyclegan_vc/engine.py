@@ -97,6 +97,11 @@ class TrainEngine:
         self.packed = {n: torch.zeros(L.mcvc_gen_packed_floats(), device=dev) for n in G_NAMES}
         self.packed.update({n: torch.zeros(L.mcvc_disc_packed_floats(), device=dev) for n in D_NAMES})
         self.slots = torch.zeros(16, device=dev)
+        # The A->B and B->A halves of the step are independent chains over different networks.  At small batch their
+        # kernels are latency-bound and far from filling 256 CUs, so the two chains run as two "lanes" on two HIP
+        # streams (lane 0 = the caller's stream) and overlap on the chip; join points are stream-event waits.
+        self.concurrent = True
+        self._side = torch.cuda.Stream(device=dev)
         self._workspaces = {}
         self._use(batch_size)
         self.reducer.broadcast_(self.g_group.flat)
@@ -126,8 +131,8 @@ class TrainEngine:
                 g_stash1=[f(L.mcvc_gen_stash_floats(B, T)) for _ in range(2)],       # cycle passes
                 d_stash1=[f(L.mcvc_disc_stash_floats(B, T)) for _ in range(4)],
                 d_stash2=[f(L.mcvc_disc_stash_floats(B2, T)) for _ in range(4)],
-                g_scratch=f(max(L.mcvc_gen_scratch_floats(B, T), L.mcvc_gen_scratch_floats(B2, T))),
-                d_scratch=f(max(L.mcvc_disc_scratch_floats(B, T), L.mcvc_disc_scratch_floats(B2, T))),
+                g_scratch=[f(max(L.mcvc_gen_scratch_floats(B, T), L.mcvc_gen_scratch_floats(B2, T))) for _ in range(2)],   # one per lane
+                d_scratch=[f(max(L.mcvc_disc_scratch_floats(B, T), L.mcvc_disc_scratch_floats(B2, T))) for _ in range(2)],
                 in_A2B=mel2(), in_B2A=mel2(),                                          # [real_A ; real_B] and [real_B ; real_A]
                 mask_A2B=torch.ones(B2, 80, T, device=dev), mask_B2A=torch.ones(B2, 80, T, device=dev),   # [mask ; ones]
                 out_A2B=mel2(), out_B2A=mel2(),                                        # [fake_B ; identity_B], [fake_A ; identity_A]
@@ -148,21 +153,37 @@ class TrainEngine:
             fn = self.L.mcvc_gen_pack if n in G_NAMES else self.L.mcvc_disc_pack
             check(fn(self._p_tab[n], ptr(self.packed[n]), stream()), "pack " + n)
 
-    def _G(self, name, x, mask, out, stash, nb):
+    def _lanes(self, fn0, fn1):
+        """Run fn0(lane=0) on the current stream and fn1(lane=1) on the side stream, then join."""
+        if not self.concurrent:
+            fn0(0); fn1(0)
+            return
+        main = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(main)
+        fn0(0)
+        with torch.cuda.stream(self._side):
+            fn1(1)
+        main.wait_stream(self._side)
+
+    def _G(self, name, x, mask, out, stash, nb, lane=0):
+        sc = self.g_scratch[lane]
         check(self.L.mcvc_gen_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(mask), ptr(out), ptr(stash),
-                                      ptr(self.g_scratch), self.g_scratch.numel(), nb, self.T, stream()), "gen_forward")
+                                      ptr(sc), sc.numel(), nb, self.T, stream()), "gen_forward")
 
-    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb):
+    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0):
+        sc = self.g_scratch[lane]
         check(self.L.mcvc_gen_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name], ptr(mask), ptr(dout), ptr(dx), acc,
-                                       ptr(stash), ptr(self.g_scratch), self.g_scratch.numel(), nb, self.T, stream()), "gen_backward")
+                                       ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream()), "gen_backward")
 
-    def _D(self, name, x, out, stash, nb):
-        check(self.L.mcvc_disc_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(out), ptr(stash), ptr(self.d_scratch),
-                                       self.d_scratch.numel(), nb, self.T, stream()), "disc_forward")
+    def _D(self, name, x, out, stash, nb, lane=0):
+        sc = self.d_scratch[lane]
+        check(self.L.mcvc_disc_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(out), ptr(stash), ptr(sc),
+                                       sc.numel(), nb, self.T, stream()), "disc_forward")
 
-    def _D_bwd(self, name, dlogit, dx, acc, stash, with_weight_grads, nb):
+    def _D_bwd(self, name, dlogit, dx, acc, stash, with_weight_grads, nb, lane=0):
+        sc = self.d_scratch[lane]
         check(self.L.mcvc_disc_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name] if with_weight_grads else None,
-                                        ptr(dlogit), 1, ptr(dx), acc, ptr(stash), ptr(self.d_scratch), self.d_scratch.numel(),
+                                        ptr(dlogit), 1, ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(),
                                         nb, self.T, stream()), "disc_backward")
 
     def _slot(self, i):
@@ -197,16 +218,22 @@ class TrainEngine:
         fake_A, identity_A = self.out_B2A[:B], self.out_B2A[B:]
         g_fake_B, g_identity_B = self.gout_A2B[:B], self.gout_A2B[B:]
         g_fake_A, g_identity_A = self.gout_B2A[:B], self.gout_B2A[B:]
-        self._G("generator_A2B", self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], B2)   # :203 fake_B  + :209-210 identity_B
-        self._G("generator_B2A", self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], B2)   # :205 fake_A  + :207-208 identity_A
-        self._G("generator_B2A", fake_B, None, m["cycle_A"], self.g_stash1[0], B)                  # :204 (mask of ones)
-        self._G("generator_A2B", fake_A, None, m["cycle_B"], self.g_stash1[1], B)                  # :206
         do, dl, ds = self.dout1, self.dlogit1, self.d_stash1
-        self._D("discriminator_A", fake_A, do[0], ds[0], B)              # :211
-        self._D("discriminator_B", fake_B, do[1], ds[1], B)              # :212
-        self._D("discriminator_A2", m["cycle_A"], do[2], ds[2], B)       # :215
-        self._D("discriminator_B2", m["cycle_B"], do[3], ds[3], B)       # :216
-        # losses (:219-237) and their gradients
+        # lane 0 follows real_A -> fake_B -> cycle_A, lane 1 follows real_B -> fake_A -> cycle_B
+        self._lanes(lambda ln: self._G("generator_A2B", self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], B2, ln),   # :203, :209-210
+                    lambda ln: self._G("generator_B2A", self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], B2, ln))   # :205, :207-208
+        self._lanes(lambda ln: self._G("generator_B2A", fake_B, None, m["cycle_A"], self.g_stash1[0], B, ln),                  # :204 (mask of ones)
+                    lambda ln: self._G("generator_A2B", fake_A, None, m["cycle_B"], self.g_stash1[1], B, ln))                  # :206
+
+        def d_fwd_a(ln):
+            self._D("discriminator_A", fake_A, do[0], ds[0], B, ln)              # :211
+            self._D("discriminator_A2", m["cycle_A"], do[2], ds[2], B, ln)       # :215
+
+        def d_fwd_b(ln):
+            self._D("discriminator_B", fake_B, do[1], ds[1], B, ln)              # :212
+            self._D("discriminator_B2", m["cycle_B"], do[3], ds[3], B, ln)       # :216
+        self._lanes(d_fwd_a, d_fwd_b)
+        # losses (:219-237) and their gradients (tiny single-block kernels; they share the loss slots -> one stream)
         self._l1(m["cycle_A"], real_A, sc.cycle_loss_lambda, m["g_cycle_A"], SLOT_CYCLE)
         self._l1(m["cycle_B"], real_B, sc.cycle_loss_lambda, m["g_cycle_B"], SLOT_CYCLE)
         self._l1(identity_A, real_A, sc.identity_loss_lambda, g_identity_A, SLOT_IDENT)
@@ -214,14 +241,19 @@ class TrainEngine:
         for i in range(4):
             self._lsgan(do[i], 1.0, 1.0, SLOT_G, SLOT_ADV_G, dl[i])
         # backward, in dependency order; discriminators contribute data-gradients only
-        self._D_bwd("discriminator_A2", dl[2], m["g_cycle_A"], 1, ds[2], False, B)
-        self._D_bwd("discriminator_B2", dl[3], m["g_cycle_B"], 1, ds[3], False, B)
-        self._D_bwd("discriminator_A", dl[0], g_fake_A, 0, ds[0], False, B)
-        self._D_bwd("discriminator_B", dl[1], g_fake_B, 0, ds[1], False, B)
-        self._G_bwd("generator_B2A", None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B)       # cycle_A = G_B2A(fake_B)
-        self._G_bwd("generator_A2B", None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B)       # cycle_B = G_A2B(fake_A)
-        self._G_bwd("generator_A2B", self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2)
-        self._G_bwd("generator_B2A", self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2)
+
+        def d_bwd_a(ln):
+            self._D_bwd("discriminator_A2", dl[2], m["g_cycle_A"], 1, ds[2], False, B, ln)
+            self._D_bwd("discriminator_A", dl[0], g_fake_A, 0, ds[0], False, B, ln)
+
+        def d_bwd_b(ln):
+            self._D_bwd("discriminator_B2", dl[3], m["g_cycle_B"], 1, ds[3], False, B, ln)
+            self._D_bwd("discriminator_B", dl[1], g_fake_B, 0, ds[1], False, B, ln)
+        self._lanes(d_bwd_a, d_bwd_b)
+        self._lanes(lambda ln: self._G_bwd("generator_B2A", None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B, ln),   # cycle_A = G_B2A(fake_B)
+                    lambda ln: self._G_bwd("generator_A2B", None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, ln))   # cycle_B = G_A2B(fake_A)
+        self._lanes(lambda ln: self._G_bwd("generator_A2B", self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2, ln),
+                    lambda ln: self._G_bwd("generator_B2A", self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2, ln))
         self.reducer.reduce_(self.g_group.grad)
         self._adam(self.g_group, sc.g_opt_lr)                                             # :242
         self.repack(G_NAMES)
@@ -239,18 +271,28 @@ class TrainEngine:
         cyc_A, cyc_B = di["discriminator_A2"][B:], di["discriminator_B2"][B:]
         di["discriminator_A"][:B].copy_(real_A); di["discriminator_A2"][:B].copy_(real_A)
         di["discriminator_B"][:B].copy_(real_B); di["discriminator_B2"][:B].copy_(real_B)
-        self._G("generator_B2A", real_B, mask_B, gen_A, self.g_stash1[0], B)     # :259 generated_A
-        self._G("generator_A2B", gen_A, None, cyc_B, self.g_stash1[1], B)        # :263 cycled_B
-        self._G("generator_A2B", real_A, mask_A, gen_B, self.g_stash1[0], B)     # :267 generated_B
-        self._G("generator_B2A", gen_B, None, cyc_A, self.g_stash1[1], B)        # :271 cycled_A
+        def chain_a(ln):
+            self._G("generator_B2A", real_B, mask_B, gen_A, self.g_stash1[0], B, ln)     # :259 generated_A
+            self._G("generator_A2B", gen_A, None, cyc_B, self.g_stash1[0], B, ln)        # :263 cycled_B
+
+        def chain_b(ln):
+            self._G("generator_A2B", real_A, mask_A, gen_B, self.g_stash1[1], B, ln)     # :267 generated_B
+            self._G("generator_B2A", gen_B, None, cyc_A, self.g_stash1[1], B, ln)        # :271 cycled_A
+        self._lanes(chain_a, chain_b)
         do, dl, ds = self.dout2, self.dlogit2, self.d_stash2
+        idx = {n: i for i, n in enumerate(D_NAMES)}
+
+        def d_fwd(names):
+            return lambda ln: [self._D(n, di[n], do[idx[n]], ds[idx[n]], B2, ln) for n in names]   # :255-258 real half, :260-273 generated half
+        self._lanes(d_fwd(("discriminator_A", "discriminator_A2")), d_fwd(("discriminator_B", "discriminator_B2")))
         # d_loss = (A + B)/2 + (A_2nd + B_2nd)/2 with each = (real + fake)/2  -> every term weighs 1/4  (:276-294)
-        for i, n in enumerate(D_NAMES):
-            self._D(n, di[n], do[i], ds[i], B2)                                  # :255-258 real half, :260-273 generated half
+        for i in range(4):
             self._lsgan(do[i][:B], 1.0, 0.25, SLOT_D, SLOT_D_REAL, dl[i][:B])
             self._lsgan(do[i][B:], 0.0, 0.25, SLOT_D, SLOT_D_FAKE, dl[i][B:])
-        for i, n in enumerate(D_NAMES):
-            self._D_bwd(n, dl[i], None, 0, ds[i], True, B2)
+
+        def d_bwd(names):
+            return lambda ln: [self._D_bwd(n, dl[idx[n]], None, 0, ds[idx[n]], True, B2, ln) for n in names]
+        self._lanes(d_bwd(("discriminator_A", "discriminator_A2")), d_bwd(("discriminator_B", "discriminator_B2")))
         self.reducer.reduce_(self.d_group.grad)
         self._adam(self.d_group, sc.d_opt_lr)                                            # :299
         self.repack(D_NAMES)
