@@ -66,13 +66,13 @@ def trace_one_step(engine, batch):
     nk = L.mcvc_trace_kinds()
     buf = (ctypes.c_double * (4 * nk))()
     torch.cuda.synchronize()
-    was = engine.concurrent
-    engine.concurrent = False          # per-kernel durations are only meaningful when launches do not overlap
+    was = (engine.concurrent, engine.use_graphs, engine.aux_wgrad)
+    engine.concurrent = engine.use_graphs = engine.aux_wgrad = False   # per-kernel durations need non-overlapping eager launches
     L.mcvc_trace_enable(1)
     engine.step(*batch)
     L.mcvc_trace_collect(buf)
     L.mcvc_trace_enable(0)
-    engine.concurrent = was
+    engine.concurrent, engine.use_graphs, engine.aux_wgrad = was
     rows = []
     for k in range(nk):
         n, ms, fl, by = buf[4 * k:4 * k + 4]
@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=12, help="timed CPU-baseline iterations (0 = skip)")
     ap.add_argument("--no-trace", action="store_true")
     ap.add_argument("--serial", action="store_true", help="disable the two-stream lane overlap (A/B comparison)")
+    ap.add_argument("--graphs", action="store_true", help="replay HIP graphs of the two phases (experimental; not faster on ROCm 7.2)")
     ap.add_argument("--dump-trace", default=None, help="write one traced step's per-launch records (launch order) to this file")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")
     args = ap.parse_args()
@@ -148,6 +149,9 @@ def main():
                          decay_after=2e5, stop_identity_after=1e4, world_size=world)     # bash_scripts/mask_cyclegan_train.sh
     engine = TrainEngine(nets, B, T, schedule=sched, reducer=FlatGradReducer())
     engine.concurrent = not args.serial
+    engine.use_graphs = args.graphs
+    if args.graphs:
+        engine.aux_wgrad = False            # lanes + auxiliary streams in one capture crash hipStreamEndCapture (ROCm 7.2)
     batches = synthetic_batches(16, B, T, rank, device)
     log("engine ready; warm-up")
 
@@ -183,13 +187,13 @@ def main():
         L = _hip.lib()
         buf = (ctypes.c_double * (4 * 8192))()
         torch.cuda.synchronize()
-        was = engine.concurrent
-        engine.concurrent = False
+        was = (engine.concurrent, engine.use_graphs, engine.aux_wgrad)
+        engine.concurrent = engine.use_graphs = engine.aux_wgrad = False
         L.mcvc_trace_enable(1)
         engine.step(*batches[0])
         n = L.mcvc_trace_collect_raw(buf, 8192)
         L.mcvc_trace_enable(0)
-        engine.concurrent = was
+        engine.concurrent, engine.use_graphs, engine.aux_wgrad = was
         with open(args.dump_trace, "w") as fh:
             for i in range(n):
                 k, ms, fl, by = buf[4 * i:4 * i + 4]

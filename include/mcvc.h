@@ -54,7 +54,9 @@ int mcvc_gen_forward(const float* const* params, const float* packed, const floa
 /*      dout: [B,80,T'] ; dx (nullable): [B,80,T], written or accumulated (accumulate_dx != 0)      */
 int mcvc_gen_backward(const float* const* params, const float* packed, float* const* grads, const float* mask,
                       const float* dout, float* dx, int accumulate_dx, const float* stash,
-                      float* scratch, long long scratch_floats, int B, int T, void* stream);
+                      float* scratch, long long scratch_floats, int B, int T, void* stream, void* aux_stream);
+/*      aux_stream (nullable): a second hipStream_t on which the weight-gradient kernels run beside the data-gradient
+ *      chain; the call returns with `stream` ordered after everything launched on aux_stream.            */
 
 /* ---- Discriminator: replaces Discriminator.forward (model.py:340-349) and its autograd
  *      x: [B,80,T]; out: [B,1,10,T8] sigmoid probabilities                                          */
@@ -65,7 +67,8 @@ int mcvc_disc_forward(const float* const* params, const float* packed, const flo
  *      train.py:211-216 -- the reference computes D weight grads there and discards them).          */
 int mcvc_disc_backward(const float* const* params, const float* packed, float* const* grads,
                        const float* dout, int dout_is_logit_grad, float* dx, int accumulate_dx,
-                       const float* stash, float* scratch, long long scratch_floats, int B, int T, void* stream);
+                       const float* stash, float* scratch, long long scratch_floats, int B, int T, void* stream,
+                       void* aux_stream);
 
 /* ---- losses (train.py:219-237, 276-294). loss_slot/term_slot: device floats, accumulated (+=) -- */
 /* loss_slot += weight*mean|a-b|, term_slot += mean|a-b|, grad_a (=|+=) weight*sign(a-b)/n           */

@@ -248,8 +248,11 @@ __global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
                     float v = acc[i][j][r];
                     if (add_bias) v += a.bias[co];
                     long long off;
-                    if (a.shuffle)
-                        off = (long long)(co >> 2) * a.y_sc + (long long)(2 * oh + ((co >> 1) & 1)) * a.y_sh + (2 * ow + (co & 1));
+                    if (a.shuffle) {
+                        const int yh = 2 * oh + ((co >> 1) & 1), yw = 2 * ow + (co & 1);
+                        if (yh >= a.YH || yw >= a.YW) continue;
+                        off = (long long)(co >> 2) * a.y_sc + (long long)yh * a.y_sh + yw;
+                    }
                     else
                         off = (long long)co * a.y_sc + (long long)oh * a.y_sh + (long long)ow * a.y_sw;
                     if (a.out_mode == CONV_OUT_ACCUM) {
@@ -459,6 +462,7 @@ int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float
     a.out_mode = io.accumulate ? CONV_OUT_ACCUM : CONV_OUT_SLAB;
     a.dbg = conv_debug_bits();
     a.shuffle = io.shuffle;
+    a.YH = io.YH > 0 ? io.YH : 2 * p.OH; a.YW = io.YW > 0 ? io.YW : 2 * p.OW;
     if (nsplit_out) *nsplit_out = a.nsplit;
     hipError_t e;
     switch (pl.cfg) {

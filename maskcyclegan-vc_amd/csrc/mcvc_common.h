@@ -49,6 +49,7 @@ struct ConvArgs {
     int PH, PW, PWp, PWh, plane, xs_floats;   // LDS patch geometry
     int out_mode;          // ConvOutMode
     int shuffle;           // 1: PixelShuffle(2) store  y[c=co>>2][2oh+((co>>1)&1)][2ow+(co&1)]
+    int YH, YW;            // shuffle mode: bounds of the shuffled image (rows/cols beyond are not stored)
     int dbg;               // timing-ablation bits (MCVC_CONV_DEBUG); 0 in production
 };
 
@@ -158,6 +159,7 @@ struct ConvIO {
     int nsplit;                                            // exact K-split count (>=1); planned by the caller
     int accumulate;                                        // 1: y += conv (atomic when nsplit > 1)
     int shuffle;
+    int YH, YW;                                            // shuffle bounds (0 = 2*OH, 2*OW)
 };
 
 int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float* wpk, int w_rows, int w_cout,

@@ -18,6 +18,9 @@
 #include "misc.h"
 #include "../../include/mcvc.h"
 #include <string.h>
+#include <map>
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -35,8 +38,52 @@ struct Exec {
     long long slab_cap;
     long long slab_need;
     int max_split;                 // 0 = planner default (<= 64)
+    // weight gradients are off the critical path of a backward pass: with an auxiliary stream they run beside the
+    // data-gradient chain.  `readers` remembers, per dY buffer, the event after which its last aux-stream reader is done.
+    hipStream_t s2;
+    float* wslabs;
+    long long wslab_cap;
+    long long wslab_need;
+    std::vector<std::pair<const void*, hipEvent_t>> readers;
     void fail(int e) { if (!err && e) err = e; }
 };
+
+// small pool of timing-less events, reused round-robin (a backward pass uses a few dozen; the pool is far larger, so an
+// event is never re-recorded while a wait on its previous use can still be pending)
+static hipEvent_t pool_event()
+{
+    static std::mutex mu;
+    static std::vector<hipEvent_t> pool;
+    static size_t next = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (pool.size() < 1024) {
+        hipEvent_t e;
+        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        pool.push_back(e);
+        return e;
+    }
+    next = (next + 1) % pool.size();
+    return pool[next];
+}
+
+// the main stream is about to overwrite `buf`: wait for aux-stream kernels that still read it
+static void wait_readers(Exec& ex, const void* buf)
+{
+    if (!ex.s2 || ex.dry) return;
+    for (auto it = ex.readers.begin(); it != ex.readers.end();) {
+        if (it->first == buf) { ex.fail((int)hipStreamWaitEvent(ex.s, it->second, 0)); it = ex.readers.erase(it); }
+        else ++it;
+    }
+}
+
+static void join_aux(Exec& ex)
+{
+    if (!ex.s2 || ex.dry) return;
+    hipEvent_t e = pool_event();
+    ex.fail((int)hipEventRecord(e, ex.s2));
+    ex.fail((int)hipStreamWaitEvent(ex.s, e, 0));
+    ex.readers.clear();
+}
 
 // -------------------------------------------------------------------------------------------------
 struct ConvSpec {
@@ -48,6 +95,9 @@ struct ConvSpec {
     long long off_fwd, off_bias, off_dgrad;
     int ncls;
     DgradClass cls[4];
+    // stride 2: the four output-parity classes are ONE stride-1 conv with 4*Cin output channels (4*ci + 2*qh + qw) whose
+    // taps are zero-padded to a common window; its PixelShuffle(2) store scatters straight into dX[ci][2a+qh][2b+qw]
+    int merged, mg_kh, mg_kw, mg_pad_h, mg_pad_w, mg_ld;
 };
 
 static void spec_finalize(ConvSpec& c, long long& cur)
@@ -76,9 +126,27 @@ static void spec_finalize(ConvSpec& c, long long& cur)
             k.pad_w = (k.kwmax - qw - c.pw) / st;
             k.qh = qh; k.qw = qw;
             k.offset = cur - c.off_dgrad;
-            cur += ((long long)c.dg_rows_co * k.nth * k.ntw + 1) * c.cin_pk;   // + zero pad row
+            if (st == 1) cur += ((long long)c.dg_rows_co * k.nth * k.ntw + 1) * c.cin_pk;   // + zero pad row
             c.cls[c.ncls++] = k;
         }
+    }
+    c.merged = 0;
+    if (st == 2) {
+        c.merged = 1;
+        c.mg_pad_h = c.mg_pad_w = 0;
+        for (int k = 0; k < c.ncls; ++k) {
+            if (c.cls[k].pad_h > c.mg_pad_h) c.mg_pad_h = c.cls[k].pad_h;
+            if (c.cls[k].pad_w > c.mg_pad_w) c.mg_pad_w = c.cls[k].pad_w;
+        }
+        c.mg_kh = c.mg_kw = 1;
+        for (int k = 0; k < c.ncls; ++k) {
+            DgradClass& d = c.cls[k];
+            d.su = c.mg_pad_h - d.pad_h; d.sv = c.mg_pad_w - d.pad_w; d.offset = 0;
+            if (d.su + d.nth > c.mg_kh) c.mg_kh = d.su + d.nth;
+            if (d.sv + d.ntw > c.mg_kw) c.mg_kw = d.sv + d.ntw;
+        }
+        c.mg_ld = round_up_i(4 * c.Cin, 32);
+        cur += ((long long)c.dg_rows_co * c.mg_kh * c.mg_kw + 1) * c.mg_ld;                  // + zero pad row
     }
     cur = (cur + 3) & ~3LL;
 }
@@ -131,6 +199,15 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
 {
     const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
     const int st = c.stride;
+    if (c.merged) {
+        ConvProblem p{c.cout_tot, OH, OW, 4 * c.Cin, (H + 1) / 2, (W + 1) / 2, c.mg_kh, c.mg_kw, 1, c.mg_pad_h, c.mg_pad_w};
+        ConvIO io{};
+        io.x = dy.p; io.x_sb = dy.sb; io.x_sc = dy.sc; io.x_sh = dy.sh;
+        io.y = dx.p; io.y_sb = dx.sb; io.y_sc = dx.sc; io.y_sh = dx.sh; io.y_sw = 1;
+        io.accumulate = accumulate; io.shuffle = 1; io.YH = H; io.YW = W;
+        run_conv(ex, p, NB, io, dx_total, packed + c.off_dgrad, c.dg_rows_co * c.mg_kh * c.mg_kw, c.mg_ld, nullptr, allow_split, 0, nsplit);
+        return;
+    }
     ConvProblem ps[4];
     int force = 0;
     for (int k = 0; k < c.ncls; ++k) {
@@ -168,17 +245,29 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
 {
     const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
     ConvProblem p{c.Cin, H, W, c.Cout, OH, OW, c.KH, c.KW, c.stride, c.ph, c.pw};
-    if (ex.dry) {          // the K-split slabs share the conv slab scratch (never live at the same time)
+    if (ex.dry) {          // K-split slabs: their own region, so they never alias the data-gradient slabs of the main stream
         const long long need = mcvc_wgrad_plan_slab_floats(p, NB);
-        if (need > ex.slab_need) ex.slab_need = need;
+        if (need > ex.wslab_need) ex.wslab_need = need;
         return;
     }
     if (!grads) return;
+    hipStream_t ws = ex.s;
+    if (ex.s2) {           // dY (and x) are complete on the main stream at this point
+        hipEvent_t e = pool_event();
+        ex.fail((int)hipEventRecord(e, ex.s));
+        ex.fail((int)hipStreamWaitEvent(ex.s2, e, 0));
+        ws = ex.s2;
+    }
     for (int br = 0; br < c.nbr; ++br) {
         float* dw = grads[c.wi[br]];
         if (!dw) continue;
         WgradIO io{x.p, x.sb, x.sc, x.sh, dy.p + (long long)br * c.Cout * dy.sc, dy.sb, dy.sc, dy.sh};
-        ex.fail(mcvc_wgrad_launch(p, NB, io, dw, ex.slabs, ex.slab_cap, ex.s));
+        ex.fail(mcvc_wgrad_launch(p, NB, io, dw, ex.wslabs, ex.wslab_cap, ws));
+    }
+    if (ex.s2) {
+        hipEvent_t e = pool_event();
+        ex.fail((int)hipEventRecord(e, ex.s2));
+        ex.readers.emplace_back((const void*)dy.p, e);
     }
 }
 
@@ -200,7 +289,8 @@ static void pack_spec(Exec& ex, const ConvSpec& c, const float* const* params, f
         ex.fail(mcvc_pack_fwd_launch(w, packed + c.off_fwd, c.Cout, K, c.cout_pk, br * c.Cout, ex.s));
         ex.fail(mcvc_copy_launch(params[c.bi[br]], packed + c.off_bias + br * c.Cout, c.Cout, ex.s));
         PackDgradArgs a{};
-        a.Cin = c.Cin; a.KH = c.KH; a.KW = c.KW; a.step = c.stride; a.ld = c.cin_pk; a.co_off = br * c.Cout; a.ncls = c.ncls;
+        a.Cin = c.Cin; a.KH = c.KH; a.KW = c.KW; a.step = c.stride; a.ld = c.merged ? c.mg_ld : c.cin_pk; a.co_off = br * c.Cout; a.ncls = c.ncls;
+        a.merged = c.merged; a.mg_kh = c.mg_kh; a.mg_kw = c.mg_kw;
         for (int k = 0; k < c.ncls; ++k) a.cls[k] = c.cls[k];
         ex.fail(mcvc_pack_dgrad_launch(w, packed + c.off_dgrad, a, c.Cout, ex.s));
     }
@@ -239,6 +329,7 @@ static void norm_bwd(Exec& ex, const float* x, long long x_sn, long long x_sc, c
                      float* dx, long long dx_sn, long long dx_sc, int dx_sh, int unshuffle, int N, int C, int H, int W, int act)
 {
     if (ex.dry) return;
+    wait_readers(ex, dx);
     NormBwdArgs a{};
     a.x = x; a.x_sn = x_sn; a.x_sc = x_sc;
     a.gamma[0] = np.g[0]; a.gamma[1] = np.g[1]; a.beta[0] = np.b[0]; a.beta[1] = np.b[1];
@@ -259,6 +350,7 @@ static void act_fwd(Exec& ex, float* x, long long x_total, int nslab, float* y, 
 static void act_bwd(Exec& ex, const float* x, float* dy, long long dy_total, int nslab, float* dx, int N, int C, int P, int act)
 {
     if (ex.dry) return;
+    wait_readers(ex, dx);
     ActBwdArgs a{}; a.x = x; a.dy = dy; a.dy_slabs = ex.slabs; a.slab_stride = dy_total; a.nslab = nslab; a.dx = dx; a.N = N; a.C = C; a.P = P; a.act = act;
     ex.fail(mcvc_act_bwd_launch(a, ex.s));
 }
@@ -339,15 +431,15 @@ static GenStash gen_stash(const GenDims& d)
     return s;
 }
 
-struct GenScratch { long long ga, gb, dh, dt1, dt2, dt3, slabs; };
+struct GenScratch { long long ga, gb, gb2, dh, dt1, dt1b, dt2, dt3, dt3b, slabs; };
 static GenScratch gen_scratch(const GenDims& d)
 {
     GenScratch s{};
     long long cur = 0;
     auto take = [&](long long n) { const long long o = cur; cur += (n + 3) & ~3LL; return o; };
-    s.ga = take(d.big); s.gb = take(d.big);
-    s.dh = take((long long)256 * d.B * d.W4); s.dt1 = take((long long)1024 * d.B * d.W4);
-    s.dt2 = take((long long)512 * d.B * d.W4); s.dt3 = take((long long)256 * d.B * d.W4);
+    s.ga = take(d.big); s.gb = take(d.big); s.gb2 = take(d.big);
+    s.dh = take((long long)256 * d.B * d.W4); s.dt1 = take((long long)1024 * d.B * d.W4); s.dt1b = take((long long)1024 * d.B * d.W4);
+    s.dt2 = take((long long)512 * d.B * d.W4); s.dt3 = take((long long)256 * d.B * d.W4); s.dt3b = take((long long)256 * d.B * d.W4);
     s.slabs = cur;
     return s;
 }
@@ -419,8 +511,16 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
     float* st = const_cast<float*>(stc);     // stash is read-only here; kernels take non-const for slab-reduce paths that are not used on it
     const int B = d.B, T = d.T, W2 = d.W2, W4 = d.W4, Wu1 = d.Wu1, Wu2 = d.Wu2;
     const long long BT4 = (long long)B * W4;
-    float* GA = sc + q.ga; float* GB = sc + q.gb;
-    float* DH = sc + q.dh; float* DT1 = sc + q.dt1; float* DT2 = sc + q.dt2; float* DT3 = sc + q.dt3;
+    // dY buffers alternate between two copies so an aux-stream weight gradient can still read layer k's dY while the
+    // main stream already produces layer k-1's
+    float* GA = sc + q.ga;
+    float* GBs[2] = {sc + q.gb, sc + q.gb2};
+    float* DT1s[2] = {sc + q.dt1, sc + q.dt1b};
+    float* DT3s[2] = {sc + q.dt3, sc + q.dt3b};
+    int gbi = 0;
+    auto nextGB = [&]() { gbi ^= 1; return GBs[gbi]; };
+    float* GB = GBs[0];
+    float* DH = sc + q.dh; float* DT1 = DT1s[0]; float* DT2 = sc + q.dt2; float* DT3 = DT3s[0];
     int ns = 1;
     // ---- last conv (model.py:278)
     {
@@ -431,6 +531,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         conv_dgrad(ex, g.last, packed, B, 80, Wu2, dyv, View{GA, 128LL * 80 * Wu2, 80LL * Wu2, Wu2}, (long long)B * 128 * 80 * Wu2, 0, 1, &ns);
     }
     // ---- upSample2 (:275): IN+SiLU backward, un-shuffled into conv-output coordinates [B][512][40][Wu1]
+    GB = nextGB();
     norm_bwd(ex, st + o.c8, 128LL * 80 * Wu2, 80LL * Wu2, normp(P, G, 102, 103), st + o.s8, GA, 128LL * 80 * Wu2, 80LL * Wu2, Wu2,
              (long long)B * 128 * 80 * Wu2, ns, GB, 512LL * 40 * Wu1, 40LL * Wu1, Wu1, 1, B, 128, 80, Wu2, ACT_SILU);
     {
@@ -441,6 +542,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         conv_dgrad(ex, g.up2, packed, B, 40, Wu1, dyv, View{GA, 256LL * 40 * Wu1, 40LL * Wu1, Wu1}, (long long)B * 256 * 40 * Wu1, 0, 1, &ns);
     }
     // ---- upSample1 (:274)
+    GB = nextGB();
     norm_bwd(ex, st + o.c7, 256LL * 40 * Wu1, 40LL * Wu1, normp(P, G, 106, 107), st + o.s7, GA, 256LL * 40 * Wu1, 40LL * Wu1, Wu1,
              (long long)B * 256 * 40 * Wu1, ns, GB, 1024LL * 20 * W4, 20LL * W4, W4, 1, B, 256, 40, Wu1, ACT_SILU);
     {
@@ -451,6 +553,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         conv_dgrad(ex, g.up1, packed, B, 20, W4, dyv, View{GA, 256LL * 20 * W4, 20LL * W4, W4}, (long long)B * 5120 * W4, 0, 1, &ns);
     }
     // ---- conv1dto2d + IN (:266-271): dy arrives NCHW, dx leaves in trunk layout
+    GB = nextGB();
     norm_bwd(ex, st + o.c6, W4, BT4, normp(P, G, 98, 99), st + o.s6, GA, 5120LL * W4, W4, W4, 5120 * BT4, ns,
              GB, W4, BT4, W4, 0, B, 5120, 1, W4, ACT_NONE);
     {
@@ -463,6 +566,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
     for (int i = 5; i >= 0; --i) {
         const int b = 24 + 12 * i;
         const float* hin = (i == 0) ? (st + o.y4) : (st + o.r[i - 1].y);
+        DT3 = DT3s[i & 1]; DT1 = DT1s[i & 1];
         norm_bwd(ex, st + o.r[i].cb, W4, BT4, normp(P, G, b + 10, b + 11), st + o.r[i].sb, DH, W4, BT4, W4, 256 * BT4, ns,
                  DT3, W4, BT4, W4, 0, B, 256, 1, W4, ACT_NONE);
         int ns2 = 1;
@@ -481,6 +585,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         ns = 1;
     }
     // ---- conv2dto1d + IN (:254-255)
+    DT3 = DT3s[1];
     norm_bwd(ex, st + o.c4, W4, BT4, normp(P, G, 22, 23), st + o.s4, DH, W4, BT4, W4, 256 * BT4, 1, DT3, W4, BT4, W4, 0, B, 256, 1, W4, ACT_NONE);
     {
         CView dyv{DT3, 0, BT4, W4};
@@ -488,6 +593,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         conv_dgrad(ex, g.c2d1d, packed, 1, B, W4, dyv, View{GA, 0, BT4, W4}, 5120 * BT4, 0, 1, &ns);
     }
     // ---- downSample2 (:246): dy is in trunk layout
+    GB = nextGB();
     norm_bwd(ex, st + o.c3, 512LL * 20 * W4, 20LL * W4, normp(P, G, 14, 15, 18, 19), st + o.s3, GA, W4, 20LL * BT4, (int)BT4, 5120 * BT4, ns,
              GB, 512LL * 20 * W4, 20LL * W4, W4, 0, B, 256, 20, W4, ACT_GLU);
     {
@@ -496,6 +602,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         conv_dgrad(ex, g.ds2, packed, B, 40, W2, dyv, View{GA, 256LL * 40 * W2, 40LL * W2, W2}, (long long)B * 256 * 40 * W2, 0, 1, &ns);
     }
     // ---- downSample1 (:245)
+    GB = nextGB();
     norm_bwd(ex, st + o.c2, 512LL * 40 * W2, 40LL * W2, normp(P, G, 6, 7, 10, 11), st + o.s2, GA, 256LL * 40 * W2, 40LL * W2, W2,
              (long long)B * 256 * 40 * W2, ns, GB, 512LL * 40 * W2, 40LL * W2, W2, 0, B, 256, 40, W2, ACT_GLU);
     {
@@ -504,6 +611,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         conv_dgrad(ex, g.ds1, packed, B, 80, T, dyv, View{GA, 128LL * 80 * T, 80LL * T, T}, (long long)B * 128 * 80 * T, 0, 1, &ns);
     }
     // ---- conv1 gated GLU (:242)
+    GB = nextGB();
     act_bwd(ex, st + o.c1, GA, (long long)B * 128 * 80 * T, ns, GB, B, 128, 80 * T, ACT_GLU);
     {
         CView dyv{GB, 256LL * 80 * T, 80LL * T, T};
@@ -514,6 +622,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
             if (!ex.dry) ex.fail(mcvc_mask_grad_launch(GA, ex.slabs, (long long)B * 2 * 80 * T, ns, mask, dx, B, 80 * T, 2, accumulate_dx, ex.s));
         }
     }
+    join_aux(ex);
 }
 
 // =================================================================================================
@@ -564,11 +673,11 @@ static DiscStash disc_stash(const DiscDims& d)
     s.total = cur;
     return s;
 }
-struct DiscScratch { long long ga, gb, slabs; };
+struct DiscScratch { long long ga, gb, gb2, slabs; };
 static DiscScratch disc_scratch(const DiscDims& d)
 {
     DiscScratch s{};
-    s.ga = 0; s.gb = (d.big + 3) & ~3LL; s.slabs = 2 * s.gb;
+    s.ga = 0; s.gb = (d.big + 3) & ~3LL; s.gb2 = 2 * s.gb; s.slabs = 3 * s.gb;
     return s;
 }
 
@@ -606,7 +715,11 @@ static void disc_backward_impl(Exec& ex, const float* const* P, const float* pac
     const DiscScratch q = disc_scratch(d);
     float* st = const_cast<float*>(stc);
     const int B = d.B, T = d.T;
-    float* GA = sc + q.ga; float* GB = sc + q.gb;
+    float* GA = sc + q.ga;
+    float* GBs[2] = {sc + q.gb, sc + q.gb2};
+    int gbi = 0;
+    auto nextGB = [&]() { gbi ^= 1; return GBs[gbi]; };
+    float* GB = GBs[0];
     const int H3 = d.H[3], W3 = d.W[3];
     int ns = 1;
     const float* dlogit = dout;
@@ -626,6 +739,7 @@ static void disc_backward_impl(Exec& ex, const float* const* P, const float* pac
     }
     for (int i = 2; i >= 0; --i) {
         const int Ci = kDC[i], Co = kDC[i + 1], Hi = d.H[i], Wi = d.W[i], Ho = d.H[i + 1], Wo = d.W[i + 1];
+        GB = nextGB();
         norm_bwd(ex, st + o.c[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, normp(P, G, 4 + 4 * i, 5 + 4 * i), st + o.s[i],
                  GA, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo, (long long)B * Co * Ho * Wo, ns,
                  GB, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo, 0, B, Co, Ho, Wo, ACT_SILU);
@@ -634,6 +748,7 @@ static void disc_backward_impl(Exec& ex, const float* const* P, const float* pac
         conv_wgrad(ex, n.ds[i], G, B, Hi, Wi, CView{hin, (long long)Ci * Hi * Wi, (long long)Hi * Wi, Wi}, dyv);
         conv_dgrad(ex, n.ds[i], packed, B, Hi, Wi, dyv, View{GA, (long long)Ci * Hi * Wi, (long long)Hi * Wi, Wi}, (long long)B * Ci * Hi * Wi, 0, 1, &ns);
     }
+    GB = nextGB();
     act_bwd(ex, st + o.c0, GA, (long long)B * 128 * 80 * T, ns, GB, B, 128, 80 * T, ACT_SILU);
     {
         CView dyv{GB, 128LL * 80 * T, 80LL * T, T};
@@ -645,15 +760,60 @@ static void disc_backward_impl(Exec& ex, const float* const* P, const float* pac
             if (!ex.dry) ex.fail(mcvc_mask_grad_launch(GA, ex.slabs, (long long)B * 80 * T, ns, nullptr, dx, B, 80 * T, 1, accumulate_dx, ex.s));
         }
     }
+    join_aux(ex);
 }
 
-static Exec make_exec(void* stream, float* scratch, long long scratch_floats, long long slab_off)
+struct Needs { long long slab, wslab; };
+
+// split of the scratch tail into [conv slabs | wgrad slabs]: from a dry run of the schedule, cached per (net, B, T)
+template <class F>
+static Needs cached_needs(int kind, int B, int T, F&& dry_run)
+{
+    static std::mutex mu;
+    static std::map<long long, Needs> cache;
+    const long long key = ((long long)kind << 60) ^ ((long long)B << 32) ^ (long long)T;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
+    Exec ex{}; ex.dry = true;
+    dry_run(ex);
+    Needs n{(ex.slab_need + 3) & ~3LL, (ex.wslab_need + 3) & ~3LL};
+    std::lock_guard<std::mutex> lk(mu);
+    cache[key] = n;
+    return n;
+}
+
+static Exec make_exec(void* stream, void* aux_stream, float* scratch, long long scratch_floats, long long slab_off, const Needs& nd)
 {
     Exec ex{};
-    ex.s = (hipStream_t)stream; ex.dry = false; ex.err = 0;
-    ex.slabs = scratch ? scratch + slab_off : nullptr;
-    ex.slab_cap = scratch_floats - slab_off;
+    ex.s = (hipStream_t)stream; ex.s2 = (hipStream_t)aux_stream; ex.dry = false; ex.err = 0;
+    ex.slabs = scratch + slab_off;
+    ex.slab_cap = nd.slab;
+    ex.wslabs = scratch + slab_off + nd.slab;
+    ex.wslab_cap = scratch_floats - slab_off - nd.slab;
     return ex;
+}
+
+static Needs gen_needs(int B, int T)
+{
+    return cached_needs(1, B, T, [&](Exec& ex) {
+        const GenDims d = gen_dims(B, T);
+        gen_forward_impl(ex, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d);
+        float dummy = 0.f;
+        gen_backward_impl(ex, nullptr, nullptr, nullptr, nullptr, nullptr, &dummy, 0, nullptr, nullptr, d);
+    });
+}
+
+static Needs disc_needs(int B, int T)
+{
+    return cached_needs(2, B, T, [&](Exec& ex) {
+        const DiscDims d = disc_dims(B, T);
+        disc_forward_impl(ex, nullptr, nullptr, nullptr, nullptr, nullptr, d);
+        float dummy = 0.f;
+        disc_backward_impl(ex, nullptr, nullptr, nullptr, nullptr, 1, &dummy, 0, nullptr, nullptr, d);
+    });
 }
 
 }  // namespace
@@ -674,12 +834,8 @@ long long mcvc_gen_stash_floats(int B, int T) { return gen_stash(gen_dims(B, T))
 
 long long mcvc_gen_scratch_floats(int B, int T)
 {
-    const GenDims d = gen_dims(B, T);
-    Exec ex{}; ex.dry = true;
-    gen_forward_impl(ex, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d);
-    float dummy = 0.f;
-    gen_backward_impl(ex, nullptr, nullptr, nullptr, nullptr, nullptr, &dummy, 0, nullptr, nullptr, d);
-    return gen_scratch(d).slabs + ex.slab_need + 64;
+    const Needs nd = gen_needs(B, T);
+    return gen_scratch(gen_dims(B, T)).slabs + nd.slab + nd.wslab + 64;
 }
 
 long long mcvc_disc_stash_floats(int B, int T)
@@ -690,12 +846,8 @@ long long mcvc_disc_stash_floats(int B, int T)
 
 long long mcvc_disc_scratch_floats(int B, int T)
 {
-    const DiscDims d = disc_dims(B, T);
-    Exec ex{}; ex.dry = true;
-    disc_forward_impl(ex, nullptr, nullptr, nullptr, nullptr, nullptr, d);
-    float dummy = 0.f;
-    disc_backward_impl(ex, nullptr, nullptr, nullptr, nullptr, 1, &dummy, 0, nullptr, nullptr, d);
-    return disc_scratch(d).slabs + ex.slab_need + 64;
+    const Needs nd = disc_needs(B, T);
+    return disc_scratch(disc_dims(B, T)).slabs + nd.slab + nd.wslab + 64;
 }
 
 int mcvc_gen_pack(const float* const* params, float* packed, void* stream)
@@ -723,19 +875,20 @@ int mcvc_gen_forward(const float* const* params, const float* packed, const floa
 {
     if (B < 1 || T < 1 || !params || !packed || !x || !out || !stash || !scratch) return MCVC_ERR_INVALID;
     const GenDims d = gen_dims(B, T);
-    Exec ex = make_exec(stream, scratch, scratch_floats, gen_scratch(d).slabs);
-    if (ex.slab_cap < 0) return MCVC_ERR_WORKSPACE;
+    Exec ex = make_exec(stream, nullptr, scratch, scratch_floats, gen_scratch(d).slabs, gen_needs(B, T));
+    if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
     gen_forward_impl(ex, params, packed, x, mask, out, stash, d);
     return ex.err;
 }
 
 int mcvc_gen_backward(const float* const* params, const float* packed, float* const* grads, const float* mask, const float* dout,
-                      float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T, void* stream)
+                      float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T, void* stream,
+                      void* aux_stream)
 {
     if (B < 1 || T < 1 || !params || !packed || !dout || !stash || !scratch) return MCVC_ERR_INVALID;
     const GenDims d = gen_dims(B, T);
-    Exec ex = make_exec(stream, scratch, scratch_floats, gen_scratch(d).slabs);
-    if (ex.slab_cap < 0) return MCVC_ERR_WORKSPACE;
+    Exec ex = make_exec(stream, aux_stream, scratch, scratch_floats, gen_scratch(d).slabs, gen_needs(B, T));
+    if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
     gen_backward_impl(ex, params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, d);
     return ex.err;
 }
@@ -745,8 +898,8 @@ int mcvc_disc_forward(const float* const* params, const float* packed, const flo
 {
     if (B < 1 || T < 1 || !params || !packed || !x || !out || !stash || !scratch) return MCVC_ERR_INVALID;
     const DiscDims d = disc_dims(B, T);
-    Exec ex = make_exec(stream, scratch, scratch_floats, disc_scratch(d).slabs);
-    if (ex.slab_cap < 0) return MCVC_ERR_WORKSPACE;
+    Exec ex = make_exec(stream, nullptr, scratch, scratch_floats, disc_scratch(d).slabs, disc_needs(B, T));
+    if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
     // keep the input for the first layer's weight gradient
     ex.fail(mcvc_copy_launch(x, stash + disc_stash(d).total, B * 80 * T, ex.s));
     disc_forward_impl(ex, params, packed, x, out, stash, d);
@@ -754,12 +907,13 @@ int mcvc_disc_forward(const float* const* params, const float* packed, const flo
 }
 
 int mcvc_disc_backward(const float* const* params, const float* packed, float* const* grads, const float* dout, int dout_is_logit_grad,
-                       float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T, void* stream)
+                       float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T, void* stream,
+                       void* aux_stream)
 {
     if (B < 1 || T < 1 || !params || !packed || !dout || !stash || !scratch) return MCVC_ERR_INVALID;
     const DiscDims d = disc_dims(B, T);
-    Exec ex = make_exec(stream, scratch, scratch_floats, disc_scratch(d).slabs);
-    if (ex.slab_cap < 0) return MCVC_ERR_WORKSPACE;
+    Exec ex = make_exec(stream, aux_stream, scratch, scratch_floats, disc_scratch(d).slabs, disc_needs(B, T));
+    if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
     disc_backward_impl(ex, params, packed, grads, dout, dout_is_logit_grad, dx, accumulate_dx, stash, scratch, d);
     return ex.err;
 }
@@ -801,7 +955,9 @@ long long mcvc_conv2d_pack_floats(int Cout, int Cin, int KH, int KW)
     ConvSpec c = mk(Cin, Cout, 1, KH, KW, 1, 0, 0, 0, 1, -1, -1, 1);
     long long cur = 0;
     spec_finalize(c, cur);
-    return cur + 4LL * c.cin_pk + 64;
+    // stride 2 uses the merged parity layout: at most (KH+1)/2+1 x (KW+1)/2+1 taps x 4*Cin columns
+    const long long merged = ((long long)c.dg_rows_co * ((KH + 1) / 2 + 1) * ((KW + 1) / 2 + 1) + 1) * round_up_i(4 * Cin, 32);
+    return cur + merged + 4LL * c.cin_pk + 64;
 }
 
 int mcvc_conv2d_forward(const float* x, const float* w, const float* bias, float* y, float* wpack, float* slabs, int max_slabs,
@@ -835,7 +991,8 @@ int mcvc_conv2d_dgrad(const float* dy, const float* w, float* dx, float* wpack, 
     const ConvSpec c = single_spec(Cout, Cin, KH, KW, stride, pad_h, pad_w);
     Exec ex{}; ex.s = (hipStream_t)stream;
     PackDgradArgs a{};
-    a.Cin = Cin; a.KH = KH; a.KW = KW; a.step = stride; a.ld = c.cin_pk; a.co_off = 0; a.ncls = c.ncls;
+    a.Cin = Cin; a.KH = KH; a.KW = KW; a.step = stride; a.ld = c.merged ? c.mg_ld : c.cin_pk; a.co_off = 0; a.ncls = c.ncls;
+    a.merged = c.merged; a.mg_kh = c.mg_kh; a.mg_kw = c.mg_kw;
     for (int k = 0; k < c.ncls; ++k) a.cls[k] = c.cls[k];
     ex.fail(mcvc_pack_dgrad_launch(w, wpack + c.off_dgrad, a, Cout, ex.s));
     const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);

@@ -7,6 +7,7 @@ struct DgradClass {
     int khmax, kwmax;      // tap u -> kh = khmax - step*u
     int pad_h, pad_w;      // padding of the equivalent stride-1 conv over dY
     int qh, qw;            // output parity (0 for stride 1)
+    int su, sv;            // merged (stride 2) layout: tap (u, v) of this class sits at (u + su, v + sv) of the common window
     long long offset;      // float offset of this class inside the layer's dgrad pack
 };
 
@@ -15,6 +16,8 @@ struct PackDgradArgs {
     int step;              // = conv stride (1 or 2)
     int ld;                // row length (Cin rounded up to 32)
     int co_off;            // channel offset of this branch inside the concatenated (value|gate) conv
+    int merged;            // 1: one matrix for all parity classes: row (co, u', v'), column 4*ci + 2*qh + qw
+    int mg_kh, mg_kw;      // common tap window of the merged layout
     int ncls;
     DgradClass cls[4];
 };

@@ -48,8 +48,15 @@ __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict
         for (int t = grp; t < nt; t += 8) {
             const int u = t / a.cls[c].ntw, v = t - u * a.cls[c].ntw;
             const int kh = a.cls[c].khmax - a.step * u, kw = a.cls[c].kwmax - a.step * v;
-            if (lane < nci)
-                dst[a.cls[c].offset + ((long long)(a.co_off + co) * nt + t) * a.ld + ci0 + lane] = lds[lane * khkw + kh * a.KW + kw];
+            if (lane < nci) {
+                const float wv = lds[lane * khkw + kh * a.KW + kw];
+                if (a.merged) {
+                    const long long row = ((long long)(a.co_off + co) * a.mg_kh + (u + a.cls[c].su)) * a.mg_kw + (v + a.cls[c].sv);
+                    dst[row * a.ld + 4 * (ci0 + lane) + 2 * a.cls[c].qh + a.cls[c].qw] = wv;
+                } else {
+                    dst[a.cls[c].offset + ((long long)(a.co_off + co) * nt + t) * a.ld + ci0 + lane] = wv;
+                }
+            }
         }
     }
 }

@@ -36,9 +36,9 @@ _SIGS = {
     "mcvc_gen_pack": (c_int, [_PP, c_void_p, c_void_p]),
     "mcvc_disc_pack": (c_int, [_PP, c_void_p, c_void_p]),
     "mcvc_gen_forward": (c_int, [_PP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
-    "mcvc_gen_backward": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
+    "mcvc_gen_backward": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p]),
     "mcvc_disc_forward": (c_int, [_PP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
-    "mcvc_disc_backward": (c_int, [_PP, c_void_p, _PP, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
+    "mcvc_disc_backward": (c_int, [_PP, c_void_p, _PP, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p]),
     "mcvc_l1_loss": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mcvc_lsgan_loss": (c_int, [c_void_p, c_longlong, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcvc_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),

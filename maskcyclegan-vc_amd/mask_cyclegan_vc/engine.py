@@ -101,12 +101,22 @@ class TrainEngine:
         # kernels are latency-bound and far from filling 256 CUs, so the two chains run as two "lanes" on two HIP
         # streams (lane 0 = the caller's stream) and overlap on the chip; join points are stream-event waits.
         self.concurrent = True
-        self._side = torch.cuda.Stream(device=dev)
+        self._sides = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        # inside a backward pass the weight-gradient kernels are off the critical path: one auxiliary stream per lane
+        self._aux = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        self.aux_wgrad = True
+        # HIP-graph replay of the two phases is available but OFF by default: measured on MI355X / ROCm 7.2 it does not
+        # shorten the step (the host is not the limiter: 19.7 ms replayed vs 19.5 ms eager) and capturing lanes together
+        # with the auxiliary streams crashes inside hipStreamEndCapture.
+        self.use_graphs = False
+        self._graphs, self._eager_runs = {}, {}
+        self._capture_stream = torch.cuda.Stream(device=dev)
         self._workspaces = {}
         self._use(batch_size)
         self.reducer.broadcast_(self.g_group.flat)
         self.reducer.broadcast_(self.d_group.flat)
         self.repack(G_NAMES + D_NAMES)
+        self._stale_g = self._stale_d = False
 
     # ---- activations / workspaces: static shapes per batch size (graph-capturable), created on first use -----------
     def _use(self, B):
@@ -132,7 +142,8 @@ class TrainEngine:
                 d_stash1=[f(L.mcvc_disc_stash_floats(B, T)) for _ in range(4)],
                 d_stash2=[f(L.mcvc_disc_stash_floats(B2, T)) for _ in range(4)],
                 g_scratch=[f(max(L.mcvc_gen_scratch_floats(B, T), L.mcvc_gen_scratch_floats(B2, T))) for _ in range(2)],   # one per lane
-                d_scratch=[f(max(L.mcvc_disc_scratch_floats(B, T), L.mcvc_disc_scratch_floats(B2, T))) for _ in range(2)],
+                d_scratch=[f(max(L.mcvc_disc_scratch_floats(B, T), L.mcvc_disc_scratch_floats(B2, T))) for _ in range(4)],
+                static_in=[f(B, 80, T) for _ in range(4)],                             # real_A, mask_A, real_B, mask_B
                 in_A2B=mel2(), in_B2A=mel2(),                                          # [real_A ; real_B] and [real_B ; real_A]
                 mask_A2B=torch.ones(B2, 80, T, device=dev), mask_B2A=torch.ones(B2, 80, T, device=dev),   # [mask ; ones]
                 out_A2B=mel2(), out_B2A=mel2(),                                        # [fake_B ; identity_B], [fake_A ; identity_A]
@@ -148,22 +159,37 @@ class TrainEngine:
             setattr(self, k, v)
 
     # ---- thin call helpers ------------------------------------------------------------------------
-    def repack(self, names):
-        for n in names:
-            fn = self.L.mcvc_gen_pack if n in G_NAMES else self.L.mcvc_disc_pack
-            check(fn(self._p_tab[n], ptr(self.packed[n]), stream()), "pack " + n)
+    def _repack1(self, n):
+        fn = self.L.mcvc_gen_pack if n in G_NAMES else self.L.mcvc_disc_pack
+        check(fn(self._p_tab[n], ptr(self.packed[n]), stream()), "pack " + n)
 
-    def _lanes(self, fn0, fn1):
-        """Run fn0(lane=0) on the current stream and fn1(lane=1) on the side stream, then join."""
+    def repack(self, names):
+        """Refresh the K-major weight copies (one lane per network when running concurrently)."""
+        names = list(names)
+        while names:
+            grp, names = names[:4], names[4:]
+            self._lanes(*[(lambda ln, n=n: self._repack1(n)) for n in grp])
+
+    def _lanes(self, *fns):
+        """Run fns[i](lane=i) concurrently: lane 0 on the current stream, lane i>0 on side stream i-1; then join."""
         if not self.concurrent:
-            fn0(0); fn1(0)
+            for fn in fns:
+                fn(0)
             return
         main = torch.cuda.current_stream(self.device)
-        self._side.wait_stream(main)
-        fn0(0)
-        with torch.cuda.stream(self._side):
-            fn1(1)
-        main.wait_stream(self._side)
+        sides = self._sides[:len(fns) - 1]
+        for st in sides:
+            st.wait_stream(main)
+        fns[0](0)
+        for i, st in enumerate(sides):
+            with torch.cuda.stream(st):
+                fns[i + 1](i + 1)
+        for st in sides:
+            main.wait_stream(st)
+
+    def _aux_ptr(self, lane):
+        import ctypes
+        return ctypes.c_void_p(self._aux[lane].cuda_stream) if self.aux_wgrad else None
 
     def _G(self, name, x, mask, out, stash, nb, lane=0):
         sc = self.g_scratch[lane]
@@ -173,7 +199,7 @@ class TrainEngine:
     def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0):
         sc = self.g_scratch[lane]
         check(self.L.mcvc_gen_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name], ptr(mask), ptr(dout), ptr(dx), acc,
-                                       ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream()), "gen_backward")
+                                       ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(), self._aux_ptr(lane)), "gen_backward")
 
     def _D(self, name, x, out, stash, nb, lane=0):
         sc = self.d_scratch[lane]
@@ -184,7 +210,7 @@ class TrainEngine:
         sc = self.d_scratch[lane]
         check(self.L.mcvc_disc_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name] if with_weight_grads else None,
                                         ptr(dlogit), 1, ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(),
-                                        nb, self.T, stream()), "disc_backward")
+                                        nb, self.T, stream(), self._aux_ptr(lane) if with_weight_grads else None), "disc_backward")
 
     def _slot(self, i):
         return self.slots[i:i + 1]
@@ -208,6 +234,7 @@ class TrainEngine:
         B, B2 = self.B, 2 * self.B
         m = self.mel
         sc = self.sched
+        self.repack(D_NAMES)               # discriminator weights changed at the end of the previous iteration
         self.slots.zero_()
         self.g_group.grad.zero_()
         # batched inputs (device-to-device copies; the batch dimension is outermost, so halves are contiguous views)
@@ -225,14 +252,10 @@ class TrainEngine:
         self._lanes(lambda ln: self._G("generator_B2A", fake_B, None, m["cycle_A"], self.g_stash1[0], B, ln),                  # :204 (mask of ones)
                     lambda ln: self._G("generator_A2B", fake_A, None, m["cycle_B"], self.g_stash1[1], B, ln))                  # :206
 
-        def d_fwd_a(ln):
-            self._D("discriminator_A", fake_A, do[0], ds[0], B, ln)              # :211
-            self._D("discriminator_A2", m["cycle_A"], do[2], ds[2], B, ln)       # :215
-
-        def d_fwd_b(ln):
-            self._D("discriminator_B", fake_B, do[1], ds[1], B, ln)              # :212
-            self._D("discriminator_B2", m["cycle_B"], do[3], ds[3], B, ln)       # :216
-        self._lanes(d_fwd_a, d_fwd_b)
+        self._lanes(lambda ln: self._D("discriminator_A", fake_A, do[0], ds[0], B, ln),              # :211
+                    lambda ln: self._D("discriminator_B", fake_B, do[1], ds[1], B, ln),              # :212
+                    lambda ln: self._D("discriminator_A2", m["cycle_A"], do[2], ds[2], B, ln),       # :215
+                    lambda ln: self._D("discriminator_B2", m["cycle_B"], do[3], ds[3], B, ln))       # :216
         # losses (:219-237) and their gradients (tiny single-block kernels; they share the loss slots -> one stream)
         self._l1(m["cycle_A"], real_A, sc.cycle_loss_lambda, m["g_cycle_A"], SLOT_CYCLE)
         self._l1(m["cycle_B"], real_B, sc.cycle_loss_lambda, m["g_cycle_B"], SLOT_CYCLE)
@@ -242,27 +265,27 @@ class TrainEngine:
             self._lsgan(do[i], 1.0, 1.0, SLOT_G, SLOT_ADV_G, dl[i])
         # backward, in dependency order; discriminators contribute data-gradients only
 
-        def d_bwd_a(ln):
-            self._D_bwd("discriminator_A2", dl[2], m["g_cycle_A"], 1, ds[2], False, B, ln)
-            self._D_bwd("discriminator_A", dl[0], g_fake_A, 0, ds[0], False, B, ln)
-
-        def d_bwd_b(ln):
-            self._D_bwd("discriminator_B2", dl[3], m["g_cycle_B"], 1, ds[3], False, B, ln)
-            self._D_bwd("discriminator_B", dl[1], g_fake_B, 0, ds[1], False, B, ln)
-        self._lanes(d_bwd_a, d_bwd_b)
+        self._lanes(lambda ln: self._D_bwd("discriminator_A2", dl[2], m["g_cycle_A"], 1, ds[2], False, B, ln),
+                    lambda ln: self._D_bwd("discriminator_B2", dl[3], m["g_cycle_B"], 1, ds[3], False, B, ln),
+                    lambda ln: self._D_bwd("discriminator_A", dl[0], g_fake_A, 0, ds[0], False, B, ln),
+                    lambda ln: self._D_bwd("discriminator_B", dl[1], g_fake_B, 0, ds[1], False, B, ln))
         self._lanes(lambda ln: self._G_bwd("generator_B2A", None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B, ln),   # cycle_A = G_B2A(fake_B)
                     lambda ln: self._G_bwd("generator_A2B", None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, ln))   # cycle_B = G_A2B(fake_A)
         self._lanes(lambda ln: self._G_bwd("generator_A2B", self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2, ln),
                     lambda ln: self._G_bwd("generator_B2A", self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2, ln))
+
+    def generator_update(self):
+        """All-reduce (data parallel) + Adam on the flat generator buffer (train.py:242); eager: its scalars change per step."""
         self.reducer.reduce_(self.g_group.grad)
-        self._adam(self.g_group, sc.g_opt_lr)                                             # :242
-        self.repack(G_NAMES)
+        self._adam(self.g_group, self.sched.g_opt_lr)
+        self._stale_g = True
 
     def discriminator_phase(self, real_A, mask_A, real_B, mask_B):
         """train.py:247-299."""
         B, B2 = self.B, 2 * self.B
         m = self.mel
         sc = self.sched
+        self.repack(G_NAMES)               # generators run with their UPDATED weights (train.py:259-273)
         self.d_group.grad.zero_()
         di = self.d_in
         # generators run with their UPDATED weights and no gradient (train.py:259-273); outputs land directly in the
@@ -282,20 +305,19 @@ class TrainEngine:
         do, dl, ds = self.dout2, self.dlogit2, self.d_stash2
         idx = {n: i for i, n in enumerate(D_NAMES)}
 
-        def d_fwd(names):
-            return lambda ln: [self._D(n, di[n], do[idx[n]], ds[idx[n]], B2, ln) for n in names]   # :255-258 real half, :260-273 generated half
-        self._lanes(d_fwd(("discriminator_A", "discriminator_A2")), d_fwd(("discriminator_B", "discriminator_B2")))
+        self._lanes(*[(lambda ln, n=n: self._D(n, di[n], do[idx[n]], ds[idx[n]], B2, ln)) for n in D_NAMES])   # :255-258 real half, :260-273 generated half
         # d_loss = (A + B)/2 + (A_2nd + B_2nd)/2 with each = (real + fake)/2  -> every term weighs 1/4  (:276-294)
         for i in range(4):
             self._lsgan(do[i][:B], 1.0, 0.25, SLOT_D, SLOT_D_REAL, dl[i][:B])
             self._lsgan(do[i][B:], 0.0, 0.25, SLOT_D, SLOT_D_FAKE, dl[i][B:])
 
-        def d_bwd(names):
-            return lambda ln: [self._D_bwd(n, dl[idx[n]], None, 0, ds[idx[n]], True, B2, ln) for n in names]
-        self._lanes(d_bwd(("discriminator_A", "discriminator_A2")), d_bwd(("discriminator_B", "discriminator_B2")))
+        self._lanes(*[(lambda ln, n=n: self._D_bwd(n, dl[idx[n]], None, 0, ds[idx[n]], True, B2, ln)) for n in D_NAMES])
+
+    def discriminator_update(self):
+        """train.py:299"""
         self.reducer.reduce_(self.d_group.grad)
-        self._adam(self.d_group, sc.d_opt_lr)                                            # :299
-        self.repack(D_NAMES)
+        self._adam(self.d_group, self.sched.d_opt_lr)
+        self._stale_d = True
 
     def step(self, real_A, mask_A, real_B, mask_B):
         """One full iteration.  Inputs: float32 [B,80,T] on the engine's device.  Returns the loss-slot
@@ -305,10 +327,42 @@ class TrainEngine:
             raise ValueError("batch shape %s does not match the engine (B, 80, %d)" % (tuple(real_A.shape), self.T))
         if real_A.shape[0] != self.B:
             self._use(int(real_A.shape[0]))
-        self.generator_phase(real_A, mask_A, real_B, mask_B)
-        self.discriminator_phase(real_A, mask_A, real_B, mask_B)
+        # static input buffers (graph replays read fixed addresses)
+        for dst, src in zip(self.static_in, (real_A, mask_A, real_B, mask_B)):
+            dst.copy_(src)
+        self._run_phase("G")
+        self.generator_update()
+        self._run_phase("D")
+        self.discriminator_update()
         self.sched.end_iteration()
         return self.slots
+
+    # ---- HIP graphs: each phase's ~500 launches (two lanes + auxiliary streams included) are captured once and replayed
+    def _run_phase(self, which):
+        fn = self.generator_phase if which == "G" else self.discriminator_phase
+        if not self.use_graphs:
+            fn(*self.static_in)
+            return
+        key = (which, self.B, float(self.sched.cycle_loss_lambda), float(self.sched.identity_loss_lambda), self.concurrent, self.aux_wgrad)
+        g = self._graphs.get(key)
+        if g is None:
+            if self._eager_runs.get(key, 0) < 2:          # warm-up: first runs are eager (lazy kernel attributes, event pool)
+                self._eager_runs[key] = self._eager_runs.get(key, 0) + 1
+                fn(*self.static_in)
+                return
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, stream=self._capture_stream):
+                    fn(*self.static_in)
+            except Exception as exc:                        # stay correct if capture is not possible on this runtime
+                print("mask_cyclegan_vc.engine: HIP graph capture failed (%s); continuing eagerly" % exc)
+                self.use_graphs = False
+                torch.cuda.synchronize(self.device)
+                fn(*self.static_in)
+                return
+            self._graphs[key] = g
+        g.replay()
 
     def losses(self):
         v = self.slots.tolist()      # device sync, like the reference's .item()

@@ -181,7 +181,7 @@ class _GeneratorFn(torch.autograd.Function):
             off += (n + 3) & ~3          # 16-byte aligned views
         dx = torch.empty((B, _hip.N_MEL, T), device=dout.device) if need[1] else None
         check(L.mcvc_gen_backward(ptr_table(params), ptr(packed), ptr_table(grads) if any(sizes) else None, ptr(mask), ptr(dout), ptr(dx), 0,
-                                  ptr(stash), ptr(scratch), scratch.numel(), B, T, stream()), "mcvc_gen_backward")
+                                  ptr(stash), ptr(scratch), scratch.numel(), B, T, stream(), None), "mcvc_gen_backward")
         return (None, dx, None, *grads)
 
 
@@ -222,7 +222,7 @@ class _DiscriminatorFn(torch.autograd.Function):
             off += (n + 3) & ~3
         dx = torch.empty((B, _hip.N_MEL, T), device=dout.device) if need[1] else None
         check(L.mcvc_disc_backward(ptr_table(params), ptr(packed), ptr_table(grads) if any(sizes) else None, ptr(dout), 0, ptr(dx), 0,
-                                   ptr(stash), ptr(scratch), scratch.numel(), B, T, stream()), "mcvc_disc_backward")
+                                   ptr(stash), ptr(scratch), scratch.numel(), B, T, stream(), None), "mcvc_disc_backward")
         return (None, dx, *grads)
 
 
