@@ -16,6 +16,7 @@
 #include "mcvc_common.h"
 #include "pack.h"
 #include "misc.h"
+#include "trunk.h"
 #include "../../include/mcvc.h"
 #include <string.h>
 #include <map>
@@ -93,6 +94,7 @@ struct ConvSpec {
     // derived
     int cout_tot, cout_pk, cin_pad, w_rows, cin_pk, dg_rows_co;
     long long off_fwd, off_bias, off_dgrad;
+    long long off_tk;          // KH == 1 convs: transposed + flipped [Cin][cout_tot*KW] copy for the fused small-batch trunk dgrad
     int ncls;
     DgradClass cls[4];
     // stride 2: the four output-parity classes are ONE stride-1 conv with 4*Cin output channels (4*ci + 2*qh + qw) whose
@@ -149,6 +151,8 @@ static void spec_finalize(ConvSpec& c, long long& cur)
         cur += ((long long)c.dg_rows_co * c.mg_kh * c.mg_kw + 1) * c.mg_ld;                  // + zero pad row
     }
     cur = (cur + 3) & ~3LL;
+    c.off_tk = -1;
+    if (c.KH == 1 && st == 1) { c.off_tk = cur; cur += (long long)c.Cin * c.cout_tot * c.KW; cur = (cur + 3) & ~3LL; }
 }
 
 static ConvSpec mk(int Cin, int Cout, int nbr, int KH, int KW, int stride, int ph, int pw, int w0, int b0, int w1, int b1, int bias_grad)
@@ -293,7 +297,85 @@ static void pack_spec(Exec& ex, const ConvSpec& c, const float* const* params, f
         a.merged = c.merged; a.mg_kh = c.mg_kh; a.mg_kw = c.mg_kw;
         for (int k = 0; k < c.ncls; ++k) a.cls[k] = c.cls[k];
         ex.fail(mcvc_pack_dgrad_launch(w, packed + c.off_dgrad, a, c.Cout, ex.s));
+        if (c.off_tk >= 0) ex.fail(mcvc_pack_trunk_t_launch(w, packed + c.off_tk, c.Cout, c.Cin, c.KW, c.cout_tot * c.KW, br * c.Cout, ex.s));
     }
+}
+
+// ---- fused small-batch trunk layer (trunk_kernels.hip) ------------------------------------------------
+static bool trunk_enabled()
+{
+    static const int en = [] { const char* e = getenv("MCVC_TRUNK"); return e ? atoi(e) : 1; }();
+    return en != 0;
+}
+
+// conv1d + bias + IN (+GLU | +residual); input / conv_out in trunk layout [C][B][W4]; y plane (b, c) at y + b*y_sn + c*y_sc
+static bool trunk_fwd(Exec& ex, const ConvSpec& c, const float* const* P, int g0, int be0, int g1, int be1, const float* x, float* conv_out,
+                      float* stats, float* y, long long y_sn, long long y_sc, const float* res, int B, int W4)
+{
+    const int mode = (c.nbr == 2) ? TRUNK_IN_GLU : TRUNK_IN;
+    if (!trunk_enabled() || c.KH != 1 || !mcvc_trunk_applies(c.Cin, c.KW, c.Cout, B, W4, mode, 1)) return false;
+    if (ex.dry) return true;
+    TrunkArgs a{};
+    a.a0 = P[c.wi[0]]; a.bias0 = P[c.bi[0]]; a.gamma0 = P[g0]; a.beta0 = P[be0];
+    if (c.nbr == 2) { a.a1 = P[c.wi[1]]; a.bias1 = P[c.bi[1]]; a.gamma1 = P[g1]; a.beta1 = P[be1]; }
+    a.x = x; a.x_sc = (long long)B * W4; a.x_sb = W4;
+    a.Cin = c.Cin; a.KW = c.KW; a.K = c.Cin * c.KW; a.M = c.Cout; a.Mtot = c.cout_tot; a.B = B; a.T4 = W4; a.N = B * W4;
+    a.conv_out = conv_out; a.c_sc = (long long)B * W4; a.c_sb = W4;
+    a.stats = stats; a.y = y; a.res = res; a.y_sn = y_sn; a.y_sc = y_sc; a.eps = kInEps; a.mode = mode;
+    ex.fail(mcvc_trunk_launch(a, 1, ex.s));
+    return true;
+}
+
+// largest K split (power-of-two multiples of `start`) the kernel accepts that still keeps the grid below ~512 workgroups
+static int trunk_pick_ksplit(int Cin, int KW, int M, int B, int W4, int must_split)
+{
+    int best = 0;
+    for (int ks = 1; ks <= 64; ++ks) {
+        if (!mcvc_trunk_applies(Cin, KW, M, B, W4, TRUNK_PLAIN, ks)) continue;
+        if (best == 0) best = ks;
+        if ((M / 16) * ks <= 512) best = ks;
+    }
+    (void)must_split;
+    return best;
+}
+
+// dX[ci][b][t] (+)= sum_{co,kw} W[co][ci][kw] dY[co][b][t + pw - kw]  through the transposed pack.  Large K (or an
+// accumulating destination) is split over workgroups that add atomically; a non-accumulating destination is zeroed first.
+static bool trunk_dgrad(Exec& ex, const ConvSpec& c, const float* packed, const float* dy, float* dx, int accumulate, int B, int W4)
+{
+    if (!trunk_enabled() || c.off_tk < 0) return false;
+    int ks = 1;
+    if (!accumulate && mcvc_trunk_applies(c.cout_tot, c.KW, c.Cin, B, W4, TRUNK_PLAIN, 1)) ks = 1;
+    else ks = trunk_pick_ksplit(c.cout_tot, c.KW, c.Cin, B, W4, 0);
+    if (ks < 1) return false;
+    if (ex.dry) return true;
+    int acc = accumulate;
+    if (!accumulate && ks > 1) { ex.fail(mcvc_fill_rows_launch(dx, nullptr, c.Cin, B * W4, ex.s)); acc = 1; }
+    TrunkArgs a{};
+    a.a0 = packed + c.off_tk;
+    a.x = dy; a.x_sc = (long long)B * W4; a.x_sb = W4;
+    a.Cin = c.cout_tot; a.KW = c.KW; a.K = c.cout_tot * c.KW; a.M = c.Cin; a.Mtot = c.Cin; a.B = B; a.T4 = W4; a.N = B * W4;
+    a.conv_out = dx; a.c_sc = (long long)B * W4; a.c_sb = W4; a.accumulate = acc; a.mode = TRUNK_PLAIN;
+    ex.fail(mcvc_trunk_launch(a, ks, ex.s));
+    return true;
+}
+
+// K too large for one workgroup (conv2dto1d, K = 5120): conv_out = bias, then K-split workgroups accumulate atomically;
+// the InstanceNorm stays a separate launch.  Weights are read straight from the OIHW parameter.
+static bool trunk_fwd_ksplit(Exec& ex, const ConvSpec& c, const float* const* P, const float* x, float* conv_out, int B, int W4)
+{
+    if (!trunk_enabled() || c.KH != 1 || c.nbr != 1) return false;
+    const int ks = trunk_pick_ksplit(c.Cin, c.KW, c.Cout, B, W4, 1);
+    if (ks < 1) return false;
+    if (ex.dry) return true;
+    ex.fail(mcvc_fill_rows_launch(conv_out, P[c.bi[0]], c.Cout, B * W4, ex.s));
+    TrunkArgs a{};
+    a.a0 = P[c.wi[0]];
+    a.x = x; a.x_sc = (long long)B * W4; a.x_sb = W4;
+    a.Cin = c.Cin; a.KW = c.KW; a.K = c.Cin * c.KW; a.M = c.Cout; a.Mtot = c.Cout; a.B = B; a.T4 = W4; a.N = B * W4;
+    a.conv_out = conv_out; a.c_sc = (long long)B * W4; a.c_sb = W4; a.accumulate = 1; a.mode = TRUNK_PLAIN;
+    ex.fail(mcvc_trunk_launch(a, ks, ex.s));
+    return true;
 }
 
 // ---- norm wrappers -------------------------------------------------------------------------------------
@@ -468,24 +550,31 @@ static void gen_forward_impl(Exec& ex, const float* const* P, const float* packe
     norm_fwd(ex, st + o.c3, 512LL * 20 * W4, 20LL * W4, (long long)B * 512 * 20 * W4, ns, normp(P, nullptr, 14, 15, 18, 19), st + o.s3,
              st + o.y3, W4, 20LL * BT4, (int)BT4, nullptr, B, 256, 20, W4, ACT_GLU);
     // ---- :254-255  1x1 5120->256 + IN ; image = [5120][B rows][W4]
-    conv_fwd(ex, g.c2d1d, packed, 1, B, W4, CView{st + o.y3, 0, BT4, W4}, View{st + o.c4, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
+    if (trunk_fwd_ksplit(ex, g.c2d1d, P, st + o.y3, st + o.c4, B, W4)) ns = 1;
+    else conv_fwd(ex, g.c2d1d, packed, 1, B, W4, CView{st + o.y3, 0, BT4, W4}, View{st + o.c4, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
     norm_fwd(ex, st + o.c4, W4, BT4, 256 * BT4, ns, normp(P, nullptr, 22, 23), st + o.s4, st + o.y4, W4, BT4, W4, nullptr, B, 256, 1, W4, ACT_NONE);
     // ---- :258-263  six residual GLU blocks
     const float* h = st + o.y4;
     for (int i = 0; i < 6; ++i) {
         const int b = 24 + 12 * i;
-        conv_fwd(ex, g.res_vg[i], packed, 1, B, W4, CView{h, 0, BT4, W4}, View{st + o.r[i].ca, 0, BT4, W4}, 1024 * BT4, 0, 1, &ns);
-        norm_fwd(ex, st + o.r[i].ca, W4, BT4, 1024 * BT4, ns, normp(P, nullptr, b + 2, b + 3, b + 6, b + 7), st + o.r[i].sa,
-                 st + o.r[i].ya, W4, BT4, W4, nullptr, B, 512, 1, W4, ACT_GLU);
-        conv_fwd(ex, g.res_out[i], packed, 1, B, W4, CView{st + o.r[i].ya, 0, BT4, W4}, View{st + o.r[i].cb, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
-        norm_fwd(ex, st + o.r[i].cb, W4, BT4, 256 * BT4, ns, normp(P, nullptr, b + 10, b + 11), st + o.r[i].sb,
-                 st + o.r[i].y, W4, BT4, W4, h, B, 256, 1, W4, ACT_NONE);
+        if (!trunk_fwd(ex, g.res_vg[i], P, b + 2, b + 3, b + 6, b + 7, h, st + o.r[i].ca, st + o.r[i].sa, st + o.r[i].ya, W4, BT4, nullptr, B, W4)) {
+            conv_fwd(ex, g.res_vg[i], packed, 1, B, W4, CView{h, 0, BT4, W4}, View{st + o.r[i].ca, 0, BT4, W4}, 1024 * BT4, 0, 1, &ns);
+            norm_fwd(ex, st + o.r[i].ca, W4, BT4, 1024 * BT4, ns, normp(P, nullptr, b + 2, b + 3, b + 6, b + 7), st + o.r[i].sa,
+                     st + o.r[i].ya, W4, BT4, W4, nullptr, B, 512, 1, W4, ACT_GLU);
+        }
+        if (!trunk_fwd(ex, g.res_out[i], P, b + 10, b + 11, -1, -1, st + o.r[i].ya, st + o.r[i].cb, st + o.r[i].sb, st + o.r[i].y, W4, BT4, h, B, W4)) {
+            conv_fwd(ex, g.res_out[i], packed, 1, B, W4, CView{st + o.r[i].ya, 0, BT4, W4}, View{st + o.r[i].cb, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
+            norm_fwd(ex, st + o.r[i].cb, W4, BT4, 256 * BT4, ns, normp(P, nullptr, b + 10, b + 11), st + o.r[i].sb,
+                     st + o.r[i].y, W4, BT4, W4, h, B, 256, 1, W4, ACT_NONE);
+        }
         h = st + o.r[i].y;
     }
     // ---- :266-271  1x1 256->5120 + IN, written as NCHW [B][256][20][W4] (5120 = c*20 + h)
-    conv_fwd(ex, g.c1d2d, packed, 1, B, W4, CView{h, 0, BT4, W4}, View{st + o.c6, 0, BT4, W4}, 5120 * BT4, 0, 1, &ns);
-    norm_fwd(ex, st + o.c6, W4, BT4, 5120 * BT4, ns, normp(P, nullptr, 98, 99), st + o.s6, st + o.y6, 5120LL * W4, W4, W4, nullptr,
-             B, 5120, 1, W4, ACT_NONE);
+    if (!trunk_fwd(ex, g.c1d2d, P, 98, 99, -1, -1, h, st + o.c6, st + o.s6, st + o.y6, 5120LL * W4, W4, nullptr, B, W4)) {
+        conv_fwd(ex, g.c1d2d, packed, 1, B, W4, CView{h, 0, BT4, W4}, View{st + o.c6, 0, BT4, W4}, 5120 * BT4, 0, 1, &ns);
+        norm_fwd(ex, st + o.c6, W4, BT4, 5120 * BT4, ns, normp(P, nullptr, 98, 99), st + o.s6, st + o.y6, 5120LL * W4, W4, W4, nullptr,
+                 B, 5120, 1, W4, ACT_NONE);
+    }
     // ---- :274  upSample1: conv 5x5 -> PixelShuffle(2) (fused into the store) -> IN -> x*sigmoid(x)
     conv_fwd(ex, g.up1, packed, B, 20, W4, CView{st + o.y6, 256LL * 20 * W4, 20LL * W4, W4}, View{st + o.c7, 256LL * 40 * Wu1, 40LL * Wu1, Wu1},
              (long long)B * 256 * 40 * Wu1, 1, 1, &ns);
@@ -560,7 +649,8 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         const float* hin = st + o.r[5].y;
         CView dyv{GB, 0, BT4, W4};
         conv_wgrad(ex, g.c1d2d, G, 1, B, W4, CView{hin, 0, BT4, W4}, dyv);
-        conv_dgrad(ex, g.c1d2d, packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
+        if (trunk_dgrad(ex, g.c1d2d, packed, GB, DH, 0, B, W4)) ns = 1;
+        else conv_dgrad(ex, g.c1d2d, packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
     }
     // ---- residual blocks (:258-263), last to first.  DH carries d(h) and is updated in place.
     for (int i = 5; i >= 0; --i) {
@@ -573,14 +663,16 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         {
             CView dyv{DT3, 0, BT4, W4};
             conv_wgrad(ex, g.res_out[i], G, 1, B, W4, CView{st + o.r[i].ya, 0, BT4, W4}, dyv);
-            conv_dgrad(ex, g.res_out[i], packed, 1, B, W4, dyv, View{DT2, 0, BT4, W4}, 512 * BT4, 0, 1, &ns2);
+            if (!trunk_dgrad(ex, g.res_out[i], packed, DT3, DT2, 0, B, W4))
+                conv_dgrad(ex, g.res_out[i], packed, 1, B, W4, dyv, View{DT2, 0, BT4, W4}, 512 * BT4, 0, 1, &ns2);
         }
         norm_bwd(ex, st + o.r[i].ca, W4, BT4, normp(P, G, b + 2, b + 3, b + 6, b + 7), st + o.r[i].sa, DT2, W4, BT4, W4, 512 * BT4, ns2,
                  DT1, W4, BT4, W4, 0, B, 512, 1, W4, ACT_GLU);
         {
             CView dyv{DT1, 0, BT4, W4};
             conv_wgrad(ex, g.res_vg[i], G, 1, B, W4, CView{hin, 0, BT4, W4}, dyv);
-            conv_dgrad(ex, g.res_vg[i], packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 1 /*accumulate: skip path*/, 1, nullptr);
+            if (!trunk_dgrad(ex, g.res_vg[i], packed, DT1, DH, 1 /*accumulate: skip path*/, B, W4))
+                conv_dgrad(ex, g.res_vg[i], packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 1, 1, nullptr);
         }
         ns = 1;
     }
@@ -590,7 +682,9 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
     {
         CView dyv{DT3, 0, BT4, W4};
         conv_wgrad(ex, g.c2d1d, G, 1, B, W4, CView{st + o.y3, 0, BT4, W4}, dyv);
-        conv_dgrad(ex, g.c2d1d, packed, 1, B, W4, dyv, View{GA, 0, BT4, W4}, 5120 * BT4, 0, 1, &ns);
+        ns = 1;
+        if (!trunk_dgrad(ex, g.c2d1d, packed, DT3, GA, 0, B, W4))
+            conv_dgrad(ex, g.c2d1d, packed, 1, B, W4, dyv, View{GA, 0, BT4, W4}, 5120 * BT4, 0, 1, &ns);
     }
     // ---- downSample2 (:246): dy is in trunk layout
     GB = nextGB();

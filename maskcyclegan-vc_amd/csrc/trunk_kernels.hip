@@ -1,0 +1,356 @@
+// Fused 1-D trunk layer for small batch (N = B * T/4 <= 32 output columns):
+//   conv1d (k = 1 or 3) + bias + InstanceNorm1d(affine) + {gated GLU | residual add | nothing}   -- ONE launch.
+//
+// Replaces, for the generator's residual trunk (reference mask_cyclegan_vc/model.py:47-76, 142-189, 254-267), the
+// generic direct-conv kernel + split-K slabs + separate norm kernel.  At bs=1 a trunk conv is 0.013-0.05 GFLOP over
+// 1.5-3 MB of weights: pure weight streaming and latency.  The timeline analysis (tools/rocpd_timeline.py) showed
+// these 52-workgroup launches alone on the chip for ~20 % of the step, so the design goal here is the fewest possible
+// dependent memory round trips, not FLOP/s:
+//   * GEMM view  out[m][n] = sum_k A[m][k] * X[k][n],  m = output channel, n = (b, t), k = (ci, kw).
+//     One workgroup owns 16 output rows (GLU: 8 value + the 8 matching gate rows) and ALL N <= 32 columns = one or two
+//     16x16 fp32 MFMA accumulators per wave; its 8 waves split K and are summed through LDS -> no inter-block split
+//     (16-row tiles rather than 32: twice the workgroups, i.e. twice the DRAM requests in flight, and 64-byte instead
+//     of 32-byte contiguous pieces per weight row and load instruction).
+//   * A (weights) is read straight from the OIHW parameter tensor ([m][k], k contiguous): 16-byte loads per lane, ALL
+//     of a wave's loads issued before anything else, each float4 feeding four v_mfma_f32_16x16x4_f32 steps.
+//     No packed copy, no LDS staging.
+//   * X (at most 512 x 32 activations, with zero halo) is staged once in LDS; the MFMA B operand is a shifted read.
+//   * Epilogue in LDS: bias, pre-norm store (backward needs it), per-(row, b) two-pass statistics, affine, GLU /
+//     residual, strided store (which also performs the reference's view(B,256,20,-1) when writing NCHW).
+//   * K = 5120 (conv2dto1d and the data-gradient of conv1dto2d) does not fit one workgroup's LDS: K-split workgroups
+//     accumulate atomically into a bias-/zero-initialised destination and the norm stays a separate launch.
+// The same kernel with mode 0 is the data-gradient of these layers (weights transposed+flipped by pack_trunk_t).
+#include "mcvc_common.h"
+#include "trace.h"
+#include "trunk.h"
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+constexpr int kTrunkWaves = 8;                 // K is split over the waves of ONE workgroup (2 per SIMD)
+constexpr int kTrunkThreads = 64 * kTrunkWaves;
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// 16x16x4 fp32 MFMA: lane l holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; D register r is row 4*(l >> 4) + r,
+// column l & 15.  A float4 of consecutive k per lane feeds four MFMAs (any 4 distinct k per instruction are fine as long as
+// the B operand uses the same ones).
+template <int KW, int NA>
+__global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const TrunkArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    constexpr int PW = (KW - 1) / 2;
+    const int TP = a.T4 + 2 * PW;                 // padded row length in LDS
+    const int RS = a.B * TP + 1;                  // per input channel (+1: a guaranteed-zero slot for idle lanes)
+    const int glu = (a.mode == TRUNK_IN_GLU);
+    const int rows_per_block = glu ? 8 : 16;
+    const int r0 = blockIdx.x * rows_per_block;
+    // K range of this workgroup (gridDim.y K-splits, accumulate mode only) and of this wave
+    const int kblk = a.K / gridDim.y;
+    const int k_count = kblk / kTrunkWaves;       // multiple of the super-group (checked on the host)
+    const int k_begin = blockIdx.y * kblk + wave * k_count;
+    const int ci_begin = (blockIdx.y * kblk) / KW;
+    const int ci_count = kblk / KW;
+
+    // A row of this lane
+    const float* arow;
+    {
+        const int i = l15;
+        if (glu) arow = (i < 8) ? (a.a0 + (long long)(r0 + i) * a.K) : (a.a1 + (long long)(r0 + i - 8) * a.K);
+        else arow = a.a0 + (long long)(r0 + i) * a.K;
+    }
+    // One super-group = NQ float4 of weights per lane = GK = 16*NQ consecutive k per wave = whole input channels, so the
+    // (ci, kw) pattern repeats and the LDS offsets of its 4*NQ MFMA steps are loop-invariant registers.  Up to CH
+    // super-groups (all of them for the generator's shapes) are requested before anything else happens: at this size the
+    // layer is one DRAM latency, not a bandwidth problem.
+    constexpr int NQ = (KW == 3) ? 3 : 2;
+    constexpr int GK = 16 * NQ;
+    constexpr int CH = 4;
+    const int sgroups = k_count / GK;
+    const float* ap = arow + k_begin + 4 * kq;
+    float4 wb[CH][NQ];
+#define TRUNK_LOAD_CHUNK(sg0)                                                                                       \
+    {                                                                                                              \
+        _Pragma("unroll") for (int c = 0; c < CH; ++c) {                                                           \
+            const int sg = (sg0) + c;                                                                              \
+            const float* pp = ap + (long long)(sg < sgroups ? sg : 0) * GK;                                        \
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q) wb[c][q] = *reinterpret_cast<const float4*>(pp + 16 * q); \
+        }                                                                                                          \
+    }
+    TRUNK_LOAD_CHUNK(0);
+
+    // ---- stage X[ci][b][t] (this block's channel slice) with zero halo
+    {
+        const float* xsrc = a.x + (long long)ci_begin * a.x_sc;
+        const bool fast = (a.x_sb == a.T4) && (a.x_sc == (long long)a.B * a.T4) && ((a.T4 & 3) == 0) &&
+                          ((reinterpret_cast<unsigned long long>(xsrc) & 15ull) == 0);
+        if (fast) {
+            const int nf4 = (ci_count * a.B * a.T4) >> 2;
+            for (int f0 = 0; f0 < nf4; f0 += 4 * kTrunkThreads) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + u * kTrunkThreads + tid;
+                    v[u] = (f < nf4) ? *reinterpret_cast<const float4*>(xsrc + 4ll * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + u * kTrunkThreads + tid;
+                    if (f < nf4) {
+                        const int e = 4 * f;
+                        const int r = e / a.T4, t = e - r * a.T4;
+                        const int ci = r / a.B, b = r - ci * a.B;
+                        float* d = smem + ci * RS + b * TP + PW + t;
+                        d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                    }
+                }
+            }
+            // halo columns + the per-channel zero slot
+            const int per = a.B * 2 * PW + 1;
+            for (int i = tid; i < ci_count * per; i += kTrunkThreads) {
+                const int ci = i / per, j = i - ci * per;
+                int pos;
+                if (j == per - 1) pos = a.B * TP;
+                else { const int b = j / (2 * PW > 0 ? 2 * PW : 1), side = j - b * 2 * PW; pos = b * TP + (side ? TP - 1 : 0); }
+                smem[ci * RS + pos] = 0.f;
+            }
+        } else {
+            const int total = ci_count * RS;
+            for (int i = tid; i < total; i += kTrunkThreads) {
+                const int ci = i / RS, rem = i - ci * RS;
+                float v = 0.f;
+                if (rem < a.B * TP) {
+                    const int b = rem / TP, tp = rem - b * TP;
+                    const int t = tp - PW;
+                    if (t >= 0 && t < a.T4) v = xsrc[(long long)ci * a.x_sc + (long long)b * a.x_sb + t];
+                }
+                smem[i] = v;
+            }
+        }
+    }
+    // B columns of this lane: n = l15 (+16 for the second accumulator) -> (b, t); idle lanes read the zero slot
+    int off[NA][NQ][4];
+#pragma unroll
+    for (int h = 0; h < NA; ++h) {
+        const int n = l15 + 16 * h;
+        int xcol = a.B * TP, live = 0;
+        if (n < a.N) { const int b = n / a.T4, t = n - b * a.T4; xcol = b * TP + t; live = 1; }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kr = 16 * q + 4 * kq + j;
+                off[h][q][j] = (kr / KW) * RS + xcol + (live ? (kr % KW) : 0);
+            }
+    }
+    f32x4 acc[NA];
+#pragma unroll
+    for (int h = 0; h < NA; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    // ---- main loop
+    {
+        const float* xs = smem + (k_begin / KW - ci_begin) * RS;
+        for (int sg0 = 0; sg0 < sgroups; sg0 += CH) {
+            if (sg0 > 0) TRUNK_LOAD_CHUNK(sg0);
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (sg0 + c < sgroups) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const float av[4] = {wb[c][q].x, wb[c][q].y, wb[c][q].z, wb[c][q].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int h = 0; h < NA; ++h) acc[h] = MFMA16(av[j], xs[off[h][q][j]], acc[h]);
+                    }
+                    xs += (GK / KW) * RS;
+                }
+            }
+        }
+#undef TRUNK_LOAD_CHUNK
+    }
+    __syncthreads();                               // everyone is done reading X from LDS
+
+    // ---- cross-wave K reduction through LDS: red[wave][h][reg][lane]
+    float* red = smem;
+#pragma unroll
+    for (int h = 0; h < NA; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * NA + h) * 4 + r) * 64 + lane] = acc[h][r];
+    __syncthreads();
+    float* tile = smem + kTrunkWaves * 2 * 4 * 64;  // [16 rows][33]
+    float* sstat = tile + 16 * 33;                 // [16 rows][B][2]
+    for (int e = tid; e < NA * 256; e += kTrunkThreads) {
+        const int h = e >> 8, r = (e >> 6) & 3, ln = e & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kTrunkWaves; ++w) v += red[((w * NA + h) * 4 + r) * 64 + ln];
+        const int row = 4 * (ln >> 4) + r, col = (ln & 15) + 16 * h;
+        tile[row * 33 + col] = v;
+    }
+    __syncthreads();
+
+    // row -> output channel(s)
+    auto row_cx = [&](int row) { return glu ? ((row < 8) ? (r0 + row) : (a.M + r0 + row - 8)) : (r0 + row); };
+
+    if (a.mode == TRUNK_PLAIN) {                    // data-gradient: store / accumulate, no bias, no norm
+        for (int e = tid; e < 16 * a.N; e += kTrunkThreads) {
+            const int row = e / a.N, nn = e - row * a.N;
+            const int b = nn / a.T4, t = nn - b * a.T4;
+            float* dst = a.conv_out + (long long)row_cx(row) * a.c_sc + (long long)b * a.c_sb + t;
+            const float v = tile[row * 33 + nn];
+            if (a.accumulate) { if (gridDim.y > 1) unsafeAtomicAdd(dst, v); else *dst += v; }
+            else *dst = v;
+        }
+        return;
+    }
+    // ---- bias + pre-norm store
+    for (int e = tid; e < 16 * a.N; e += kTrunkThreads) {
+        const int row = e / a.N, nn = e - row * a.N;
+        const int cx = row_cx(row);
+        const float bias = glu ? ((row < 8) ? a.bias0[r0 + row] : a.bias1[r0 + row - 8]) : a.bias0[r0 + row];
+        const float v = tile[row * 33 + nn] + bias;
+        tile[row * 33 + nn] = v;
+        const int b = nn / a.T4, t = nn - b * a.T4;
+        a.conv_out[(long long)cx * a.c_sc + (long long)b * a.c_sb + t] = v;
+    }
+    __syncthreads();
+    // ---- statistics per (row, b): two-pass over T4 (<= 32) elements, one thread each
+    if (tid < 16 * a.B) {
+        const int row = tid / a.B, b = tid - row * a.B;
+        const float* p = tile + row * 33 + b * a.T4;
+        float s = 0.f;
+        for (int t = 0; t < a.T4; ++t) s += p[t];
+        const float mean = s / (float)a.T4;
+        float q = 0.f;
+        for (int t = 0; t < a.T4; ++t) { const float d = p[t] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(q / (float)a.T4 + a.eps);
+        sstat[(row * a.B + b) * 2] = mean; sstat[(row * a.B + b) * 2 + 1] = rstd;
+        float* st = a.stats + ((long long)b * a.Mtot + row_cx(row)) * 2;
+        st[0] = mean; st[1] = rstd;
+    }
+    __syncthreads();
+    // ---- affine + activation + residual + store
+    const int out_rows = glu ? 8 : 16;
+    for (int e = tid; e < out_rows * a.N; e += kTrunkThreads) {
+        const int row = e / a.N, nn = e - row * a.N;
+        const int c = r0 + row;
+        const int b = nn / a.T4, t = nn - b * a.T4;
+        const float m0 = sstat[(row * a.B + b) * 2], s0 = sstat[(row * a.B + b) * 2 + 1];
+        const float z0 = (tile[row * 33 + nn] - m0) * s0 * a.gamma0[c] + a.beta0[c];
+        float y;
+        if (glu) {
+            const int rg = row + 8;
+            const float m1 = sstat[(rg * a.B + b) * 2], s1 = sstat[(rg * a.B + b) * 2 + 1];
+            const float z1 = (tile[rg * 33 + nn] - m1) * s1 * a.gamma1[c] + a.beta1[c];
+            y = z0 * sigmoidf_(z1);
+        } else {
+            y = z0;
+        }
+        const long long yo = (long long)b * a.y_sn + (long long)c * a.y_sc + t;
+        if (a.res) y += a.res[yo];
+        a.y[yo] = y;
+    }
+}
+
+// Wt[ci][(co_off + co) * KW + kwp] = W[co][ci][KW-1-kwp]   (transposed + flipped copy for the trunk data-gradient)
+__global__ void __launch_bounds__(256) pack_trunk_t_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int KW,
+                                                           int ld, int co_off)
+{
+    __shared__ float tile[32][33];
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int kw = 0; kw < KW; ++kw) {
+        for (int r = ty; r < 32; r += 8) {          // r = co, tx = ci : reads stride KW (small), fine
+            const int co = co0 + r, ci = ci0 + tx;
+            tile[r][tx] = (co < Cout && ci < Cin) ? w[((long long)co * Cin + ci) * KW + kw] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {          // r = ci, tx = co : consecutive co -> stride KW floats
+            const int ci = ci0 + r, co = co0 + tx;
+            if (ci < Cin && co < Cout) dst[(long long)ci * ld + (long long)(co_off + co) * KW + (KW - 1 - kw)] = tile[tx][r];
+        }
+        __syncthreads();
+    }
+}
+
+// dst[c][0..per_row) = bias ? bias[c] : 0   (initial value of an atomically accumulated K-split trunk layer)
+__global__ void __launch_bounds__(256) fill_rows_kernel(float* __restrict__ dst, const float* __restrict__ bias, int C, int per_row)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C * per_row) return;
+    dst[i] = bias ? bias[i / per_row] : 0.f;
+}
+
+}  // namespace
+
+int mcvc_fill_rows_launch(float* dst, const float* bias, int C, int per_row, hipStream_t s)
+{
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * C * per_row);
+    hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)cdiv_i(C * per_row, 256)), dim3(256), 0, s, dst, bias, C, per_row);
+    return (int)hipGetLastError();
+}
+
+bool mcvc_trunk_applies(int Cin, int KW, int M, int B, int T4, int mode, int ksplit)
+{
+    if (KW != 1 && KW != 3) return false;
+    if (B * T4 > 32 || T4 > 32 || B > 8) return false;
+    const int K = Cin * KW;
+    if (ksplit < 1 || (K % ksplit) != 0) return false;
+    const int kblk = K / ksplit;
+    const int gk = (KW == 3) ? 48 : 32;                          // one weight super-group per wave (see the kernel)
+    if ((kblk % (gk * kTrunkWaves)) != 0) return false;
+    const int rows = (mode == TRUNK_IN_GLU) ? 8 : 16;
+    if (M % rows != 0) return false;
+    const long long lds = mcvc_trunk_lds_floats(Cin, KW, B, T4, ksplit);
+    return lds * 4 <= 150 * 1024;
+}
+
+long long mcvc_trunk_lds_floats(int Cin, int KW, int B, int T4, int ksplit)
+{
+    const int TP = T4 + (KW - 1);
+    const long long xs = (long long)(Cin / ksplit) * (B * TP + 1);
+    const long long epi = kTrunkWaves * 2 * 4 * 64 + 16 * 33 + 16 * B * 2 + 16;
+    return xs > epi ? xs : epi;
+}
+
+template <int KW, int NA>
+static int trunk_launch_t(const TrunkArgs& a, dim3 grid, size_t lds, hipStream_t s)
+{
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_layer_kernel<KW, NA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    hipLaunchKernelGGL((trunk_layer_kernel<KW, NA>), grid, dim3(kTrunkThreads), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_trunk_launch(const TrunkArgs& a, int ksplit, hipStream_t s)
+{
+    if (!mcvc_trunk_applies(a.Cin, a.KW, a.M, a.B, a.T4, a.mode, ksplit)) return MCVC_ERR_INVALID;
+    if (ksplit > 1 && !(a.mode == TRUNK_PLAIN && a.accumulate)) return MCVC_ERR_INVALID;
+    const int rows = (a.mode == TRUNK_IN_GLU) ? 8 : 16;
+    dim3 grid((unsigned)(a.M / rows), (unsigned)ksplit);
+    const size_t lds = (size_t)mcvc_trunk_lds_floats(a.Cin, a.KW, a.B, a.T4, ksplit) * sizeof(float);
+    const double mt = (a.mode == TRUNK_IN_GLU) ? 2.0 * a.M : (double)a.M;
+    TraceScope ts(K_TRUNK, s, 2.0 * mt * a.K * a.N, 4.0 * (mt * a.K + (double)a.Cin * a.N + 3.0 * mt * a.N));
+    const bool wide = a.N > 16;
+    if (a.KW == 3) return wide ? trunk_launch_t<3, 2>(a, grid, lds, s) : trunk_launch_t<3, 1>(a, grid, lds, s);
+    return wide ? trunk_launch_t<1, 2>(a, grid, lds, s) : trunk_launch_t<1, 1>(a, grid, lds, s);
+}
+
+int mcvc_pack_trunk_t_launch(const float* w, float* dst, int Cout, int Cin, int KW, int ld, int co_off, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv_i(Cin, 32), (unsigned)cdiv_i(Cout, 32));
+    TraceScope ts(K_PACK, s, 0.0, 8.0 * (double)Cout * Cin * KW);
+    hipLaunchKernelGGL(pack_trunk_t_kernel, grid, dim3(256), 0, s, w, dst, Cout, Cin, KW, ld, co_off);
+    return (int)hipGetLastError();
+}
