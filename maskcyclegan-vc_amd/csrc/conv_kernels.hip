@@ -8,6 +8,7 @@
 #include "mcvc_common.h"
 #include "trace.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
@@ -39,6 +40,14 @@ __device__ __forceinline__ int xcd_logical_id(int linear, int total)
     const int q = total >> 3, r = total & 7;
     const int xcd = linear & 7, k = linear >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+__device__ float g_wgrad_zero[64];      // zero-initialised: DMA source for out-of-image elements
+
+__device__ __forceinline__ void glds4(const float* g, float* l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 4, 0, 0);
 }
 
 __device__ __forceinline__ void glds16(const float* g, float* l)
@@ -487,15 +496,15 @@ int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float
 // output channel's [ci][kh][kw] run (contiguous in OIHW) is written with coalesced stores -- either
 // `dw +=` directly (ksplit == 1, deterministic) or to this K-split's private slab, which
 // wgrad_reduce_kernel then folds into dw (no atomics anywhere).
-template <int MS, int KWT, int MAXT>
-__global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
+template <int MS, int KWT, int MAXT, int MINW>
+__global__ void __launch_bounds__(MAXT, MINW) conv_wgrad_kernel(const WgradArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int hw = tid >> 5, nhw = nthreads >> 5;
+    const int nwaves_ = nthreads >> 6;
 
     const int tasks_per_group = a.KH * a.nkwg;
     const int cgrp = wave / tasks_per_group;
@@ -547,36 +556,42 @@ __global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
         const int oh0 = ty * a.toh, ow0 = tx * a.tow;
         const int ih0 = oh0 * a.stride - a.pad_h, iw0 = ow0 * a.stride - a.pad_w;
         __syncthreads();
-        // stage dY chunk rows (co, r): tow <= 32 contiguous floats each, one half-wave per row
+        // Staging by LDS-DMA (global_load_lds, 4 B per lane, no VGPRs): a wave fills 64 consecutive LDS floats per
+        // instruction, each lane fetching its own (bounds-checked) global element or a zero; all of a wave's requests
+        // are in flight together and drained once by the vmcnt(0) in front of the barrier.  (The synchronous
+        // load->ds_write loop this replaces was latency-bound: ~100 dependent round trips per wave and tile.)
         {
+            // dY: per output channel one contiguous run of toh*tow floats (rows of the pixel tile)
             const float* dyn = a.dy + (long long)n * a.dy_sb;
-            const int ow = ow0 + l31;
-            const bool cok = (l31 < a.tow) && (ow < a.OW);
-#pragma unroll 4
-            for (int row = hw; row < rows_a; row += nhw) {
-                const int co = row / a.toh, r = row - co * a.toh;
-                const int oh = oh0 + r, cg = co0 + co;
-                float v = 0.f;
-                if (cok && cg < a.Cout && oh < a.OH) v = dyn[(long long)cg * a.dy_sc + (long long)oh * a.dy_sh + ow];
-                if (l31 < a.tow) As[co * a.pitch_a + r * a.tow + l31] = v;
+            const int LA = a.toh * a.tow;
+            const int chunks = (LA + 63) >> 6;
+            const int tow_log2 = 31 - __builtin_clz((unsigned)a.tow);
+            for (int job = wave; job < a.cot * chunks; job += nwaves_) {
+                const int co = job / chunks, ch = job - co * chunks;
+                const int idx = ch * 64 + lane;
+                const int r = idx >> tow_log2, c = idx & (a.tow - 1);
+                const int oh = oh0 + r, ow = ow0 + c, cg = co0 + co;
+                const bool ok = (cg < a.Cout) && (oh < a.OH) && (ow < a.OW);
+                const float* src = ok ? (dyn + (long long)cg * a.dy_sc + (long long)oh * a.dy_sh + ow) : (g_wgrad_zero + lane);
+                if (idx < LA) glds4(src, As + co * a.pitch_a + ch * 64);
             }
         }
-        // stage X patch rows (ci, r): PW floats each
         {
+            // X: per input channel one contiguous run of PH*PW floats (the haloed patch, PWp == PW)
             const float* xn = a.x + (long long)n * a.x_sb;
-#pragma unroll 2
-            for (int row = hw; row < rows_x; row += nhw) {
-                const int ci = row / a.PH, r = row - ci * a.PH;
-                const int ih = ih0 + r, cg = ci_base + ci;
-                const bool rok = (cg < a.Cin) && (ih >= 0) && (ih < a.H);
-                const float* src = xn + (long long)cg * a.x_sc + (long long)ih * a.x_sh;
-                float* dst = Xs + ci * a.plane + r * a.PWp;
-                for (int c = l31; c < a.PW; c += 32) {
-                    const int iw = iw0 + c;
-                    float v = 0.f;
-                    if (rok && iw >= 0 && iw < a.W) v = src[iw];
-                    dst[c] = v;
-                }
+            const int LX = a.PH * a.PW;
+            const int chunks = (LX + 63) >> 6;
+            const float inv_pw = 1.0f / (float)a.PW;
+            for (int job = wave; job < nci * chunks; job += nwaves_) {
+                const int ci = job / chunks, ch = job - ci * chunks;
+                const int idx = ch * 64 + lane;
+                int r = (int)((float)idx * inv_pw);                     // idx < 2^16: exact after the fix-up below
+                int c = idx - r * a.PW;
+                if (c < 0) { c += a.PW; --r; } else if (c >= a.PW) { c -= a.PW; ++r; }
+                const int ih = ih0 + r, iw = iw0 + c, cg = ci_base + ci;
+                const bool ok = (cg < a.Cin) && (ih >= 0) && (ih < a.H) && (iw >= 0) && (iw < a.W);
+                const float* src = ok ? (xn + (long long)cg * a.x_sc + (long long)ih * a.x_sh + iw) : (g_wgrad_zero + lane);
+                if (idx < LX) glds4(src, Xs + ci * a.plane + ch * 64);
             }
         }
         __syncthreads();
@@ -603,7 +618,7 @@ __global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
     const int RL = nci * KHKW;                  // LDS row pitch
     const int RLv = nci_valid * KHKW;           // valid (contiguous in OIHW) run per output channel
     const int ngroups = a.cot / (MS * 32);
-    float* out = (a.ksplit > 1) ? (a.slabs + (long long)zsplit * a.slab_stride) : a.dw;
+    float* out = (a.ksplit > 1 && !a.atomic) ? (a.slabs + (long long)zsplit * a.slab_stride) : a.dw;
     float* Tt = smem;
 #pragma unroll
     for (int i = 0; i < MS; ++i) {
@@ -631,7 +646,9 @@ __global__ void __launch_bounds__(MAXT) conv_wgrad_kernel(const WgradArgs a)
                 if (co < a.Cout) {
                     const long long o = ((long long)co * a.Cin + ci_base) * KHKW + e;
                     const float v = Tt[grow * RL + e];
-                    if (a.ksplit > 1) out[o] = v; else out[o] += v;
+                    if (a.atomic) unsafeAtomicAdd(out + o, v);       // tiny dW: coalesced L2 atomics, no slabs
+                    else if (a.ksplit > 1) out[o] = v;
+                    else out[o] += v;
                 }
             }
         }
@@ -733,11 +750,11 @@ __global__ void __launch_bounds__(256) wgrad_smallk_kernel(const SmallKArgs a)
 }
 
 namespace {
-template <int MS, int KWT, int MAXT>
+template <int MS, int KWT, int MAXT, int MINW = 1>
 static hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, int nwaves, size_t lds, hipStream_t s)
 {
     if (64 * nwaves > MAXT) return hipErrorInvalidValue;
-    auto kern = conv_wgrad_kernel<MS, KWT, MAXT>;
+    auto kern = conv_wgrad_kernel<MS, KWT, MAXT, MINW>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -753,6 +770,18 @@ static hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, int nwaves, size_t
     return hipGetLastError();
 }
 
+// planner knobs (tools/wgrad_tune.py): read once, or on every call when MCVC_WGRAD_TUNE=1 was set at load time
+static int wgrad_knob(const char* name, int dflt)
+{
+    static const int tune = env_int("MCVC_WGRAD_TUNE", 0);
+    if (tune) return env_int(name, dflt);
+    return dflt;
+}
+static int wgrad_knob_ms() { return wgrad_knob("MCVC_WGRAD_MS", 0); }
+static int wgrad_knob_waves() { return wgrad_knob("MCVC_WGRAD_WAVES", 0); }
+static int wgrad_knob_lds_floats() { return wgrad_knob("MCVC_WGRAD_LDS_KB", 78) * 256; }
+static int wgrad_knob_ksplit() { return wgrad_knob("MCVC_WGRAD_KSPLIT", 0); }
+
 struct WgradPlan { WgradArgs a; dim3 grid; int MS, KWT, nwaves; size_t lds; };
 
 static bool plan_wgrad(const ConvProblem& p, int NB, long long slab_cap_floats, WgradPlan* out)
@@ -763,18 +792,23 @@ static bool plan_wgrad(const ConvProblem& p, int NB, long long slab_cap_floats, 
     a.KH = p.KH; a.KW = p.KW; a.stride = p.stride; a.pad_h = p.pad_h; a.pad_w = p.pad_w;
     a.dw_floats = (long long)p.Cout * p.Cin * p.KH * p.KW;
     a.slab_stride = (a.dw_floats + 3) & ~3LL;
-    int MS, KWT;
+    // Tile shape.  MS = 1 (80 / 48 accumulator registers) everywhere: measured on gfx950 the smaller register footprint
+    // (more resident waves to hide the LDS reads) beats the better MFMA : ds_read ratio of MS = 2.
+    int MS, KWT, wave_cap = 8;
     a.lane_mode = (p.Cin * p.KW <= 32 && p.Cin <= 4) ? 1 : 0;
     if (a.lane_mode == 1) { MS = (p.Cout >= 128) ? 4 : 1; KWT = 1; a.nkwg = 1; }
-    else if (p.KW % 5 == 0) { KWT = 5; a.nkwg = p.KW / 5; MS = (p.Cout >= 64) ? 2 : 1; }
-    else if (p.KW == 3) { KWT = 3; a.nkwg = 1; MS = (p.Cout >= 64) ? 2 : 1; }
+    else if (p.KW % 5 == 0) { KWT = 5; a.nkwg = p.KW / 5; MS = 1; wave_cap = 10; }      // 2 co-groups x 5 kernel rows
+    else if (p.KW == 3) { KWT = 3; a.nkwg = 1; MS = 1; }
     else if (p.KW == 1) { KWT = 1; a.nkwg = 1; MS = (p.Cout >= 128) ? 4 : 1; }
     else return false;
     const int tasks = p.KH * a.nkwg;
     if (tasks > 16) return false;
+    if (tasks == 1) wave_cap = 4;
     int groups = 1;
+    if (a.lane_mode == 0 && wgrad_knob_ms() > 0 && p.Cout >= 32 * wgrad_knob_ms() && KWT > 1) MS = wgrad_knob_ms();
+    if (wgrad_knob_waves() > 0) wave_cap = wgrad_knob_waves();
     const int max_groups = cdiv_i(p.Cout, 32 * MS);
-    while (groups * 2 * tasks <= 8 && groups * 2 <= max_groups && groups * 2 * MS * 32 <= 256) groups *= 2;
+    while (groups * 2 * tasks <= wave_cap && groups * 2 <= max_groups && groups * 2 * MS * 32 <= 256) groups *= 2;
     pl.nwaves = groups * tasks;
     pl.MS = MS; pl.KWT = KWT;
     a.cot = groups * MS * 32;
@@ -782,16 +816,60 @@ static bool plan_wgrad(const ConvProblem& p, int NB, long long slab_cap_floats, 
     int tow = 32;
     while (tow > 2 && tow / 2 >= p.OW) tow /= 2;      // smallest power of two >= OW, capped at 32
     a.tow = tow;
+    a.tiles_w = cdiv_i(p.OW, tow);
     const int nci = (a.lane_mode == 0) ? 32 : p.Cin;
     const int khkw = p.KH * p.KW;
     const int tfloats = groups * 8 * nci * khkw;      // write-out transpose tile
-    int toh = 1;
-    for (int cand = 1; cand <= p.OH && cand <= 16; ++cand) {
+    const int ci_tiles = (a.lane_mode == 0) ? cdiv_i(p.Cin, 32) : 1;
+    const int co_tiles = cdiv_i(p.Cout, a.cot);
+    const int base = ci_tiles * co_tiles;
+
+    // K split: the sweep in tools/wgrad_tune.py puts the optimum of every layer of the network at "one workgroup per CU"
+    // (256): fewer leaves CUs idle, more multiplies the dW-sized slab traffic.  Tiles are made as tall as LDS allows but
+    // no taller than what still yields `want` pixel tiles, and balanced (toh = ceil(OH / tiles_h)).
+    int want = (base >= 256) ? 1 : cdiv_i(256, base);
+    // tiny dW (edge layers: a few thousand outputs over thousands of pixels): K-split workgroups add straight into dW with
+    // coalesced atomics -- the slab round trip and the reduce launch would cost more than the layer
+    const bool tiny = a.dw_floats <= 65536;
+    if (tiny) { if (want > 128) want = 128; }
+    else {
+        long long cap = a.slab_stride > 0 ? slab_cap_floats / a.slab_stride : 0;
+        const long long hard = 32;
+        if (cap > hard) cap = hard;
+        if (want > cap) want = (int)cap;
+        if (want < 2) want = 1;
+    }
+    if (wgrad_knob_ksplit() > 0) {
+        want = wgrad_knob_ksplit();
+        const long long cap = a.slab_stride > 0 ? slab_cap_floats / a.slab_stride : 0;
+        if (!tiny && want > cap) want = cap < 2 ? 1 : (int)cap;
+    }
+    a.atomic = tiny ? 1 : 0;
+    // two workgroups per CU can overlap each other's staging / write-out only if there are that many of them
+    const int lds_budget = wgrad_knob("MCVC_WGRAD_LDS_KB", ((long long)base * want >= 512) ? 78 : 156) * 256;
+    int toh_max = 1;
+    for (int cand = 1; cand <= p.OH && cand <= 32; ++cand) {
         const int PH = (cand - 1) * p.stride + p.KH, PW = (tow - 1) * p.stride + p.KW;
         const int plane = (PH * PW) | 1;
         const int pitch_a = (cand * tow) | 1;
-        if (a.cot * pitch_a + nci * plane + 64 <= kLdsBudgetFloats) toh = cand; else break;
+        if (a.cot * pitch_a + nci * plane + 64 <= lds_budget && PH * PW < 65536) toh_max = cand; else break;
     }
+    int tiles_h = cdiv_i(p.OH, toh_max);
+    {
+        const int need = cdiv_i(want, NB * a.tiles_w);
+        if (need > tiles_h) tiles_h = need;
+        if (tiles_h > p.OH) tiles_h = p.OH;
+        // prefer a tile count that the K split divides evenly (a few extra, shorter tiles are cheaper than one idle round)
+        int best = tiles_h, best_cost = 1 << 30;
+        for (int th = tiles_h; th <= p.OH && th < tiles_h + 4; ++th) {
+            const int toh_c = cdiv_i(p.OH, th), it = NB * cdiv_i(p.OH, toh_c) * a.tiles_w;
+            const int ks = it < want ? it : want;
+            const int cost = cdiv_i(it, ks) * (toh_c + 1);          // rows walked by the busiest workgroup (+1: per-tile overhead)
+            if (cost < best_cost) { best_cost = cost; best = th; }
+        }
+        tiles_h = best;
+    }
+    const int toh = cdiv_i(p.OH, tiles_h);
     a.toh = toh;
     a.PH = (toh - 1) * p.stride + p.KH;
     a.PW = (tow - 1) * p.stride + p.KW;
@@ -799,32 +877,19 @@ static bool plan_wgrad(const ConvProblem& p, int NB, long long slab_cap_floats, 
     a.plane = (a.PH * a.PWp) | 1;
     a.pitch_a = (toh * tow) | 1;
     a.tiles_h = cdiv_i(p.OH, toh);
-    a.tiles_w = cdiv_i(p.OW, tow);
     int lds_floats = a.cot * a.pitch_a + nci * a.plane + 64;
     if (tfloats > lds_floats) lds_floats = tfloats;
     pl.lds = (size_t)lds_floats * sizeof(float);
     if (pl.lds > 160 * 1024) return false;
 
-    const int ci_tiles = (a.lane_mode == 0) ? cdiv_i(p.Cin, 32) : 1;
-    const int co_tiles = cdiv_i(p.Cout, a.cot);
     const int items = NB * a.tiles_h * a.tiles_w;
-    const int waves = ci_tiles * co_tiles * pl.nwaves;
-    int ksplit = 1;
-    if (waves < 1024) ksplit = cdiv_i(1536, waves);   // ~1.5 waves per SIMD chip-wide
-    if (ksplit > items) ksplit = items;
-    if (a.dw_floats <= 65536 && items > ksplit) {     // tiny dW (edge layers): slabs are free, the dY stream is the cost
-        ksplit = cdiv_i(4096, waves);
-        if (ksplit > items) ksplit = items;
-    }
-    if (ksplit > 1) {
-        long long cap = slab_cap_floats / a.slab_stride;
-        const long long hard = (a.dw_floats <= 65536) ? 512 : 32;
-        if (cap > hard) cap = hard;
-        if (ksplit > cap) ksplit = (int)cap;
-        if (ksplit < 2) ksplit = 1;
-    }
+    int ksplit = want < items ? want : items;
+    if (ksplit < 1) ksplit = 1;
     a.ksplit = ksplit; a.ci_tiles = ci_tiles;
     pl.grid = dim3((unsigned)(ci_tiles * co_tiles * ksplit));
+    if (wgrad_knob("MCVC_WGRAD_VERBOSE", 0))
+        fprintf(stderr, "[wgrad plan] Cin=%d Cout=%d k=%dx%d s=%d NB=%d out=%dx%d | MS=%d KWT=%d waves=%d cot=%d tow=%d toh=%d items=%d ksplit=%d grid=%d lds=%zu\n",
+                p.Cin, p.Cout, p.KH, p.KW, p.stride, NB, p.OH, p.OW, MS, KWT, pl.nwaves, a.cot, a.tow, a.toh, items, ksplit, (int)pl.grid.x, pl.lds);
     *out = pl;
     return true;
 }
@@ -836,7 +901,7 @@ long long mcvc_wgrad_plan_slab_floats(const ConvProblem& p, int NB)
     if (smallk_applies(p, NB)) return 0;
     WgradPlan pl;
     if (!plan_wgrad(p, NB, 1LL << 40, &pl)) return -1;
-    return pl.a.ksplit > 1 ? (long long)pl.a.ksplit * pl.a.slab_stride : 0;
+    return (pl.a.ksplit > 1 && !pl.a.atomic) ? (long long)pl.a.ksplit * pl.a.slab_stride : 0;
 }
 
 static bool smallk_applies(const ConvProblem& p, int NB)
@@ -876,7 +941,7 @@ int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw
     else if (MS == 4 && KWT == 1) e = launch_wgrad<4, 1, 512>(a, pl.grid, pl.nwaves, pl.lds, s);
     else e = launch_wgrad<1, 1, 1024>(a, pl.grid, pl.nwaves, pl.lds, s);
     if (e != hipSuccess) return (int)e;
-    if (a.ksplit > 1) {
+    if (a.ksplit > 1 && !a.atomic) {
         long long b = cdiv_ll(a.dw_floats >> 2, 256);
         if (b > 2048) b = 2048;
         if (b < 1) b = 1;

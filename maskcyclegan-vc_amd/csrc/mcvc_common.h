@@ -80,6 +80,7 @@ struct WgradArgs {
     int lane_mode;         // 0: N lane = ci ; 1: N lane = ci*KW + kw  (Cin*KW <= 32)
     int nkwg;              // kw groups per kh (lane_mode 0)
     int cot;               // output channels per block
+    int atomic;            // K-split workgroups add into dw with atomics (tiny dW); otherwise private slabs + reduce
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -301,6 +301,73 @@ static void pack_spec(Exec& ex, const ConvSpec& c, const float* const* params, f
     }
 }
 
+// ---- whole-network pack: job table built once per network kind, resident on the device ---------------------
+struct PackTable { std::vector<PackJob> jobs; std::vector<PackDgradArgs> dga; int nblocks = 0; double bytes = 0.0; };
+
+static void add_job(PackTable& t, PackJob j, int gx, int gy)
+{
+    j.block0 = t.nblocks; j.gx = gx;
+    t.nblocks += gx * gy;
+    t.jobs.push_back(j);
+}
+
+static void add_spec_jobs(PackTable& t, const ConvSpec& c)
+{
+    const int K = c.Cin * c.KH * c.KW;
+    for (int br = 0; br < c.nbr; ++br) {
+        PackJob f{}; f.kind = PACK_FWD; f.param = c.wi[br]; f.dst = c.off_fwd; f.Cout = c.Cout; f.K = K; f.ld = c.cout_pk; f.co_off = br * c.Cout;
+        add_job(t, f, cdiv_i(K, 32), cdiv_i(c.Cout, 32));
+        PackJob b{}; b.kind = PACK_COPY; b.param = c.bi[br]; b.dst = c.off_bias + br * c.Cout; b.Cout = c.Cout;
+        add_job(t, b, cdiv_i(c.Cout, 256), 1);
+        PackDgradArgs a{};
+        a.Cin = c.Cin; a.KH = c.KH; a.KW = c.KW; a.step = c.stride; a.ld = c.merged ? c.mg_ld : c.cin_pk; a.co_off = br * c.Cout; a.ncls = c.ncls;
+        a.merged = c.merged; a.mg_kh = c.mg_kh; a.mg_kw = c.mg_kw;
+        for (int k = 0; k < c.ncls; ++k) a.cls[k] = c.cls[k];
+        PackJob d{}; d.kind = PACK_DGRAD; d.param = c.wi[br]; d.dst = c.off_dgrad; d.dg = (int)t.dga.size();
+        t.dga.push_back(a);
+        add_job(t, d, cdiv_i(c.Cin, 32), c.Cout);
+        if (c.off_tk >= 0) {
+            PackJob q{}; q.kind = PACK_TRUNK_T; q.param = c.wi[br]; q.dst = c.off_tk; q.Cout = c.Cout; q.Cin = c.Cin; q.KW = c.KW;
+            q.ld = c.cout_tot * c.KW; q.co_off = br * c.Cout;
+            add_job(t, q, cdiv_i(c.Cin, 32), cdiv_i(c.Cout, 32));
+        }
+        t.bytes += 4.0 * ((c.off_tk >= 0 ? 6.0 : 4.0) * c.Cout * K + 2.0 * c.Cout);
+    }
+}
+
+struct DevPackTable { PackJob* jobs; PackDgradArgs* dga; int njobs, nblocks; double bytes; std::vector<int> used; };
+
+// one upload per (device, network kind); the first call must happen outside stream capture (it allocates)
+template <class Build>
+static const DevPackTable* dev_pack_table(int kind, Build&& build, int* err)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, DevPackTable> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { *err = MCVC_ERR_INVALID; return nullptr; }
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({dev, kind});
+    if (it != cache.end()) return &it->second;
+    PackTable t;
+    build(t);
+    DevPackTable d{};
+    d.njobs = (int)t.jobs.size(); d.nblocks = t.nblocks; d.bytes = t.bytes;
+    hipError_t e = hipMalloc((void**)&d.jobs, t.jobs.size() * sizeof(PackJob));
+    if (e == hipSuccess) e = hipMalloc((void**)&d.dga, t.dga.size() * sizeof(PackDgradArgs));
+    if (e == hipSuccess) e = hipMemcpy(d.jobs, t.jobs.data(), t.jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d.dga, t.dga.data(), t.dga.size() * sizeof(PackDgradArgs), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { *err = (int)e; return nullptr; }
+    for (const PackJob& j : t.jobs) d.used.push_back(j.param);
+    return &cache.emplace(std::make_pair(dev, kind), std::move(d)).first->second;
+}
+
+static int pack_net(const DevPackTable* t, const float* const* params, float* packed, hipStream_t s)
+{
+    PackPtrs ptrs{};
+    for (int i : t->used) { if (i < 0 || i >= 128) return MCVC_ERR_INVALID; ptrs.p[i] = params[i]; }
+    return mcvc_pack_net_launch(t->jobs, t->njobs, t->nblocks, t->dga, ptrs, packed, t->bytes, s);
+}
+
 // ---- fused small-batch trunk layer (trunk_kernels.hip) ------------------------------------------------
 static bool trunk_enabled()
 {
@@ -946,22 +1013,28 @@ long long mcvc_disc_scratch_floats(int B, int T)
 
 int mcvc_gen_pack(const float* const* params, float* packed, void* stream)
 {
-    const GenNet& g = gen_net();
-    Exec ex{}; ex.s = (hipStream_t)stream;
-    const ConvSpec* all[] = {&g.conv1, &g.ds1, &g.ds2, &g.c2d1d, &g.c1d2d, &g.up1, &g.up2, &g.last};
-    for (const ConvSpec* c : all) pack_spec(ex, *c, params, packed);
-    for (int i = 0; i < 6; ++i) { pack_spec(ex, g.res_vg[i], params, packed); pack_spec(ex, g.res_out[i], params, packed); }
-    return ex.err;
+    int err = 0;
+    const DevPackTable* t = dev_pack_table(0, [](PackTable& pt) {
+        const GenNet& g = gen_net();
+        const ConvSpec* all[] = {&g.conv1, &g.ds1, &g.ds2, &g.c2d1d, &g.c1d2d, &g.up1, &g.up2, &g.last};
+        for (const ConvSpec* c : all) add_spec_jobs(pt, *c);
+        for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i]); add_spec_jobs(pt, g.res_out[i]); }
+    }, &err);
+    if (!t) return err;
+    return pack_net(t, params, packed, (hipStream_t)stream);
 }
 
 int mcvc_disc_pack(const float* const* params, float* packed, void* stream)
 {
-    const DiscNet& n = disc_net();
-    Exec ex{}; ex.s = (hipStream_t)stream;
-    pack_spec(ex, n.conv1, params, packed);
-    for (int i = 0; i < 3; ++i) pack_spec(ex, n.ds[i], params, packed);
-    pack_spec(ex, n.outc, params, packed);
-    return ex.err;
+    int err = 0;
+    const DevPackTable* t = dev_pack_table(1, [](PackTable& pt) {
+        const DiscNet& n = disc_net();
+        add_spec_jobs(pt, n.conv1);
+        for (int i = 0; i < 3; ++i) add_spec_jobs(pt, n.ds[i]);
+        add_spec_jobs(pt, n.outc);
+    }, &err);
+    if (!t) return err;
+    return pack_net(t, params, packed, (hipStream_t)stream);
 }
 
 int mcvc_gen_forward(const float* const* params, const float* packed, const float* x, const float* mask, float* out, float* stash,

@@ -25,3 +25,19 @@ struct PackDgradArgs {
 int mcvc_pack_fwd_launch(const float* w, float* dst, int Cout, int K, int ld, int co_off, hipStream_t s);
 int mcvc_pack_dgrad_launch(const float* w, float* dst, const PackDgradArgs& a, int Cout, hipStream_t s);
 int mcvc_copy_launch(const float* src, float* dst, int n, hipStream_t s);
+
+// ---- whole-network re-pack (one launch): device-resident job table
+enum PackKind { PACK_FWD = 0, PACK_DGRAD = 1, PACK_COPY = 2, PACK_TRUNK_T = 3 };
+struct PackJob {
+    int kind, param;       // param = index into the parameter-pointer table
+    int block0, gx;        // first workgroup of this job in the flat grid; tile (bx, by) = (rel % gx, rel / gx)
+    long long dst;         // float offset inside the packed buffer
+    int Cout, K, ld, co_off, KW, Cin;
+    int dg;                // PACK_DGRAD: index into the PackDgradArgs table
+    int pad_;
+};
+struct PackPtrs { const float* p[128]; };
+constexpr size_t kPackNetLds = 32 * 75 * sizeof(float);      // largest tap count (5x15) x 32 input channels; >= one 32x33 tile
+int mcvc_pack_net_launch(const PackJob* d_jobs, int njobs, int nblocks, const PackDgradArgs* d_dga, const PackPtrs& ptrs, float* packed,
+                         double bytes, hipStream_t s);
+int mcvc_pack_trunk_t_launch(const float* w, float* dst, int Cout, int Cin, int KW, int ld, int co_off, hipStream_t s);

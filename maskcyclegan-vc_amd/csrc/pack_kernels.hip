@@ -15,11 +15,11 @@
 #include "trace.h"
 
 // [R=Cout][K] -> dst[k*ld + co_off + co], 32x32 LDS tiles, both sides coalesced
-__global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ dst,
-                                                       int Cout, int K, int ld, int co_off)
+__device__ __forceinline__ void pack_fwd_tile(const float* __restrict__ w, float* __restrict__ dst, int Cout, int K, int ld, int co_off,
+                                              int bx, int by, float* smem)
 {
-    __shared__ float tile[32][33];
-    const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    float (*tile)[33] = reinterpret_cast<float (*)[33]>(smem);
+    const int k0 = bx * 32, c0 = by * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
     for (int r = ty; r < 32; r += 8) {
         const int co = c0 + r, k = k0 + tx;
@@ -33,10 +33,10 @@ __global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__
 }
 
 // one block per (ci tile of 32, co): load W[co][ci0..ci0+32)[taps] (contiguous) and scatter rows of 32 ci
-__global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ dst, PackDgradArgs a)
+__device__ __forceinline__ void pack_dgrad_tile(const float* __restrict__ w, float* __restrict__ dst, const PackDgradArgs& a, int bx, int by,
+                                                float* lds)
 {
-    extern __shared__ float lds[];
-    const int ci0 = blockIdx.x * 32, co = blockIdx.y;
+    const int ci0 = bx * 32, co = by;
     const int khkw = a.KH * a.KW;
     int nci = a.Cin - ci0; if (nci > 32) nci = 32;
     const float* src = w + ((long long)co * a.Cin + ci0) * khkw;
@@ -61,10 +61,88 @@ __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict
     }
 }
 
+// Wt[ci][(co_off + co) * KW + kwp] = W[co][ci][KW-1-kwp]   (transposed + flipped copy for the fused trunk data-gradient)
+__device__ __forceinline__ void pack_trunk_t_tile(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int KW, int ld,
+                                                  int co_off, int bx, int by, float* smem)
+{
+    float (*tile)[33] = reinterpret_cast<float (*)[33]>(smem);
+    const int ci0 = bx * 32, co0 = by * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int kw = 0; kw < KW; ++kw) {
+        for (int r = ty; r < 32; r += 8) {          // r = co, tx = ci
+            const int co = co0 + r, ci = ci0 + tx;
+            tile[r][tx] = (co < Cout && ci < Cin) ? w[((long long)co * Cin + ci) * KW + kw] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {          // r = ci, tx = co
+            const int ci = ci0 + r, co = co0 + tx;
+            if (ci < Cin && co < Cout) dst[(long long)ci * ld + (long long)(co_off + co) * KW + (KW - 1 - kw)] = tile[tx][r];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) pack_fwd_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int K, int ld, int co_off)
+{
+    __shared__ float smem[32 * 33];
+    pack_fwd_tile(w, dst, Cout, K, ld, co_off, blockIdx.x, blockIdx.y, smem);
+}
+
+__global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ dst, PackDgradArgs a)
+{
+    extern __shared__ float lds[];
+    pack_dgrad_tile(w, dst, a, blockIdx.x, blockIdx.y, lds);
+}
+
+__global__ void __launch_bounds__(256) pack_trunk_t_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int KW, int ld,
+                                                           int co_off)
+{
+    __shared__ float smem[32 * 33];
+    pack_trunk_t_tile(w, dst, Cout, Cin, KW, ld, co_off, blockIdx.x, blockIdx.y, smem);
+}
+
 __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
+}
+
+// Whole-network re-pack in ONE launch: a device-resident job table maps each workgroup to (job, tile).  Replaces ~130
+// tiny launches per generator (and their launch gaps) after every optimizer step.
+__global__ void __launch_bounds__(256) pack_net_kernel(const PackJob* __restrict__ jobs, int njobs, const PackDgradArgs* __restrict__ dga,
+                                                       const PackPtrs ptrs, float* __restrict__ packed)
+{
+    extern __shared__ float lds[];
+    const int blk = blockIdx.x;
+    int lo = 0, hi = njobs - 1;                       // last job with block0 <= blk
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (jobs[mid].block0 <= blk) lo = mid; else hi = mid - 1; }
+    const PackJob j = jobs[lo];
+    const int rel = blk - j.block0;
+    const int bx = rel % j.gx, by = rel / j.gx;
+    const float* w = ptrs.p[j.param];
+    float* dst = packed + j.dst;
+    switch (j.kind) {
+    case PACK_FWD: pack_fwd_tile(w, dst, j.Cout, j.K, j.ld, j.co_off, bx, by, lds); break;
+    case PACK_DGRAD: pack_dgrad_tile(w, dst, dga[j.dg], bx, by, lds); break;
+    case PACK_TRUNK_T: pack_trunk_t_tile(w, dst, j.Cout, j.Cin, j.KW, j.ld, j.co_off, bx, by, lds); break;
+    default: { const int i = rel * 256 + threadIdx.x; if (i < j.Cout) dst[i] = w[i]; } break;     // PACK_COPY
+    }
+}
+
+int mcvc_pack_net_launch(const PackJob* d_jobs, int njobs, int nblocks, const PackDgradArgs* d_dga, const PackPtrs& ptrs, float* packed,
+                         double bytes, hipStream_t s)
+{
+    TraceScope ts(K_PACK, s, 0.0, bytes);
+    hipLaunchKernelGGL(pack_net_kernel, dim3((unsigned)nblocks), dim3(256), kPackNetLds, s, d_jobs, njobs, d_dga, ptrs, packed);
+    return (int)hipGetLastError();
+}
+
+int mcvc_pack_trunk_t_launch(const float* w, float* dst, int Cout, int Cin, int KW, int ld, int co_off, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv_i(Cin, 32), (unsigned)cdiv_i(Cout, 32));
+    TraceScope ts(K_PACK, s, 0.0, 8.0 * (double)Cout * Cin * KW);
+    hipLaunchKernelGGL(pack_trunk_t_kernel, grid, dim3(256), 0, s, w, dst, Cout, Cin, KW, ld, co_off);
+    return (int)hipGetLastError();
 }
 
 int mcvc_pack_fwd_launch(const float* w, float* dst, int Cout, int K, int ld, int co_off, hipStream_t s)

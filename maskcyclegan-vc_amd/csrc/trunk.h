@@ -23,5 +23,4 @@ struct TrunkArgs {
 bool mcvc_trunk_applies(int Cin, int KW, int M, int B, int T4, int mode, int ksplit);
 long long mcvc_trunk_lds_floats(int Cin, int KW, int B, int T4, int ksplit);
 int mcvc_trunk_launch(const TrunkArgs& a, int ksplit, hipStream_t s);
-int mcvc_pack_trunk_t_launch(const float* w, float* dst, int Cout, int Cin, int KW, int ld, int co_off, hipStream_t s);
 int mcvc_fill_rows_launch(float* dst, const float* bias, int C, int per_row, hipStream_t s);

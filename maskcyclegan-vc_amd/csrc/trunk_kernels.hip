@@ -259,27 +259,6 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const TrunkA
     }
 }
 
-// Wt[ci][(co_off + co) * KW + kwp] = W[co][ci][KW-1-kwp]   (transposed + flipped copy for the trunk data-gradient)
-__global__ void __launch_bounds__(256) pack_trunk_t_kernel(const float* __restrict__ w, float* __restrict__ dst, int Cout, int Cin, int KW,
-                                                           int ld, int co_off)
-{
-    __shared__ float tile[32][33];
-    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int kw = 0; kw < KW; ++kw) {
-        for (int r = ty; r < 32; r += 8) {          // r = co, tx = ci : reads stride KW (small), fine
-            const int co = co0 + r, ci = ci0 + tx;
-            tile[r][tx] = (co < Cout && ci < Cin) ? w[((long long)co * Cin + ci) * KW + kw] : 0.f;
-        }
-        __syncthreads();
-        for (int r = ty; r < 32; r += 8) {          // r = ci, tx = co : consecutive co -> stride KW floats
-            const int ci = ci0 + r, co = co0 + tx;
-            if (ci < Cin && co < Cout) dst[(long long)ci * ld + (long long)(co_off + co) * KW + (KW - 1 - kw)] = tile[tx][r];
-        }
-        __syncthreads();
-    }
-}
-
 // dst[c][0..per_row) = bias ? bias[c] : 0   (initial value of an atomically accumulated K-split trunk layer)
 __global__ void __launch_bounds__(256) fill_rows_kernel(float* __restrict__ dst, const float* __restrict__ bias, int C, int per_row)
 {
@@ -345,12 +324,4 @@ int mcvc_trunk_launch(const TrunkArgs& a, int ksplit, hipStream_t s)
     const bool wide = a.N > 16;
     if (a.KW == 3) return wide ? trunk_launch_t<3, 2>(a, grid, lds, s) : trunk_launch_t<3, 1>(a, grid, lds, s);
     return wide ? trunk_launch_t<1, 2>(a, grid, lds, s) : trunk_launch_t<1, 1>(a, grid, lds, s);
-}
-
-int mcvc_pack_trunk_t_launch(const float* w, float* dst, int Cout, int Cin, int KW, int ld, int co_off, hipStream_t s)
-{
-    dim3 grid((unsigned)cdiv_i(Cin, 32), (unsigned)cdiv_i(Cout, 32));
-    TraceScope ts(K_PACK, s, 0.0, 8.0 * (double)Cout * Cin * KW);
-    hipLaunchKernelGGL(pack_trunk_t_kernel, grid, dim3(256), 0, s, w, dst, Cout, Cin, KW, ld, co_off);
-    return (int)hipGetLastError();
 }
