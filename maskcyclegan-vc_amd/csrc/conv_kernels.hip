@@ -59,7 +59,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l)
 // KW is a template parameter: the kw taps of a kernel row are fully unrolled and their LDS offsets are
 // ds_read immediates.  (With runtime kh/kw/stride arithmetic each tap cost ~30 SALU instructions; the scalar unit
 // is shared by the CU's 8 resident waves, which made the loop SALU-bound at ~2x the MFMA time.)
-template <int WM, int WN, int BMW, int BNW, int KW>
+template <int WM, int WN, int BMW, int BNW, int KW, bool S2>
 __global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
     const int oh0 = tile_y * toh, ow0 = tile_x * tow;
     const int ih0 = oh0 * a.stride - a.pad_h;
     const int iw0 = ow0 * a.stride - a.pad_w;
-    const bool s2 = (a.stride == 2);
+    constexpr bool s2 = S2;                          // stride 2 (de-interleaved patch columns) is a compile-time variant
 
     // LDS map (float offsets into smem): [X buf0][X buf1][W buf0][W buf1].  Buffers are addressed as
     // smem[offset] -- never through a selected pointer, which would decay to a flat pointer and turn every
@@ -203,35 +203,55 @@ __global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
             if (!(a.dbg & 1)) dma_weights(ch + 1, wbase + (cur ^ 1) * ws_floats);
             if (!(a.dbg & 2)) fetch_patch(ch + 1);
         }
-        // ---- MFMA main loop: (channel pair, kh) at run time, the KW taps of a row unrolled with immediate offsets
-        int a_off = wbase + cur * ws_floats + a_lane;
-        int x_pair = cur * a.xs_floats;
-        for (int cp = 0; cp < ((a.dbg & 4) ? 0 : npairs); ++cp) {
-            int x_row = x_pair;
-            for (int kh = 0; kh < a.KH; ++kh) {
-                int xe[WN], xo[WN];
+        // ---- MFMA main loop: (channel pair, kh) rows at run time, the KW taps of a row unrolled with immediate
+        // offsets.  Operand reads are software-pipelined one tap ahead (the reads of tap t+1 -- or of the next row's
+        // first tap -- are issued before the MFMAs of tap t), so the LDS latency hides behind the matrix pipe instead of
+        // sitting between every pair of MFMAs.
+        if (!(a.dbg & 4)) {
+            int a_off = wbase + cur * ws_floats + a_lane;
+            int x_row = cur * a.xs_floats;
+            const int nrows = npairs * a.KH;
+            float av[WM], bv[WN];
+            auto load_tap = [&](int aoff, int xrow, int kw, float (&ra)[WM], float (&rb)[WN]) {
 #pragma unroll
-                for (int j = 0; j < WN; ++j) { xe[j] = x_row + b_lane[j]; xo[j] = xe[j] + odd_off; }
+                for (int i = 0; i < WM; ++i) ra[i] = smem[aoff + kw * COT + i * 32];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    // stride 1: column kw.  stride 2 (de-interleaved): even kw -> kw/2, odd kw -> PWh + kw/2
+                    const int xo = xrow + b_lane[j];
+                    rb[j] = s2 ? ((kw & 1) ? smem[xo + odd_off + (kw >> 1)] : smem[xo + (kw >> 1)]) : smem[xo + kw];
+                }
+            };
+            load_tap(a_off, x_row, 0, av, bv);
+            int kh = 0;
+            for (int row = 0; row < nrows; ++row) {
+                int a_next = a_off + KW * COT, x_next = x_row + a.PWp;
+                if (++kh == a.KH) {                 // next channel pair: skip the odd channel's weight rows / plane
+                    kh = 0;
+                    a_next += KHKW * COT;
+                    x_next += 2 * a.plane - a.KH * a.PWp;
+                }
+                if (row + 1 == nrows) { a_next = a_off; x_next = x_row; }      // nothing follows: harmless re-read
 #pragma unroll
                 for (int kw = 0; kw < KW; ++kw) {
-                    float av[WM], bv[WN];
-#pragma unroll
-                    for (int i = 0; i < WM; ++i) av[i] = smem[a_off + kw * COT + i * 32];
-#pragma unroll
-                    for (int j = 0; j < WN; ++j) {
-                        // stride 1: column kw.  stride 2 (de-interleaved): even kw -> kw/2, odd kw -> PWh + kw/2
-                        bv[j] = s2 ? ((kw & 1) ? smem[xo[j] + (kw >> 1)] : smem[xe[j] + (kw >> 1)]) : smem[xe[j] + kw];
-                    }
+                    float nav[WM], nbv[WN];
+                    if (kw + 1 < KW) load_tap(a_off, x_row, kw + 1, nav, nbv);
+                    else load_tap(a_next, x_next, 0, nav, nbv);
 #pragma unroll
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
                         for (int j = 0; j < WN; ++j) acc[i][j] = MFMA32(av[i], bv[j], acc[i][j]);
+                    // pin the order "reads of the next tap, then this tap's MFMAs": left alone, the scheduler sinks the
+                    // reads below the MFMAs to shorten live ranges and re-exposes the LDS latency
+                    __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, WM * WN, 0);
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) av[i] = nav[i];
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) bv[j] = nbv[j];
                 }
-                a_off += KW * COT;
-                x_row += a.PWp;
+                a_off = a_next; x_row = x_next;
             }
-            a_off += KHKW * COT;                    // skip the odd channel's rows (read by the upper half-wave)
-            x_pair += 2 * a.plane;
         }
         if (more && !(a.dbg & 2)) commit_patch((cur ^ 1) * a.xs_floats);
         __syncthreads();
@@ -285,11 +305,17 @@ static int env_int(const char* name, int dflt)
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-static int conv_lds_budget_floats() { static const int v = env_int("MCVC_CONV_LDS_KB", 78) * 256; return v; }
-static int conv_small_tile_below() { static const int v = env_int("MCVC_CONV_Q_BELOW", 0); return v; }
+// planner knobs (tools/conv_tune.py): read once, or on every call when MCVC_CONV_TUNE=1 was set at load time
+static int conv_knob(const char* name, int dflt)
+{
+    static const int tune = env_int("MCVC_CONV_TUNE", 0);
+    if (tune) return env_int(name, dflt);
+    return dflt;
+}
+static int conv_lds_budget_floats() { static const int v = env_int("MCVC_CONV_LDS_KB", 78) * 256; return conv_knob("MCVC_CONV_LDS_KB", v / 256) * 256; }
 static int conv_debug_bits() { static const int v = env_int("MCVC_CONV_DEBUG", 0); return v; }   // timing ablations only (wrong results)
 
-enum ConvCfg { CFG_L = 0, CFG_M, CFG_N, CFG_T, CFG_S, CFG_S2, CFG_Q, CFG_COUNT };
+enum ConvCfg { CFG_L = 0, CFG_M, CFG_N, CFG_T, CFG_S, CFG_S2, CFG_COUNT };
 struct CfgDesc { int cot, npix, kind; };
 static const CfgDesc kCfg[CFG_COUNT] = {
     {128, 128, K_CONV_L},   // L: 2x2 waves of 2x2 accumulators
@@ -298,7 +324,6 @@ static const CfgDesc kCfg[CFG_COUNT] = {
     {256, 32, K_CONV_T},    // T: 4x1 waves of 2x1   (1-D trunk: few pixels, many channels)
     {32, 256, K_CONV_S},    // S: 1x4 waves of 1x2   (Cout <= 32)
     {32, 128, K_CONV_S2},   // S2: 1x4 waves of 1x1  (Cout <= 32, small images)
-    {64, 64, K_CONV_Q},     // Q: 2x2 waves of 1x1   (small batch: twice the workgroups of M, half the LDS)
 };
 
 constexpr int kLdsBudgetFloats = 19 * 1024 + 512;   // 78 KiB per workgroup -> 2 workgroups per CU (160 KiB LDS)
@@ -334,28 +359,38 @@ static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_n
 {
     if (p.stride != 1 && p.stride != 2) return false;
     if (p.KW != 1 && p.KW != 2 && p.KW != 3 && p.KW != 5 && p.KW != 15) return false;
+    if (p.stride == 2 && p.KW != 3 && p.KW != 5) return false;
     const int tow_log2 = pick_tow_log2(p.OW);
     const int tow = 1 << tow_log2, rps = 32 >> tow_log2;
     const int npix_img = p.OH * p.OW;
     // candidate tile configurations in order of preference; the first one whose LDS / register-prefetch
     // geometry fits is used
+    // Rules distilled from the per-layer sweep of tools/conv_tune.py on gfx950 (profiles/r01_conv_tune.log):
+    //  * <= 3x3-sized filters on small images (<= 320 px) with many output channels stream weights: the 256-channel
+    //    x 32-pixel tile (T) wins by 10-45 %;
+    //  * few output channels (<= 256): the 32-channel x 128-pixel tile (S2) -- many more workgroups, and as fast per
+    //    MFMA as the big tiles because every wave keeps only one accumulator (more resident waves);
+    //  * otherwise the 128x128 tile (L) when the image is large enough to tile without waste and split-K can still
+    //    fill the chip, else 128x64 (M) under the same condition, else S2.
     int cand[4], ncand = 0;
+    const int khkw_ = p.KH * p.KW;
     if (p.Cout <= 32) {
-        if (npix_img > 160) cand[ncand++] = CFG_S;
+        if (npix_img <= 320 && khkw_ <= 9) cand[ncand++] = CFG_T;
         cand[ncand++] = CFG_S2; cand[ncand++] = CFG_S;
-    } else if (npix_img <= 48 && p.Cout >= 256) {
+    } else if (khkw_ <= 9 && npix_img <= 320 && p.Cout >= 256) {
         cand[ncand++] = CFG_T; cand[ncand++] = CFG_M; cand[ncand++] = CFG_N;
-    } else if (p.KH * p.KW > 25 || p.Cout <= 64) {
-        cand[ncand++] = CFG_N; cand[ncand++] = CFG_M;
+    } else if (p.Cout <= 256) {
+        cand[ncand++] = CFG_S2; cand[ncand++] = CFG_M; cand[ncand++] = CFG_N;
     } else {
-        const int toh_l = (kCfg[CFG_L].npix / 32) * rps;
+        const int toh_l = (kCfg[CFG_L].npix / 32) * rps, toh_m = (kCfg[CFG_M].npix / 32) * rps;
         const long long blocks_l = (long long)cdiv_i(p.OW, tow) * cdiv_i(p.OH, toh_l) * cdiv_i(p.Cout, 128) * NB;
-        if (blocks_l >= 512) cand[ncand++] = CFG_L;      // the big tile only when it still fills the chip
-        const int toh_m = (kCfg[CFG_M].npix / 32) * rps;
         const long long blocks_m = (long long)cdiv_i(p.OW, tow) * cdiv_i(p.OH, toh_m) * cdiv_i(p.Cout, 128) * NB;
-        if (blocks_m < conv_small_tile_below()) cand[ncand++] = CFG_Q;
+        const int max_split = 16;          // (the same for the planning and the launching call: both must pick one tile)
+        if (npix_img >= 1024 && blocks_l * max_split >= 512 && khkw_ <= 25) cand[ncand++] = CFG_L;
+        else if (blocks_m * max_split < 512) cand[ncand++] = CFG_S2;
         cand[ncand++] = CFG_M; cand[ncand++] = CFG_N;
     }
+    if (conv_knob("MCVC_CONV_CFG", -1) >= 0) { cand[0] = conv_knob("MCVC_CONV_CFG", -1); ncand = 1; }
     const int khkw = p.KH * p.KW;
     const int cin_pad = round_up_i(p.Cin, 2);
     for (int t = 0; t < ncand; ++t) {
@@ -398,6 +433,10 @@ static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_n
                 if (nsplit > 16) nsplit = 16;             // every slab is re-read by the consumer kernel
                 if (nsplit < 1) nsplit = 1;
             }
+            if (allow_split && conv_knob("MCVC_CONV_NSPLIT", 0) > 0) {
+                nsplit = conv_knob("MCVC_CONV_NSPLIT", 0);
+                if (nsplit > a.nchunks) nsplit = a.nchunks;
+            }
             a.chunks_per_split = cdiv_i(a.nchunks, nsplit);
             a.nsplit = cdiv_i(a.nchunks, a.chunks_per_split);
         }
@@ -408,16 +447,19 @@ static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_n
         a.tiles_total = a.tiles_w * tiles_h; a.nb = NB;
         pl.grid = dim3((unsigned)(a.tiles_total * cotiles * NB * a.nsplit));
         pl.lds_bytes = (size_t)2 * (a.xs_floats + cic * khkw * cot) * sizeof(float);
+        if (conv_knob("MCVC_CONV_VERBOSE", 0))
+            fprintf(stderr, "[conv plan] Cin=%d Cout=%d k=%dx%d s=%d NB=%d out=%dx%d | cfg=%d cic=%d chunks=%d nsplit=%d grid=%u lds=%zu\n",
+                    p.Cin, p.Cout, p.KH, p.KW, p.stride, NB, p.OH, p.OW, cfg, cic, a.nchunks, a.nsplit, pl.grid.x, pl.lds_bytes);
         *out = pl;
         return true;
     }
     return false;
 }
 
-template <int WM, int WN, int BMW, int BNW, int KW>
+template <int WM, int WN, int BMW, int BNW, int KW, bool S2>
 static hipError_t launch_cfg_kw(const ConvPlan& pl, hipStream_t s)
 {
-    auto kern = conv_direct_kernel<WM, WN, BMW, BNW, KW>;
+    auto kern = conv_direct_kernel<WM, WN, BMW, BNW, KW, S2>;
     static bool attr_done = false;             // once per instantiation (benign race: idempotent)
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -436,12 +478,19 @@ static hipError_t launch_cfg_kw(const ConvPlan& pl, hipStream_t s)
 template <int WM, int WN, int BMW, int BNW>
 static hipError_t launch_cfg(const ConvPlan& pl, hipStream_t s)
 {
+    if (pl.a.stride == 2) {                     // the network's strided convs are 5x5 (generator) and 3x3 (discriminator)
+        switch (pl.a.KW) {
+            case 3: return launch_cfg_kw<WM, WN, BMW, BNW, 3, true>(pl, s);
+            case 5: return launch_cfg_kw<WM, WN, BMW, BNW, 5, true>(pl, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (pl.a.KW) {
-        case 1: return launch_cfg_kw<WM, WN, BMW, BNW, 1>(pl, s);
-        case 2: return launch_cfg_kw<WM, WN, BMW, BNW, 2>(pl, s);
-        case 3: return launch_cfg_kw<WM, WN, BMW, BNW, 3>(pl, s);
-        case 5: return launch_cfg_kw<WM, WN, BMW, BNW, 5>(pl, s);
-        case 15: return launch_cfg_kw<WM, WN, BMW, BNW, 15>(pl, s);
+        case 1: return launch_cfg_kw<WM, WN, BMW, BNW, 1, false>(pl, s);
+        case 2: return launch_cfg_kw<WM, WN, BMW, BNW, 2, false>(pl, s);
+        case 3: return launch_cfg_kw<WM, WN, BMW, BNW, 3, false>(pl, s);
+        case 5: return launch_cfg_kw<WM, WN, BMW, BNW, 5, false>(pl, s);
+        case 15: return launch_cfg_kw<WM, WN, BMW, BNW, 15, false>(pl, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -480,7 +529,6 @@ int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float
         case CFG_N: e = launch_cfg<1, 2, 2, 2>(pl, s); break;
         case CFG_T: e = launch_cfg<2, 1, 4, 1>(pl, s); break;
         case CFG_S2: e = launch_cfg<1, 1, 1, 4>(pl, s); break;
-        case CFG_Q: e = launch_cfg<1, 1, 2, 2>(pl, s); break;
         default:    e = launch_cfg<1, 2, 1, 4>(pl, s); break;
     }
     return (int)e;
