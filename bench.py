@@ -60,6 +60,17 @@ def build_nets(device):
     return nets
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of this kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    tools/pmc_traffic.py); None when no PMC summary for it is in profiles/ (the counters cannot be read from inside the bench)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            fam = json.load(fh)["families"].get(kernel)
+        return None if fam is None else fam["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def trace_one_step(engine, batch):
     from mask_cyclegan_vc import _hip
     L = _hip.lib()
@@ -222,7 +233,7 @@ def main():
             total_ms = sum(r["ms"] for r in rows)
             ach = dom["gflop"] / dom["ms"]          # GFLOP/ms == TFLOP/s
             res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "kernel": dom["kernel"],
+                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom["kernel"]), "kernel": dom["kernel"],
                                "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                                "share_of_kernel_time": dom["ms"] / total_ms}
             res["kernel_time_ms_per_step"] = {r["kernel"]: round(r["ms"], 4) for r in rows}
