@@ -111,6 +111,10 @@ class TrainEngine:
         self.use_graphs = False
         self._graphs, self._eager_runs = {}, {}
         self._capture_stream = torch.cuda.Stream(device=dev)
+        # data parallel: start the discriminator gradient all-reduce at the end of an iteration and finish the update
+        # (wait + Adam + re-pack) where the discriminators are next used, i.e. after the next generator forwards
+        self.defer_d_update = self.reducer.world > 1
+        self._pending_d_lr = None
         self._workspaces = {}
         self._use(batch_size)
         self.reducer.broadcast_(self.g_group.flat)
@@ -234,7 +238,8 @@ class TrainEngine:
         B, B2 = self.B, 2 * self.B
         m = self.mel
         sc = self.sched
-        self.repack(D_NAMES)               # discriminator weights changed at the end of the previous iteration
+        if not self.defer_d_update:
+            self.repack(D_NAMES)           # discriminator weights changed at the end of the previous iteration
         self.slots.zero_()
         self.g_group.grad.zero_()
         # batched inputs (device-to-device copies; the batch dimension is outermost, so halves are contiguous views)
@@ -252,6 +257,9 @@ class TrainEngine:
         self._lanes(lambda ln: self._G("generator_B2A", fake_B, None, m["cycle_A"], self.g_stash1[0], B, ln),                  # :204 (mask of ones)
                     lambda ln: self._G("generator_A2B", fake_A, None, m["cycle_B"], self.g_stash1[1], B, ln))                  # :206
 
+        if self.defer_d_update:            # data parallel: the D gradient all-reduce of the previous iteration ran behind the
+            self._finish_d_update()        # generator forwards above; the discriminators are first needed here
+            self.repack(D_NAMES)
         self._lanes(lambda ln: self._D("discriminator_A", fake_A, do[0], ds[0], B, ln),              # :211
                     lambda ln: self._D("discriminator_B", fake_B, do[1], ds[1], B, ln),              # :212
                     lambda ln: self._D("discriminator_A2", m["cycle_A"], do[2], ds[2], B, ln),       # :215
@@ -314,10 +322,27 @@ class TrainEngine:
         self._lanes(*[(lambda ln, n=n: self._D_bwd(n, dl[idx[n]], None, 0, ds[idx[n]], True, B2, ln)) for n in D_NAMES])
 
     def discriminator_update(self):
-        """train.py:299"""
+        """train.py:299.  With more than one rank the all-reduce is only *started* here; Adam runs when the discriminators
+        are next needed (``_finish_d_update``), so the exchange overlaps the next iteration's generator forwards."""
+        if self.defer_d_update:
+            self.reducer.reduce_async_(self.d_group.grad)
+            self._pending_d_lr = self.sched.d_opt_lr          # the value torch.optim would have used now
+            return
         self.reducer.reduce_(self.d_group.grad)
         self._adam(self.d_group, self.sched.d_opt_lr)
         self._stale_d = True
+
+    def _finish_d_update(self):
+        if self._pending_d_lr is None:
+            return
+        self.reducer.wait(self.device)
+        self._adam(self.d_group, self._pending_d_lr)
+        self._pending_d_lr = None
+        self._stale_d = True
+
+    def flush(self):
+        """Complete a deferred discriminator update (call before reading parameters / optimizer state from outside)."""
+        self._finish_d_update()
 
     def step(self, real_A, mask_A, real_B, mask_B):
         """One full iteration.  Inputs: float32 [B,80,T] on the engine's device.  Returns the loss-slot
@@ -385,6 +410,7 @@ class TrainEngine:
     def optimizer_state_dict(self, which):
         """``torch.optim.Adam.state_dict()``-shaped dict: per-parameter ``step/exp_avg/exp_avg_sq`` keyed by the
         position in the concatenated parameter list (G: 0..219; D: 0..79 with the dead 14-17,34-37,... absent)."""
+        self.flush()
         grp = self.g_group if which == "G" else self.d_group
         names = G_NAMES if which == "G" else D_NAMES
         lr = self.sched.g_opt_lr if which == "G" else self.sched.d_opt_lr
@@ -408,6 +434,7 @@ class TrainEngine:
         return {"state": state, "param_groups": [group]}
 
     def load_optimizer_state_dict(self, which, sd):
+        self.flush()
         grp = self.g_group if which == "G" else self.d_group
         names = G_NAMES if which == "G" else D_NAMES
         idx, off, step = 0, 0, 0

@@ -74,6 +74,29 @@ class FlatGradReducer:
                 dist.all_reduce(flat[lo:min(n, lo + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
+    def reduce_async_(self, flat: torch.Tensor):
+        """Start the bucketed SUM all-reduce of ``flat`` on the communication stream and return immediately; the caller's
+        stream keeps computing.  ``wait()`` makes the current stream wait for it.  (The engine uses this to hide the
+        discriminator gradient exchange behind the next iteration's generator forwards.)"""
+        if self.world == 1:
+            return flat
+        if not (flat.is_cuda and self._use_side_stream):
+            return self.reduce_(flat)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=flat.device)
+        cur = torch.cuda.current_stream(flat.device)
+        self._stream.wait_stream(cur)
+        n = flat.numel()
+        with torch.cuda.stream(self._stream):
+            for lo in range(0, n, self.bucket_elems):
+                dist.all_reduce(flat[lo:min(n, lo + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
+    def wait(self, device=None):
+        """Order the current stream after everything queued on the communication stream."""
+        if self._stream is not None:
+            torch.cuda.current_stream(device).wait_stream(self._stream)
+
     def broadcast_(self, flat: torch.Tensor, src=0):
         """Make every rank start from rank ``src``'s parameters."""
         if self.world > 1:

@@ -107,10 +107,12 @@ class MaskCycleGANVCTraining(object):
                 if self.args.max_iters and done >= self.args.max_iters:
                     break
             if epoch % self.epochs_per_save == 0:
+                self.engine.flush()                                        # a deferred (data-parallel) D update must land first
                 self.save_all(epoch)
             self.logger.end_epoch()
             if self.args.max_iters and done >= self.args.max_iters:
                 break
+        self.engine.flush()
 
 
 def main(argv=None):

@@ -150,3 +150,23 @@ def test_building_blocks_match_torch():
     a = F.instance_norm(F.conv2d(x2, q["convLayer.0.weight"], q["convLayer.0.bias"], 2, 2), None, None, q["convLayer.1.weight"], q["convLayer.1.bias"], True, 0.0, 1e-5)
     gt = F.instance_norm(F.conv2d(x2, q["convLayer_gates.0.weight"], q["convLayer_gates.0.bias"], 2, 2), None, None, q["convLayer_gates.1.weight"], q["convLayer_gates.1.bias"], True, 0.0, 1e-5)
     assert rel_l2(ds.cuda()(x2.cuda()), a * torch.sigmoid(gt)) < TOL
+
+
+def test_inference_config_bs16_512_frames(nets, meta):
+    """BASELINE configs[4] shape (generator_A2B inference, 80 x 512 frames, bs=16; computed in fp32 here, i.e. at or above
+    the bf16 the config names): every sample of the batched forward equals its own bs=1 forward (per-sample ops only),
+    and sample 0 matches the CPU oracle within 1e-3."""
+    g = nets[0]
+    rs = np.random.RandomState(5)
+    x = torch.from_numpy(rs.randn(16, 80, 512).astype(np.float32)).cuda()
+    mask = torch.ones_like(x)
+    with torch.no_grad():
+        y = g(x, mask)
+        assert y.shape == (16, 80, 512) and bool(torch.isfinite(y).all())
+        for i in (0, 7, 15):
+            yi = g(x[i:i + 1].contiguous(), mask[i:i + 1].contiguous())
+            assert float((y[i:i + 1] - yi).abs().max()) <= 1e-4 * float(yi.abs().max())
+    p = {k: v.detach().cpu() for k, v in g.state_dict().items()}
+    ref = orc.generator_forward(p, x[:1].cpu(), mask[:1].cpu())
+    err = float((y[:1].cpu() - ref).norm() / ref.norm())
+    assert err < 1e-3, err
