@@ -150,6 +150,7 @@ def main():
     rank, world, local_rank = init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    local_rank %= max(torch.cuda.device_count(), 1)      # (only differs on a box with fewer GPUs than ranks: gloo test runs)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     B, T = args.batch_size, args.frames
@@ -172,6 +173,7 @@ def main():
         if i == 0:
             lo = engine.losses()
             first = (lo["g_loss"], lo["d_loss"])
+    engine.flush()                         # a deferred (data-parallel) discriminator update belongs to the warm-up
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -180,6 +182,7 @@ def main():
     for i in range(args.steps):
         engine.step(*batches[(args.warmup + i) % len(batches)])
         engine.losses()                    # the reference reads both losses every iteration (train.py:303)
+    engine.flush()                         # ... and the last one to the timed region: exactly K complete iterations
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
