@@ -57,6 +57,15 @@ int mcvc_gen_backward(const float* const* params, const float* packed, float* co
                       float* scratch, long long scratch_floats, int B, int T, void* stream, void* aux_stream);
 /*      aux_stream (nullable): a second hipStream_t on which the weight-gradient kernels run beside the data-gradient
  *      chain; the call returns with `stream` ordered after everything launched on aux_stream.            */
+/*      Same, plus gradient-ready milestones for overlapping a data-parallel all-reduce with the rest of the pass
+ *      (new: the reference has no distributed code).  milestones (nullable): two caller-owned hipEvent_t handles;
+ *      [0] is recorded once every gradient of parameters [100,110) (upSample1/2 + lastConvLayer; named_parameters()
+ *      order) has been produced, [1] once those of [24,100) (six residual blocks + conv1dto2d) have; the remaining
+ *      [0,24) are complete when the call's work on `stream` is.  A consumer stream waits on the event.       */
+int mcvc_gen_backward_overlap(const float* const* params, const float* packed, float* const* grads, const float* mask,
+                              const float* dout, float* dx, int accumulate_dx, const float* stash,
+                              float* scratch, long long scratch_floats, int B, int T, void* stream, void* aux_stream,
+                              void* const* milestones);
 
 /* ---- Discriminator: replaces Discriminator.forward (model.py:340-349) and its autograd
  *      x: [B,80,T]; out: [B,1,10,T8] sigmoid probabilities                                          */

@@ -658,8 +658,23 @@ static void gen_forward_impl(Exec& ex, const float* const* P, const float* packe
     if (ns > 1) act_fwd(ex, out, (long long)B * 80 * Wu2, ns, nullptr, B, 1, 80 * Wu2, ACT_NONE);
 }
 
+// every gradient kernel launched so far (main stream: norm / bias gradients; aux stream: weight gradients) is ordered
+// before `ev`
+static void record_milestone(Exec& ex, void* ev)
+{
+    if (!ev || ex.dry) return;
+    hipStream_t on = ex.s;
+    if (ex.s2) {
+        hipEvent_t e = pool_event();
+        ex.fail((int)hipEventRecord(e, ex.s));
+        ex.fail((int)hipStreamWaitEvent(ex.s2, e, 0));
+        on = ex.s2;
+    }
+    ex.fail((int)hipEventRecord((hipEvent_t)ev, on));
+}
+
 static void gen_backward_impl(Exec& ex, const float* const* P, const float* packed, float* const* G, const float* mask, const float* dout,
-                              float* dx, int accumulate_dx, const float* stc, float* sc, const GenDims& d)
+                              float* dx, int accumulate_dx, const float* stc, float* sc, const GenDims& d, void* const* milestones = nullptr)
 {
     const GenNet& g = gen_net();
     const GenStash o = gen_stash(d);
@@ -708,6 +723,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         conv_bias_grad(ex, g.up1, G, B, dyv, 20 * W4);
         conv_dgrad(ex, g.up1, packed, B, 20, W4, dyv, View{GA, 256LL * 20 * W4, 20LL * W4, W4}, (long long)B * 5120 * W4, 0, 1, &ns);
     }
+    if (milestones) record_milestone(ex, milestones[0]);          // parameters [100,110) are done
     // ---- conv1dto2d + IN (:266-271): dy arrives NCHW, dx leaves in trunk layout
     GB = nextGB();
     norm_bwd(ex, st + o.c6, W4, BT4, normp(P, G, 98, 99), st + o.s6, GA, 5120LL * W4, W4, W4, 5120 * BT4, ns,
@@ -743,6 +759,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         }
         ns = 1;
     }
+    if (milestones) record_milestone(ex, milestones[1]);          // parameters [24,100) are done
     // ---- conv2dto1d + IN (:254-255)
     DT3 = DT3s[1];
     norm_bwd(ex, st + o.c4, W4, BT4, normp(P, G, 22, 23), st + o.s4, DH, W4, BT4, W4, 256 * BT4, 1, DT3, W4, BT4, W4, 0, B, 256, 1, W4, ACT_NONE);
@@ -1048,16 +1065,24 @@ int mcvc_gen_forward(const float* const* params, const float* packed, const floa
     return ex.err;
 }
 
-int mcvc_gen_backward(const float* const* params, const float* packed, float* const* grads, const float* mask, const float* dout,
-                      float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T, void* stream,
-                      void* aux_stream)
+int mcvc_gen_backward_overlap(const float* const* params, const float* packed, float* const* grads, const float* mask, const float* dout,
+                              float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T,
+                              void* stream, void* aux_stream, void* const* milestones)
 {
     if (B < 1 || T < 1 || !params || !packed || !dout || !stash || !scratch) return MCVC_ERR_INVALID;
     const GenDims d = gen_dims(B, T);
     Exec ex = make_exec(stream, aux_stream, scratch, scratch_floats, gen_scratch(d).slabs, gen_needs(B, T));
     if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
-    gen_backward_impl(ex, params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, d);
+    gen_backward_impl(ex, params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, d, milestones);
     return ex.err;
+}
+
+int mcvc_gen_backward(const float* const* params, const float* packed, float* const* grads, const float* mask, const float* dout,
+                      float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T, void* stream,
+                      void* aux_stream)
+{
+    return mcvc_gen_backward_overlap(params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, scratch_floats, B, T, stream,
+                                     aux_stream, nullptr);
 }
 
 int mcvc_disc_forward(const float* const* params, const float* packed, const float* x, float* out, float* stash, float* scratch,

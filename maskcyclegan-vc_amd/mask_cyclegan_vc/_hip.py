@@ -37,6 +37,8 @@ _SIGS = {
     "mcvc_disc_pack": (c_int, [_PP, c_void_p, c_void_p]),
     "mcvc_gen_forward": (c_int, [_PP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "mcvc_gen_backward": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p]),
+    "mcvc_gen_backward_overlap": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int,
+                                          c_void_p, c_void_p, _PP]),
     "mcvc_disc_forward": (c_int, [_PP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "mcvc_disc_backward": (c_int, [_PP, c_void_p, _PP, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p]),
     "mcvc_l1_loss": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

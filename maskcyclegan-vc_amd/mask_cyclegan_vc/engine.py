@@ -18,6 +18,8 @@ checkpoints and the autograd API keep working on the same storage.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _hip
@@ -115,6 +117,21 @@ class TrainEngine:
         # (wait + Adam + re-pack) where the discriminators are next used, i.e. after the next generator forwards
         self.defer_d_update = self.reducer.world > 1
         self._pending_d_lr = None
+        # ... and the generator gradient all-reduce starts per parameter range while the last backward passes are still
+        # running: the library records an event when a range's gradients are complete (mcvc_gen_backward_overlap)
+        self.overlap_g_reduce = self.reducer.world > 1 and dev.type == "cuda"
+        self._ms = {}
+        for n in G_NAMES:
+            evs = [torch.cuda.Event() for _ in range(2)]
+            for e in evs:
+                e.record()                                  # forces creation of the underlying hipEvent_t
+            self._ms[n] = (evs, (ctypes.c_void_p * 2)(*[e.cuda_event for e in evs]))
+        # flat-buffer ranges [lo, hi) of parameters [100,110), [24,100), [0,24) of each generator
+        self._g_ranges = {}
+        base = self.g_group.grad.data_ptr()
+        for n, gv in zip(G_NAMES, self.g_group.grad_views):
+            off = [(g.data_ptr() - base) // 4 for g in gv] + [(gv[-1].data_ptr() - base) // 4 + _align4(gv[-1].numel())]
+            self._g_ranges[n] = [(off[100], off[110]), (off[24], off[100]), (off[0], off[24])]
         self._workspaces = {}
         self._use(batch_size)
         self.reducer.broadcast_(self.g_group.flat)
@@ -200,10 +217,11 @@ class TrainEngine:
         check(self.L.mcvc_gen_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(mask), ptr(out), ptr(stash),
                                       ptr(sc), sc.numel(), nb, self.T, stream()), "gen_forward")
 
-    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0):
+    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0, milestones=False):
         sc = self.g_scratch[lane]
-        check(self.L.mcvc_gen_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name], ptr(mask), ptr(dout), ptr(dx), acc,
-                                       ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(), self._aux_ptr(lane)), "gen_backward")
+        ms = self._ms[name][1] if milestones else None
+        check(self.L.mcvc_gen_backward_overlap(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name], ptr(mask), ptr(dout), ptr(dx), acc,
+                                               ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(), self._aux_ptr(lane), ms), "gen_backward")
 
     def _D(self, name, x, out, stash, nb, lane=0):
         sc = self.d_scratch[lane]
@@ -279,12 +297,25 @@ class TrainEngine:
                     lambda ln: self._D_bwd("discriminator_B", dl[1], g_fake_B, 0, ds[1], False, B, ln))
         self._lanes(lambda ln: self._G_bwd("generator_B2A", None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B, ln),   # cycle_A = G_B2A(fake_B)
                     lambda ln: self._G_bwd("generator_A2B", None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, ln))   # cycle_B = G_A2B(fake_A)
-        self._lanes(lambda ln: self._G_bwd("generator_A2B", self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2, ln),
-                    lambda ln: self._G_bwd("generator_B2A", self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2, ln))
+        # the last pass over each generator: its gradient ranges become final one after the other (milestone events)
+        ov = self.overlap_g_reduce
+        self._lanes(lambda ln: self._G_bwd("generator_A2B", self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2, ln, ov),
+                    lambda ln: self._G_bwd("generator_B2A", self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2, ln, ov))
 
     def generator_update(self):
         """All-reduce (data parallel) + Adam on the flat generator buffer (train.py:242); eager: its scalars change per step."""
-        self.reducer.reduce_(self.g_group.grad)
+        if self.overlap_g_reduce:
+            # same collective order on every rank: range k of A2B, range k of B2A, k = 0, 1, then the two tails
+            for k in range(2):
+                for n in G_NAMES:
+                    lo, hi = self._g_ranges[n][k]
+                    self.reducer.reduce_range_after_(self.g_group.grad, lo, hi, self._ms[n][0][k])
+            for n in G_NAMES:
+                lo, hi = self._g_ranges[n][2]
+                self.reducer.reduce_range_after_(self.g_group.grad, lo, hi, None)
+            self.reducer.wait(self.device)
+        else:
+            self.reducer.reduce_(self.g_group.grad)
         self._adam(self.g_group, self.sched.g_opt_lr)
         self._stale_g = True
 

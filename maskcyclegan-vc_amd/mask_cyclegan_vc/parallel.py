@@ -93,6 +93,21 @@ class FlatGradReducer:
                 dist.all_reduce(flat[lo:min(n, lo + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
+    def reduce_range_after_(self, flat: torch.Tensor, lo: int, hi: int, event=None):
+        """Queue the SUM all-reduce of ``flat[lo:hi]`` on the communication stream, to start once ``event`` (recorded by the
+        producer of that range; None = everything queued on the current stream so far) has completed.  Pair with ``wait()``."""
+        if self.world == 1 or hi <= lo:
+            return
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=flat.device)
+        if event is not None:
+            self._stream.wait_event(event)
+        else:
+            self._stream.wait_stream(torch.cuda.current_stream(flat.device))
+        with torch.cuda.stream(self._stream):
+            for a in range(lo, hi, self.bucket_elems):
+                dist.all_reduce(flat[a:min(hi, a + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group)
+
     def wait(self, device=None):
         """Order the current stream after everything queued on the communication stream."""
         if self._stream is not None:
