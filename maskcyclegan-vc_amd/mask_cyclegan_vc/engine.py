@@ -109,7 +109,9 @@ class TrainEngine:
         self.aux_wgrad = True
         # HIP-graph replay of the two phases is available but OFF by default: measured on MI355X / ROCm 7.2 it does not
         # shorten the step (the host is not the limiter: 19.7 ms replayed vs 19.5 ms eager) and capturing lanes together
-        # with the auxiliary streams crashes inside hipStreamEndCapture.
+        # with the auxiliary streams crashes inside hipStreamEndCapture.  Also tried and dropped at 13.8 ms/step: one graph
+        # per network pass (forward passes: 13.9 ms, no gain; with backward passes: 16.7 ms, slower) and one host thread per
+        # lane (no change -- the ~4 ms of real host work per step is not on the critical path; tools/host_overhead.py).
         self.use_graphs = False
         self._graphs, self._eager_runs = {}, {}
         self._capture_stream = torch.cuda.Stream(device=dev)
