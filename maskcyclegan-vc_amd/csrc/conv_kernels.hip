@@ -11,6 +11,9 @@
 #include <stdio.h>
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#ifndef MCVC_CONV_MINW
+#define MCVC_CONV_MINW 2
+#endif
 
 // =================================================================================================
 // forward / data-gradient kernel
@@ -60,7 +63,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l)
 // ds_read immediates.  (With runtime kh/kw/stride arithmetic each tap cost ~30 SALU instructions; the scalar unit
 // is shared by the CU's 8 resident waves, which made the loop SALU-bound at ~2x the MFMA time.)
 template <int WM, int WN, int BMW, int BNW, int KW, bool S2>
-__global__ void __launch_bounds__(256, 2) conv_direct_kernel(const ConvArgs a)
+__global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int COT = 32 * WM * BMW;
