@@ -45,6 +45,12 @@ int mcvc_disc_out_frames(int T);         /* last dim of Discriminator.forward (T
 
 /* ---- weight packing (after every optimizer step / load_state_dict) --------------------------- */
 int mcvc_gen_pack(const float* const* params, float* packed, void* stream);
+/*      Small-batch variant: when every pass until the next re-pack has batch <= max_batch at n_frames T and
+ *      mcvc_gen_trunk_fused(max_batch, T) is 1, the 1-D trunk runs on the fused trunk kernels, which read the OIHW
+ *      parameters directly -- the generic K-major copies of the trunk layers (60 % of the generator's weights) are then
+ *      not refreshed.  Falls back to the full re-pack otherwise.                                                   */
+int mcvc_gen_trunk_fused(int B, int T);
+int mcvc_gen_pack_small_batch(const float* const* params, float* packed, int max_batch, int T, void* stream);
 int mcvc_disc_pack(const float* const* params, float* packed, void* stream);
 
 /* ---- Generator: replaces Generator.forward (mask_cyclegan_vc/model.py:239-280) and its autograd

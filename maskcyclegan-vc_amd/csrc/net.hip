@@ -311,10 +311,18 @@ static void add_job(PackTable& t, PackJob j, int gx, int gy)
     t.jobs.push_back(j);
 }
 
-static void add_spec_jobs(PackTable& t, const ConvSpec& c)
+// trunk_only: the layer runs on the fused trunk kernels (OIHW forward); only the transposed data-gradient copy is needed
+static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = false)
 {
     const int K = c.Cin * c.KH * c.KW;
     for (int br = 0; br < c.nbr; ++br) {
+        if (trunk_only && c.off_tk >= 0) {
+            PackJob q{}; q.kind = PACK_TRUNK_T; q.param = c.wi[br]; q.dst = c.off_tk; q.Cout = c.Cout; q.Cin = c.Cin; q.KW = c.KW;
+            q.ld = c.cout_tot * c.KW; q.co_off = br * c.Cout;
+            add_job(t, q, cdiv_i(c.Cin, 32), cdiv_i(c.Cout, 32));
+            t.bytes += 8.0 * c.Cout * K;
+            continue;
+        }
         PackJob f{}; f.kind = PACK_FWD; f.param = c.wi[br]; f.dst = c.off_fwd; f.Cout = c.Cout; f.K = K; f.ld = c.cout_pk; f.co_off = br * c.Cout;
         add_job(t, f, cdiv_i(K, 32), cdiv_i(c.Cout, 32));
         PackJob b{}; b.kind = PACK_COPY; b.param = c.bi[br]; b.dst = c.off_bias + br * c.Cout; b.Cout = c.Cout;
@@ -1036,6 +1044,43 @@ int mcvc_gen_pack(const float* const* params, float* packed, void* stream)
         const ConvSpec* all[] = {&g.conv1, &g.ds1, &g.ds2, &g.c2d1d, &g.c1d2d, &g.up1, &g.up2, &g.last};
         for (const ConvSpec* c : all) add_spec_jobs(pt, *c);
         for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i]); add_spec_jobs(pt, g.res_out[i]); }
+    }, &err);
+    if (!t) return err;
+    return pack_net(t, params, packed, (hipStream_t)stream);
+}
+
+// 1 if every 1-D layer of a generator pass with batch B at T frames takes the fused trunk path (see trunk_fwd / trunk_dgrad)
+int mcvc_gen_trunk_fused(int B, int T)
+{
+    if (B < 1 || T < 1 || !trunk_enabled()) return 0;
+    const GenNet& g = gen_net();
+    const GenDims d = gen_dims(B, T);
+    const int W4 = d.W4;
+    bool ok = true;
+    for (int i = 0; i < 6 && ok; ++i) {
+        ok = ok && mcvc_trunk_applies(g.res_vg[i].Cin, 3, g.res_vg[i].Cout, B, W4, TRUNK_IN_GLU, 1);
+        ok = ok && mcvc_trunk_applies(g.res_out[i].Cin, 3, g.res_out[i].Cout, B, W4, TRUNK_IN, 1);
+        ok = ok && mcvc_trunk_applies(g.res_out[i].cout_tot, 3, g.res_out[i].Cin, B, W4, TRUNK_PLAIN, 1);
+        ok = ok && trunk_pick_ksplit(g.res_vg[i].cout_tot, 3, g.res_vg[i].Cin, B, W4, 0) >= 1;
+    }
+    ok = ok && mcvc_trunk_applies(g.c1d2d.Cin, 1, g.c1d2d.Cout, B, W4, TRUNK_IN, 1);
+    ok = ok && trunk_pick_ksplit(g.c1d2d.cout_tot, 1, g.c1d2d.Cin, B, W4, 0) >= 1;       // its data-gradient (K = 5120)
+    ok = ok && trunk_pick_ksplit(g.c2d1d.Cin, 1, g.c2d1d.Cout, B, W4, 1) >= 1;           // conv2dto1d forward (K = 5120)
+    ok = ok && mcvc_trunk_applies(g.c2d1d.cout_tot, 1, g.c2d1d.Cin, B, W4, TRUNK_PLAIN, 1);
+    return ok ? 1 : 0;
+}
+
+int mcvc_gen_pack_small_batch(const float* const* params, float* packed, int max_batch, int T, void* stream)
+{
+    for (int b = 1; b <= max_batch; ++b)
+        if (!mcvc_gen_trunk_fused(b, T)) return mcvc_gen_pack(params, packed, stream);
+    int err = 0;
+    const DevPackTable* t = dev_pack_table(2, [](PackTable& pt) {
+        const GenNet& g = gen_net();
+        const ConvSpec* full[] = {&g.conv1, &g.ds1, &g.ds2, &g.up1, &g.up2, &g.last};
+        for (const ConvSpec* c : full) add_spec_jobs(pt, *c);
+        add_spec_jobs(pt, g.c2d1d, true); add_spec_jobs(pt, g.c1d2d, true);
+        for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i], true); add_spec_jobs(pt, g.res_out[i], true); }
     }, &err);
     if (!t) return err;
     return pack_net(t, params, packed, (hipStream_t)stream);

@@ -135,6 +135,7 @@ class TrainEngine:
             off = [(g.data_ptr() - base) // 4 for g in gv] + [(gv[-1].data_ptr() - base) // 4 + _align4(gv[-1].numel())]
             self._g_ranges[n] = [(off[100], off[110]), (off[24], off[100]), (off[0], off[24])]
         self._workspaces = {}
+        self._max_B = batch_size
         self._use(batch_size)
         self.reducer.broadcast_(self.g_group.flat)
         self.reducer.broadcast_(self.d_group.flat)
@@ -150,6 +151,11 @@ class TrainEngine:
         every op is per-sample).  Generator phase: G_A2B on [real_A|mask_A ; real_B|ones] and G_B2A on
         [real_B|mask_B ; real_A|ones] (translation + identity), then the two cycle passes.  Discriminator phase:
         each discriminator sees [real ; generated] in one pass."""
+        if B > self._max_B:                 # a larger batch than any so far may leave the fused-trunk regime: full re-pack
+            self._max_B = B
+            self._stale_g = True
+            if hasattr(self, "packed"):
+                self.repack(G_NAMES)
         ws = self._workspaces.get(B)
         if ws is None:
             L, T, dev = self.L, self.T, self.device
@@ -183,8 +189,12 @@ class TrainEngine:
 
     # ---- thin call helpers ------------------------------------------------------------------------
     def _repack1(self, n):
-        fn = self.L.mcvc_gen_pack if n in G_NAMES else self.L.mcvc_disc_pack
-        check(fn(self._p_tab[n], ptr(self.packed[n]), stream()), "pack " + n)
+        if n in G_NAMES:
+            # every generator pass of this engine has batch <= 2B at T frames: at small batch the trunk layers run on the
+            # fused kernels and their generic K-major copies need no refresh (the library falls back to the full pack)
+            check(self.L.mcvc_gen_pack_small_batch(self._p_tab[n], ptr(self.packed[n]), 2 * self._max_B, self.T, stream()), "pack " + n)
+        else:
+            check(self.L.mcvc_disc_pack(self._p_tab[n], ptr(self.packed[n]), stream()), "pack " + n)
 
     def repack(self, names):
         """Refresh the K-major weight copies (one lane per network when running concurrently)."""
