@@ -502,6 +502,7 @@ static hipError_t launch_cfg(const ConvPlan& pl, hipStream_t s)
 
 int mcvc_conv_plan_nsplit(const ConvProblem& p, int NB, int allow_split)
 {
+    if (mcvc_fewout_applies(p)) return mcvc_fewout_plan_nsplit(p, NB, allow_split);
     ConvPlan pl;
     if (!make_plan(p, NB, allow_split, 0, &pl)) return -1;
     return pl.a.nsplit;
@@ -513,6 +514,10 @@ int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float
     ConvPlan pl;
     if (io.nsplit < 1) return MCVC_ERR_INVALID;
     if (io.nsplit > 1 && !io.accumulate && io.slabs == nullptr) return MCVC_ERR_WORKSPACE;
+    if (mcvc_fewout_applies(p) && !io.shuffle) {
+        if (nsplit_out) *nsplit_out = io.nsplit;
+        return mcvc_fewout_launch(p, NB, io, wpk, w_cout, bias, s);
+    }
     if (!make_plan(p, NB, 0, io.nsplit, &pl)) return MCVC_ERR_INVALID;
     ConvArgs& a = pl.a;
     if ((w_cout & 3) != 0) return MCVC_ERR_INVALID;

@@ -1,0 +1,177 @@
+// Direct convolution with very few output channels (Cout <= 4, stride 1) on the VALU.
+//
+// lastConvLayer (128 -> 1, 5x15; model.py:207-211), the data-gradient of conv1 / conv1_gates (256 -> 2, 5x15; :116-126), the
+// data-gradient of the discriminator's first conv (256 -> 1, 3x3; :290-295) and its output conv (1024 -> 1, 1x3; :322-327)
+// have 1-2 useful rows in a 32-row MFMA tile: on the matrix path they ran at 1-5 TFLOP/s (50-130 us each for 0.1-0.4
+// GFLOP).  Here the GEMM shape is dropped altogether: one thread owns 4 adjacent output pixels x all CO output channels,
+// the haloed input rows of a few channels sit in LDS, a thread pulls its 4+KW-1 row window into registers with 16-byte LDS
+// reads and slides the KW taps over it (60 FMAs per 20 LDS floats at KW=15), and the weights -- indexed only by loop
+// counters -- are wave-uniform scalar loads straight from the packed K-major matrix (rows (ci,kh,kw), columns co), so an FMA
+// is `v_fmac v, s, v`.  Input channels are split over workgroups; partial sums leave through the same split-K slab /
+// accumulate conventions as conv_direct_kernel (the consumer kernel folds the slabs).
+#include "mcvc_common.h"
+#include "trace.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int kFewTW = 64;       // tile: 16 threads x 4 pixels wide
+constexpr int kFewTH = 16;       //       16 rows
+constexpr int kFewCC = 4;        // input channels staged per LDS round
+
+struct FewArgs {
+    const float* x; const float* w; const float* bias;
+    float* y; float* y_slabs;
+    long long x_sb, x_sc, y_sb, y_sc, slab_stride;
+    int x_sh, y_sh, y_sw;
+    int Cin, H, W, Cout, OH, OW, KH, pad_h, pad_w;
+    int w_cout;                  // row pitch of the packed weight matrix
+    int tiles_w, tiles_h;
+    int nsplit, ch_per_split;
+    int PH, PWp;                 // LDS patch rows / pitch (multiple of 4)
+    int accumulate;
+};
+
+template <int CO, int KW>
+__global__ void __launch_bounds__(256) conv_fewout_kernel(const FewArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float xs[];          // [kFewCC][PH][PWp]
+    constexpr int NV = (4 + KW - 1 + 3) / 4;                            // float4 reads per row window
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const int tile = blockIdx.x, n = blockIdx.y, split = blockIdx.z;
+    const int oh0 = (tile / a.tiles_w) * kFewTH, ow0 = (tile % a.tiles_w) * kFewTW;
+    const int ih0 = oh0 - a.pad_h, iw0 = ow0 - a.pad_w;
+    const int plane = a.PH * a.PWp;
+    const int c_begin = split * a.ch_per_split;
+    int c_end = c_begin + a.ch_per_split;
+    if (c_end > a.Cin) c_end = a.Cin;
+
+    float acc[CO][4];
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
+
+    const float* xn = a.x + (long long)n * a.x_sb;
+    for (int c0 = c_begin; c0 < c_end; c0 += kFewCC) {
+        __syncthreads();
+        // stage kFewCC haloed planes (zero outside the image / past the channel range); rows are contiguous -> coalesced
+        for (int i = tid; i < kFewCC * plane; i += 256) {
+            const int ci = i / plane, rem = i - ci * plane;
+            const int r = rem / a.PWp, c = rem - r * a.PWp;
+            const int ih = ih0 + r, iw = iw0 + c, cg = c0 + ci;
+            float v = 0.f;
+            if (cg < c_end && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = xn[(long long)cg * a.x_sc + (long long)ih * a.x_sh + iw];
+            xs[i] = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ci = 0; ci < kFewCC; ++ci) {
+            if (c0 + ci >= c_end) break;
+            const float* wrow = a.w + (long long)(c0 + ci) * a.KH * KW * a.w_cout;     // wave-uniform -> scalar loads
+            const float* xrow = xs + ci * plane + ty * a.PWp + tx * 4;
+#pragma unroll 1
+            for (int kh = 0; kh < a.KH; ++kh) {
+                float xr[4 * NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float4 q = *reinterpret_cast<const float4*>(xrow + kh * a.PWp + 4 * v);
+                    xr[4 * v] = q.x; xr[4 * v + 1] = q.y; xr[4 * v + 2] = q.z; xr[4 * v + 3] = q.w;
+                }
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+#pragma unroll
+                    for (int co = 0; co < CO; ++co) {
+                        const float wv = wrow[(kh * KW + kw) * a.w_cout + co];
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(wv, xr[p + kw], acc[co][p]);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: split 0 (+bias) -> y, split s >= 1 -> slab s-1; accumulate mode adds into y
+    const int oh = oh0 + ty;
+    if (oh >= a.OH) return;
+    float* base = (split == 0 || a.accumulate) ? a.y : (a.y_slabs + (long long)(split - 1) * a.slab_stride);
+    base += (long long)n * a.y_sb + (long long)oh * a.y_sh;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        if (co >= a.Cout) break;
+        const float b = (a.bias != nullptr && split == 0) ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int ow = ow0 + tx * 4 + p;
+            if (ow >= a.OW) continue;
+            float* dst = base + (long long)co * a.y_sc + (long long)ow * a.y_sw;
+            const float v = acc[co][p] + b;
+            if (a.accumulate) { if (a.nsplit > 1) unsafeAtomicAdd(dst, v); else *dst += v; }
+            else *dst = v;
+        }
+    }
+}
+
+static int few_enabled()
+{
+    static const int v = [] { const char* e = getenv("MCVC_FEWOUT"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
+static int few_nsplit(const ConvProblem& p, int NB, int allow_split)
+{
+    if (!allow_split) return 1;
+    const int rounds = cdiv_i(p.Cin, kFewCC);
+    const int tiles = cdiv_i(p.OW, kFewTW) * cdiv_i(p.OH, kFewTH) * NB;
+    int ns = cdiv_i(512, tiles);                     // enough workgroups for two per CU
+    if (ns > rounds) ns = rounds;
+    if (ns > 64) ns = 64;                            // every slab is one more read of the (tiny) output by the consumer
+    if (ns < 1) ns = 1;
+    return ns;
+}
+
+template <int CO, int KW>
+static int few_launch_t(const FewArgs& a, dim3 grid, size_t lds, hipStream_t s)
+{
+    hipLaunchKernelGGL((conv_fewout_kernel<CO, KW>), grid, dim3(256), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+bool mcvc_fewout_applies(const ConvProblem& p)
+{
+    if (!few_enabled()) return false;
+    if (p.Cout > 4 || p.stride != 1) return false;
+    if (p.KW != 3 && p.KW != 15) return false;
+    const int PH = kFewTH + p.KH - 1, PWp = round_up_i(kFewTW + p.KW - 1 + 3, 4);
+    return (size_t)kFewCC * PH * PWp * sizeof(float) <= 64 * 1024;
+}
+
+int mcvc_fewout_plan_nsplit(const ConvProblem& p, int NB, int allow_split) { return few_nsplit(p, NB, allow_split); }
+
+int mcvc_fewout_launch(const ConvProblem& p, int NB, const ConvIO& io, const float* wpk, int w_cout, const float* bias, hipStream_t s)
+{
+    if (!mcvc_fewout_applies(p) || io.shuffle || io.nsplit < 1) return MCVC_ERR_INVALID;
+    FewArgs a{};
+    a.x = io.x; a.x_sb = io.x_sb; a.x_sc = io.x_sc; a.x_sh = io.x_sh;
+    a.y = io.y; a.y_sb = io.y_sb; a.y_sc = io.y_sc; a.y_sh = io.y_sh; a.y_sw = io.y_sw;
+    a.y_slabs = io.slabs; a.slab_stride = io.slab_stride;
+    a.w = wpk; a.w_cout = w_cout; a.bias = bias;
+    a.Cin = p.Cin; a.H = p.H; a.W = p.W; a.Cout = p.Cout; a.OH = p.OH; a.OW = p.OW; a.KH = p.KH; a.pad_h = p.pad_h; a.pad_w = p.pad_w;
+    a.tiles_w = cdiv_i(p.OW, kFewTW); a.tiles_h = cdiv_i(p.OH, kFewTH);
+    a.nsplit = io.nsplit;
+    a.ch_per_split = round_up_i(cdiv_i(p.Cin, io.nsplit), 1);
+    a.PH = kFewTH + p.KH - 1;
+    a.PWp = round_up_i(kFewTW + p.KW - 1 + 3, 4);           // (+3: the last float4 of a row window may read past PW)
+    a.accumulate = io.accumulate;
+    dim3 grid((unsigned)(a.tiles_w * a.tiles_h), (unsigned)NB, (unsigned)io.nsplit);
+    const size_t lds = (size_t)kFewCC * a.PH * a.PWp * sizeof(float);
+    const double px = (double)NB * p.OH * p.OW;
+    TraceScope ts(K_CONV_FEW, s, 2.0 * px * p.Cout * p.Cin * p.KH * p.KW,
+                  4.0 * ((double)NB * p.Cin * p.H * p.W + (double)p.Cin * p.KH * p.KW * p.Cout + px * p.Cout * io.nsplit));
+    const int co = p.Cout <= 1 ? 1 : (p.Cout <= 2 ? 2 : 4);
+    if (p.KW == 15) return co == 1 ? few_launch_t<1, 15>(a, grid, lds, s) : co == 2 ? few_launch_t<2, 15>(a, grid, lds, s) : few_launch_t<4, 15>(a, grid, lds, s);
+    return co == 1 ? few_launch_t<1, 3>(a, grid, lds, s) : co == 2 ? few_launch_t<2, 3>(a, grid, lds, s) : few_launch_t<4, 3>(a, grid, lds, s);
+}

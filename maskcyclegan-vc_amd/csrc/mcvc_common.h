@@ -167,6 +167,10 @@ int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float
                      const float* bias, hipStream_t s, int* nsplit_out);
 // number of split-K slabs the planner would use (for workspace sizing)
 int mcvc_conv_plan_nsplit(const ConvProblem& p, int NB, int allow_split);
+// few-output-channel VALU path (fewout_kernels.hip); mcvc_conv_plan_nsplit / mcvc_conv_launch route to it when it applies
+bool mcvc_fewout_applies(const ConvProblem& p);
+int mcvc_fewout_plan_nsplit(const ConvProblem& p, int NB, int allow_split);
+int mcvc_fewout_launch(const ConvProblem& p, int NB, const ConvIO& io, const float* wpk, int w_cout, const float* bias, hipStream_t s);
 
 struct WgradIO {
     const float* x; long long x_sb, x_sc; int x_sh;
