@@ -5,10 +5,11 @@
 // have 1-2 useful rows in a 32-row MFMA tile: on the matrix path they ran at 1-5 TFLOP/s (50-130 us each for 0.1-0.4
 // GFLOP).  Here the GEMM shape is dropped altogether: one thread owns 4 adjacent output pixels x all CO output channels,
 // the haloed input rows of a few channels sit in LDS, a thread pulls its 4+KW-1 row window into registers with 16-byte LDS
-// reads and slides the KW taps over it (60 FMAs per 20 LDS floats at KW=15), and the weights -- indexed only by loop
-// counters -- are wave-uniform scalar loads straight from the packed K-major matrix (rows (ci,kh,kw), columns co), so an FMA
-// is `v_fmac v, s, v`.  Input channels are split over workgroups; partial sums leave through the same split-K slab /
-// accumulate conventions as conv_direct_kernel (the consumer kernel folds the slabs).
+// reads and slides the KW taps over it (60 FMAs per 20 LDS floats at KW=15).  The round's weights are gathered from the
+// packed K-major matrix (rows (ci,kh,kw), columns co) into LDS next to the planes and read back as broadcast 16-byte reads
+// (a first version fetched them with wave-uniform scalar loads: every tap is its own cache line, and the ~1 us scalar-load
+// round trip per kernel row made the kernel 40-75 us).  Input channels are split over workgroups; partial sums leave
+// through the same split-K slab / accumulate conventions as conv_direct_kernel (the consumer kernel folds the slabs).
 #include "mcvc_common.h"
 #include "trace.h"
 #include <stdlib.h>
@@ -18,6 +19,14 @@ namespace {
 constexpr int kFewTW = 64;       // tile: 16 threads x 4 pixels wide
 constexpr int kFewTH = 16;       //       16 rows
 constexpr int kFewCC = 4;        // input channels staged per LDS round
+
+__device__ float g_few_zero[64];         // zero-initialised: DMA source for out-of-image elements
+
+__device__ __forceinline__ void glds4(const float* g, float* l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 4, 0, 0);
+}
 
 struct FewArgs {
     const float* x; const float* w; const float* bias;
@@ -35,7 +44,7 @@ struct FewArgs {
 template <int CO, int KW>
 __global__ void __launch_bounds__(256) conv_fewout_kernel(const FewArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float xs[];          // [kFewCC][PH][PWp]
+    extern __shared__ __attribute__((aligned(16))) float xs[];          // [2 buffers][kFewCC][PH][PWp]
     constexpr int NV = (4 + KW - 1 + 3) / 4;                            // float4 reads per row window
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
@@ -54,23 +63,55 @@ __global__ void __launch_bounds__(256) conv_fewout_kernel(const FewArgs a)
         for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
 
     const float* xn = a.x + (long long)n * a.x_sb;
-    for (int c0 = c_begin; c0 < c_end; c0 += kFewCC) {
-        __syncthreads();
-        // stage kFewCC haloed planes (zero outside the image / past the channel range); rows are contiguous -> coalesced
-        for (int i = tid; i < kFewCC * plane; i += 256) {
-            const int ci = i / plane, rem = i - ci * plane;
-            const int r = rem / a.PWp, c = rem - r * a.PWp;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // rows of the patch that an in-image output row of this tile can touch (small images: far fewer than PH)
+    int rows = a.OH - oh0 + a.KH - 1;
+    if (rows > a.PH) rows = a.PH;
+    const int LX = rows * a.PWp;
+    const int chunks = (LX + 63) >> 6;
+    const float inv_pitch = 1.0f / (float)a.PWp;
+    // Staging by LDS-DMA (global_load_lds, 4 B/lane, no VGPRs, all requests in flight), double-buffered: the planes of
+    // round r+1 stream in while round r is being computed; one barrier per round.
+    constexpr int KWP = (KW + 3) & ~3;                                  // taps of one kernel row, padded to float4s
+    const int wsz = kFewCC * a.KH * CO * KWP;                           // weights of one round: [ci][kh][co][KWP]
+    const int bufsz = kFewCC * plane + ((wsz + 3) & ~3);
+    auto stage = [&](int c0, float* dst) {
+        for (int job = wave; job < kFewCC * chunks; job += 4) {
+            const int ci = job / chunks, ch = job - ci * chunks;
+            const int idx = ch * 64 + lane;
+            int r = (int)((float)idx * inv_pitch);
+            int c = idx - r * a.PWp;
+            if (c < 0) { c += a.PWp; --r; } else if (c >= a.PWp) { c -= a.PWp; ++r; }
             const int ih = ih0 + r, iw = iw0 + c, cg = c0 + ci;
-            float v = 0.f;
-            if (cg < c_end && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v = xn[(long long)cg * a.x_sc + (long long)ih * a.x_sh + iw];
-            xs[i] = v;
+            const bool ok = (cg < c_end) && (ih >= 0) && (ih < a.H) && (iw >= 0) && (iw < a.W);
+            const float* src = ok ? (xn + (long long)cg * a.x_sc + (long long)ih * a.x_sh + iw) : (g_few_zero + lane);
+            if (idx < LX) glds4(src, dst + ci * plane + ch * 64);
         }
-        __syncthreads();
+        float* wdst = dst + kFewCC * plane;
+        for (int ch = wave; ch * 64 < wsz; ch += 4) {
+            const int d = ch * 64 + lane;
+            const int kw = d % KWP; int t = d / KWP;
+            const int co = t % CO; t /= CO;
+            const int kh = t % a.KH, ci = t / a.KH;
+            const bool ok = (d < wsz) && (kw < KW) && (c0 + ci < c_end) && (co < a.Cout);
+            const float* src = ok ? (a.w + ((long long)((c0 + ci) * a.KH + kh) * KW + kw) * a.w_cout + co) : (g_few_zero + lane);
+            if (d < wsz) glds4(src, wdst + ch * 64);
+        }
+    };
+    const int nrounds = (c_end > c_begin) ? (c_end - c_begin + kFewCC - 1) / kFewCC : 0;
+    if (nrounds > 0) stage(c_begin, xs);
+    for (int rd = 0; rd < nrounds; ++rd) {
+        const int c0 = c_begin + rd * kFewCC;
+        float* cur = xs + (rd & 1) * bufsz;
+        __syncthreads();                                   // DMA of this round landed (vmcnt(0) in front of the barrier);
+                                                           // everyone is done with the other buffer
+        if (rd + 1 < nrounds) stage(c0 + kFewCC, xs + ((rd + 1) & 1) * bufsz);
+        const float* wcur = cur + kFewCC * plane;
 #pragma unroll 1
         for (int ci = 0; ci < kFewCC; ++ci) {
             if (c0 + ci >= c_end) break;
-            const float* wrow = a.w + (long long)(c0 + ci) * a.KH * KW * a.w_cout;     // wave-uniform -> scalar loads
-            const float* xrow = xs + ci * plane + ty * a.PWp + tx * 4;
+            const float* xrow = cur + ci * plane + ty * a.PWp + tx * 4;
 #pragma unroll 1
             for (int kh = 0; kh < a.KH; ++kh) {
                 float xr[4 * NV];
@@ -79,14 +120,19 @@ __global__ void __launch_bounds__(256) conv_fewout_kernel(const FewArgs a)
                     const float4 q = *reinterpret_cast<const float4*>(xrow + kh * a.PWp + 4 * v);
                     xr[4 * v] = q.x; xr[4 * v + 1] = q.y; xr[4 * v + 2] = q.z; xr[4 * v + 3] = q.w;
                 }
+                const float* wr = wcur + (ci * a.KH + kh) * CO * KWP;       // same address in every lane: LDS broadcast
 #pragma unroll
-                for (int kw = 0; kw < KW; ++kw) {
+                for (int co = 0; co < CO; ++co) {
+                    float wv[KWP];
 #pragma unroll
-                    for (int co = 0; co < CO; ++co) {
-                        const float wv = wrow[(kh * KW + kw) * a.w_cout + co];
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(wv, xr[p + kw], acc[co][p]);
+                    for (int v = 0; v < KWP / 4; ++v) {
+                        const float4 q = *reinterpret_cast<const float4*>(wr + co * KWP + 4 * v);
+                        wv[4 * v] = q.x; wv[4 * v + 1] = q.y; wv[4 * v + 2] = q.z; wv[4 * v + 3] = q.w;
                     }
+#pragma unroll
+                    for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(wv[kw], xr[p + kw], acc[co][p]);
                 }
             }
         }
@@ -146,7 +192,7 @@ bool mcvc_fewout_applies(const ConvProblem& p)
     if (p.Cout > 4 || p.stride != 1) return false;
     if (p.KW != 3 && p.KW != 15) return false;
     const int PH = kFewTH + p.KH - 1, PWp = round_up_i(kFewTW + p.KW - 1 + 3, 4);
-    return (size_t)kFewCC * PH * PWp * sizeof(float) <= 64 * 1024;
+    return (size_t)2 * (kFewCC * PH * PWp + kFewCC * p.KH * 4 * ((p.KW + 3) & ~3) + 4) * sizeof(float) <= 64 * 1024;
 }
 
 int mcvc_fewout_plan_nsplit(const ConvProblem& p, int NB, int allow_split) { return few_nsplit(p, NB, allow_split); }
@@ -167,11 +213,12 @@ int mcvc_fewout_launch(const ConvProblem& p, int NB, const ConvIO& io, const flo
     a.PWp = round_up_i(kFewTW + p.KW - 1 + 3, 4);           // (+3: the last float4 of a row window may read past PW)
     a.accumulate = io.accumulate;
     dim3 grid((unsigned)(a.tiles_w * a.tiles_h), (unsigned)NB, (unsigned)io.nsplit);
-    const size_t lds = (size_t)kFewCC * a.PH * a.PWp * sizeof(float);
+    const int co_t = p.Cout <= 1 ? 1 : (p.Cout <= 2 ? 2 : 4);
+    const size_t lds = (size_t)2 * (kFewCC * a.PH * a.PWp + kFewCC * p.KH * co_t * ((p.KW + 3) & ~3) + 4) * sizeof(float);
     const double px = (double)NB * p.OH * p.OW;
     TraceScope ts(K_CONV_FEW, s, 2.0 * px * p.Cout * p.Cin * p.KH * p.KW,
                   4.0 * ((double)NB * p.Cin * p.H * p.W + (double)p.Cin * p.KH * p.KW * p.Cout + px * p.Cout * io.nsplit));
-    const int co = p.Cout <= 1 ? 1 : (p.Cout <= 2 ? 2 : 4);
+    const int co = co_t;
     if (p.KW == 15) return co == 1 ? few_launch_t<1, 15>(a, grid, lds, s) : co == 2 ? few_launch_t<2, 15>(a, grid, lds, s) : few_launch_t<4, 15>(a, grid, lds, s);
     return co == 1 ? few_launch_t<1, 3>(a, grid, lds, s) : co == 2 ? few_launch_t<2, 3>(a, grid, lds, s) : few_launch_t<4, 3>(a, grid, lds, s);
 }

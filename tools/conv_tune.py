@@ -35,7 +35,7 @@ L = lib()
 L.mcvc_trace_kind_name.restype = ctypes.c_char_p
 NK = L.mcvc_trace_kinds()
 KINDS = [L.mcvc_trace_kind_name(k).decode() for k in range(NK)]
-COUNT = [k for k, n in enumerate(KINDS) if n.startswith("conv_direct") or n == "act_fwd"]
+COUNT = [k for k, n in enumerate(KINDS) if n.startswith("conv_direct") or n in ("conv_fewout", "act_fwd")]
 KNOBS = ("MCVC_CONV_CFG", "MCVC_CONV_NSPLIT", "MCVC_CONV_LDS_KB")
 buf = (ctypes.c_double * (4 * NK))()
 
