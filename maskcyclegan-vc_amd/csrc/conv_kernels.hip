@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const 
             }
         }
         if (more && !(a.dbg & 2)) commit_patch((cur ^ 1) * a.xs_floats);
-        __syncthreads();
+        if (!(a.dbg & 16)) __syncthreads();
     }
 
     // ---- epilogue: bias, (shuffled) store / slab store / accumulate
