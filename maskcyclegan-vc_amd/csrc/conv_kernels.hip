@@ -886,7 +886,7 @@ static bool plan_wgrad(const ConvProblem& p, int NB, long long slab_cap_floats, 
     int want = (base >= 256) ? 1 : cdiv_i(256, base);
     // tiny dW (edge layers: a few thousand outputs over thousands of pixels): K-split workgroups add straight into dW with
     // coalesced atomics -- the slab round trip and the reduce launch would cost more than the layer
-    const bool tiny = a.dw_floats <= 65536;
+    const bool tiny = a.dw_floats <= (long long)wgrad_knob("MCVC_WGRAD_ATOMIC_BELOW", 65536);
     if (tiny) { if (want > 128) want = 128; }
     else {
         long long cap = a.slab_stride > 0 ? slab_cap_floats / a.slab_stride : 0;
