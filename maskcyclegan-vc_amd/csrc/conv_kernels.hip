@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const 
     const int d_row0 = tid / V;
     int d_co = co0 + (tid % V) * 4;
     if (d_co > a.w_cout - 4) d_co = a.w_cout - 4;  // column tile past the row end: finite neighbours, outputs discarded
-    const float* d_src0 = a.w + d_co;
+    const float* d_src0 = a.w + (long long)n * a.w_nstride + d_co;
 
     float preg[kMaxPR][kMaxPC];
 
@@ -191,10 +191,23 @@ __global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const 
         }
     };
 
+    // GEMM mode (1x1, unit stride, no padding, image width == tile width): the pixel tile of a channel is `plane` contiguous
+    // floats in memory, so the patch is streamed by the same 16-byte LDS-DMA as the weights -- no register prefetch, and the
+    // channel chunk is no longer limited by the prefetch registers
+    auto dma_patch = [&](int ch, int xdst_off) {
+        const float* src0 = xn + (long long)(ch * a.cic) * a.x_sc + (long long)oh0 * a.x_sh;
+        const int f4_per_ch = a.plane >> 2;
+        const int total = a.cic * f4_per_ch;                 // float4s in the chunk; 64 per wave instruction
+        for (int i0 = wave * 64; i0 < total; i0 += 256) {
+            const int i = i0 + lane;
+            const int ci = i / f4_per_ch, q = i - ci * f4_per_ch;
+            if (i < total) glds16(src0 + (long long)ci * a.x_sc + 4 * q, smem + xdst_off + i0 * 4);
+        }
+    };
     if (ch_begin < ch_end) {
         dma_weights(ch_begin, wbase);
-        fetch_patch(ch_begin);
-        commit_patch(0);
+        if (a.gemm) dma_patch(ch_begin, 0);
+        else { fetch_patch(ch_begin); commit_patch(0); }
     }
     __syncthreads();
     const int npairs = a.cic >> 1;
@@ -204,13 +217,32 @@ __global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const 
         const bool more = (ch + 1 < ch_end);
         if (more) {
             if (!(a.dbg & 1)) dma_weights(ch + 1, wbase + (cur ^ 1) * ws_floats);
-            if (!(a.dbg & 2)) fetch_patch(ch + 1);
+            if (!(a.dbg & 2)) { if (a.gemm) dma_patch(ch + 1, (cur ^ 1) * a.xs_floats); else fetch_patch(ch + 1); }
         }
         // ---- MFMA main loop: (channel pair, kh) rows at run time, the KW taps of a row unrolled with immediate
         // offsets.  Operand reads are software-pipelined one tap ahead (the reads of tap t+1 -- or of the next row's
         // first tap -- are issued before the MFMAs of tap t), so the LDS latency hides behind the matrix pipe instead of
         // sitting between every pair of MFMAs.
-        if (!(a.dbg & 4)) {
+        if (KW == 1 && a.KH == 1) {
+            // 1x1 (GEMM-shaped: the Winograd products, the generic trunk): one tap per channel pair -- a plain K loop with
+            // fixed operand strides, unrolled so that several pairs' operand reads are in flight
+            if (!(a.dbg & 4)) {
+                const int a0 = wbase + cur * ws_floats + a_lane;
+                const int x0 = cur * a.xs_floats;
+#pragma unroll 4
+                for (int cp = 0; cp < npairs; ++cp) {
+                    float av[WM], bv[WN];
+#pragma unroll
+                    for (int i = 0; i < WM; ++i) av[i] = smem[a0 + cp * 2 * COT + i * 32];
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) bv[j] = smem[x0 + cp * 2 * a.plane + b_lane[j]];
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) acc[i][j] = MFMA32(av[i], bv[j], acc[i][j]);
+                }
+            }
+        } else if (!(a.dbg & 4)) {
             int a_off = wbase + cur * ws_floats + a_lane;
             int x_row = cur * a.xs_floats;
             const int nrows = npairs * a.KH;
@@ -256,7 +288,7 @@ __global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const 
                 a_off = a_next; x_row = x_next;
             }
         }
-        if (more && !(a.dbg & 2)) commit_patch((cur ^ 1) * a.xs_floats);
+        if (more && !(a.dbg & 2) && !a.gemm) commit_patch((cur ^ 1) * a.xs_floats);
         if (!(a.dbg & 16)) __syncthreads();
     }
 
@@ -358,7 +390,7 @@ static void patch_geometry(const ConvProblem& p, int npix, int tow_log2, int* PH
     *PWp = pwp;
 }
 
-static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_nsplit, ConvPlan* out)
+static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_nsplit, ConvPlan* out, int force_cfg = -1, int allow_gemm = 0)
 {
     if (p.stride != 1 && p.stride != 2) return false;
     if (p.KW != 1 && p.KW != 2 && p.KW != 3 && p.KW != 5 && p.KW != 15) return false;
@@ -393,6 +425,7 @@ static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_n
         else if (blocks_m * max_split < 512) cand[ncand++] = CFG_S2;
         cand[ncand++] = CFG_M; cand[ncand++] = CFG_N;
     }
+    if (force_cfg >= 0 && force_cfg < CFG_COUNT) { cand[0] = force_cfg; ncand = 1; }
     if (conv_knob("MCVC_CONV_CFG", -1) >= 0) { cand[0] = conv_knob("MCVC_CONV_CFG", -1); ncand = 1; }
     const int khkw = p.KH * p.KW;
     const int cin_pad = round_up_i(p.Cin, 2);
@@ -414,8 +447,18 @@ static bool make_plan(const ConvProblem& p, int NB, int allow_split, int force_n
         };
         int cic = 2;
         while (fits(cic + 2)) cic += 2;
+        // GEMM mode: both operands by DMA (see the kernel); the chunk must divide Cin (no partially valid chunk: the
+        // un-fetched tail would be stale LDS, and 0 * NaN is NaN)
+        a.gemm = 0;
+        if (allow_gemm && khkw == 1 && p.stride == 1 && p.pad_h == 0 && p.pad_w == 0 && p.W == tow && p.OW == tow && tow == 32 && (a.plane & 3) == 0 &&
+            a.PWp == tow && (p.Cin & 1) == 0) {
+            int best = 0;
+            for (int c = 2; c <= p.Cin && c <= 128; c += 2)
+                if (p.Cin % c == 0 && 2 * (c * a.plane + c * cot) <= budget) best = c;
+            if (best >= 8) { a.gemm = 1; cic = best; }
+        }
         if (2 * (round_up_i(cic * a.plane, 4) + cic * khkw * cot) > 40 * 1024) continue;   // would not fit 160 KiB
-        if (cic * a.PH > 8 * kMaxPR) continue;
+        if (!a.gemm && cic * a.PH > 8 * kMaxPR) continue;
         a.cic = cic;
         a.xs_floats = round_up_i(cic * a.plane, 4);
         a.nchunks = cdiv_i(cin_pad, cic);
@@ -518,13 +561,14 @@ int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float
         if (nsplit_out) *nsplit_out = io.nsplit;
         return mcvc_fewout_launch(p, NB, io, wpk, w_cout, bias, s);
     }
-    if (!make_plan(p, NB, 0, io.nsplit, &pl)) return MCVC_ERR_INVALID;
+    const int gemm_ok = io.gemm_ok && io.x_sh == p.W && (io.x_sc & 3) == 0 && (io.x_sb & 3) == 0 && ((uintptr_t)io.x & 15) == 0;
+    if (!make_plan(p, NB, 0, io.nsplit, &pl, io.tile_cfg - 1, gemm_ok)) return MCVC_ERR_INVALID;
     ConvArgs& a = pl.a;
     if ((w_cout & 3) != 0) return MCVC_ERR_INVALID;
     a.x = io.x; a.x_sb = io.x_sb; a.x_sc = io.x_sc; a.x_sh = io.x_sh;
     a.y = io.y; a.y_sb = io.y_sb; a.y_sc = io.y_sc; a.y_sh = io.y_sh; a.y_sw = io.y_sw;
     a.y_slabs = io.slabs; a.slab_stride = io.slab_stride;
-    a.w = wpk; a.w_rows = w_rows; a.w_cout = w_cout; a.bias = bias;
+    a.w = wpk; a.w_rows = w_rows; a.w_cout = w_cout; a.bias = bias; a.w_nstride = io.w_nstride;
     a.out_mode = io.accumulate ? CONV_OUT_ACCUM : CONV_OUT_SLAB;
     a.dbg = conv_debug_bits();
     a.shuffle = io.shuffle;

@@ -51,6 +51,8 @@ struct ConvArgs {
     int shuffle;           // 1: PixelShuffle(2) store  y[c=co>>2][2oh+((co>>1)&1)][2ow+(co&1)]
     int YH, YW;            // shuffle mode: bounds of the shuffled image (rows/cols beyond are not stored)
     int dbg;               // timing-ablation bits (MCVC_CONV_DEBUG); 0 in production
+    long long w_nstride;   // image n uses the packed weights at w + n*w_nstride (0: shared; Winograd: one matrix per transform point)
+    int gemm;              // 1: GEMM mode (1x1 conv whose pixel tiles are contiguous): the input patch is streamed by LDS-DMA too
 };
 
 struct ConvProblem {
@@ -161,6 +163,9 @@ struct ConvIO {
     int accumulate;                                        // 1: y += conv (atomic when nsplit > 1)
     int shuffle;
     int YH, YW;                                            // shuffle bounds (0 = 2*OH, 2*OW)
+    long long w_nstride;                                   // per-image weight stride in floats (0 = all images share w)
+    int gemm_ok;                                           // caller guarantees contiguous pixel rows (x_sh == W): GEMM mode may be used
+    int tile_cfg;                                          // 0 = planner's choice; k > 0 forces tile configuration k-1 (0 = 128x128, 1 = 128x64, ...)
 };
 
 int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float* wpk, int w_rows, int w_cout,

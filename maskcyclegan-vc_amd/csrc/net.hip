@@ -17,6 +17,7 @@
 #include "pack.h"
 #include "misc.h"
 #include "trunk.h"
+#include "wino.h"
 #include "../../include/mcvc.h"
 #include <string.h>
 #include <map>
@@ -45,6 +46,8 @@ struct Exec {
     float* wslabs;
     long long wslab_cap;
     long long wslab_need;
+    float* wv; float* wm;          // Winograd scratch: transformed input V[36][K][tiles], products M[36][M][tiles]
+    long long wino_cap;            // floats available in each
     std::vector<std::pair<const void*, hipEvent_t>> readers;
     void fail(int e) { if (!err && e) err = e; }
 };
@@ -94,6 +97,8 @@ struct ConvSpec {
     // derived
     int cout_tot, cout_pk, cin_pad, w_rows, cin_pk, dg_rows_co;
     long long off_fwd, off_bias, off_dgrad;
+    // 5x5 stride-1 single-branch convs (upSample1/2): Winograd F(2x2,5x5) weight sets U[36][K+1][ld], forward and data-gradient
+    int wino; long long off_wf, off_wd, wf_xi, wd_xi;
     long long off_tk;          // KH == 1 convs: transposed + flipped [Cin][cout_tot*KW] copy for the fused small-batch trunk dgrad
     int ncls;
     DgradClass cls[4];
@@ -151,6 +156,15 @@ static void spec_finalize(ConvSpec& c, long long& cur)
         cur += ((long long)c.dg_rows_co * c.mg_kh * c.mg_kw + 1) * c.mg_ld;                  // + zero pad row
     }
     cur = (cur + 3) & ~3LL;
+    c.wino = (c.KH == 5 && c.KW == 5 && st == 1 && c.nbr == 1 && c.Cin >= 64 && c.Cout >= 64) ? 1 : 0;
+    c.off_wf = c.off_wd = -1; c.wf_xi = c.wd_xi = 0;
+    if (c.wino) {
+        c.wf_xi = (long long)(c.cin_pad + 1) * c.cout_pk;                          // rows ci (+ zero pad row), columns co
+        c.off_wf = cur; cur += 36 * c.wf_xi;
+        c.wd_xi = (long long)(c.dg_rows_co + 1) * c.cin_pk;                       // rows co, columns ci
+        c.off_wd = cur; cur += 36 * c.wd_xi;
+        cur = (cur + 3) & ~3LL;
+    }
     c.off_tk = -1;
     if (c.KH == 1 && st == 1) { c.off_tk = cur; cur += (long long)c.Cin * c.cout_tot * c.KW; cur = (cur + 3) & ~3LL; }
 }
@@ -185,9 +199,62 @@ static void run_conv(Exec& ex, const ConvProblem& p, int NB, ConvIO io, long lon
     ex.fail(mcvc_conv_launch(p, NB, io, w, w_rows, w_cout, bias, ex.s, nullptr));
 }
 
+static bool wino_enabled()
+{
+    static const int en = [] { const char* e = getenv("MCVC_WINO"); return e ? atoi(e) : 1; }();
+    return en != 0;
+}
+
+// tile of the 36 batched products: 128 channels x 64 tiles measured best on all four shapes (128x128 wastes the ragged
+// tile count of upSample1, 256x32 re-reads V too often); knob: MCVC_WINO_CFG = planner index + 1
+static int wino_tile_cfg(int M, long long NT)
+{
+    static const int knob = [] { const char* e = getenv("MCVC_WINO_CFG"); return e ? atoi(e) : -1; }();
+    (void)M; (void)NT;
+    return knob >= 0 ? knob : 2;
+}
+
+// 5x5 stride-1 conv as Winograd F(2x2,5x5): input transform -> 36 batched [M x K] x [K x tiles] products (one launch of the
+// direct-conv kernel as a 1x1 conv over 36 images with per-image weights) -> output transform (+bias, PixelShuffle store).
+// dgrad: the same on the flipped / transposed weight set; K = conv output channels, M = conv input channels.
+static bool conv_wino(Exec& ex, const ConvSpec& c, const float* packed, int dgrad, int NB, int H, int W, CView x, View y, int shuffle,
+                      int accumulate)
+{
+    if (!c.wino || !wino_enabled() || !ex.wv) return false;
+    const int K = dgrad ? c.cout_tot : c.Cin, M = dgrad ? c.Cin : c.cout_tot;
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+    const long long NT = (long long)NB * TH * TW;
+    // the 36 products see the tiles as a (NTp/32) x 32 "image" so that the conv kernel's 2-D pixel tiles are full
+    const long long NTp = (NT + 31) & ~31LL;
+    if (NT > 16384 || 36LL * (K > M ? K : M) * NTp > ex.wino_cap) return false;
+    if (ex.dry) return true;
+    WinoXformArgs xi{};
+    xi.x = x.p; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv;
+    xi.N = NB; xi.C = K; xi.H = H; xi.W = W; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 2;
+    ex.fail(mcvc_wino_input_launch(xi, ex.s));
+    ConvProblem p{K, (int)(NTp / 32), 32, M, (int)(NTp / 32), 32, 1, 1, 1, 0, 0};
+    ConvIO io{};
+    io.x = ex.wv; io.x_sb = (long long)K * NTp; io.x_sc = NTp; io.x_sh = 32;
+    io.y = ex.wm; io.y_sb = (long long)M * NTp; io.y_sc = NTp; io.y_sh = 32; io.y_sw = 1;
+    io.nsplit = 1;
+    io.w_nstride = dgrad ? c.wd_xi : c.wf_xi;
+    io.tile_cfg = wino_tile_cfg(M, NT);
+    io.gemm_ok = 1;
+    ex.fail(mcvc_conv_launch(p, 36, io, packed + (dgrad ? c.off_wd : c.off_wf), dgrad ? c.dg_rows_co : c.cin_pad, dgrad ? c.cin_pk : c.cout_pk,
+                             nullptr, ex.s, nullptr));
+    WinoOutArgs oa{};
+    oa.m = ex.wm; oa.bias = dgrad ? nullptr : packed + c.off_bias;
+    oa.y = y.p; oa.y_sb = y.sb; oa.y_sc = y.sc; oa.y_sh = y.sh;
+    oa.N = NB; oa.Cout = M; oa.OH = H; oa.OW = W; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
+    oa.shuffle = shuffle; oa.YH = 2 * H; oa.YW = 2 * W; oa.accumulate = accumulate;
+    ex.fail(mcvc_wino_output_launch(oa, ex.s));
+    return true;
+}
+
 static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, int H, int W, CView x, View y, long long y_total,
                      int shuffle, int allow_split, int* nsplit)
 {
+    if (conv_wino(ex, c, packed, 0, NB, H, W, x, y, shuffle, 0)) { if (nsplit) *nsplit = 1; return; }
     ConvProblem p{c.Cin, H, W, c.cout_tot, conv_out(H, c.KH, c.stride, c.ph), conv_out(W, c.KW, c.stride, c.pw),
                   c.KH, c.KW, c.stride, c.ph, c.pw};
     ConvIO io{};
@@ -201,6 +268,7 @@ static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, i
 static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB, int H, int W, CView dy, View dx, long long dx_total,
                        int accumulate, int allow_split, int* nsplit)
 {
+    if (conv_wino(ex, c, packed, 1, NB, H, W, dy, dx, 0, accumulate)) { if (nsplit) *nsplit = 1; return; }
     const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
     const int st = c.stride;
     if (c.merged) {
@@ -338,6 +406,15 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             PackJob q{}; q.kind = PACK_TRUNK_T; q.param = c.wi[br]; q.dst = c.off_tk; q.Cout = c.Cout; q.Cin = c.Cin; q.KW = c.KW;
             q.ld = c.cout_tot * c.KW; q.co_off = br * c.Cout;
             add_job(t, q, cdiv_i(c.Cin, 32), cdiv_i(c.Cout, 32));
+        }
+        if (c.wino) {
+            PackJob wf{}; wf.kind = PACK_WINO_F; wf.param = c.wi[br]; wf.dst = c.off_wf; wf.Cout = c.Cout; wf.Cin = c.Cin; wf.ld = c.cout_pk;
+            wf.xi_stride = c.wf_xi; wf.co_off = br * c.Cout;
+            add_job(t, wf, cdiv_i(c.Cout, 256), c.Cin);
+            PackJob wd{}; wd.kind = PACK_WINO_D; wd.param = c.wi[br]; wd.dst = c.off_wd; wd.Cout = c.Cout; wd.Cin = c.Cin; wd.ld = c.cin_pk;
+            wd.xi_stride = c.wd_xi; wd.co_off = br * c.Cout;
+            add_job(t, wd, cdiv_i(c.Cin, 256), c.Cout);
+            t.bytes += 4.0 * 2.0 * (25.0 + 36.0) * c.Cout * c.Cin;
         }
         t.bytes += 4.0 * ((c.off_tk >= 0 ? 6.0 : 4.0) * c.Cout * K + 2.0 * c.Cout);
     }
@@ -588,7 +665,7 @@ static GenStash gen_stash(const GenDims& d)
     return s;
 }
 
-struct GenScratch { long long ga, gb, gb2, dh, dt1, dt1b, dt2, dt3, dt3b, slabs; };
+struct GenScratch { long long ga, gb, gb2, dh, dt1, dt1b, dt2, dt3, dt3b, wv, wm, wino_floats, slabs; };
 static GenScratch gen_scratch(const GenDims& d)
 {
     GenScratch s{};
@@ -597,6 +674,13 @@ static GenScratch gen_scratch(const GenDims& d)
     s.ga = take(d.big); s.gb = take(d.big); s.gb2 = take(d.big);
     s.dh = take((long long)256 * d.B * d.W4); s.dt1 = take((long long)1024 * d.B * d.W4); s.dt1b = take((long long)1024 * d.B * d.W4);
     s.dt2 = take((long long)512 * d.B * d.W4); s.dt3 = take((long long)256 * d.B * d.W4); s.dt3b = take((long long)256 * d.B * d.W4);
+    // Winograd V / M of upSample1 (1024 ch, tiles of a 20 x W4 image) and upSample2 (512 ch, 40 x 2*W4)
+    {
+        const long long nt1 = ((long long)d.B * 10 * ((d.W4 + 1) / 2) + 31) & ~31LL, nt2 = ((long long)d.B * 20 * ((d.Wu1 + 1) / 2) + 31) & ~31LL;
+        const long long a1 = 36LL * 1024 * nt1, a2 = 36LL * 512 * nt2;
+        s.wino_floats = wino_enabled() ? (a1 > a2 ? a1 : a2) : 0;
+        s.wv = take(s.wino_floats); s.wm = take(s.wino_floats);
+    }
     s.slabs = cur;
     return s;
 }
@@ -1106,6 +1190,7 @@ int mcvc_gen_forward(const float* const* params, const float* packed, const floa
     const GenDims d = gen_dims(B, T);
     Exec ex = make_exec(stream, nullptr, scratch, scratch_floats, gen_scratch(d).slabs, gen_needs(B, T));
     if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
+    { const GenScratch q = gen_scratch(d); ex.wv = scratch + q.wv; ex.wm = scratch + q.wm; ex.wino_cap = q.wino_floats; }
     gen_forward_impl(ex, params, packed, x, mask, out, stash, d);
     return ex.err;
 }
@@ -1118,6 +1203,7 @@ int mcvc_gen_backward_overlap(const float* const* params, const float* packed, f
     const GenDims d = gen_dims(B, T);
     Exec ex = make_exec(stream, aux_stream, scratch, scratch_floats, gen_scratch(d).slabs, gen_needs(B, T));
     if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
+    { const GenScratch q = gen_scratch(d); ex.wv = scratch + q.wv; ex.wm = scratch + q.wm; ex.wino_cap = q.wino_floats; }
     gen_backward_impl(ex, params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, d, milestones);
     return ex.err;
 }

@@ -27,7 +27,7 @@ int mcvc_pack_dgrad_launch(const float* w, float* dst, const PackDgradArgs& a, i
 int mcvc_copy_launch(const float* src, float* dst, int n, hipStream_t s);
 
 // ---- whole-network re-pack (one launch): device-resident job table
-enum PackKind { PACK_FWD = 0, PACK_DGRAD = 1, PACK_COPY = 2, PACK_TRUNK_T = 3 };
+enum PackKind { PACK_FWD = 0, PACK_DGRAD = 1, PACK_COPY = 2, PACK_TRUNK_T = 3, PACK_WINO_F = 4, PACK_WINO_D = 5 };
 struct PackJob {
     int kind, param;       // param = index into the parameter-pointer table
     int block0, gx;        // first workgroup of this job in the flat grid; tile (bx, by) = (rel % gx, rel / gx)
@@ -35,6 +35,7 @@ struct PackJob {
     int Cout, K, ld, co_off, KW, Cin;
     int dg;                // PACK_DGRAD: index into the PackDgradArgs table
     int pad_;
+    long long xi_stride;   // PACK_WINO_*: floats between the 36 transformed matrices
 };
 struct PackPtrs { const float* p[128]; };
 constexpr size_t kPackNetLds = 32 * 75 * sizeof(float);      // largest tap count (5x15) x 32 input channels; >= one 32x33 tile

@@ -13,6 +13,7 @@
 #include "mcvc_common.h"
 #include "pack.h"
 #include "trace.h"
+#include "wino.h"
 
 // [R=Cout][K] -> dst[k*ld + co_off + co], 32x32 LDS tiles, both sides coalesced
 __device__ __forceinline__ void pack_fwd_tile(const float* __restrict__ w, float* __restrict__ dst, int Cout, int K, int ld, int co_off,
@@ -125,6 +126,8 @@ __global__ void __launch_bounds__(256) pack_net_kernel(const PackJob* __restrict
     case PACK_FWD: pack_fwd_tile(w, dst, j.Cout, j.K, j.ld, j.co_off, bx, by, lds); break;
     case PACK_DGRAD: pack_dgrad_tile(w, dst, dga[j.dg], bx, by, lds); break;
     case PACK_TRUNK_T: pack_trunk_t_tile(w, dst, j.Cout, j.Cin, j.KW, j.ld, j.co_off, bx, by, lds); break;
+    case PACK_WINO_F: wino_weight_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, 0, bx, by); break;
+    case PACK_WINO_D: wino_weight_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, 1, bx, by); break;
     default: { const int i = rel * 256 + threadIdx.x; if (i < j.Cout) dst[i] = w[i]; } break;     // PACK_COPY
     }
 }

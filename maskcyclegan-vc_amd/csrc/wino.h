@@ -1,0 +1,72 @@
+// Winograd F(2x2, 5x5) pieces for the stride-1 5x5 convolutions (upSample1 / upSample2 forward and data-gradient).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct WinoXformArgs {
+    // input transform: x[n][c][h][w] -> V[xi][c][tile], xi = 0..35, tile = (n*TH + ty)*TW + tx
+    const float* x; long long x_sb, x_sc; int x_sh;
+    float* v;                 // [36][C][NT]
+    int N, C, H, W;           // input image
+    int TH, TW, NT;           // tiles per image (rows, cols) and in total
+    int NTp;                  // tile pitch of V (NT rounded up to 32)
+    int pad;                  // conv padding (2)
+};
+
+struct WinoOutArgs {
+    // output transform: M[xi][co][tile] -> y (+bias), 2x2 outputs per tile; optional PixelShuffle(2) store
+    const float* m;           // [36][Cout][NT]
+    const float* bias;        // [Cout] or nullptr
+    float* y; long long y_sb, y_sc; int y_sh;
+    int N, Cout, OH, OW, TH, TW, NT, NTp;
+    int shuffle, YH, YW;
+    int accumulate;           // y += (data-gradient into an accumulating destination)
+};
+
+int mcvc_wino_input_launch(const WinoXformArgs& a, hipStream_t s);
+int mcvc_wino_output_launch(const WinoOutArgs& a, hipStream_t s);
+// Weight transform U = G g G^T, one thread per (co, ci), called from the whole-network re-pack kernel:
+// U[xi][k][col] (K-major, `ld` columns, xi_stride floats between transform points) from OIHW weights w[Cout][Cin][5][5].
+//   dgrad == 0: k = ci, col = co_off + co             (forward)
+//   dgrad == 1: k = co_off + co, col = ci, taps flipped (data-gradient)
+// G (6x5) for points {0, 1, -1, 2, -2, inf}
+static __device__ __forceinline__ void wino_weight_tile(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int dgrad, int bx, int by)
+{
+    // forward: threads along co (columns of the K-major matrix); data-gradient: threads along ci
+    const int a_idx = bx * 256 + threadIdx.x;       // fastest index: co (forward) / ci (dgrad)
+    const int b_idx = by;                           //                ci (forward) / co (dgrad)
+    const int co = dgrad ? b_idx : a_idx, ci = dgrad ? a_idx : b_idx;
+    if (co >= Cout || ci >= Cin) return;
+    const float* g = w + ((long long)co * Cin + ci) * 25;
+    float gg[5][5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int l = 0; l < 5; ++l) gg[k][l] = dgrad ? g[(4 - k) * 5 + (4 - l)] : g[k * 5 + l];
+    auto grow = [](const float v[5], float o[6]) {
+        const float s_even = v[0] + v[2] + v[4], s_odd = v[1] + v[3];
+        o[0] = 0.25f * v[0];
+        o[1] = -(s_even + s_odd) * (1.0f / 6.0f);
+        o[2] = -(s_even - s_odd) * (1.0f / 6.0f);
+        const float e2 = v[0] * (1.0f / 24.0f) + v[2] * (1.0f / 6.0f) + v[4] * (2.0f / 3.0f);
+        const float o2 = v[1] * (1.0f / 12.0f) + v[3] * (1.0f / 3.0f);
+        o[3] = e2 + o2;
+        o[4] = e2 - o2;
+        o[5] = v[4];
+    };
+    float t[5][6];                                  // t[k][b] = sum_l g[k][l] G[b][l]
+#pragma unroll
+    for (int k = 0; k < 5; ++k) grow(gg[k], t[k]);
+    const long long row = dgrad ? (co_off + co) : ci;
+    const long long col = dgrad ? ci : (co_off + co);
+    float* d0 = dst + row * ld + col;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        float colv[5], o[6];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) colv[k] = t[k][b];
+        grow(colv, o);                              // U[a][b] = sum_k G[a][k] t[k][b]
+#pragma unroll
+        for (int aa = 0; aa < 6; ++aa) d0[(long long)(aa * 6 + b) * xi_stride] = o[aa];
+    }
+}
+
