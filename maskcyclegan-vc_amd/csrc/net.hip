@@ -232,16 +232,26 @@ static bool conv_wino(Exec& ex, const ConvSpec& c, const float* packed, int dgra
     xi.x = x.p; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv;
     xi.N = NB; xi.C = K; xi.H = H; xi.W = W; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 2;
     ex.fail(mcvc_wino_input_launch(xi, ex.s));
-    ConvProblem p{K, (int)(NTp / 32), 32, M, (int)(NTp / 32), 32, 1, 1, 1, 0, 0};
-    ConvIO io{};
-    io.x = ex.wv; io.x_sb = (long long)K * NTp; io.x_sc = NTp; io.x_sh = 32;
-    io.y = ex.wm; io.y_sb = (long long)M * NTp; io.y_sc = NTp; io.y_sh = 32; io.y_sw = 1;
-    io.nsplit = 1;
-    io.w_nstride = dgrad ? c.wd_xi : c.wf_xi;
-    io.tile_cfg = wino_tile_cfg(M, NT);
-    io.gemm_ok = 1;
-    ex.fail(mcvc_conv_launch(p, 36, io, packed + (dgrad ? c.off_wd : c.off_wf), dgrad ? c.dg_rows_co : c.cin_pad, dgrad ? c.cin_pk : c.cout_pk,
-                             nullptr, ex.s, nullptr));
+    static const int own_gemm = [] { const char* e = getenv("MCVC_WINO_GEMM"); return e ? atoi(e) : 1; }();
+    if (own_gemm && (M % 128) == 0 && (K % 16) == 0 && NTp >= 64) {
+        WinoGemmArgs ga{};
+        ga.a = packed + (dgrad ? c.off_wd : c.off_wf); ga.a_xi = dgrad ? c.wd_xi : c.wf_xi; ga.lda = dgrad ? c.cin_pk : c.cout_pk;
+        ga.b = ex.wv; ga.b_xi = (long long)K * NTp; ga.ldb = (int)NTp;
+        ga.c = ex.wm; ga.c_xi = (long long)M * NTp; ga.ldc = (int)NTp;
+        ga.M = M; ga.N = (int)NTp; ga.K = K;
+        ex.fail(mcvc_wino_gemm_launch(ga, ex.s));
+    } else {
+        ConvProblem p{K, (int)(NTp / 32), 32, M, (int)(NTp / 32), 32, 1, 1, 1, 0, 0};
+        ConvIO io{};
+        io.x = ex.wv; io.x_sb = (long long)K * NTp; io.x_sc = NTp; io.x_sh = 32;
+        io.y = ex.wm; io.y_sb = (long long)M * NTp; io.y_sc = NTp; io.y_sh = 32; io.y_sw = 1;
+        io.nsplit = 1;
+        io.w_nstride = dgrad ? c.wd_xi : c.wf_xi;
+        io.tile_cfg = wino_tile_cfg(M, NT);
+        io.gemm_ok = 1;
+        ex.fail(mcvc_conv_launch(p, 36, io, packed + (dgrad ? c.off_wd : c.off_wf), dgrad ? c.dg_rows_co : c.cin_pad, dgrad ? c.cin_pk : c.cout_pk,
+                                 nullptr, ex.s, nullptr));
+    }
     WinoOutArgs oa{};
     oa.m = ex.wm; oa.bias = dgrad ? nullptr : packed + c.off_bias;
     oa.y = y.p; oa.y_sb = y.sb; oa.y_sc = y.sc; oa.y_sh = y.sh;

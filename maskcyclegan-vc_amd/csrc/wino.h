@@ -70,3 +70,12 @@ static __device__ __forceinline__ void wino_weight_tile(const float* w, float* d
     }
 }
 
+
+// Batched product of the 36 Winograd points:  C[xi][m][n] = sum_k A[xi][k][m] * B[xi][k][n]   (all operands K-major)
+struct WinoGemmArgs {
+    const float* a; long long a_xi; int lda;     // U: [36][K (+pad row)][lda]
+    const float* b; long long b_xi; int ldb;     // V: [36][K][ldb]
+    float* c; long long c_xi; int ldc;           // M: [36][M][ldc]
+    int M, N, K;                                 // N = valid columns (multiple of 32)
+};
+int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s);

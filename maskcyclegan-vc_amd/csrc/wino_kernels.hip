@@ -112,6 +112,98 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const WinoOutArgs a)
     }
 }
 
+
+// ---- batched product of the 36 points -----------------------------------------------------------------------------
+// Workgroup = 4 waves, tile 128 (m) x 64 (n); wave (wm, wn) owns 64 x 32 = two v_mfma_f32_32x32x2_f32 accumulators.
+// K advances in stages of 16; both operands are plain K-major matrices, so a stage is two rectangular copies
+// (16 x 128 and 16 x 64 floats) done by LDS-DMA, 16 bytes per lane.  FOUR stages are in flight: unlike the conv kernel
+// (one stage of lookahead, drained by the vmcnt(0) that __syncthreads() implies) the wait here is an explicit
+// s_waitcnt vmcnt(n) that leaves the newer stages outstanding, so a stage has three stages of MFMA work (~2.5 us) to land.
+constexpr int kGK = 16;                 // k per stage
+constexpr int kGStages = 4;
+constexpr int kGA = kGK * 128;          // floats of A per stage
+constexpr int kGB = kGK * 64;
+constexpr int kGStage = kGA + kGB;
+
+__device__ __forceinline__ void wg_glds16(const float* g, float* l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ void __launch_bounds__(256, 3) wino_gemm_kernel(const WinoGemmArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [kGStages][A 16x128 | B 16x64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 128, xi = blockIdx.z;
+    const float* A = a.a + (long long)xi * a.a_xi + m0;
+    const float* B = a.b + (long long)xi * a.b_xi + n0;
+    // DMA lane constants.  A stage: 16 rows x 32 float4 = 512 float4 = 8 wave-instructions (2 per wave);
+    //                      B stage: 16 rows x 16 float4 = 256 float4 = 4 wave-instructions (1 per wave)
+    const int fa0 = wave * 64 + lane, fa1 = fa0 + 256;                // float4 index inside the A stage
+    const float* a_src0 = A + (long long)(fa0 >> 5) * a.lda + 4 * (fa0 & 31);
+    const float* a_src1 = A + (long long)(fa1 >> 5) * a.lda + 4 * (fa1 & 31);
+    const int fb = wave * 64 + lane;
+    int bcol = 4 * (fb & 15);
+    if (n0 + bcol > a.ldb - 4) bcol = a.ldb - 4 - n0;                 // tile hanging over the row end: finite neighbours
+    const float* b_src = B + (long long)(fb >> 4) * a.ldb + bcol;
+    const long long a_step = (long long)kGK * a.lda, b_step = (long long)kGK * a.ldb;
+    auto issue = [&](int stage_k, int buf) {                          // 3 DMA instructions per wave
+        float* base = smem + buf * kGStage;
+        wg_glds16(a_src0 + stage_k * a_step, base + (wave * 64) * 4);
+        wg_glds16(a_src1 + stage_k * a_step, base + (wave * 64 + 256) * 4);
+        wg_glds16(b_src + stage_k * b_step, base + kGA + (wave * 64) * 4);
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int nst = a.K / kGK;
+#pragma unroll
+    for (int s = 0; s < kGStages - 1; ++s)
+        if (s < nst) issue(s, s);
+    const int a_lane = half * 128 + wm * 64 + l31;                    // A[k = 2p + half][m]
+    const int b_lane = kGA + half * 64 + wn * 32 + l31;               // B[k = 2p + half][n]
+    for (int st = 0; st < nst; ++st) {
+        // stage `st` must have landed: at most the (up to) two newer stages' 3 + 3 DMA instructions may stay outstanding
+        const int newer = (nst - 1 - st) < (kGStages - 2) ? (nst - 1 - st) : (kGStages - 2);
+        if (newer >= 2) __builtin_amdgcn_s_waitcnt(0x0F76);           // vmcnt(6)
+        else if (newer == 1) __builtin_amdgcn_s_waitcnt(0x0F73);      // vmcnt(3)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
+        __builtin_amdgcn_s_barrier();                                 // everyone's part of stage st is in LDS; buffer (st-1)%4 is free
+        if (st + kGStages - 1 < nst) issue(st + kGStages - 1, (st + kGStages - 1) % kGStages);
+        const float* sb = smem + (st % kGStages) * kGStage;
+        // operand reads run one k-pair ahead of the MFMAs (pinned: the scheduler otherwise sinks them below the MFMAs)
+        float a0 = sb[a_lane], a1 = sb[a_lane + 32], b0 = sb[b_lane];
+#pragma unroll
+        for (int p = 0; p < kGK / 2; ++p) {
+            const int q = (p + 1 < kGK / 2) ? p + 1 : p;
+            const float na0 = sb[a_lane + q * 256], na1 = sb[a_lane + q * 256 + 32], nb0 = sb[b_lane + q * 128];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            a0 = na0; a1 = na1; b0 = nb0;
+        }
+    }
+    // ---- store: D register r of lane (l31, half) is row (r&3) + 8*(r>>2) + 4*half, column l31
+    const int n = n0 + wn * 32 + l31;
+    if (n < a.N) {
+        float* C = a.c + (long long)xi * a.c_xi + n;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < a.M) C[(long long)m * a.ldc] = acc[i][r];
+            }
+    }
+}
+
 }  // namespace
 
 int mcvc_wino_input_launch(const WinoXformArgs& a, hipStream_t s)
@@ -127,5 +219,15 @@ int mcvc_wino_output_launch(const WinoOutArgs& a, hipStream_t s)
     dim3 grid((unsigned)cdiv_i(a.NT, 256), (unsigned)a.Cout);
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (36.0 * a.Cout * a.NT + 4.0 * a.Cout * a.NT));
     hipLaunchKernelGGL(wino_output_kernel, grid, dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
+{
+    if ((a.K % kGK) != 0 || (a.M % 128) != 0 || (a.lda & 3) || (a.ldb & 3) || a.ldb < 64) return MCVC_ERR_INVALID;
+    dim3 grid((unsigned)cdiv_i(a.N, 64), (unsigned)(a.M / 128), 36);
+    const size_t lds = (size_t)kGStages * kGStage * sizeof(float);
+    TraceScope ts(K_CONV_M, s, 2.0 * 36.0 * a.M * a.N * a.K, 4.0 * 36.0 * ((double)a.K * a.M + (double)a.K * a.N + (double)a.M * a.N));
+    hipLaunchKernelGGL(wino_gemm_kernel, grid, dim3(256), lds, s, a);
     return (int)hipGetLastError();
 }
