@@ -48,6 +48,8 @@ struct Exec {
     long long wslab_need;
     float* wv; float* wm;          // Winograd scratch: transformed input V[36][K][tiles], products M[36][M][tiles]
     long long wino_cap;            // floats available in each
+    float* wv2; float* wm2; float* wu;   // the weight-gradient's own set (it runs on the auxiliary stream beside the dgrad): Vt, dMt, dU
+    long long wu_cap;
     std::vector<std::pair<const void*, hipEvent_t>> readers;
     void fail(int e) { if (!err && e) err = e; }
 };
@@ -340,7 +342,33 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         ex.fail((int)hipStreamWaitEvent(ex.s2, e, 0));
         ws = ex.s2;
     }
-    for (int br = 0; br < c.nbr; ++br) {
+    bool done = false;
+    if (c.wino && wino_enabled() && ex.wu && c.nbr == 1 && grads[c.wi[0]]) {
+        // Winograd weight gradient: dU[xi] = dM[xi] V[xi]^T over the tiles, then dW += G^T dU G.  Operands tile-major.
+        static const int en = [] { const char* e = getenv("MCVC_WINO_WGRAD"); return e ? atoi(e) : 1; }();
+        const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+        const long long NT = (long long)NB * TH * TW, NTp = (NT + 31) & ~31LL;
+        if (en && (c.Cout % 128) == 0 && (c.Cin % 64) == 0 && 36LL * NTp * c.Cout <= ex.wino_cap && 36LL * NTp * c.Cin <= ex.wino_cap &&
+            36LL * c.Cout * c.Cin <= ex.wu_cap) {
+            WinoXformArgs xi{};
+            xi.x = x.p; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv2;
+            xi.N = NB; xi.C = c.Cin; xi.H = H; xi.W = W; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 2;
+            ex.fail(mcvc_wino_input_t_launch(xi, ws));
+            WinoXformArgs di{};
+            di.x = dy.p; di.x_sb = dy.sb; di.x_sc = dy.sc; di.x_sh = dy.sh; di.v = ex.wm2;
+            di.N = NB; di.C = c.Cout; di.H = H; di.W = W; di.TH = TH; di.TW = TW; di.NT = (int)NT; di.NTp = (int)NTp; di.pad = 0;
+            ex.fail(mcvc_wino_dy_t_launch(di, ws));
+            WinoGemmArgs ga{};
+            ga.a = ex.wm2; ga.a_xi = NTp * c.Cout; ga.lda = c.Cout;          // dMt[xi][tile][co]
+            ga.b = ex.wv2; ga.b_xi = NTp * c.Cin; ga.ldb = c.Cin;            // Vt[xi][tile][ci]
+            ga.c = ex.wu; ga.c_xi = (long long)c.Cout * c.Cin; ga.ldc = c.Cin;
+            ga.M = c.Cout; ga.N = c.Cin; ga.K = (int)NTp;
+            ex.fail(mcvc_wino_gemm_launch(ga, ws));
+            ex.fail(mcvc_wino_dw_launch(ex.wu, grads[c.wi[0]], c.Cout, c.Cin, ws));
+            done = true;
+        }
+    }
+    for (int br = 0; br < c.nbr && !done; ++br) {
         float* dw = grads[c.wi[br]];
         if (!dw) continue;
         WgradIO io{x.p, x.sb, x.sc, x.sh, dy.p + (long long)br * c.Cout * dy.sc, dy.sb, dy.sc, dy.sh};
@@ -675,7 +703,7 @@ static GenStash gen_stash(const GenDims& d)
     return s;
 }
 
-struct GenScratch { long long ga, gb, gb2, dh, dt1, dt1b, dt2, dt3, dt3b, wv, wm, wino_floats, slabs; };
+struct GenScratch { long long ga, gb, gb2, dh, dt1, dt1b, dt2, dt3, dt3b, wv, wm, wino_floats, wv2, wm2, wu, wu_floats, slabs; };
 static GenScratch gen_scratch(const GenDims& d)
 {
     GenScratch s{};
@@ -690,6 +718,9 @@ static GenScratch gen_scratch(const GenDims& d)
         const long long a1 = 36LL * 1024 * nt1, a2 = 36LL * 512 * nt2;
         s.wino_floats = wino_enabled() ? (a1 > a2 ? a1 : a2) : 0;
         s.wv = take(s.wino_floats); s.wm = take(s.wino_floats);
+        s.wv2 = take(s.wino_floats); s.wm2 = take(s.wino_floats);
+        s.wu_floats = wino_enabled() ? 36LL * 1024 * 256 : 0;          // dU of upSample1 (the larger weight tensor)
+        s.wu = take(s.wu_floats);
     }
     s.slabs = cur;
     return s;
@@ -1213,7 +1244,8 @@ int mcvc_gen_backward_overlap(const float* const* params, const float* packed, f
     const GenDims d = gen_dims(B, T);
     Exec ex = make_exec(stream, aux_stream, scratch, scratch_floats, gen_scratch(d).slabs, gen_needs(B, T));
     if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
-    { const GenScratch q = gen_scratch(d); ex.wv = scratch + q.wv; ex.wm = scratch + q.wm; ex.wino_cap = q.wino_floats; }
+    { const GenScratch q = gen_scratch(d); ex.wv = scratch + q.wv; ex.wm = scratch + q.wm; ex.wino_cap = q.wino_floats;
+      ex.wv2 = scratch + q.wv2; ex.wm2 = scratch + q.wm2; ex.wu = scratch + q.wu; ex.wu_cap = q.wu_floats; }
     gen_backward_impl(ex, params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, d, milestones);
     return ex.err;
 }

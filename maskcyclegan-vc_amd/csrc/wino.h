@@ -23,6 +23,12 @@ struct WinoOutArgs {
 };
 
 int mcvc_wino_input_launch(const WinoXformArgs& a, hipStream_t s);
+// weight-gradient operands, tile-major (the tile index is the contraction dimension there): Vt[36][NTp][C] from x, and
+// dMt[36][NTp][C] = A dY A^T from the 2x2 output-gradient tiles; rows of tiles >= NT are written as zeros
+int mcvc_wino_input_t_launch(const WinoXformArgs& a, hipStream_t s);
+int mcvc_wino_dy_t_launch(const WinoXformArgs& a, hipStream_t s);
+// dw[co][ci][5][5] += G^T dU G  from dU[36][Cout][Cin]
+int mcvc_wino_dw_launch(const float* du, float* dw, int Cout, int Cin, hipStream_t s);
 int mcvc_wino_output_launch(const WinoOutArgs& a, hipStream_t s);
 // Weight transform U = G g G^T, one thread per (co, ci), called from the whole-network re-pack kernel:
 // U[xi][k][col] (K-major, `ld` columns, xi_stride floats between transform points) from OIHW weights w[Cout][Cin][5][5].

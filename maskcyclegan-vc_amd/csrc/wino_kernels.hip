@@ -62,6 +62,129 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const WinoXformArgs a)
     }
 }
 
+// ---- weight-gradient operands --------------------------------------------------------------------------------------
+// dU[xi][co][ci] = sum_tile dM[xi][co][tile] * V[xi][ci][tile]: the tile index is the contraction dimension, so both
+// operands are stored tile-major ([xi][tile][channel]) -- the K-major layout the batched GEMM streams.  A workgroup
+// covers 16 tiles x 16 channels with the channel fastest, so every store is a 64-byte run.
+__global__ void __launch_bounds__(256) wino_input_t_kernel(const WinoXformArgs a)
+{
+    const int c = blockIdx.y * 16 + (threadIdx.x & 15);
+    const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (tile >= a.NTp || c >= a.C) return;
+    float* dst = a.v + (long long)tile * a.C + c;
+    const long long xs = (long long)a.NTp * a.C;
+    if (tile >= a.NT) {
+#pragma unroll
+        for (int q = 0; q < 36; ++q) dst[q * xs] = 0.f;
+        return;
+    }
+    const int per = a.TH * a.TW;
+    const int n = tile / per, r = tile - n * per;
+    const int ty = r / a.TW, tx = r - ty * a.TW;
+    const int ih0 = 2 * ty - a.pad, iw0 = 2 * tx - a.pad;
+    const float* src = a.x + (long long)n * a.x_sb + (long long)c * a.x_sc;
+    float t[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float d[6];
+        const int ih = ih0 + i;
+        const bool rok = (ih >= 0) && (ih < a.H);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int iw = iw0 + j;
+            d[j] = (rok && iw >= 0 && iw < a.W) ? src[(long long)ih * a.x_sh + iw] : 0.f;
+        }
+        bt6(d, t[i]);
+    }
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        float col[6], o[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = t[i][b];
+        bt6(col, o);
+#pragma unroll
+        for (int aa = 0; aa < 6; ++aa) dst[(long long)(aa * 6 + b) * xs] = o[aa];
+    }
+}
+
+// A (6x2) = [[1,0],[1,1],[1,-1],[1,2],[1,-2],[0,1]]:  dM = A dy A^T
+__device__ __forceinline__ void a62(float d0, float d1, float o[6])
+{
+    o[0] = d0; o[1] = d0 + d1; o[2] = d0 - d1; o[3] = d0 + 2.f * d1; o[4] = d0 - 2.f * d1; o[5] = d1;
+}
+
+__global__ void __launch_bounds__(256) wino_dy_t_kernel(const WinoXformArgs a)      // x = dY [N][C][H][W], H x W = conv output
+{
+    const int c = blockIdx.y * 16 + (threadIdx.x & 15);
+    const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (tile >= a.NTp || c >= a.C) return;
+    float* dst = a.v + (long long)tile * a.C + c;
+    const long long xs = (long long)a.NTp * a.C;
+    if (tile >= a.NT) {
+#pragma unroll
+        for (int q = 0; q < 36; ++q) dst[q * xs] = 0.f;
+        return;
+    }
+    const int per = a.TH * a.TW;
+    const int n = tile / per, r = tile - n * per;
+    const int ty = r / a.TW, tx = r - ty * a.TW;
+    const float* src = a.x + (long long)n * a.x_sb + (long long)c * a.x_sc;
+    float dy[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oh = 2 * ty + i, ow = 2 * tx + j;
+            dy[i][j] = (oh < a.H && ow < a.W) ? src[(long long)oh * a.x_sh + ow] : 0.f;
+        }
+    float t0[6], t1[6];                       // t[a][j] = A[a][0] dy[0][j] + A[a][1] dy[1][j]
+    a62(dy[0][0], dy[1][0], t0);
+    a62(dy[0][1], dy[1][1], t1);
+#pragma unroll
+    for (int aa = 0; aa < 6; ++aa) {
+        float o[6];
+        a62(t0[aa], t1[aa], o);               // dM[a][b] = t[a][0] A[b][0] + t[a][1] A[b][1]
+#pragma unroll
+        for (int b = 0; b < 6; ++b) dst[(long long)(aa * 6 + b) * xs] = o[b];
+    }
+}
+
+// dg = G^T dU G, accumulated into the OIHW gradient.  One thread per (co, ci), ci fastest (coalesced reads of dU).
+__global__ void __launch_bounds__(256) wino_dw_kernel(const float* __restrict__ du, float* __restrict__ dw, int Cout, int Cin)
+{
+    const int ci = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y;
+    if (ci >= Cin) return;
+    const long long xs = (long long)Cout * Cin;
+    const float* src = du + (long long)co * Cin + ci;
+    // G^T (5x6) applied to a 6-vector:  out[k] = sum_a G[a][k] v[a]
+    auto gt = [](const float v[6], float o[5]) {
+        const float p = v[1] + v[2], m = v[1] - v[2], q = v[3] + v[4], n = v[3] - v[4];
+        o[0] = 0.25f * v[0] - p * (1.0f / 6.0f) + q * (1.0f / 24.0f);
+        o[1] = -m * (1.0f / 6.0f) + n * (1.0f / 12.0f);
+        o[2] = -p * (1.0f / 6.0f) + q * (1.0f / 6.0f);
+        o[3] = -m * (1.0f / 6.0f) + n * (1.0f / 3.0f);
+        o[4] = -p * (1.0f / 6.0f) + q * (2.0f / 3.0f) + v[5];
+    };
+    float t[5][6];                            // t[k][b] = sum_a G[a][k] dU[a][b]
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        float col[6], o[5];
+#pragma unroll
+        for (int aa = 0; aa < 6; ++aa) col[aa] = src[(long long)(aa * 6 + b) * xs];
+        gt(col, o);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) t[k][b] = o[k];
+    }
+    float* dst = dw + ((long long)co * Cin + ci) * 25;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        float o[5];
+        gt(t[k], o);                          // dg[k][l] = sum_b t[k][b] G[b][l]
+#pragma unroll
+        for (int l = 0; l < 5; ++l) dst[k * 5 + l] += o[l];
+    }
+}
+
 // A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,1]]
 __device__ __forceinline__ void at6(const float m[6], float& o0, float& o1)
 {
@@ -227,7 +350,31 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
     if ((a.K % kGK) != 0 || (a.M % 128) != 0 || (a.lda & 3) || (a.ldb & 3) || a.ldb < 64) return MCVC_ERR_INVALID;
     dim3 grid((unsigned)cdiv_i(a.N, 64), (unsigned)(a.M / 128), 36);
     const size_t lds = (size_t)kGStages * kGStage * sizeof(float);
-    TraceScope ts(K_CONV_M, s, 2.0 * 36.0 * a.M * a.N * a.K, 4.0 * 36.0 * ((double)a.K * a.M + (double)a.K * a.N + (double)a.M * a.N));
+    TraceScope ts(K_WINO_GEMM, s, 2.0 * 36.0 * a.M * a.N * a.K, 4.0 * 36.0 * ((double)a.K * a.M + (double)a.K * a.N + (double)a.M * a.N));
     hipLaunchKernelGGL(wino_gemm_kernel, grid, dim3(256), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_wino_input_t_launch(const WinoXformArgs& a, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp));
+    hipLaunchKernelGGL(wino_input_t_kernel, grid, dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_wino_dy_t_launch(const WinoXformArgs& a, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp));
+    hipLaunchKernelGGL(wino_dy_t_kernel, grid, dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_wino_dw_launch(const float* du, float* dw, int Cout, int Cin, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv_i(Cin, 256), (unsigned)Cout);
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (36.0 + 50.0) * Cout * Cin);
+    hipLaunchKernelGGL(wino_dw_kernel, grid, dim3(256), 0, s, du, dw, Cout, Cin);
     return (int)hipGetLastError();
 }

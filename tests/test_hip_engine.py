@@ -170,8 +170,10 @@ def test_large_batch_generator_phase_is_the_mean_of_single_sample_phases():
     Also exercises the generic (non-fused) trunk path: 32 samples x 16 frames > 32 columns."""
     B = 32
     nets = _nets([410 + i for i in range(6)])
-    eng = TrainEngine(nets, B, 64, schedule=StepSchedule(batch_size=B, n_samples=64))
-    keys = ("g_loss", "cycle_loss", "identity_loss", "adv_loss")
+    # adversarial terms only: they are smooth, so the linearity is exact up to rounding; the L1 cycle / identity terms are
+    # covered against the oracle at bs=1,2 above
+    eng = TrainEngine(nets, B, 64, schedule=StepSchedule(batch_size=B, n_samples=64, cycle_loss_lambda=0.0, identity_loss_lambda=0.0))
+    keys = ("g_loss", "adv_loss")
 
     def g_phase(b):
         if b[0].shape[0] != eng.B:
@@ -182,18 +184,11 @@ def test_large_batch_generator_phase_is_the_mean_of_single_sample_phases():
         lo = eng.losses()
         return [lo[k] for k in keys], eng.g_group.grad.double().clone()
 
-    # the L1 losses have a kink at 0: an element of (cycle - real) / (identity - real) within rounding of 0 may take the
-    # other sign in the differently-tiled bs=1 kernels, and ONE flipped sign moves that loss's gradient by 2/sqrt(N) = 0.5 %.
-    # Draw batches until no element sits that close (judged on the engine's own bs=32 outputs).
-    for seed in range(77, 140):
-        batch = _rand_batch(B, seed)
-        big_l, big_g = g_phase(batch)
-        B_ = B
-        pairs = [(eng.mel["cycle_A"], batch[0]), (eng.mel["cycle_B"], batch[2]), (eng.out_B2A[B_:], batch[0]), (eng.out_A2B[B_:], batch[2])]
-        if min(float((a - b).abs().min()) for a, b in pairs) > 1e-5:
-            break
-    else:
-        pytest.skip("no kink-free batch found")
+    # (the L1 terms are switched off for this property -- see the schedule above -- because |x| has a kink at 0: with 650 k
+    # elements per batch some (cycle - real) always sits within rounding of 0, may take the other sign in the differently
+    # tiled bs=1 kernels, and ONE flipped sign moves that loss's gradient by 2/sqrt(N) = 0.5 %)
+    batch = _rand_batch(B, 77)
+    big_l, big_g = g_phase(batch)
     acc_l, acc_g = np.zeros(len(keys)), torch.zeros_like(big_g)
     for i in range(B):
         l1, g1 = g_phase([t[i:i + 1].contiguous() for t in batch])
