@@ -348,7 +348,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         static const int en = [] { const char* e = getenv("MCVC_WINO_WGRAD"); return e ? atoi(e) : 1; }();
         const int TH = (H + 1) / 2, TW = (W + 1) / 2;
         const long long NT = (long long)NB * TH * TW, NTp = (NT + 31) & ~31LL;
-        if (en && (c.Cout % 128) == 0 && (c.Cin % 64) == 0 && 36LL * NTp * c.Cout <= ex.wino_cap && 36LL * NTp * c.Cin <= ex.wino_cap &&
+        if (en && NT <= 16384 && (c.Cout % 128) == 0 && (c.Cin % 64) == 0 && 36LL * NTp * c.Cout <= ex.wino_cap && 36LL * NTp * c.Cin <= ex.wino_cap &&
             36LL * c.Cout * c.Cin <= ex.wu_cap) {
             WinoXformArgs xi{};
             xi.x = x.p; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv2;
@@ -715,7 +715,8 @@ static GenScratch gen_scratch(const GenDims& d)
     // Winograd V / M of upSample1 (1024 ch, tiles of a 20 x W4 image) and upSample2 (512 ch, 40 x 2*W4)
     {
         const long long nt1 = ((long long)d.B * 10 * ((d.W4 + 1) / 2) + 31) & ~31LL, nt2 = ((long long)d.B * 20 * ((d.Wu1 + 1) / 2) + 31) & ~31LL;
-        const long long a1 = 36LL * 1024 * nt1, a2 = 36LL * 512 * nt2;
+        // (beyond 16384 tiles the layers fall back to the direct kernels -- conv_wino / conv_wgrad -- and need no scratch)
+        const long long a1 = nt1 <= 16384 ? 36LL * 1024 * nt1 : 0, a2 = nt2 <= 16384 ? 36LL * 512 * nt2 : 0;
         s.wino_floats = wino_enabled() ? (a1 > a2 ? a1 : a2) : 0;
         s.wv = take(s.wino_floats); s.wm = take(s.wino_floats);
         s.wv2 = take(s.wino_floats); s.wm2 = take(s.wino_floats);
