@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--cpu-iters", type=int, default=12, help="timed CPU-baseline iterations (0 = skip)")
     ap.add_argument("--no-trace", action="store_true")
-    ap.add_argument("--serial", action="store_true", help="disable the two-stream lane overlap (A/B comparison)")
+    ap.add_argument("--serial", action="store_true", help="one stream: no lanes, no auxiliary weight-gradient stream (A/B comparison, per-kernel profiling)")
     ap.add_argument("--graphs", action="store_true", help="replay HIP graphs of the two phases (experimental; not faster on ROCm 7.2)")
     ap.add_argument("--dump-trace", default=None, help="write one traced step's per-launch records (launch order) to this file")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")
@@ -161,6 +161,8 @@ def main():
                          decay_after=2e5, stop_identity_after=1e4, world_size=world)     # bash_scripts/mask_cyclegan_train.sh
     engine = TrainEngine(nets, B, T, schedule=sched, reducer=FlatGradReducer())
     engine.concurrent = not args.serial
+    if args.serial:
+        engine.aux_wgrad = False          # truly one stream: per-kernel durations comparable with the traced step's
     engine.use_graphs = args.graphs
     if args.graphs:
         engine.aux_wgrad = False            # lanes + auxiliary streams in one capture crash hipStreamEndCapture (ROCm 7.2)
