@@ -101,6 +101,8 @@ struct ConvSpec {
     long long off_fwd, off_bias, off_dgrad;
     // 5x5 stride-1 single-branch convs (upSample1/2): Winograd F(2x2,5x5) weight sets U[36][K+1][ld], forward and data-gradient
     int wino; long long off_wf, off_wd, wf_xi, wd_xi;
+    // 5x5 stride-2 convs (downSample1/2): their merged 3x3 data-gradient as Winograd F(2x2,3x3): U[16][co (+1)][mg_ld]
+    int wino3; long long off_w3, w3_xi;
     long long off_tk;          // KH == 1 convs: transposed + flipped [Cin][cout_tot*KW] copy for the fused small-batch trunk dgrad
     int ncls;
     DgradClass cls[4];
@@ -167,6 +169,9 @@ static void spec_finalize(ConvSpec& c, long long& cur)
         c.off_wd = cur; cur += 36 * c.wd_xi;
         cur = (cur + 3) & ~3LL;
     }
+    c.wino3 = (c.merged && c.KH == 5 && c.KW == 5 && c.ph == 2 && c.pw == 2 && (4 * c.Cin) % 128 == 0 && c.cout_tot % 16 == 0) ? 1 : 0;
+    c.off_w3 = -1; c.w3_xi = 0;
+    if (c.wino3) { c.w3_xi = (long long)(c.dg_rows_co + 1) * c.mg_ld; c.off_w3 = cur; cur += 16 * c.w3_xi; cur = (cur + 3) & ~3LL; }
     c.off_tk = -1;
     if (c.KH == 1 && st == 1) { c.off_tk = cur; cur += (long long)c.Cin * c.cout_tot * c.KW; cur = (cur + 3) & ~3LL; }
 }
@@ -283,6 +288,34 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
     if (conv_wino(ex, c, packed, 1, NB, H, W, dy, dx, 0, accumulate)) { if (nsplit) *nsplit = 1; return; }
     const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
     const int st = c.stride;
+    if (c.wino3 && wino_enabled() && ex.wv) {
+        // merged stride-2 data-gradient = a 3x3 stride-1 conv over dY with 4*Cin output channels: Winograd F(2x2,3x3)
+        static const int en = [] { const char* e = getenv("MCVC_WINO3"); return e ? atoi(e) : 1; }();
+        const int K = c.cout_tot, M = 4 * c.Cin;
+        const int TH = (OH + 1) / 2, TW = (OW + 1) / 2;
+        const long long NT = (long long)NB * TH * TW, NTp = (NT + 31) & ~31LL;
+        if (en && NT <= 16384 && NTp >= 64 && 16LL * (K > M ? K : M) * NTp <= ex.wino_cap && (H + 1) / 2 == OH && (W + 1) / 2 == OW) {
+            if (nsplit) *nsplit = 1;
+            if (ex.dry) return;
+            WinoXformArgs xi{};
+            xi.x = dy.p; xi.x_sb = dy.sb; xi.x_sc = dy.sc; xi.x_sh = dy.sh; xi.v = ex.wv;
+            xi.N = NB; xi.C = K; xi.H = OH; xi.W = OW; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 1;
+            ex.fail(mcvc_wino3_input_launch(xi, ex.s));
+            WinoGemmArgs ga{};
+            ga.a = packed + c.off_w3; ga.a_xi = c.w3_xi; ga.lda = c.mg_ld;
+            ga.b = ex.wv; ga.b_xi = (long long)K * NTp; ga.ldb = (int)NTp;
+            ga.c = ex.wm; ga.c_xi = (long long)M * NTp; ga.ldc = (int)NTp;
+            ga.M = M; ga.N = (int)NTp; ga.K = K; ga.nxi = 16;
+            ex.fail(mcvc_wino_gemm_launch(ga, ex.s));
+            WinoOutArgs oa{};
+            oa.m = ex.wm; oa.bias = nullptr;
+            oa.y = dx.p; oa.y_sb = dx.sb; oa.y_sc = dx.sc; oa.y_sh = dx.sh;
+            oa.N = NB; oa.Cout = M; oa.OH = OH; oa.OW = OW; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
+            oa.shuffle = 1; oa.YH = H; oa.YW = W; oa.accumulate = accumulate;
+            ex.fail(mcvc_wino3_output_launch(oa, ex.s));
+            return;
+        }
+    }
     if (c.merged) {
         ConvProblem p{c.cout_tot, OH, OW, 4 * c.Cin, (H + 1) / 2, (W + 1) / 2, c.mg_kh, c.mg_kw, 1, c.mg_pad_h, c.mg_pad_w};
         ConvIO io{};
@@ -444,6 +477,12 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             PackJob q{}; q.kind = PACK_TRUNK_T; q.param = c.wi[br]; q.dst = c.off_tk; q.Cout = c.Cout; q.Cin = c.Cin; q.KW = c.KW;
             q.ld = c.cout_tot * c.KW; q.co_off = br * c.Cout;
             add_job(t, q, cdiv_i(c.Cin, 32), cdiv_i(c.Cout, 32));
+        }
+        if (c.wino3) {
+            PackJob w3{}; w3.kind = PACK_WINO3_D; w3.param = c.wi[br]; w3.dst = c.off_w3; w3.Cout = c.Cout; w3.Cin = c.Cin; w3.ld = c.mg_ld;
+            w3.xi_stride = c.w3_xi; w3.co_off = br * c.Cout;
+            add_job(t, w3, cdiv_i(c.Cin, 256), c.Cout);
+            t.bytes += 4.0 * (25.0 + 64.0) * c.Cout * c.Cin;
         }
         if (c.wino) {
             PackJob wf{}; wf.kind = PACK_WINO_F; wf.param = c.wi[br]; wf.dst = c.off_wf; wf.Cout = c.Cout; wf.Cin = c.Cin; wf.ld = c.cout_pk;

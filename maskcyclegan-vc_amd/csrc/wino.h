@@ -23,6 +23,9 @@ struct WinoOutArgs {
 };
 
 int mcvc_wino_input_launch(const WinoXformArgs& a, hipStream_t s);
+// F(2x2,3x3) variants (4x4 tiles, 16 points, padding 1): the merged data-gradient of the stride-2 5x5 convs is a 3x3 conv
+int mcvc_wino3_input_launch(const WinoXformArgs& a, hipStream_t s);
+int mcvc_wino3_output_launch(const WinoOutArgs& a, hipStream_t s);
 // weight-gradient operands, tile-major (the tile index is the contraction dimension there): Vt[36][NTp][C] from x, and
 // dMt[36][NTp][C] = A dY A^T from the 2x2 output-gradient tiles; rows of tiles >= NT are written as zeros
 int mcvc_wino_input_t_launch(const WinoXformArgs& a, hipStream_t s);
@@ -83,5 +86,48 @@ struct WinoGemmArgs {
     const float* b; long long b_xi; int ldb;     // V: [36][K][ldb]
     float* c; long long c_xi; int ldc;           // M: [36][M][ldc]
     int M, N, K;                                 // N = valid columns (multiple of 32)
+    int nxi;                                     // transform points: 36 (F(2x2,5x5)) or 16 (F(2x2,3x3)); 0 = 36
 };
 int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s);
+
+// Weight transform for the F(2x2,3x3) data-gradient of a stride-2 5x5 conv (padding 2).  The data-gradient is ONE stride-1
+// 3x3 conv over dY with 4*Cin output channels (column 4*ci + 2*qh + qw = output parity class), whose taps are
+//   g'[u'][v'] = W[co][ci][kh(u',qh)][kw(v',qw)],  kh(u',0) = 4 - 2u',  kh(u',1) = 5 - 2u' (u' >= 1, else no tap)
+// (pack_dgrad_tile builds the same matrix for the direct kernel).  U = G g' G^T with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
+// One thread per (co, ci), ci fastest: stores 4 consecutive columns x 16 points.
+static __device__ __forceinline__ void wino3_weight_tile(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int bx, int by)
+{
+    const int ci = bx * 256 + threadIdx.x, co = by;
+    if (co >= Cout || ci >= Cin) return;
+    const float* g = w + ((long long)co * Cin + ci) * 25;
+    float gg[5][5];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) gg[k / 5][k % 5] = g[k];
+    auto g3 = [](float v0, float v1, float v2, float o[4]) {
+        o[0] = v0; o[1] = 0.5f * (v0 + v1 + v2); o[2] = 0.5f * (v0 - v1 + v2); o[3] = v2;
+    };
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh)
+#pragma unroll
+        for (int qw = 0; qw < 2; ++qw) {
+            float t[3][4];                       // t[u'][b] = sum_v' g'[u'][v'] G[b][v']
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int kh = qh ? 5 - 2 * u : 4 - 2 * u;          // qh = 1, u = 0 -> 5: no such tap
+                float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+                if (kh <= 4) {
+                    if (qw) { r1 = gg[kh][3]; r2 = gg[kh][1]; }
+                    else { r0 = gg[kh][4]; r1 = gg[kh][2]; r2 = gg[kh][0]; }
+                }
+                g3(r0, r1, r2, t[u]);
+            }
+            float* d0 = dst + (long long)(co_off + co) * ld + 4 * ci + 2 * qh + qw;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                float o[4];
+                g3(t[0][b], t[1][b], t[2][b], o);                   // U[a][b] = sum_u' G[a][u'] t[u'][b]
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) d0[(long long)(aa * 4 + b) * xi_stride] = o[aa];
+            }
+        }
+}

@@ -62,6 +62,91 @@ __global__ void __launch_bounds__(256) wino_input_kernel(const WinoXformArgs a)
     }
 }
 
+// ---- F(2x2,3x3): 4x4 tiles, points {0, 1, -1, inf} -------------------------------------------------------------------
+// B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]   A^T = [[1,1,1,0],[0,1,-1,-1]]
+__device__ __forceinline__ void bt4(const float d[4], float o[4])
+{
+    o[0] = d[0] - d[2]; o[1] = d[1] + d[2]; o[2] = d[2] - d[1]; o[3] = d[1] - d[3];
+}
+
+__global__ void __launch_bounds__(256) wino3_input_kernel(const WinoXformArgs a)
+{
+    const int tile = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y;
+    if (tile >= a.NT) return;
+    const int per = a.TH * a.TW;
+    const int n = tile / per, r = tile - n * per;
+    const int ty = r / a.TW, tx = r - ty * a.TW;
+    const int ih0 = 2 * ty - a.pad, iw0 = 2 * tx - a.pad;
+    const float* src = a.x + (long long)n * a.x_sb + (long long)c * a.x_sc;
+    float t[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float d[4];
+        const int ih = ih0 + i;
+        const bool rok = (ih >= 0) && (ih < a.H);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iw = iw0 + j;
+            d[j] = (rok && iw >= 0 && iw < a.W) ? src[(long long)ih * a.x_sh + iw] : 0.f;
+        }
+        bt4(d, t[i]);
+    }
+    float* dst = a.v + (long long)c * a.NTp + tile;
+    const long long xs = (long long)a.C * a.NTp;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        float col[4], o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) col[i] = t[i][b];
+        bt4(col, o);
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) dst[(long long)(aa * 4 + b) * xs] = o[aa];
+    }
+}
+
+__global__ void __launch_bounds__(256) wino3_output_kernel(const WinoOutArgs a)
+{
+    const int tile = blockIdx.x * 256 + threadIdx.x;
+    const int co = blockIdx.y;
+    if (tile >= a.NT) return;
+    const int per = a.TH * a.TW;
+    const int n = tile / per, r = tile - n * per;
+    const int ty = r / a.TW, tx = r - ty * a.TW;
+    const float* src = a.m + (long long)co * a.NTp + tile;
+    const long long xs = (long long)a.Cout * a.NTp;
+    float u[2][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        float m[4];
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) m[aa] = src[(long long)(aa * 4 + b) * xs];
+        u[0][b] = m[0] + m[1] + m[2];
+        u[1][b] = m[1] - m[2] - m[3];
+    }
+    const float bias = a.bias ? a.bias[co] : 0.f;
+    float* yn = a.y + (long long)n * a.y_sb;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float ov[2] = {u[i][0] + u[i][1] + u[i][2] + bias, u[i][1] - u[i][2] - u[i][3] + bias};
+        const int oh = 2 * ty + i;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ow = 2 * tx + j;
+            if (oh >= a.OH || ow >= a.OW) continue;
+            long long off;
+            if (a.shuffle) {
+                const int yh = 2 * oh + ((co >> 1) & 1), yw = 2 * ow + (co & 1);
+                if (yh >= a.YH || yw >= a.YW) continue;
+                off = (long long)(co >> 2) * a.y_sc + (long long)yh * a.y_sh + yw;
+            } else {
+                off = (long long)co * a.y_sc + (long long)oh * a.y_sh + ow;
+            }
+            if (a.accumulate) yn[off] += ov[j]; else yn[off] = ov[j];
+        }
+    }
+}
+
 // ---- weight-gradient operands --------------------------------------------------------------------------------------
 // dU[xi][co][ci] = sum_tile dM[xi][co][tile] * V[xi][ci][tile]: the tile index is the contraction dimension, so both
 // operands are stored tile-major ([xi][tile][channel]) -- the K-major layout the batched GEMM streams.  A workgroup
@@ -348,9 +433,10 @@ int mcvc_wino_output_launch(const WinoOutArgs& a, hipStream_t s)
 int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
 {
     if ((a.K % kGK) != 0 || (a.M % 128) != 0 || (a.lda & 3) || (a.ldb & 3) || a.ldb < 64) return MCVC_ERR_INVALID;
-    dim3 grid((unsigned)cdiv_i(a.N, 64), (unsigned)(a.M / 128), 36);
+    const int nxi = a.nxi > 0 ? a.nxi : 36;
+    dim3 grid((unsigned)cdiv_i(a.N, 64), (unsigned)(a.M / 128), (unsigned)nxi);
     const size_t lds = (size_t)kGStages * kGStage * sizeof(float);
-    TraceScope ts(K_WINO_GEMM, s, 2.0 * 36.0 * a.M * a.N * a.K, 4.0 * 36.0 * ((double)a.K * a.M + (double)a.K * a.N + (double)a.M * a.N));
+    TraceScope ts(K_WINO_GEMM, s, 2.0 * nxi * a.M * a.N * a.K, 4.0 * nxi * ((double)a.K * a.M + (double)a.K * a.N + (double)a.M * a.N));
     hipLaunchKernelGGL(wino_gemm_kernel, grid, dim3(256), lds, s, a);
     return (int)hipGetLastError();
 }
@@ -376,5 +462,21 @@ int mcvc_wino_dw_launch(const float* du, float* dw, int Cout, int Cin, hipStream
     dim3 grid((unsigned)cdiv_i(Cin, 256), (unsigned)Cout);
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (36.0 + 50.0) * Cout * Cin);
     hipLaunchKernelGGL(wino_dw_kernel, grid, dim3(256), 0, s, du, dw, Cout, Cin);
+    return (int)hipGetLastError();
+}
+
+int mcvc_wino3_input_launch(const WinoXformArgs& a, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv_i(a.NT, 256), (unsigned)a.C);
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 16.0 * a.C * a.NT));
+    hipLaunchKernelGGL(wino3_input_kernel, grid, dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_wino3_output_launch(const WinoOutArgs& a, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv_i(a.NT, 256), (unsigned)a.Cout);
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (16.0 * a.Cout * a.NT + 4.0 * a.Cout * a.NT));
+    hipLaunchKernelGGL(wino3_output_kernel, grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }

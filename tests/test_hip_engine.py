@@ -62,7 +62,11 @@ def _run_against_golden(golden_dir, tag, n_it):
                 if pn in skip:
                     continue
                 mine = float(p.detach().double().norm())
-                assert abs(mine - rn) <= 1e-3 * max(rn, 1e-3), (it, name, pn)
+                # single-element parameters (the discriminators' 1-channel output bias): their gradient is a sum of
+                # opposite-signed real / fake terms, so rounding is amplified by cancellation and then by Adam's
+                # normalisation; observed run-to-run spread 2e-3 of a value of 5e-3 (one lr step would be 2e-2 of it)
+                tol = 1e-2 if p.numel() == 1 else 1e-3
+                assert abs(mine - rn) <= tol * max(rn, 1e-3), (it, name, pn)
     return eng, js
 
 
