@@ -103,6 +103,7 @@ struct ConvSpec {
     int wino; long long off_wf, off_wd, wf_xi, wd_xi;
     // 5x5 stride-2 convs (downSample1/2): their merged 3x3 data-gradient as Winograd F(2x2,3x3): U[16][co (+1)][mg_ld]
     int wino3; long long off_w3, w3_xi;
+    long long off_w3f, w3f_xi;     // forward twin over the four input phases: U[16][4*Cin (+1)][cout_pk]
     long long off_tk;          // KH == 1 convs: transposed + flipped [Cin][cout_tot*KW] copy for the fused small-batch trunk dgrad
     int ncls;
     DgradClass cls[4];
@@ -171,7 +172,11 @@ static void spec_finalize(ConvSpec& c, long long& cur)
     }
     c.wino3 = (c.merged && c.KH == 5 && c.KW == 5 && c.ph == 2 && c.pw == 2 && (4 * c.Cin) % 128 == 0 && c.cout_tot % 16 == 0) ? 1 : 0;
     c.off_w3 = -1; c.w3_xi = 0;
-    if (c.wino3) { c.w3_xi = (long long)(c.dg_rows_co + 1) * c.mg_ld; c.off_w3 = cur; cur += 16 * c.w3_xi; cur = (cur + 3) & ~3LL; }
+    c.off_w3f = -1; c.w3f_xi = 0;
+    if (c.wino3) {
+        c.w3_xi = (long long)(c.dg_rows_co + 1) * c.mg_ld; c.off_w3 = cur; cur += 16 * c.w3_xi; cur = (cur + 3) & ~3LL;
+        c.w3f_xi = (long long)(4 * c.Cin + 1) * c.cout_pk; c.off_w3f = cur; cur += 16 * c.w3f_xi; cur = (cur + 3) & ~3LL;
+    }
     c.off_tk = -1;
     if (c.KH == 1 && st == 1) { c.off_tk = cur; cur += (long long)c.Cin * c.cout_tot * c.KW; cur = (cur + 3) & ~3LL; }
 }
@@ -272,6 +277,34 @@ static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, i
                      int shuffle, int allow_split, int* nsplit)
 {
     if (conv_wino(ex, c, packed, 0, NB, H, W, x, y, shuffle, 0)) { if (nsplit) *nsplit = 1; return; }
+    if (c.wino3 && wino_enabled() && ex.wv && !shuffle && (H & 1) == 0 && (W & 1) == 0 && (c.cout_tot % 128) == 0) {
+        // stride-2 5x5 forward = 3x3 stride-1 conv over the four input phases: Winograd F(2x2,3x3), K = 4*Cin
+        static const int en = [] { const char* e = getenv("MCVC_WINO3_FWD"); return e ? atoi(e) : 1; }();
+        const int OH = H / 2, OW = W / 2, K = 4 * c.Cin, M = c.cout_tot;
+        const int TH = (OH + 1) / 2, TW = (OW + 1) / 2;
+        const long long NT = (long long)NB * TH * TW, NTp = (NT + 31) & ~31LL;
+        if (en && NT <= 16384 && NTp >= 64 && 16LL * (K > M ? K : M) * NTp <= ex.wino_cap) {
+            if (nsplit) *nsplit = 1;
+            if (ex.dry) return;
+            WinoXformArgs xi{};
+            xi.x = x.p; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv;
+            xi.N = NB; xi.C = K; xi.H = OH; xi.W = OW; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 1;
+            ex.fail(mcvc_wino3_input_phase_launch(xi, H, W, ex.s));
+            WinoGemmArgs ga{};
+            ga.a = packed + c.off_w3f; ga.a_xi = c.w3f_xi; ga.lda = c.cout_pk;
+            ga.b = ex.wv; ga.b_xi = (long long)K * NTp; ga.ldb = (int)NTp;
+            ga.c = ex.wm; ga.c_xi = (long long)M * NTp; ga.ldc = (int)NTp;
+            ga.M = M; ga.N = (int)NTp; ga.K = K; ga.nxi = 16;
+            ex.fail(mcvc_wino_gemm_launch(ga, ex.s));
+            WinoOutArgs oa{};
+            oa.m = ex.wm; oa.bias = packed + c.off_bias;
+            oa.y = y.p; oa.y_sb = y.sb; oa.y_sc = y.sc; oa.y_sh = y.sh;
+            oa.N = NB; oa.Cout = M; oa.OH = OH; oa.OW = OW; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
+            oa.shuffle = 0; oa.YH = OH; oa.YW = OW; oa.accumulate = 0;
+            ex.fail(mcvc_wino3_output_launch(oa, ex.s));
+            return;
+        }
+    }
     ConvProblem p{c.Cin, H, W, c.cout_tot, conv_out(H, c.KH, c.stride, c.ph), conv_out(W, c.KW, c.stride, c.pw),
                   c.KH, c.KW, c.stride, c.ph, c.pw};
     ConvIO io{};
@@ -482,7 +515,10 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             PackJob w3{}; w3.kind = PACK_WINO3_D; w3.param = c.wi[br]; w3.dst = c.off_w3; w3.Cout = c.Cout; w3.Cin = c.Cin; w3.ld = c.mg_ld;
             w3.xi_stride = c.w3_xi; w3.co_off = br * c.Cout;
             add_job(t, w3, cdiv_i(c.Cin, 256), c.Cout);
-            t.bytes += 4.0 * (25.0 + 64.0) * c.Cout * c.Cin;
+            PackJob w3f{}; w3f.kind = PACK_WINO3_F; w3f.param = c.wi[br]; w3f.dst = c.off_w3f; w3f.Cout = c.Cout; w3f.Cin = c.Cin; w3f.ld = c.cout_pk;
+            w3f.xi_stride = c.w3f_xi; w3f.co_off = br * c.Cout;
+            add_job(t, w3f, cdiv_i(c.Cout, 256), c.Cin);
+            t.bytes += 4.0 * 2.0 * (25.0 + 64.0) * c.Cout * c.Cin;
         }
         if (c.wino) {
             PackJob wf{}; wf.kind = PACK_WINO_F; wf.param = c.wi[br]; wf.dst = c.off_wf; wf.Cout = c.Cout; wf.Cin = c.Cin; wf.ld = c.cout_pk;

@@ -129,6 +129,7 @@ __global__ void __launch_bounds__(256) pack_net_kernel(const PackJob* __restrict
     case PACK_WINO_F: wino_weight_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, 0, bx, by); break;
     case PACK_WINO_D: wino_weight_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, 1, bx, by); break;
     case PACK_WINO3_D: wino3_weight_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, bx, by); break;
+    case PACK_WINO3_F: wino3_weight_fwd_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, bx, by); break;
     default: { const int i = rel * 256 + threadIdx.x; if (i < j.Cout) dst[i] = w[i]; } break;     // PACK_COPY
     }
 }

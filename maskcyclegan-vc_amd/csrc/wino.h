@@ -26,6 +26,9 @@ int mcvc_wino_input_launch(const WinoXformArgs& a, hipStream_t s);
 // F(2x2,3x3) variants (4x4 tiles, 16 points, padding 1): the merged data-gradient of the stride-2 5x5 convs is a 3x3 conv
 int mcvc_wino3_input_launch(const WinoXformArgs& a, hipStream_t s);
 int mcvc_wino3_output_launch(const WinoOutArgs& a, hipStream_t s);
+// forward of a stride-2 5x5 conv as a 3x3 stride-1 conv over the 4 input phases: channel k = 4*ci + 2*p + q is the plane
+// x[ci][2i+p][2j+q]; a.C = 4*Cin, a.H x a.W = the phase-plane size (= conv output size), a.x_* address the ORIGINAL image
+int mcvc_wino3_input_phase_launch(const WinoXformArgs& a, int XH, int XW, hipStream_t s);
 // weight-gradient operands, tile-major (the tile index is the contraction dimension there): Vt[36][NTp][C] from x, and
 // dMt[36][NTp][C] = A dY A^T from the 2x2 output-gradient tiles; rows of tiles >= NT are written as zeros
 int mcvc_wino_input_t_launch(const WinoXformArgs& a, hipStream_t s);
@@ -126,6 +129,43 @@ static __device__ __forceinline__ void wino3_weight_tile(const float* w, float* 
             for (int b = 0; b < 4; ++b) {
                 float o[4];
                 g3(t[0][b], t[1][b], t[2][b], o);                   // U[a][b] = sum_u' G[a][u'] t[u'][b]
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) d0[(long long)(aa * 4 + b) * xi_stride] = o[aa];
+            }
+        }
+}
+
+// Forward twin: y[oh][ow] = sum w[kh][kw] x[2oh+kh-2][2ow+kw-2] = 3x3 stride-1 pad-1 correlation over the phase planes
+// X[4ci+2p+q][i][j] = x[ci][2i+p][2j+q] with taps g'[u'][v'] = w[co][ci][2u'+p][2v'+q] (absent when the index exceeds 4).
+// U[xi][k = 4ci+2p+q][col = co_off + co].  One thread per (co, ci), co fastest.
+static __device__ __forceinline__ void wino3_weight_fwd_tile(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int bx, int by)
+{
+    const int co = bx * 256 + threadIdx.x, ci = by;
+    if (co >= Cout || ci >= Cin) return;
+    const float* g = w + ((long long)co * Cin + ci) * 25;
+    float gg[5][5];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) gg[k / 5][k % 5] = g[k];
+    auto g3 = [](float v0, float v1, float v2, float o[4]) {
+        o[0] = v0; o[1] = 0.5f * (v0 + v1 + v2); o[2] = 0.5f * (v0 - v1 + v2); o[3] = v2;
+    };
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float t[3][4];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int kh = 2 * u + p;
+                float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+                if (kh <= 4) { r0 = gg[kh][q]; r1 = gg[kh][2 + q]; r2 = q ? 0.f : gg[kh][4]; }
+                g3(r0, r1, r2, t[u]);
+            }
+            float* d0 = dst + (long long)(4 * ci + 2 * p + q) * ld + co_off + co;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                float o[4];
+                g3(t[0][b], t[1][b], t[2][b], o);
 #pragma unroll
                 for (int aa = 0; aa < 4; ++aa) d0[(long long)(aa * 4 + b) * xi_stride] = o[aa];
             }

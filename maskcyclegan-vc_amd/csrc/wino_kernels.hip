@@ -105,6 +105,44 @@ __global__ void __launch_bounds__(256) wino3_input_kernel(const WinoXformArgs a)
     }
 }
 
+// phase-plane variant: channel k = 4ci + 2p + q reads x[ci][2i+p][2j+q] of an XH x XW image
+__global__ void __launch_bounds__(256) wino3_input_phase_kernel(const WinoXformArgs a, int XH, int XW)
+{
+    const int tile = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (tile >= a.NT) return;
+    const int ci = k >> 2, p = (k >> 1) & 1, q = k & 1;
+    const int per = a.TH * a.TW;
+    const int n = tile / per, r = tile - n * per;
+    const int ty = r / a.TW, tx = r - ty * a.TW;
+    const int i0 = 2 * ty - 1, j0 = 2 * tx - 1;                 // phase-plane coordinates (padding 1)
+    const float* src = a.x + (long long)n * a.x_sb + (long long)ci * a.x_sc;
+    float t[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float d[4];
+        const int ih = 2 * (i0 + i) + p;
+        const bool rok = (i0 + i >= 0) && (ih < XH);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iw = 2 * (j0 + j) + q;
+            d[j] = (rok && j0 + j >= 0 && iw < XW) ? src[(long long)ih * a.x_sh + iw] : 0.f;
+        }
+        bt4(d, t[i]);
+    }
+    float* dst = a.v + (long long)k * a.NTp + tile;
+    const long long xs = (long long)a.C * a.NTp;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        float col[4], o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) col[i] = t[i][b];
+        bt4(col, o);
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) dst[(long long)(aa * 4 + b) * xs] = o[aa];
+    }
+}
+
 __global__ void __launch_bounds__(256) wino3_output_kernel(const WinoOutArgs a)
 {
     const int tile = blockIdx.x * 256 + threadIdx.x;
@@ -478,5 +516,13 @@ int mcvc_wino3_output_launch(const WinoOutArgs& a, hipStream_t s)
     dim3 grid((unsigned)cdiv_i(a.NT, 256), (unsigned)a.Cout);
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (16.0 * a.Cout * a.NT + 4.0 * a.Cout * a.NT));
     hipLaunchKernelGGL(wino3_output_kernel, grid, dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_wino3_input_phase_launch(const WinoXformArgs& a, int XH, int XW, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv_i(a.NT, 256), (unsigned)a.C);
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * (a.C / 4) * XH * XW + 16.0 * a.C * a.NT));
+    hipLaunchKernelGGL(wino3_input_phase_kernel, grid, dim3(256), 0, s, a, XH, XW);
     return (int)hipGetLastError();
 }
