@@ -434,6 +434,33 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
             done = true;
         }
     }
+    if (!done && c.wino3 && wino_enabled() && ex.wu && (H & 1) == 0 && (W & 1) == 0 && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]])) {
+        // stride-2 5x5 weight gradient in the phase formulation (see conv_fwd): dU[xi][co][4ci+2p+q] over the tiles, both
+        // branches (value | gate) in one product, then the 3x3 blocks are scattered back into the two 5x5 gradients
+        static const int en = [] { const char* e = getenv("MCVC_WINO3_WGRAD"); return e ? atoi(e) : 1; }();
+        const int K4 = 4 * c.Cin, M = c.cout_tot;
+        const int TH = (OH + 1) / 2, TW = (OW + 1) / 2;
+        const long long NT = (long long)NB * TH * TW, NTp = (NT + 31) & ~31LL;
+        if (en && NT <= 16384 && (M % 128) == 0 && (K4 % 64) == 0 && 16LL * NTp * M <= ex.wino_cap && 16LL * NTp * K4 <= ex.wino_cap &&
+            16LL * M * K4 <= ex.wu_cap) {
+            WinoXformArgs xi{};
+            xi.x = x.p; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv2;
+            xi.N = NB; xi.C = K4; xi.H = OH; xi.W = OW; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 1;
+            ex.fail(mcvc_wino3_input_phase_t_launch(xi, H, W, ws));
+            WinoXformArgs di{};
+            di.x = dy.p; di.x_sb = dy.sb; di.x_sc = dy.sc; di.x_sh = dy.sh; di.v = ex.wm2;
+            di.N = NB; di.C = M; di.H = OH; di.W = OW; di.TH = TH; di.TW = TW; di.NT = (int)NT; di.NTp = (int)NTp; di.pad = 0;
+            ex.fail(mcvc_wino3_dy_t_launch(di, ws));
+            WinoGemmArgs ga{};
+            ga.a = ex.wm2; ga.a_xi = NTp * M; ga.lda = M;
+            ga.b = ex.wv2; ga.b_xi = NTp * K4; ga.ldb = K4;
+            ga.c = ex.wu; ga.c_xi = (long long)M * K4; ga.ldc = K4;
+            ga.M = M; ga.N = K4; ga.K = (int)NTp; ga.nxi = 16;
+            ex.fail(mcvc_wino_gemm_launch(ga, ws));
+            ex.fail(mcvc_wino3_dw_launch(ex.wu, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.nbr, c.Cin, ws));
+            done = true;
+        }
+    }
     for (int br = 0; br < c.nbr && !done; ++br) {
         float* dw = grads[c.wi[br]];
         if (!dw) continue;

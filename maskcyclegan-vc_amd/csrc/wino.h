@@ -29,6 +29,11 @@ int mcvc_wino3_output_launch(const WinoOutArgs& a, hipStream_t s);
 // forward of a stride-2 5x5 conv as a 3x3 stride-1 conv over the 4 input phases: channel k = 4*ci + 2*p + q is the plane
 // x[ci][2i+p][2j+q]; a.C = 4*Cin, a.H x a.W = the phase-plane size (= conv output size), a.x_* address the ORIGINAL image
 int mcvc_wino3_input_phase_launch(const WinoXformArgs& a, int XH, int XW, hipStream_t s);
+// weight gradient of the stride-2 5x5 convs in the same phase formulation: tile-major operands, then
+// dw[co][ci][2u'+p][2v'+q] += (G3^T dU G3)[u'][v'] for dU[16][Cout_tot][4*Cin]; output channels >= Cout go to dw1 (gate branch)
+int mcvc_wino3_input_phase_t_launch(const WinoXformArgs& a, int XH, int XW, hipStream_t s);
+int mcvc_wino3_dy_t_launch(const WinoXformArgs& a, hipStream_t s);
+int mcvc_wino3_dw_launch(const float* du, float* dw0, float* dw1, int Cout, int nbr, int Cin, hipStream_t s);
 // weight-gradient operands, tile-major (the tile index is the contraction dimension there): Vt[36][NTp][C] from x, and
 // dMt[36][NTp][C] = A dY A^T from the 2x2 output-gradient tiles; rows of tiles >= NT are written as zeros
 int mcvc_wino_input_t_launch(const WinoXformArgs& a, hipStream_t s);

@@ -143,6 +143,129 @@ __global__ void __launch_bounds__(256) wino3_input_phase_kernel(const WinoXformA
     }
 }
 
+// tile-major twins for the weight gradient (16 tiles x 16 channels per workgroup, channel fastest)
+__global__ void __launch_bounds__(256) wino3_input_phase_t_kernel(const WinoXformArgs a, int XH, int XW)
+{
+    const int k = blockIdx.y * 16 + (threadIdx.x & 15);
+    const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (tile >= a.NTp || k >= a.C) return;
+    float* dst = a.v + (long long)tile * a.C + k;
+    const long long xs = (long long)a.NTp * a.C;
+    if (tile >= a.NT) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dst[q * xs] = 0.f;
+        return;
+    }
+    const int ci = k >> 2, p = (k >> 1) & 1, q = k & 1;
+    const int per = a.TH * a.TW;
+    const int n = tile / per, r = tile - n * per;
+    const int ty = r / a.TW, tx = r - ty * a.TW;
+    const int i0 = 2 * ty - 1, j0 = 2 * tx - 1;
+    const float* src = a.x + (long long)n * a.x_sb + (long long)ci * a.x_sc;
+    float t[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float d[4];
+        const int ih = 2 * (i0 + i) + p;
+        const bool rok = (i0 + i >= 0) && (ih < XH);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iw = 2 * (j0 + j) + q;
+            d[j] = (rok && j0 + j >= 0 && iw < XW) ? src[(long long)ih * a.x_sh + iw] : 0.f;
+        }
+        bt4(d, t[i]);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        float col[4], o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) col[i] = t[i][b];
+        bt4(col, o);
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) dst[(long long)(aa * 4 + b) * xs] = o[aa];
+    }
+}
+
+// A3 (4x2) = [[1,0],[1,1],[1,-1],[0,-1]]:  dM = A3 dy A3^T
+__device__ __forceinline__ void a42(float d0, float d1, float o[4]) { o[0] = d0; o[1] = d0 + d1; o[2] = d0 - d1; o[3] = -d1; }
+
+__global__ void __launch_bounds__(256) wino3_dy_t_kernel(const WinoXformArgs a)
+{
+    const int c = blockIdx.y * 16 + (threadIdx.x & 15);
+    const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (tile >= a.NTp || c >= a.C) return;
+    float* dst = a.v + (long long)tile * a.C + c;
+    const long long xs = (long long)a.NTp * a.C;
+    if (tile >= a.NT) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dst[q * xs] = 0.f;
+        return;
+    }
+    const int per = a.TH * a.TW;
+    const int n = tile / per, r = tile - n * per;
+    const int ty = r / a.TW, tx = r - ty * a.TW;
+    const float* src = a.x + (long long)n * a.x_sb + (long long)c * a.x_sc;
+    float dy[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oh = 2 * ty + i, ow = 2 * tx + j;
+            dy[i][j] = (oh < a.H && ow < a.W) ? src[(long long)oh * a.x_sh + ow] : 0.f;
+        }
+    float t0[4], t1[4];
+    a42(dy[0][0], dy[1][0], t0);
+    a42(dy[0][1], dy[1][1], t1);
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) {
+        float o[4];
+        a42(t0[aa], t1[aa], o);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dst[(long long)(aa * 4 + b) * xs] = o[b];
+    }
+}
+
+// dg' = G3^T dU G3 (3x3 per (co, k = 4ci+2p+q)), scattered into the OIHW gradient: dw[co][ci][2u'+p][2v'+q] += dg'[u'][v']
+__global__ void __launch_bounds__(256) wino3_dw_kernel(const float* __restrict__ du, float* __restrict__ dw0, float* __restrict__ dw1,
+                                                       int Cout, int nbr, int Cin)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y;
+    const int K = 4 * Cin;
+    if (k >= K) return;
+    const long long xs = (long long)Cout * nbr * K;
+    const float* src = du + (long long)co * K + k;
+    auto gt3 = [](const float v[4], float o[3]) {
+        o[0] = v[0] + 0.5f * (v[1] + v[2]); o[1] = 0.5f * (v[1] - v[2]); o[2] = 0.5f * (v[1] + v[2]) + v[3];
+    };
+    float t[3][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        float col[4], o[3];
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) col[aa] = src[(long long)(aa * 4 + b) * xs];
+        gt3(col, o);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) t[u][b] = o[u];
+    }
+    const int ci = k >> 2, p = (k >> 1) & 1, q = k & 1;
+    float* dw = (co < Cout) ? dw0 : dw1;
+    const int col = (co < Cout) ? co : co - Cout;
+    if (!dw) return;
+    float* dst = dw + ((long long)col * Cin + ci) * 25;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        float o[3];
+        gt3(t[u], o);
+        const int kh = 2 * u + p;
+        if (kh > 4) continue;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int kw = 2 * v + q;
+            if (kw <= 4) dst[kh * 5 + kw] += o[v];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) wino3_output_kernel(const WinoOutArgs a)
 {
     const int tile = blockIdx.x * 256 + threadIdx.x;
@@ -524,5 +647,29 @@ int mcvc_wino3_input_phase_launch(const WinoXformArgs& a, int XH, int XW, hipStr
     dim3 grid((unsigned)cdiv_i(a.NT, 256), (unsigned)a.C);
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * (a.C / 4) * XH * XW + 16.0 * a.C * a.NT));
     hipLaunchKernelGGL(wino3_input_phase_kernel, grid, dim3(256), 0, s, a, XH, XW);
+    return (int)hipGetLastError();
+}
+
+int mcvc_wino3_input_phase_t_launch(const WinoXformArgs& a, int XH, int XW, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * (a.C / 4) * XH * XW + 16.0 * a.C * a.NTp));
+    hipLaunchKernelGGL(wino3_input_phase_t_kernel, grid, dim3(256), 0, s, a, XH, XW);
+    return (int)hipGetLastError();
+}
+
+int mcvc_wino3_dy_t_launch(const WinoXformArgs& a, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 16.0 * a.C * a.NTp));
+    hipLaunchKernelGGL(wino3_dy_t_kernel, grid, dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_wino3_dw_launch(const float* du, float* dw0, float* dw1, int Cout, int nbr, int Cin, hipStream_t s)
+{
+    dim3 grid((unsigned)cdiv_i(4 * Cin, 256), (unsigned)(Cout * nbr));
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (16.0 * 4.0 + 2.0 * 25.0) * Cout * nbr * Cin);
+    hipLaunchKernelGGL(wino3_dw_kernel, grid, dim3(256), 0, s, du, dw0, dw1, Cout, nbr, Cin);
     return (int)hipGetLastError();
 }
