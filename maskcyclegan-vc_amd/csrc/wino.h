@@ -95,6 +95,7 @@ struct WinoGemmArgs {
     float* c; long long c_xi; int ldc;           // M: [36][M][ldc]
     int M, N, K;                                 // N = valid columns (multiple of 32)
     int nxi;                                     // transform points: 36 (F(2x2,5x5)) or 16 (F(2x2,3x3)); 0 = 36
+    int nt, mt;                                  // (filled by the launcher) tiles along n and m
 };
 int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s);
 
