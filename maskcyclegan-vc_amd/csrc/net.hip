@@ -511,10 +511,12 @@ static void add_job(PackTable& t, PackJob j, int gx, int gy)
 }
 
 // trunk_only: the layer runs on the fused trunk kernels (OIHW forward); only the transposed data-gradient copy is needed
-static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = false)
+// wino_only: the layer runs on the Winograd kernels in every pass (forward, data-gradient); its direct K-major copies are skipped
+static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = false, bool wino_only = false)
 {
     const int K = c.Cin * c.KH * c.KW;
     for (int br = 0; br < c.nbr; ++br) {
+        const bool skip_direct = wino_only && (c.wino || c.wino3);
         if (trunk_only && c.off_tk >= 0) {
             PackJob q{}; q.kind = PACK_TRUNK_T; q.param = c.wi[br]; q.dst = c.off_tk; q.Cout = c.Cout; q.Cin = c.Cin; q.KW = c.KW;
             q.ld = c.cout_tot * c.KW; q.co_off = br * c.Cout;
@@ -523,7 +525,7 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             continue;
         }
         PackJob f{}; f.kind = PACK_FWD; f.param = c.wi[br]; f.dst = c.off_fwd; f.Cout = c.Cout; f.K = K; f.ld = c.cout_pk; f.co_off = br * c.Cout;
-        add_job(t, f, cdiv_i(K, 32), cdiv_i(c.Cout, 32));
+        if (!skip_direct) add_job(t, f, cdiv_i(K, 32), cdiv_i(c.Cout, 32));
         PackJob b{}; b.kind = PACK_COPY; b.param = c.bi[br]; b.dst = c.off_bias + br * c.Cout; b.Cout = c.Cout;
         add_job(t, b, cdiv_i(c.Cout, 256), 1);
         PackDgradArgs a{};
@@ -531,8 +533,10 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
         a.merged = c.merged; a.mg_kh = c.mg_kh; a.mg_kw = c.mg_kw;
         for (int k = 0; k < c.ncls; ++k) a.cls[k] = c.cls[k];
         PackJob d{}; d.kind = PACK_DGRAD; d.param = c.wi[br]; d.dst = c.off_dgrad; d.dg = (int)t.dga.size();
-        t.dga.push_back(a);
-        add_job(t, d, cdiv_i(c.Cin, 32), c.Cout);
+        if (!skip_direct) {
+            t.dga.push_back(a);
+            add_job(t, d, cdiv_i(c.Cin, 32), c.Cout);
+        }
         if (c.off_tk >= 0) {
             PackJob q{}; q.kind = PACK_TRUNK_T; q.param = c.wi[br]; q.dst = c.off_tk; q.Cout = c.Cout; q.Cin = c.Cin; q.KW = c.KW;
             q.ld = c.cout_tot * c.KW; q.co_off = br * c.Cout;
@@ -1302,14 +1306,21 @@ int mcvc_gen_pack_small_batch(const float* const* params, float* packed, int max
 {
     for (int b = 1; b <= max_batch; ++b)
         if (!mcvc_gen_trunk_fused(b, T)) return mcvc_gen_pack(params, packed, stream);
+    // every 5x5 layer of every such pass runs on the Winograd kernels (conv_wino / the wino3 branches take no fallback) when
+    // the frame count keeps all image sizes even, the tile counts are inside the kernels' range and nothing was switched
+    // off through the MCVC_WINO* knobs: then their direct K-major copies are not refreshed either
+    static const bool knobs_default = !getenv("MCVC_WINO") && !getenv("MCVC_WINO3") && !getenv("MCVC_WINO3_FWD") && !getenv("MCVC_WINO_GEMM");
+    const GenDims dm = gen_dims(max_batch, T);
+    const bool wino_only = knobs_default && (T % 4) == 0 && T >= 32 && (long long)max_batch * 20 * dm.W4 <= 16384;
     int err = 0;
-    const DevPackTable* t = dev_pack_table(2, [](PackTable& pt) {
+    auto build = [wino_only](PackTable& pt) {
         const GenNet& g = gen_net();
         const ConvSpec* full[] = {&g.conv1, &g.ds1, &g.ds2, &g.up1, &g.up2, &g.last};
-        for (const ConvSpec* c : full) add_spec_jobs(pt, *c);
+        for (const ConvSpec* c : full) add_spec_jobs(pt, *c, false, wino_only);
         add_spec_jobs(pt, g.c2d1d, true); add_spec_jobs(pt, g.c1d2d, true);
         for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i], true); add_spec_jobs(pt, g.res_out[i], true); }
-    }, &err);
+    };
+    const DevPackTable* t = dev_pack_table(wino_only ? 3 : 2, build, &err);
     if (!t) return err;
     return pack_net(t, params, packed, (hipStream_t)stream);
 }
