@@ -76,7 +76,7 @@ class TrainEngine:
             raise RuntimeError("TrainEngine needs the networks on a HIP device (no CPU path)")
         self.device = dev
         self.B, self.T = batch_size, n_frames
-        self.sched = schedule or StepSchedule(batch_size=batch_size)
+        self.sched = schedule or StepSchedule(batch_size=batch_size, n_samples=batch_size)   # (the reference divides by n_samples // batch_size)
         self.reducer = reducer or FlatGradReducer()
         self.betas, self.eps = betas, eps
         L = self.L = lib()
