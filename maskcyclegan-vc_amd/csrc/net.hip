@@ -637,39 +637,52 @@ static int trunk_pick_ksplit(int Cin, int KW, int M, int B, int W4, int must_spl
 
 // dX[ci][b][t] (+)= sum_{co,kw} W[co][ci][kw] dY[co][b][t + pw - kw]  through the transposed pack.  Large K (or an
 // accumulating destination) is split over workgroups that add atomically; a non-accumulating destination is zeroed first.
-static bool trunk_dgrad(Exec& ex, const ConvSpec& c, const float* packed, const float* dy, float* dx, int accumulate, int B, int W4)
+static bool trunk_dgrad(Exec& ex, const ConvSpec& c, const float* packed, const float* dy, float* dx, int accumulate, int B, int W4,
+                        int* nsplit = nullptr)
 {
     if (!trunk_enabled() || c.off_tk < 0) return false;
     int ks = 1;
     if (!accumulate && mcvc_trunk_applies(c.cout_tot, c.KW, c.Cin, B, W4, TRUNK_PLAIN, 1)) ks = 1;
     else ks = trunk_pick_ksplit(c.cout_tot, c.KW, c.Cin, B, W4, 0);
     if (ks < 1) return false;
+    if (!accumulate && ks > 1 && !nsplit) return false;             // slabs need a consumer that sums them
+    const long long tot = (long long)c.Cin * B * W4;
+    if (!accumulate && ks > 1) {
+        const long long need = (long long)(ks - 1) * tot;
+        if (need > ex.slab_need) ex.slab_need = need;
+        if (!ex.dry && need > ex.slab_cap) { ex.fail(MCVC_ERR_WORKSPACE); return true; }
+    }
+    if (nsplit) *nsplit = accumulate ? 1 : ks;
     if (ex.dry) return true;
-    int acc = accumulate;
-    if (!accumulate && ks > 1) { ex.fail(mcvc_fill_rows_launch(dx, nullptr, c.Cin, B * W4, ex.s)); acc = 1; }
     TrunkArgs a{};
     a.a0 = packed + c.off_tk;
     a.x = dy; a.x_sc = (long long)B * W4; a.x_sb = W4;
     a.Cin = c.cout_tot; a.KW = c.KW; a.K = c.cout_tot * c.KW; a.M = c.Cin; a.Mtot = c.Cin; a.B = B; a.T4 = W4; a.N = B * W4;
-    a.conv_out = dx; a.c_sc = (long long)B * W4; a.c_sb = W4; a.accumulate = acc; a.mode = TRUNK_PLAIN;
+    a.conv_out = dx; a.c_sc = (long long)B * W4; a.c_sb = W4; a.accumulate = accumulate; a.mode = TRUNK_PLAIN;
+    a.slabs = ex.slabs; a.slab_stride = tot;
     ex.fail(mcvc_trunk_launch(a, ks, ex.s));
     return true;
 }
 
-// K too large for one workgroup (conv2dto1d, K = 5120): conv_out = bias, then K-split workgroups accumulate atomically;
-// the InstanceNorm stays a separate launch.  Weights are read straight from the OIHW parameter.
-static bool trunk_fwd_ksplit(Exec& ex, const ConvSpec& c, const float* const* P, const float* x, float* conv_out, int B, int W4)
+// K too large for one workgroup (conv2dto1d, K = 5120): K-split workgroups write private slabs (split 0 adds the bias) that
+// the InstanceNorm launch sums -- no atomics, no zero-fill.  Weights are read straight from the OIHW parameter.
+static bool trunk_fwd_ksplit(Exec& ex, const ConvSpec& c, const float* const* P, const float* x, float* conv_out, int B, int W4, int* nsplit)
 {
     if (!trunk_enabled() || c.KH != 1 || c.nbr != 1) return false;
     const int ks = trunk_pick_ksplit(c.Cin, c.KW, c.Cout, B, W4, 1);
     if (ks < 1) return false;
+    const long long tot = (long long)c.Cout * B * W4;
+    const long long need = (long long)(ks - 1) * tot;
+    if (need > ex.slab_need) ex.slab_need = need;
+    if (!ex.dry && need > ex.slab_cap) { ex.fail(MCVC_ERR_WORKSPACE); return true; }
+    *nsplit = ks;
     if (ex.dry) return true;
-    ex.fail(mcvc_fill_rows_launch(conv_out, P[c.bi[0]], c.Cout, B * W4, ex.s));
     TrunkArgs a{};
-    a.a0 = P[c.wi[0]];
+    a.a0 = P[c.wi[0]]; a.bias0 = P[c.bi[0]];
     a.x = x; a.x_sc = (long long)B * W4; a.x_sb = W4;
     a.Cin = c.Cin; a.KW = c.KW; a.K = c.Cin * c.KW; a.M = c.Cout; a.Mtot = c.Cout; a.B = B; a.T4 = W4; a.N = B * W4;
-    a.conv_out = conv_out; a.c_sc = (long long)B * W4; a.c_sb = W4; a.accumulate = 1; a.mode = TRUNK_PLAIN;
+    a.conv_out = conv_out; a.c_sc = (long long)B * W4; a.c_sb = W4; a.accumulate = 0; a.mode = TRUNK_PLAIN;
+    a.slabs = ex.slabs; a.slab_stride = tot;
     ex.fail(mcvc_trunk_launch(a, ks, ex.s));
     return true;
 }
@@ -857,7 +870,7 @@ static void gen_forward_impl(Exec& ex, const float* const* P, const float* packe
     norm_fwd(ex, st + o.c3, 512LL * 20 * W4, 20LL * W4, (long long)B * 512 * 20 * W4, ns, normp(P, nullptr, 14, 15, 18, 19), st + o.s3,
              st + o.y3, W4, 20LL * BT4, (int)BT4, nullptr, B, 256, 20, W4, ACT_GLU);
     // ---- :254-255  1x1 5120->256 + IN ; image = [5120][B rows][W4]
-    if (trunk_fwd_ksplit(ex, g.c2d1d, P, st + o.y3, st + o.c4, B, W4)) ns = 1;
+    if (trunk_fwd_ksplit(ex, g.c2d1d, P, st + o.y3, st + o.c4, B, W4, &ns)) {}
     else conv_fwd(ex, g.c2d1d, packed, 1, B, W4, CView{st + o.y3, 0, BT4, W4}, View{st + o.c4, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
     norm_fwd(ex, st + o.c4, W4, BT4, 256 * BT4, ns, normp(P, nullptr, 22, 23), st + o.s4, st + o.y4, W4, BT4, W4, nullptr, B, 256, 1, W4, ACT_NONE);
     // ---- :258-263  six residual GLU blocks
@@ -972,7 +985,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         const float* hin = st + o.r[5].y;
         CView dyv{GB, 0, BT4, W4};
         conv_wgrad(ex, g.c1d2d, G, 1, B, W4, CView{hin, 0, BT4, W4}, dyv);
-        if (trunk_dgrad(ex, g.c1d2d, packed, GB, DH, 0, B, W4)) ns = 1;
+        if (trunk_dgrad(ex, g.c1d2d, packed, GB, DH, 0, B, W4, &ns)) {}
         else conv_dgrad(ex, g.c1d2d, packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
     }
     // ---- residual blocks (:258-263), last to first.  DH carries d(h) and is updated in place.

@@ -17,8 +17,8 @@
 //   * X (at most 512 x 32 activations, with zero halo) is staged once in LDS; the MFMA B operand is a shifted read.
 //   * Epilogue in LDS: bias, pre-norm store (backward needs it), per-(row, b) two-pass statistics, affine, GLU /
 //     residual, strided store (which also performs the reference's view(B,256,20,-1) when writing NCHW).
-//   * K = 5120 (conv2dto1d and the data-gradient of conv1dto2d) does not fit one workgroup's LDS: K-split workgroups
-//     accumulate atomically into a bias-/zero-initialised destination and the norm stays a separate launch.
+//   * K = 5120 (conv2dto1d and the data-gradient of conv1dto2d) does not fit one workgroup's LDS: K-split workgroups write
+//     private slabs (split 0 adds the bias) that the following norm launch sums -- no atomics, no zero-fill launch.
 // The same kernel with mode 0 is the data-gradient of these layers (weights transposed+flipped by pack_trunk_t).
 #include "mcvc_common.h"
 #include "trace.h"
@@ -199,12 +199,15 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const TrunkA
     // row -> output channel(s)
     auto row_cx = [&](int row) { return glu ? ((row < 8) ? (r0 + row) : (a.M + r0 + row - 8)) : (r0 + row); };
 
-    if (a.mode == TRUNK_PLAIN) {                    // data-gradient: store / accumulate, no bias, no norm
+    if (a.mode == TRUNK_PLAIN) {                    // data-gradient / K-split forward: store, accumulate, or private slab
+        const bool slab = (gridDim.y > 1) && !a.accumulate;
+        float* base = (slab && blockIdx.y > 0) ? (a.slabs + (long long)(blockIdx.y - 1) * a.slab_stride) : a.conv_out;
         for (int e = tid; e < 16 * a.N; e += kTrunkThreads) {
             const int row = e / a.N, nn = e - row * a.N;
             const int b = nn / a.T4, t = nn - b * a.T4;
-            float* dst = a.conv_out + (long long)row_cx(row) * a.c_sc + (long long)b * a.c_sb + t;
-            const float v = tile[row * 33 + nn];
+            float* dst = base + (long long)row_cx(row) * a.c_sc + (long long)b * a.c_sb + t;
+            float v = tile[row * 33 + nn];
+            if (a.bias0 && blockIdx.y == 0) v += a.bias0[r0 + row];
             if (a.accumulate) { if (gridDim.y > 1) unsafeAtomicAdd(dst, v); else *dst += v; }
             else *dst = v;
         }
@@ -315,7 +318,7 @@ static int trunk_launch_t(const TrunkArgs& a, dim3 grid, size_t lds, hipStream_t
 int mcvc_trunk_launch(const TrunkArgs& a, int ksplit, hipStream_t s)
 {
     if (!mcvc_trunk_applies(a.Cin, a.KW, a.M, a.B, a.T4, a.mode, ksplit)) return MCVC_ERR_INVALID;
-    if (ksplit > 1 && !(a.mode == TRUNK_PLAIN && a.accumulate)) return MCVC_ERR_INVALID;
+    if (ksplit > 1 && !(a.mode == TRUNK_PLAIN && (a.accumulate || a.slabs))) return MCVC_ERR_INVALID;
     const int rows = (a.mode == TRUNK_IN_GLU) ? 8 : 16;
     dim3 grid((unsigned)(a.M / rows), (unsigned)ksplit);
     const size_t lds = (size_t)mcvc_trunk_lds_floats(a.Cin, a.KW, a.B, a.T4, ksplit) * sizeof(float);
