@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- MaskCycleGAN-VC full G+D training step on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                  # N=1, 50 timed steps after 10 warm-up
+    python bench.py --batch-size 32                  # BASELINE configs[2]   (--batch-size 8: the per-GPU shape of configs[3])
+    python bench.py --mode infer --dtype bf16        # BASELINE configs[4]: generator_A2B, bs=16, 80x512
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -27,7 +29,20 @@ import torch.distributed as dist  # noqa: E402
 
 ALG_GFLOP_PER_SAMPLE_ITER = 504.1      # necessary conv MAC*2 work of one bs=1 iteration
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
+PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense (the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
+INFER_GFLOP_PER_SAMPLE_64 = 19.676     # generator forward, conv MAC*2, per sample of 64 frames
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def synthetic_batches(n_batches, B, T, rank, device, max_mask_len=25):
@@ -60,15 +75,21 @@ def build_nets(device):
     return nets
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of this kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
-    tools/pmc_traffic.py); None when no PMC summary for it is in profiles/ (the counters cannot be read from inside the bench)."""
+def pmc_traffic(kernel, B):
+    """(HBM bytes per launch, source) of this kernel family from the committed rocprofv3 PMC passes of THIS round's binary
+    (two separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE, summarised by tools/pmc_traffic.py into
+    profiles/r02_pmc_traffic_bs<B>.json together with the git revision they were taken at).  The counters cannot be read
+    from inside the bench, so this is a labelled constant, not a live measurement; (None, None) when there is no summary."""
+    name = "r02_pmc_traffic_bs%d.json" % B
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            fam = json.load(fh)["families"].get(kernel)
-        return None if fam is None else fam["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            js = json.load(fh)
+        fam = js["families"].get(kernel)
+        if fam is None:
+            return None, None
+        return fam["hbm_bytes_per_launch"], "profiles/%s@%s" % (name, js.get("git_rev", "?"))
     except (OSError, ValueError, KeyError):
-        return None
+        return None, None
 
 
 def trace_one_step(engine, batch):
@@ -115,10 +136,78 @@ def cpu_baseline(B, T, n_timed, first_losses, threads=0):
     parity = None
     if first_losses is not None:
         parity = {"g_loss_rel": abs(first_losses[0] - g0) / abs(g0), "d_loss_rel": abs(first_losses[1] - d0) / abs(d0)}
-    return {"value": n_timed / dt, "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": n_timed / dt, "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": cpu_model(),
             "sample": "%d timed full G+D iterations at bs=%d 80x%d after 1 warm-up (%.1f s); oracle/mcvc_oracle.StepOracle, "
                       "reference autograd semantics incl. its discarded work" % (n_timed, B, T, t_first),
             "host_cpus": os.cpu_count()}, parity
+
+
+def infer_main(args, rank, world, device):
+    """BASELINE configs[4]: generator_A2B inference (test.py path), bs=16, 80 mel x 512 frames, all-ones mask, weights = the seeded
+    default init cast to the compute dtype.  A step = one batched forward; value = mel-frames/s = 16*512 / latency, summed over ranks
+    (independent replicas: inference has no exchange step)."""
+    from mask_cyclegan_vc.model import Generator
+    dtype = args.dtype or "bf16"
+    B = args.batch_size if args.batch_size != 1 else 16
+    T = args.frames if args.frames != 64 else 512
+    torch.manual_seed(0)
+    gen = Generator().to(device)
+    g = torch.Generator().manual_seed(1234 + rank)
+    xs = [torch.randn(B, 80, T, generator=g).to(device) for _ in range(4)]
+    log("infer: %s, bs=%d, %d frames" % (dtype, B, T))
+    outs = None
+    for i in range(args.warmup):
+        outs = gen.infer(xs[i % len(xs)], dtype=dtype)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        outs = gen.infer(xs[i % len(xs)], dtype=dtype)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    finite = bool(torch.isfinite(outs).all())
+    if rank == 0:
+        ms = 1e3 * dt / args.steps
+        gflop = INFER_GFLOP_PER_SAMPLE_64 * (T / 64.0) * B
+        peak = PEAK_BF16_MFMA_TFLOPS if dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
+        ach = gflop / ms
+        res = {"metric": "generator_A2B inference mel-frames/s, bs=%d x %d frames" % (B, T), "value": world * B * T * args.steps / dt,
+               "unit": "mel-frames/s (= batch x frames / latency, summed over GPUs)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+               "config": {"workload": "generator_A2B forward (test.py path), bs=%d, 80 mel x %d frames, all-ones mask, %s, default-init "
+                                      "weights (seed 0)" % (B, T, dtype), "global_batch": world * B, "parallelism": "replicas%d" % world},
+               "roofline": {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                            "kernel": "whole generator forward (%.1f GFLOP algorithmic per batch)" % gflop},
+               "outputs_finite": finite}
+        if world == 1 and args.cpu_iters != 0:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import mcvc_oracle as orc
+            torch.set_num_threads(args.cpu_threads if args.cpu_threads > 0 else min(os.cpu_count() or 1, 32))
+            params = {k: v.detach().cpu() for k, v in gen.state_dict().items()}
+            nb = 2                                       # bounded sample: two samples of the batch (a full batch is ~16x that)
+            x = xs[0][:nb].cpu()
+            with torch.no_grad():
+                orc.generator_forward(params, x[:1], torch.ones_like(x[:1]))      # warm-up
+                t0 = time.perf_counter()
+                ref = orc.generator_forward(params, x, torch.ones_like(x))
+                cdt = time.perf_counter() - t0
+            got = gen.infer(xs[0], dtype=dtype)[:nb].float().cpu()
+            res["cpu_baseline"] = {"value": nb * T / cdt, "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "cpu_model": cpu_model(), "host_cpus": os.cpu_count(),
+                                   "sample": "oracle.generator_forward (fp32) on %d of the %d samples x %d frames (%.1f s)" % (nb, B, T, cdt)}
+            res["parity_vs_cpu_rel_l2"] = float((got.double() - ref.double()).norm() / ref.double().norm())
+            res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 _T0 = time.perf_counter()
@@ -131,11 +220,16 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", choices=("train", "infer"), default="train", help="train: full G+D iteration (BASELINE metric); "
+                    "infer: generator_A2B forward, bs=16 x 512 frames (BASELINE configs[4])")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default=None, help="infer mode arithmetic (default bf16); training is fp32")
+    ap.add_argument("--n-batches", type=int, default=64, help="pre-generated synthetic minibatches cycled through (SURVEY.md section 8d)")
+    ap.add_argument("--deterministic", action="store_true", help="bit-reproducible mode (no floating-point atomics)")
     ap.add_argument("--batch-size", type=int, default=1, help="per-GPU minibatch (BASELINE metric: 1)")
     ap.add_argument("--frames", type=int, default=64)
-    ap.add_argument("--cpu-iters", type=int, default=12, help="timed CPU-baseline iterations (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=-1, help="timed CPU-baseline iterations (0 = skip; default: about 10-30 s of CPU work)")
     ap.add_argument("--no-trace", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one stream: no lanes, no auxiliary weight-gradient stream (A/B comparison, per-kernel profiling)")
     ap.add_argument("--graphs", action="store_true", help="replay HIP graphs of the two phases (experimental; not faster on ROCm 7.2)")
@@ -153,7 +247,14 @@ def main():
     local_rank %= max(torch.cuda.device_count(), 1)      # (only differs on a box with fewer GPUs than ranks: gloo test runs)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if args.mode == "infer":
+        return infer_main(args, rank, world, device)
     B, T = args.batch_size, args.frames
+    if args.cpu_iters < 0:                 # bounded CPU sample: ~1 s per bs=1 iteration on 32 threads of the GPU box's host
+        args.cpu_iters = max(2, min(12, 12 // B))
+    if args.deterministic:
+        from mask_cyclegan_vc import _hip
+        _hip.lib().mcvc_set_deterministic(1)
 
     log("building nets")
     nets = build_nets(device)
@@ -166,7 +267,7 @@ def main():
     engine.use_graphs = args.graphs
     if args.graphs:
         engine.aux_wgrad = False            # lanes + auxiliary streams in one capture crash hipStreamEndCapture (ROCm 7.2)
-    batches = synthetic_batches(16, B, T, rank, device)
+    batches = synthetic_batches(args.n_batches, B, T, rank, device)
     log("engine ready; warm-up")
 
     first = None
@@ -221,7 +322,7 @@ def main():
         value = world * args.steps / dt
         sample_iters = world * B * args.steps / dt
         res = {
-            "metric": "train iters/s (full G+D step), 80x64 mel bs=1",
+            "metric": "train iters/s (full G+D step), 80x%d mel bs=%d" % (T, B),
             "value": value, "unit": "iters/s (per-GPU bs=%d iterations, summed over GPUs)" % B,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -230,15 +331,16 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "mel_frames_per_s": sample_iters * T,
             "step_mfma_fraction": sample_iters * ALG_GFLOP_PER_SAMPLE_ITER / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world),
-            "losses_finite": finite, "last_losses": final,
+            "losses_finite": finite, "last_losses": final, "n_batches": len(batches), "deterministic": bool(args.deterministic),
         }
         if rows:
             conv = [r for r in rows if r["gflop"] > 0]
             dom = max(conv, key=lambda r: r["ms"])
             total_ms = sum(r["ms"] for r in rows)
             ach = dom["gflop"] / dom["ms"]          # GFLOP/ms == TFLOP/s
+            traffic, traffic_src = pmc_traffic(dom["kernel"], B)
             res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(dom["kernel"]), "kernel": dom["kernel"],
+                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dom["kernel"],
                                "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                                "share_of_kernel_time": dom["ms"] / total_ms}
             res["kernel_time_ms_per_step"] = {r["kernel"]: round(r["ms"], 4) for r in rows}

@@ -8,7 +8,11 @@
  * Conventions
  *   - plain pointers and sizes; every pointer is a DEVICE pointer to contiguous fp32 unless noted;
  *   - `stream` is a hipStream_t passed as void* (0 = null stream); all calls are asynchronous w.r.t.
- *     the host, allocate nothing, keep no global state, and are re-entrant;
+ *     the host and allocate no device memory on the compute path.  Process-wide state the library DOES keep
+ *     (all behind mutexes): a pool of timing-less hipEvents for the lane <-> auxiliary-stream hand-offs, per-device
+ *     weight-pack job tables (one small hipMalloc each on first use, outside stream capture), the cached workspace
+ *     plans per (network, B, T), the deterministic-mode switch and the opt-in trace log.  Calls on different streams
+ *     may be issued from different host threads, EXCEPT while the trace is enabled (its log is not thread-safe);
  *   - return value 0 = success, otherwise a hipError_t value or MCVC_ERR_* (>= 1000); the Python
  *     wrapper raises RuntimeError;
  *   - parameter tables are arrays of device pointers in the reference's `named_parameters()` order
@@ -32,6 +36,13 @@ extern "C" {
 #define MCVC_N_MEL 80
 
 int mcvc_version(void);
+
+/* Deterministic mode (default: env MCVC_DETERMINISTIC, else off).  When on, every reduction that would otherwise use
+ * floating-point atomics (K-split accumulate of a conv / trunk data-gradient, the tiny-dW weight gradients) takes a
+ * fixed-order path (private slabs summed by the consumer), so a step is bit-reproducible run to run like the
+ * reference's CPU path.  Workspaces are always sized for both modes.  Returns the previous setting.             */
+int mcvc_set_deterministic(int on);
+int mcvc_get_deterministic(void);
 
 /* ---- sizes (floats) -------------------------------------------------------------------------- */
 long long mcvc_gen_packed_floats(void);
@@ -98,6 +109,18 @@ int mcvc_lsgan_loss(const float* d, long long n, float target, float weight, flo
 int mcvc_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                    float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
 int mcvc_axpy(float* y, const float* x, float alpha, long long n, void* stream);
+
+/* ---- on-device input pipeline: replaces VCDataset.__getitem__ + DataLoader collate + 4 H2D copies per iteration
+ *      (dataset/vc_dataset.py:19-77, mask_cyclegan_vc/train.py:82-96, 187-190) with one launch per minibatch.
+ *      bank_X: [80][frames_X] fp32, all utterances of speaker X side by side along the frame axis; offs_X: int32 [n_X+1]
+ *      first frame of each utterance (every utterance >= T frames).  Per sample and speaker: utterance ~ U{0..n-1},
+ *      crop lo ~ U{0..len-T}, mask size ~ U{0..max_mask_len-1}, start ~ U{0..T-size-1} -- the reference's distributions
+ *      (vc_dataset.py:33-70) from a counter-based SplitMix64 stream keyed by (seed, step, sample, speaker): restated
+ *      bit-exactly in oracle/sampler_oracle.py.  Outputs [B][80][T]; draws (nullable): int32 [B][2][4] =
+ *      (utterance, lo, size, start).                                                                        */
+int mcvc_draw_batch(const float* bank_A, const int* offs_A, int n_A, long long frames_A, const float* bank_B, const int* offs_B, int n_B,
+                    long long frames_B, int B, int T, int max_mask_len, unsigned long long seed, unsigned long long step,
+                    float* real_A, float* mask_A, float* real_B, float* mask_B, int* draws, void* stream);
 
 /* ---- single-op entry points (kernel parity tests; same kernels the network calls use) ---------- */
 /* y[N,Cout,OH,OW] = conv2d(x[N,Cin,H,W], w[Cout,Cin,KH,KW]) + bias ; stride 1 or 2.

@@ -54,8 +54,9 @@ class BaseArgParser(object):
             args.isTrain = self.isTrain
         run_dir = os.path.join(args.save_dir, args.name)
         os.makedirs(run_dir, exist_ok=True)
-        with open(os.path.join(run_dir, ("train" if args.isTrain else "test") + "_args.json"), "w") as fh:
-            json.dump(vars(args), fh, indent=4, sort_keys=True)
+        if int(os.environ.get("RANK", "0")) == 0:                # under torchrun only rank 0 writes the run's files
+            with open(os.path.join(run_dir, ("train" if args.isTrain else "test") + "_args.json"), "w") as fh:
+                json.dump(vars(args), fh, indent=4, sort_keys=True)
         if args.isTrain:
             args.ckpt_dir = os.path.join(run_dir, "ckpts")
             os.makedirs(args.ckpt_dir, exist_ok=True)

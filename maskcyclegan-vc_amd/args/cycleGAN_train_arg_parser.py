@@ -19,5 +19,7 @@ class CycleGANTrainArgParser(TrainArgParser):
         # (new) MI355X / data-parallel knobs -- additive, defaults keep the reference behaviour
         ("--allreduce_bucket_mb", dict(type=int, default=64, help="(new) RCCL gradient all-reduce bucket size in MiB.")),
         ("--max_iters", dict(type=int, default=0, help="(new) stop after this many iterations (0 = run all epochs).")),
+        ("--host_sampler", dict(action="store_true", help="(new) draw minibatches on the host with the reference's RNG-exact VCDataset + DataLoader "
+                                                          "instead of the on-device sampler (same distributions, no H2D copies).")),
     ]
     DEFAULT_OVERRIDES = dict(batch_size=1, num_epochs=50, decay_after=1e4, start_epoch=1, steps_per_print=100, num_frames=64)

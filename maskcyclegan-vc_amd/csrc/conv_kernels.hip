@@ -884,7 +884,8 @@ static int wgrad_knob_ksplit() { return wgrad_knob("MCVC_WGRAD_KSPLIT", 0); }
 
 struct WgradPlan { WgradArgs a; dim3 grid; int MS, KWT, nwaves; size_t lds; };
 
-static bool plan_wgrad(const ConvProblem& p, int NB, long long slab_cap_floats, WgradPlan* out)
+// force_slabs: never use the atomic tiny-dW path (deterministic mode)
+static bool plan_wgrad(const ConvProblem& p, int NB, long long slab_cap_floats, WgradPlan* out, bool force_slabs)
 {
     WgradPlan pl{};
     WgradArgs& a = pl.a;
@@ -930,7 +931,7 @@ static bool plan_wgrad(const ConvProblem& p, int NB, long long slab_cap_floats, 
     int want = (base >= 256) ? 1 : cdiv_i(256, base);
     // tiny dW (edge layers: a few thousand outputs over thousands of pixels): K-split workgroups add straight into dW with
     // coalesced atomics -- the slab round trip and the reduce launch would cost more than the layer
-    const bool tiny = a.dw_floats <= (long long)wgrad_knob("MCVC_WGRAD_ATOMIC_BELOW", 65536);
+    const bool tiny = !force_slabs && a.dw_floats <= (long long)wgrad_knob("MCVC_WGRAD_ATOMIC_BELOW", 65536);
     if (tiny) { if (want > 128) want = 128; }
     else {
         long long cap = a.slab_stride > 0 ? slab_cap_floats / a.slab_stride : 0;
@@ -999,9 +1000,15 @@ static bool smallk_applies(const ConvProblem& p, int NB);
 long long mcvc_wgrad_plan_slab_floats(const ConvProblem& p, int NB)
 {
     if (smallk_applies(p, NB)) return 0;
-    WgradPlan pl;
-    if (!plan_wgrad(p, NB, 1LL << 40, &pl)) return -1;
-    return (pl.a.ksplit > 1 && !pl.a.atomic) ? (long long)pl.a.ksplit * pl.a.slab_stride : 0;
+    // sized for the deterministic (slab-only) plan as well, so the mode can be switched without re-sizing workspaces
+    long long need = 0;
+    for (int det = 0; det < 2; ++det) {
+        WgradPlan pl;
+        if (!plan_wgrad(p, NB, 1LL << 40, &pl, det != 0)) return -1;
+        const long long n = (pl.a.ksplit > 1 && !pl.a.atomic) ? (long long)pl.a.ksplit * pl.a.slab_stride : 0;
+        if (n > need) need = n;
+    }
+    return need;
 }
 
 static bool smallk_applies(const ConvProblem& p, int NB)
@@ -1026,7 +1033,7 @@ int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw
         return (int)hipGetLastError();
     }
     WgradPlan pl;
-    if (!plan_wgrad(p, NB, slabs ? slab_cap_floats : 0, &pl)) return MCVC_ERR_INVALID;
+    if (!plan_wgrad(p, NB, slabs ? slab_cap_floats : 0, &pl, mcvc_deterministic() != 0)) return MCVC_ERR_INVALID;
     WgradArgs& a = pl.a;
     a.x = io.x; a.x_sb = io.x_sb; a.x_sc = io.x_sc; a.x_sh = io.x_sh;
     a.dy = io.dy; a.dy_sb = io.dy_sb; a.dy_sc = io.dy_sc; a.dy_sh = io.dy_sh;

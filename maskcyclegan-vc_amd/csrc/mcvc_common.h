@@ -12,6 +12,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define MCVC_ERR_INVALID 1001
 #define MCVC_ERR_WORKSPACE 1002
 
+// Process-wide switch (mcvc_set_deterministic / env MCVC_DETERMINISTIC=1): every accumulation that would use floating-point
+// atomics (order depends on workgroup scheduling) takes a fixed-order path instead -- private slabs summed by the consumer.
+// The reference's CPU path is bit-reproducible run to run; this mode restores that property.
+int mcvc_deterministic();
+
 static inline int cdiv_i(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdiv_ll(long long a, long long b) { return (a + b - 1) / b; }
 static inline int round_up_i(int a, int b) { return cdiv_i(a, b) * b; }

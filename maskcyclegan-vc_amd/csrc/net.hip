@@ -18,11 +18,15 @@
 #include "misc.h"
 #include "trunk.h"
 #include "wino.h"
+#include "sampler.h"
 #include "../../include/mcvc.h"
 #include <string.h>
 #include <map>
 #include <mutex>
 #include <vector>
+
+static int g_deterministic = [] { const char* e = getenv("MCVC_DETERMINISTIC"); return (e && atoi(e) != 0) ? 1 : 0; }();
+int mcvc_deterministic() { return g_deterministic; }
 
 namespace {
 
@@ -200,6 +204,7 @@ static void run_conv(Exec& ex, const ConvProblem& p, int NB, ConvIO io, long lon
     else if (allow_split) ns = mcvc_conv_plan_nsplit(p, NB, 1);
     if (ns < 1) { ex.fail(MCVC_ERR_INVALID); ns = 1; }
     if (ex.max_split > 0 && ns > ex.max_split) ns = ex.max_split;
+    if (io.accumulate && mcvc_deterministic()) ns = 1;          // a K-split accumulate adds with atomics
     if (!io.accumulate) {
         const long long need = (long long)(ns - 1) * y_total;
         if (need > ex.slab_need) ex.slab_need = need;
@@ -647,19 +652,21 @@ static bool trunk_dgrad(Exec& ex, const ConvSpec& c, const float* packed, const 
     if (ks < 1) return false;
     if (!accumulate && ks > 1 && !nsplit) return false;             // slabs need a consumer that sums them
     const long long tot = (long long)c.Cin * B * W4;
-    if (!accumulate && ks > 1) {
-        const long long need = (long long)(ks - 1) * tot;
+    // deterministic mode: an accumulating K split leaves dx alone and writes ks private slabs; the consumer sums dx + slabs
+    const bool slab_all = accumulate && ks > 1 && nsplit && mcvc_deterministic();
+    if (ks > 1 && (!accumulate || nsplit)) {
+        const long long need = (long long)(accumulate ? ks : ks - 1) * tot;      // (sized for both modes)
         if (need > ex.slab_need) ex.slab_need = need;
         if (!ex.dry && need > ex.slab_cap) { ex.fail(MCVC_ERR_WORKSPACE); return true; }
     }
-    if (nsplit) *nsplit = accumulate ? 1 : ks;
+    if (nsplit) *nsplit = slab_all ? ks + 1 : (accumulate ? 1 : ks);
     if (ex.dry) return true;
     TrunkArgs a{};
     a.a0 = packed + c.off_tk;
     a.x = dy; a.x_sc = (long long)B * W4; a.x_sb = W4;
     a.Cin = c.cout_tot; a.KW = c.KW; a.K = c.cout_tot * c.KW; a.M = c.Cin; a.Mtot = c.Cin; a.B = B; a.T4 = W4; a.N = B * W4;
     a.conv_out = dx; a.c_sc = (long long)B * W4; a.c_sb = W4; a.accumulate = accumulate; a.mode = TRUNK_PLAIN;
-    a.slabs = ex.slabs; a.slab_stride = tot;
+    a.slabs = ex.slabs; a.slab_stride = tot; a.slab_all = slab_all ? 1 : 0;
     ex.fail(mcvc_trunk_launch(a, ks, ex.s));
     return true;
 }
@@ -1007,15 +1014,15 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         {
             CView dyv{DT1, 0, BT4, W4};
             conv_wgrad(ex, g.res_vg[i], G, 1, B, W4, CView{hin, 0, BT4, W4}, dyv);
-            if (!trunk_dgrad(ex, g.res_vg[i], packed, DT1, DH, 1 /*accumulate: skip path*/, B, W4))
+            ns = 1;          // (deterministic mode: DH is left alone and its K-split partials go to slabs the next norm_bwd sums)
+            if (!trunk_dgrad(ex, g.res_vg[i], packed, DT1, DH, 1 /*accumulate: skip path*/, B, W4, &ns))
                 conv_dgrad(ex, g.res_vg[i], packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 1, 1, nullptr);
         }
-        ns = 1;
     }
     if (milestones) record_milestone(ex, milestones[1]);          // parameters [24,100) are done
     // ---- conv2dto1d + IN (:254-255)
     DT3 = DT3s[1];
-    norm_bwd(ex, st + o.c4, W4, BT4, normp(P, G, 22, 23), st + o.s4, DH, W4, BT4, W4, 256 * BT4, 1, DT3, W4, BT4, W4, 0, B, 256, 1, W4, ACT_NONE);
+    norm_bwd(ex, st + o.c4, W4, BT4, normp(P, G, 22, 23), st + o.s4, DH, W4, BT4, W4, 256 * BT4, ns, DT3, W4, BT4, W4, 0, B, 256, 1, W4, ACT_NONE);
     {
         CView dyv{DT3, 0, BT4, W4};
         conv_wgrad(ex, g.c2d1d, G, 1, B, W4, CView{st + o.y3, 0, BT4, W4}, dyv);
@@ -1256,6 +1263,9 @@ extern "C" {
 
 int mcvc_version(void) { return MCVC_ABI_VERSION; }
 
+int mcvc_set_deterministic(int on) { const int was = g_deterministic; g_deterministic = on ? 1 : 0; return was; }
+int mcvc_get_deterministic(void) { return g_deterministic; }
+
 long long mcvc_gen_packed_floats(void) { return gen_net().packed_floats; }
 long long mcvc_disc_packed_floats(void) { return disc_net().packed_floats; }
 int mcvc_gen_out_frames(int T) { return gen_dims(1, T).Wu2; }
@@ -1425,6 +1435,18 @@ int mcvc_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, 
                    float eps, int step, float grad_scale, void* stream)
 {
     return mcvc_adam_launch(p, g, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream);
+}
+
+int mcvc_draw_batch(const float* bank_A, const int* offs_A, int n_A, long long frames_A, const float* bank_B, const int* offs_B, int n_B,
+                    long long frames_B, int B, int T, int max_mask_len, unsigned long long seed, unsigned long long step,
+                    float* real_A, float* mask_A, float* real_B, float* mask_B, int* draws, void* stream)
+{
+    if (!bank_A || !offs_A || !bank_B || !offs_B || n_A < 1 || n_B < 1 || !real_A || !mask_A || !real_B || !mask_B) return MCVC_ERR_INVALID;
+    DrawArgs a{};
+    a.bank[0] = bank_A; a.bank[1] = bank_B; a.offs[0] = offs_A; a.offs[1] = offs_B; a.ld[0] = frames_A; a.ld[1] = frames_B;
+    a.n[0] = n_A; a.n[1] = n_B; a.B = B; a.T = T; a.max_mask_len = max_mask_len; a.seed = seed; a.step = step;
+    a.real[0] = real_A; a.real[1] = real_B; a.mask[0] = mask_A; a.mask[1] = mask_B; a.draws = draws;
+    return mcvc_draw_batch_launch(a, (hipStream_t)stream);
 }
 
 int mcvc_axpy(float* y, const float* x, float alpha, long long n, void* stream)

@@ -13,6 +13,8 @@ struct TrunkArgs {
     int B, T4, N;                           // N = B*T4 <= 32
     float* conv_out; long long c_sc; long long c_sb;  // pre-norm conv output (mode 0: the result), [Mtot][B][T4]
     int accumulate;                         // mode 0 only
+    int slab_all;                           // mode 0, K split: EVERY split s writes slabs + s*slab_stride and the destination is left alone
+                                            // (deterministic accumulate: the consumer sums destination + all slabs in a fixed order)
     float* slabs; long long slab_stride;    // mode 0, K split without accumulate: split s >= 1 writes slabs + (s-1)*slab_stride (the consumer sums)
     float* stats;                           // [B][Mtot][2] (mean, rstd)
     const float* gamma0; const float* beta0; const float* gamma1; const float* beta1;

@@ -202,13 +202,15 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const TrunkA
     if (a.mode == TRUNK_PLAIN) {                    // data-gradient / K-split forward: store, accumulate, or private slab
         const bool slab = (gridDim.y > 1) && !a.accumulate;
         float* base = (slab && blockIdx.y > 0) ? (a.slabs + (long long)(blockIdx.y - 1) * a.slab_stride) : a.conv_out;
+        if (a.slab_all) base = a.slabs + (long long)blockIdx.y * a.slab_stride;
         for (int e = tid; e < 16 * a.N; e += kTrunkThreads) {
             const int row = e / a.N, nn = e - row * a.N;
             const int b = nn / a.T4, t = nn - b * a.T4;
             float* dst = base + (long long)row_cx(row) * a.c_sc + (long long)b * a.c_sb + t;
             float v = tile[row * 33 + nn];
             if (a.bias0 && blockIdx.y == 0) v += a.bias0[r0 + row];
-            if (a.accumulate) { if (gridDim.y > 1) unsafeAtomicAdd(dst, v); else *dst += v; }
+            if (a.slab_all) *dst = v;
+            else if (a.accumulate) { if (gridDim.y > 1) unsafeAtomicAdd(dst, v); else *dst += v; }
             else *dst = v;
         }
         return;
@@ -319,6 +321,7 @@ int mcvc_trunk_launch(const TrunkArgs& a, int ksplit, hipStream_t s)
 {
     if (!mcvc_trunk_applies(a.Cin, a.KW, a.M, a.B, a.T4, a.mode, ksplit)) return MCVC_ERR_INVALID;
     if (ksplit > 1 && !(a.mode == TRUNK_PLAIN && (a.accumulate || a.slabs))) return MCVC_ERR_INVALID;
+    if (a.slab_all && !(a.mode == TRUNK_PLAIN && a.slabs)) return MCVC_ERR_INVALID;
     const int rows = (a.mode == TRUNK_IN_GLU) ? 8 : 16;
     dim3 grid((unsigned)(a.M / rows), (unsigned)ksplit);
     const size_t lds = (size_t)mcvc_trunk_lds_floats(a.Cin, a.KW, a.B, a.T4, ksplit) * sizeof(float);

@@ -4,19 +4,10 @@ seeded run draws bit-identical crops and masks; pinned by tests/golden/dataset_d
 
 Reference behaviour that is kept on purpose (vc_dataset.py:19-77): every ``__getitem__`` re-shuffles all
 utterance indices and crops / masks EVERY pair before returning element ``index``; ``mask_B`` takes its shape
-from the A crop.  ``draw_batch`` is the (new) cheap path used when RNG-stream parity with a reference run is
-not required: same distributions, O(batch) work."""
+from the A crop.  The training CLI uses this RNG-exact host path only behind ``--host_sampler``; its default is the
+on-device sampler (``dataset/device_sampler.py``: same distributions, one kernel launch per minibatch, no H2D copies)."""
 import numpy as np
 from torch.utils.data.dataset import Dataset
-
-
-def _fif_mask(shape, n_frames, max_mask_len, rng):
-    """ones with frames [start, start+size) zeroed; size ~ U{0..max_mask_len-1}, start ~ U{0..n_frames-size-1}."""
-    size = rng.randint(0, max_mask_len)
-    assert n_frames > size
-    start = rng.randint(0, n_frames - size)
-    mask = np.ones(shape, dtype=np.float32) if shape is not None else None
-    return size, start, mask
 
 
 class VCDataset(Dataset):
@@ -61,19 +52,3 @@ class VCDataset(Dataset):
                 bucket.append(item)
         da, ma, db, mb = (np.array(v) for v in out)
         return da[index], ma[index], db[index], mb[index]
-
-    # ---- (new) O(batch) sampler with the same distributions, own RandomState -------------------------------
-    def draw_batch(self, batch_size, rng):
-        A, B = self.datasetA, self.datasetB
-        T = self.n_frames
-        outs = [np.empty((batch_size, A[0].shape[0], T), dtype=np.float32) for _ in range(4)]
-        for b in range(batch_size):
-            for src, xo, mo in ((A, outs[0], outs[1]), (B, outs[2], outs[3])):
-                utt = src[rng.randint(len(src))]
-                lo = rng.randint(utt.shape[1] - T + 1)
-                xo[b] = utt[:, lo:lo + T]
-                size = rng.randint(0, self.max_mask_len)
-                start = rng.randint(0, T - size)
-                mo[b] = 1.0
-                mo[b, :, start:start + size] = 0.0
-        return outs

@@ -33,25 +33,31 @@ def _summary_writer(log_dir):
 
 
 class TrainLogger(object):
-    def __init__(self, args, dataset_len, world_size=1):
+    def __init__(self, args, dataset_len, world_size=1, rank=0):
         self.args = args
+        self.rank = rank                         # data parallel: only rank 0 writes the .log / stdout lines / TensorBoard events
         self.batch_size = args.batch_size
         self.world_size = world_size
         self.dataset_len = dataset_len
         self.save_dir = args.save_dir
         self.steps_per_print = args.steps_per_print
         self.num_epochs = args.num_epochs
-        self.summary_writer = _summary_writer(os.path.join(args.save_dir, "logs", args.name + "_" + datetime.now().strftime("%y%m%d_%H%M%S")))
+        self.summary_writer = None
+        if rank == 0:
+            self.summary_writer = _summary_writer(os.path.join(args.save_dir, "logs", args.name + "_" + datetime.now().strftime("%y%m%d_%H%M%S")))
         self.log_path = os.path.join(self.save_dir, args.name, "%s.log" % args.name)
         self.epoch = args.start_epoch
         self.iter = 0
         raw = (self.epoch - 1) * dataset_len
-        self.global_step = int(self.batch_size * round(float(raw) / self.batch_size))
+        # (x world_size: under data parallelism every iteration advances global_step by batch_size * world_size, end_iter)
+        self.global_step = int(self.batch_size * round(float(raw) / self.batch_size)) * world_size
         self.iter_start_time = None
         self.epoch_start_time = None
         self.loss_meters = None
 
     def write(self, message, print_to_stdout=True):
+        if self.rank != 0:
+            return
         with open(self.log_path, "a") as fh:
             fh.write(message + "\n")
         if print_to_stdout:
@@ -66,6 +72,21 @@ class TrainLogger(object):
         for k, v in metrics.items():
             self.write("[%s: %s]" % (k, v))
         self._scalars(metrics)
+
+    def log_spectrograms(self, out_dir, arrays):
+        """Validation dump (reference train.py:317-358 logs figures / audio to TensorBoard through librosa + the MelGAN
+        vocoder, neither available here): the same tensors as float32 ``.npy`` files, one per name, tagged with the epoch."""
+        if self.rank != 0:
+            return []
+        import numpy as np
+        os.makedirs(out_dir, exist_ok=True)
+        paths = []
+        for name, arr in arrays.items():
+            path = os.path.join(out_dir, "epoch%05d_%s.npy" % (self.epoch, name))
+            np.save(path, np.asarray(arr, dtype=np.float32))
+            paths.append(path)
+        self.write("[validation: wrote %d spectrograms to %s]" % (len(paths), out_dir))
+        return paths
 
     def start_epoch(self):
         self.epoch_start_time = time()

@@ -25,6 +25,8 @@ _PP = ctypes.POINTER(c_void_p)
 
 _SIGS = {
     "mcvc_version": (c_int, []),
+    "mcvc_set_deterministic": (c_int, [c_int]),
+    "mcvc_get_deterministic": (c_int, []),
     "mcvc_gen_packed_floats": (c_longlong, []),
     "mcvc_disc_packed_floats": (c_longlong, []),
     "mcvc_gen_stash_floats": (c_longlong, [c_int, c_int]),
@@ -46,6 +48,8 @@ _SIGS = {
     "mcvc_l1_loss": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "mcvc_lsgan_loss": (c_int, [c_void_p, c_longlong, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcvc_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
+    "mcvc_draw_batch": (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_int,
+                                ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcvc_axpy": (c_int, [c_void_p, c_void_p, c_float, c_longlong, c_void_p]),
     "mcvc_conv2d_pack_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "mcvc_conv2d_forward": (c_int, [c_void_p] * 6 + [c_int] * 12 + [c_void_p]),

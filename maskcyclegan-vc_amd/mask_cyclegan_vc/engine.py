@@ -143,7 +143,6 @@ class TrainEngine:
         self.reducer.broadcast_(self.g_group.flat)
         self.reducer.broadcast_(self.d_group.flat)
         self.repack(G_NAMES + D_NAMES)
-        self._stale_g = self._stale_d = False
 
     # ---- activations / workspaces: static shapes per batch size (graph-capturable), created on first use -----------
     def _use(self, B):
@@ -156,7 +155,6 @@ class TrainEngine:
         each discriminator sees [real ; generated] in one pass."""
         if B > self._max_B:                 # a larger batch than any so far may leave the fused-trunk regime: full re-pack
             self._max_B = B
-            self._stale_g = True
             if hasattr(self, "packed"):
                 self.repack(G_NAMES)
         ws = self._workspaces.get(B)
@@ -264,6 +262,10 @@ class TrainEngine:
         grp.step += 1
         check(self.L.mcvc_adam_step(ptr(grp.flat), ptr(grp.grad), ptr(grp.exp_avg), ptr(grp.exp_avg_sq), grp.numel, float(lr),
                                     self.betas[0], self.betas[1], self.eps, grp.step, self.reducer.grad_scale, stream()), "adam_step")
+        # the raw-pointer update does not bump the parameters' autograd version counters: drop the modules' own packed-weight
+        # caches so that a later module-API forward (validation, in-process inference) re-packs from the new values
+        for n in (G_NAMES if grp is self.g_group else D_NAMES):
+            self.nets[n]._packed_version = None
 
     # ---- the two phases -------------------------------------------------------------------------------
     def generator_phase(self, real_A, mask_A, real_B, mask_B):
@@ -332,7 +334,6 @@ class TrainEngine:
         else:
             self.reducer.reduce_(self.g_group.grad)
         self._adam(self.g_group, self.sched.g_opt_lr)
-        self._stale_g = True
 
     def discriminator_phase(self, real_A, mask_A, real_B, mask_B):
         """train.py:247-299."""
@@ -376,7 +377,6 @@ class TrainEngine:
             return
         self.reducer.reduce_(self.d_group.grad)
         self._adam(self.d_group, self.sched.d_opt_lr)
-        self._stale_d = True
 
     def _finish_d_update(self):
         if self._pending_d_lr is None:
@@ -384,7 +384,6 @@ class TrainEngine:
         self.reducer.wait(self.device)
         self._adam(self.d_group, self._pending_d_lr)
         self._pending_d_lr = None
-        self._stale_d = True
 
     def flush(self):
         """Complete a deferred discriminator update (call before reading parameters / optimizer state from outside)."""
@@ -401,6 +400,18 @@ class TrainEngine:
         # static input buffers (graph replays read fixed addresses)
         for dst, src in zip(self.static_in, (real_A, mask_A, real_B, mask_B)):
             dst.copy_(src)
+        return self._step_static()
+
+    def step_sampled(self, sampler, batch_size=None):
+        """One full iteration on a minibatch drawn ON THE DEVICE (dataset.device_sampler.DeviceSampler): the sampler's kernel
+        writes crops and masks straight into the static input buffers -- no DataLoader, no H2D copy."""
+        B = self.B if batch_size is None else int(batch_size)
+        if B != self.B:
+            self._use(B)
+        sampler.draw_into(*self.static_in)
+        return self._step_static()
+
+    def _step_static(self):
         self._run_phase("G")
         self.generator_update()
         self._run_phase("D")

@@ -105,6 +105,7 @@ class _NetBase(nn.Module):
         self._packed = None
         self._packed_version = None
         self._ws = {}
+        self._iws = {}
 
     def _plist(self):
         ps = list(self.parameters())
@@ -140,7 +141,7 @@ class _NetBase(nn.Module):
             else:
                 n_stash, n_scr = L.mcvc_disc_stash_floats(B, T), L.mcvc_disc_scratch_floats(B, T)
             ws = (n_stash, torch.empty(n_scr, device=device))
-            self._ws = {key: ws}            # keep one shape resident
+            self._ws = {key: ws}            # keep one shape resident (drops the previous shape's scratch and inference stash)
         return ws
 
 
@@ -278,6 +279,47 @@ class Generator(_NetBase):
 
     def forward(self, x, mask):
         return _GeneratorFn.apply(self, x, mask, *self._plist())
+
+    def _infer_workspace(self, B, T, device):
+        """(stash, scratch) of the gradient-free forward, one set per (shape, HIP stream): the bucketed inference driver runs
+        forwards of different shapes on two streams at once, which must not share transient buffers."""
+        key = (B, T, str(device), torch.cuda.current_stream(device).cuda_stream)
+        ws = self._iws.get(key)
+        if ws is None:
+            L = lib()
+            while len(self._iws) >= 4:
+                self._iws.pop(next(iter(self._iws)))
+            ws = (torch.empty(L.mcvc_gen_stash_floats(B, T), device=device), torch.empty(L.mcvc_gen_scratch_floats(B, T), device=device))
+            self._iws[key] = ws
+        return ws
+
+    def prepare_inference(self, dtype="f32"):
+        """Build / refresh the packed weights ``infer`` reads, on the current stream (call before forking inference streams)."""
+        if dtype == "f32":
+            self.packed_weights()
+        elif dtype != "bf16":
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+
+    def infer(self, x, mask=None, dtype="f32"):
+        """Gradient-free forward for the inference driver (reference test.py:85-119 calls ``generator(real, ones_like(real))``
+        and never back-propagates): no autograd node, no fresh stash allocation per call.  ``mask=None`` is the all-ones
+        mask of test.py:92.  ``dtype``: "f32" (bit-for-bit the training forward) or "bf16" (BASELINE configs[4]: bf16 MFMA
+        with fp32 accumulation and fp32 InstanceNorm statistics; weights are cast from the fp32 parameters)."""
+        x = x.contiguous()
+        _hip.require_cuda_f32(x, mask)
+        B, n_mel, T = x.shape
+        if n_mel != _hip.N_MEL:
+            raise RuntimeError("Generator expects %d mel bins" % _hip.N_MEL)
+        L = lib()
+        ps = self._plist()
+        out = torch.empty((B, n_mel, L.mcvc_gen_out_frames(T)), device=x.device)
+        if dtype == "f32":
+            packed = self.packed_weights(ps)
+            stash, scratch = self._infer_workspace(B, T, x.device)
+            check(L.mcvc_gen_forward(ptr_table(ps), ptr(packed), ptr(x), ptr(mask.contiguous() if mask is not None else None), ptr(out),
+                                     ptr(stash), ptr(scratch), scratch.numel(), B, T, stream()), "mcvc_gen_forward")
+            return out
+        raise ValueError("dtype must be 'f32' or 'bf16'")
 
 
 class Discriminator(_NetBase):

@@ -35,6 +35,11 @@ def init_from_env(backend=None):
             # MCVC_DIST_BACKEND=gloo: test hook (two ranks sharing the one GPU of a dev box; RCCL refuses duplicate devices)
             backend = os.environ.get("MCVC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            # RCCL needs one GPU per rank: fail loudly instead of hanging in the first collective
+            if torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+                raise RuntimeError("RCCL (backend nccl) needs one GPU per local rank: %d visible, %s ranks on this node "
+                                   "(set MCVC_DIST_BACKEND=gloo only for single-GPU choreography tests)"
+                                   % (torch.cuda.device_count(), os.environ.get("LOCAL_WORLD_SIZE", world)))
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:

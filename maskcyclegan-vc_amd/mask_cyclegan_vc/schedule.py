@@ -32,8 +32,10 @@ class StepSchedule:
         self.g_opt_lr = generator_lr
         self.d_opt_lr = discriminator_lr
         dataset_len = n_samples if dataset_len is None else dataset_len
-        # base_logger.py:53-56: round_down((epoch-1)*dataset_len, batch_size), python round()
-        self.global_step = int(batch_size * round(float((start_epoch - 1) * dataset_len) / batch_size))
+        # base_logger.py:53-56: round_down((epoch-1)*dataset_len, batch_size), python round().  Under data parallelism an
+        # epoch advances global_step by ~dataset_len * world_size (every rank consumes batch_size samples per iteration,
+        # end_iteration below), so the re-derived resume value carries the same factor.
+        self.global_step = int(batch_size * round(float((start_epoch - 1) * dataset_len) / batch_size)) * world_size
 
     def end_iteration(self):
         """Call once per iteration after the optimizer steps (train.py:302-315)."""

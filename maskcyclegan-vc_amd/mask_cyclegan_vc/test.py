@@ -2,7 +2,13 @@
 
 Loads one generator checkpoint and converts every utterance of the source speaker with an all-ones mask
 (test.py:92, 107).  The MelGAN vocoder decode + wav writing of the reference need network access and audio packages
-(out of scope); the converted, de-normalised mel-spectrograms are written as .npy next to where the wavs would go."""
+(out of scope); the converted, de-normalised mel-spectrograms are written as .npy next to where the wavs would go.
+
+Batching (new): InstanceNorm statistics run over an utterance's whole time axis, so zero-padding utterances to a common
+length would change every output.  Utterances are therefore bucketed by EXACT length: a bucket of k equal-length utterances
+is one batched forward (up to ``--max_batch``; every op is per-sample, so results equal the bs=1 results), buckets are
+visited longest first and alternate between two HIP streams so that short utterances overlap on the chip.  ``--dtype bf16``
+selects the bf16-MFMA forward (BASELINE configs[4])."""
 import os
 
 import numpy as np
@@ -37,15 +43,34 @@ class MaskCycleGANVCTesting(object):
         src = self.dataset_A if a2b else self.dataset_B
         mean, std = (self.dataset_B_mean, self.dataset_B_std) if a2b else (self.dataset_A_mean, self.dataset_A_std)
         tag = ("%s_to_%s" % (self.args.speaker_A_id, self.args.speaker_B_id)) if a2b else ("%s_to_%s" % (self.args.speaker_B_id, self.args.speaker_A_id))
-        outs = []
+        outs = [None] * len(src)
+        buckets = {}
+        for i, mel in enumerate(src):
+            buckets.setdefault(int(np.asarray(mel).shape[1]), []).append(i)
+        self.generator.prepare_inference(self.args.dtype)      # weight packs are built once, on the current stream, before the lanes fork
+        streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+        pending = []
+        k = 0
         with torch.no_grad():
-            for i, mel in enumerate(src):
-                real = torch.from_numpy(np.asarray(mel, dtype=np.float32)).unsqueeze(0).to(self.device)
-                fake = self.generator(real, torch.ones_like(real))
-                conv = denormalize_mel(fake[0].cpu().numpy(), mean, std)
-                path = os.path.join(self.converted_dir, "%d-converted_%s.npy" % (i, tag))
-                np.save(path, conv.astype(np.float32))
-                outs.append(path)
+            for T in sorted(buckets, reverse=True):
+                ids = buckets[T]
+                for lo in range(0, len(ids), max(1, self.args.max_batch)):
+                    grp = ids[lo:lo + max(1, self.args.max_batch)]
+                    st = streams[k % 2]; k += 1
+                    st.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(st):
+                        real = torch.from_numpy(np.stack([np.asarray(src[i], dtype=np.float32) for i in grp])).to(self.device, non_blocking=True)
+                        fake = self.generator.infer(real, None, dtype=self.args.dtype).float()      # all-ones mask (test.py:92)
+                    pending.append((grp, fake, real))         # keep `real` alive until the stream is done with it
+            for st in streams:
+                torch.cuda.current_stream(self.device).wait_stream(st)
+            torch.cuda.synchronize(self.device)
+            for grp, fake, _ in pending:
+                host = fake.cpu().numpy()
+                for j, i in enumerate(grp):
+                    path = os.path.join(self.converted_dir, "%d-converted_%s.npy" % (i, tag))
+                    np.save(path, denormalize_mel(host[j], mean, std).astype(np.float32))
+                    outs[i] = path
         print("wrote %d converted mel-spectrograms to %s" % (len(outs), self.converted_dir))
         return outs
 

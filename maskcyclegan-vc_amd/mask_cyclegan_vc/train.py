@@ -4,8 +4,12 @@ Same CLI (args/), same dataset files, same checkpoint layout, same per-iteration
 arithmetic runs in the HIP engine (engine.py).  Launch one process per GPU with torchrun for data-parallel training
 (RCCL gradient all-reduce, parallel.py); a single process behaves exactly like the reference's single-device loop.
 
-Not built: the MelGAN vocoder load, validation figures and audio dumps of
-train.py:46-48, 317-358 -- they need network access and audio packages and are not on the step path."""
+Input pipeline: by default minibatches are drawn ON THE DEVICE (dataset/device_sampler.py: HBM-resident utterance bank, one
+kernel launch per iteration, no DataLoader and no H2D copy); ``--host_sampler`` keeps the reference's RNG-exact
+VCDataset + DataLoader path (dataset/vc_dataset.py).  Validation (reference train.py:317-358): every ``--epochs_per_plot``
+epochs the last training pair and the full-utterance conversions of the first validation pair are written as ``.npy``
+spectrograms under ``<save_dir>/<name>/validation/`` -- the reference renders them through librosa figures and the MelGAN
+vocoder into TensorBoard, which need network access and audio packages (out of scope)."""
 import os
 import pickle
 
@@ -14,6 +18,7 @@ import torch
 import torch.utils.data as data
 
 from args.cycleGAN_train_arg_parser import CycleGANTrainArgParser
+from dataset.device_sampler import DeviceSampler
 from dataset.vc_dataset import VCDataset
 from logger.train_logger import TrainLogger
 from saver.model_saver import ModelSaver
@@ -22,6 +27,7 @@ from .engine import D_NAMES, G_NAMES, TrainEngine
 from .model import Discriminator, Generator
 from .parallel import FlatGradReducer, init_from_env
 from .schedule import StepSchedule
+from .utils import denormalize_mel
 
 NET_NAMES = G_NAMES + D_NAMES          # construction order of the reference (train.py:103-110)
 
@@ -47,15 +53,26 @@ class MaskCycleGANVCTraining(object):
         self.start_epoch = args.start_epoch
         self.mini_batch_size = args.batch_size
         self.epochs_per_save = args.epochs_per_save
+        self.epochs_per_plot = args.epochs_per_plot
         self.dataset_A, self.dataset_A_mean, self.dataset_A_std = load_speaker(args.preprocessed_data_dir, args.speaker_A_id)
         self.dataset_B, self.dataset_B_mean, self.dataset_B_std = load_speaker(args.preprocessed_data_dir, args.speaker_B_id)
         self.n_samples = len(self.dataset_A)
-        print("n_samples = %d" % self.n_samples)
+        if self.rank == 0:
+            print("n_samples = %d" % self.n_samples)
         if self.world > 1:                       # every rank draws its own minibatches
             np.random.seed(args.seed + self.rank)
         self.dataset = VCDataset(datasetA=self.dataset_A, datasetB=self.dataset_B, n_frames=args.num_frames, max_mask_len=args.max_mask_len)
-        self.train_dataloader = data.DataLoader(dataset=self.dataset, batch_size=self.mini_batch_size, shuffle=True, drop_last=False)
-        self.logger = TrainLogger(args, len(self.train_dataloader.dataset), world_size=self.world)
+        self.train_dataloader = None
+        self.sampler = None
+        if args.host_sampler:                    # the reference's path, bit-identical draws for a given --seed (vc_dataset.py:19-77)
+            self.train_dataloader = data.DataLoader(dataset=self.dataset, batch_size=self.mini_batch_size, shuffle=True, drop_last=False)
+        else:
+            self.sampler = DeviceSampler(self.dataset_A, self.dataset_B, n_frames=args.num_frames, max_mask_len=args.max_mask_len,
+                                         device=self.device, seed=args.seed + 7919 * self.rank)
+        # validation pair (reference train.py:86-96: VCDataset(valid=True), batch_size 1, no shuffle -> the first utterances, whole)
+        self.validation_dataset = VCDataset(datasetA=self.dataset_A, datasetB=self.dataset_B, n_frames=args.num_frames_validation,
+                                            max_mask_len=args.max_mask_len, valid=True)
+        self.logger = TrainLogger(args, len(self.dataset), world_size=self.world, rank=self.rank)
         self.saver = ModelSaver(args)            # like the reference, max_ckpts is not passed: nothing is pruned
         # six networks in the reference's construction order; parse_args() seeded torch, so default init matches
         torch.manual_seed(args.seed)
@@ -92,20 +109,59 @@ class MaskCycleGANVCTraining(object):
             opt = self.generator_optimizer if n in G_NAMES else self.discriminator_optimizer
             self.saver.save(epoch, self.nets[n], opt, None, self.device, n)
 
+    def _epoch_batches(self):
+        """Yield one iteration's work at a time: a callable that runs the step.  Epoch length and the short last batch follow
+        the reference's DataLoader(shuffle=True, drop_last=False) over len(dataset) samples."""
+        if self.train_dataloader is not None:
+            for real_A, mask_A, real_B, mask_B in self.train_dataloader:
+                batch = [t.to(self.device, dtype=torch.float).contiguous() for t in (real_A, mask_A, real_B, mask_B)]
+                yield lambda b=batch: self.engine.step(*b)
+        else:
+            left = len(self.dataset)
+            while left > 0:
+                nb = min(self.mini_batch_size, left)
+                left -= nb
+                yield lambda nb=nb: self.engine.step_sampled(self.sampler, nb)
+
+    def validate(self):
+        """Reference train.py:317-358 without the figure / vocoder back-ends: the last training pair's first sample
+        (real_A, generated_A, real_B, generated_B of the discriminator phase) and the full-utterance conversions of the first
+        validation pair (G_A2B(real_full_A, ones), G_B2A(real_full_B, ones)), de-normalised, as .npy spectrograms."""
+        eng = self.engine
+        eng.flush()
+        B = eng.B
+        arrays = {
+            "real_A_spec": eng.static_in[0][0].cpu().numpy(), "real_B_spec": eng.static_in[2][0].cpu().numpy(),
+            "fake_A_spec": eng.d_in["discriminator_A"][B].cpu().numpy(),      # generated_A = G_B2A(real_B, mask_B), train.py:259
+            "fake_B_spec": eng.d_in["discriminator_B"][B].cpu().numpy(),      # generated_B = G_A2B(real_A, mask_A), train.py:267
+        }
+        full_A, full_B = self.validation_dataset[0]
+        with torch.no_grad():
+            xa = torch.from_numpy(np.asarray(full_A, dtype=np.float32)).unsqueeze(0).to(self.device)
+            xb = torch.from_numpy(np.asarray(full_B, dtype=np.float32)).unsqueeze(0).to(self.device)
+            fake_full_B = self.generator_A2B(xa, torch.ones_like(xa))[0].cpu().numpy()
+            fake_full_A = self.generator_B2A(xb, torch.ones_like(xb))[0].cpu().numpy()
+        arrays["real_speaker_A_mel"] = denormalize_mel(np.asarray(full_A), self.dataset_A_mean, self.dataset_A_std)
+        arrays["fake_speaker_A_mel"] = denormalize_mel(fake_full_A, self.dataset_A_mean, self.dataset_A_std)
+        arrays["real_speaker_B_mel"] = denormalize_mel(np.asarray(full_B), self.dataset_B_mean, self.dataset_B_std)
+        arrays["fake_speaker_B_mel"] = denormalize_mel(fake_full_B, self.dataset_B_mean, self.dataset_B_std)
+        return self.logger.log_spectrograms(os.path.join(self.args.save_dir, self.args.name, "validation"), arrays)
+
     def train(self):
         done = 0
         for epoch in range(self.start_epoch, self.num_epochs + 1):
             self.logger.start_epoch()
-            for real_A, mask_A, real_B, mask_B in self.train_dataloader:
+            for run_step in self._epoch_batches():
                 self.logger.start_iter()
-                batch = [t.to(self.device, dtype=torch.float).contiguous() for t in (real_A, mask_A, real_B, mask_B)]
-                self.engine.step(*batch)                                   # G phase, D phase, lr / lambda bookkeeping
+                run_step()                                                 # G phase, D phase, lr / lambda bookkeeping
                 lo = self.engine.losses()                                  # host read, like .item() in train.py:303
                 self.logger.log_iter(loss_dict={"g_loss": lo["g_loss"], "d_loss": lo["d_loss"]})
                 self.logger.end_iter()
                 done += 1
                 if self.args.max_iters and done >= self.args.max_iters:
                     break
+            if done and self.epochs_per_plot and epoch % self.epochs_per_plot == 0 and self.rank == 0:
+                self.validate()                                            # train.py:317
             if epoch % self.epochs_per_save == 0:
                 self.engine.flush()                                        # a deferred (data-parallel) D update must land first
                 self.save_all(epoch)
@@ -114,10 +170,22 @@ class MaskCycleGANVCTraining(object):
                 break
         self.engine.flush()
 
+    def close(self):
+        """Tear down the process group (RCCL warns / may hang at interpreter exit otherwise)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            torch.cuda.synchronize(self.device)
+            dist.barrier()
+            dist.destroy_process_group()
+
 
 def main(argv=None):
     args = CycleGANTrainArgParser().parse_args(argv)
-    MaskCycleGANVCTraining(args).train()
+    job = MaskCycleGANVCTraining(args)
+    try:
+        job.train()
+    finally:
+        job.close()
 
 
 if __name__ == "__main__":

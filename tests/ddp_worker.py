@@ -39,18 +39,52 @@ def sample(seed):
     return out
 
 
+def batch_of(seeds):
+    parts = [sample(s) for s in seeds]
+    return [torch.cat([p[k] for p in parts], 0).contiguous() for k in range(4)]
+
+
+def kink_free_seeds(eng, n, seed0, margin=3e-5):
+    """|a-b| has a kinked gradient: an L1 residual within rounding of zero may legitimately take either sign in two
+    differently tiled runs (bs=8 per rank vs bs=16 in one process), and ONE flipped sign is a 1e-3-level gradient error.
+    Pick samples whose cycle / identity residuals all stay `margin` away from zero (every op is per-sample, so a batch of
+    such samples is kink-free); probed with the engine itself at bs=1."""
+    keep, s = [], seed0
+    B0 = eng.B
+    eng._use(1)
+    while len(keep) < n:
+        b = sample(s)
+        for dst, src in zip(eng.static_in, b):
+            dst.copy_(src)
+        eng._run_phase("G")
+        res = [(eng.mel["cycle_A"] - b[0]).abs().min(), (eng.mel["cycle_B"] - b[2]).abs().min(),
+               (eng.out_B2A[1:] - b[0]).abs().min(), (eng.out_A2B[1:] - b[2]).abs().min()]      # identity halves
+        if float(min(res)) > margin:
+            keep.append(s)
+        s += 1
+        assert s < seed0 + 20 * n + 40, "no kink-free samples"
+    eng._use(B0)
+    return keep
+
+
+PER_RANK = 8          # BASELINE configs[3]: bs=8 per GPU
+
+
 def main():
     import faulthandler
-    faulthandler.dump_traceback_later(150, exit=True)      # a mismatched collective would otherwise hang the GPU box
+    faulthandler.dump_traceback_later(300, exit=True)      # a mismatched collective would otherwise hang the GPU box
     os.environ["MCVC_DIST_BACKEND"] = "gloo"
     rank, world, _ = init_from_env()
     assert world == 2
     torch.cuda.set_device(0)
-    # ---- (1) gradient equivalence of the generator phase
-    eng = TrainEngine(nets_for(700 + 10 * 0), 1, 64, schedule=StepSchedule(batch_size=1, n_samples=8, world_size=world),
+    # ---- (1) gradient equivalence of the generator phase at bs=8 per rank
+    eng = TrainEngine(nets_for(700 + 10 * 0), PER_RANK, 64, schedule=StepSchedule(batch_size=PER_RANK, n_samples=64, world_size=world),
                       reducer=FlatGradReducer())
     assert eng.defer_d_update
-    mine = sample(40 + rank)
+    seeds = kink_free_seeds(eng, PER_RANK, 4000 + 1000 * rank)
+    all_seeds = [None, None]
+    dist.all_gather_object(all_seeds, seeds)
+    mine = batch_of(seeds)
     for dst, src in zip(eng.static_in, mine):
         dst.copy_(src)
     eng._run_phase("G")
@@ -58,21 +92,24 @@ def main():
     avg = (eng.g_group.grad * eng.reducer.grad_scale).double().cpu()
     ok = True
     if rank == 0:
-        both = [torch.cat([a, b]) for a, b in zip(sample(40), sample(41))]
+        both = batch_of(all_seeds[0] + all_seeds[1])
         solo = FlatGradReducer()
         solo.world = 1                  # the single-process reference must not issue collectives
-        ref = TrainEngine(nets_for(700), 2, 64, schedule=StepSchedule(batch_size=2, n_samples=8), reducer=solo)
+        ref = TrainEngine(nets_for(700), 2 * PER_RANK, 64, schedule=StepSchedule(batch_size=2 * PER_RANK, n_samples=64), reducer=solo)
         for dst, src in zip(ref.static_in, both):
             dst.copy_(src)
         ref._run_phase("G")
         g2 = ref.g_group.grad.double().cpu()
         err = float((avg - g2).norm() / g2.norm())
-        print("ddp grad vs batch-2 grad rel err %.3e" % err, flush=True)
-        ok = ok and err < 2e-2          # (L1 kinks: one flipped sign is 0.5 % -- see test_hip_engine.py)
+        print("ddp grad (2 ranks x bs=%d) vs single-process bs=%d grad rel err %.3e" % (PER_RANK, 2 * PER_RANK, err), flush=True)
+        ok = ok and err < 1e-4
+        del ref
     # ---- (2) ranks stay identical through full iterations (deferred D update, async all-reduce)
-    eng2 = TrainEngine(nets_for(800), 1, 64, schedule=StepSchedule(batch_size=1, n_samples=8, world_size=world), reducer=FlatGradReducer())
+    del eng
+    eng2 = TrainEngine(nets_for(800), PER_RANK, 64, schedule=StepSchedule(batch_size=PER_RANK, n_samples=64, world_size=world),
+                       reducer=FlatGradReducer())
     for it in range(3):
-        eng2.step(*sample(100 + 2 * it + rank))
+        eng2.step(*batch_of(range(100 + 16 * it + 8 * rank, 100 + 16 * it + 8 * rank + PER_RANK)))
         lo = eng2.losses()
         assert np.isfinite(lo["g_loss"]) and np.isfinite(lo["d_loss"])
     eng2.flush()

@@ -1,0 +1,40 @@
+"""GPU: the exact command the driver uses for the multi-GPU scaling bench -- ``python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W`` -- end to end with two
+ranks.  A dev box has ONE GPU, so both ranks share cuda:0 and exchange over gloo (MCVC_DIST_BACKEND=gloo; RCCL refuses
+duplicate devices): what is exercised is bench.py's own choreography (env rendezvous, barriers, MAX-reduce of the timed
+region, ONE JSON line from rank 0 only, clean process-group teardown), not the transport."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_under_torchrun_two_ranks():
+    env = dict(os.environ, MCVC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                  # rank 0 only
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 4 and res["warmup"] == 2 and res["scaling"] == "weak"
+    assert res["config"]["global_batch"] == 2 and res["config"]["parallelism"] == "dp2"
+    assert res["losses_finite"] and res["value"] > 0
+    assert abs(res["value"] - 2 * 1e3 / res["ms_per_step"]) < 1e-6 * res["value"]        # whole-job rate = ranks x per-rank rate
+    assert "cpu_baseline" not in res                           # N=1 only
+
+
+def test_nccl_backend_refuses_fewer_gpus_than_ranks():
+    import torch
+    code = ("import os, sys; sys.path.insert(0, %r); "
+            "os.environ.update(RANK='0', WORLD_SIZE='%d', LOCAL_RANK='0', LOCAL_WORLD_SIZE='%d', MASTER_ADDR='127.0.0.1', MASTER_PORT='29547'); "
+            "from mask_cyclegan_vc.parallel import init_from_env; init_from_env(backend='nccl')")
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, "-c", code % (os.path.join(ROOT, "maskcyclegan-vc_amd"), n, n)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "one GPU per local rank" in r.stderr

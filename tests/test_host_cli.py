@@ -68,10 +68,70 @@ def test_dataset_draws_are_bit_identical_to_reference(golden_dir):
     # validation mode returns whole utterances
     v = VCDataset(dsA, dsB, valid=True)
     assert v[1][0] is dsA[1] and v[1][1] is dsB[1]
-    # O(batch) sampler: same mask law
-    xa, ma, xb, mb = ds.draw_batch(5, np.random.RandomState(3))
+
+
+def test_device_sampler_restatement_follows_the_reference_distributions():
+    """oracle/sampler_oracle.py restates the on-device sampler's counter-based draws (the HIP kernel is checked bit-exactly
+    against it on the GPU, tests/test_hip_sampler.py).  Here: the DISTRIBUTIONS are the reference's (vc_dataset.py:33-70):
+    utterance uniform with replacement, crop start uniform on {0..len-T}, mask size uniform on {0..max_mask_len-1}, mask
+    start uniform on {0..T-size-1}; chi-square against those laws on 40k draws (99.9 % quantiles)."""
+    import sampler_oracle as so
+    from scipy import stats
+    lens_a, lens_b = [70, 75, 80, 64], [90, 93, 96, 99, 102]
+    T, mml, B, steps = 64, 25, 8, 2500
+    idx = np.concatenate([so.draw_indices(lens_a, lens_b, B, T, mml, seed=11, step=s) for s in range(steps)])   # [steps*B, 2, 4]
+    n = idx.shape[0]
+    for side, lens in enumerate((lens_a, lens_b)):
+        utt, lo, size, start = (idx[:, side, k] for k in range(4))
+        assert utt.min() >= 0 and utt.max() == len(lens) - 1
+        assert stats.chisquare(np.bincount(utt, minlength=len(lens))).pvalue > 1e-3
+        assert stats.chisquare(np.bincount(size, minlength=mml)).pvalue > 1e-3 and size.max() == mml - 1
+        for u, ln in enumerate(lens):                      # crop start | utterance ~ U{0..len-T}
+            sel = lo[utt == u]
+            assert sel.min() >= 0 and sel.max() <= ln - T
+            if ln > T:
+                assert stats.chisquare(np.bincount(sel, minlength=ln - T + 1)).pvalue > 1e-3
+        for sz in (0, 7, 24):                               # mask start | size ~ U{0..T-size-1}
+            sel = start[size == sz]
+            assert sel.max() <= T - sz - 1
+            assert stats.chisquare(np.bincount(sel, minlength=T - sz)).pvalue > 1e-3
+        assert (start + size <= T).all()
+    # the two speakers and consecutive steps are independent streams: no repeated rows
+    assert len({tuple(r) for r in idx.reshape(n, 8)}) > 0.99 * n
+    # materialised batch: crops are slices of the chosen utterances, masks are per-frame (identical over the 80 bins)
+    rs = np.random.RandomState(5)
+    dA = [rs.randn(80, ln).astype(np.float32) for ln in lens_a]
+    dB = [rs.randn(80, ln).astype(np.float32) for ln in lens_b]
+    (xa, ma, xb, mb), ix = so.draw_batch(dA, dB, 5, T, mml, seed=3, step=9)
     assert xa.shape == ma.shape == xb.shape == mb.shape == (5, 80, 64)
-    assert set(np.unique(ma)).issubset({0.0, 1.0}) and (ma == ma[:, :1, :]).all()
+    assert set(np.unique(ma)).issubset({0.0, 1.0}) and (ma == ma[:, :1, :]).all() and (mb == mb[:, :1, :]).all()
+    u, lo, size, start = ix[2, 1]
+    assert np.array_equal(xb[2], dB[u][:, lo:lo + T]) and mb[2, 0].sum() == T - size and (mb[2, 0, start:start + size] == 0).all()
+
+
+def test_preprocessed_format_writer_roundtrip(tmp_path):
+    """data_preprocessing.preprocess_vcc2018 writes what train.load_speaker (and the reference trainer, train.py:51-64)
+    reads; normalisation per reference preprocess_vcc2018.py:35-47 (std + 1e-9, utterances under 64 frames dropped)."""
+    from data_preprocessing.preprocess_vcc2018 import main as prep_main, normalize_mels
+    import pickle
+    rs = np.random.RandomState(0)
+    mels = [(3.0 + 2.0 * rs.randn(80, n)).astype(np.float32) for n in (70, 40, 128, 64)]
+    for i, m in enumerate(mels):
+        os.makedirs(tmp_path / "mels" / "SPK", exist_ok=True)
+        np.save(tmp_path / "mels" / "SPK" / ("u%d.npy" % i), m)
+    prep_main(["--mel_directory", str(tmp_path / "mels"), "--preprocessed_data_directory", str(tmp_path / "out"), "--speaker_ids", "SPK"])
+    with open(tmp_path / "out" / "SPK" / "SPK_normalized.pickle", "rb") as fh:
+        norm = pickle.load(fh)
+    stat = np.load(tmp_path / "out" / "SPK" / "SPK_norm_stat.npz")
+    kept = [m for m in mels if m.shape[1] >= 64]
+    assert len(norm) == 3 and [n.shape for n in norm] == [m.shape for m in kept]
+    cat = np.concatenate(kept, axis=1)
+    assert stat["mean"].shape == stat["std"].shape == (80, 1)
+    assert np.allclose(stat["mean"], cat.mean(1, keepdims=True)) and np.allclose(stat["std"], cat.std(1, keepdims=True) + 1e-9)
+    assert all(n.dtype == np.float32 for n in norm)
+    assert np.allclose(norm[1], (kept[1] - stat["mean"]) / stat["std"], atol=1e-6)
+    again, _, _ = normalize_mels(kept)
+    assert all(np.array_equal(a, b) for a, b in zip(again, norm))
 
 
 class _FakeAdam(object):
@@ -104,6 +164,55 @@ def test_checkpoint_layout_roundtrip(tmp_path):
     saver.load_model(d2, "discriminator_A", None, opt)
     assert all(torch.equal(a, b) for a, b in zip(d.state_dict().values(), d2.state_dict().values()))
     assert opt.sd["param_groups"][0]["lr"] == 2e-4
+
+
+def _describe(v):
+    if torch.is_tensor(v):
+        return {"tensor": str(v.dtype).replace("torch.", ""), "shape": list(v.shape), "device": v.device.type}
+    if isinstance(v, (list, tuple)):
+        return {"type": type(v).__name__, "len": len(v), "elem": type(v[0]).__name__ if len(v) else None}
+    return {"type": type(v).__name__, "value": v if isinstance(v, (int, float, bool, str, type(None))) else None}
+
+
+def test_saver_writes_the_structure_of_a_reference_written_checkpoint(tmp_path, golden_dir):
+    """tests/golden/ckpt_structure.json describes files written by the REFERENCE's own ModelSaver.save (make_golden_ckpt.py):
+    file name, top-level keys, model_state keys / dtypes / shapes, optimizer state indices and entry layout, param_groups keys.
+    This repo's saver + modules + a torch.optim.Adam must produce the same structure."""
+    from argparse import Namespace
+    from mask_cyclegan_vc.model import Discriminator, Generator
+    ref = json.load(open(os.path.join(golden_dir, "ckpt_structure.json")))
+    plain = json.load(open(os.path.join(golden_dir, "step_plain.json")))
+    saver = ModelSaver(Namespace(ckpt_dir=str(tmp_path), load_epoch=3, gpu_ids=[0]))
+    torch.manual_seed(0)
+    for name, model in (("generator_A2B", Generator()), ("discriminator_A", Discriminator())):
+        n_copies = 2 if name.startswith("generator") else 4               # the optimizers span both G / all four D (train.py:113-122)
+        others = [type(model)() for _ in range(n_copies - 1)]
+        params = [p for m in [model] + others for p in m.parameters()]
+        opt = torch.optim.Adam(params, lr=2e-4 if n_copies == 2 else 1e-4, betas=(0.5, 0.999))
+        for m in [model] + others:
+            for pn, p in m.named_parameters():
+                if not pn.startswith("downSample4."):
+                    p.grad = torch.ones_like(p)
+        opt.step()
+        path = saver.save(3, model, opt, None, "cpu", name)
+        r = ref[name]
+        assert os.path.basename(path) == r["file_name"]
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        assert list(ck.keys()) == r["top_level_keys"]
+        assert ck["ckpt_info"] == r["ckpt_info"] and ck["model_class"] == r["model_class"] and ck["lr_scheduler"] is r["lr_scheduler"]
+        assert type(ck["model_state"]).__name__ == r["model_state_type"]
+        assert {k: _describe(v) for k, v in ck["model_state"].items()} == r["model_state"]
+        assert list(ck["model_state"].keys()) == r["model_state_order"]
+        st = ck["optimizer"]["state"]
+        assert list(ck["optimizer"].keys()) == r["optimizer_keys"] and sorted(st.keys()) == r["optimizer_state_indices"]
+        assert {k: _describe(v) for k, v in st[sorted(st)[0]].items()} == r["optimizer_state_entry"]
+        assert {str(i): list(st[i]["exp_avg"].shape) for i in sorted(st)} == r["optimizer_state_shapes"]
+        grp = ck["optimizer"]["param_groups"][0]
+        want = dict(r["param_group"])
+        if n_copies == 4:
+            want["lr"] = dict(want["lr"], value=1e-4)
+        assert {k: _describe(v) for k, v in grp.items()} == want
+        assert sorted(grp.keys()) == plain["adam_group_keys"]            # recorded from the unmodified train() run as well
 
 
 def test_logger_counters(tmp_path):

@@ -27,7 +27,27 @@ def test_schedule_replays_reference_decay_trace(golden_dir):
 
 
 def test_schedule_resume_and_world_size():
+    s1 = StepSchedule(n_samples=81, batch_size=1, start_epoch=3, dataset_len=81, world_size=1)
+    assert s1.global_step == 162                                 # base_logger.py:55-56
     s = StepSchedule(n_samples=81, batch_size=1, start_epoch=3, dataset_len=81, world_size=8)
-    assert s.global_step == 162                                  # base_logger.py:55-56
+    assert s.global_step == 162 * 8                              # an epoch advances global_step by dataset_len * world
     s.end_iteration()
-    assert s.global_step == 170                                  # every rank consumed batch_size samples
+    assert s.global_step == 162 * 8 + 8                          # every rank consumed batch_size samples
+
+
+def test_resumed_global_step_equals_the_uninterrupted_counter_under_data_parallelism():
+    """with R ranks the resumed counter used to be R times too small (identity loss switched back on, LR decay
+    start shifted).  Two epochs of 81 single-sample iterations on 2 ranks, then a resume at epoch 3."""
+    from argparse import Namespace
+    import os
+    import tempfile
+    from logger.train_logger import TrainLogger
+    run = StepSchedule(n_samples=81, batch_size=1, start_epoch=1, dataset_len=81, world_size=2)
+    for _ in range(2 * 81):
+        run.end_iteration()
+    resumed = StepSchedule(n_samples=81, batch_size=1, start_epoch=3, dataset_len=81, world_size=2)
+    assert resumed.global_step == run.global_step == 324
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "n"))
+        lg = TrainLogger(Namespace(batch_size=1, save_dir=d, name="n", start_epoch=3, steps_per_print=1, num_epochs=5), 81, world_size=2)
+        assert lg.global_step == run.global_step
