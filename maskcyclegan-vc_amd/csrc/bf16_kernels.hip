@@ -1,0 +1,634 @@
+// bf16 inference kernels of the Generator for gfx950 (MI355X): NHWC bf16 activations, v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation, fp32 InstanceNorm statistics.  Replaces, for `generator(real, ones)` of the reference's inference driver
+// (mask_cyclegan_vc/test.py:85-119 -> model.py:239-280), the fp32 path when the caller asks for bf16 (BASELINE configs[4]).
+//
+// Convolution = implicit GEMM, im2col-free:  M = output channel, N = output pixel, K = (kh, ci-chunk, kw, ci).
+//   * activations are channel-innermost, so the 8 consecutive k of one MFMA operand lane are 8 consecutive input channels of
+//     ONE pixel: a 16-byte LDS read; every tap (kh, kw) of the filter reads a SHIFTED window of the same staged input patch.
+//   * LDS rows are 64 bytes (32 channels) per pixel / per (weight row, tap); the four 16-byte chunks of a row are XOR-swizzled
+//     with bits 2-3 of the row index, which makes the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte bank slots
+//     (stride-1 pixels and odd KW; stride-2 pixel reads are 2-way).
+//   * weights stream per (kh, ci-chunk) stage through registers into a double buffer: the global loads of stage s+1 are in
+//     flight while the MFMAs of stage s run; one __syncthreads() per stage.
+#include "mcvc_common.h"
+#include "bf16.h"
+#include "trace.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+__device__ __forceinline__ bf16_t f2bf(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);      // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                               // round to nearest even
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f)
+{
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(w[i] << 16); f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ uint4 pack8(const float* f)
+{
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(f[2 * i]) | ((unsigned)f2bf(f[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ======================================================================================================================
+// convolution
+// ======================================================================================================================
+constexpr int kConvThreads = 256;
+
+template <int WM, int WN, int MT, int NT>
+__global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvArgs a)
+{
+    static_assert(WM * WN == 4, "four waves");
+    static_assert(WN * NT * 32 == 128, "128-pixel tile");
+    constexpr int BM = WM * MT * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // ---- block -> (output-channel tile, pixel tile).  Workgroup b runs on XCD b % 8 (observed placement, speed only): when the
+    // number of channel tiles divides 8, the workgroups of one XCD all use ONE weight slice, which then stays in that XCD's L2.
+    const int n_co = a.Cout_pad / BM;
+    const int n_px = a.N * a.tiles_h * a.tiles_w;
+    int co_tile, px_tile;
+    {
+        const int b = blockIdx.x;
+        if (n_co <= 8 && (8 % n_co) == 0 && (n_px % (8 / n_co)) == 0) {
+            const int xcd = b & 7, j = b >> 3, per = 8 / n_co;
+            co_tile = xcd % n_co;
+            px_tile = j * per + xcd / n_co;
+        } else {
+            co_tile = b % n_co;
+            px_tile = b / n_co;
+        }
+    }
+    const int co0 = co_tile * BM;
+    const int TW = 1 << a.tw_log2;
+    const int n_img = px_tile / (a.tiles_h * a.tiles_w);
+    const int trem = px_tile - n_img * (a.tiles_h * a.tiles_w);
+    const int oh0 = (trem / a.tiles_w) * a.TH, ow0 = (trem % a.tiles_w) * TW;
+    const int ih0 = oh0 * a.stride - a.pad_h, iw0 = ow0 * a.stride - a.pad_w;
+
+    const int patch_px = a.PH * a.PW;
+    unsigned char* Xs = smem;                                             // [patch_px][64 B]
+    const int wbuf_bytes = BM * a.KW * 64;
+    unsigned char* Ws = smem + (((size_t)patch_px * 64 + 255) & ~(size_t)255);   // 2 x [BM][KW][64 B]
+
+    const int ncc = a.Cin >> 5;
+    const int nstage = ncc * a.KH;                                        // stage = (cc, kh): KW taps x 32 input channels
+    const int w_pieces = BM * a.KW * 4;                                   // 16-byte pieces per weight stage
+    constexpr int MAXWP = 10;                                             // pieces per thread kept in registers (BM*KW*4 <= 2560)
+    uint4 wreg[MAXWP];
+
+    auto load_w = [&](int stage) {
+        const int cc = stage / a.KH, kh = stage - cc * a.KH;
+#pragma unroll
+        for (int i = 0; i < MAXWP; ++i) {
+            const int q = tid + i * kConvThreads;
+            if (q < w_pieces) {
+                const int row = q / (a.KW * 4), rem = q - row * (a.KW * 4);
+                const int tap = rem >> 2, pos = rem & 3;
+                const int lc = pos ^ ((row >> 2) & 3);
+                const bf16_t* src = a.w + ((((long long)(co0 + row) * a.KH + kh) * ncc + cc) * a.KW + tap) * 32 + lc * 8;
+                wreg[i] = *reinterpret_cast<const uint4*>(src);
+            }
+        }
+    };
+    auto store_w = [&](int buf) {
+        unsigned char* dst = Ws + buf * wbuf_bytes;
+#pragma unroll
+        for (int i = 0; i < MAXWP; ++i) {
+            const int q = tid + i * kConvThreads;
+            if (q < w_pieces) *reinterpret_cast<uint4*>(dst + (size_t)q * 16) = wreg[i];
+        }
+    };
+    auto stage_patch = [&](int cc) {
+        const bf16_t* xb = a.x + (long long)n_img * a.x_sn + cc * 32;
+        for (int q = tid; q < patch_px * 4; q += kConvThreads) {
+            const int pp = q >> 2, pos = q & 3;
+            const int pr = pp / a.PW, pc = pp - pr * a.PW;
+            const int ih = ih0 + pr, iw = iw0 + pc;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+                const int lc = pos ^ ((pp >> 2) & 3);
+                v = *reinterpret_cast<const uint4*>(xb + (long long)ih * a.x_sh + (long long)iw * a.x_sw + lc * 8);
+            }
+            *reinterpret_cast<uint4*>(Xs + (size_t)q * 16) = v;
+        }
+    };
+
+    // ---- per-lane operand coordinates
+    int rowA[MT], gA[MT], ppB[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { rowA[mt] = (wm * MT + mt) * 32 + l31; gA[mt] = (rowA[mt] >> 2) & 3; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = (wn * NT + nt) * 32 + l31;
+        const int pr = n >> a.tw_log2, pc = n & (TW - 1);
+        ppB[nt] = pr * a.stride * a.PW + pc * a.stride;
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    load_w(0);
+    for (int stage = 0; stage < nstage; ++stage) {
+        const int cc = stage / a.KH, kh = stage - cc * a.KH;
+        const int buf = stage & 1;
+        if (kh == 0) {
+            if (stage > 0) __syncthreads();                 // every wave is done reading the previous chunk's patch
+            stage_patch(cc);
+        }
+        store_w(buf);
+        __syncthreads();
+        if (stage + 1 < nstage) load_w(stage + 1);          // in flight during the MFMAs below
+        const unsigned char* Wb = Ws + buf * wbuf_bytes;
+        for (int tap = 0; tap < a.KW; ++tap) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int lc = ks * 2 + half;
+                bf16x8 av[MT], bv[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    av[mt] = *reinterpret_cast<const bf16x8*>(Wb + (size_t)(((rowA[mt] * a.KW + tap) << 2) + (lc ^ gA[mt])) * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int pp = ppB[nt] + kh * a.PW + tap;
+                    bv[nt] = *reinterpret_cast<const bf16x8*>(Xs + (size_t)((pp << 2) + (lc ^ ((pp >> 2) & 3))) * 16);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias (+ fused GLU), bf16 NHWC store.  Accumulator register r of a lane is output row
+    //      (r & 3) + 8 * (r >> 2) + 4 * half of the 32-row tile, column l31: four consecutive channels per r >> 2 -> 8-byte stores.
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = (wn * NT + nt) * 32 + l31;
+        const int oh = oh0 + (n >> a.tw_log2), ow = ow0 + (n & (TW - 1));
+        if (oh >= a.OH || ow >= a.OW) continue;
+        bf16_t* yp = a.y + (long long)n_img * a.y_sn + (long long)oh * a.y_sh + (long long)ow * a.y_sw;
+        if (a.glu) {
+            if constexpr (MT == 2) {
+                const int cbase = (co0 >> 1) + wm * 32;             // 64-row block = [32 value | 32 gate] rows of channels cbase..+31
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = cbase + 8 * q + 4 * half;
+                    if (c < a.Cout) {
+                        float o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v = acc[0][nt][4 * q + j], g = acc[1][nt][4 * q + j];
+                            if (a.bias) { v += a.bias[co0 + wm * 64 + 8 * q + 4 * half + j]; g += a.bias[co0 + wm * 64 + 32 + 8 * q + 4 * half + j]; }
+                            o[j] = v * sigmoidf_(g);
+                        }
+                        uint2 pk;
+                        pk.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+                        pk.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+                        *reinterpret_cast<uint2*>(yp + c) = pk;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = co0 + (wm * MT + mt) * 32 + 8 * q + 4 * half;
+                    if (co < a.Cout) {                               // Cout % 4 == 0 (checked on the host)
+                        float o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = acc[mt][nt][4 * q + j] + (a.bias ? a.bias[co + j] : 0.f);
+                        uint2 pk;
+                        pk.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+                        pk.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+                        *reinterpret_cast<uint2*>(yp + co) = pk;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MT, int NT>
+int conv_launch_t(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
+{
+    constexpr int BM = WM * MT * 32;
+    auto kern = bf16_conv_kernel<WM, WN, MT, NT>;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    const unsigned grid = (unsigned)((a.Cout_pad / BM) * a.N * a.tiles_h * a.tiles_w);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kConvThreads), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+void mcvc_bf16_conv_tile(int OH, int OW, int KH, int KW, int stride, int* TH, int* tw_log2)
+{
+    // candidates TH x TW = 128 pixels; fewest tiles (least overhang) first, then the smallest staged input patch
+    long long best_cost = -1;
+    for (int l = 3; l <= 7; ++l) {
+        const int tw = 1 << l, th = 128 >> l;
+        const long long tiles = (long long)cdiv_i(OH, th) * cdiv_i(OW, tw);
+        const long long patch = (long long)((th - 1) * stride + KH) * ((tw - 1) * stride + KW);
+        if (patch * 64 > 96 * 1024) continue;
+        const long long cost = tiles * 4096 + patch;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; *tw_log2 = l; *TH = th; }
+    }
+}
+
+int mcvc_bf16_conv_launch(const Bf16ConvArgs& a0, hipStream_t s)
+{
+    Bf16ConvArgs a = a0;
+    if ((a.Cin & 31) || (a.Cout & 3) || a.KW < 1 || a.KH < 1) return MCVC_ERR_INVALID;
+    const int TW = 1 << a.tw_log2;
+    if (a.TH * TW != 128) return MCVC_ERR_INVALID;
+    a.tiles_h = cdiv_i(a.OH, a.TH); a.tiles_w = cdiv_i(a.OW, TW);
+    a.PH = (a.TH - 1) * a.stride + a.KH; a.PW = (TW - 1) * a.stride + a.KW;
+    const bool big = (a.Cout_pad % 128) == 0;
+    const int BM = big ? 128 : 32;
+    if (a.Cout_pad % BM) return MCVC_ERR_INVALID;
+    if (a.glu && !big) return MCVC_ERR_INVALID;
+    if (BM * a.KW * 4 > 10 * kConvThreads) return MCVC_ERR_INVALID;
+    const size_t lds = (((size_t)a.PH * a.PW * 64 + 255) & ~(size_t)255) + 2 * (size_t)BM * a.KW * 64;
+    if (lds > 160 * 1024) return MCVC_ERR_INVALID;
+    const double px = (double)a.N * a.OH * a.OW;
+    TraceScope ts(K_CONV_L, s, 2.0 * px * a.Cout_pad * a.Cin * a.KH * a.KW,
+                  2.0 * ((double)a.N * a.H * a.W * a.Cin + px * a.Cout + (double)a.Cout_pad * a.Cin * a.KH * a.KW));
+    return big ? conv_launch_t<2, 2, 2, 2>(a, lds, s) : conv_launch_t<1, 4, 1, 1>(a, lds, s);
+}
+
+// ======================================================================================================================
+// InstanceNorm + activation (NHWC bf16)
+// ======================================================================================================================
+namespace {
+
+// normalised-channel index of conv channel cx: shuffle -> cx / 4, else cx (GLU gate channels: C + c)
+// Statistics pass: block = 32 pixel lanes x 8 channel octets (64 conv channels); grid (channel groups, S splits, N).
+__global__ void __launch_bounds__(256) bf16_stats_kernel(const Bf16NormArgs a)
+{
+    __shared__ float red[32 * 64 * 2];
+    const int tid = threadIdx.x;
+    const int oct = tid & 7, pl = tid >> 3;
+    const int c0 = blockIdx.x * 64 + oct * 8;
+    const int n = blockIdx.z;
+    const int P = a.H * a.W;
+    const int per = (P + a.S - 1) / a.S;
+    const int p_begin = blockIdx.y * per;
+    int p_end = p_begin + per; if (p_end > P) p_end = P;
+    float s1[8], s2[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; sh[j] = 0.f; }
+    const bool live = c0 < a.Cx;
+    if (live) {
+        const bf16_t* xb = a.x + (long long)n * a.x_sn + c0;
+        {   // common shift of every thread / split for these channels: the first pixel's value (shuffle: of the group's first channel)
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(xb), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sh[j] = a.shuffle ? f[j & ~3] : f[j];
+        }
+        for (int p = p_begin + pl; p < p_end; p += 32) {
+            const int h = p / a.W, w = p - h * a.W;
+            float f[8];
+            unpack8(*reinterpret_cast<const uint4*>(xb + (long long)h * a.x_sh + (long long)w * a.x_sw), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = f[j] - sh[j]; s1[j] += d; s2[j] += d * d; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[(pl * 64 + oct * 8 + j) * 2] = s1[j]; red[(pl * 64 + oct * 8 + j) * 2 + 1] = s2[j]; }
+    __syncthreads();
+    if (tid < 128) {
+        const int ch = tid >> 1, k = tid & 1;
+        float t = 0.f;
+        for (int i = 0; i < 32; ++i) t += red[(i * 64 + ch) * 2 + k];
+        red[ch * 2 + k] = t;                    // (row 0 of the array is its own destination: each thread only re-writes what it summed)
+    }
+    __syncthreads();
+    // normalised channels of this block: shuffle -> 16 (sum over the 4 conv channels), else 64
+    const int Cn = a.shuffle ? a.Cx / 4 : a.Cx;
+    const int ncn = a.shuffle ? 16 : 64;
+    if (tid < ncn * 2) {
+        const int cn_l = tid >> 1, k = tid & 1;
+        float t;
+        if (a.shuffle) t = red[(4 * cn_l) * 2 + k] + red[(4 * cn_l + 1) * 2 + k] + red[(4 * cn_l + 2) * 2 + k] + red[(4 * cn_l + 3) * 2 + k];
+        else t = red[cn_l * 2 + k];
+        const int cn = (a.shuffle ? blockIdx.x * 16 : blockIdx.x * 64) + cn_l;
+        if (cn < Cn) a.partial[(((long long)n * a.S + blockIdx.y) * Cn + cn) * 2 + k] = t;
+    }
+}
+
+// stats[n][cn] = (mean, rstd) from the S partials and the shift (re-read from the first pixel)
+__global__ void __launch_bounds__(256) bf16_finalize_kernel(const Bf16NormArgs a)
+{
+    const int Cn = a.shuffle ? a.Cx / 4 : a.Cx;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.N * Cn) return;
+    const int n = (int)(i / Cn), cn = (int)(i - (long long)n * Cn);
+    float s1 = 0.f, s2 = 0.f;
+    for (int s = 0; s < a.S; ++s) {
+        const float* p = a.partial + (((long long)n * a.S + s) * Cn + cn) * 2;
+        s1 += p[0]; s2 += p[1];
+    }
+    const float cnt = (float)a.H * a.W * (a.shuffle ? 4.f : 1.f);
+    const float shift = bf2f(a.x[(long long)n * a.x_sn + (a.shuffle ? 4 * cn : cn)]);
+    const float m = s1 / cnt;
+    float var = s2 / cnt - m * m;
+    if (var < 0.f) var = 0.f;
+    a.stats[i * 2] = shift + m;
+    a.stats[i * 2 + 1] = 1.0f / sqrtf(var + a.eps);
+}
+
+// one thread = one pixel x 8 OUTPUT channels (16-byte store); shuffle: 32 conv channels in, 4 output pixels
+__global__ void __launch_bounds__(256) bf16_apply_kernel(const Bf16NormArgs a)
+{
+    const int C = a.shuffle ? a.Cx / 4 : (a.act == BF16_ACT_GLU ? a.Cx / 2 : a.Cx);      // output channels
+    const int noct = C >> 3;
+    const long long total = (long long)a.N * a.H * a.W * noct;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int oct = (int)(idx % noct);
+        const long long pix = idx / noct;
+        const int P = a.H * a.W;
+        const int n = (int)(pix / P), p = (int)(pix - (long long)n * P);
+        const int h = p / a.W, w = p - h * a.W;
+        const int c0 = oct * 8;
+        const bf16_t* xp = a.x + (long long)n * a.x_sn + (long long)h * a.x_sh + (long long)w * a.x_sw;
+        float g0[8], b0[8], mean0[8], rstd0[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (a.has_norm) {
+                g0[j] = a.gamma[0][c0 + j]; b0[j] = a.beta[0][c0 + j];
+                const float* st = a.stats + ((long long)n * (a.act == BF16_ACT_GLU ? 2 * C : C) + c0 + j) * 2;
+                mean0[j] = st[0]; rstd0[j] = st[1];
+            } else { g0[j] = 1.f; b0[j] = 0.f; mean0[j] = 0.f; rstd0[j] = 1.f; }
+        }
+        auto out_ptr = [&](int oh, int ow) {
+            long long o = (long long)n * a.y_sn + (long long)oh * a.y_sh + (long long)ow * a.y_sw;
+            if (a.y_csplit > 0) o += (long long)(c0 / a.y_csplit) * a.y_sc2 + (c0 % a.y_csplit); else o += c0;
+            return o;
+        };
+        if (a.shuffle) {
+            float f[32];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) unpack8(*reinterpret_cast<const uint4*>(xp + 4 * c0 + 8 * q), f + 8 * q);
+#pragma unroll
+            for (int ij = 0; ij < 4; ++ij) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float z = (f[4 * j + ij] - mean0[j]) * rstd0[j] * g0[j] + b0[j];
+                    o[j] = (a.act == BF16_ACT_SILU) ? z * sigmoidf_(z) : z;
+                }
+                *reinterpret_cast<uint4*>(a.y + out_ptr(2 * h + (ij >> 1), 2 * w + (ij & 1))) = pack8(o);
+            }
+        } else {
+            float f[8], o[8];
+            unpack8(*reinterpret_cast<const uint4*>(xp + c0), f);
+            if (a.act == BF16_ACT_GLU) {
+                float fg[8];
+                unpack8(*reinterpret_cast<const uint4*>(xp + C + c0), fg);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float zg = fg[j];
+                    if (a.has_norm) {
+                        const float* st = a.stats + ((long long)n * 2 * C + C + c0 + j) * 2;
+                        zg = (fg[j] - st[0]) * st[1] * a.gamma[1][c0 + j] + a.beta[1][c0 + j];
+                    }
+                    const float z = (f[j] - mean0[j]) * rstd0[j] * g0[j] + b0[j];
+                    o[j] = z * sigmoidf_(zg);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float z = (f[j] - mean0[j]) * rstd0[j] * g0[j] + b0[j];
+                    o[j] = (a.act == BF16_ACT_SILU) ? z * sigmoidf_(z) : z;
+                }
+            }
+            const long long yo = out_ptr(h, w);
+            if (a.res) {
+                float r[8];
+                unpack8(*reinterpret_cast<const uint4*>(a.res + yo), r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += r[j];
+            }
+            *reinterpret_cast<uint4*>(a.y + yo) = pack8(o);
+        }
+    }
+}
+
+}  // namespace
+
+int mcvc_bf16_norm_splits(int N, int P, int Cn)
+{
+    // enough workgroups to fill the chip, at least 64 pixels per split
+    const int groups = N * cdiv_i(Cn, 64);
+    int S = cdiv_i(1024, groups > 0 ? groups : 1);
+    const int cap = cdiv_i(P, 64);
+    if (S > cap) S = cap;
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    return S;
+}
+
+long long mcvc_bf16_norm_partial_floats(const Bf16NormArgs& a)
+{
+    const int Cn = a.shuffle ? a.Cx / 4 : a.Cx;
+    return (long long)a.N * a.S * Cn * 2;
+}
+
+int mcvc_bf16_norm_launch(const Bf16NormArgs& a, hipStream_t s)
+{
+    if ((a.Cx & 7) || (a.shuffle && (a.Cx & 31))) return MCVC_ERR_INVALID;
+    const int C = a.shuffle ? a.Cx / 4 : (a.act == BF16_ACT_GLU ? a.Cx / 2 : a.Cx);
+    if (C & 7) return MCVC_ERR_INVALID;
+    const double el = (double)a.N * a.H * a.W * a.Cx;
+    if (a.has_norm) {
+        if (a.S < 1) return MCVC_ERR_INVALID;
+        {
+            TraceScope ts(K_NORM_FWD, s, 0.0, 2.0 * el);
+            hipLaunchKernelGGL(bf16_stats_kernel, dim3((unsigned)cdiv_i(a.Cx, 64), (unsigned)a.S, (unsigned)a.N), dim3(256), 0, s, a);
+        }
+        const int Cn = a.shuffle ? a.Cx / 4 : a.Cx;
+        hipLaunchKernelGGL(bf16_finalize_kernel, dim3((unsigned)cdiv_ll((long long)a.N * Cn, 256)), dim3(256), 0, s, a);
+    }
+    const long long work = (long long)a.N * a.H * a.W * (C >> 3);
+    long long blocks = cdiv_ll(work, 256);
+    if (blocks > 8192) blocks = 8192;
+    TraceScope ts(K_NORM_FWD, s, 0.0, 2.0 * (el + (double)a.N * a.H * a.W * C * (a.shuffle ? 4.0 : 1.0)));
+    hipLaunchKernelGGL(bf16_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+// ======================================================================================================================
+// edges
+// ======================================================================================================================
+namespace {
+
+__global__ void __launch_bounds__(256) bf16_prep_kernel(const float* __restrict__ x, const float* __restrict__ mask, bf16_t* __restrict__ xin,
+                                                        int B, int H, int W)
+{
+    // one thread = one (pixel, octet of the 32 folded channels): channels kw*2 + ci, kw = 4*oct .. 4*oct+3
+    const long long total = (long long)B * H * W * 4;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int oct = (int)(idx & 3);
+        const long long pix = idx >> 2;
+        const int w = (int)(pix % W);
+        const long long row = pix / W;              // b*H + h
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kw = oct * 4 + j;
+            const int iw = w + kw - 7;
+            float xv = 0.f, mv = 0.f;
+            if (kw < 15 && iw >= 0 && iw < W) {
+                mv = mask ? mask[row * W + iw] : 1.0f;
+                xv = x[row * W + iw] * mv;
+            }
+            o[2 * j] = xv; o[2 * j + 1] = mv;
+        }
+        *reinterpret_cast<uint4*>(xin + pix * 32 + oct * 8) = pack8(o);
+    }
+}
+
+__global__ void __launch_bounds__(256) bf16_last_kernel(const bf16_t* __restrict__ z, const float* __restrict__ bias, float* __restrict__ out,
+                                                        int B, int H, int W)
+{
+    const long long total = (long long)B * H * W;
+    const float b = bias ? bias[0] : 0.f;
+    for (long long pix = (long long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long long)gridDim.x * 256) {
+        const int w = (int)(pix % W);
+        const long long row = pix / W;
+        float s = b;
+#pragma unroll
+        for (int kw = 0; kw < 15; ++kw) {
+            const int iw = w + kw - 7;
+            if (iw >= 0 && iw < W) s += bf2f(z[(row * W + iw) * 32 + kw]);
+        }
+        out[pix] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) bf16_pack_kernel(const Bf16PackArgs a)
+{
+    const int ncc = a.Cin >> 5;
+    const long long total = (long long)a.Cout_pad * a.KH * ncc * a.KW * 32;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx & 31);
+        long long t = idx >> 5;
+        const int kw = (int)(t % a.KW); t /= a.KW;
+        const int cc = (int)(t % ncc); t /= ncc;
+        const int kh = (int)(t % a.KH);
+        int row = (int)(t / a.KH);
+        const int k = cc * 32 + j;                   // packed input-channel index
+        if (a.glu_interleave) {                      // packed row -> logical row of the [value | gate] concatenation
+            const int blk = row >> 6, r = row & 63;
+            row = (r < 32) ? (blk * 32 + r) : (a.Cout_pad / 2 + blk * 32 + (r - 32));
+        }
+        float v = 0.f;
+        if (a.kind == BF16_PACK_KW_OUT) {
+            if (row < a.KW_src && k < a.Cin_src) v = a.w[0][((long long)k * a.KH + kh) * a.KW_src + row];            // [0][ci][kh][kw = row]
+        } else {
+            int br = 0, co = row;
+            if (a.kind == BF16_PACK_HC_OUT) { if (row < a.Cout_src) co = (row & 255) * 20 + (row >> 8); }               // row = h*256 + c  <- c*20 + h
+            if (a.nbr == 2) { const int halfc = a.glu_interleave ? a.Cout_pad / 2 : a.Cout_src; br = co >= halfc ? 1 : 0; co -= br * halfc; }
+            if (co < a.Cout_src) {
+                if (a.kind == BF16_PACK_FOLD_KW) {
+                    const int skw = k / a.Cin_src, ci = k - skw * a.Cin_src;
+                    if (skw < a.KW_src) v = a.w[br][(((long long)co * a.Cin_src + ci) * a.KH + kh) * a.KW_src + skw];
+                } else if (a.kind == BF16_PACK_HC_IN) {
+                    if (k < a.Cin_src) { const int ci = (k & 255) * 20 + (k >> 8); v = a.w[br][(long long)co * a.Cin_src + ci]; }
+                } else {
+                    if (k < a.Cin_src) v = a.w[br][(((long long)co * a.Cin_src + k) * a.KH + kh) * a.KW_src + kw];
+                }
+            }
+        }
+        a.dst[idx] = f2bf(v);
+    }
+}
+
+// kind PLAIN: dst = [src | src2] (src2 optional, n_src elements each); HC_OUT: dst[h*256 + c] = src[c*20 + h];
+// kind -1 (GLU interleave): 64-element blocks = [32 of src | 32 of src2]
+__global__ void __launch_bounds__(256) bf16_vec_kernel(const float* __restrict__ src, const float* __restrict__ src2, float* __restrict__ dst,
+                                                       int n_src, int n_dst, int kind)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_dst) return;
+    float v = 0.f;
+    if (kind == -1) {
+        const int blk = i >> 6, r = i & 63, c = blk * 32 + (r & 31);
+        if (c < n_src) v = (r < 32) ? src[c] : src2[c];
+    } else if (kind == BF16_PACK_HC_OUT) {
+        if (i < n_src) v = src[(i & 255) * 20 + (i >> 8)];
+    } else {
+        if (i < n_src) v = src[i];
+        else if (src2 && i < 2 * n_src) v = src2[i - n_src];
+    }
+    dst[i] = v;
+}
+
+static unsigned ew_blocks(long long total)
+{
+    long long b = cdiv_ll(total, 256);
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+int mcvc_bf16_prep_launch(const float* x, const float* mask, bf16_t* xin, int B, int H, int W, hipStream_t s)
+{
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, (double)B * H * W * (8.0 + 64.0));
+    hipLaunchKernelGGL(bf16_prep_kernel, dim3(ew_blocks((long long)B * H * W * 4)), dim3(256), 0, s, x, mask, xin, B, H, W);
+    return (int)hipGetLastError();
+}
+
+int mcvc_bf16_last_launch(const bf16_t* z, const float* bias, float* out, int B, int H, int W, hipStream_t s)
+{
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, (double)B * H * W * (64.0 + 4.0));
+    hipLaunchKernelGGL(bf16_last_kernel, dim3(ew_blocks((long long)B * H * W)), dim3(256), 0, s, z, bias, out, B, H, W);
+    return (int)hipGetLastError();
+}
+
+int mcvc_bf16_pack_launch(const Bf16PackArgs& a, hipStream_t s)
+{
+    if ((a.Cin & 31) || a.nbr < 1 || a.nbr > 2) return MCVC_ERR_INVALID;
+    const long long total = (long long)a.Cout_pad * a.KH * (a.Cin >> 5) * a.KW * 32;
+    hipLaunchKernelGGL(bf16_pack_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_bf16_vec_launch(const float* src, const float* src2, float* dst, int n_src, int n_dst, int kind, hipStream_t s)
+{
+    hipLaunchKernelGGL(bf16_vec_kernel, dim3((unsigned)cdiv_i(n_dst, 256)), dim3(256), 0, s, src, src2, dst, n_src, n_dst, kind);
+    return (int)hipGetLastError();
+}

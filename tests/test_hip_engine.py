@@ -123,7 +123,7 @@ def test_step_full_tensor_parity_vs_oracle(golden_dir, B, T):
     so = orc.StepOracle(onets, skip_wasted=True)
     before = {n: {k: v.clone() for k, v in onets[n].items()} for n in onets}
     g_ref, d_ref, g_grads, d_grads = so.step(*batch, return_grads=True)
-    eng = TrainEngine(nets, B, T, schedule=StepSchedule(batch_size=B, n_samples=4))
+    eng = TrainEngine(nets, B, T, schedule=StepSchedule(batch_size=B, n_samples=4 * B))
     # the iteration, phase by phase (what eng.step() does), so that the discriminator phase can start from the ORACLE's
     # updated generators: Adam's first step is lr*sign(g), i.e. rounding-level differences in near-zero generator gradients
     # become +-2e-4 parameter differences, and comparing discriminator gradients downstream of two such generator sets
@@ -239,7 +239,7 @@ def test_large_batch_generator_phase_is_the_mean_of_single_sample_phases():
 
 def _three_steps(defer, seeds, B=1):
     nets = _nets(seeds)
-    eng = TrainEngine(nets, B, 64, schedule=StepSchedule(batch_size=B, n_samples=4))
+    eng = TrainEngine(nets, B, 64, schedule=StepSchedule(batch_size=B, n_samples=4 * B))
     eng.defer_d_update = defer
     losses = []
     for it in range(3):
