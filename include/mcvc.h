@@ -84,6 +84,30 @@ int mcvc_gen_backward_overlap(const float* const* params, const float* packed, f
                               float* scratch, long long scratch_floats, int B, int T, void* stream, void* aux_stream,
                               void* const* milestones);
 
+/* ---- Generator inference in bf16 (BASELINE configs[4]: generator_A2B, bs=16, 80 x 512 frames).  Replaces the call
+ *      `generator(real, ones_like(real))` of the reference's inference driver (mask_cyclegan_vc/test.py:92, 107 ->
+ *      Generator.forward, model.py:239-280) when the caller asks for bf16: NHWC bf16 activations, bf16 MFMA with fp32
+ *      accumulation, fp32 InstanceNorm statistics; x / mask / out stay fp32 [B,80,T] at the boundary.
+ *      packed: mcvc_gen_bf16_packed_bytes() bytes, refreshed with mcvc_gen_bf16_pack after every parameter change
+ *      (weights are cast from the fp32 parameters); workspace: mcvc_gen_bf16_workspace_bytes(B, T) bytes, 256-byte aligned;
+ *      mask NULL = all ones.  No gradient path.                                                               */
+long long mcvc_gen_bf16_packed_bytes(void);
+long long mcvc_gen_bf16_workspace_bytes(int B, int T);
+int mcvc_gen_bf16_pack(const float* const* params, void* packed, void* stream);
+int mcvc_gen_infer_bf16(const float* const* params, const void* packed, const float* x, const float* mask, float* out, void* workspace,
+                        long long workspace_bytes, int B, int T, void* stream);
+
+/*      single-op entry points of the bf16 path (kernel parity tests; same kernels the forward uses).  Tensors are NHWC bf16
+ *      (raw 16-bit storage = torch.bfloat16): y[N][OH][OW][Cout] = conv2d(x[N][H][W][Cin], w[Cout][Cin][KH][KW] fp32 -> bf16) + bias;
+ *      Cin % 32 == 0, Cout % 4 == 0; wpack: mcvc_bf16_conv2d_pack_bytes() bytes of scratch.                      */
+long long mcvc_bf16_conv2d_pack_bytes(int Cout, int Cin, int KH, int KW);
+int mcvc_bf16_conv2d(const void* x, const float* w, const float* bias, void* y, void* wpack, int N, int H, int W, int Cin, int Cout,
+                     int KH, int KW, int stride, int pad_h, int pad_w, void* stream);
+/*      y = act(InstanceNorm(x)) (+ residual): act 0 none, 1 gated GLU (Cx = 2C: value | gate), 2 x*sigmoid(x); pixel_shuffle != 0:
+ *      the normalised tensor is PixelShuffle(2)(x), output [N][2H][2W][Cx/4].  scratch: N * 65 * Cx * 2 floats.      */
+int mcvc_bf16_instnorm_act(const void* x, const float* gamma, const float* beta, const float* gamma_gate, const float* beta_gate,
+                           const void* residual, void* y, float* scratch, int N, int H, int W, int Cx, int act, int pixel_shuffle, void* stream);
+
 /* ---- Discriminator: replaces Discriminator.forward (model.py:340-349) and its autograd
  *      x: [B,80,T]; out: [B,1,10,T8] sigmoid probabilities                                          */
 int mcvc_disc_forward(const float* const* params, const float* packed, const float* x, float* out,

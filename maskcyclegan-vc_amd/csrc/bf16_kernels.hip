@@ -94,19 +94,22 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     constexpr int MAXWP = 10;                                             // pieces per thread kept in registers (BM*KW*4 <= 2560)
     uint4 wreg[MAXWP];
 
+    // piece -> (weight row, tap, swizzled chunk) is stage-invariant: element offsets computed once
+    int woff[MAXWP];
+#pragma unroll
+    for (int i = 0; i < MAXWP; ++i) {
+        const int q = tid + i * kConvThreads;
+        const int row = q / (a.KW * 4), rem = q - row * (a.KW * 4);
+        const int tap = rem >> 2, pos = rem & 3;
+        const int lc = pos ^ ((row >> 2) & 3);
+        woff[i] = (q < w_pieces) ? ((co0 + row) * a.KH * ncc * a.KW + tap) * 32 + lc * 8 : -1;
+    }
     auto load_w = [&](int stage) {
         const int cc = stage / a.KH, kh = stage - cc * a.KH;
+        const bf16_t* base = a.w + (long long)(kh * ncc + cc) * a.KW * 32;
 #pragma unroll
-        for (int i = 0; i < MAXWP; ++i) {
-            const int q = tid + i * kConvThreads;
-            if (q < w_pieces) {
-                const int row = q / (a.KW * 4), rem = q - row * (a.KW * 4);
-                const int tap = rem >> 2, pos = rem & 3;
-                const int lc = pos ^ ((row >> 2) & 3);
-                const bf16_t* src = a.w + ((((long long)(co0 + row) * a.KH + kh) * ncc + cc) * a.KW + tap) * 32 + lc * 8;
-                wreg[i] = *reinterpret_cast<const uint4*>(src);
-            }
-        }
+        for (int i = 0; i < MAXWP; ++i)
+            if (woff[i] >= 0) wreg[i] = *reinterpret_cast<const uint4*>(base + woff[i]);
     };
     auto store_w = [&](int buf) {
         unsigned char* dst = Ws + buf * wbuf_bytes;

@@ -259,4 +259,53 @@ int mcvc_gen_infer_bf16(const float* const* params, const void* packed, const fl
     return r.err;
 }
 
+// ---- single-op entry points (kernel parity tests; same kernels the forward uses) -----------------------------------------------
+// y[N][OH][OW][Cout] (bf16 NHWC) = conv2d(x[N][H][W][Cin] bf16 NHWC, w[Cout][Cin][KH][KW] fp32 OIHW -> bf16) + bias
+long long mcvc_bf16_conv2d_pack_bytes(int Cout, int Cin, int KH, int KW)
+{
+    const int cout_pad = (Cout % 128 == 0) ? Cout : ((Cout + 31) / 32) * 32;
+    return 2LL * cout_pad * KH * Cin * KW + 4LL * cout_pad + 512;
+}
+
+int mcvc_bf16_conv2d(const void* x, const float* w, const float* bias, void* y, void* wpack, int N, int H, int W, int Cin, int Cout,
+                     int KH, int KW, int stride, int pad_h, int pad_w, void* stream)
+{
+    if ((Cin & 31) || (Cout & 3) || !x || !w || !y || !wpack) return MCVC_ERR_INVALID;
+    const int cout_pad = (Cout % 128 == 0) ? Cout : ((Cout + 31) / 32) * 32;
+    LayerB l = mkl(BF16_PACK_PLAIN, 0, 1, -1, -1, Cout, Cin, KH, KW, Cin, KW, cout_pad, stride, pad_h, pad_w);
+    l.off_w = 0; l.off_bias = ((2LL * cout_pad * KH * Cin * KW) + 255) & ~255LL;
+    const float* P[2] = {w, bias};
+    Run r{}; r.s = (hipStream_t)stream; r.P = P; r.pk = static_cast<const unsigned char*>(wpack);
+    Bf16PackArgs a{};
+    a.w[0] = w; a.dst = reinterpret_cast<bf16_t*>(wpack); a.kind = BF16_PACK_PLAIN; a.nbr = 1; a.Cout_src = Cout; a.Cin_src = Cin; a.KH = KH; a.KW_src = KW;
+    a.Cout_pad = cout_pad; a.KW = KW; a.Cin = Cin;
+    r.fail(mcvc_bf16_pack_launch(a, r.s));
+    r.fail(mcvc_bf16_vec_launch(bias, nullptr, reinterpret_cast<float*>(static_cast<unsigned char*>(wpack) + l.off_bias), bias ? Cout : 0, cout_pad,
+                                BF16_PACK_PLAIN, r.s));
+    const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
+    conv(r, l, static_cast<const bf16_t*>(x), (long long)H * W * Cin, W * Cin, Cin, N, H, W, static_cast<bf16_t*>(y), (long long)OH * OW * Cout,
+         OW * Cout, Cout, Cout);
+    return r.err;
+}
+
+// y = act(InstanceNorm(x)) on NHWC bf16.  x: [N][H][W][Cx]; act 0 none, 1 gated GLU (Cx = 2C: value | gate), 2 x*sigmoid(x);
+// pixel_shuffle != 0: the normalised tensor is PixelShuffle(2)(x) (C = Cx / 4, output [N][2H][2W][C]).  scratch: N*(64+1)*Cx*2 floats.
+int mcvc_bf16_instnorm_act(const void* x, const float* gamma, const float* beta, const float* gamma_gate, const float* beta_gate,
+                           const void* residual, void* y, float* scratch, int N, int H, int W, int Cx, int act, int pixel_shuffle, void* stream)
+{
+    if (!x || !y || !scratch || !gamma || !beta) return MCVC_ERR_INVALID;
+    const int C = pixel_shuffle ? Cx / 4 : (act == BF16_ACT_GLU ? Cx / 2 : Cx);
+    Bf16NormArgs a{};
+    a.x = static_cast<const bf16_t*>(x); a.x_sn = (long long)H * W * Cx; a.x_sh = W * Cx; a.x_sw = Cx; a.N = N; a.H = H; a.W = W; a.Cx = Cx;
+    a.shuffle = pixel_shuffle ? 1 : 0; a.act = act; a.has_norm = 1;
+    a.gamma[0] = gamma; a.beta[0] = beta; a.gamma[1] = gamma_gate; a.beta[1] = beta_gate;
+    const int Cn = pixel_shuffle ? Cx / 4 : Cx;
+    a.S = mcvc_bf16_norm_splits(N, H * W, Cn);
+    a.partial = scratch; a.stats = scratch + (long long)N * 64 * Cx * 2;
+    a.res = static_cast<const bf16_t*>(residual); a.y = static_cast<bf16_t*>(y);
+    const int OHn = pixel_shuffle ? 2 * H : H, OWn = pixel_shuffle ? 2 * W : W;
+    a.y_sn = (long long)OHn * OWn * C; a.y_sh = OWn * C; a.y_sw = C; a.eps = kEps;
+    return mcvc_bf16_norm_launch(a, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -43,6 +43,13 @@ _SIGS = {
     "mcvc_gen_backward": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p]),
     "mcvc_gen_backward_overlap": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int,
                                           c_void_p, c_void_p, _PP]),
+    "mcvc_gen_bf16_packed_bytes": (c_longlong, []),
+    "mcvc_gen_bf16_workspace_bytes": (c_longlong, [c_int, c_int]),
+    "mcvc_gen_bf16_pack": (c_int, [_PP, c_void_p, c_void_p]),
+    "mcvc_gen_infer_bf16": (c_int, [_PP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
+    "mcvc_bf16_conv2d_pack_bytes": (c_longlong, [c_int, c_int, c_int, c_int]),
+    "mcvc_bf16_conv2d": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
+    "mcvc_bf16_instnorm_act": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
     "mcvc_disc_forward": (c_int, [_PP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "mcvc_disc_backward": (c_int, [_PP, c_void_p, _PP, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p]),
     "mcvc_l1_loss": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

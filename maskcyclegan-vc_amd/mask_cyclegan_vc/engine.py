@@ -266,6 +266,7 @@ class TrainEngine:
         # caches so that a later module-API forward (validation, in-process inference) re-packs from the new values
         for n in (G_NAMES if grp is self.g_group else D_NAMES):
             self.nets[n]._packed_version = None
+            self.nets[n]._bf16_version = None
 
     # ---- the two phases -------------------------------------------------------------------------------
     def generator_phase(self, real_A, mask_A, real_B, mask_B):

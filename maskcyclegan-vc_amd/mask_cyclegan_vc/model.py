@@ -106,6 +106,8 @@ class _NetBase(nn.Module):
         self._packed_version = None
         self._ws = {}
         self._iws = {}
+        self._bf16 = None
+        self._bf16_version = None
 
     def _plist(self):
         ps = list(self.parameters())
@@ -297,8 +299,24 @@ class Generator(_NetBase):
         """Build / refresh the packed weights ``infer`` reads, on the current stream (call before forking inference streams)."""
         if dtype == "f32":
             self.packed_weights()
-        elif dtype != "bf16":
+        elif dtype == "bf16":
+            self._bf16_pack()
+        else:
             raise ValueError("dtype must be 'f32' or 'bf16'")
+
+    def _bf16_pack(self, ps=None):
+        """bf16 weight pack of the inference forward (cast from the fp32 parameters); refreshed when a parameter changed."""
+        ps = ps or self._plist()
+        _hip.require_cuda_f32(*ps)
+        ver = self._param_version(ps)
+        L = lib()
+        if self._bf16 is None or self._bf16.device != ps[0].device:
+            self._bf16 = torch.zeros(L.mcvc_gen_bf16_packed_bytes(), dtype=torch.uint8, device=ps[0].device)
+            self._bf16_version = None
+        if ver != self._bf16_version:
+            check(L.mcvc_gen_bf16_pack(ptr_table(ps), ptr(self._bf16), stream()), "mcvc_gen_bf16_pack")
+            self._bf16_version = ver
+        return self._bf16
 
     def infer(self, x, mask=None, dtype="f32"):
         """Gradient-free forward for the inference driver (reference test.py:85-119 calls ``generator(real, ones_like(real))``
@@ -318,6 +336,18 @@ class Generator(_NetBase):
             stash, scratch = self._infer_workspace(B, T, x.device)
             check(L.mcvc_gen_forward(ptr_table(ps), ptr(packed), ptr(x), ptr(mask.contiguous() if mask is not None else None), ptr(out),
                                      ptr(stash), ptr(scratch), scratch.numel(), B, T, stream()), "mcvc_gen_forward")
+            return out
+        if dtype == "bf16":
+            packed = self._bf16_pack(ps)
+            key = ("bf16", B, T, str(x.device), torch.cuda.current_stream(x.device).cuda_stream)
+            ws = self._iws.get(key)
+            if ws is None:
+                while len(self._iws) >= 4:
+                    self._iws.pop(next(iter(self._iws)))
+                ws = torch.empty(L.mcvc_gen_bf16_workspace_bytes(B, T), dtype=torch.uint8, device=x.device)
+                self._iws[key] = ws
+            check(L.mcvc_gen_infer_bf16(ptr_table(ps), ptr(packed), ptr(x), ptr(mask.contiguous() if mask is not None else None), ptr(out),
+                                        ptr(ws), ws.numel(), B, T, stream()), "mcvc_gen_infer_bf16")
             return out
         raise ValueError("dtype must be 'f32' or 'bf16'")
 
