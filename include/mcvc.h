@@ -43,6 +43,10 @@ int mcvc_version(void);
  * reference's CPU path.  Workspaces are always sized for both modes.  Returns the previous setting.             */
 int mcvc_set_deterministic(int on);
 int mcvc_get_deterministic(void);
+/* Small-batch generator passes (B * T/4 <= 32) run the 1-D trunk (six residual blocks + conv1dto2d, model.py:258-271) as ONE
+ * persistent launch per direction instead of one fused launch per layer (default on; env MCVC_TRUNK_NET=0).  Results are
+ * bit-identical either way; the switch exists for A/B timing and tests.  Returns the previous setting.                 */
+int mcvc_set_trunk_persistent(int on);
 
 /* ---- sizes (floats) -------------------------------------------------------------------------- */
 long long mcvc_gen_packed_floats(void);

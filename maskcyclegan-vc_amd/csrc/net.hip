@@ -54,6 +54,7 @@ struct Exec {
     long long wino_cap;            // floats available in each
     float* wv2; float* wm2; float* wu;   // the weight-gradient's own set (it runs on the auxiliary stream beside the dgrad): Vt, dMt, dU
     long long wu_cap;
+    unsigned* sync;                // arrival counters of the persistent trunk kernels (MCVC_TRUNK_SYNC_WORDS words of the scratch)
     std::vector<std::pair<const void*, hipEvent_t>> readers;
     void fail(int e) { if (!err && e) err = e; }
 };
@@ -609,6 +610,10 @@ static bool trunk_enabled()
     return en != 0;
 }
 
+// persistent 13-layer forward (trunk_fwd_net_kernel) instead of one fused launch per layer; knob MCVC_TRUNK_NET=0 for A/B runs
+static int g_trunk_net = [] { const char* e = getenv("MCVC_TRUNK_NET"); return e ? (atoi(e) != 0) : 1; }();
+static bool trunk_net_enabled() { return g_trunk_net != 0; }
+
 // conv1d + bias + IN (+GLU | +residual); input / conv_out in trunk layout [C][B][W4]; y plane (b, c) at y + b*y_sn + c*y_sc
 static bool trunk_fwd(Exec& ex, const ConvSpec& c, const float* const* P, int g0, int be0, int g1, int be1, const float* x, float* conv_out,
                       float* stats, float* y, long long y_sn, long long y_sc, const float* res, int B, int W4)
@@ -829,7 +834,7 @@ static GenStash gen_stash(const GenDims& d)
     return s;
 }
 
-struct GenScratch { long long ga, gb, gb2, dh, dt1, dt1b, dt2, dt3, dt3b, wv, wm, wino_floats, wv2, wm2, wu, wu_floats, slabs; };
+struct GenScratch { long long ga, gb, gb2, dh, dt1, dt1b, dt2, dt3, dt3b, wv, wm, wino_floats, wv2, wm2, wu, wu_floats, sync, slabs; };
 static GenScratch gen_scratch(const GenDims& d)
 {
     GenScratch s{};
@@ -849,6 +854,7 @@ static GenScratch gen_scratch(const GenDims& d)
         s.wu_floats = wino_enabled() ? 36LL * 1024 * 256 : 0;          // dU of upSample1 (the larger weight tensor)
         s.wu = take(s.wu_floats);
     }
+    s.sync = take(2 * MCVC_TRUNK_SYNC_WORDS);            // forward | backward persistent trunk kernels
     s.slabs = cur;
     return s;
 }
@@ -880,8 +886,35 @@ static void gen_forward_impl(Exec& ex, const float* const* P, const float* packe
     if (trunk_fwd_ksplit(ex, g.c2d1d, P, st + o.y3, st + o.c4, B, W4, &ns)) {}
     else conv_fwd(ex, g.c2d1d, packed, 1, B, W4, CView{st + o.y3, 0, BT4, W4}, View{st + o.c4, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
     norm_fwd(ex, st + o.c4, W4, BT4, 256 * BT4, ns, normp(P, nullptr, 22, 23), st + o.s4, st + o.y4, W4, BT4, W4, nullptr, B, 256, 1, W4, ACT_NONE);
-    // ---- :258-263  six residual GLU blocks
+    // ---- :258-271  six residual GLU blocks + 1x1 256->5120 + IN (written as NCHW [B][256][20][W4], 5120 = c*20 + h)
     const float* h = st + o.y4;
+    if (trunk_net_enabled() && trunk_enabled() && ex.sync && mcvc_trunk_net_applies(B, W4)) {
+        // small batch: the 12 dependent residual layers in ONE persistent launch (trunk.h)
+        if (!ex.dry) {
+            TrunkFwdNetArgs na{};
+            int l = 0;
+            auto fill = [&](const ConvSpec& c, int g0, int be0, int g1, int be1, const float* x, float* cvo, float* stats, float* y,
+                            long long y_sn, long long y_sc, const float* res, int rows) {
+                TrunkLayerDesc& d = na.L[l++];
+                d.a0 = P[c.wi[0]]; d.bias0 = P[c.bi[0]]; d.gamma0 = P[g0]; d.beta0 = P[be0];
+                if (c.nbr == 2) { d.a1 = P[c.wi[1]]; d.bias1 = P[c.bi[1]]; d.gamma1 = P[g1]; d.beta1 = P[be1]; }
+                d.x = x; d.conv_out = cvo; d.stats = stats; d.y = y; d.y_sn = y_sn; d.y_sc = y_sc; d.res = res;
+                d.Cin = c.Cin; d.KW = c.KW; d.M = c.Cout; d.mode = (c.nbr == 2) ? TRUNK_IN_GLU : TRUNK_IN; d.rows = rows;
+            };
+            for (int i = 0; i < 6; ++i) {
+                const int b = 24 + 12 * i;
+                fill(g.res_vg[i], b + 2, b + 3, b + 6, b + 7, h, st + o.r[i].ca, st + o.r[i].sa, st + o.r[i].ya, W4, BT4, nullptr, 8);
+                fill(g.res_out[i], b + 10, b + 11, -1, -1, st + o.r[i].ya, st + o.r[i].cb, st + o.r[i].sb, st + o.r[i].y, W4, BT4, h, 4);
+                h = st + o.r[i].y;
+            }
+            na.nlayers = l; na.B = B; na.T4 = W4; na.eps = kInEps; na.sync = ex.sync;
+            ex.fail(mcvc_trunk_fwd_net_launch(na, ex.s));
+        } else {
+            h = st + o.r[5].y;
+        }
+        // 1x1 256 -> 5120 + IN: 320 independent row tiles -- its own (wide) launch
+        if (!trunk_fwd(ex, g.c1d2d, P, 98, 99, -1, -1, h, st + o.c6, st + o.s6, st + o.y6, 5120LL * W4, W4, nullptr, B, W4)) ex.fail(MCVC_ERR_INVALID);
+    } else {
     for (int i = 0; i < 6; ++i) {
         const int b = 24 + 12 * i;
         if (!trunk_fwd(ex, g.res_vg[i], P, b + 2, b + 3, b + 6, b + 7, h, st + o.r[i].ca, st + o.r[i].sa, st + o.r[i].ya, W4, BT4, nullptr, B, W4)) {
@@ -901,6 +934,7 @@ static void gen_forward_impl(Exec& ex, const float* const* P, const float* packe
         conv_fwd(ex, g.c1d2d, packed, 1, B, W4, CView{h, 0, BT4, W4}, View{st + o.c6, 0, BT4, W4}, 5120 * BT4, 0, 1, &ns);
         norm_fwd(ex, st + o.c6, W4, BT4, 5120 * BT4, ns, normp(P, nullptr, 98, 99), st + o.s6, st + o.y6, 5120LL * W4, W4, W4, nullptr,
                  B, 5120, 1, W4, ACT_NONE);
+    }
     }
     // ---- :274  upSample1: conv 5x5 -> PixelShuffle(2) (fused into the store) -> IN -> x*sigmoid(x)
     conv_fwd(ex, g.up1, packed, B, 20, W4, CView{st + o.y6, 256LL * 20 * W4, 20LL * W4, W4}, View{st + o.c7, 256LL * 40 * Wu1, 40LL * Wu1, Wu1},
@@ -1265,6 +1299,7 @@ int mcvc_version(void) { return MCVC_ABI_VERSION; }
 
 int mcvc_set_deterministic(int on) { const int was = g_deterministic; g_deterministic = on ? 1 : 0; return was; }
 int mcvc_get_deterministic(void) { return g_deterministic; }
+int mcvc_set_trunk_persistent(int on) { const int was = g_trunk_net; g_trunk_net = on ? 1 : 0; return was; }
 
 long long mcvc_gen_packed_floats(void) { return gen_net().packed_floats; }
 long long mcvc_disc_packed_floats(void) { return disc_net().packed_floats; }
@@ -1368,7 +1403,8 @@ int mcvc_gen_forward(const float* const* params, const float* packed, const floa
     const GenDims d = gen_dims(B, T);
     Exec ex = make_exec(stream, nullptr, scratch, scratch_floats, gen_scratch(d).slabs, gen_needs(B, T));
     if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
-    { const GenScratch q = gen_scratch(d); ex.wv = scratch + q.wv; ex.wm = scratch + q.wm; ex.wino_cap = q.wino_floats; }
+    { const GenScratch q = gen_scratch(d); ex.wv = scratch + q.wv; ex.wm = scratch + q.wm; ex.wino_cap = q.wino_floats;
+      ex.sync = reinterpret_cast<unsigned*>(scratch + q.sync); }
     gen_forward_impl(ex, params, packed, x, mask, out, stash, d);
     return ex.err;
 }

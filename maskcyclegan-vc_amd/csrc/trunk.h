@@ -27,3 +27,32 @@ bool mcvc_trunk_applies(int Cin, int KW, int M, int B, int T4, int mode, int ksp
 long long mcvc_trunk_lds_floats(int Cin, int KW, int B, int T4, int ksplit);
 int mcvc_trunk_launch(const TrunkArgs& a, int ksplit, hipStream_t s);
 int mcvc_fill_rows_launch(float* dst, const float* bias, int C, int per_row, hipStream_t s);
+
+// ---- persistent trunk forward: the six residual blocks + conv1dto2d (13 dependent layers) in ONE launch ---------------------------
+// Layer l+1 needs every output row of layer l, so a plain launch chain is 13 dependent kernel boundaries of ~10 us each for ~1.5 us of
+// arithmetic.  Here a fixed set of workgroups walks the layers; between layers they meet at an in-kernel arrival counter
+// (write-through stores of the activations, one agent-scope acquire per workgroup -- cdna_hip_programming.md section 6, Guideline 16).
+struct TrunkLayerDesc {
+    const float* a0; const float* a1;        // OIHW weights [M][Cin*KW]; a1 = gate branch (mode TRUNK_IN_GLU)
+    const float* bias0; const float* bias1;
+    const float* gamma0; const float* beta0; const float* gamma1; const float* beta1;
+    const float* x;                          // input [Cin][B][T4]
+    float* conv_out;                         // pre-norm conv output [Mtot][B][T4]   (backward needs it)
+    float* stats;                            // [B][Mtot][2]
+    float* y; long long y_sn, y_sc;          // plane (b, c) at y + b*y_sn + c*y_sc
+    const float* res;                        // residual, addressed like y
+    int Cin, KW, M, mode;
+    int rows;                                // output rows of one tile per branch: 8 (GLU: + the 8 gate rows), 4 or 16
+};
+#define MCVC_TRUNK_NET_LAYERS 13
+struct TrunkFwdNetArgs {
+    TrunkLayerDesc L[MCVC_TRUNK_NET_LAYERS];
+    int nlayers, B, T4;
+    int x_floats;                            // LDS floats reserved for the staged input (max over the layers)
+    float eps;
+    unsigned* sync;                          // [nlayers + 2] arrival counters + error word, zeroed by the launcher
+};
+// true when the persistent forward handles (B, T4) -- same regime as the per-layer fused kernels (N = B*T4 <= 32)
+bool mcvc_trunk_net_applies(int B, int T4);
+int mcvc_trunk_fwd_net_launch(TrunkFwdNetArgs& a, hipStream_t s);
+#define MCVC_TRUNK_SYNC_WORDS 32

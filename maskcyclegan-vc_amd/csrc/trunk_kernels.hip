@@ -264,6 +264,295 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const TrunkA
     }
 }
 
+// =====================================================================================================================
+// Persistent trunk forward: residual blocks + conv1dto2d in one launch (see trunk.h).
+// Same arithmetic as trunk_layer_kernel per layer (same MFMA order, same two-pass statistics): results are bit-identical
+// to the per-layer launches.  What changes is the hand-off: activations are stored write-through (sc1), every storing wave
+// drains its stores, ONE lane bumps the layer's arrival counter, and every workgroup waits for all arrivals with ONE relaxed
+// poller + ONE agent-scope acquire before it stages the next layer's input (placement-independent; every spin is bounded).
+// =====================================================================================================================
+constexpr int kNetWaves = 8;
+constexpr int kNetThreads = 64 * kNetWaves;
+constexpr int kNetGrid = 64;
+constexpr int kNetEpiFloats = kNetWaves * 2 * 4 * 64 + 16 * 33 + 16 * 8 * 2 + 16;     // red | tile | sstat | flag
+
+__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool wait_arrivals(unsigned* ctr, unsigned target)
+{
+    for (unsigned spins = 0; spins < (1u << 21); ++spins) {
+        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return false;
+}
+
+// stage X[ci][b][t] (all Cin channels) with zero halo + a zero slot per channel (same layout as trunk_layer_kernel)
+// `fresh`: the source was written by OTHER workgroups of this launch with write-through (sc1) stores: read it with sc1 loads, which
+// are served by L2 / memory and never by this CU's (possibly stale) L1 -- no acquire fence needed (Guideline 16, R1 with sc1 on both sides)
+typedef int v4i_ __attribute__((ext_vector_type(4)));
+template <int KW>
+__device__ __forceinline__ void net_stage_x(const float* __restrict__ xsrc, float* Xs, int Cin, int B, int T4, int tid, bool fresh)
+{
+    constexpr int PW = (KW - 1) / 2;
+    const int TP = T4 + 2 * PW, RS = B * TP + 1;
+    if (((T4 & 3) == 0) && ((reinterpret_cast<unsigned long long>(xsrc) & 15ull) == 0)) {
+        const int nf4 = (Cin * B * T4) >> 2;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc), 0, nf4 * 16, 0x00020000);
+        for (int f0 = 0; f0 < nf4; f0 += 4 * kNetThreads) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u * kNetThreads + tid;
+                if (fresh) v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, f * 16, 0, 16));    // out of range -> 0
+                else v[u] = (f < nf4) ? *reinterpret_cast<const float4*>(xsrc + 4ll * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u * kNetThreads + tid;
+                if (f < nf4) {
+                    const int e = 4 * f;
+                    const int r = e / T4, t = e - r * T4;
+                    const int ci = r / B, b = r - ci * B;
+                    float* dd = Xs + ci * RS + b * TP + PW + t;
+                    dd[0] = v[u].x; dd[1] = v[u].y; dd[2] = v[u].z; dd[3] = v[u].w;
+                }
+            }
+        }
+        const int per = B * 2 * PW + 1;
+        for (int i = tid; i < Cin * per; i += kNetThreads) {
+            const int ci = i / per, j = i - ci * per;
+            int pos;
+            if (j == per - 1) pos = B * TP;
+            else { const int b = j / (2 * PW > 0 ? 2 * PW : 1), side = j - b * 2 * PW; pos = b * TP + (side ? TP - 1 : 0); }
+            Xs[ci * RS + pos] = 0.f;
+        }
+    } else {
+        const int total = Cin * RS;
+        for (int i = tid; i < total; i += kNetThreads) {
+            const int ci = i / RS, rem = i - ci * RS;
+            float v = 0.f;
+            if (rem < B * TP) {
+                const int b = rem / TP, tp = rem - b * TP;
+                const int t = tp - PW;
+                if (t >= 0 && t < T4) {
+                    const float* q = xsrc + (long long)ci * B * T4 + (long long)b * T4 + t;
+                    v = fresh ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+                }
+            }
+            Xs[i] = v;
+        }
+    }
+}
+
+// weights of one tile: all of a wave's loads issued at once (the first CH super-groups = everything for the generator's shapes)
+template <int KW>
+struct NetW { float4 wb[4][(KW == 3) ? 3 : 2]; };
+
+template <int KW>
+__device__ __forceinline__ void net_load_w(const TrunkLayerDesc& d, int tile, NetW<KW>& w)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int K = d.Cin * KW;
+    const int glu = (d.mode == TRUNK_IN_GLU);
+    const int rows = d.rows, rows_tot = glu ? 2 * rows : rows;
+    const int r0 = tile * rows;
+    const int k_count = K / kNetWaves;
+    const float* arow;
+    if (glu) arow = (l15 < rows) ? (d.a0 + (long long)(r0 + l15) * K) : (d.a1 + (long long)(r0 + (l15 < rows_tot ? l15 - rows : 0)) * K);
+    else arow = d.a0 + (long long)(r0 + (l15 < rows ? l15 : rows - 1)) * K;       // idle MFMA rows re-read the last row (results unused)
+    constexpr int NQ = (KW == 3) ? 3 : 2;
+    constexpr int GK = 16 * NQ;
+    const int sgroups = k_count / GK;
+    const float* ap = arow + wave * k_count + 4 * kq;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float* pp = ap + (long long)(c < sgroups ? c : 0) * GK;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) w.wb[c][q] = *reinterpret_cast<const float4*>(pp + 16 * q);
+    }
+}
+
+// one tile of output rows of one layer: conv (K split over the 8 waves) + bias + IN + GLU / residual, stores included
+template <int KW, int NA>
+__device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4, float eps, int tile, const float* Xs, float* epi, bool wt,
+                                         NetW<KW>& pre)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    constexpr int PW = (KW - 1) / 2;
+    const int TP = T4 + 2 * PW, RS = B * TP + 1;
+    const int N = B * T4, K = d.Cin * KW;
+    const int glu = (d.mode == TRUNK_IN_GLU);
+    const int rows = d.rows;                       // per branch
+    const int rows_tot = glu ? 2 * rows : rows;    // MFMA rows in use (<= 16)
+    const int r0 = tile * rows;
+    const int Mtot = glu ? 2 * d.M : d.M;
+    const int k_count = K / kNetWaves;
+    const int k_begin = wave * k_count;
+    const float* arow;
+    {
+        const int i = l15;
+        if (glu) arow = (i < rows) ? (d.a0 + (long long)(r0 + i) * K) : (d.a1 + (long long)(r0 + (i < rows_tot ? i - rows : 0)) * K);
+        else arow = d.a0 + (long long)(r0 + (i < rows ? i : rows - 1)) * K;       // idle MFMA rows re-read the last row (results unused)
+    }
+    constexpr int NQ = (KW == 3) ? 3 : 2;
+    constexpr int GK = 16 * NQ;
+    constexpr int CH = 4;
+    const int sgroups = k_count / GK;
+    const float* ap = arow + k_begin + 4 * kq;
+    float4 (&wb)[CH][NQ] = pre.wb;                 // super-groups 0..CH-1 were requested by net_load_w (before the layer's wait)
+    int off[NA][NQ][4];
+#pragma unroll
+    for (int h = 0; h < NA; ++h) {
+        const int n = l15 + 16 * h;
+        int xcol = B * TP, live = 0;
+        if (n < N) { const int b = n / T4, t = n - b * T4; xcol = b * TP + t; live = 1; }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kr = 16 * q + 4 * kq + j;
+                off[h][q][j] = (kr / KW) * RS + xcol + (live ? (kr % KW) : 0);
+            }
+    }
+    f32x4 acc[NA];
+#pragma unroll
+    for (int h = 0; h < NA; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const float* xs = Xs + (k_begin / KW) * RS;
+        for (int sg0 = 0; sg0 < sgroups; sg0 += CH) {
+            if (sg0 > 0) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const float* pp = ap + (long long)(sg0 + c < sgroups ? sg0 + c : 0) * GK;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) wb[c][q] = *reinterpret_cast<const float4*>(pp + 16 * q);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (sg0 + c < sgroups) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const float av[4] = {wb[c][q].x, wb[c][q].y, wb[c][q].z, wb[c][q].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int h = 0; h < NA; ++h) acc[h] = MFMA16(av[j], xs[off[h][q][j]], acc[h]);
+                    }
+                    xs += (GK / KW) * RS;
+                }
+            }
+        }
+    }
+    // ---- cross-wave K reduction: red[wave][h][reg][lane]
+    float* red = epi;
+    float* tl = epi + kNetWaves * 2 * 4 * 64;      // [16][33]
+    float* sstat = tl + 16 * 33;                   // [16][B][2]
+#pragma unroll
+    for (int h = 0; h < NA; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * NA + h) * 4 + r) * 64 + lane] = acc[h][r];
+    __syncthreads();
+    for (int e = tid; e < NA * 256; e += kNetThreads) {
+        const int h = e >> 8, r = (e >> 6) & 3, ln = e & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kNetWaves; ++w) v += red[((w * NA + h) * 4 + r) * 64 + ln];
+        const int row = 4 * (ln >> 4) + r, col = (ln & 15) + 16 * h;
+        tl[row * 33 + col] = v;
+    }
+    __syncthreads();
+    auto row_cx = [&](int row) { return glu ? ((row < rows) ? (r0 + row) : (d.M + r0 + row - rows)) : (r0 + row); };
+    for (int e = tid; e < rows_tot * N; e += kNetThreads) {
+        const int row = e / N, nn = e - row * N;
+        const int cx = row_cx(row);
+        const float bias = glu ? ((row < rows) ? d.bias0[r0 + row] : d.bias1[r0 + row - rows]) : d.bias0[r0 + row];
+        const float v = tl[row * 33 + nn] + bias;
+        tl[row * 33 + nn] = v;
+        d.conv_out[(long long)cx * N + nn] = v;
+    }
+    __syncthreads();
+    if (tid < rows_tot * B) {
+        const int row = tid / B, b = tid - row * B;
+        const float* p = tl + row * 33 + b * T4;
+        float s = 0.f;
+        for (int t = 0; t < T4; ++t) s += p[t];
+        const float mean = s / (float)T4;
+        float q = 0.f;
+        for (int t = 0; t < T4; ++t) { const float dd = p[t] - mean; q += dd * dd; }
+        const float rstd = 1.0f / sqrtf(q / (float)T4 + eps);
+        sstat[(row * B + b) * 2] = mean; sstat[(row * B + b) * 2 + 1] = rstd;
+        float* st = d.stats + ((long long)b * Mtot + row_cx(row)) * 2;
+        st[0] = mean; st[1] = rstd;
+    }
+    __syncthreads();
+    for (int e = tid; e < rows * N; e += kNetThreads) {
+        const int row = e / N, nn = e - row * N;
+        const int c = r0 + row;
+        const int b = nn / T4, t = nn - b * T4;
+        const float m0 = sstat[(row * B + b) * 2], s0 = sstat[(row * B + b) * 2 + 1];
+        const float z0 = (tl[row * 33 + nn] - m0) * s0 * d.gamma0[c] + d.beta0[c];
+        float y;
+        if (glu) {
+            const int rg = row + rows;
+            const float m1 = sstat[(rg * B + b) * 2], s1 = sstat[(rg * B + b) * 2 + 1];
+            const float z1 = (tl[rg * 33 + nn] - m1) * s1 * d.gamma1[c] + d.beta1[c];
+            y = z0 * sigmoidf_(z1);
+        } else {
+            y = z0;
+        }
+        const long long yo = (long long)b * d.y_sn + (long long)c * d.y_sc + t;
+        if (d.res) y += __hip_atomic_load(d.res + yo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (this workgroup's own rows, two layers back)
+        if (wt) st_wt(d.y + yo, y); else d.y[yo] = y;
+    }
+}
+
+template <int NA>
+__global__ void __launch_bounds__(kNetThreads) trunk_fwd_net_kernel(const TrunkFwdNetArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;
+    float* epi = smem + a.x_floats;
+    float* flag = epi + kNetEpiFloats - 16;
+    const int tid = threadIdx.x;
+    for (int l = 0; l < a.nlayers; ++l) {
+        const TrunkLayerDesc& d = a.L[l];
+        const int ntiles = d.M / d.rows;
+        // this layer's weights do not depend on the previous layer: request them BEFORE waiting for its activations
+        NetW<3> w3; NetW<1> w1;
+        const bool mine = (int)blockIdx.x < ntiles;
+        if (mine) { if (d.KW == 3) net_load_w<3>(d, blockIdx.x, w3); else net_load_w<1>(d, blockIdx.x, w1); }
+        if (l > 0) {
+            if (tid == 0) {
+                const bool ok = wait_arrivals(a.sync + (l - 1), gridDim.x);
+                if (!ok) __hip_atomic_store(a.sync + MCVC_TRUNK_SYNC_WORDS - 1, 1u + (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                flag[0] = ok ? 1.f : 0.f;
+            }
+            __syncthreads();
+            if (flag[0] == 0.f) return;            // (uniform) a workgroup never arrived: give up instead of hanging the device
+        }
+        if (d.KW == 3) net_stage_x<3>(d.x, Xs, d.Cin, a.B, a.T4, tid, l > 0); else net_stage_x<1>(d.x, Xs, d.Cin, a.B, a.T4, tid, l > 0);
+        __syncthreads();
+        const bool wt = (l + 1 < a.nlayers);       // the last layer's output is consumed after the kernel boundary
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            if (tile != (int)blockIdx.x) { if (d.KW == 3) net_load_w<3>(d, tile, w3); else net_load_w<1>(d, tile, w1); }
+            if (d.KW == 3) net_tile<3, NA>(d, a.B, a.T4, a.eps, tile, Xs, epi, wt, w3);
+            else net_tile<1, NA>(d, a.B, a.T4, a.eps, tile, Xs, epi, wt, w1);
+        }
+        if (wt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // EVERY storing wave drains its write-through stores
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(a.sync + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // dst[c][0..per_row) = bias ? bias[c] : 0   (initial value of an atomically accumulated K-split trunk layer)
 __global__ void __launch_bounds__(256) fill_rows_kernel(float* __restrict__ dst, const float* __restrict__ bias, int C, int per_row)
 {
@@ -330,4 +619,49 @@ int mcvc_trunk_launch(const TrunkArgs& a, int ksplit, hipStream_t s)
     const bool wide = a.N > 16;
     if (a.KW == 3) return wide ? trunk_launch_t<3, 2>(a, grid, lds, s) : trunk_launch_t<3, 1>(a, grid, lds, s);
     return wide ? trunk_launch_t<1, 2>(a, grid, lds, s) : trunk_launch_t<1, 1>(a, grid, lds, s);
+}
+
+bool mcvc_trunk_net_applies(int B, int T4)
+{
+    if (B < 1 || B > 8 || T4 < 1 || T4 > 32 || B * T4 > 32) return false;
+    const long long x = (long long)512 * (B * (T4 + 2) + 1);          // widest staged input: 512 channels, k = 3
+    return (x + kNetEpiFloats) * 4 <= 156 * 1024;
+}
+
+int mcvc_trunk_fwd_net_launch(TrunkFwdNetArgs& a, hipStream_t s)
+{
+    if (!mcvc_trunk_net_applies(a.B, a.T4) || a.nlayers < 1 || a.nlayers > MCVC_TRUNK_NET_LAYERS || !a.sync) return MCVC_ERR_INVALID;
+    long long xmax = 0;
+    double flops = 0.0, bytes = 0.0;
+    const int N = a.B * a.T4;
+    for (int l = 0; l < a.nlayers; ++l) {
+        const TrunkLayerDesc& d = a.L[l];
+        if (d.KW != 1 && d.KW != 3) return MCVC_ERR_INVALID;
+        const int K = d.Cin * d.KW, gk = (d.KW == 3) ? 48 : 32;
+        if (K % (gk * kNetWaves) != 0 || d.rows < 1 || d.rows > 16 || d.M % d.rows != 0) return MCVC_ERR_INVALID;
+        if (d.mode == TRUNK_IN_GLU && d.rows > 8) return MCVC_ERR_INVALID;
+        if (d.mode != TRUNK_IN_GLU && d.mode != TRUNK_IN) return MCVC_ERR_INVALID;
+        const long long x = (long long)d.Cin * (a.B * (a.T4 + d.KW - 1) + 1);
+        if (x > xmax) xmax = x;
+        const double mt = (d.mode == TRUNK_IN_GLU) ? 2.0 * d.M : (double)d.M;
+        flops += 2.0 * mt * K * N;
+        bytes += 4.0 * (mt * K + (double)d.Cin * N + 3.0 * mt * N);
+    }
+    a.x_floats = (int)((xmax + 3) & ~3LL);
+    const size_t lds = ((size_t)a.x_floats + kNetEpiFloats) * sizeof(float);
+    if (lds > 160 * 1024) return MCVC_ERR_INVALID;
+    hipError_t e = hipMemsetAsync(a.sync, 0, MCVC_TRUNK_SYNC_WORDS * sizeof(unsigned), s);
+    if (e != hipSuccess) return (int)e;
+    TraceScope ts(K_TRUNK, s, flops, bytes);
+    const bool wide = N > 16;
+    static bool done[2] = {false, false};
+    if (!done[wide]) {
+        const void* fn = wide ? reinterpret_cast<const void*>(trunk_fwd_net_kernel<2>) : reinterpret_cast<const void*>(trunk_fwd_net_kernel<1>);
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done[wide] = true;
+    }
+    if (wide) hipLaunchKernelGGL(trunk_fwd_net_kernel<2>, dim3(kNetGrid), dim3(kNetThreads), lds, s, a);
+    else hipLaunchKernelGGL(trunk_fwd_net_kernel<1>, dim3(kNetGrid), dim3(kNetThreads), lds, s, a);
+    return (int)hipGetLastError();
 }

@@ -27,6 +27,7 @@ _SIGS = {
     "mcvc_version": (c_int, []),
     "mcvc_set_deterministic": (c_int, [c_int]),
     "mcvc_get_deterministic": (c_int, []),
+    "mcvc_set_trunk_persistent": (c_int, [c_int]),
     "mcvc_gen_packed_floats": (c_longlong, []),
     "mcvc_disc_packed_floats": (c_longlong, []),
     "mcvc_gen_stash_floats": (c_longlong, [c_int, c_int]),

@@ -170,3 +170,37 @@ def test_inference_config_bs16_512_frames(nets, meta):
     ref = orc.generator_forward(p, x[:1].cpu(), mask[:1].cpu())
     err = float((y[:1].cpu() - ref).norm() / ref.norm())
     assert err < 1e-3, err
+
+
+@pytest.mark.parametrize("B,T", [(1, 64), (2, 64), (1, 32), (4, 32), (1, 128)])
+def test_persistent_trunk_forward_is_bit_identical_to_the_per_layer_launches(B, T):
+    """The 13 dependent trunk layers (model.py:258-271) run as ONE persistent launch whose workgroups hand activations to each
+    other inside the kernel (write-through stores, arrival counter, agent-scope acquire).  Same arithmetic as the per-layer
+    fused kernels -> outputs AND every stashed intermediate must be bit-identical; repeated with fresh inputs into the SAME
+    buffers so that a stale L1 / L2 line from the previous pass (the hazard of an in-kernel hand-off) would show up."""
+    from mask_cyclegan_vc._hip import check, lib, ptr, ptr_table, stream
+    L = lib()
+    g = Generator()
+    g.load_state_dict(orc.filler_params("G", 31), strict=True)
+    g = g.cuda()
+    ps = list(g.parameters())
+    packed = g.packed_weights(ps)
+    n_stash, n_scr = L.mcvc_gen_stash_floats(B, T), L.mcvc_gen_scratch_floats(B, T)
+    stash = [torch.zeros(n_stash, device="cuda") for _ in range(2)]
+    scratch = torch.zeros(n_scr, device="cuda")
+    out = [torch.empty(B, 80, L.mcvc_gen_out_frames(T), device="cuda") for _ in range(2)]
+    tab = ptr_table(ps)
+    was = L.mcvc_set_trunk_persistent(1)
+    try:
+        for it in range(12):
+            x = torch.randn(B, 80, T, device="cuda") * (1.0 + it)
+            m = torch.ones_like(x)
+            m[:, :, 3 * it:3 * it + 5] = 0
+            for k, on in enumerate((1, 0)):
+                L.mcvc_set_trunk_persistent(on)
+                check(L.mcvc_gen_forward(tab, ptr(packed), ptr(x), ptr(m), ptr(out[k]), ptr(stash[k]), ptr(scratch), n_scr, B, T, stream()), "fwd")
+            torch.cuda.synchronize()
+            assert torch.equal(out[0], out[1]), it
+            assert torch.equal(stash[0], stash[1]), it           # conv outputs, statistics, activations of every layer
+    finally:
+        L.mcvc_set_trunk_persistent(was)
