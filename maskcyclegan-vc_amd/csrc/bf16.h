@@ -17,14 +17,15 @@ struct Bf16ConvArgs {
     const float* bias;                  // [Cout_pad] or nullptr
     bf16_t* y; long long y_sn; int y_sh, y_sw;
     int N, H, W, Cin, Cout, Cout_pad, OH, OW, KH, KW, stride, pad_h, pad_w;
-    int TH, tw_log2, tiles_h, tiles_w;  // pixel tile = TH x (1 << tw_log2) = 128 pixels
+    int TH, tw_log2, tiles_h, tiles_w;  // pixel tile = TH x (1 << tw_log2) = 128 or 64 pixels (chosen by the launcher)
     int PH, PW;                         // input patch of a tile: (TH-1)*stride + KH rows, (TW-1)*stride + KW columns
+    int wbufs;                          // LDS weight buffers (2 = double buffer; 1 when that lets two workgroups share a CU)
     int glu;                            // 1: rows [0, Cout_pad/2) are value channels, [Cout_pad/2, Cout_pad) their gates, interleaved per
                                         //    64-row block by the packer; the epilogue stores value * sigmoid(gate): Cout = Cout_pad / 2
 };
 int mcvc_bf16_conv_launch(const Bf16ConvArgs& a, hipStream_t s);
-// pixel-tile shape for an OH x OW output grid (TH * TW = 128)
-void mcvc_bf16_conv_tile(int OH, int OW, int KH, int KW, int stride, int* TH, int* tw_log2);
+// pixel-tile shape for an OH x OW output grid (TH * TW = bn)
+void mcvc_bf16_conv_tile(int OH, int OW, int KH, int KW, int stride, int bn, int* TH, int* tw_log2);
 
 // ---- InstanceNorm (+ activation) on NHWC bf16 ---------------------------------------------------------------------
 // x: conv output, element (n, p = (h, w), cx) at x + n*x_sn + h*x_sh + w*x_sw + cx.

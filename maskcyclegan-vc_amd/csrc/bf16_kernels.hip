@@ -46,19 +46,26 @@ __device__ __forceinline__ uint4 pack8(const float* f)
 // convolution
 // ======================================================================================================================
 constexpr int kConvThreads = 256;
+constexpr int kMaxWP = 10;          // 16-byte weight pieces per thread and stage (BM * KW * 4 <= 2560)
+// 16-byte input-patch pieces per thread that are prefetched through registers one channel chunk ahead: template parameter PPT
+// (4 for stride-1 layers, 12 for the stride-2 layers whose patch is ~4x larger)
 
-template <int WM, int WN, int MT, int NT>
+// KWT > 0: the kernel width is a compile-time constant (taps fully unrolled: the compiler hoists the next operands' LDS reads above
+// the current MFMAs); KWT == 0: run-time width.
+template <int WM, int WN, int MT, int NT, int KWT, int PPT>
 __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvArgs a)
 {
+    constexpr int kMaxPP = PPT;
     static_assert(WM * WN == 4, "four waves");
-    static_assert(WN * NT * 32 == 128, "128-pixel tile");
     constexpr int BM = WM * MT * 32;
+    constexpr int BN = WN * NT * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
+    const int KW = KWT > 0 ? KWT : a.KW;
 
     // ---- block -> (output-channel tile, pixel tile).  Workgroup b runs on XCD b % 8 (observed placement, speed only): when the
     // number of channel tiles divides 8, the workgroups of one XCD all use ONE weight slice, which then stays in that XCD's L2.
@@ -84,53 +91,87 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     const int ih0 = oh0 * a.stride - a.pad_h, iw0 = ow0 * a.stride - a.pad_w;
 
     const int patch_px = a.PH * a.PW;
+    const int patch_pieces = patch_px * 4;
     unsigned char* Xs = smem;                                             // [patch_px][64 B]
-    const int wbuf_bytes = BM * a.KW * 64;
-    unsigned char* Ws = smem + (((size_t)patch_px * 64 + 255) & ~(size_t)255);   // 2 x [BM][KW][64 B]
+    const int wbuf_bytes = BM * KW * 64;
+    unsigned char* Ws = smem + (((size_t)patch_px * 64 + 255) & ~(size_t)255);   // wbufs x [BM][KW][64 B]
+    const bool wdouble = a.wbufs > 1;
 
     const int ncc = a.Cin >> 5;
     const int nstage = ncc * a.KH;                                        // stage = (cc, kh): KW taps x 32 input channels
-    const int w_pieces = BM * a.KW * 4;                                   // 16-byte pieces per weight stage
-    constexpr int MAXWP = 10;                                             // pieces per thread kept in registers (BM*KW*4 <= 2560)
-    uint4 wreg[MAXWP];
-
+    const int w_pieces = BM * KW * 4;                                     // 16-byte pieces per weight stage
+    uint4 wreg[kMaxWP];
     // piece -> (weight row, tap, swizzled chunk) is stage-invariant: element offsets computed once
-    int woff[MAXWP];
+    int woff[kMaxWP];
 #pragma unroll
-    for (int i = 0; i < MAXWP; ++i) {
+    for (int i = 0; i < kMaxWP; ++i) {
         const int q = tid + i * kConvThreads;
-        const int row = q / (a.KW * 4), rem = q - row * (a.KW * 4);
+        const int row = q / (KW * 4), rem = q - row * (KW * 4);
         const int tap = rem >> 2, pos = rem & 3;
         const int lc = pos ^ ((row >> 2) & 3);
-        woff[i] = (q < w_pieces) ? ((co0 + row) * a.KH * ncc * a.KW + tap) * 32 + lc * 8 : -1;
+        woff[i] = (q < w_pieces) ? ((co0 + row) * a.KH * ncc * KW + tap) * 32 + lc * 8 : -1;
     }
     auto load_w = [&](int stage) {
         const int cc = stage / a.KH, kh = stage - cc * a.KH;
-        const bf16_t* base = a.w + (long long)(kh * ncc + cc) * a.KW * 32;
+        const bf16_t* base = a.w + (long long)(kh * ncc + cc) * KW * 32;
 #pragma unroll
-        for (int i = 0; i < MAXWP; ++i)
+        for (int i = 0; i < kMaxWP; ++i)
             if (woff[i] >= 0) wreg[i] = *reinterpret_cast<const uint4*>(base + woff[i]);
     };
     auto store_w = [&](int buf) {
         unsigned char* dst = Ws + buf * wbuf_bytes;
 #pragma unroll
-        for (int i = 0; i < MAXWP; ++i) {
+        for (int i = 0; i < kMaxWP; ++i) {
             const int q = tid + i * kConvThreads;
             if (q < w_pieces) *reinterpret_cast<uint4*>(dst + (size_t)q * 16) = wreg[i];
         }
     };
-    auto stage_patch = [&](int cc) {
-        const bf16_t* xb = a.x + (long long)n_img * a.x_sn + cc * 32;
-        for (int q = tid; q < patch_px * 4; q += kConvThreads) {
-            const int pp = q >> 2, pos = q & 3;
-            const int pr = pp / a.PW, pc = pp - pr * a.PW;
-            const int ih = ih0 + pr, iw = iw0 + pc;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
-                const int lc = pos ^ ((pp >> 2) & 3);
-                v = *reinterpret_cast<const uint4*>(xb + (long long)ih * a.x_sh + (long long)iw * a.x_sw + lc * 8);
+    // ---- input patch: small patches (<= kMaxPP pieces per thread) are prefetched through registers one chunk ahead; large ones
+    //      (stride-2 layers) are staged synchronously, four loads in flight per thread
+    const bool p_pref = patch_pieces <= kMaxPP * kConvThreads;
+    long long poff[kMaxPP];                   // element offset of the piece inside the image (without the chunk offset); -1 = zero fill
+#pragma unroll
+    for (int i = 0; i < kMaxPP; ++i) {
+        const int q = tid + i * kConvThreads;
+        const int pp = q >> 2, pos = q & 3;
+        const int pr = pp / a.PW, pc = pp - pr * a.PW;
+        const int ih = ih0 + pr, iw = iw0 + pc;
+        const bool ok = p_pref && q < patch_pieces && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+        poff[i] = ok ? ((long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 2) & 3)) * 8) : -1;
+    }
+    const bf16_t* ximg = a.x + (long long)n_img * a.x_sn;
+    uint4 preg[kMaxPP];
+    auto load_patch = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < kMaxPP; ++i)
+            preg[i] = (poff[i] >= 0) ? *reinterpret_cast<const uint4*>(ximg + cc * 32 + poff[i]) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < kMaxPP; ++i) {
+            const int q = tid + i * kConvThreads;
+            if (q < patch_pieces) *reinterpret_cast<uint4*>(Xs + (size_t)q * 16) = preg[i];
+        }
+    };
+    auto stage_patch_sync = [&](int cc) {
+        const bf16_t* xb = ximg + cc * 32;
+        for (int q0 = tid; q0 < patch_pieces; q0 += 4 * kConvThreads) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + u * kConvThreads;
+                const int pp = q >> 2, pos = q & 3;
+                const int pr = pp / a.PW, pc = pp - pr * a.PW;
+                const int ih = ih0 + pr, iw = iw0 + pc;
+                v[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (q < patch_pieces && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
+                    v[u] = *reinterpret_cast<const uint4*>(xb + (long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 2) & 3)) * 8);
             }
-            *reinterpret_cast<uint4*>(Xs + (size_t)q * 16) = v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + u * kConvThreads;
+                if (q < patch_pieces) *reinterpret_cast<uint4*>(Xs + (size_t)q * 16) = v[u];
+            }
         }
     };
 
@@ -153,28 +194,31 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     load_w(0);
+    if (p_pref) load_patch(0);
     for (int stage = 0; stage < nstage; ++stage) {
         const int cc = stage / a.KH, kh = stage - cc * a.KH;
-        const int buf = stage & 1;
-        if (kh == 0) {
-            if (stage > 0) __syncthreads();                 // every wave is done reading the previous chunk's patch
-            stage_patch(cc);
+        const int buf = wdouble ? (stage & 1) : 0;
+        if (kh == 0 || !wdouble) {
+            if (stage > 0) __syncthreads();                 // every wave is done reading the previous patch / the single weight buffer
         }
+        if (kh == 0) { if (p_pref) store_patch(); else stage_patch_sync(cc); }
         store_w(buf);
         __syncthreads();
         if (stage + 1 < nstage) load_w(stage + 1);          // in flight during the MFMAs below
+        if (p_pref && kh == a.KH - 1 && cc + 1 < ncc) load_patch(cc + 1);
         const unsigned char* Wb = Ws + buf * wbuf_bytes;
-        for (int tap = 0; tap < a.KW; ++tap) {
+        const int pk = kh * a.PW;
+        auto tap_step = [&](int tap) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int lc = ks * 2 + half;
                 bf16x8 av[MT], bv[NT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    av[mt] = *reinterpret_cast<const bf16x8*>(Wb + (size_t)(((rowA[mt] * a.KW + tap) << 2) + (lc ^ gA[mt])) * 16);
+                    av[mt] = *reinterpret_cast<const bf16x8*>(Wb + (size_t)(((rowA[mt] * KW + tap) << 2) + (lc ^ gA[mt])) * 16);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int pp = ppB[nt] + kh * a.PW + tap;
+                    const int pp = ppB[nt] + pk + tap;
                     bv[nt] = *reinterpret_cast<const bf16x8*>(Xs + (size_t)((pp << 2) + (lc ^ ((pp >> 2) & 3))) * 16);
                 }
 #pragma unroll
@@ -183,6 +227,12 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
             }
+        };
+        if constexpr (KWT > 0) {
+#pragma unroll
+            for (int tap = 0; tap < KWT; ++tap) tap_step(tap);
+        } else {
+            for (int tap = 0; tap < KW; ++tap) tap_step(tap);
         }
     }
 
@@ -208,10 +258,10 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
                             if (a.bias) { v += a.bias[co0 + wm * 64 + 8 * q + 4 * half + j]; g += a.bias[co0 + wm * 64 + 32 + 8 * q + 4 * half + j]; }
                             o[j] = v * sigmoidf_(g);
                         }
-                        uint2 pk;
-                        pk.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-                        pk.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
-                        *reinterpret_cast<uint2*>(yp + c) = pk;
+                        uint2 pk2;
+                        pk2.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+                        pk2.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+                        *reinterpret_cast<uint2*>(yp + c) = pk2;
                     }
                 }
             }
@@ -225,10 +275,10 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
                         float o[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) o[j] = acc[mt][nt][4 * q + j] + (a.bias ? a.bias[co + j] : 0.f);
-                        uint2 pk;
-                        pk.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-                        pk.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
-                        *reinterpret_cast<uint2*>(yp + co) = pk;
+                        uint2 pk2;
+                        pk2.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+                        pk2.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+                        *reinterpret_cast<uint2*>(yp + co) = pk2;
                     }
                 }
             }
@@ -236,11 +286,11 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     }
 }
 
-template <int WM, int WN, int MT, int NT>
+template <int WM, int WN, int MT, int NT, int KWT, int PPT>
 int conv_launch_t(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
 {
     constexpr int BM = WM * MT * 32;
-    auto kern = bf16_conv_kernel<WM, WN, MT, NT>;
+    auto kern = bf16_conv_kernel<WM, WN, MT, NT, KWT, PPT>;
     static bool done = false;
     if (!done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -252,14 +302,39 @@ int conv_launch_t(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
     return (int)hipGetLastError();
 }
 
+template <int WM, int WN, int MT, int NT>
+int conv_launch_kw(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
+{
+    const bool big_patch = a.PH * a.PW * 4 > 4 * kConvThreads;
+    if (a.KW == 5) return big_patch ? conv_launch_t<WM, WN, MT, NT, 5, 12>(a, lds, s) : conv_launch_t<WM, WN, MT, NT, 5, 4>(a, lds, s);
+    if (a.KW == 3) return big_patch ? conv_launch_t<WM, WN, MT, NT, 3, 12>(a, lds, s) : conv_launch_t<WM, WN, MT, NT, 3, 4>(a, lds, s);
+    if (a.KW == 1) return conv_launch_t<WM, WN, MT, NT, 1, 4>(a, lds, s);
+    return conv_launch_t<WM, WN, MT, NT, 0, 4>(a, lds, s);
+}
+
 }  // namespace
 
-void mcvc_bf16_conv_tile(int OH, int OW, int KH, int KW, int stride, int* TH, int* tw_log2)
+// tile configuration: 0 = 128 channels x 128 pixels, 1 = 64 x 64 (few pixels: more workgroups), 2 = 32 x 128 (few output channels)
+static int conv_config(const Bf16ConvArgs& a)
 {
-    // candidates TH x TW = 128 pixels; fewest tiles (least overhang) first, then the smallest staged input patch
+    if (a.Cout_pad % 64 != 0) return 2;
+    const long long px = (long long)a.N * a.OH * a.OW;
+    if (a.Cout_pad % 128 != 0 || a.glu == 0) {
+        // small problems: 128 x 128 tiles would leave most of the 256 CUs idle
+        const long long wg128 = (a.Cout_pad / 128) * ((px + 127) / 128);
+        if (a.Cout_pad % 128 != 0 || wg128 < 512) return 1;
+    }
+    return 0;
+}
+
+void mcvc_bf16_conv_tile(int OH, int OW, int KH, int KW, int stride, int bn, int* TH, int* tw_log2)
+{
+    // candidates TH x TW = bn pixels; fewest tiles (least overhang) first, then the smallest staged input patch
     long long best_cost = -1;
-    for (int l = 3; l <= 7; ++l) {
-        const int tw = 1 << l, th = 128 >> l;
+    int lmax = 0;
+    while ((1 << (lmax + 1)) <= bn) ++lmax;
+    for (int l = 3; l <= lmax; ++l) {
+        const int tw = 1 << l, th = bn >> l;
         const long long tiles = (long long)cdiv_i(OH, th) * cdiv_i(OW, tw);
         const long long patch = (long long)((th - 1) * stride + KH) * ((tw - 1) * stride + KW);
         if (patch * 64 > 96 * 1024) continue;
@@ -272,21 +347,26 @@ int mcvc_bf16_conv_launch(const Bf16ConvArgs& a0, hipStream_t s)
 {
     Bf16ConvArgs a = a0;
     if ((a.Cin & 31) || (a.Cout & 3) || a.KW < 1 || a.KH < 1) return MCVC_ERR_INVALID;
+    const int cfg = conv_config(a);
+    const int BM = cfg == 0 ? 128 : (cfg == 1 ? 64 : 32), BN = cfg == 1 ? 64 : 128;
+    if (a.Cout_pad % BM) return MCVC_ERR_INVALID;
+    if (a.glu && cfg != 0) return MCVC_ERR_INVALID;
+    mcvc_bf16_conv_tile(a.OH, a.OW, a.KH, a.KW, a.stride, BN, &a.TH, &a.tw_log2);
     const int TW = 1 << a.tw_log2;
-    if (a.TH * TW != 128) return MCVC_ERR_INVALID;
     a.tiles_h = cdiv_i(a.OH, a.TH); a.tiles_w = cdiv_i(a.OW, TW);
     a.PH = (a.TH - 1) * a.stride + a.KH; a.PW = (TW - 1) * a.stride + a.KW;
-    const bool big = (a.Cout_pad % 128) == 0;
-    const int BM = big ? 128 : 32;
-    if (a.Cout_pad % BM) return MCVC_ERR_INVALID;
-    if (a.glu && !big) return MCVC_ERR_INVALID;
-    if (BM * a.KW * 4 > 10 * kConvThreads) return MCVC_ERR_INVALID;
-    const size_t lds = (((size_t)a.PH * a.PW * 64 + 255) & ~(size_t)255) + 2 * (size_t)BM * a.KW * 64;
+    if (BM * a.KW * 4 > kMaxWP * kConvThreads) return MCVC_ERR_INVALID;
+    const size_t patch = ((size_t)a.PH * a.PW * 64 + 255) & ~(size_t)255, wb = (size_t)BM * a.KW * 64;
+    // two workgroups per CU hide each other's barriers and load latencies: single weight buffer when that is what makes two fit
+    a.wbufs = (patch + 2 * wb <= 80 * 1024) ? 2 : ((patch + wb <= 80 * 1024) ? 1 : 2);
+    const size_t lds = patch + a.wbufs * wb;
     if (lds > 160 * 1024) return MCVC_ERR_INVALID;
     const double px = (double)a.N * a.OH * a.OW;
     TraceScope ts(K_CONV_L, s, 2.0 * px * a.Cout_pad * a.Cin * a.KH * a.KW,
                   2.0 * ((double)a.N * a.H * a.W * a.Cin + px * a.Cout + (double)a.Cout_pad * a.Cin * a.KH * a.KW));
-    return big ? conv_launch_t<2, 2, 2, 2>(a, lds, s) : conv_launch_t<1, 4, 1, 1>(a, lds, s);
+    if (cfg == 0) return conv_launch_kw<2, 2, 2, 2>(a, lds, s);
+    if (cfg == 1) return conv_launch_kw<2, 2, 1, 1>(a, lds, s);
+    return conv_launch_kw<1, 4, 1, 1>(a, lds, s);
 }
 
 // ======================================================================================================================
@@ -371,29 +451,42 @@ __global__ void __launch_bounds__(256) bf16_finalize_kernel(const Bf16NormArgs a
     a.stats[i * 2 + 1] = 1.0f / sqrtf(var + a.eps);
 }
 
-// one thread = one pixel x 8 OUTPUT channels (16-byte store); shuffle: 32 conv channels in, 4 output pixels
+// one thread = 8 OUTPUT channels (16-byte store) of a run of pixels: the launcher makes the grid stride a multiple of the octet count,
+// so a thread keeps its channel octet and its statistics / affine parameters stay in registers while it walks over pixels
+// (they are re-read only when it crosses into the next image).  shuffle: 32 conv channels in, 4 output pixels.
 __global__ void __launch_bounds__(256) bf16_apply_kernel(const Bf16NormArgs a)
 {
     const int C = a.shuffle ? a.Cx / 4 : (a.act == BF16_ACT_GLU ? a.Cx / 2 : a.Cx);      // output channels
     const int noct = C >> 3;
-    const long long total = (long long)a.N * a.H * a.W * noct;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int oct = (int)(idx % noct);
+    const int P = a.H * a.W;
+    const long long total = (long long)a.N * P * noct;
+    const long long stride = (long long)gridDim.x * 256;
+    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c0 = (int)(idx % noct) * 8;
+    const int Cs = (a.act == BF16_ACT_GLU) ? 2 * C : C;                                    // channels of the statistics table
+    float g0[8], b0[8], g1[8], b1[8], sc0[8], sh0[8], sc1[8], sh1[8];                      // z = x * sc + sh
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        g0[j] = a.has_norm ? a.gamma[0][c0 + j] : 1.f; b0[j] = a.has_norm ? a.beta[0][c0 + j] : 0.f;
+        g1[j] = (a.has_norm && a.act == BF16_ACT_GLU) ? a.gamma[1][c0 + j] : 1.f;
+        b1[j] = (a.has_norm && a.act == BF16_ACT_GLU) ? a.beta[1][c0 + j] : 0.f;
+        sc0[j] = g0[j]; sh0[j] = b0[j]; sc1[j] = g1[j]; sh1[j] = b1[j];
+    }
+    int n_cached = -1;
+    for (; idx < total; idx += stride) {
         const long long pix = idx / noct;
-        const int P = a.H * a.W;
         const int n = (int)(pix / P), p = (int)(pix - (long long)n * P);
         const int h = p / a.W, w = p - h * a.W;
-        const int c0 = oct * 8;
-        const bf16_t* xp = a.x + (long long)n * a.x_sn + (long long)h * a.x_sh + (long long)w * a.x_sw;
-        float g0[8], b0[8], mean0[8], rstd0[8];
+        if (a.has_norm && n != n_cached) {
+            n_cached = n;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (a.has_norm) {
-                g0[j] = a.gamma[0][c0 + j]; b0[j] = a.beta[0][c0 + j];
-                const float* st = a.stats + ((long long)n * (a.act == BF16_ACT_GLU ? 2 * C : C) + c0 + j) * 2;
-                mean0[j] = st[0]; rstd0[j] = st[1];
-            } else { g0[j] = 1.f; b0[j] = 0.f; mean0[j] = 0.f; rstd0[j] = 1.f; }
+            for (int j = 0; j < 8; ++j) {
+                const float* st = a.stats + ((long long)n * Cs + c0 + j) * 2;
+                sc0[j] = st[1] * g0[j]; sh0[j] = b0[j] - st[0] * sc0[j];
+                if (a.act == BF16_ACT_GLU) { const float* sg = st + 2 * C; sc1[j] = sg[1] * g1[j]; sh1[j] = b1[j] - sg[0] * sc1[j]; }
+            }
         }
+        const bf16_t* xp = a.x + (long long)n * a.x_sn + (long long)h * a.x_sh + (long long)w * a.x_sw;
         auto out_ptr = [&](int oh, int ow) {
             long long o = (long long)n * a.y_sn + (long long)oh * a.y_sh + (long long)ow * a.y_sw;
             if (a.y_csplit > 0) o += (long long)(c0 / a.y_csplit) * a.y_sc2 + (c0 % a.y_csplit); else o += c0;
@@ -408,7 +501,7 @@ __global__ void __launch_bounds__(256) bf16_apply_kernel(const Bf16NormArgs a)
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float z = (f[4 * j + ij] - mean0[j]) * rstd0[j] * g0[j] + b0[j];
+                    const float z = f[4 * j + ij] * sc0[j] + sh0[j];
                     o[j] = (a.act == BF16_ACT_SILU) ? z * sigmoidf_(z) : z;
                 }
                 *reinterpret_cast<uint4*>(a.y + out_ptr(2 * h + (ij >> 1), 2 * w + (ij & 1))) = pack8(o);
@@ -420,19 +513,11 @@ __global__ void __launch_bounds__(256) bf16_apply_kernel(const Bf16NormArgs a)
                 float fg[8];
                 unpack8(*reinterpret_cast<const uint4*>(xp + C + c0), fg);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float zg = fg[j];
-                    if (a.has_norm) {
-                        const float* st = a.stats + ((long long)n * 2 * C + C + c0 + j) * 2;
-                        zg = (fg[j] - st[0]) * st[1] * a.gamma[1][c0 + j] + a.beta[1][c0 + j];
-                    }
-                    const float z = (f[j] - mean0[j]) * rstd0[j] * g0[j] + b0[j];
-                    o[j] = z * sigmoidf_(zg);
-                }
+                for (int j = 0; j < 8; ++j) o[j] = (f[j] * sc0[j] + sh0[j]) * sigmoidf_(fg[j] * sc1[j] + sh1[j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float z = (f[j] - mean0[j]) * rstd0[j] * g0[j] + b0[j];
+                    const float z = f[j] * sc0[j] + sh0[j];
                     o[j] = (a.act == BF16_ACT_SILU) ? z * sigmoidf_(z) : z;
                 }
             }
@@ -484,8 +569,15 @@ int mcvc_bf16_norm_launch(const Bf16NormArgs& a, hipStream_t s)
         hipLaunchKernelGGL(bf16_finalize_kernel, dim3((unsigned)cdiv_ll((long long)a.N * Cn, 256)), dim3(256), 0, s, a);
     }
     const long long work = (long long)a.N * a.H * a.W * (C >> 3);
-    long long blocks = cdiv_ll(work, 256);
-    if (blocks > 8192) blocks = 8192;
+    long long blocks = cdiv_ll(work, 256 * 4);              // ~4 pixels per thread
+    if (blocks > 4096) blocks = 4096;
+    {   // grid stride a multiple of the octet count: a thread keeps its channel octet (statistics stay in registers)
+        const int noct = C >> 3;
+        int g = noct, r = 256;
+        while (r) { const int t = g % r; g = r; r = t; }    // gcd(noct, 256)
+        const int unit = noct / g;
+        blocks = cdiv_ll(blocks, unit) * unit;
+    }
     TraceScope ts(K_NORM_FWD, s, 0.0, 2.0 * (el + (double)a.N * a.H * a.W * C * (a.shuffle ? 4.0 : 1.0)));
     hipLaunchKernelGGL(bf16_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     return (int)hipGetLastError();

@@ -133,7 +133,6 @@ static void conv(Run& r, const LayerB& l, const bf16_t* x, long long x_sn, int x
     a.KH = l.KH; a.KW = l.KW; a.stride = l.stride; a.pad_h = l.pad_h; a.pad_w = l.pad_w;
     a.OH = conv_out(H, l.KH, l.stride, l.pad_h); a.OW = conv_out(W, l.KW, l.stride, l.pad_w);
     a.glu = l.glu_fused;
-    mcvc_bf16_conv_tile(a.OH, a.OW, a.KH, a.KW, a.stride, &a.TH, &a.tw_log2);
     r.fail(mcvc_bf16_conv_launch(a, r.s));
 }
 
