@@ -647,8 +647,16 @@ static int trunk_pick_ksplit(int Cin, int KW, int M, int B, int W4, int must_spl
 
 // dX[ci][b][t] (+)= sum_{co,kw} W[co][ci][kw] dY[co][b][t + pw - kw]  through the transposed pack.  Large K (or an
 // accumulating destination) is split over workgroups that add atomically; a non-accumulating destination is zeroed first.
+struct TrunkPre {              // fused InstanceNorm backward in front of the data-gradient (trunk.h)
+    int kind;                  // 1 plain IN, 2 IN + gated GLU
+    const float* x; const float* stats;
+    const float* g0; const float* b0; const float* g1; const float* b1;
+    float* out;                // X' = gradient w.r.t. the conv output (the weight gradient reads it)
+    float* dg0; float* db0; float* dg1; float* db1;
+};
+
 static bool trunk_dgrad(Exec& ex, const ConvSpec& c, const float* packed, const float* dy, float* dx, int accumulate, int B, int W4,
-                        int* nsplit = nullptr)
+                        int* nsplit = nullptr, const TrunkPre* pre = nullptr)
 {
     if (!trunk_enabled() || c.off_tk < 0) return false;
     int ks = 1;
@@ -672,6 +680,12 @@ static bool trunk_dgrad(Exec& ex, const ConvSpec& c, const float* packed, const 
     a.Cin = c.cout_tot; a.KW = c.KW; a.K = c.cout_tot * c.KW; a.M = c.Cin; a.Mtot = c.Cin; a.B = B; a.T4 = W4; a.N = B * W4;
     a.conv_out = dx; a.c_sc = (long long)B * W4; a.c_sb = W4; a.accumulate = accumulate; a.mode = TRUNK_PLAIN;
     a.slabs = ex.slabs; a.slab_stride = tot; a.slab_all = slab_all ? 1 : 0;
+    if (pre) {
+        a.pre = pre->kind; a.pre_C = (pre->kind == 2) ? c.cout_tot / 2 : c.cout_tot;
+        a.pre_x = pre->x; a.pre_stats = pre->stats; a.pre_gamma0 = pre->g0; a.pre_beta0 = pre->b0; a.pre_gamma1 = pre->g1; a.pre_beta1 = pre->b1;
+        a.pre_out = pre->out; a.pre_dgamma0 = pre->dg0; a.pre_dbeta0 = pre->db0; a.pre_dgamma1 = pre->dg1; a.pre_dbeta1 = pre->db1;
+        wait_readers(ex, pre->out);
+    }
     ex.fail(mcvc_trunk_launch(a, ks, ex.s));
     return true;
 }
@@ -1030,10 +1044,27 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         else conv_dgrad(ex, g.c1d2d, packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
     }
     // ---- residual blocks (:258-263), last to first.  DH carries d(h) and is updated in place.
+    // small batch: the InstanceNorm backward of each layer is recomputed inside the data-gradient launch that consumes it (one thread
+    // per channel of the workgroup's K slice) -- 2 dependent launches per residual block instead of 4.  Needs an un-split upstream
+    // gradient (the fused staging does not sum slabs) and the fused data-gradient kernels for both convs of the block.
+    static const int fuse_knob = [] { const char* e = getenv("MCVC_TRUNK_BWD_FUSE"); return e ? atoi(e) : 1; }();
     for (int i = 5; i >= 0; --i) {
         const int b = 24 + 12 * i;
         const float* hin = (i == 0) ? (st + o.y4) : (st + o.r[i - 1].y);
         DT3 = DT3s[i & 1]; DT1 = DT1s[i & 1];
+        const bool fuse = fuse_knob && trunk_enabled() && ns == 1 && !ex.dry && G && g.res_out[i].off_tk >= 0 && g.res_vg[i].off_tk >= 0 &&
+                          mcvc_trunk_applies(g.res_out[i].cout_tot, 3, g.res_out[i].Cin, B, W4, TRUNK_PLAIN, 1) &&
+                          trunk_pick_ksplit(g.res_vg[i].cout_tot, 3, g.res_vg[i].Cin, B, W4, 0) >= 1;
+        if (fuse) {
+            TrunkPre pa{1, st + o.r[i].cb, st + o.r[i].sb, P[b + 10], P[b + 11], nullptr, nullptr, DT3, G[b + 10], G[b + 11], nullptr, nullptr};
+            trunk_dgrad(ex, g.res_out[i], packed, DH, DT2, 0, B, W4, nullptr, &pa);
+            conv_wgrad(ex, g.res_out[i], G, 1, B, W4, CView{st + o.r[i].ya, 0, BT4, W4}, CView{DT3, 0, BT4, W4});
+            TrunkPre pb{2, st + o.r[i].ca, st + o.r[i].sa, P[b + 2], P[b + 3], P[b + 6], P[b + 7], DT1, G[b + 2], G[b + 3], G[b + 6], G[b + 7]};
+            ns = 1;
+            trunk_dgrad(ex, g.res_vg[i], packed, DT2, DH, 1, B, W4, &ns, &pb);
+            conv_wgrad(ex, g.res_vg[i], G, 1, B, W4, CView{hin, 0, BT4, W4}, CView{DT1, 0, BT4, W4});
+            continue;
+        }
         norm_bwd(ex, st + o.r[i].cb, W4, BT4, normp(P, G, b + 10, b + 11), st + o.r[i].sb, DH, W4, BT4, W4, 256 * BT4, ns,
                  DT3, W4, BT4, W4, 0, B, 256, 1, W4, ACT_NONE);
         int ns2 = 1;

@@ -21,6 +21,17 @@ struct TrunkArgs {
     float* y; const float* res; long long y_sn; long long y_sc;   // plane (b, c) at y + b*y_sn + c*y_sc
     float eps;
     int mode;
+    // ---- fused InstanceNorm backward in front of a data-gradient (mode TRUNK_PLAIN): the staged input is not `x` itself but
+    //      X' = IN-backward(x) of the layer being back-propagated -- every workgroup recomputes the rows of its K slice (a few hundred
+    //      flops per row) instead of waiting for a separate norm_bwd launch; the workgroups with blockIdx.x == 0 also store X' (the
+    //      weight-gradient kernel reads it) and accumulate d(gamma), d(beta).
+    int pre;                                // 0 none; 1 plain IN (x = upstream gradient of the norm output); 2 IN + gated GLU
+    int pre_C;                              // normalised channels per branch (X' has pre_C or 2*pre_C channels)
+    const float* pre_x;                     // conv output of the forward pass (pre-norm), [Cx][B][T4]
+    const float* pre_stats;                 // [B][Cx][2] mean, rstd
+    const float* pre_gamma0; const float* pre_beta0; const float* pre_gamma1; const float* pre_beta1;
+    float* pre_out;                         // X' [Cx][B][T4]
+    float* pre_dgamma0; float* pre_dbeta0; float* pre_dgamma1; float* pre_dbeta1;     // accumulated (+=); nullable
 };
 
 bool mcvc_trunk_applies(int Cin, int KW, int M, int B, int T4, int mode, int ksplit);

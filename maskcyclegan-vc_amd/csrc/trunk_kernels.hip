@@ -36,7 +36,7 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 // 16x16x4 fp32 MFMA: lane l holds A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; D register r is row 4*(l >> 4) + r,
 // column l & 15.  A float4 of consecutive k per lane feeds four MFMAs (any 4 distinct k per instruction are fine as long as
 // the B operand uses the same ones).
-template <int KW, int NA>
+template <int KW, int NA, bool PRE>
 __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const TrunkArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -85,7 +85,100 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const TrunkA
     TRUNK_LOAD_CHUNK(0);
 
     // ---- stage X[ci][b][t] (this block's channel slice) with zero halo
-    {
+    if constexpr (PRE) {
+        // fused InstanceNorm backward (see trunk.h): one thread per channel of the slice, two passes over its T4 <= 32 elements per sample
+        const int C = a.pre_C;
+        const bool pglu = (a.pre == 2);
+        const int Cx = pglu ? 2 * C : C;
+        const bool out = (blockIdx.x == 0);
+        const float invT = 1.0f / (float)a.T4;
+        const bool vec = ((a.T4 & 3) == 0) && ((a.x_sb & 3) == 0) && ((a.x_sc & 3) == 0) &&
+                         (((reinterpret_cast<unsigned long long>(a.x) | reinterpret_cast<unsigned long long>(a.pre_x)) & 15ull) == 0);
+        const int nq = a.T4 >> 2;                            // float4 per row (<= 8)
+        for (int ci = tid; ci < ci_count; ci += kTrunkThreads) {
+            const int cx = ci_begin + ci;
+            const bool gate = pglu && cx >= C;
+            const int c = gate ? cx - C : cx;
+            const float g0 = a.pre_gamma0[c], b0 = a.pre_beta0[c];
+            const float g1 = pglu ? a.pre_gamma1[c] : 0.f, b1 = pglu ? a.pre_beta1[c] : 0.f;
+            float* xrow = smem + ci * RS;
+            float dgam = 0.f, dbet = 0.f;
+            for (int b = 0; b < a.B; ++b) {
+                const float* st = a.pre_stats + (long long)b * Cx * 2;
+                const float m0 = st[2 * c], r0 = st[2 * c + 1];
+                const float m1 = pglu ? st[2 * (c + C)] : 0.f, r1 = pglu ? st[2 * (c + C) + 1] : 1.f;
+                const float* dyr = a.x + (long long)c * a.x_sc + (long long)b * a.x_sb;
+                const float* x0r = a.pre_x + ((long long)c * a.B + b) * a.T4;
+                const float* x1r = a.pre_x + ((long long)(c + C) * a.B + b) * a.T4;
+                // all loads of the (up to three) rows first, then everything from registers: dz / xh are kept for the second pass
+                float dzv[32], xhv[32];
+                {
+                    float4 vd[8], v0[8], v1[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (vec) {
+                            const bool ok = q < nq;
+                            vd[q] = ok ? *reinterpret_cast<const float4*>(dyr + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            v0[q] = ok ? *reinterpret_cast<const float4*>(x0r + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                            v1[q] = (ok && pglu) ? *reinterpret_cast<const float4*>(x1r + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        } else {
+                            float td[4], t0[4], t1[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int t = 4 * q + j;
+                                const bool ok = t < a.T4;
+                                td[j] = ok ? dyr[t] : 0.f; t0[j] = ok ? x0r[t] : 0.f; t1[j] = (ok && pglu) ? x1r[t] : 0.f;
+                            }
+                            vd[q] = make_float4(td[0], td[1], td[2], td[3]); v0[q] = make_float4(t0[0], t0[1], t0[2], t0[3]);
+                            v1[q] = make_float4(t1[0], t1[1], t1[2], t1[3]);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const float dd[4] = {vd[q].x, vd[q].y, vd[q].z, vd[q].w};
+                        const float a0[4] = {v0[q].x, v0[q].y, v0[q].z, v0[q].w};
+                        const float a1[4] = {v1[q].x, v1[q].y, v1[q].z, v1[q].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float xh0 = (a0[j] - m0) * r0;
+                            float dz, xh;
+                            if (pglu) {
+                                const float xh1 = (a1[j] - m1) * r1;
+                                const float sg = sigmoidf_(xh1 * g1 + b1);
+                                if (gate) { dz = dd[j] * (xh0 * g0 + b0) * sg * (1.0f - sg); xh = xh1; }
+                                else { dz = dd[j] * sg; xh = xh0; }
+                            } else { dz = dd[j]; xh = xh0; }
+                            const bool live = (4 * q + j) < a.T4;
+                            dzv[4 * q + j] = live ? dz : 0.f; xhv[4 * q + j] = live ? xh : 0.f;
+                        }
+                    }
+                }
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int t = 0; t < 32; ++t) { s1 += dzv[t]; s2 += dzv[t] * xhv[t]; }
+                const float gr = gate ? g1 * r1 : g0 * r0;
+                float* xs = xrow + b * TP + PW;
+                float* od = out ? (a.pre_out + ((long long)cx * a.B + b) * a.T4) : nullptr;
+#pragma unroll
+                for (int t = 0; t < 32; ++t) {
+                    if (t < a.T4) {
+                        const float dxv = gr * (dzv[t] - s1 * invT - xhv[t] * (s2 * invT));
+                        xs[t] = dxv;
+                        if (od) od[t] = dxv;
+                    }
+                }
+                for (int hcol = 0; hcol < PW; ++hcol) { xrow[b * TP + hcol] = 0.f; xrow[b * TP + PW + a.T4 + hcol] = 0.f; }
+                dgam += s2; dbet += s1;
+            }
+            xrow[a.B * TP] = 0.f;
+            if (out) {
+                float* dg = gate ? a.pre_dgamma1 : a.pre_dgamma0;
+                float* db = gate ? a.pre_dbeta1 : a.pre_dbeta0;
+                if (dg) dg[c] += dgam;
+                if (db) db[c] += dbet;
+            }
+        }
+    } else {
         const float* xsrc = a.x + (long long)ci_begin * a.x_sc;
         const bool fast = (a.x_sb == a.T4) && (a.x_sc == (long long)a.B * a.T4) && ((a.T4 & 3) == 0) &&
                           ((reinterpret_cast<unsigned long long>(xsrc) & 15ull) == 0);
@@ -593,17 +686,23 @@ long long mcvc_trunk_lds_floats(int Cin, int KW, int B, int T4, int ksplit)
     return xs > epi ? xs : epi;
 }
 
-template <int KW, int NA>
-static int trunk_launch_t(const TrunkArgs& a, dim3 grid, size_t lds, hipStream_t s)
+template <int KW, int NA, bool PRE>
+static int trunk_launch_p(const TrunkArgs& a, dim3 grid, size_t lds, hipStream_t s)
 {
     static bool done = false;
     if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_layer_kernel<KW, NA>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(trunk_layer_kernel<KW, NA, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         done = true;
     }
-    hipLaunchKernelGGL((trunk_layer_kernel<KW, NA>), grid, dim3(kTrunkThreads), lds, s, a);
+    hipLaunchKernelGGL((trunk_layer_kernel<KW, NA, PRE>), grid, dim3(kTrunkThreads), lds, s, a);
     return (int)hipGetLastError();
+}
+
+template <int KW, int NA>
+static int trunk_launch_t(const TrunkArgs& a, dim3 grid, size_t lds, hipStream_t s)
+{
+    return a.pre ? trunk_launch_p<KW, NA, true>(a, grid, lds, s) : trunk_launch_p<KW, NA, false>(a, grid, lds, s);
 }
 
 int mcvc_trunk_launch(const TrunkArgs& a, int ksplit, hipStream_t s)
@@ -611,6 +710,7 @@ int mcvc_trunk_launch(const TrunkArgs& a, int ksplit, hipStream_t s)
     if (!mcvc_trunk_applies(a.Cin, a.KW, a.M, a.B, a.T4, a.mode, ksplit)) return MCVC_ERR_INVALID;
     if (ksplit > 1 && !(a.mode == TRUNK_PLAIN && (a.accumulate || a.slabs))) return MCVC_ERR_INVALID;
     if (a.slab_all && !(a.mode == TRUNK_PLAIN && a.slabs)) return MCVC_ERR_INVALID;
+    if (a.pre && (a.mode != TRUNK_PLAIN || a.T4 > 32 || !a.pre_x || !a.pre_stats || !a.pre_out)) return MCVC_ERR_INVALID;
     const int rows = (a.mode == TRUNK_IN_GLU) ? 8 : 16;
     dim3 grid((unsigned)(a.M / rows), (unsigned)ksplit);
     const size_t lds = (size_t)mcvc_trunk_lds_floats(a.Cin, a.KW, a.B, a.T4, ksplit) * sizeof(float);

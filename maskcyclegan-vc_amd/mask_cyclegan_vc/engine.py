@@ -118,6 +118,10 @@ class TrainEngine:
         self.use_graphs = False
         self._graphs, self._eager_runs = {}, {}
         self._capture_stream = torch.cuda.Stream(device=dev)
+        # the discriminators' weight re-pack after their Adam step is needed only ~1.5 ms later (after the next iteration's
+        # four generator forwards): it runs on its own stream and the discriminator forwards wait for its event
+        self._pack_stream = torch.cuda.Stream(device=dev)
+        self._d_pack_event = None
         # data parallel: start the discriminator gradient all-reduce at the end of an iteration and finish the update
         # (wait + Adam + re-pack) where the discriminators are next used, i.e. after the next generator forwards
         self.defer_d_update = self.reducer.world > 1
@@ -274,8 +278,6 @@ class TrainEngine:
         B, B2 = self.B, 2 * self.B
         m = self.mel
         sc = self.sched
-        if not self.defer_d_update:
-            self.repack(D_NAMES)           # discriminator weights changed at the end of the previous iteration
         self.slots.zero_()
         self.g_group.grad.zero_()
         # batched inputs (device-to-device copies; the batch dimension is outermost, so halves are contiguous views)
@@ -295,7 +297,7 @@ class TrainEngine:
 
         if self.defer_d_update:            # data parallel: the D gradient all-reduce of the previous iteration ran behind the
             self._finish_d_update()        # generator forwards above; the discriminators are first needed here
-            self.repack(D_NAMES)
+        self._wait_d_pack()                # discriminator weights changed at the end of the previous iteration
         self._lanes(lambda ln: self._D("discriminator_A", fake_A, do[0], ds[0], B, ln),              # :211
                     lambda ln: self._D("discriminator_B", fake_B, do[1], ds[1], B, ln),              # :212
                     lambda ln: self._D("discriminator_A2", m["cycle_A"], do[2], ds[2], B, ln),       # :215
@@ -378,6 +380,7 @@ class TrainEngine:
             return
         self.reducer.reduce_(self.d_group.grad)
         self._adam(self.d_group, self.sched.d_opt_lr)
+        self._repack_d_async()
 
     def _finish_d_update(self):
         if self._pending_d_lr is None:
@@ -385,10 +388,28 @@ class TrainEngine:
         self.reducer.wait(self.device)
         self._adam(self.d_group, self._pending_d_lr)
         self._pending_d_lr = None
+        self._repack_d_async()
+
+    def _repack_d_async(self):
+        """Refresh the discriminators' packed weights on the pack stream (ordered after the Adam step just queued)."""
+        cur = torch.cuda.current_stream(self.device)
+        self._pack_stream.wait_stream(cur)
+        with torch.cuda.stream(self._pack_stream):
+            for n in D_NAMES:
+                self._repack1(n)
+            ev = torch.cuda.Event()
+            ev.record()
+        self._d_pack_event = ev
+
+    def _wait_d_pack(self):
+        if self._d_pack_event is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._d_pack_event)
+            self._d_pack_event = None
 
     def flush(self):
         """Complete a deferred discriminator update (call before reading parameters / optimizer state from outside)."""
         self._finish_d_update()
+        self._wait_d_pack()
 
     def step(self, real_A, mask_A, real_B, mask_B):
         """One full iteration.  Inputs: float32 [B,80,T] on the engine's device.  Returns the loss-slot

@@ -21,6 +21,11 @@ LAYERS = {  # Cin, Cout(total, value|gate concatenated), KH, KW, stride, ph, pw,
     "g.up1": (256, 1024, 5, 5, 1, 2, 2, 20, 16, 1), "g.up2": (256, 512, 5, 5, 1, 2, 2, 40, 32, 1), "g.last": (128, 1, 5, 15, 1, 2, 7, 80, 64, 0),
     "d.conv1": (1, 256, 3, 3, 1, 1, 1, 80, 64, 0), "d.ds1": (128, 512, 3, 3, 2, 1, 1, 80, 64, 0), "d.ds2": (256, 1024, 3, 3, 2, 1, 1, 40, 32, 0),
     "d.ds3": (512, 2048, 3, 3, 2, 1, 1, 20, 16, 0), "d.ds4": (1024, 2048, 1, 5, 1, 0, 2, 10, 8, 0), "d.out": (1024, 1, 1, 3, 1, 0, 1, 10, 8, 0),
+    # the discriminator's real layers and the 1-D trunk as the network runs it at larger batch: ONE image of B rows x T/4 columns
+    "D.ds1": (128, 256, 3, 3, 2, 1, 1, 80, 64, 0), "D.ds2": (256, 512, 3, 3, 2, 1, 1, 40, 32, 0), "D.ds3": (512, 1024, 3, 3, 2, 1, 1, 20, 16, 0),
+    "t.vg8": (256, 1024, 1, 3, 1, 0, 1, 8, 16, 0), "t.vg16": (256, 1024, 1, 3, 1, 0, 1, 16, 16, 0), "t.vg64": (256, 1024, 1, 3, 1, 0, 1, 64, 16, 0),
+    "t.out8": (512, 256, 1, 3, 1, 0, 1, 8, 16, 0), "t.out16": (512, 256, 1, 3, 1, 0, 1, 16, 16, 0), "t.out64": (512, 256, 1, 3, 1, 0, 1, 64, 16, 0),
+    "t.c2d16": (5120, 256, 1, 1, 1, 0, 0, 16, 16, 0), "t.c1d16": (256, 5120, 1, 1, 1, 0, 0, 16, 16, 0),
 }
 ap = argparse.ArgumentParser()
 ap.add_argument("layers", nargs="*")
