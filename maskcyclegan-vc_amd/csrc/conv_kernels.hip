@@ -849,6 +849,84 @@ __global__ void __launch_bounds__(256) wgrad_smallk_kernel(const SmallKArgs a)
             if (co0 + c < a.Cout) a.dw[((long long)(co0 + c) * a.Cin + ci) * KW + k] = old[c][k] + acc[c][k];
 }
 
+// ---- the same, batched over layers (k = 3, trunk layout [C][B][T4], B*T4 <= 128): block -> (job, 4 output channels, 256 input channels)
+struct SmallKBatch { SmallKJob job[MCVC_SMALLK_MAX_JOBS]; int first[MCVC_SMALLK_MAX_JOBS + 1]; int njobs, B, T4; };
+
+__global__ void __launch_bounds__(256) wgrad_smallk_batch_kernel(const SmallKBatch bt)
+{
+    constexpr int KW = 3, COB = 4;
+    __shared__ float dys[COB * 128];
+    const int tid = threadIdx.x;
+    int j = 0;
+    while (j + 1 < bt.njobs && (int)blockIdx.x >= bt.first[j + 1]) ++j;
+    const SmallKJob jb = bt.job[j];
+    const int local = (int)blockIdx.x - bt.first[j];
+    const int ci_tiles = (jb.Cin + 255) >> 8;
+    const int co0 = (local / ci_tiles) * COB;
+    const int ci = (local % ci_tiles) * 256 + tid;
+    const int npix = bt.B * bt.T4;
+    for (int i = tid; i < COB * npix; i += 256) {
+        const int co = i / npix, p = i - co * npix;
+        dys[co * npix + p] = (co0 + co < jb.Cout) ? jb.dy[(long long)(co0 + co) * npix + p] : 0.f;
+    }
+    __syncthreads();
+    if (ci >= jb.Cin) return;
+    float acc[COB][KW];
+#pragma unroll
+    for (int c = 0; c < COB; ++c)
+#pragma unroll
+        for (int k = 0; k < KW; ++k) acc[c][k] = 0.f;
+    for (int b = 0; b < bt.B; ++b) {
+        const float* xr = jb.x + (long long)ci * npix + b * bt.T4;
+        const float* dr = dys + b * bt.T4;
+#pragma unroll 4
+        for (int q = 0; q < bt.T4; ++q) {
+            const float xv = xr[q];
+#pragma unroll
+            for (int k = 0; k < KW; ++k) {
+                const int ow = q - k + 1;
+                if (ow >= 0 && ow < bt.T4) {
+#pragma unroll
+                    for (int c = 0; c < COB; ++c) acc[c][k] += dr[c * npix + ow] * xv;
+                }
+            }
+        }
+    }
+    float old[COB][KW];
+#pragma unroll
+    for (int c = 0; c < COB; ++c)
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            old[c][k] = (co0 + c < jb.Cout) ? jb.dw[((long long)(co0 + c) * jb.Cin + ci) * KW + k] : 0.f;
+#pragma unroll
+    for (int c = 0; c < COB; ++c)
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            if (co0 + c < jb.Cout) jb.dw[((long long)(co0 + c) * jb.Cin + ci) * KW + k] = old[c][k] + acc[c][k];
+}
+
+bool mcvc_wgrad_smallk_batch_applies(int B, int T4) { return B >= 1 && T4 >= 1 && (long long)B * T4 <= 128; }
+
+int mcvc_wgrad_smallk_batch_launch(const SmallKJob* jobs, int njobs, int B, int T4, hipStream_t s)
+{
+    if (njobs < 1 || njobs > MCVC_SMALLK_MAX_JOBS || !mcvc_wgrad_smallk_batch_applies(B, T4)) return MCVC_ERR_INVALID;
+    SmallKBatch bt{};
+    int total = 0;
+    double flops = 0.0, bytes = 0.0;
+    const double px = (double)B * T4;
+    for (int j = 0; j < njobs; ++j) {
+        bt.job[j] = jobs[j];
+        bt.first[j] = total;
+        total += cdiv_i(jobs[j].Cout, 4) * cdiv_i(jobs[j].Cin, 256);
+        flops += 2.0 * px * jobs[j].Cout * jobs[j].Cin * 3;
+        bytes += 4.0 * (2.0 * jobs[j].Cout * jobs[j].Cin * 3 + px * (jobs[j].Cin + jobs[j].Cout));
+    }
+    bt.first[njobs] = total; bt.njobs = njobs; bt.B = B; bt.T4 = T4;
+    TraceScope ts(K_WGRAD_SMALLK, s, flops, bytes);
+    hipLaunchKernelGGL(wgrad_smallk_batch_kernel, dim3((unsigned)total), dim3(256), 0, s, bt);
+    return (int)hipGetLastError();
+}
+
 namespace {
 template <int MS, int KWT, int MAXT, int MINW = 1>
 static hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, int nwaves, size_t lds, hipStream_t s)

@@ -190,6 +190,13 @@ int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw
 // scratch floats the K-split of this weight gradient wants (0 = no split)
 long long mcvc_wgrad_plan_slab_floats(const ConvProblem& p, int NB);
 
+// Batched small-K weight gradients (1-D trunk at small batch): all of a backward pass's trunk layers in ONE launch.
+// Every job is dW[co][ci][kw] += sum_{b,t} dY[co][b][t] * X[ci][b][t + kw - 1]  with dY, X in trunk layout [C][B][T4].
+struct SmallKJob { const float* x; const float* dy; float* dw; int Cin, Cout; };
+#define MCVC_SMALLK_MAX_JOBS 24
+int mcvc_wgrad_smallk_batch_launch(const SmallKJob* jobs, int njobs, int B, int T4, hipStream_t s);
+bool mcvc_wgrad_smallk_batch_applies(int B, int T4);
+
 int mcvc_norm_fwd_launch(const NormArgs& a, hipStream_t s);
 int mcvc_norm_bwd_launch(const NormBwdArgs& a, hipStream_t s);
 int mcvc_act_fwd_launch(const ActArgs& a, hipStream_t s);

@@ -848,7 +848,7 @@ static GenStash gen_stash(const GenDims& d)
     return s;
 }
 
-struct GenScratch { long long ga, gb, gb2, dh, dt1, dt1b, dt2, dt3, dt3b, wv, wm, wino_floats, wv2, wm2, wu, wu_floats, sync, slabs; };
+struct GenScratch { long long ga, gb, gb2, dh, dt1, dt1b, dt2, dt3, dt3b, dtx1, dtx3, wv, wm, wino_floats, wv2, wm2, wu, wu_floats, sync, slabs; };
 static GenScratch gen_scratch(const GenDims& d)
 {
     GenScratch s{};
@@ -857,6 +857,9 @@ static GenScratch gen_scratch(const GenDims& d)
     s.ga = take(d.big); s.gb = take(d.big); s.gb2 = take(d.big);
     s.dh = take((long long)256 * d.B * d.W4); s.dt1 = take((long long)1024 * d.B * d.W4); s.dt1b = take((long long)1024 * d.B * d.W4);
     s.dt2 = take((long long)512 * d.B * d.W4); s.dt3 = take((long long)256 * d.B * d.W4); s.dt3b = take((long long)256 * d.B * d.W4);
+    // small batch: one conv-output gradient buffer per residual layer, so that ONE batched launch computes all their weight gradients
+    s.dtx1 = take(mcvc_wgrad_smallk_batch_applies(d.B, d.W4) ? 6LL * 1024 * d.B * d.W4 : 0);
+    s.dtx3 = take(mcvc_wgrad_smallk_batch_applies(d.B, d.W4) ? 6LL * 256 * d.B * d.W4 : 0);
     // Winograd V / M of upSample1 (1024 ch, tiles of a 20 x W4 image) and upSample2 (512 ch, 40 x 2*W4)
     {
         const long long nt1 = ((long long)d.B * 10 * ((d.W4 + 1) / 2) + 31) & ~31LL, nt2 = ((long long)d.B * 20 * ((d.Wu1 + 1) / 2) + 31) & ~31LL;
@@ -1048,6 +1051,10 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
     // per channel of the workgroup's K slice) -- 2 dependent launches per residual block instead of 4.  Needs an un-split upstream
     // gradient (the fused staging does not sum slabs) and the fused data-gradient kernels for both convs of the block.
     static const int fuse_knob = [] { const char* e = getenv("MCVC_TRUNK_BWD_FUSE"); return e ? atoi(e) : 1; }();
+    static const int batch_knob = [] { const char* e = getenv("MCVC_TRUNK_WGRAD_BATCH"); return e ? atoi(e) : 1; }();
+    SmallKJob wjobs[MCVC_SMALLK_MAX_JOBS];
+    int nwjobs = 0;
+    const bool batch_w = batch_knob && mcvc_wgrad_smallk_batch_applies(B, W4) && (W4 <= 128);
     for (int i = 5; i >= 0; --i) {
         const int b = 24 + 12 * i;
         const float* hin = (i == 0) ? (st + o.y4) : (st + o.r[i - 1].y);
@@ -1056,13 +1063,20 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
                           mcvc_trunk_applies(g.res_out[i].cout_tot, 3, g.res_out[i].Cin, B, W4, TRUNK_PLAIN, 1) &&
                           trunk_pick_ksplit(g.res_vg[i].cout_tot, 3, g.res_vg[i].Cin, B, W4, 0) >= 1;
         if (fuse) {
+            if (batch_w) { DT3 = sc + q.dtx3 + (long long)i * 256 * BT4; DT1 = sc + q.dtx1 + (long long)i * 1024 * BT4; }
             TrunkPre pa{1, st + o.r[i].cb, st + o.r[i].sb, P[b + 10], P[b + 11], nullptr, nullptr, DT3, G[b + 10], G[b + 11], nullptr, nullptr};
             trunk_dgrad(ex, g.res_out[i], packed, DH, DT2, 0, B, W4, nullptr, &pa);
-            conv_wgrad(ex, g.res_out[i], G, 1, B, W4, CView{st + o.r[i].ya, 0, BT4, W4}, CView{DT3, 0, BT4, W4});
             TrunkPre pb{2, st + o.r[i].ca, st + o.r[i].sa, P[b + 2], P[b + 3], P[b + 6], P[b + 7], DT1, G[b + 2], G[b + 3], G[b + 6], G[b + 7]};
             ns = 1;
             trunk_dgrad(ex, g.res_vg[i], packed, DT2, DH, 1, B, W4, &ns, &pb);
-            conv_wgrad(ex, g.res_vg[i], G, 1, B, W4, CView{hin, 0, BT4, W4}, CView{DT1, 0, BT4, W4});
+            if (batch_w) {          // weight gradients of the block: queued for the batched launch behind the chain
+                wjobs[nwjobs++] = SmallKJob{st + o.r[i].ya, DT3, G[g.res_out[i].wi[0]], 512, 256};
+                wjobs[nwjobs++] = SmallKJob{hin, DT1, G[g.res_vg[i].wi[0]], 256, 512};
+                wjobs[nwjobs++] = SmallKJob{hin, DT1 + 512LL * BT4, G[g.res_vg[i].wi[1]], 256, 512};
+            } else {
+                conv_wgrad(ex, g.res_out[i], G, 1, B, W4, CView{st + o.r[i].ya, 0, BT4, W4}, CView{DT3, 0, BT4, W4});
+                conv_wgrad(ex, g.res_vg[i], G, 1, B, W4, CView{hin, 0, BT4, W4}, CView{DT1, 0, BT4, W4});
+            }
             continue;
         }
         norm_bwd(ex, st + o.r[i].cb, W4, BT4, normp(P, G, b + 10, b + 11), st + o.r[i].sb, DH, W4, BT4, W4, 256 * BT4, ns,
@@ -1083,6 +1097,16 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
             if (!trunk_dgrad(ex, g.res_vg[i], packed, DT1, DH, 1 /*accumulate: skip path*/, B, W4, &ns))
                 conv_dgrad(ex, g.res_vg[i], packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 1, 1, nullptr);
         }
+    }
+    if (nwjobs > 0) {              // ONE launch for the residual layers' weight gradients, beside the rest of the backward chain
+        hipStream_t ws = ex.s;
+        if (ex.s2) {
+            hipEvent_t e = pool_event();
+            ex.fail((int)hipEventRecord(e, ex.s));
+            ex.fail((int)hipStreamWaitEvent(ex.s2, e, 0));
+            ws = ex.s2;
+        }
+        ex.fail(mcvc_wgrad_smallk_batch_launch(wjobs, nwjobs, B, W4, ws));
     }
     if (milestones) record_milestone(ex, milestones[1]);          // parameters [24,100) are done
     // ---- conv2dto1d + IN (:254-255)
