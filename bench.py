@@ -233,6 +233,7 @@ def main():
     ap.add_argument("--no-trace", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one stream: no lanes, no auxiliary weight-gradient stream (A/B comparison, per-kernel profiling)")
     ap.add_argument("--graphs", action="store_true", help="replay HIP graphs of the two phases (experimental; not faster on ROCm 7.2)")
+    ap.add_argument("--graphs-aux", action="store_true", help="with --graphs: keep the auxiliary weight-gradient streams inside the capture")
     ap.add_argument("--dump-trace", default=None, help="write one traced step's per-launch records (launch order) to this file")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")
     args = ap.parse_args()
@@ -265,7 +266,7 @@ def main():
     if args.serial:
         engine.aux_wgrad = False          # truly one stream: per-kernel durations comparable with the traced step's
     engine.use_graphs = args.graphs
-    if args.graphs:
+    if args.graphs and not args.graphs_aux:
         engine.aux_wgrad = False            # lanes + auxiliary streams in one capture crash hipStreamEndCapture (ROCm 7.2)
     batches = synthetic_batches(args.n_batches, B, T, rank, device)
     log("engine ready; warm-up")

@@ -128,6 +128,11 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     };
     // ---- input patch: small patches (<= kMaxPP pieces per thread) are prefetched through registers one chunk ahead; large ones
     //      (stride-2 layers) are staged synchronously, four loads in flight per thread
+    // stride 2: patch columns are stored de-interleaved (even columns, then odd columns) so that the 16 lanes of an operand read --
+    // output columns c, c+1, ... = input columns 2c+kw, 2c+2+kw, ... -- walk CONSECUTIVE LDS pixels (conflict-free with the swizzle)
+    const bool s2 = a.stride == 2;
+    const int PWe = (a.PW + 1) >> 1;
+    auto patch_col = [&](int j) { return s2 ? (j < PWe ? 2 * j : 2 * (j - PWe) + 1) : j; };
     const bool p_pref = patch_pieces <= kMaxPP * kConvThreads;
     long long poff[kMaxPP];                   // element offset of the piece inside the image (without the chunk offset); -1 = zero fill
 #pragma unroll
@@ -135,7 +140,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
         const int q = tid + i * kConvThreads;
         const int pp = q >> 2, pos = q & 3;
         const int pr = pp / a.PW, pc = pp - pr * a.PW;
-        const int ih = ih0 + pr, iw = iw0 + pc;
+        const int ih = ih0 + pr, iw = iw0 + patch_col(pc);
         const bool ok = p_pref && q < patch_pieces && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
         poff[i] = ok ? ((long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 2) & 3)) * 8) : -1;
     }
@@ -162,7 +167,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
                 const int q = q0 + u * kConvThreads;
                 const int pp = q >> 2, pos = q & 3;
                 const int pr = pp / a.PW, pc = pp - pr * a.PW;
-                const int ih = ih0 + pr, iw = iw0 + pc;
+                const int ih = ih0 + pr, iw = iw0 + patch_col(pc);
                 v[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (q < patch_pieces && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
                     v[u] = *reinterpret_cast<const uint4*>(xb + (long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 2) & 3)) * 8);
@@ -183,7 +188,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     for (int nt = 0; nt < NT; ++nt) {
         const int n = (wn * NT + nt) * 32 + l31;
         const int pr = n >> a.tw_log2, pc = n & (TW - 1);
-        ppB[nt] = pr * a.stride * a.PW + pc * a.stride;
+        ppB[nt] = pr * a.stride * a.PW + pc;          // (stride 2: de-interleaved columns -> lane stride 1)
     }
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -218,7 +223,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
                     av[mt] = *reinterpret_cast<const bf16x8*>(Wb + (size_t)(((rowA[mt] * KW + tap) << 2) + (lc ^ gA[mt])) * 16);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int pp = ppB[nt] + pk + tap;
+                    const int pp = ppB[nt] + pk + (s2 ? (tap >> 1) + (tap & 1) * PWe : tap);
                     bv[nt] = *reinterpret_cast<const bf16x8*>(Xs + (size_t)((pp << 2) + (lc ^ ((pp >> 2) & 3))) * 16);
                 }
 #pragma unroll
@@ -314,10 +319,14 @@ int conv_launch_kw(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
 
 }  // namespace
 
-// tile configuration: 0 = 128 channels x 128 pixels, 1 = 64 x 64 (few pixels: more workgroups), 2 = 32 x 128 (few output channels)
+// tile configuration: 0 = 128 channels x 128 pixels, 1 = 64 x 64 (few pixels: more workgroups), 2 = 32 x 128 (few output channels),
+// 3 = 128 x 64 (tried for the stride-2 layers -- two workgroups per CU instead of one: measured SLOWER, 187 vs 206 TF/s, so it is
+// only reachable through MCVC_BF16_CFG=3 for experiments)
 static int conv_config(const Bf16ConvArgs& a)
 {
+    static const int knob = [] { const char* e = getenv("MCVC_BF16_CFG"); return e ? atoi(e) : -1; }();
     if (a.Cout_pad % 64 != 0) return 2;
+    if (knob == 3 && a.stride == 2 && a.Cout_pad % 128 == 0 && !a.glu) return 3;
     const long long px = (long long)a.N * a.OH * a.OW;
     if (a.Cout_pad % 128 != 0 || a.glu == 0) {
         // small problems: 128 x 128 tiles would leave most of the 256 CUs idle
@@ -348,7 +357,7 @@ int mcvc_bf16_conv_launch(const Bf16ConvArgs& a0, hipStream_t s)
     Bf16ConvArgs a = a0;
     if ((a.Cin & 31) || (a.Cout & 3) || a.KW < 1 || a.KH < 1) return MCVC_ERR_INVALID;
     const int cfg = conv_config(a);
-    const int BM = cfg == 0 ? 128 : (cfg == 1 ? 64 : 32), BN = cfg == 1 ? 64 : 128;
+    const int BM = (cfg == 0 || cfg == 3) ? 128 : (cfg == 1 ? 64 : 32), BN = (cfg == 1 || cfg == 3) ? 64 : 128;
     if (a.Cout_pad % BM) return MCVC_ERR_INVALID;
     if (a.glu && cfg != 0) return MCVC_ERR_INVALID;
     mcvc_bf16_conv_tile(a.OH, a.OW, a.KH, a.KW, a.stride, BN, &a.TH, &a.tw_log2);
@@ -366,6 +375,7 @@ int mcvc_bf16_conv_launch(const Bf16ConvArgs& a0, hipStream_t s)
                   2.0 * ((double)a.N * a.H * a.W * a.Cin + px * a.Cout + (double)a.Cout_pad * a.Cin * a.KH * a.KW));
     if (cfg == 0) return conv_launch_kw<2, 2, 2, 2>(a, lds, s);
     if (cfg == 1) return conv_launch_kw<2, 2, 1, 1>(a, lds, s);
+    if (cfg == 3) return conv_launch_kw<2, 2, 2, 1>(a, lds, s);
     return conv_launch_kw<1, 4, 1, 1>(a, lds, s);
 }
 
