@@ -177,6 +177,16 @@ int mcvc_instnorm_act_backward(const float* x, const float* gamma, const float* 
                                float* dgamma, float* dbeta, float* dgamma_gate, float* dbeta_gate,
                                int N, int C, int H, int W, int act, void* stream);
 
+/* Fused 1-D trunk layer at small batch (B * T4 <= 32): ONE launch for Conv1d(k = 1 | 3, padding (k-1)/2) + bias + InstanceNorm1d(affine)
+ * + {gated GLU when w_gate != NULL | residual add | nothing} -- the building block of ResidualLayer.forward (model.py:47-76:
+ * value|gate pair, then the output conv with the skip connection) and of conv1dto2dLayer + its norm (model.py:266-267) -- SURVEY.md
+ * section 8b's resblock1d / gemm1x1_in ops.  Trunk layout, channel-major with the batch inside: x [Cin][B][T4], w [Cout][Cin][KW] (the
+ * nn.Conv1d tensor as is), conv_out [Cout (x2 with a gate)][B][T4] (pre-norm, kept for backward), stats [B][Cout (x2)][2] = (mean, rstd),
+ * y / residual [Cout][B][T4].                                                                                         */
+int mcvc_trunk_layer_forward(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, const float* w_gate,
+                             const float* bias_gate, const float* gamma_gate, const float* beta_gate, const float* residual, float* conv_out,
+                             float* stats, float* y, int B, int Cin, int T4, int Cout, int KW, void* stream);
+
 /* db[C] += sum over (n, h, w) of dy[N,C,P] */
 int mcvc_bias_grad(const float* dy, float* db, int N, int C, int P, void* stream);
 /* norm-less activations: act 1 gated GLU (x[N,2C,P] -> y[N,C,P]), 2 x*sigmoid(x), 3 sigmoid */

@@ -1651,6 +1651,24 @@ int mcvc_instnorm_act_backward(const float* x, const float* gamma, const float* 
     return ex.err;
 }
 
+// fused 1-D trunk layer (small batch): conv1d(k = 1 or 3, pad (k-1)/2) + bias + InstanceNorm1d(affine) + {gated GLU | + residual | nothing}
+int mcvc_trunk_layer_forward(const float* x, const float* w, const float* bias, const float* gamma, const float* beta, const float* w_gate,
+                             const float* bias_gate, const float* gamma_gate, const float* beta_gate, const float* residual, float* conv_out,
+                             float* stats, float* y, int B, int Cin, int T4, int Cout, int KW, void* stream)
+{
+    if (!x || !w || !bias || !gamma || !beta || !conv_out || !stats || !y) return MCVC_ERR_INVALID;
+    const int mode = w_gate ? TRUNK_IN_GLU : TRUNK_IN;
+    if (!mcvc_trunk_applies(Cin, KW, Cout, B, T4, mode, 1)) return MCVC_ERR_INVALID;
+    TrunkArgs a{};
+    a.a0 = w; a.bias0 = bias; a.gamma0 = gamma; a.beta0 = beta;
+    a.a1 = w_gate; a.bias1 = bias_gate; a.gamma1 = gamma_gate; a.beta1 = beta_gate;
+    a.x = x; a.x_sc = (long long)B * T4; a.x_sb = T4;
+    a.Cin = Cin; a.KW = KW; a.K = Cin * KW; a.M = Cout; a.Mtot = w_gate ? 2 * Cout : Cout; a.B = B; a.T4 = T4; a.N = B * T4;
+    a.conv_out = conv_out; a.c_sc = (long long)B * T4; a.c_sb = T4;
+    a.stats = stats; a.y = y; a.res = residual; a.y_sn = T4; a.y_sc = (long long)B * T4; a.eps = kInEps; a.mode = mode;
+    return mcvc_trunk_launch(a, 1, (hipStream_t)stream);
+}
+
 int mcvc_bias_grad(const float* dy, float* db, int N, int C, int P, void* stream)
 {
     return mcvc_bias_grad_launch(dy, (long long)C * P, (long long)P, N, C, P, db, (hipStream_t)stream);

@@ -66,6 +66,7 @@ _SIGS = {
     "mcvc_conv2d_wgrad": (c_int, [c_void_p] * 4 + [c_longlong] + [c_int] * 10 + [c_void_p]),
     "mcvc_instnorm_act_forward": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
     "mcvc_instnorm_act_backward": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p]),
+    "mcvc_trunk_layer_forward": (c_int, [c_void_p] * 13 + [c_int] * 5 + [c_void_p]),
     "mcvc_bias_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mcvc_act_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mcvc_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -191,3 +191,45 @@ def test_losses_and_adam():
         gd = gr.cuda()
         check(L.mcvc_adam_step(ptr(pd), ptr(gd), ptr(m), ptr(v), n, 2e-4, 0.5, 0.999, 1e-8, step, 1.0, stream()))
     assert float((pd.cpu() - pr.detach()).abs().max()) < 2e-7
+
+
+@pytest.mark.parametrize("B,T4,Cin,Cout,KW,kind", [(1, 16, 256, 512, 3, "glu"), (2, 16, 256, 512, 3, "glu"), (2, 16, 512, 256, 3, "res"),
+                                                   (1, 16, 512, 256, 3, "res"), (2, 16, 256, 5120, 1, "plain"), (4, 8, 256, 512, 3, "glu"),
+                                                   (1, 32, 512, 256, 3, "res")])
+def test_fused_trunk_layer_matches_torch(B, T4, Cin, Cout, KW, kind):
+    """Isolated parity of trunk_layer_kernel (SURVEY.md section 8b resblock1d / gemm1x1_in): Conv1d + InstanceNorm1d + gated GLU /
+    residual in one launch vs the same ops in plain PyTorch fp32 (reference model.py:47-76, 266-267)."""
+    import torch.nn.functional as F
+    from mask_cyclegan_vc._hip import check, lib, ptr, stream
+    L = lib()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, T4, generator=g).cuda()
+    mk = lambda *s: (torch.randn(*s, generator=g) / (Cin * KW) ** 0.5).cuda()      # noqa: E731
+    w, b = mk(Cout, Cin, KW), torch.randn(Cout, generator=g).cuda()
+    ga, be = (1 + 0.1 * torch.randn(Cout, generator=g)).cuda(), (0.1 * torch.randn(Cout, generator=g)).cuda()
+    wg, bg = mk(Cout, Cin, KW), torch.randn(Cout, generator=g).cuda()
+    gg, bgt = (1 + 0.1 * torch.randn(Cout, generator=g)).cuda(), (0.1 * torch.randn(Cout, generator=g)).cuda()
+    res = torch.randn(B, Cout, T4, generator=g).cuda()
+    xt = x.permute(1, 0, 2).contiguous()                     # trunk layout [C][B][T4]
+    rt = res.permute(1, 0, 2).contiguous()
+    ncx = 2 * Cout if kind == "glu" else Cout
+    conv_out = torch.empty(ncx, B, T4, device="cuda"); stats = torch.empty(B, ncx, 2, device="cuda"); y = torch.empty(Cout, B, T4, device="cuda")
+    glu = kind == "glu"
+    check(L.mcvc_trunk_layer_forward(ptr(xt), ptr(w), ptr(b), ptr(ga), ptr(be), ptr(wg) if glu else None, ptr(bg) if glu else None,
+                                     ptr(gg) if glu else None, ptr(bgt) if glu else None, ptr(rt) if kind == "res" else None, ptr(conv_out),
+                                     ptr(stats), ptr(y), B, Cin, T4, Cout, KW, stream()), "trunk_layer_forward")
+    pad = (KW - 1) // 2
+    c0 = F.conv1d(x, w, b, padding=pad)
+    z = F.instance_norm(c0, weight=ga, bias=be, eps=1e-5)
+    if glu:
+        c1 = F.conv1d(x, wg, bg, padding=pad)
+        ref = z * torch.sigmoid(F.instance_norm(c1, weight=gg, bias=bgt, eps=1e-5))
+        ref_conv = torch.cat((c0, c1), 1)
+    else:
+        ref = z + res if kind == "res" else z
+        ref_conv = c0
+    got = y.permute(1, 0, 2)
+    assert float((got - ref).norm() / ref.norm()) < 2e-5
+    assert float((conv_out.permute(1, 0, 2) - ref_conv).norm() / ref_conv.norm()) < 2e-5
+    mean = ref_conv.mean(2)
+    assert float((stats[:, :, 0] - mean).abs().max()) < 1e-4
