@@ -491,8 +491,6 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const WinoOutArgs a)
 constexpr int kGK = 16;                 // k per stage
 constexpr int kGStages = 4;
 constexpr int kGA = kGK * 128;          // floats of A per stage
-constexpr int kGB = kGK * 64;
-constexpr int kGStage = kGA + kGB;
 
 __device__ __forceinline__ void wg_glds16(const float* g, float* l)
 {
@@ -500,13 +498,21 @@ __device__ __forceinline__ void wg_glds16(const float* g, float* l)
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-__global__ void __launch_bounds__(256, 3) wino_gemm_kernel(const WinoGemmArgs a)
+// BN = 64: waves 2 (m) x 2 (n), two accumulators each (64 x 32).  BN = 32 (r2): waves 4 (m) x 1, one accumulator each (32 x 32) -- for
+// the ragged tile counts of upSample1 / downSample2 at B <= 2 (N = 96, 160 columns): with 64-column tiles a quarter of the MFMA work
+// was padding and 576 workgroups of 6.8 us left a third of the chip idle in the last round; 32-column tiles are exact, half the size,
+// and four of them fit a CU (40 KB of LDS each).
+template <int BN>
+__global__ void __launch_bounds__(256, (BN == 64 ? 3 : 4)) wino_gemm_kernel(const WinoGemmArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // [kGStages][A 16x128 | B 16x64]
+    constexpr int kGB = kGK * BN;
+    constexpr int kGStage = kGA + kGB;
+    constexpr int NACC = (BN == 64) ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [kGStages][A 16x128 | B 16xBN]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (BN == 64) ? (wave >> 1) : wave, wn = (BN == 64) ? (wave & 1) : 0;
     // XCD-aware order (8 XCDs, private L2 each; hardware deals consecutive workgroup ids round-robin to the XCDs): every XCD
     // gets one contiguous range of logical ids, and logical ids run n-tile fastest, then m-tile, then point -- so the
     // workgroups that share an A panel (same m, xi) or a B panel (same n, xi) sit behind the same L2.  PMC before this
@@ -517,38 +523,42 @@ __global__ void __launch_bounds__(256, 3) wino_gemm_kernel(const WinoGemmArgs a)
         const int q = total >> 3, r = total & 7, xcd = linear & 7, k = linear >> 3;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    const int n0 = (lid % a.nt) * 64; lid /= a.nt;
+    const int n0 = (lid % a.nt) * BN; lid /= a.nt;
     const int m0 = (lid % a.mt) * 128;
     const int xi = lid / a.mt;
     const float* A = a.a + (long long)xi * a.a_xi + m0;
     const float* B = a.b + (long long)xi * a.b_xi + n0;
     // DMA lane constants.  A stage: 16 rows x 32 float4 = 512 float4 = 8 wave-instructions (2 per wave);
-    //                      B stage: 16 rows x 16 float4 = 256 float4 = 4 wave-instructions (1 per wave)
+    //                      B stage: 16 rows x BN/4 float4: BN = 64 -> 4 wave-instructions (1 per wave); BN = 32 -> 2, issued by
+    //                      waves 0-1 and DUPLICATED by waves 2-3 (same bytes to the same LDS words) so that every wave has exactly
+    //                      three DMA instructions per stage in flight and one vmcnt immediate serves all of them
     const int fa0 = wave * 64 + lane, fa1 = fa0 + 256;                // float4 index inside the A stage
     const float* a_src0 = A + (long long)(fa0 >> 5) * a.lda + 4 * (fa0 & 31);
     const float* a_src1 = A + (long long)(fa1 >> 5) * a.lda + 4 * (fa1 & 31);
-    const int fb = wave * 64 + lane;
-    int bcol = 4 * (fb & 15);
+    const int bw = (BN == 64) ? wave : (wave & 1);
+    const int fb = bw * 64 + lane;
+    constexpr int F4R = BN / 4;                                       // float4 per B row
+    int bcol = 4 * (fb % F4R);
     if (n0 + bcol > a.ldb - 4) bcol = a.ldb - 4 - n0;                 // tile hanging over the row end: finite neighbours
-    const float* b_src = B + (long long)(fb >> 4) * a.ldb + bcol;
+    const float* b_src = B + (long long)(fb / F4R) * a.ldb + bcol;
     const long long a_step = (long long)kGK * a.lda, b_step = (long long)kGK * a.ldb;
     auto issue = [&](int stage_k, int buf) {                          // 3 DMA instructions per wave
         float* base = smem + buf * kGStage;
         wg_glds16(a_src0 + stage_k * a_step, base + (wave * 64) * 4);
         wg_glds16(a_src1 + stage_k * a_step, base + (wave * 64 + 256) * 4);
-        wg_glds16(b_src + stage_k * b_step, base + kGA + (wave * 64) * 4);
+        wg_glds16(b_src + stage_k * b_step, base + kGA + (bw * 64) * 4);
     };
-    f32x16 acc[2];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NACC; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     const int nst = a.K / kGK;
 #pragma unroll
     for (int s = 0; s < kGStages - 1; ++s)
         if (s < nst) issue(s, s);
-    const int a_lane = half * 128 + wm * 64 + l31;                    // A[k = 2p + half][m]
-    const int b_lane = kGA + half * 64 + wn * 32 + l31;               // B[k = 2p + half][n]
+    const int a_lane = half * 128 + wm * (32 * NACC) + l31;           // A[k = 2p + half][m]
+    const int b_lane = kGA + half * BN + wn * 32 + l31;               // B[k = 2p + half][n]
     for (int st = 0; st < nst; ++st) {
         // stage `st` must have landed: at most the (up to) two newer stages' 3 + 3 DMA instructions may stay outstanding
         const int newer = (nst - 1 - st) < (kGStages - 2) ? (nst - 1 - st) : (kGStages - 2);
@@ -559,16 +569,29 @@ __global__ void __launch_bounds__(256, 3) wino_gemm_kernel(const WinoGemmArgs a)
         if (st + kGStages - 1 < nst) issue(st + kGStages - 1, (st + kGStages - 1) % kGStages);
         const float* sb = smem + (st % kGStages) * kGStage;
         // operand reads run one k-pair ahead of the MFMAs (pinned: the scheduler otherwise sinks them below the MFMAs)
-        float a0 = sb[a_lane], a1 = sb[a_lane + 32], b0 = sb[b_lane];
+        if constexpr (BN == 64) {
+            float a0 = sb[a_lane], a1 = sb[a_lane + 32], b0 = sb[b_lane];
 #pragma unroll
-        for (int p = 0; p < kGK / 2; ++p) {
-            const int q = (p + 1 < kGK / 2) ? p + 1 : p;
-            const float na0 = sb[a_lane + q * 256], na1 = sb[a_lane + q * 256 + 32], nb0 = sb[b_lane + q * 128];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            a0 = na0; a1 = na1; b0 = nb0;
+            for (int p = 0; p < kGK / 2; ++p) {
+                const int q = (p + 1 < kGK / 2) ? p + 1 : p;
+                const float na0 = sb[a_lane + q * 256], na1 = sb[a_lane + q * 256 + 32], nb0 = sb[b_lane + q * 2 * BN];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                a0 = na0; a1 = na1; b0 = nb0;
+            }
+        } else {
+            float a0 = sb[a_lane], b0 = sb[b_lane];
+#pragma unroll
+            for (int p = 0; p < kGK / 2; ++p) {
+                const int q = (p + 1 < kGK / 2) ? p + 1 : p;
+                const float na0 = sb[a_lane + q * 256], nb0 = sb[b_lane + q * 2 * BN];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                a0 = na0; b0 = nb0;
+            }
         }
     }
     // ---- store: D register r of lane (l31, half) is row (r&3) + 8*(r>>2) + 4*half, column l31
@@ -576,10 +599,10 @@ __global__ void __launch_bounds__(256, 3) wino_gemm_kernel(const WinoGemmArgs a)
     if (n < a.N) {
         float* C = a.c + (long long)xi * a.c_xi + n;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NACC; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int m = m0 + wm * (32 * NACC) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m < a.M) C[(long long)m * a.ldc] = acc[i][r];
             }
     }
@@ -608,11 +631,26 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
     if ((a.K % kGK) != 0 || (a.M % 128) != 0 || (a.lda & 3) || (a.ldb & 3) || a.ldb < 64) return MCVC_ERR_INVALID;
     const int nxi = a.nxi > 0 ? a.nxi : 36;
     WinoGemmArgs b = a;
-    b.nt = cdiv_i(a.N, 64); b.mt = a.M / 128;
-    dim3 grid((unsigned)(b.nt * b.mt * nxi));
-    const size_t lds = (size_t)kGStages * kGStage * sizeof(float);
+    // 32-column tiles when 64-column tiles would pad the N range by more than 10 % on a short range (ragged tile counts at B <= 2)
+    static const int knob = [] { const char* e = getenv("MCVC_WINO_BN"); return e ? atoi(e) : 0; }();
+    const int pad64 = cdiv_i(a.N, 64) * 64, pad32 = cdiv_i(a.N, 32) * 32;
+    bool narrow = (pad64 * 10 > pad32 * 11) && a.N <= 512 && a.ldb >= 32;
+    if (knob == 32) narrow = a.ldb >= 32; else if (knob == 64) narrow = false;
+    b.mt = a.M / 128;
     TraceScope ts(K_WINO_GEMM, s, 2.0 * nxi * a.M * a.N * a.K, 4.0 * nxi * ((double)a.K * a.M + (double)a.K * a.N + (double)a.M * a.N));
-    hipLaunchKernelGGL(wino_gemm_kernel, grid, dim3(256), lds, s, b);
+    if (narrow) {
+        b.nt = cdiv_i(a.N, 32);
+        static bool done = false;
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+            if (e != hipSuccess) return (int)e;
+            done = true;
+        }
+        hipLaunchKernelGGL(wino_gemm_kernel<32>, dim3((unsigned)(b.nt * b.mt * nxi)), dim3(256), (size_t)kGStages * (kGA + kGK * 32) * sizeof(float), s, b);
+    } else {
+        b.nt = cdiv_i(a.N, 64);
+        hipLaunchKernelGGL(wino_gemm_kernel<64>, dim3((unsigned)(b.nt * b.mt * nxi)), dim3(256), (size_t)kGStages * (kGA + kGK * 64) * sizeof(float), s, b);
+    }
     return (int)hipGetLastError();
 }
 
