@@ -86,92 +86,85 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const TrunkA
 
     // ---- stage X[ci][b][t] (this block's channel slice) with zero halo
     if constexpr (PRE) {
-        // fused InstanceNorm backward (see trunk.h): one thread per channel of the slice, two passes over its T4 <= 32 elements per sample
+        // fused InstanceNorm backward (see trunk.h).  Work item = a quarter of one (channel, sample) row: four adjacent lanes own a
+        // row, each holds ceil(T4/4) <= 8 consecutive elements, the two row sums are width-4 shuffles.  d(gamma), d(beta) of a channel
+        // are summed over its samples in a fixed order through a small LDS table (deterministic, no atomics).
         const int C = a.pre_C;
         const bool pglu = (a.pre == 2);
         const int Cx = pglu ? 2 * C : C;
         const bool out = (blockIdx.x == 0);
         const float invT = 1.0f / (float)a.T4;
-        const bool vec = ((a.T4 & 3) == 0) && ((a.x_sb & 3) == 0) && ((a.x_sc & 3) == 0) &&
-                         (((reinterpret_cast<unsigned long long>(a.x) | reinterpret_cast<unsigned long long>(a.pre_x)) & 15ull) == 0);
-        const int nq = a.T4 >> 2;                            // float4 per row (<= 8)
-        for (int ci = tid; ci < ci_count; ci += kTrunkThreads) {
+        const int E = (a.T4 + 3) >> 2;                        // elements per lane (<= 8)
+        float* rsum = smem + ci_count * RS;                   // [ci_count][B][2] row sums (s1, s2) -- behind the staged slice
+        const int items = ci_count * a.B * 4;
+        for (int it0 = 0; it0 < items; it0 += kTrunkThreads) {
+            const int item = it0 + tid;
+            const bool live = item < items;                   // (whole 4-lane groups are live or dead together: items % 4 == 0)
+            const int q4 = item & 3, row = live ? (item >> 2) : 0;
+            const int ci = row / a.B, b = row - ci * a.B;
             const int cx = ci_begin + ci;
             const bool gate = pglu && cx >= C;
             const int c = gate ? cx - C : cx;
             const float g0 = a.pre_gamma0[c], b0 = a.pre_beta0[c];
             const float g1 = pglu ? a.pre_gamma1[c] : 0.f, b1 = pglu ? a.pre_beta1[c] : 0.f;
-            float* xrow = smem + ci * RS;
-            float dgam = 0.f, dbet = 0.f;
-            for (int b = 0; b < a.B; ++b) {
-                const float* st = a.pre_stats + (long long)b * Cx * 2;
-                const float m0 = st[2 * c], r0 = st[2 * c + 1];
-                const float m1 = pglu ? st[2 * (c + C)] : 0.f, r1 = pglu ? st[2 * (c + C) + 1] : 1.f;
-                const float* dyr = a.x + (long long)c * a.x_sc + (long long)b * a.x_sb;
-                const float* x0r = a.pre_x + ((long long)c * a.B + b) * a.T4;
-                const float* x1r = a.pre_x + ((long long)(c + C) * a.B + b) * a.T4;
-                // all loads of the (up to three) rows first, then everything from registers: dz / xh are kept for the second pass
-                float dzv[32], xhv[32];
-                {
-                    float4 vd[8], v0[8], v1[8];
+            const float* st = a.pre_stats + (long long)b * Cx * 2;
+            const float m0 = st[2 * c], r0 = st[2 * c + 1];
+            const float m1 = pglu ? st[2 * (c + C)] : 0.f, r1 = pglu ? st[2 * (c + C) + 1] : 1.f;
+            const int t0 = q4 * E;
+            const float* dyr = a.x + (long long)c * a.x_sc + (long long)b * a.x_sb + t0;
+            const float* x0r = a.pre_x + ((long long)c * a.B + b) * a.T4 + t0;
+            const float* x1r = a.pre_x + ((long long)(c + C) * a.B + b) * a.T4 + t0;
+            float vd[8], v0[8], v1[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if (vec) {
-                            const bool ok = q < nq;
-                            vd[q] = ok ? *reinterpret_cast<const float4*>(dyr + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-                            v0[q] = ok ? *reinterpret_cast<const float4*>(x0r + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-                            v1[q] = (ok && pglu) ? *reinterpret_cast<const float4*>(x1r + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        } else {
-                            float td[4], t0[4], t1[4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int t = 4 * q + j;
-                                const bool ok = t < a.T4;
-                                td[j] = ok ? dyr[t] : 0.f; t0[j] = ok ? x0r[t] : 0.f; t1[j] = (ok && pglu) ? x1r[t] : 0.f;
-                            }
-                            vd[q] = make_float4(td[0], td[1], td[2], td[3]); v0[q] = make_float4(t0[0], t0[1], t0[2], t0[3]);
-                            v1[q] = make_float4(t1[0], t1[1], t1[2], t1[3]);
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float dd[4] = {vd[q].x, vd[q].y, vd[q].z, vd[q].w};
-                        const float a0[4] = {v0[q].x, v0[q].y, v0[q].z, v0[q].w};
-                        const float a1[4] = {v1[q].x, v1[q].y, v1[q].z, v1[q].w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float xh0 = (a0[j] - m0) * r0;
-                            float dz, xh;
-                            if (pglu) {
-                                const float xh1 = (a1[j] - m1) * r1;
-                                const float sg = sigmoidf_(xh1 * g1 + b1);
-                                if (gate) { dz = dd[j] * (xh0 * g0 + b0) * sg * (1.0f - sg); xh = xh1; }
-                                else { dz = dd[j] * sg; xh = xh0; }
-                            } else { dz = dd[j]; xh = xh0; }
-                            const bool live = (4 * q + j) < a.T4;
-                            dzv[4 * q + j] = live ? dz : 0.f; xhv[4 * q + j] = live ? xh : 0.f;
-                        }
-                    }
-                }
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int t = 0; t < 32; ++t) { s1 += dzv[t]; s2 += dzv[t] * xhv[t]; }
-                const float gr = gate ? g1 * r1 : g0 * r0;
-                float* xs = xrow + b * TP + PW;
-                float* od = out ? (a.pre_out + ((long long)cx * a.B + b) * a.T4) : nullptr;
-#pragma unroll
-                for (int t = 0; t < 32; ++t) {
-                    if (t < a.T4) {
-                        const float dxv = gr * (dzv[t] - s1 * invT - xhv[t] * (s2 * invT));
-                        xs[t] = dxv;
-                        if (od) od[t] = dxv;
-                    }
-                }
-                for (int hcol = 0; hcol < PW; ++hcol) { xrow[b * TP + hcol] = 0.f; xrow[b * TP + PW + a.T4 + hcol] = 0.f; }
-                dgam += s2; dbet += s1;
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = live && e < E && (t0 + e) < a.T4;
+                vd[e] = ok ? dyr[e] : 0.f; v0[e] = ok ? x0r[e] : 0.f; v1[e] = (ok && pglu) ? x1r[e] : 0.f;
             }
-            xrow[a.B * TP] = 0.f;
-            if (out) {
+            float dzv[8], xhv[8];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = e < E && (t0 + e) < a.T4;
+                const float xh0 = (v0[e] - m0) * r0;
+                float dz, xh;
+                if (pglu) {
+                    const float xh1 = (v1[e] - m1) * r1;
+                    const float sg = sigmoidf_(xh1 * g1 + b1);
+                    if (gate) { dz = vd[e] * (xh0 * g0 + b0) * sg * (1.0f - sg); xh = xh1; }
+                    else { dz = vd[e] * sg; xh = xh0; }
+                } else { dz = vd[e]; xh = xh0; }
+                dzv[e] = ok ? dz : 0.f; xhv[e] = ok ? xh : 0.f;
+                s1 += dzv[e]; s2 += dzv[e] * xhv[e];
+            }
+            s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+            s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+            if (live) {
+                const float gr = gate ? g1 * r1 : g0 * r0;
+                float* xrow = smem + ci * RS + b * TP;
+                float* od = out ? (a.pre_out + ((long long)cx * a.B + b) * a.T4 + t0) : nullptr;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (e < E && (t0 + e) < a.T4) {
+                        const float dxv = gr * (dzv[e] - s1 * invT - xhv[e] * (s2 * invT));
+                        xrow[PW + t0 + e] = dxv;
+                        if (od) od[e] = dxv;
+                    }
+                }
+                if (q4 == 0) {
+                    for (int hcol = 0; hcol < PW; ++hcol) { xrow[hcol] = 0.f; xrow[PW + a.T4 + hcol] = 0.f; }
+                    if (b == 0) smem[ci * RS + a.B * TP] = 0.f;
+                    rsum[(ci * a.B + b) * 2] = s1; rsum[(ci * a.B + b) * 2 + 1] = s2;
+                }
+            }
+        }
+        if (out) {
+            __syncthreads();
+            for (int ci = tid; ci < ci_count; ci += kTrunkThreads) {
+                const int cx = ci_begin + ci;
+                const bool gate = pglu && cx >= C;
+                const int c = gate ? cx - C : cx;
+                float dgam = 0.f, dbet = 0.f;
+                for (int b = 0; b < a.B; ++b) { dbet += rsum[(ci * a.B + b) * 2]; dgam += rsum[(ci * a.B + b) * 2 + 1]; }
                 float* dg = gate ? a.pre_dgamma1 : a.pre_dgamma0;
                 float* db = gate ? a.pre_dbeta1 : a.pre_dbeta0;
                 if (dg) dg[c] += dgam;
@@ -713,7 +706,12 @@ int mcvc_trunk_launch(const TrunkArgs& a, int ksplit, hipStream_t s)
     if (a.pre && (a.mode != TRUNK_PLAIN || a.T4 > 32 || !a.pre_x || !a.pre_stats || !a.pre_out)) return MCVC_ERR_INVALID;
     const int rows = (a.mode == TRUNK_IN_GLU) ? 8 : 16;
     dim3 grid((unsigned)(a.M / rows), (unsigned)ksplit);
-    const size_t lds = (size_t)mcvc_trunk_lds_floats(a.Cin, a.KW, a.B, a.T4, ksplit) * sizeof(float);
+    size_t lds = (size_t)mcvc_trunk_lds_floats(a.Cin, a.KW, a.B, a.T4, ksplit) * sizeof(float);
+    if (a.pre) {          // + [channels of a K slice][B][2] row sums behind the staged slice
+        const long long xs = (long long)(a.Cin / ksplit) * (a.B * (a.T4 + a.KW - 1) + 1) + (long long)(a.Cin / ksplit) * a.B * 2;
+        if ((size_t)xs * sizeof(float) > lds) lds = (size_t)xs * sizeof(float);
+        if (lds > 160 * 1024) return MCVC_ERR_INVALID;
+    }
     const double mt = (a.mode == TRUNK_IN_GLU) ? 2.0 * a.M : (double)a.M;
     TraceScope ts(K_TRUNK, s, 2.0 * mt * a.K * a.N, 4.0 * (mt * a.K + (double)a.Cin * a.N + 3.0 * mt * a.N));
     const bool wide = a.N > 16;
