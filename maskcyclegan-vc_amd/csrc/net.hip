@@ -67,11 +67,9 @@ static hipEvent_t pool_event()
     static std::vector<hipEvent_t> pool;
     static size_t next = 0;
     std::lock_guard<std::mutex> lk(mu);
-    if (pool.size() < 1024) {
-        hipEvent_t e;
-        (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        pool.push_back(e);
-        return e;
+    if (pool.empty()) {            // the whole pool is created on first use (outside any stream capture: the warm-up iterations)
+        pool.resize(1024);
+        for (hipEvent_t& e : pool) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     }
     next = (next + 1) % pool.size();
     return pool[next];

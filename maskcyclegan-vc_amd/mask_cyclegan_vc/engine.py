@@ -227,6 +227,10 @@ class TrainEngine:
 
     def _aux_ptr(self, lane):
         import ctypes
+        import os
+        only = os.environ.get("MCVC_AUX_LANES")            # experiment knob: comma list of lanes that get an auxiliary stream
+        if only is not None and str(lane) not in only.split(","):
+            return None
         return ctypes.c_void_p(self._aux[lane].cuda_stream) if self.aux_wgrad else None
 
     def _G(self, name, x, mask, out, stash, nb, lane=0):
@@ -458,7 +462,16 @@ class TrainEngine:
             g = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(g, stream=self._capture_stream):
+                    # the auxiliary weight-gradient streams join the capture as FIRST-LEVEL forks of the capture stream: forking
+                    # them from an already forked lane stream (a nested fork) segfaults inside hipStreamEndCapture on ROCm 7.2
+                    cur = torch.cuda.current_stream(self.device)
+                    if self.aux_wgrad:
+                        for ax in self._aux:
+                            ax.wait_stream(cur)
                     fn(*self.static_in)
+                    if self.aux_wgrad:
+                        for ax in self._aux:
+                            cur.wait_stream(ax)
             except Exception as exc:                        # stay correct if capture is not possible on this runtime
                 print("mask_cyclegan_vc.engine: HIP graph capture failed (%s); continuing eagerly" % exc)
                 self.use_graphs = False

@@ -17,6 +17,9 @@ if len(sys.argv) > 1:
     torch.cuda.synchronize()
     print("conc=%s aux=%s graphs=%s: %.2f ms/step g_loss=%.4f" % (conc, aux, eng.use_graphs, 1e3 * (time.perf_counter() - t0) / 20, eng.losses()["g_loss"]))
 else:
-    for c, a in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
-        r = subprocess.run([sys.executable, __file__, c, a], capture_output=True, text=True, timeout=200)
-        print("lanes=%s aux=%s rc=%d :: %s" % (c, a, r.returncode, (r.stdout.strip().splitlines() or ["-"])[-1]))
+    for c, a, only in (("1", "1", "0"), ("1", "1", "1"), ("1", "1", "0,1")):
+        env = dict(os.environ, MCVC_AUX_LANES=only)
+        r = subprocess.run([sys.executable, __file__, c, a], capture_output=True, text=True, timeout=200, env=env)
+        print("lanes=%s aux=%s aux_lanes=%s rc=%d :: %s" % (c, a, only, r.returncode, (r.stdout.strip().splitlines() or ["-"])[-1]))
+        if r.returncode:
+            print(r.stderr[-600:])
