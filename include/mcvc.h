@@ -187,6 +187,13 @@ int mcvc_trunk_layer_forward(const float* x, const float* w, const float* bias, 
                              const float* bias_gate, const float* gamma_gate, const float* beta_gate, const float* residual, float* conv_out,
                              float* stats, float* y, int B, int Cin, int T4, int Cout, int KW, void* stream);
 
+/* Batched fp32 GEMM of the Winograd convolution paths (the 36 / 16 per-point products of upSample1/2 and downSample1/2, forward,
+ * data-gradient and weight-gradient: the kernel family with the largest share of a bs=1 step).  For x in [0, nbatch):
+ *   C_x[m][n] = sum_k A_x[k][m] * B_x[k][n]     A_x = a + x*a_stride, K-major [K][lda]; B_x [K][ldb]; C_x [M][ldc].
+ * M % 128 == 0, K % 16 == 0, lda / ldb % 4 == 0, ldb >= 64, N <= ldb.  Exact fp32 (v_mfma_f32_32x32x2_f32).            */
+int mcvc_batched_gemm(const float* a, const float* b, float* c, int nbatch, int M, int N, int K, int lda, int ldb, int ldc,
+                      long long a_stride, long long b_stride, long long c_stride, void* stream);
+
 /* db[C] += sum over (n, h, w) of dy[N,C,P] */
 int mcvc_bias_grad(const float* dy, float* db, int N, int C, int P, void* stream);
 /* norm-less activations: act 1 gated GLU (x[N,2C,P] -> y[N,C,P]), 2 x*sigmoid(x), 3 sigmoid */

@@ -1667,6 +1667,17 @@ int mcvc_trunk_layer_forward(const float* x, const float* w, const float* bias, 
     return mcvc_trunk_launch(a, 1, (hipStream_t)stream);
 }
 
+// batched fp32 GEMM of the Winograd paths: C[x] = A[x]^T-major product, A K-major ([K][lda] rows of M), B [K][ldb], C [M][ldc]
+int mcvc_batched_gemm(const float* a, const float* b, float* c, int nbatch, int M, int N, int K, int lda, int ldb, int ldc,
+                      long long a_stride, long long b_stride, long long c_stride, void* stream)
+{
+    if (!a || !b || !c || nbatch < 1) return MCVC_ERR_INVALID;
+    WinoGemmArgs ga{};
+    ga.a = a; ga.a_xi = a_stride; ga.lda = lda; ga.b = b; ga.b_xi = b_stride; ga.ldb = ldb; ga.c = c; ga.c_xi = c_stride; ga.ldc = ldc;
+    ga.M = M; ga.N = N; ga.K = K; ga.nxi = nbatch;
+    return mcvc_wino_gemm_launch(ga, (hipStream_t)stream);
+}
+
 int mcvc_bias_grad(const float* dy, float* db, int N, int C, int P, void* stream)
 {
     return mcvc_bias_grad_launch(dy, (long long)C * P, (long long)P, N, C, P, db, (hipStream_t)stream);

@@ -608,6 +608,117 @@ __global__ void __launch_bounds__(256, (BN == 64 ? 3 : 4)) wino_gemm_kernel(cons
     }
 }
 
+// ---- generalised tile / stage shapes (r2 tuning: tools/gemm_tune.py) ------------------------------------------------------------
+// BM x BN output tile, GK k per stage, ST stages in flight.  Waves: BM=128,BN=64 -> 2x2 of 64x32 (two accumulators); BM=128,BN=32 ->
+// 4x1 of 32x32; BM=64,BN=64 -> 2x2 of 32x32.  Every wave issues the same number of DMA instructions per stage (fractional shares are
+// duplicated), so one vmcnt immediate per "stages still in flight" serves all waves.
+template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
+
+template <int BM, int BN, int GK, int ST>
+__global__ void __launch_bounds__(256) gemm2_kernel(const WinoGemmArgs a)
+{
+    constexpr int SA = GK * BM, SB = GK * BN, STAGE = SA + SB;
+    constexpr int NACC = (BM == 128 && BN == 64) ? 2 : 1;
+    constexpr int NA = (SA / 4 + 255) / 256, NB = (SB / 4 + 255) / 256, ND = NA + NB;     // DMA instructions per wave and stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = (BN == 64) ? (wave >> 1) : wave, wn = (BN == 64) ? (wave & 1) : 0;
+    int lid;
+    {
+        const int total = (int)gridDim.x, linear = (int)blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = linear & 7, k = linear >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int n0 = (lid % a.nt) * BN; lid /= a.nt;
+    const int m0 = (lid % a.mt) * BM;
+    const int xi = lid / a.mt;
+    const float* A = a.a + (long long)xi * a.a_xi + m0;
+    const float* B = a.b + (long long)xi * a.b_xi + n0;
+    constexpr int A4R = BM / 4, B4R = BN / 4;                     // float4 per row
+    const float* asrc[NA]; int adst[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int f = (tid + i * 256) % (SA / 4);                 // (duplicates when the stage has fewer than 256 float4 per sweep)
+        asrc[i] = A + (long long)(f / A4R) * a.lda + 4 * (f % A4R);
+        adst[i] = (((wave * 64 + i * 256) % (SA / 4))) * 4;      // wave-uniform LDS base (float index) of this instruction
+    }
+    const float* bsrc[NB]; int bdst[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int f = (tid + i * 256) % (SB / 4);
+        int bcol = 4 * (f % B4R);
+        if (n0 + bcol > a.ldb - 4) bcol = a.ldb - 4 - n0;
+        bsrc[i] = B + (long long)(f / B4R) * a.ldb + bcol;
+        bdst[i] = SA + (((wave * 64 + i * 256) % (SB / 4))) * 4;
+    }
+    const long long a_step = (long long)GK * a.lda, b_step = (long long)GK * a.ldb;
+    auto issue = [&](int stage_k, int buf) {
+        float* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) wg_glds16(asrc[i] + stage_k * a_step, base + adst[i]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) wg_glds16(bsrc[i] + stage_k * b_step, base + bdst[i]);
+    };
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const int nst = a.K / GK;
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s)
+        if (s < nst) issue(s, s);
+    const int a_lane = half * BM + wm * (32 * NACC) + l31;
+    const int b_lane = SA + half * BN + wn * 32 + l31;
+    for (int st = 0; st < nst; ++st) {
+        const int newer = (nst - 1 - st) < (ST - 2) ? (nst - 1 - st) : (ST - 2);
+        if (newer >= 2) wait_vm<2 * ND>(); else if (newer == 1) wait_vm<ND>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (st + ST - 1 < nst) issue(st + ST - 1, (st + ST - 1) % ST);
+        const float* sb = smem + (st % ST) * STAGE;
+        float a0 = sb[a_lane], a1 = (NACC == 2) ? sb[a_lane + 32] : 0.f, b0 = sb[b_lane];
+#pragma unroll
+        for (int p = 0; p < GK / 2; ++p) {
+            const int q = (p + 1 < GK / 2) ? p + 1 : p;
+            const float na0 = sb[a_lane + q * 2 * BM], na1 = (NACC == 2) ? sb[a_lane + q * 2 * BM + 32] : 0.f, nb0 = sb[b_lane + q * 2 * BN];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+            if constexpr (NACC == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NACC + 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NACC, 0);
+            a0 = na0; a1 = na1; b0 = nb0;
+        }
+    }
+    const int n = n0 + wn * 32 + l31;
+    if (n < a.N) {
+        float* C = a.c + (long long)xi * a.c_xi + n;
+#pragma unroll
+        for (int i = 0; i < NACC; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (32 * NACC) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < a.M) C[(long long)m * a.ldc] = acc[i][r];
+            }
+    }
+}
+
+template <int BM, int BN, int GK, int ST>
+static int gemm2_launch(WinoGemmArgs b, int nxi, hipStream_t s)
+{
+    if ((b.M % BM) != 0 || (b.K % GK) != 0) return MCVC_ERR_INVALID;
+    b.nt = cdiv_i(b.N, BN); b.mt = b.M / BM;
+    constexpr size_t lds = (size_t)ST * (GK * BM + GK * BN) * sizeof(float);
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm2_kernel<BM, BN, GK, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    hipLaunchKernelGGL((gemm2_kernel<BM, BN, GK, ST>), dim3((unsigned)(b.nt * b.mt * nxi)), dim3(256), lds, s, b);
+    return (int)hipGetLastError();
+}
+
 }  // namespace
 
 int mcvc_wino_input_launch(const WinoXformArgs& a, hipStream_t s)
@@ -638,6 +749,24 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
     if (knob == 32) narrow = a.ldb >= 32; else if (knob == 64) narrow = false;
     b.mt = a.M / 128;
     TraceScope ts(K_WINO_GEMM, s, 2.0 * nxi * a.M * a.N * a.K, 4.0 * nxi * ((double)a.K * a.M + (double)a.K * a.N + (double)a.M * a.N));
+    static const int cfg2 = [] { const char* e = getenv("MCVC_GEMM_CFG"); return e ? atoi(e) : 0; }();     // tuning: force a gemm2 shape
+    switch (cfg2) {
+        case 1: return gemm2_launch<128, 64, 16, 4>(b, nxi, s);
+        case 2: return gemm2_launch<128, 32, 16, 4>(b, nxi, s);
+        case 3: return gemm2_launch<64, 64, 16, 4>(b, nxi, s);
+        case 4: return gemm2_launch<128, 64, 32, 3>(b, nxi, s);
+        case 5: return gemm2_launch<128, 32, 32, 3>(b, nxi, s);
+        case 6: return gemm2_launch<64, 64, 32, 3>(b, nxi, s);
+        case 7: return gemm2_launch<128, 64, 16, 6>(b, nxi, s);
+        case 8: return gemm2_launch<128, 32, 16, 6>(b, nxi, s);
+        case 9: return gemm2_launch<64, 64, 16, 6>(b, nxi, s);
+        case 10: return gemm2_launch<128, 64, 32, 4>(b, nxi, s);
+        case 11: return gemm2_launch<64, 64, 32, 4>(b, nxi, s);
+        default: break;
+    }
+    // long-K products (the F(2x2,3x3) layers: K = 4*Cin or Cout >= 512): 64x64 tiles with 32-deep stages measured 10-20 % faster than
+    // 128x64 / 128x32 with 16-deep stages (profiles/r02_gemm_tune.log) -- twice the workgroups and half the barriers per k
+    if (cfg2 == 0 && a.K >= 512 && (a.K % 32) == 0 && (a.M % 64) == 0) return gemm2_launch<64, 64, 32, 4>(b, nxi, s);
     if (narrow) {
         b.nt = cdiv_i(a.N, 32);
         static bool done = false;

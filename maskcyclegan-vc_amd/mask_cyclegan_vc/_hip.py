@@ -67,6 +67,7 @@ _SIGS = {
     "mcvc_instnorm_act_forward": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
     "mcvc_instnorm_act_backward": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p]),
     "mcvc_trunk_layer_forward": (c_int, [c_void_p] * 13 + [c_int] * 5 + [c_void_p]),
+    "mcvc_batched_gemm": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_longlong] * 3 + [c_void_p]),
     "mcvc_bias_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mcvc_act_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mcvc_act_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

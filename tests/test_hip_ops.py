@@ -233,3 +233,24 @@ def test_fused_trunk_layer_matches_torch(B, T4, Cin, Cout, KW, kind):
     assert float((conv_out.permute(1, 0, 2) - ref_conv).norm() / ref_conv.norm()) < 2e-5
     mean = ref_conv.mean(2)
     assert float((stats[:, :, 0] - mean).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("nb,M,N,K", [(36, 1024, 96, 256), (36, 1024, 160, 256), (36, 512, 320, 256), (16, 512, 96, 1024), (16, 512, 640, 512),
+                                      (36, 256, 1024, 96), (3, 128, 64, 16), (2, 256, 200, 48)])
+def test_batched_winograd_gemm_matches_torch(nb, M, N, K):
+    """Isolated parity of wino_gemm_kernel (both tile widths) -- the 36 / 16 per-point products of the Winograd convolutions, in the
+    shapes the generator produces at B = 1, 2, 4 (incl. the ragged 96- and 160-column cases that take the 32-column tile)."""
+    from mask_cyclegan_vc._hip import check, lib, ptr, stream
+    L = lib()
+    g = torch.Generator().manual_seed(3)
+    ldb = (N + 31) // 32 * 32
+    if ldb < 64:
+        ldb = 64
+    a = torch.randn(nb, K, M, generator=g).cuda()
+    b = torch.zeros(nb, K, ldb, device="cuda"); b[:, :, :N] = torch.randn(nb, K, N, generator=g).cuda()
+    c = torch.full((nb, M, ldb), float("nan"), device="cuda")
+    check(L.mcvc_batched_gemm(ptr(a), ptr(b), ptr(c), nb, M, N, K, M, ldb, ldb, K * M, K * ldb, M * ldb, stream()), "batched_gemm")
+    ref = torch.bmm(a.transpose(1, 2).double(), b[:, :, :N].double())
+    got = c[:, :, :N].double()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).norm() / ref.norm()) < 2e-6
