@@ -98,13 +98,13 @@ def trace_one_step(engine, batch):
     nk = L.mcvc_trace_kinds()
     buf = (ctypes.c_double * (4 * nk))()
     torch.cuda.synchronize()
-    was = (engine.concurrent, engine.use_graphs, engine.aux_wgrad)
-    engine.concurrent = engine.use_graphs = engine.aux_wgrad = False   # per-kernel durations need non-overlapping eager launches
+    was = (engine.concurrent, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs)
+    engine.concurrent = engine.use_graphs = engine.aux_wgrad = engine.pass_graphs = False   # per-kernel durations need non-overlapping eager launches
     L.mcvc_trace_enable(1)
     engine.step(*batch)
     L.mcvc_trace_collect(buf)
     L.mcvc_trace_enable(0)
-    engine.concurrent, engine.use_graphs, engine.aux_wgrad = was
+    engine.concurrent, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs = was
     rows = []
     for k in range(nk):
         n, ms, fl, by = buf[4 * k:4 * k + 4]
@@ -233,6 +233,7 @@ def main():
     ap.add_argument("--no-trace", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one stream: no lanes, no auxiliary weight-gradient stream (A/B comparison, per-kernel profiling)")
     ap.add_argument("--graphs", action="store_true", help="replay HIP graphs of the two phases (experimental; not faster on ROCm 7.2)")
+    ap.add_argument("--no-pass-graphs", action="store_true", help="launch every network pass eagerly instead of replaying its HIP graph (A/B)")
     ap.add_argument("--graphs-aux", action="store_true", help="with --graphs: keep the auxiliary weight-gradient streams inside the capture")
     ap.add_argument("--dump-trace", default=None, help="write one traced step's per-launch records (launch order) to this file")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")
@@ -266,11 +267,17 @@ def main():
     if args.serial:
         engine.aux_wgrad = False          # truly one stream: per-kernel durations comparable with the traced step's
     engine.use_graphs = args.graphs
+    if args.graphs or args.no_pass_graphs:
+        engine.pass_graphs = False          # (phase-level capture and per-pass capture do not nest)
     if args.graphs and not args.graphs_aux:
         engine.aux_wgrad = False            # lanes + auxiliary streams in one capture crash hipStreamEndCapture (ROCm 7.2)
     batches = synthetic_batches(args.n_batches, B, T, rank, device)
     log("engine ready; warm-up")
 
+    # the whole benchmark runs on a non-default stream when asked (experiment: the legacy NULL stream has its own ordering rules)
+    import contextlib
+    run_ctx = torch.cuda.stream(torch.cuda.Stream(device=device)) if os.environ.get("MCVC_BENCH_STREAM") == "1" else contextlib.nullcontext()
+    run_ctx.__enter__()
     first = None
     for i in range(args.warmup):
         engine.step(*batches[i % len(batches)])
@@ -296,6 +303,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    run_ctx.__exit__(None, None, None)
     log("timed region done: %.2f ms/step" % (1e3 * dt / args.steps))
     final = engine.losses()
     finite = all(np.isfinite(v) for v in final.values())
@@ -305,13 +313,13 @@ def main():
         L = _hip.lib()
         buf = (ctypes.c_double * (4 * 8192))()
         torch.cuda.synchronize()
-        was = (engine.concurrent, engine.use_graphs, engine.aux_wgrad)
-        engine.concurrent = engine.use_graphs = engine.aux_wgrad = False
+        was = (engine.concurrent, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs)
+        engine.concurrent = engine.use_graphs = engine.aux_wgrad = engine.pass_graphs = False
         L.mcvc_trace_enable(1)
         engine.step(*batches[0])
         n = L.mcvc_trace_collect_raw(buf, 8192)
         L.mcvc_trace_enable(0)
-        engine.concurrent, engine.use_graphs, engine.aux_wgrad = was
+        engine.concurrent, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs = was
         with open(args.dump_trace, "w") as fh:
             for i in range(n):
                 k, ms, fl, by = buf[4 * i:4 * i + 4]

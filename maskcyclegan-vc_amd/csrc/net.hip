@@ -113,6 +113,10 @@ struct ConvSpec {
     // stride 2: the four output-parity classes are ONE stride-1 conv with 4*Cin output channels (4*ci + 2*qh + qw) whose
     // taps are zero-padded to a common window; its PixelShuffle(2) store scatters straight into dX[ci][2a+qh][2b+qw]
     int merged, mg_kh, mg_kw, mg_pad_h, mg_pad_w, mg_ld;
+    // 3x3 stride-2 convs (the discriminators') at large batch: the merged matrix multiplies 16 tap slots of which 9 are non-zero; with
+    // enough pixels to fill the chip per launch the four parity classes run as four exact stride-1 convs instead (1.78x fewer MACs)
+    long long off_dcls;            // -1: no per-class copies
+    DgradClass ucls[4];
 };
 
 static void spec_finalize(ConvSpec& c, long long& cur)
@@ -162,6 +166,16 @@ static void spec_finalize(ConvSpec& c, long long& cur)
         }
         c.mg_ld = round_up_i(4 * c.Cin, 32);
         cur += ((long long)c.dg_rows_co * c.mg_kh * c.mg_kw + 1) * c.mg_ld;                  // + zero pad row
+    }
+    c.off_dcls = -1;
+    if (st == 2 && c.KH == 3 && c.KW == 3 && c.Cin >= 64) {
+        cur = (cur + 3) & ~3LL;
+        c.off_dcls = cur;
+        for (int k = 0; k < c.ncls; ++k) {
+            c.ucls[k] = c.cls[k];
+            c.ucls[k].offset = cur - c.off_dcls;
+            cur += ((long long)c.dg_rows_co * c.cls[k].nth * c.cls[k].ntw + 1) * c.cin_pk;   // + zero pad row
+        }
     }
     cur = (cur + 3) & ~3LL;
     c.wino = (c.KH == 5 && c.KW == 5 && st == 1 && c.nbr == 1 && c.Cin >= 64 && c.Cout >= 64) ? 1 : 0;
@@ -353,7 +367,9 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
             return;
         }
     }
-    if (c.merged) {
+    static const int ucls_nb = [] { const char* e = getenv("MCVC_DGRAD_CLASSES_NB"); return e ? atoi(e) : 8; }();
+    const bool per_class = c.merged && c.off_dcls >= 0 && NB >= ucls_nb;
+    if (c.merged && !per_class) {
         ConvProblem p{c.cout_tot, OH, OW, 4 * c.Cin, (H + 1) / 2, (W + 1) / 2, c.mg_kh, c.mg_kw, 1, c.mg_pad_h, c.mg_pad_w};
         ConvIO io{};
         io.x = dy.p; io.x_sb = dy.sb; io.x_sc = dy.sc; io.x_sh = dy.sh;
@@ -362,10 +378,12 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
         run_conv(ex, p, NB, io, dx_total, packed + c.off_dgrad, c.dg_rows_co * c.mg_kh * c.mg_kw, c.mg_ld, nullptr, allow_split, 0, nsplit);
         return;
     }
+    const DgradClass* klass = per_class ? c.ucls : c.cls;
+    const long long kbase = per_class ? c.off_dcls : c.off_dgrad;
     ConvProblem ps[4];
     int force = 0;
     for (int k = 0; k < c.ncls; ++k) {
-        const DgradClass& d = c.cls[k];
+        const DgradClass& d = klass[k];
         ps[k] = ConvProblem{c.cout_tot, OH, OW, c.Cin, (H - d.qh + st - 1) / st, (W - d.qw + st - 1) / st,
                             d.nth, d.ntw, 1, d.pad_h, d.pad_w};
     }
@@ -377,7 +395,7 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
     }
     int ns_all = 1;
     for (int k = 0; k < c.ncls; ++k) {
-        const DgradClass& d = c.cls[k];
+        const DgradClass& d = klass[k];
         if (ps[k].OH <= 0 || ps[k].OW <= 0) continue;
         ConvIO io{};
         io.x = dy.p; io.x_sb = dy.sb; io.x_sc = dy.sc; io.x_sh = dy.sh;
@@ -387,7 +405,7 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
         // slabs of class k live at the same slab base + the class's element offset
         Exec sub = ex;
         if (!ex.dry) sub.slabs = ex.slabs + (long long)d.qh * dx.sh + d.qw;
-        run_conv(sub, ps[k], NB, io, dx_total, packed + c.off_dgrad + d.offset, c.dg_rows_co * d.nth * d.ntw, c.cin_pk, nullptr,
+        run_conv(sub, ps[k], NB, io, dx_total, packed + kbase + d.offset, c.dg_rows_co * d.nth * d.ntw, c.cin_pk, nullptr,
                  allow_split, force, &ns);
         ex.err = sub.err; ex.slab_need = sub.slab_need;
         if (ns > ns_all) ns_all = ns;
@@ -540,6 +558,15 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
         if (!skip_direct) {
             t.dga.push_back(a);
             add_job(t, d, cdiv_i(c.Cin, 32), c.Cout);
+        }
+        if (c.off_dcls >= 0) {          // exact per-class copies (large-batch data-gradient of the 3x3 stride-2 layers)
+            PackDgradArgs u = a;
+            u.merged = 0; u.ld = c.cin_pk;
+            for (int k = 0; k < c.ncls; ++k) u.cls[k] = c.ucls[k];
+            PackJob du{}; du.kind = PACK_DGRAD; du.param = c.wi[br]; du.dst = c.off_dcls; du.dg = (int)t.dga.size();
+            t.dga.push_back(u);
+            add_job(t, du, cdiv_i(c.Cin, 32), c.Cout);
+            t.bytes += 4.0 * 2.0 * c.Cout * K;
         }
         if (c.off_tk >= 0) {
             PackJob q{}; q.kind = PACK_TRUNK_T; q.param = c.wi[br]; q.dst = c.off_tk; q.Cout = c.Cout; q.Cin = c.Cin; q.KW = c.KW;
@@ -1549,6 +1576,7 @@ static ConvSpec single_spec(int Cout, int Cin, int KH, int KW, int stride, int p
     ConvSpec c = mk(Cin, Cout, 1, KH, KW, stride, ph, pw, 0, 1, -1, -1, 1);
     long long cur = 0;
     spec_finalize(c, cur);
+    c.off_dcls = -1;               // (the single-op pack holds the merged matrix only)
     return c;
 }
 

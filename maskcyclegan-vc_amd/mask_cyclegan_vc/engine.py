@@ -19,6 +19,7 @@ checkpoints and the autograd API keep working on the same storage.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -106,7 +107,7 @@ class TrainEngine:
         self._sides = [torch.cuda.Stream(device=dev) for _ in range(3)]
         # inside a backward pass the weight-gradient kernels are off the critical path: one auxiliary stream per lane
         self._aux = [torch.cuda.Stream(device=dev) for _ in range(4)]
-        self.aux_wgrad = True
+        self.aux_wgrad = os.environ.get("MCVC_AUX_WGRAD", "1") != "0"
         # ... for the generators only: the four discriminator lanes already occupy the four hardware queues, and giving each a
         # second stream for its weight gradients measured 1.2 % slower (101.5 vs 102.8 it/s)
         self.aux_wgrad_d = False
@@ -117,9 +118,23 @@ class TrainEngine:
         # lane (no change -- the ~4 ms of real host work per step is not on the critical path; tools/host_overhead.py).
         self.use_graphs = False
         self._graphs, self._eager_runs = {}, {}
+        # Round 2: the per-queue timeline (profiles/r02_lanes_bs1_eager.txt) shows the two generator lanes running one AFTER the other in
+        # the backward rounds: a backward pass is ~70 launches of ~10 us plus ~60 event record / wait calls, the host needs about as long
+        # to submit it as the GPU needs to run it, and lane 1 is only submitted when lane 0's submission is finished.  So every
+        # network PASS (one library call) is captured once into its own HIP graph -- its auxiliary stream is a first-level fork of the
+        # capture stream, the form that survives hipStreamEndCapture -- and a round is two (four) graph launches on two (four) streams.
+        # MCVC_PASS_GRAPHS: "0" off, "1" all passes, or a comma list of pass kinds (G, Gb, D, Db)
+        pg = os.environ.get("MCVC_PASS_GRAPHS", "0")       # measured: neutral for forward / discriminator passes, +1.2 ms for the forked backward
+        self.pass_graphs = pg != "0"
+        self._pass_kinds = None if pg in ("0", "1") else set(pg.split(","))
+        self._pgraphs = {}
         self._capture_stream = torch.cuda.Stream(device=dev)
         # the discriminators' weight re-pack after their Adam step is needed only ~1.5 ms later (after the next iteration's
         # four generator forwards): it runs on its own stream and the discriminator forwards wait for its event
+        self.threaded_lanes = os.environ.get("MCVC_THREADED_LANES", "0") == "1"
+        if self.threaded_lanes:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=3)
         self._pack_stream = torch.cuda.Stream(device=dev)
         self._d_pack_event = None
         # data parallel: start the discriminator gradient all-reduce at the end of an iteration and finish the update
@@ -209,7 +224,9 @@ class TrainEngine:
             self._lanes(*[(lambda ln, n=n: self._repack1(n)) for n in grp])
 
     def _lanes(self, *fns):
-        """Run fns[i](lane=i) concurrently: lane 0 on the current stream, lane i>0 on side stream i-1; then join."""
+        """Run fns[i](lane=i) concurrently: lane 0 on the current stream, lane i>0 on side stream i-1; then join.
+        With ``threaded_lanes`` every lane is SUBMITTED from its own host thread (the library calls release the GIL): the host needs
+        ~4 us per launch, a generator pass is ~70 launches, and submitted one lane after the other the second lane starts ~0.3 ms late."""
         if not self.concurrent:
             for fn in fns:
                 fn(0)
@@ -218,10 +235,20 @@ class TrainEngine:
         sides = self._sides[:len(fns) - 1]
         for st in sides:
             st.wait_stream(main)
-        fns[0](0)
-        for i, st in enumerate(sides):
-            with torch.cuda.stream(st):
-                fns[i + 1](i + 1)
+        if self.threaded_lanes and len(fns) > 1:
+            def run(i, st):
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(st):
+                    fns[i + 1](i + 1)
+            futs = [self._pool.submit(run, i, st) for i, st in enumerate(sides)]
+            fns[0](0)
+            for f in futs:
+                f.result()
+        else:
+            fns[0](0)
+            for i, st in enumerate(sides):
+                with torch.cuda.stream(st):
+                    fns[i + 1](i + 1)
         for st in sides:
             main.wait_stream(st)
 
@@ -233,27 +260,56 @@ class TrainEngine:
             return None
         return ctypes.c_void_p(self._aux[lane].cuda_stream) if self.aux_wgrad else None
 
+    def _pass(self, key, fn):
+        """Run one network pass (a library call with static arguments): eagerly the first two times (lazy kernel attributes, event pool),
+        then captured once into a HIP graph and replayed on the current stream."""
+        if not self.pass_graphs or (self._pass_kinds is not None and key[0] not in self._pass_kinds):
+            return fn()
+        key = key + (self.L.mcvc_get_deterministic(),)          # the accumulation mode is baked into a captured pass
+        ent = self._pgraphs.get(key)
+        if ent is None:
+            ent = self._pgraphs[key] = [0, None]
+        if ent[1] is None:
+            if ent[0] < 2:
+                ent[0] += 1
+                return fn()
+            cur = torch.cuda.current_stream(self.device)
+            cur.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self._capture_stream):
+                fn()
+            ent[1] = g
+            torch.cuda.current_stream(self.device).wait_stream(self._capture_stream)
+        ent[1].replay()
+
     def _G(self, name, x, mask, out, stash, nb, lane=0):
         sc = self.g_scratch[lane]
-        check(self.L.mcvc_gen_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(mask), ptr(out), ptr(stash),
-                                      ptr(sc), sc.numel(), nb, self.T, stream()), "gen_forward")
+        self._pass(("G", name, x.data_ptr(), 0 if mask is None else mask.data_ptr(), out.data_ptr(), stash.data_ptr(), nb, lane),
+                   lambda: check(self.L.mcvc_gen_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(mask), ptr(out), ptr(stash),
+                                                         ptr(sc), sc.numel(), nb, self.T, stream()), "gen_forward"))
 
     def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0, milestones=False):
         sc = self.g_scratch[lane]
         ms = self._ms[name][1] if milestones else None
-        check(self.L.mcvc_gen_backward_overlap(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name], ptr(mask), ptr(dout), ptr(dx), acc,
-                                               ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(), self._aux_ptr(lane), ms), "gen_backward")
+        self._pass(("Gb", name, 0 if mask is None else mask.data_ptr(), dout.data_ptr(), 0 if dx is None else dx.data_ptr(), acc, stash.data_ptr(),
+                    nb, lane, bool(milestones), self.aux_wgrad),
+                   lambda: check(self.L.mcvc_gen_backward_overlap(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name], ptr(mask), ptr(dout),
+                                                                  ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(),
+                                                                  self._aux_ptr(lane), ms), "gen_backward"))
 
     def _D(self, name, x, out, stash, nb, lane=0):
         sc = self.d_scratch[lane]
-        check(self.L.mcvc_disc_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(out), ptr(stash), ptr(sc),
-                                       sc.numel(), nb, self.T, stream()), "disc_forward")
+        self._pass(("D", name, x.data_ptr(), out.data_ptr(), stash.data_ptr(), nb, lane),
+                   lambda: check(self.L.mcvc_disc_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(out), ptr(stash), ptr(sc),
+                                                          sc.numel(), nb, self.T, stream()), "disc_forward"))
 
     def _D_bwd(self, name, dlogit, dx, acc, stash, with_weight_grads, nb, lane=0):
         sc = self.d_scratch[lane]
-        check(self.L.mcvc_disc_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name] if with_weight_grads else None,
-                                        ptr(dlogit), 1, ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(),
-                                        nb, self.T, stream(), self._aux_ptr(lane) if (with_weight_grads and self.aux_wgrad_d) else None), "disc_backward")
+        self._pass(("Db", name, dlogit.data_ptr(), 0 if dx is None else dx.data_ptr(), acc, stash.data_ptr(), bool(with_weight_grads), nb, lane),
+                   lambda: check(self.L.mcvc_disc_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name] if with_weight_grads else None,
+                                                           ptr(dlogit), 1, ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(),
+                                                           self._aux_ptr(lane) if (with_weight_grads and self.aux_wgrad_d) else None),
+                                 "disc_backward"))
 
     def _slot(self, i):
         return self.slots[i:i + 1]
