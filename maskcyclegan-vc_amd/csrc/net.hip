@@ -54,10 +54,24 @@ struct Exec {
     long long wino_cap;            // floats available in each
     float* wv2; float* wm2; float* wu;   // the weight-gradient's own set (it runs on the auxiliary stream beside the dgrad): Vt, dMt, dU
     long long wu_cap;
+    int pack_skips;                // what the last re-pack of `packed` left stale: bit 0 = generic trunk copies, bit 1 = direct copies of the Winograd layers
     unsigned* sync;                // arrival counters of the persistent trunk kernels (MCVC_TRUNK_SYNC_WORDS words of the scratch)
     std::vector<std::pair<const void*, hipEvent_t>> readers;
     void fail(int e) { if (!err && e) err = e; }
 };
+
+// What the last re-pack of a packed-weight buffer skipped (mcvc_gen_pack_small_batch refreshes only the copies the small-batch schedule
+// reads).  The run-time dispatch predicates and the pack predicate are written separately; if they ever diverge, the generic path would
+// read zero / stale weights silently -- so every pass looks its buffer up and the generic paths refuse to run on a skipped region.
+static std::mutex g_pack_mu;
+static std::map<const void*, int> g_pack_skips;
+static void set_pack_skips(const void* packed, int skips) { std::lock_guard<std::mutex> lk(g_pack_mu); g_pack_skips[packed] = skips; }
+static int get_pack_skips(const void* packed)
+{
+    std::lock_guard<std::mutex> lk(g_pack_mu);
+    auto it = g_pack_skips.find(packed);
+    return it == g_pack_skips.end() ? 0 : it->second;          // never packed through the small-batch entry: assume a full pack
+}
 
 // small pool of timing-less events, reused round-robin (a backward pass uses a few dozen; the pool is far larger, so an
 // event is never re-recorded while a wait on its previous use can still be pending)
@@ -323,6 +337,7 @@ static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, i
             return;
         }
     }
+    if (!ex.dry && (((ex.pack_skips & 1) && c.off_tk >= 0) || ((ex.pack_skips & 2) && (c.wino || c.wino3)))) { ex.fail(MCVC_ERR_INVALID); return; }
     ConvProblem p{c.Cin, H, W, c.cout_tot, conv_out(H, c.KH, c.stride, c.ph), conv_out(W, c.KW, c.stride, c.pw),
                   c.KH, c.KW, c.stride, c.ph, c.pw};
     ConvIO io{};
@@ -367,6 +382,7 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
             return;
         }
     }
+    if (!ex.dry && (((ex.pack_skips & 1) && c.off_tk >= 0) || ((ex.pack_skips & 2) && (c.wino || c.wino3)))) { ex.fail(MCVC_ERR_INVALID); return; }
     static const int ucls_nb = [] { const char* e = getenv("MCVC_DGRAD_CLASSES_NB"); return e ? atoi(e) : 8; }();
     const bool per_class = c.merged && c.off_dcls >= 0 && NB >= ucls_nb;
     if (c.merged && !per_class) {
@@ -1416,6 +1432,7 @@ int mcvc_gen_pack(const float* const* params, float* packed, void* stream)
         for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i]); add_spec_jobs(pt, g.res_out[i]); }
     }, &err);
     if (!t) return err;
+    set_pack_skips(packed, 0);
     return pack_net(t, params, packed, (hipStream_t)stream);
 }
 
@@ -1460,6 +1477,7 @@ int mcvc_gen_pack_small_batch(const float* const* params, float* packed, int max
     };
     const DevPackTable* t = dev_pack_table(wino_only ? 3 : 2, build, &err);
     if (!t) return err;
+    set_pack_skips(packed, wino_only ? 3 : 1);
     return pack_net(t, params, packed, (hipStream_t)stream);
 }
 
@@ -1485,6 +1503,7 @@ int mcvc_gen_forward(const float* const* params, const float* packed, const floa
     if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
     { const GenScratch q = gen_scratch(d); ex.wv = scratch + q.wv; ex.wm = scratch + q.wm; ex.wino_cap = q.wino_floats;
       ex.sync = reinterpret_cast<unsigned*>(scratch + q.sync); }
+    ex.pack_skips = get_pack_skips(packed);
     gen_forward_impl(ex, params, packed, x, mask, out, stash, d);
     return ex.err;
 }
@@ -1499,6 +1518,7 @@ int mcvc_gen_backward_overlap(const float* const* params, const float* packed, f
     if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
     { const GenScratch q = gen_scratch(d); ex.wv = scratch + q.wv; ex.wm = scratch + q.wm; ex.wino_cap = q.wino_floats;
       ex.wv2 = scratch + q.wv2; ex.wm2 = scratch + q.wm2; ex.wu = scratch + q.wu; ex.wu_cap = q.wu_floats; }
+    ex.pack_skips = get_pack_skips(packed);
     gen_backward_impl(ex, params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, d, milestones);
     return ex.err;
 }
