@@ -133,6 +133,12 @@ int mcvc_l1_loss(const float* a, const float* b, long long n, float weight, floa
 int mcvc_lsgan_loss(const float* d, long long n, float target, float weight, float* loss_slot, float* term_slot,
                     float* grad_logit, void* stream);
 
+/* The terms of one phase may be produced on different streams, each into its own pair pairs[2k] = weight*mean, pairs[2k+1] = mean
+ * (pass them as loss_slot / term_slot above, zeroed before).  This adds pair k to slots[loss_dst[k]] / slots[term_dst[k]] (-1 =
+ * skip), k = 0..n-1 in that order (n <= 16; the two index arrays are HOST memory): the order of the reference's sums
+ * (train.py:233-237, 276-294) whatever the streams' timing was.                                       */
+int mcvc_loss_combine(const float* pairs, int n, const int* loss_dst, const int* term_dst, float* slots, void* stream);
+
 /* ---- optimizer: torch.optim.Adam(betas, eps, weight_decay=0) on a flat buffer (train.py:119-122) */
 int mcvc_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                    float beta1, float beta2, float eps, int step, float grad_scale, void* stream);

@@ -112,6 +112,19 @@ __global__ void __launch_bounds__(1024) lsgan_loss_kernel(const float* __restric
     }
 }
 
+// The loss terms of one phase are produced on different streams, each into a PRIVATE pair (weighted value, plain mean); this single
+// thread adds them to the public slots in a FIXED order (the reference's: train.py:233-237, 276-294), so the sums are reproducible
+// whatever the streams' relative timing was.
+struct LossCombineArgs { int n; int loss_dst[16]; int term_dst[16]; };
+__global__ void loss_combine_kernel(const float* __restrict__ pairs, float* __restrict__ slots, const LossCombineArgs c)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int k = 0; k < c.n; ++k) {
+        if (c.term_dst[k] >= 0) slots[c.term_dst[k]] += pairs[2 * k + 1];
+        if (c.loss_dst[k] >= 0) slots[c.loss_dst[k]] += pairs[2 * k];
+    }
+}
+
 // torch.optim.Adam single-tensor math on a flat buffer (weight_decay 0, amsgrad off):
 //   m = lerp(m, g, 1-b1); v = b2*v + (1-b2) g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -203,6 +216,17 @@ int mcvc_lsgan_loss_launch(const float* d, long long n, float target, float weig
 {
     TraceScope ts(K_LOSS, s, 0.0, 8.0 * n);
     hipLaunchKernelGGL(lsgan_loss_kernel, dim3(1), dim3(1024), 0, s, d, n, target, weight, loss_slot, term_slot, grad_logit);
+    return (int)hipGetLastError();
+}
+
+int mcvc_loss_combine_launch(const float* pairs, int n, const int* loss_dst, const int* term_dst, float* slots, hipStream_t s)
+{
+    if (n < 0 || n > 16) return (int)hipErrorInvalidValue;
+    LossCombineArgs c;
+    c.n = n;
+    for (int k = 0; k < n; ++k) { c.loss_dst[k] = loss_dst[k]; c.term_dst[k] = term_dst[k]; }
+    TraceScope ts(K_LOSS, s, 0.0, 16.0 * n);
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, s, pairs, slots, c);
     return (int)hipGetLastError();
 }
 

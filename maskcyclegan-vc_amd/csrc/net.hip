@@ -1562,6 +1562,12 @@ int mcvc_l1_loss(const float* a, const float* b, long long n, float weight, floa
     return mcvc_l1_loss_launch(a, b, n, weight, loss_slot, term_slot, grad_a, accumulate_grad, (hipStream_t)stream);
 }
 
+int mcvc_loss_combine(const float* pairs, int n, const int* loss_dst, const int* term_dst, float* slots, void* stream)
+{
+    if (!pairs || !slots || !loss_dst || !term_dst) return MCVC_ERR_INVALID;
+    return mcvc_loss_combine_launch(pairs, n, loss_dst, term_dst, slots, (hipStream_t)stream);
+}
+
 int mcvc_lsgan_loss(const float* d, long long n, float target, float weight, float* loss_slot, float* term_slot, float* grad_logit, void* stream)
 {
     return mcvc_lsgan_loss_launch(d, n, target, weight, loss_slot, term_slot, grad_logit, (hipStream_t)stream);

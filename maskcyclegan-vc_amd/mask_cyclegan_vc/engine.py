@@ -99,7 +99,12 @@ class TrainEngine:
         # ---- packed weights
         self.packed = {n: torch.zeros(L.mcvc_gen_packed_floats(), device=dev) for n in G_NAMES}
         self.packed.update({n: torch.zeros(L.mcvc_disc_packed_floats(), device=dev) for n in D_NAMES})
-        self.slots = torch.zeros(16, device=dev)
+        # [0, 8): the public loss slots; [8, 40): one private (weighted value, mean) pair per loss call of an iteration -- the calls run on
+        # different lanes, mcvc_loss_combine adds them to the public slots in the reference's order
+        self.slots = torch.zeros(8 + 2 * 16, device=dev)
+        ia = lambda v: (ctypes.c_int * len(v))(*v)          # noqa: E731
+        self._comb_g = (8, ia([SLOT_G] * 8), ia([SLOT_CYCLE, SLOT_CYCLE, SLOT_IDENT, SLOT_IDENT] + [SLOT_ADV_G] * 4))
+        self._comb_d = (8, ia([SLOT_D] * 8), ia([SLOT_D_REAL, SLOT_D_FAKE] * 4))
         # The A->B and B->A halves of the step are independent chains over different networks.  At small batch their
         # kernels are latency-bound and far from filling 256 CUs, so the two chains run as two "lanes" on two HIP
         # streams (lane 0 = the caller's stream) and overlap on the chip; join points are stream-event waits.
@@ -131,10 +136,7 @@ class TrainEngine:
         self._capture_stream = torch.cuda.Stream(device=dev)
         # the discriminators' weight re-pack after their Adam step is needed only ~1.5 ms later (after the next iteration's
         # four generator forwards): it runs on its own stream and the discriminator forwards wait for its event
-        self.threaded_lanes = os.environ.get("MCVC_THREADED_LANES", "0") == "1"
-        if self.threaded_lanes:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=3)
+        self._task_events = {}
         self._pack_stream = torch.cuda.Stream(device=dev)
         self._d_pack_event = None
         # data parallel: start the discriminator gradient all-reduce at the end of an iteration and finish the update
@@ -221,36 +223,39 @@ class TrainEngine:
         names = list(names)
         while names:
             grp, names = names[:4], names[4:]
-            self._lanes(*[(lambda ln, n=n: self._repack1(n)) for n in grp])
+            self._run_tasks([(i, (lambda ln, n=n: self._repack1(n)), (), None) for i, n in enumerate(grp)])
 
-    def _lanes(self, *fns):
-        """Run fns[i](lane=i) concurrently: lane 0 on the current stream, lane i>0 on side stream i-1; then join.
-        With ``threaded_lanes`` every lane is SUBMITTED from its own host thread (the library calls release the GIL): the host needs
-        ~4 us per launch, a generator pass is ~70 launches, and submitted one lane after the other the second lane starts ~0.3 ms late."""
+    def _run_tasks(self, tasks):
+        """Submit a phase as a dependency graph instead of fork/join rounds.
+
+        ``tasks`` is a list of ``(lane, fn, waits, record)`` in a valid topological order: ``fn(lane)`` is queued on lane ``lane``'s HIP
+        stream (lane 0 = the caller's stream) after the events named in ``waits``; ``record`` names the event recorded behind it.  Work of
+        one lane is ordered by its stream, cross-lane edges are events, everything joins the caller's stream at the end.  Serial mode runs
+        the same list in order on one stream."""
         if not self.concurrent:
-            for fn in fns:
-                fn(0)
+            for lane, fn, _, _ in tasks:
+                fn(lane)
             return
         main = torch.cuda.current_stream(self.device)
-        sides = self._sides[:len(fns) - 1]
-        for st in sides:
-            st.wait_stream(main)
-        if self.threaded_lanes and len(fns) > 1:
-            def run(i, st):
-                torch.cuda.set_device(self.device)
-                with torch.cuda.stream(st):
-                    fns[i + 1](i + 1)
-            futs = [self._pool.submit(run, i, st) for i, st in enumerate(sides)]
-            fns[0](0)
-            for f in futs:
-                f.result()
-        else:
-            fns[0](0)
-            for i, st in enumerate(sides):
-                with torch.cuda.stream(st):
-                    fns[i + 1](i + 1)
-        for st in sides:
-            main.wait_stream(st)
+        streams = [main] + self._sides
+        used = sorted({t[0] for t in tasks} - {0})
+        for ln in used:
+            streams[ln].wait_stream(main)
+        done = {}
+        for lane, fn, waits, rec in tasks:
+            st = streams[lane]
+            with torch.cuda.stream(st):
+                for w in waits:
+                    st.wait_event(done[w])
+                fn(lane)
+                if rec is not None:
+                    ev = self._task_events.get(rec)
+                    if ev is None:
+                        ev = self._task_events[rec] = torch.cuda.Event()
+                    ev.record(st)
+                    done[rec] = ev
+        for ln in used:
+            main.wait_stream(streams[ln])
 
     def _aux_ptr(self, lane):
         import ctypes
@@ -314,13 +319,18 @@ class TrainEngine:
     def _slot(self, i):
         return self.slots[i:i + 1]
 
-    def _l1(self, a, b, weight, grad, term_slot):
-        check(self.L.mcvc_l1_loss(ptr(a), ptr(b), a.numel(), float(weight), ptr(self._slot(SLOT_G)), ptr(self._slot(term_slot)), ptr(grad), 0,
+    def _l1(self, a, b, weight, grad, k):
+        """Loss call ``k`` of the iteration: value and mean go to its private pair (zeroed with the slots at the start of the iteration)."""
+        check(self.L.mcvc_l1_loss(ptr(a), ptr(b), a.numel(), float(weight), ptr(self._slot(8 + 2 * k)), ptr(self._slot(9 + 2 * k)), ptr(grad), 0,
                                   stream()), "l1_loss")
 
-    def _lsgan(self, d, target, weight, loss_slot, term_slot, dlogit):
-        check(self.L.mcvc_lsgan_loss(ptr(d), d.numel(), float(target), float(weight), ptr(self._slot(loss_slot)), ptr(self._slot(term_slot)),
+    def _lsgan(self, d, target, weight, k, dlogit):
+        check(self.L.mcvc_lsgan_loss(ptr(d), d.numel(), float(target), float(weight), ptr(self._slot(8 + 2 * k)), ptr(self._slot(9 + 2 * k)),
                                      ptr(dlogit), stream()), "lsgan_loss")
+
+    def _combine(self, first, comb):
+        n, loss_dst, term_dst = comb
+        check(self.L.mcvc_loss_combine(ptr(self._slot(8 + 2 * first)), n, loss_dst, term_dst, ptr(self.slots), stream()), "loss_combine")
 
     def _adam(self, grp, lr):
         grp.step += 1
@@ -349,38 +359,54 @@ class TrainEngine:
         g_fake_B, g_identity_B = self.gout_A2B[:B], self.gout_A2B[B:]
         g_fake_A, g_identity_A = self.gout_B2A[:B], self.gout_B2A[B:]
         do, dl, ds = self.dout1, self.dlogit1, self.d_stash1
-        # lane 0 follows real_A -> fake_B -> cycle_A, lane 1 follows real_B -> fake_A -> cycle_B
-        self._lanes(lambda ln: self._G("generator_A2B", self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], B2, ln),   # :203, :209-210
-                    lambda ln: self._G("generator_B2A", self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], B2, ln))   # :205, :207-208
-        self._lanes(lambda ln: self._G("generator_B2A", fake_B, None, m["cycle_A"], self.g_stash1[0], B, ln),                  # :204 (mask of ones)
-                    lambda ln: self._G("generator_A2B", fake_A, None, m["cycle_B"], self.g_stash1[1], B, ln))                  # :206
+        # The phase as a dependency graph over four lanes.  Lane 0 follows real_A -> fake_B -> cycle_A -> D_A2 and back, lane 1 follows
+        # real_B -> fake_A -> cycle_B -> D_B2 and back: these two are the critical path.  The first-step adversarial terms D_A(fake_A),
+        # D_B(fake_B) need only the translated batches: lanes 2 and 3 run their forward, loss and data-gradient WHILE lanes 0/1 are in the
+        # cycle forwards (round 2 ran them after, four discriminators abreast).  Cross-lane edges: the translated batches (g0, g1), the
+        # adversarial gradients that the cycle backward accumulates onto (dA, dB), and the two backward passes of one generator, which
+        # accumulate into the same weight gradients (c0, c1).
+        cl, il = sc.cycle_loss_lambda, sc.identity_loss_lambda
 
-        if self.defer_d_update:            # data parallel: the D gradient all-reduce of the previous iteration ran behind the
-            self._finish_d_update()        # generator forwards above; the discriminators are first needed here
-        self._wait_d_pack()                # discriminator weights changed at the end of the previous iteration
-        self._lanes(lambda ln: self._D("discriminator_A", fake_A, do[0], ds[0], B, ln),              # :211
-                    lambda ln: self._D("discriminator_B", fake_B, do[1], ds[1], B, ln),              # :212
-                    lambda ln: self._D("discriminator_A2", m["cycle_A"], do[2], ds[2], B, ln),       # :215
-                    lambda ln: self._D("discriminator_B2", m["cycle_B"], do[3], ds[3], B, ln))       # :216
-        # losses (:219-237) and their gradients (tiny single-block kernels; they share the loss slots -> one stream)
-        self._l1(m["cycle_A"], real_A, sc.cycle_loss_lambda, m["g_cycle_A"], SLOT_CYCLE)
-        self._l1(m["cycle_B"], real_B, sc.cycle_loss_lambda, m["g_cycle_B"], SLOT_CYCLE)
-        self._l1(identity_A, real_A, sc.identity_loss_lambda, g_identity_A, SLOT_IDENT)
-        self._l1(identity_B, real_B, sc.identity_loss_lambda, g_identity_B, SLOT_IDENT)
-        for i in range(4):
-            self._lsgan(do[i], 1.0, 1.0, SLOT_G, SLOT_ADV_G, dl[i])
-        # backward, in dependency order; discriminators contribute data-gradients only
+        def cycle_a(ln):
+            self._G("generator_B2A", fake_B, None, m["cycle_A"], self.g_stash1[0], B, ln)                  # :204 (mask of ones)
+            self._l1(m["cycle_A"], real_A, cl, m["g_cycle_A"], 0)                                          # :219
+            self._l1(identity_B, real_B, il, g_identity_B, 3)                                              # :224
 
-        self._lanes(lambda ln: self._D_bwd("discriminator_A2", dl[2], m["g_cycle_A"], 1, ds[2], False, B, ln),
-                    lambda ln: self._D_bwd("discriminator_B2", dl[3], m["g_cycle_B"], 1, ds[3], False, B, ln),
-                    lambda ln: self._D_bwd("discriminator_A", dl[0], g_fake_A, 0, ds[0], False, B, ln),
-                    lambda ln: self._D_bwd("discriminator_B", dl[1], g_fake_B, 0, ds[1], False, B, ln))
-        self._lanes(lambda ln: self._G_bwd("generator_B2A", None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B, ln),   # cycle_A = G_B2A(fake_B)
-                    lambda ln: self._G_bwd("generator_A2B", None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, ln))   # cycle_B = G_A2B(fake_A)
-        # the last pass over each generator: its gradient ranges become final one after the other (milestone events)
+        def cycle_b(ln):
+            self._G("generator_A2B", fake_A, None, m["cycle_B"], self.g_stash1[1], B, ln)                  # :206
+            self._l1(m["cycle_B"], real_B, cl, m["g_cycle_B"], 1)                                          # :220
+            self._l1(identity_A, real_A, il, g_identity_A, 2)                                              # :223
+
+        def adv(name, i, x, gx, acc):
+            def run(ln):
+                self._wait_d_pack()            # discriminator weights changed at the end of the previous iteration
+                self._D(name, x, do[i], ds[i], B, ln)                                                      # :211-216
+                self._lsgan(do[i], 1.0, 1.0, 4 + i, dl[i])                                                 # :227-231
+                self._D_bwd(name, dl[i], gx, acc, ds[i], False, B, ln)         # discriminators contribute data-gradients only
+            return run
+
+        def finish_d(ln):                      # data parallel: the D gradient all-reduce of the previous iteration ran behind the
+            self._finish_d_update()            # generator forwards; the discriminators are first needed after this point
         ov = self.overlap_g_reduce
-        self._lanes(lambda ln: self._G_bwd("generator_A2B", self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2, ln, ov),
-                    lambda ln: self._G_bwd("generator_B2A", self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2, ln, ov))
+        self._run_tasks([
+            (0, lambda ln: self._G("generator_A2B", self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], B2, ln), (), "g0"),   # :203, :209-210
+            (1, lambda ln: self._G("generator_B2A", self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], B2, ln), (), "g1"),   # :205, :207-208
+            (0, cycle_a, (), None),
+            (1, cycle_b, (), None),
+            (0, finish_d, (), None),
+            (2, adv("discriminator_A", 0, fake_A, g_fake_A, 0), ("g1",), "dA"),
+            (3, adv("discriminator_B", 1, fake_B, g_fake_B, 0), ("g0",), "dB"),
+            (0, adv("discriminator_A2", 2, m["cycle_A"], m["g_cycle_A"], 1), (), None),
+            (1, adv("discriminator_B2", 3, m["cycle_B"], m["g_cycle_B"], 1), (), None),
+            # backward through the cycle passes: cycle_A = G_B2A(fake_B) adds to d(fake_B), cycle_B = G_A2B(fake_A) to d(fake_A)
+            (0, lambda ln: self._G_bwd("generator_B2A", None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B, ln), ("dB",), "c0"),
+            (1, lambda ln: self._G_bwd("generator_A2B", None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, ln), ("dA",), "c1"),
+            # the last pass over each generator: its gradient ranges become final one after the other (milestone events)
+            (0, lambda ln: self._G_bwd("generator_A2B", self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2, ln, ov), ("c1",), None),
+            (1, lambda ln: self._G_bwd("generator_B2A", self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2, ln, ov), ("c0",), None),
+        ])
+        self._d_pack_event = None
+        self._combine(0, self._comb_g)          # g_loss and its terms, summed in the reference's order (:233-237)
 
     def generator_update(self):
         """All-reduce (data parallel) + Adam on the flat generator buffer (train.py:242); eager: its scalars change per step."""
@@ -403,7 +429,6 @@ class TrainEngine:
         B, B2 = self.B, 2 * self.B
         m = self.mel
         sc = self.sched
-        self.repack(G_NAMES)               # generators run with their UPDATED weights (train.py:259-273)
         self.d_group.grad.zero_()
         di = self.d_in
         # generators run with their UPDATED weights and no gradient (train.py:259-273); outputs land directly in the
@@ -412,24 +437,35 @@ class TrainEngine:
         cyc_A, cyc_B = di["discriminator_A2"][B:], di["discriminator_B2"][B:]
         di["discriminator_A"][:B].copy_(real_A); di["discriminator_A2"][:B].copy_(real_A)
         di["discriminator_B"][:B].copy_(real_B); di["discriminator_B2"][:B].copy_(real_B)
-        def chain_a(ln):
-            self._G("generator_B2A", real_B, mask_B, gen_A, self.g_stash1[0], B, ln)     # :259 generated_A
-            self._G("generator_A2B", gen_A, None, cyc_B, self.g_stash1[0], B, ln)        # :263 cycled_B
-
-        def chain_b(ln):
-            self._G("generator_A2B", real_A, mask_A, gen_B, self.g_stash1[1], B, ln)     # :267 generated_B
-            self._G("generator_B2A", gen_B, None, cyc_A, self.g_stash1[1], B, ln)        # :271 cycled_A
-        self._lanes(chain_a, chain_b)
         do, dl, ds = self.dout2, self.dlogit2, self.d_stash2
         idx = {n: i for i, n in enumerate(D_NAMES)}
 
-        self._lanes(*[(lambda ln, n=n: self._D(n, di[n], do[idx[n]], ds[idx[n]], B2, ln)) for n in D_NAMES])   # :255-258 real half, :260-273 generated half
-        # d_loss = (A + B)/2 + (A_2nd + B_2nd)/2 with each = (real + fake)/2  -> every term weighs 1/4  (:276-294)
-        for i in range(4):
-            self._lsgan(do[i][:B], 1.0, 0.25, SLOT_D, SLOT_D_REAL, dl[i][:B])
-            self._lsgan(do[i][B:], 0.0, 0.25, SLOT_D, SLOT_D_FAKE, dl[i][B:])
+        def disc(name):
+            i = idx[name]
 
-        self._lanes(*[(lambda ln, n=n: self._D_bwd(n, dl[idx[n]], None, 0, ds[idx[n]], True, B2, ln)) for n in D_NAMES])
+            def run(ln):
+                self._D(name, di[name], do[i], ds[i], B2, ln)                      # :255-258 real half, :260-273 generated half
+                # d_loss = (A + B)/2 + (A_2nd + B_2nd)/2 with each = (real + fake)/2  -> every term weighs 1/4  (:276-294)
+                self._lsgan(do[i][:B], 1.0, 0.25, 8 + 2 * i, dl[i][:B])
+                self._lsgan(do[i][B:], 0.0, 0.25, 9 + 2 * i, dl[i][B:])
+                self._D_bwd(name, dl[i], None, 0, ds[i], True, B2, ln)
+            return run
+        # Same shape as the generator phase: lanes 0/1 carry real_B -> generated_A -> cycled_B -> D_B2 and real_A -> generated_B ->
+        # cycled_A -> D_A2; D_A / D_B need only the generated batches and run on lanes 2/3 while lanes 0/1 are in the cycle forwards.
+        # A lane re-packs the generator it runs first; the other lane's second pass waits for that re-pack (p0 / p1).
+        self._run_tasks([
+            (0, lambda ln: self._repack1("generator_B2A"), (), "p0"),
+            (1, lambda ln: self._repack1("generator_A2B"), (), "p1"),
+            (0, lambda ln: self._G("generator_B2A", real_B, mask_B, gen_A, self.g_stash1[0], B, ln), (), "gA"),      # :259 generated_A
+            (1, lambda ln: self._G("generator_A2B", real_A, mask_A, gen_B, self.g_stash1[1], B, ln), (), "gB"),      # :267 generated_B
+            (0, lambda ln: self._G("generator_A2B", gen_A, None, cyc_B, self.g_stash1[0], B, ln), ("p1",), None),    # :263 cycled_B
+            (1, lambda ln: self._G("generator_B2A", gen_B, None, cyc_A, self.g_stash1[1], B, ln), ("p0",), None),    # :271 cycled_A
+            (2, disc("discriminator_A"), ("gA",), None),
+            (3, disc("discriminator_B"), ("gB",), None),
+            (0, disc("discriminator_B2"), (), None),
+            (1, disc("discriminator_A2"), (), None),
+        ])
+        self._combine(8, self._comb_d)
 
     def discriminator_update(self):
         """train.py:299.  With more than one rank the all-reduce is only *started* here; Adam runs when the discriminators
@@ -462,14 +498,16 @@ class TrainEngine:
         self._d_pack_event = ev
 
     def _wait_d_pack(self):
+        """Make the CURRENT stream wait for the discriminators' re-pack (every lane that runs a discriminator calls this; the generator
+        phase drops the event once all lanes have joined)."""
         if self._d_pack_event is not None:
             torch.cuda.current_stream(self.device).wait_event(self._d_pack_event)
-            self._d_pack_event = None
 
     def flush(self):
         """Complete a deferred discriminator update (call before reading parameters / optimizer state from outside)."""
         self._finish_d_update()
         self._wait_d_pack()
+        self._d_pack_event = None
 
     def step(self, real_A, mask_A, real_B, mask_B):
         """One full iteration.  Inputs: float32 [B,80,T] on the engine's device.  Returns the loss-slot
