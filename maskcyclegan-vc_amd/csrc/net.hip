@@ -18,6 +18,7 @@
 #include "misc.h"
 #include "trunk.h"
 #include "wino.h"
+#include "sgemm.h"
 #include "sampler.h"
 #include "../../include/mcvc.h"
 #include <string.h>
@@ -54,6 +55,8 @@ struct Exec {
     long long wino_cap;            // floats available in each
     float* wv2; float* wm2; float* wu;   // the weight-gradient's own set (it runs on the auxiliary stream beside the dgrad): Vt, dMt, dU
     long long wu_cap;
+    float* sg; long long sg_cap, sg_need;    // staging region of the large-batch GEMM path of the strided 3x3 convs (sgemm.h)
+    const float* const* params;    // the pass's parameter table (that path's data gradient multiplies the OIHW tensors themselves)
     int pack_skips;                // what the last re-pack of `packed` left stale: bit 0 = generic trunk copies, bit 1 = direct copies of the Winograd layers
     unsigned* sync;                // arrival counters of the persistent trunk kernels (MCVC_TRUNK_SYNC_WORDS words of the scratch)
     std::vector<std::pair<const void*, hipEvent_t>> readers;
@@ -258,6 +261,23 @@ static int wino_tile_cfg(int M, long long NT)
     return knob >= 0 ? knob : 2;
 }
 
+// Samples per Winograd pass: the V / M workspaces hold at most kWinoMaxTiles tiles; a larger batch runs in equal chunks of samples
+// (every op of the three-launch pipeline is per sample; weight gradients add up over the chunks).  0 = not applicable.
+constexpr long long kWinoMaxTiles = 16384;
+static int wino_chunk(int NB, long long tiles_per_sample)
+{
+    if (tiles_per_sample <= 0 || tiles_per_sample > kWinoMaxTiles) return 0;
+    const long long nbmax = kWinoMaxTiles / tiles_per_sample;
+    if (NB <= nbmax) return NB;
+    const long long nch = (NB + nbmax - 1) / nbmax;
+    return (int)((NB + nch - 1) / nch);
+}
+static long long wino_chunk_tiles(int NB, long long tiles_per_sample)          // padded tile count of the largest chunk
+{
+    const int nbc = wino_chunk(NB, tiles_per_sample);
+    return nbc ? ((nbc * tiles_per_sample + 31) & ~31LL) : 0;
+}
+
 // 5x5 stride-1 conv as Winograd F(2x2,5x5): input transform -> 36 batched [M x K] x [K x tiles] products (one launch of the
 // direct-conv kernel as a 1x1 conv over 36 images with per-image weights) -> output transform (+bias, PixelShuffle store).
 // dgrad: the same on the flipped / transposed weight set; K = conv output channels, M = conv input channels.
@@ -267,73 +287,114 @@ static bool conv_wino(Exec& ex, const ConvSpec& c, const float* packed, int dgra
     if (!c.wino || !wino_enabled() || !ex.wv) return false;
     const int K = dgrad ? c.cout_tot : c.Cin, M = dgrad ? c.Cin : c.cout_tot;
     const int TH = (H + 1) / 2, TW = (W + 1) / 2;
-    const long long NT = (long long)NB * TH * TW;
-    // the 36 products see the tiles as a (NTp/32) x 32 "image" so that the conv kernel's 2-D pixel tiles are full
-    const long long NTp = (NT + 31) & ~31LL;
-    if (NT > 16384 || 36LL * (K > M ? K : M) * NTp > ex.wino_cap) return false;
+    const int nbc = wino_chunk(NB, (long long)TH * TW);
+    if (!nbc || 36LL * (K > M ? K : M) * wino_chunk_tiles(NB, (long long)TH * TW) > ex.wino_cap) return false;
     if (ex.dry) return true;
-    WinoXformArgs xi{};
-    xi.x = x.p; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv;
-    xi.N = NB; xi.C = K; xi.H = H; xi.W = W; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 2;
-    ex.fail(mcvc_wino_input_launch(xi, ex.s));
     static const int own_gemm = [] { const char* e = getenv("MCVC_WINO_GEMM"); return e ? atoi(e) : 1; }();
-    if (own_gemm && (M % 128) == 0 && (K % 16) == 0 && NTp >= 64) {
-        WinoGemmArgs ga{};
-        ga.a = packed + (dgrad ? c.off_wd : c.off_wf); ga.a_xi = dgrad ? c.wd_xi : c.wf_xi; ga.lda = dgrad ? c.cin_pk : c.cout_pk;
-        ga.b = ex.wv; ga.b_xi = (long long)K * NTp; ga.ldb = (int)NTp;
-        ga.c = ex.wm; ga.c_xi = (long long)M * NTp; ga.ldc = (int)NTp;
-        ga.M = M; ga.N = (int)NTp; ga.K = K;
-        ex.fail(mcvc_wino_gemm_launch(ga, ex.s));
-    } else {
-        ConvProblem p{K, (int)(NTp / 32), 32, M, (int)(NTp / 32), 32, 1, 1, 1, 0, 0};
-        ConvIO io{};
-        io.x = ex.wv; io.x_sb = (long long)K * NTp; io.x_sc = NTp; io.x_sh = 32;
-        io.y = ex.wm; io.y_sb = (long long)M * NTp; io.y_sc = NTp; io.y_sh = 32; io.y_sw = 1;
-        io.nsplit = 1;
-        io.w_nstride = dgrad ? c.wd_xi : c.wf_xi;
-        io.tile_cfg = wino_tile_cfg(M, NT);
-        io.gemm_ok = 1;
-        ex.fail(mcvc_conv_launch(p, 36, io, packed + (dgrad ? c.off_wd : c.off_wf), dgrad ? c.dg_rows_co : c.cin_pad, dgrad ? c.cin_pk : c.cout_pk,
-                                 nullptr, ex.s, nullptr));
+    for (int b0 = 0; b0 < NB; b0 += nbc) {
+        const int nb = NB - b0 < nbc ? NB - b0 : nbc;
+        const long long NT = (long long)nb * TH * TW;
+        // the 36 products see the tiles as a (NTp/32) x 32 "image" so that the conv kernel's 2-D pixel tiles are full
+        const long long NTp = (NT + 31) & ~31LL;
+        WinoXformArgs xi{};
+        xi.x = x.p + (long long)b0 * x.sb; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv;
+        xi.N = nb; xi.C = K; xi.H = H; xi.W = W; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 2;
+        ex.fail(mcvc_wino_input_launch(xi, ex.s));
+        if (own_gemm && (M % 128) == 0 && (K % 16) == 0 && NTp >= 64) {
+            WinoGemmArgs ga{};
+            ga.a = packed + (dgrad ? c.off_wd : c.off_wf); ga.a_xi = dgrad ? c.wd_xi : c.wf_xi; ga.lda = dgrad ? c.cin_pk : c.cout_pk;
+            ga.b = ex.wv; ga.b_xi = (long long)K * NTp; ga.ldb = (int)NTp;
+            ga.c = ex.wm; ga.c_xi = (long long)M * NTp; ga.ldc = (int)NTp;
+            ga.M = M; ga.N = (int)NTp; ga.K = K;
+            ex.fail(mcvc_wino_gemm_launch(ga, ex.s));
+        } else {
+            ConvProblem p{K, (int)(NTp / 32), 32, M, (int)(NTp / 32), 32, 1, 1, 1, 0, 0};
+            ConvIO io{};
+            io.x = ex.wv; io.x_sb = (long long)K * NTp; io.x_sc = NTp; io.x_sh = 32;
+            io.y = ex.wm; io.y_sb = (long long)M * NTp; io.y_sc = NTp; io.y_sh = 32; io.y_sw = 1;
+            io.nsplit = 1;
+            io.w_nstride = dgrad ? c.wd_xi : c.wf_xi;
+            io.tile_cfg = wino_tile_cfg(M, NT);
+            io.gemm_ok = 1;
+            ex.fail(mcvc_conv_launch(p, 36, io, packed + (dgrad ? c.off_wd : c.off_wf), dgrad ? c.dg_rows_co : c.cin_pad, dgrad ? c.cin_pk : c.cout_pk,
+                                     nullptr, ex.s, nullptr));
+        }
+        WinoOutArgs oa{};
+        oa.m = ex.wm; oa.bias = dgrad ? nullptr : packed + c.off_bias;
+        oa.y = y.p + (long long)b0 * y.sb; oa.y_sb = y.sb; oa.y_sc = y.sc; oa.y_sh = y.sh;
+        oa.N = nb; oa.Cout = M; oa.OH = H; oa.OW = W; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
+        oa.shuffle = shuffle; oa.YH = 2 * H; oa.YW = 2 * W; oa.accumulate = accumulate;
+        ex.fail(mcvc_wino_output_launch(oa, ex.s));
     }
-    WinoOutArgs oa{};
-    oa.m = ex.wm; oa.bias = dgrad ? nullptr : packed + c.off_bias;
-    oa.y = y.p; oa.y_sb = y.sb; oa.y_sc = y.sc; oa.y_sh = y.sh;
-    oa.N = NB; oa.Cout = M; oa.OH = H; oa.OW = W; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
-    oa.shuffle = shuffle; oa.YH = 2 * H; oa.YW = 2 * W; oa.accumulate = accumulate;
-    ex.fail(mcvc_wino_output_launch(oa, ex.s));
     return true;
 }
+
+// The discriminators' stride-2 3x3 layers at large batch: staged GEMMs (sgemm.h).  MCVC_SGEMM_NB = smallest batch (0 = never).
+static int sgemm_min_nb()
+{
+    static const int v = [] { const char* e = getenv("MCVC_SGEMM_NB"); return e ? atoi(e) : 8; }();
+    return v;
+}
+static bool sgemm_applies(const ConvSpec& c, int NB, int H, int W)
+{
+    const int P = ((H + 1) / 2) * ((W + 1) / 2);
+    return sgemm_min_nb() > 0 && NB >= sgemm_min_nb() && c.KH == 3 && c.KW == 3 && c.stride == 2 && c.ph == 1 && c.pw == 1 && c.nbr <= 2 &&
+           (c.cout_tot % 64) == 0 && ((c.Cin * 9) % 64) == 0 && (c.Cout % 32) == 0 && c.cin_pad == c.Cin && (P % 4) == 0;
+}
+static void sgemm_want(Exec& ex, long long floats) { if (floats > ex.sg_need) ex.sg_need = floats; }
 
 static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, int H, int W, CView x, View y, long long y_total,
                      int shuffle, int allow_split, int* nsplit)
 {
+    if (!shuffle && sgemm_applies(c, NB, H, W)) {
+        const int OH = (H + 1) / 2, OW = (W + 1) / 2, P = OH * OW, K9 = 9 * c.Cin;
+        const long long NT = (long long)NB * P;
+        if (ex.dry) { sgemm_want(ex, K9 * NT); if (nsplit) *nsplit = 1; return; }
+        if (ex.sg && K9 * NT <= ex.sg_cap && y.sh == OW && y.sc == P) {
+            StageArgs sa{x.p, x.sb, x.sc, x.sh, NB, c.Cin, H, W, OH, OW, ex.sg, NT, 0};
+            ex.fail(mcvc_im2col_s2_launch(sa, ex.s));
+            SGemmArgs g{};
+            g.a = packed + c.off_fwd; g.lda = c.cout_pk;                       // Wt[k = 9*ci + tap][co] (value | gate columns)
+            g.b = ex.sg; g.ldb = NT; g.bseg = (int)NT; g.b_sn = 0;
+            g.c = y.p; g.ldc = y.sc; g.cseg = P; g.c_sn = y.sb;
+            g.bias = packed + c.off_bias;
+            g.M = c.cout_tot; g.N = (int)NT; g.K = K9; g.nsplit = 1;
+            ex.fail(mcvc_sgemm_launch(g, ex.s));
+            if (nsplit) *nsplit = 1;
+            return;
+        }
+    }
     if (conv_wino(ex, c, packed, 0, NB, H, W, x, y, shuffle, 0)) { if (nsplit) *nsplit = 1; return; }
     if (c.wino3 && wino_enabled() && ex.wv && !shuffle && (H & 1) == 0 && (W & 1) == 0 && (c.cout_tot % 128) == 0) {
         // stride-2 5x5 forward = 3x3 stride-1 conv over the four input phases: Winograd F(2x2,3x3), K = 4*Cin
         static const int en = [] { const char* e = getenv("MCVC_WINO3_FWD"); return e ? atoi(e) : 1; }();
         const int OH = H / 2, OW = W / 2, K = 4 * c.Cin, M = c.cout_tot;
         const int TH = (OH + 1) / 2, TW = (OW + 1) / 2;
-        const long long NT = (long long)NB * TH * TW, NTp = (NT + 31) & ~31LL;
-        if (en && NT <= 16384 && NTp >= 64 && 16LL * (K > M ? K : M) * NTp <= ex.wino_cap) {
+        const int nbc = wino_chunk(NB, (long long)TH * TW);
+        const long long NTc = wino_chunk_tiles(NB, (long long)TH * TW);
+        if (en && nbc && NTc >= 64 && 16LL * (K > M ? K : M) * NTc <= ex.wino_cap) {
             if (nsplit) *nsplit = 1;
             if (ex.dry) return;
-            WinoXformArgs xi{};
-            xi.x = x.p; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv;
-            xi.N = NB; xi.C = K; xi.H = OH; xi.W = OW; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 1;
-            ex.fail(mcvc_wino3_input_phase_launch(xi, H, W, ex.s));
-            WinoGemmArgs ga{};
-            ga.a = packed + c.off_w3f; ga.a_xi = c.w3f_xi; ga.lda = c.cout_pk;
-            ga.b = ex.wv; ga.b_xi = (long long)K * NTp; ga.ldb = (int)NTp;
-            ga.c = ex.wm; ga.c_xi = (long long)M * NTp; ga.ldc = (int)NTp;
-            ga.M = M; ga.N = (int)NTp; ga.K = K; ga.nxi = 16;
-            ex.fail(mcvc_wino_gemm_launch(ga, ex.s));
-            WinoOutArgs oa{};
-            oa.m = ex.wm; oa.bias = packed + c.off_bias;
-            oa.y = y.p; oa.y_sb = y.sb; oa.y_sc = y.sc; oa.y_sh = y.sh;
-            oa.N = NB; oa.Cout = M; oa.OH = OH; oa.OW = OW; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
-            oa.shuffle = 0; oa.YH = OH; oa.YW = OW; oa.accumulate = 0;
-            ex.fail(mcvc_wino3_output_launch(oa, ex.s));
+            for (int b0 = 0; b0 < NB; b0 += nbc) {
+                const int nb = NB - b0 < nbc ? NB - b0 : nbc;
+                const long long NT = (long long)nb * TH * TW, NTp = (NT + 31) & ~31LL;
+                WinoXformArgs xi{};
+                xi.x = x.p + (long long)b0 * x.sb; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv;
+                xi.N = nb; xi.C = K; xi.H = OH; xi.W = OW; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 1;
+                ex.fail(mcvc_wino3_input_phase_launch(xi, H, W, ex.s));
+                WinoGemmArgs ga{};
+                ga.a = packed + c.off_w3f; ga.a_xi = c.w3f_xi; ga.lda = c.cout_pk;
+                ga.b = ex.wv; ga.b_xi = (long long)K * NTp; ga.ldb = (int)NTp;
+                ga.c = ex.wm; ga.c_xi = (long long)M * NTp; ga.ldc = (int)NTp;
+                ga.M = M; ga.N = (int)NTp; ga.K = K; ga.nxi = 16;
+                ex.fail(mcvc_wino_gemm_launch(ga, ex.s));
+                WinoOutArgs oa{};
+                oa.m = ex.wm; oa.bias = packed + c.off_bias;
+                oa.y = y.p + (long long)b0 * y.sb; oa.y_sb = y.sb; oa.y_sc = y.sc; oa.y_sh = y.sh;
+                oa.N = nb; oa.Cout = M; oa.OH = OH; oa.OW = OW; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
+                oa.shuffle = 0; oa.YH = OH; oa.YW = OW; oa.accumulate = 0;
+                ex.fail(mcvc_wino3_output_launch(oa, ex.s));
+            }
             return;
         }
     }
@@ -354,31 +415,54 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
     if (conv_wino(ex, c, packed, 1, NB, H, W, dy, dx, 0, accumulate)) { if (nsplit) *nsplit = 1; return; }
     const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
     const int st = c.stride;
+    if (sgemm_applies(c, NB, H, W) && (ex.dry || ex.params)) {
+        const int P = OH * OW, K9 = 9 * c.Cin;
+        const long long NT = (long long)NB * P;
+        if (ex.dry) { sgemm_want(ex, K9 * NT); if (nsplit) *nsplit = 1; return; }
+        if (ex.sg && K9 * NT <= ex.sg_cap && dy.sh == OW && dy.sc == P && ex.params[c.wi[0]] && (c.nbr == 1 || ex.params[c.wi[1]])) {
+            SGemmArgs g{};
+            g.a = ex.params[c.wi[0]]; g.lda = K9;                                                      // W[co][k]: the OIHW tensors themselves
+            if (c.nbr == 2) { g.a2 = ex.params[c.wi[1]]; g.k_split = c.Cout; }                         // (value | gate rows)
+            g.b = dy.p; g.ldb = dy.sc; g.bseg = P; g.b_sn = dy.sb;                                      // dY[co][n] read in place
+            g.c = ex.sg; g.ldc = NT; g.cseg = (int)NT; g.c_sn = 0;                                       // dXcol[k][n]
+            g.M = K9; g.N = (int)NT; g.K = c.cout_tot; g.nsplit = 1;
+            ex.fail(mcvc_sgemm_launch(g, ex.s));
+            StageArgs sa{dx.p, dx.sb, dx.sc, dx.sh, NB, c.Cin, H, W, OH, OW, ex.sg, NT, 0};
+            ex.fail(mcvc_col2im_s2_launch(sa, accumulate, ex.s));
+            if (nsplit) *nsplit = 1;
+            return;
+        }
+    }
     if (c.wino3 && wino_enabled() && ex.wv) {
         // merged stride-2 data-gradient = a 3x3 stride-1 conv over dY with 4*Cin output channels: Winograd F(2x2,3x3)
         static const int en = [] { const char* e = getenv("MCVC_WINO3"); return e ? atoi(e) : 1; }();
         const int K = c.cout_tot, M = 4 * c.Cin;
         const int TH = (OH + 1) / 2, TW = (OW + 1) / 2;
-        const long long NT = (long long)NB * TH * TW, NTp = (NT + 31) & ~31LL;
-        if (en && NT <= 16384 && NTp >= 64 && 16LL * (K > M ? K : M) * NTp <= ex.wino_cap && (H + 1) / 2 == OH && (W + 1) / 2 == OW) {
+        const int nbc = wino_chunk(NB, (long long)TH * TW);
+        const long long NTc = wino_chunk_tiles(NB, (long long)TH * TW);
+        if (en && nbc && NTc >= 64 && 16LL * (K > M ? K : M) * NTc <= ex.wino_cap && (H + 1) / 2 == OH && (W + 1) / 2 == OW) {
             if (nsplit) *nsplit = 1;
             if (ex.dry) return;
-            WinoXformArgs xi{};
-            xi.x = dy.p; xi.x_sb = dy.sb; xi.x_sc = dy.sc; xi.x_sh = dy.sh; xi.v = ex.wv;
-            xi.N = NB; xi.C = K; xi.H = OH; xi.W = OW; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 1;
-            ex.fail(mcvc_wino3_input_launch(xi, ex.s));
-            WinoGemmArgs ga{};
-            ga.a = packed + c.off_w3; ga.a_xi = c.w3_xi; ga.lda = c.mg_ld;
-            ga.b = ex.wv; ga.b_xi = (long long)K * NTp; ga.ldb = (int)NTp;
-            ga.c = ex.wm; ga.c_xi = (long long)M * NTp; ga.ldc = (int)NTp;
-            ga.M = M; ga.N = (int)NTp; ga.K = K; ga.nxi = 16;
-            ex.fail(mcvc_wino_gemm_launch(ga, ex.s));
-            WinoOutArgs oa{};
-            oa.m = ex.wm; oa.bias = nullptr;
-            oa.y = dx.p; oa.y_sb = dx.sb; oa.y_sc = dx.sc; oa.y_sh = dx.sh;
-            oa.N = NB; oa.Cout = M; oa.OH = OH; oa.OW = OW; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
-            oa.shuffle = 1; oa.YH = H; oa.YW = W; oa.accumulate = accumulate;
-            ex.fail(mcvc_wino3_output_launch(oa, ex.s));
+            for (int b0 = 0; b0 < NB; b0 += nbc) {
+                const int nb = NB - b0 < nbc ? NB - b0 : nbc;
+                const long long NT = (long long)nb * TH * TW, NTp = (NT + 31) & ~31LL;
+                WinoXformArgs xi{};
+                xi.x = dy.p + (long long)b0 * dy.sb; xi.x_sb = dy.sb; xi.x_sc = dy.sc; xi.x_sh = dy.sh; xi.v = ex.wv;
+                xi.N = nb; xi.C = K; xi.H = OH; xi.W = OW; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 1;
+                ex.fail(mcvc_wino3_input_launch(xi, ex.s));
+                WinoGemmArgs ga{};
+                ga.a = packed + c.off_w3; ga.a_xi = c.w3_xi; ga.lda = c.mg_ld;
+                ga.b = ex.wv; ga.b_xi = (long long)K * NTp; ga.ldb = (int)NTp;
+                ga.c = ex.wm; ga.c_xi = (long long)M * NTp; ga.ldc = (int)NTp;
+                ga.M = M; ga.N = (int)NTp; ga.K = K; ga.nxi = 16;
+                ex.fail(mcvc_wino_gemm_launch(ga, ex.s));
+                WinoOutArgs oa{};
+                oa.m = ex.wm; oa.bias = nullptr;
+                oa.y = dx.p + (long long)b0 * dx.sb; oa.y_sb = dx.sb; oa.y_sc = dx.sc; oa.y_sh = dx.sh;
+                oa.N = nb; oa.Cout = M; oa.OH = OH; oa.OW = OW; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
+                oa.shuffle = 1; oa.YH = H; oa.YW = W; oa.accumulate = accumulate;
+                ex.fail(mcvc_wino3_output_launch(oa, ex.s));
+            }
             return;
         }
     }
@@ -433,12 +517,39 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
 {
     const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
     ConvProblem p{c.Cin, H, W, c.Cout, OH, OW, c.KH, c.KW, c.stride, c.ph, c.pw};
+    // large-batch GEMM form of the strided 3x3 layers (sgemm.h): pixel-major operands, K-split slabs, then dw += slabs
+    int sg_split = 1; long long sg_rows = 0;
+    const bool sg = sgemm_applies(c, NB, H, W) && !ex.s2;
+    if (sg) {
+        const int tiles = (c.cout_tot / 64) * (9 * c.Cin / 64);
+        while (sg_split < 8 && tiles * sg_split < 512) sg_split *= 2;
+        const long long unit = 32LL * sg_split, NT = (long long)NB * OH * OW;
+        sg_rows = (NT + unit - 1) / unit * unit;
+    }
+    const long long sg_floats = sg ? sg_rows * (9LL * c.Cin + c.cout_tot) + (long long)sg_split * c.cout_tot * 9 * c.Cin : 0;
     if (ex.dry) {          // K-split slabs: their own region, so they never alias the data-gradient slabs of the main stream
+        if (sg) sgemm_want(ex, sg_floats);                 // (and the direct kernel's slabs: a pass with an auxiliary stream takes that path)
         const long long need = mcvc_wgrad_plan_slab_floats(p, NB);
         if (need > ex.wslab_need) ex.wslab_need = need;
         return;
     }
     if (!grads) return;
+    if (sg && ex.sg && sg_floats <= ex.sg_cap && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]])) {
+        const int K9 = 9 * c.Cin;
+        float* xt = ex.sg; float* dyt = xt + sg_rows * K9; float* slabs = dyt + sg_rows * c.cout_tot;
+        StageArgs sx{x.p, x.sb, x.sc, x.sh, NB, c.Cin, H, W, OH, OW, xt, K9, (int)sg_rows};
+        ex.fail(mcvc_im2col_s2_t_launch(sx, ex.s));
+        StageArgs sy{dy.p, dy.sb, dy.sc, dy.sh, NB, c.cout_tot, OH, OW, OH, OW, dyt, c.cout_tot, (int)sg_rows};
+        ex.fail(mcvc_planes_t_launch(sy, ex.s));
+        SGemmArgs g{};
+        g.a = dyt; g.lda = c.cout_tot;                                        // dYt[n][co]
+        g.b = xt; g.ldb = K9; g.bseg = K9; g.b_sn = 0;                        // XcolT[n][k]
+        g.c = slabs; g.ldc = K9; g.cseg = K9; g.c_sn = 0; g.c_split = (long long)c.cout_tot * K9;
+        g.M = c.cout_tot; g.N = K9; g.K = (int)sg_rows; g.nsplit = sg_split;
+        ex.fail(mcvc_sgemm_launch(g, ex.s));
+        ex.fail(mcvc_dw_accum_launch(slabs, sg_split, g.c_split, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.cout_tot, K9, ex.s));
+        return;
+    }
     hipStream_t ws = ex.s;
     if (ex.s2) {           // dY (and x) are complete on the main stream at this point
         hipEvent_t e = pool_event();
@@ -451,24 +562,29 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         // Winograd weight gradient: dU[xi] = dM[xi] V[xi]^T over the tiles, then dW += G^T dU G.  Operands tile-major.
         static const int en = [] { const char* e = getenv("MCVC_WINO_WGRAD"); return e ? atoi(e) : 1; }();
         const int TH = (H + 1) / 2, TW = (W + 1) / 2;
-        const long long NT = (long long)NB * TH * TW, NTp = (NT + 31) & ~31LL;
-        if (en && NT <= 16384 && (c.Cout % 128) == 0 && (c.Cin % 64) == 0 && 36LL * NTp * c.Cout <= ex.wino_cap && 36LL * NTp * c.Cin <= ex.wino_cap &&
+        const int nbc = wino_chunk(NB, (long long)TH * TW);
+        const long long NTc = wino_chunk_tiles(NB, (long long)TH * TW);
+        if (en && nbc && (c.Cout % 128) == 0 && (c.Cin % 64) == 0 && 36LL * NTc * c.Cout <= ex.wino_cap && 36LL * NTc * c.Cin <= ex.wino_cap &&
             36LL * c.Cout * c.Cin <= ex.wu_cap) {
-            WinoXformArgs xi{};
-            xi.x = x.p; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv2;
-            xi.N = NB; xi.C = c.Cin; xi.H = H; xi.W = W; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 2;
-            ex.fail(mcvc_wino_input_t_launch(xi, ws));
-            WinoXformArgs di{};
-            di.x = dy.p; di.x_sb = dy.sb; di.x_sc = dy.sc; di.x_sh = dy.sh; di.v = ex.wm2;
-            di.N = NB; di.C = c.Cout; di.H = H; di.W = W; di.TH = TH; di.TW = TW; di.NT = (int)NT; di.NTp = (int)NTp; di.pad = 0;
-            ex.fail(mcvc_wino_dy_t_launch(di, ws));
-            WinoGemmArgs ga{};
-            ga.a = ex.wm2; ga.a_xi = NTp * c.Cout; ga.lda = c.Cout;          // dMt[xi][tile][co]
-            ga.b = ex.wv2; ga.b_xi = NTp * c.Cin; ga.ldb = c.Cin;            // Vt[xi][tile][ci]
-            ga.c = ex.wu; ga.c_xi = (long long)c.Cout * c.Cin; ga.ldc = c.Cin;
-            ga.M = c.Cout; ga.N = c.Cin; ga.K = (int)NTp;
-            ex.fail(mcvc_wino_gemm_launch(ga, ws));
-            ex.fail(mcvc_wino_dw_launch(ex.wu, grads[c.wi[0]], c.Cout, c.Cin, ws));
+            for (int b0 = 0; b0 < NB; b0 += nbc) {
+                const int nb = NB - b0 < nbc ? NB - b0 : nbc;
+                const long long NT = (long long)nb * TH * TW, NTp = (NT + 31) & ~31LL;
+                WinoXformArgs xi{};
+                xi.x = x.p + (long long)b0 * x.sb; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv2;
+                xi.N = nb; xi.C = c.Cin; xi.H = H; xi.W = W; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 2;
+                ex.fail(mcvc_wino_input_t_launch(xi, ws));
+                WinoXformArgs di{};
+                di.x = dy.p + (long long)b0 * dy.sb; di.x_sb = dy.sb; di.x_sc = dy.sc; di.x_sh = dy.sh; di.v = ex.wm2;
+                di.N = nb; di.C = c.Cout; di.H = H; di.W = W; di.TH = TH; di.TW = TW; di.NT = (int)NT; di.NTp = (int)NTp; di.pad = 0;
+                ex.fail(mcvc_wino_dy_t_launch(di, ws));
+                WinoGemmArgs ga{};
+                ga.a = ex.wm2; ga.a_xi = NTp * c.Cout; ga.lda = c.Cout;          // dMt[xi][tile][co]
+                ga.b = ex.wv2; ga.b_xi = NTp * c.Cin; ga.ldb = c.Cin;            // Vt[xi][tile][ci]
+                ga.c = ex.wu; ga.c_xi = (long long)c.Cout * c.Cin; ga.ldc = c.Cin;
+                ga.M = c.Cout; ga.N = c.Cin; ga.K = (int)NTp;
+                ex.fail(mcvc_wino_gemm_launch(ga, ws));
+                ex.fail(mcvc_wino_dw_launch(ex.wu, grads[c.wi[0]], c.Cout, c.Cin, ws));      // dW += G^T dU G: the chunks add up
+            }
             done = true;
         }
     }
@@ -478,24 +594,29 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         static const int en = [] { const char* e = getenv("MCVC_WINO3_WGRAD"); return e ? atoi(e) : 1; }();
         const int K4 = 4 * c.Cin, M = c.cout_tot;
         const int TH = (OH + 1) / 2, TW = (OW + 1) / 2;
-        const long long NT = (long long)NB * TH * TW, NTp = (NT + 31) & ~31LL;
-        if (en && NT <= 16384 && (M % 128) == 0 && (K4 % 64) == 0 && 16LL * NTp * M <= ex.wino_cap && 16LL * NTp * K4 <= ex.wino_cap &&
+        const int nbc = wino_chunk(NB, (long long)TH * TW);
+        const long long NTc = wino_chunk_tiles(NB, (long long)TH * TW);
+        if (en && nbc && (M % 128) == 0 && (K4 % 64) == 0 && 16LL * NTc * M <= ex.wino_cap && 16LL * NTc * K4 <= ex.wino_cap &&
             16LL * M * K4 <= ex.wu_cap) {
-            WinoXformArgs xi{};
-            xi.x = x.p; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv2;
-            xi.N = NB; xi.C = K4; xi.H = OH; xi.W = OW; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 1;
-            ex.fail(mcvc_wino3_input_phase_t_launch(xi, H, W, ws));
-            WinoXformArgs di{};
-            di.x = dy.p; di.x_sb = dy.sb; di.x_sc = dy.sc; di.x_sh = dy.sh; di.v = ex.wm2;
-            di.N = NB; di.C = M; di.H = OH; di.W = OW; di.TH = TH; di.TW = TW; di.NT = (int)NT; di.NTp = (int)NTp; di.pad = 0;
-            ex.fail(mcvc_wino3_dy_t_launch(di, ws));
-            WinoGemmArgs ga{};
-            ga.a = ex.wm2; ga.a_xi = NTp * M; ga.lda = M;
-            ga.b = ex.wv2; ga.b_xi = NTp * K4; ga.ldb = K4;
-            ga.c = ex.wu; ga.c_xi = (long long)M * K4; ga.ldc = K4;
-            ga.M = M; ga.N = K4; ga.K = (int)NTp; ga.nxi = 16;
-            ex.fail(mcvc_wino_gemm_launch(ga, ws));
-            ex.fail(mcvc_wino3_dw_launch(ex.wu, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.nbr, c.Cin, ws));
+            for (int b0 = 0; b0 < NB; b0 += nbc) {
+                const int nb = NB - b0 < nbc ? NB - b0 : nbc;
+                const long long NT = (long long)nb * TH * TW, NTp = (NT + 31) & ~31LL;
+                WinoXformArgs xi{};
+                xi.x = x.p + (long long)b0 * x.sb; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv2;
+                xi.N = nb; xi.C = K4; xi.H = OH; xi.W = OW; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 1;
+                ex.fail(mcvc_wino3_input_phase_t_launch(xi, H, W, ws));
+                WinoXformArgs di{};
+                di.x = dy.p + (long long)b0 * dy.sb; di.x_sb = dy.sb; di.x_sc = dy.sc; di.x_sh = dy.sh; di.v = ex.wm2;
+                di.N = nb; di.C = M; di.H = OH; di.W = OW; di.TH = TH; di.TW = TW; di.NT = (int)NT; di.NTp = (int)NTp; di.pad = 0;
+                ex.fail(mcvc_wino3_dy_t_launch(di, ws));
+                WinoGemmArgs ga{};
+                ga.a = ex.wm2; ga.a_xi = NTp * M; ga.lda = M;
+                ga.b = ex.wv2; ga.b_xi = NTp * K4; ga.ldb = K4;
+                ga.c = ex.wu; ga.c_xi = (long long)M * K4; ga.ldc = K4;
+                ga.M = M; ga.N = K4; ga.K = (int)NTp; ga.nxi = 16;
+                ex.fail(mcvc_wino_gemm_launch(ga, ws));
+                ex.fail(mcvc_wino3_dw_launch(ex.wu, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.nbr, c.Cin, ws));
+            }
             done = true;
         }
     }
@@ -903,9 +1024,9 @@ static GenScratch gen_scratch(const GenDims& d)
     s.dtx3 = take(mcvc_wgrad_smallk_batch_applies(d.B, d.W4) ? 6LL * 256 * d.B * d.W4 : 0);
     // Winograd V / M of upSample1 (1024 ch, tiles of a 20 x W4 image) and upSample2 (512 ch, 40 x 2*W4)
     {
-        const long long nt1 = ((long long)d.B * 10 * ((d.W4 + 1) / 2) + 31) & ~31LL, nt2 = ((long long)d.B * 20 * ((d.Wu1 + 1) / 2) + 31) & ~31LL;
-        // (beyond 16384 tiles the layers fall back to the direct kernels -- conv_wino / conv_wgrad -- and need no scratch)
-        const long long a1 = nt1 <= 16384 ? 36LL * 1024 * nt1 : 0, a2 = nt2 <= 16384 ? 36LL * 512 * nt2 : 0;
+        // (a batch beyond kWinoMaxTiles tiles runs in chunks of samples: the workspaces are sized for one chunk)
+        const long long nt1 = wino_chunk_tiles(d.B, 10LL * ((d.W4 + 1) / 2)), nt2 = wino_chunk_tiles(d.B, 20LL * ((d.Wu1 + 1) / 2));
+        const long long a1 = 36LL * 1024 * nt1, a2 = 36LL * 512 * nt2;
         s.wino_floats = wino_enabled() ? (a1 > a2 ? a1 : a2) : 0;
         s.wv = take(s.wino_floats); s.wm = take(s.wino_floats);
         s.wv2 = take(s.wino_floats); s.wm2 = take(s.wino_floats);
@@ -1251,6 +1372,7 @@ static DiscScratch disc_scratch(const DiscDims& d)
 
 static void disc_forward_impl(Exec& ex, const float* const* P, const float* packed, const float* x, float* out, float* st, const DiscDims& d)
 {
+    ex.params = P;
     const DiscNet& n = disc_net();
     const DiscStash o = disc_stash(d);
     const int B = d.B, T = d.T;
@@ -1278,6 +1400,7 @@ static void disc_forward_impl(Exec& ex, const float* const* P, const float* pack
 static void disc_backward_impl(Exec& ex, const float* const* P, const float* packed, float* const* G, const float* dout, int is_logit_grad,
                                float* dx, int accumulate_dx, const float* stc, float* sc, const DiscDims& d)
 {
+    ex.params = P;
     const DiscNet& n = disc_net();
     const DiscStash o = disc_stash(d);
     const DiscScratch q = disc_scratch(d);
@@ -1331,7 +1454,7 @@ static void disc_backward_impl(Exec& ex, const float* const* P, const float* pac
     join_aux(ex);
 }
 
-struct Needs { long long slab, wslab; };
+struct Needs { long long slab, wslab, sg; };
 
 // split of the scratch tail into [conv slabs | wgrad slabs]: from a dry run of the schedule, cached per (net, B, T)
 template <class F>
@@ -1347,7 +1470,7 @@ static Needs cached_needs(int kind, int B, int T, F&& dry_run)
     }
     Exec ex{}; ex.dry = true;
     dry_run(ex);
-    Needs n{(ex.slab_need + 3) & ~3LL, (ex.wslab_need + 3) & ~3LL};
+    Needs n{(ex.slab_need + 3) & ~3LL, (ex.wslab_need + 3) & ~3LL, (ex.sg_need + 3) & ~3LL};
     std::lock_guard<std::mutex> lk(mu);
     cache[key] = n;
     return n;
@@ -1359,8 +1482,10 @@ static Exec make_exec(void* stream, void* aux_stream, float* scratch, long long 
     ex.s = (hipStream_t)stream; ex.s2 = (hipStream_t)aux_stream; ex.dry = false; ex.err = 0;
     ex.slabs = scratch + slab_off;
     ex.slab_cap = nd.slab;
-    ex.wslabs = scratch + slab_off + nd.slab;
-    ex.wslab_cap = scratch_floats - slab_off - nd.slab;
+    ex.sg = nd.sg ? scratch + slab_off + nd.slab : nullptr;
+    ex.sg_cap = nd.sg;
+    ex.wslabs = scratch + slab_off + nd.slab + nd.sg;
+    ex.wslab_cap = scratch_floats - slab_off - nd.slab - nd.sg;
     return ex;
 }
 
@@ -1407,7 +1532,7 @@ long long mcvc_gen_stash_floats(int B, int T) { return gen_stash(gen_dims(B, T))
 long long mcvc_gen_scratch_floats(int B, int T)
 {
     const Needs nd = gen_needs(B, T);
-    return gen_scratch(gen_dims(B, T)).slabs + nd.slab + nd.wslab + 64;
+    return gen_scratch(gen_dims(B, T)).slabs + nd.slab + nd.sg + nd.wslab + 64;
 }
 
 long long mcvc_disc_stash_floats(int B, int T)
@@ -1419,7 +1544,7 @@ long long mcvc_disc_stash_floats(int B, int T)
 long long mcvc_disc_scratch_floats(int B, int T)
 {
     const Needs nd = disc_needs(B, T);
-    return disc_scratch(disc_dims(B, T)).slabs + nd.slab + nd.wslab + 64;
+    return disc_scratch(disc_dims(B, T)).slabs + nd.slab + nd.sg + nd.wslab + 64;
 }
 
 int mcvc_gen_pack(const float* const* params, float* packed, void* stream)

@@ -1,0 +1,293 @@
+// Staged-GEMM path of the discriminators' stride-2 3x3 convolutions at large batch: see sgemm.h.
+#include "sgemm.h"
+#include "mcvc_common.h"
+#include "trace.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void glds16(const float* g, float* l)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
+
+// C = A^T B on 64 x 64 tiles, 32-deep stages, 4-stage LDS-DMA pipeline (global_load_lds, explicit vmcnt), v_mfma_f32_32x32x2_f32:
+// the pipeline of gemm2_kernel<64,64,32,4> (wino_kernels.hip) with generalised operand addressing -- two A sources along K (the value
+// and gate weight tensors), column-segmented B and C (image layouts [b][c][p] read / written in place), bias, and a K-split grid axis.
+constexpr int BM = 64, BN = 64, GK = 32, ST = 4;
+constexpr int SA = GK * BM, SB = GK * BN, STAGE = SA + SB;
+constexpr int NA = SA / 4 / 256, NBI = SB / 4 / 256, ND = NA + NBI;          // DMA instructions per wave and stage (2 + 2)
+
+__global__ void __launch_bounds__(256) sgemm_kernel(const SGemmArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    int lid;
+    {   // consecutive tiles (same A panel) on the same XCD: they share its L2
+        const int total = (int)gridDim.x, linear = (int)blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = linear & 7, k = linear >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int n0 = (lid % a.nt) * BN; lid /= a.nt;
+    const int m0 = (lid % a.mt) * BM;
+    const int ks = lid / a.mt;
+    const int Kc = a.K / a.nsplit;
+    const int kbase = ks * Kc;
+    long long aoff[NA], boff[NBI]; int adst[NA], bdst[NBI];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int f = tid + i * 256;
+        aoff[i] = (long long)(f / (BM / 4)) * a.lda + m0 + 4 * (f % (BM / 4));
+        adst[i] = (wave * 64 + i * 256) * 4;                       // wave-uniform LDS base (float index) of this instruction
+    }
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+        const int f = tid + i * 256;
+        int n = n0 + 4 * (f % (BN / 4));
+        if (n > a.N - 4) n = a.N - 4;                              // columns past N: any valid address (masked at the store)
+        boff[i] = (long long)(f / (BN / 4)) * a.ldb + (long long)(n / a.bseg) * a.b_sn + (n % a.bseg);
+        bdst[i] = SA + (wave * 64 + i * 256) * 4;
+    }
+    auto issue = [&](int stage_k, int buf) {
+        float* base = smem + buf * STAGE;
+        const int k0 = kbase + stage_k * GK;
+        const float* ab = (k0 < a.k_split) ? a.a + (long long)k0 * a.lda : a.a2 + (long long)(k0 - a.k_split) * a.lda;
+        const float* bb = a.b + (long long)k0 * a.ldb;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) glds16(ab + aoff[i], base + adst[i]);
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) glds16(bb + boff[i], base + bdst[i]);
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nst = Kc / GK;
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s)
+        if (s < nst) issue(s, s);
+    const int a_lane = half * BM + wm * 32 + l31;                  // A[k = 2p + half][m]
+    const int b_lane = SA + half * BN + wn * 32 + l31;             // B[k = 2p + half][n]
+    for (int st = 0; st < nst; ++st) {
+        const int newer = (nst - 1 - st) < (ST - 2) ? (nst - 1 - st) : (ST - 2);
+        if (newer >= 2) wait_vm<2 * ND>(); else if (newer == 1) wait_vm<ND>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (st + ST - 1 < nst) issue(st + ST - 1, (st + ST - 1) % ST);
+        const float* sb = smem + (st % ST) * STAGE;
+        float a0 = sb[a_lane], b0 = sb[b_lane];
+#pragma unroll
+        for (int p = 0; p < GK / 2; ++p) {
+            const int q = (p + 1 < GK / 2) ? p + 1 : p;
+            const float na0 = sb[a_lane + q * 2 * BM], nb0 = sb[b_lane + q * 2 * BN];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            a0 = na0; b0 = nb0;
+        }
+    }
+    const int n = n0 + wn * 32 + l31;
+    if (n < a.N) {
+        const long long coff = (long long)(n / a.cseg) * a.c_sn + (n % a.cseg) + (long long)ks * a.c_split;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* row = (m < a.m_split) ? a.c + (long long)m * a.ldc : a.c2 + (long long)(m - a.m_split) * a.ldc;
+            row[coff] = a.bias ? acc[r] + a.bias[m] : acc[r];
+        }
+    }
+}
+
+// ---- staging ----------------------------------------------------------------------------------------------------------------
+// tap (kh, kw) of output pixel (oh, ow) reads x[2*oh + kh - 1][2*ow + kw - 1]
+__global__ void __launch_bounds__(256) im2col_s2_kernel(const StageArgs a)
+{
+    const int P = a.OH * a.OW;
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int ci = blockIdx.y;
+    if (n >= (long long)a.NB * P) return;
+    const int b = (int)(n / P), p = (int)(n - (long long)b * P);
+    const int oh = p / a.OW, ow = p - oh * a.OW;
+    const float* xp = a.x + (long long)b * a.x_sb + (long long)ci * a.x_sc;
+    float* o = a.out + (long long)ci * 9 * a.ld + n;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = 2 * oh + kh - 1;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iw = 2 * ow + kw - 1;
+            const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+            o[(long long)(3 * kh + kw) * a.ld] = ok ? xp[(long long)ih * a.x_sh + iw] : 0.f;
+        }
+    }
+}
+
+// XcolT[n][9*ci + tap]: 32 pixels x 32 channels per workgroup through LDS (reads along pixels, writes along k)
+__global__ void __launch_bounds__(256) im2col_s2_t_kernel(const StageArgs a)
+{
+    __shared__ float tile[32][32 * 9 + 1];
+    const int P = a.OH * a.OW;
+    const long long NT = (long long)a.NB * P;
+    const long long n0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int nl = threadIdx.x & 31, cw = threadIdx.x >> 5;        // 8 channel rows per sweep
+    const long long n = n0 + nl;
+    const bool live = n < NT;
+    int b = 0, oh = 0, ow = 0;
+    if (live) { b = (int)(n / P); const int p = (int)(n - (long long)b * P); oh = p / a.OW; ow = p - oh * a.OW; }
+    for (int cl = cw; cl < 32; cl += 8) {
+        const int ci = c0 + cl;
+        const float* xp = a.x + (long long)b * a.x_sb + (long long)ci * a.x_sc;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = 2 * oh + kh - 1;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = 2 * ow + kw - 1;
+                const bool ok = live && ci < a.C && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
+                tile[nl][cl * 9 + 3 * kh + kw] = ok ? xp[(long long)ih * a.x_sh + iw] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    const int kmax = (a.C - c0 < 32 ? a.C - c0 : 32) * 9;
+    for (int e = threadIdx.x; e < 32 * 288; e += 256) {
+        const int r = e / 288, k = e - r * 288;
+        if (n0 + r < a.rows_pad && k < kmax) a.out[(n0 + r) * a.ld + (long long)c0 * 9 + k] = tile[r][k];
+    }
+}
+
+// Yt[n][c] from y[b][c][p]
+__global__ void __launch_bounds__(256) planes_t_kernel(const StageArgs a)
+{
+    __shared__ float tile[32][33];
+    const int P = a.H * a.W;
+    const long long NT = (long long)a.NB * P;
+    const long long n0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long long n = n0 + tx;
+    int b = 0, p = 0;
+    if (n < NT) { b = (int)(n / P); p = (int)(n - (long long)b * P); }
+    const int h = p / a.W, w = p - h * a.W;
+    for (int cl = ty; cl < 32; cl += 8) {
+        const int c = c0 + cl;
+        tile[cl][tx] = (n < NT && c < a.C) ? a.x[(long long)b * a.x_sb + (long long)c * a.x_sc + (long long)h * a.x_sh + w] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (n0 + r < a.rows_pad && c0 + tx < a.C) a.out[(n0 + r) * a.ld + c0 + tx] = tile[tx][r];
+}
+
+// dx[b][ci][ih][iw] (=|+=) the taps that reach it: kh = ih + 1 - 2*oh in [0, 3)
+__global__ void __launch_bounds__(256) col2im_s2_kernel(const StageArgs a, int accumulate)
+{
+    const int HW = a.H * a.W, P = a.OH * a.OW;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int ci = blockIdx.y;
+    if (e >= (long long)a.NB * HW) return;
+    const int b = (int)(e / HW), q = (int)(e - (long long)b * HW);
+    const int ih = q / a.W, iw = q - ih * a.W;
+    const float* col = a.out + (long long)ci * 9 * a.ld + (long long)b * P;
+    float s = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int t = ih + 1 - kh;
+        if (t < 0 || (t & 1)) continue;
+        const int oh = t >> 1;
+        if (oh >= a.OH) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int u = iw + 1 - kw;
+            if (u < 0 || (u & 1)) continue;
+            const int ow = u >> 1;
+            if (ow >= a.OW) continue;
+            s += col[(long long)(3 * kh + kw) * a.ld + oh * a.OW + ow];
+        }
+    }
+    float* d = const_cast<float*>(a.x) + (long long)b * a.x_sb + (long long)ci * a.x_sc + (long long)ih * a.x_sh + iw;
+    *d = accumulate ? *d + s : s;
+}
+
+__global__ void __launch_bounds__(256) dw_accum_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride, float* __restrict__ g0,
+                                                       float* __restrict__ g1, int Cout, int rows, int K9)
+{
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= (long long)rows * K9) return;
+    float4 s = *reinterpret_cast<const float4*>(slabs + i);
+    for (int k = 1; k < nslab; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(slabs + (long long)k * slab_stride + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const long long split = (long long)Cout * K9;
+    float4* d = reinterpret_cast<float4*>(i < split ? g0 + i : g1 + (i - split));
+    float4 o = *d;
+    o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+    *d = o;
+}
+
+}  // namespace
+
+int mcvc_sgemm_launch(const SGemmArgs& a0, hipStream_t s)
+{
+    SGemmArgs a = a0;
+    if (a.nsplit < 1) a.nsplit = 1;
+    if ((a.M % BM) != 0 || (a.K % (GK * a.nsplit)) != 0 || (a.N & 3) || a.N < 4 || (a.lda & 3) || (a.ldb & 3) || (a.bseg & 3) || (a.b_sn & 3) ||
+        a.bseg < 4 || a.cseg < 1)
+        return MCVC_ERR_INVALID;
+    if (!a.a2) { a.a2 = a.a; a.k_split = a.K; }
+    if (!a.c2) { a.c2 = a.c; a.m_split = a.M; }
+    a.nt = cdiv_i(a.N, BN); a.mt = a.M / BM;
+    constexpr size_t lds = (size_t)ST * STAGE * sizeof(float);
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sgemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    TraceScope ts(K_SGEMM, s, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.K * a.M + (double)a.K * a.N + (double)a.M * a.N * a.nsplit));
+    hipLaunchKernelGGL(sgemm_kernel, dim3((unsigned)(a.nt * a.mt * a.nsplit)), dim3(256), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_im2col_s2_launch(const StageArgs& a, hipStream_t s)
+{
+    const long long NT = (long long)a.NB * a.OH * a.OW;
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.NB * a.C * a.H * a.W + 9.0 * a.C * NT));
+    hipLaunchKernelGGL(im2col_s2_kernel, dim3((unsigned)((NT + 255) / 256), (unsigned)a.C), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_im2col_s2_t_launch(const StageArgs& a, hipStream_t s)
+{
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.NB * a.C * a.H * a.W + 9.0 * a.C * a.rows_pad));
+    hipLaunchKernelGGL(im2col_s2_t_kernel, dim3((unsigned)((a.rows_pad + 31) / 32), (unsigned)cdiv_i(a.C, 32)), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_planes_t_launch(const StageArgs& a, hipStream_t s)
+{
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.NB * a.C * a.H * a.W + (double)a.C * a.rows_pad));
+    hipLaunchKernelGGL(planes_t_kernel, dim3((unsigned)((a.rows_pad + 31) / 32), (unsigned)cdiv_i(a.C, 32)), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_col2im_s2_launch(const StageArgs& a, int accumulate, hipStream_t s)
+{
+    const long long NE = (long long)a.NB * a.H * a.W;
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((accumulate ? 2.0 : 1.0) * a.NB * a.C * a.H * a.W + 9.0 * a.C * a.NB * a.OH * a.OW));
+    hipLaunchKernelGGL(col2im_s2_kernel, dim3((unsigned)((NE + 255) / 256), (unsigned)a.C), dim3(256), 0, s, a, accumulate);
+    return (int)hipGetLastError();
+}
+
+int mcvc_dw_accum_launch(const float* slabs, int nslab, long long slab_stride, float* g0, float* g1, int Cout, int rows, int K9, hipStream_t s)
+{
+    const long long n = (long long)rows * K9;
+    if ((n & 3) || (((long long)Cout * K9) & 3) || (rows > Cout && !g1)) return MCVC_ERR_INVALID;
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * n * (nslab + 2.0));
+    hipLaunchKernelGGL(dw_accum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, slabs, nslab, slab_stride, g0, g1, Cout, rows, K9);
+    return (int)hipGetLastError();
+}

@@ -17,7 +17,7 @@ hipEvent_t get_event()
 const char* kNames[K_COUNT] = {
     "conv_direct<2,2,2,2>", "conv_direct<2,1,2,2>", "conv_direct<1,2,2,2>", "conv_direct<2,1,4,1>", "conv_direct<1,2,1,4>", "conv_direct<1,1,1,4>", "conv_direct<1,1,2,2>", "conv_fewout", "wino_gemm",
     "conv_wgrad<2,5>", "conv_wgrad<1,5>", "conv_wgrad<2,3>", "conv_wgrad<1,3>", "conv_wgrad<4,1>", "conv_wgrad<1,1>", "wgrad_smallk", "trunk_layer",
-    "norm_fwd", "norm_bwd", "act_fwd", "act_bwd", "pack", "bias_grad", "loss", "adam", "elementwise"};
+    "norm_fwd", "norm_bwd", "act_fwd", "act_bwd", "pack", "bias_grad", "loss", "adam", "elementwise", "sgemm"};
 }
 
 void mcvc_trace_begin_(int kind, hipStream_t s, double flops, double bytes)

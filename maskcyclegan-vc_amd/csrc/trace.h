@@ -7,7 +7,7 @@
 enum KernelKind {
     K_CONV_L = 0, K_CONV_M, K_CONV_N, K_CONV_T, K_CONV_S, K_CONV_S2, K_CONV_Q, K_CONV_FEW, K_WINO_GEMM,
     K_WGRAD_2x5, K_WGRAD_1x5, K_WGRAD_2x3, K_WGRAD_1x3, K_WGRAD_4x1, K_WGRAD_1x1, K_WGRAD_SMALLK, K_TRUNK,
-    K_NORM_FWD, K_NORM_BWD, K_ACT_FWD, K_ACT_BWD, K_PACK, K_BIAS_GRAD, K_LOSS, K_ADAM, K_ELEMENTWISE,
+    K_NORM_FWD, K_NORM_BWD, K_ACT_FWD, K_ACT_BWD, K_PACK, K_BIAS_GRAD, K_LOSS, K_ADAM, K_ELEMENTWISE, K_SGEMM,
     K_COUNT
 };
 

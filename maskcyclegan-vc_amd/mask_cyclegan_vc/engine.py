@@ -33,7 +33,16 @@ D_NAMES = ("discriminator_A", "discriminator_B", "discriminator_A2", "discrimina
 _DEAD = range(14, 18)          # discriminator downSample4.* slots in named_parameters() order
 
 # loss slots (device float32[16])
-SLOT_G, SLOT_D, SLOT_CYCLE, SLOT_IDENT, SLOT_ADV_G, SLOT_D_REAL, SLOT_D_FAKE = range(7)
+# loss slots: one block per phase (the discriminator phase's tail may still be writing its block while the next iteration's generator
+# phase zeroes its own): [public 4 | 8 private (weighted value, mean) pairs]
+SLOT_G, SLOT_CYCLE, SLOT_IDENT, SLOT_ADV_G = range(4)
+SLOT_D, SLOT_D_REAL, SLOT_D_FAKE = 20, 21, 22
+_BLOCK = 20
+
+
+def _pair(k):
+    """Offset of the private pair of loss call k (0..7 generator phase, 8..15 discriminator phase)."""
+    return 4 + 2 * k if k < 8 else _BLOCK + 4 + 2 * (k - 8)
 
 
 def _align4(n):
@@ -99,9 +108,9 @@ class TrainEngine:
         # ---- packed weights
         self.packed = {n: torch.zeros(L.mcvc_gen_packed_floats(), device=dev) for n in G_NAMES}
         self.packed.update({n: torch.zeros(L.mcvc_disc_packed_floats(), device=dev) for n in D_NAMES})
-        # [0, 8): the public loss slots; [8, 40): one private (weighted value, mean) pair per loss call of an iteration -- the calls run on
-        # different lanes, mcvc_loss_combine adds them to the public slots in the reference's order
-        self.slots = torch.zeros(8 + 2 * 16, device=dev)
+        # the loss calls of a phase run on different lanes, each into its private pair; mcvc_loss_combine adds them to the public slots
+        # in the reference's order
+        self.slots = torch.zeros(2 * _BLOCK, device=dev)
         ia = lambda v: (ctypes.c_int * len(v))(*v)          # noqa: E731
         self._comb_g = (8, ia([SLOT_G] * 8), ia([SLOT_CYCLE, SLOT_CYCLE, SLOT_IDENT, SLOT_IDENT] + [SLOT_ADV_G] * 4))
         self._comb_d = (8, ia([SLOT_D] * 8), ia([SLOT_D_REAL, SLOT_D_FAKE] * 4))
@@ -137,6 +146,7 @@ class TrainEngine:
         # the discriminators' weight re-pack after their Adam step is needed only ~1.5 ms later (after the next iteration's
         # four generator forwards): it runs on its own stream and the discriminator forwards wait for its event
         self._task_events = {}
+        self._timeline = None
         self._pack_stream = torch.cuda.Stream(device=dev)
         self._d_pack_event = None
         # data parallel: start the discriminator gradient all-reduce at the end of an iteration and finish the update
@@ -242,12 +252,19 @@ class TrainEngine:
         for ln in used:
             streams[ln].wait_stream(main)
         done = {}
-        for lane, fn, waits, rec in tasks:
+        for ti, (lane, fn, waits, rec) in enumerate(tasks):
             st = streams[lane]
             with torch.cuda.stream(st):
                 for w in waits:
                     st.wait_event(done[w])
-                fn(lane)
+                if self._timeline is not None:             # tools/task_timeline.py: a native (un-profiled) per-task Gantt chart
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                    fn(lane)
+                    e1.record(st)
+                    self._timeline.append((ti, lane, rec, waits, e0, e1))
+                else:
+                    fn(lane)
                 if rec is not None:
                     ev = self._task_events.get(rec)
                     if ev is None:
@@ -321,16 +338,16 @@ class TrainEngine:
 
     def _l1(self, a, b, weight, grad, k):
         """Loss call ``k`` of the iteration: value and mean go to its private pair (zeroed with the slots at the start of the iteration)."""
-        check(self.L.mcvc_l1_loss(ptr(a), ptr(b), a.numel(), float(weight), ptr(self._slot(8 + 2 * k)), ptr(self._slot(9 + 2 * k)), ptr(grad), 0,
+        check(self.L.mcvc_l1_loss(ptr(a), ptr(b), a.numel(), float(weight), ptr(self._slot(_pair(k))), ptr(self._slot(_pair(k) + 1)), ptr(grad), 0,
                                   stream()), "l1_loss")
 
     def _lsgan(self, d, target, weight, k, dlogit):
-        check(self.L.mcvc_lsgan_loss(ptr(d), d.numel(), float(target), float(weight), ptr(self._slot(8 + 2 * k)), ptr(self._slot(9 + 2 * k)),
+        check(self.L.mcvc_lsgan_loss(ptr(d), d.numel(), float(target), float(weight), ptr(self._slot(_pair(k))), ptr(self._slot(_pair(k) + 1)),
                                      ptr(dlogit), stream()), "lsgan_loss")
 
     def _combine(self, first, comb):
         n, loss_dst, term_dst = comb
-        check(self.L.mcvc_loss_combine(ptr(self._slot(8 + 2 * first)), n, loss_dst, term_dst, ptr(self.slots), stream()), "loss_combine")
+        check(self.L.mcvc_loss_combine(ptr(self._slot(_pair(first))), n, loss_dst, term_dst, ptr(self.slots), stream()), "loss_combine")
 
     def _adam(self, grp, lr):
         grp.step += 1
@@ -348,7 +365,7 @@ class TrainEngine:
         B, B2 = self.B, 2 * self.B
         m = self.mel
         sc = self.sched
-        self.slots.zero_()
+        self.slots[:_BLOCK].zero_()
         self.g_group.grad.zero_()
         # batched inputs (device-to-device copies; the batch dimension is outermost, so halves are contiguous views)
         self.in_A2B[:B].copy_(real_A); self.in_A2B[B:].copy_(real_B)
@@ -385,15 +402,15 @@ class TrainEngine:
                 self._D_bwd(name, dl[i], gx, acc, ds[i], False, B, ln)         # discriminators contribute data-gradients only
             return run
 
-        def finish_d(ln):                      # data parallel: the D gradient all-reduce of the previous iteration ran behind the
-            self._finish_d_update()            # generator forwards; the discriminators are first needed after this point
+        def finish_d(ln):                      # data parallel: the D gradient all-reduce of the previous iteration runs behind the
+            self._finish_d_update()            # generator forwards; lane 2 is the first to need the discriminators
         ov = self.overlap_g_reduce
         self._run_tasks([
             (0, lambda ln: self._G("generator_A2B", self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], B2, ln), (), "g0"),   # :203, :209-210
             (1, lambda ln: self._G("generator_B2A", self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], B2, ln), (), "g1"),   # :205, :207-208
             (0, cycle_a, (), None),
             (1, cycle_b, (), None),
-            (0, finish_d, (), None),
+            (2, finish_d, (), None),
             (2, adv("discriminator_A", 0, fake_A, g_fake_A, 0), ("g1",), "dA"),
             (3, adv("discriminator_B", 1, fake_B, g_fake_B, 0), ("g0",), "dB"),
             (0, adv("discriminator_A2", 2, m["cycle_A"], m["g_cycle_A"], 1), (), None),
@@ -429,6 +446,7 @@ class TrainEngine:
         B, B2 = self.B, 2 * self.B
         m = self.mel
         sc = self.sched
+        self.slots[_BLOCK:].zero_()
         self.d_group.grad.zero_()
         di = self.d_in
         # generators run with their UPDATED weights and no gradient (train.py:259-273); outputs land directly in the
@@ -453,7 +471,7 @@ class TrainEngine:
         # Same shape as the generator phase: lanes 0/1 carry real_B -> generated_A -> cycled_B -> D_B2 and real_A -> generated_B ->
         # cycled_A -> D_A2; D_A / D_B need only the generated batches and run on lanes 2/3 while lanes 0/1 are in the cycle forwards.
         # A lane re-packs the generator it runs first; the other lane's second pass waits for that re-pack (p0 / p1).
-        self._run_tasks([
+        gens = [
             (0, lambda ln: self._repack1("generator_B2A"), (), "p0"),
             (1, lambda ln: self._repack1("generator_A2B"), (), "p1"),
             (0, lambda ln: self._G("generator_B2A", real_B, mask_B, gen_A, self.g_stash1[0], B, ln), (), "gA"),      # :259 generated_A
@@ -462,6 +480,8 @@ class TrainEngine:
             (1, lambda ln: self._G("generator_B2A", gen_B, None, cyc_A, self.g_stash1[1], B, ln), ("p0",), None),    # :271 cycled_A
             (2, disc("discriminator_A"), ("gA",), None),
             (3, disc("discriminator_B"), ("gB",), None),
+        ]
+        self._run_tasks(gens + [
             (0, disc("discriminator_B2"), (), None),
             (1, disc("discriminator_A2"), (), None),
         ])

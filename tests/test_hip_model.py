@@ -204,3 +204,62 @@ def test_persistent_trunk_forward_is_bit_identical_to_the_per_layer_launches(B, 
             assert torch.equal(stash[0], stash[1]), it           # conv outputs, statistics, activations of every layer
     finally:
         L.mcvc_set_trunk_persistent(was)
+
+
+def _launches(kind_name, fn):
+    """Run fn() with the library's per-launch trace on; returns the number of launches of one kernel family."""
+    import ctypes
+    from mask_cyclegan_vc import _hip
+    L = _hip.lib()
+    L.mcvc_trace_kind_name.restype = ctypes.c_char_p
+    nk = L.mcvc_trace_kinds()
+    names = [L.mcvc_trace_kind_name(k).decode() for k in range(nk)]
+    buf = (ctypes.c_double * (4 * nk))()
+    torch.cuda.synchronize()
+    L.mcvc_trace_enable(1)
+    try:
+        fn()
+        L.mcvc_trace_collect(buf)
+    finally:
+        L.mcvc_trace_enable(0)
+    return int(buf[4 * names.index(kind_name)])
+
+
+@pytest.mark.parametrize("B,T", [(8, 64), (9, 64), (8, 72)])
+def test_discriminator_large_batch_gemm_path_vs_oracle(B, T, nets, meta):
+    """From 8 samples per pass the discriminators' stride-2 3x3 layers run as staged GEMMs (csrc/sgemm.h: tap planes -> batched-GEMM
+    pipeline -> gather), forward, data gradient and weight gradient: whole discriminator, every gradient, vs the CPU oracle (model.py:
+    298-349).  B = 9: a pixel count that is not a multiple of the K-split unit (zero rows); T = 72: the last strided layer's plane is
+    not a multiple of 4 and stays on the direct kernels."""
+    _, d = nets
+    dp = orc.filler_params("D", meta["filler_seeds"]["D"])
+    dn = orc.discriminator_param_names()
+    live_d = [k for k in dn if not k.startswith(orc.DISC_DEAD_PREFIX)]
+    x = torch.randn(B, 80, T, generator=torch.Generator().manual_seed(300 + B + T))
+    xr = x.clone().requires_grad_(True)
+    leaves = [xr] + [dp[k].requires_grad_(True) for k in live_d]
+    dr = orc.discriminator_forward(dp, xr)
+    w = torch.randn(dr.shape, generator=torch.Generator().manual_seed(6))
+    ref = torch.autograd.grad((dr * w).sum(), leaves)
+    xd = x.cuda().requires_grad_(True)
+    for p in d.parameters():
+        p.grad = None
+    out = {}
+
+    def run():
+        dd = d(xd)
+        (dd * w.cuda()).sum().backward()
+        out["d"] = dd
+    n_gemm = _launches("sgemm", run)
+    assert n_gemm == (9 if T == 64 else 6), n_gemm            # 3 layers (2 at T = 72) x {forward, data gradient, weight gradient}
+    assert rel_l2(out["d"], dr) < TOL
+    assert rel_l2(xd.grad, ref[0]) < TOL
+    ddict = dict(d.named_parameters())
+    worst = 0.0
+    for k, r in zip(live_d, ref[1:]):
+        if k.startswith("downSample") and k.endswith(".0.bias"):      # conv bias in front of an InstanceNorm: its exact gradient is 0,
+            assert float(ddict[k].grad.abs().max()) == 0.0            # the oracle's autograd leaves rounding noise there
+            continue
+        e = rel_l2(ddict[k].grad, r); worst = max(worst, e)
+        assert e < TOL, (k, e)
+    print("B=%d T=%d staged-GEMM discriminator: worst parameter-gradient rel-L2 vs oracle %.3e" % (B, T, worst))
