@@ -1,16 +1,15 @@
-// Strided 3x3 convolutions of the discriminators (downSample1-3, model.py:298-314) at LARGE batch as staged GEMMs.
+// Strided 3x3 convolutions of the discriminators (downSample1-3, model.py:298-314) as staged GEMMs.
 //
-// With >= 8 samples in a pass the three stride-2 layers are plain matrix products with thousands of columns, and the 64x64 / k32 LDS-DMA
-// GEMM pipeline (wino_kernels.hip) runs them at 105-120 TF/s where the direct stride-2 kernels reach 40-60 (forward), 40 (data
-// gradient) and 35-39 TF/s (weight gradient): profiles/r02_gemm_probe.log.  The operands that are not already matrices are staged
-// once per pass (tap planes of x, 2.25x its size; everything stays in HBM / MALL):
+// The three stride-2 layers are plain matrix products, and the 64x64 / k32 LDS-DMA GEMM pipeline (wino_kernels.hip) runs them at
+// 105-120 TF/s at 32+ samples per pass where the direct stride-2 kernels reach 40-60 (forward), 40 (data gradient) and 35-39 TF/s
+// (weight gradient): profiles/r02_gemm_probe.log; with a K-split it also wins at one sample per pass (13 % of the bs=1 iteration).
+// The operands that are not already matrices are staged once per pass (tap planes of x, 2.25x its size; all of it stays in HBM / MALL):
 //
 //   forward        Y[co][n]     = sum_k  Wt[k][co]  * Xcol[k][n]        k = 9*ci + 3*kh + kw, n = (b, oh, ow); + bias, stored as y[b][co][p]
 //   data gradient  dXcol[k][n]  = sum_co W[co][k]   * dY[co][n]         W = the OIHW parameter tensors themselves (value | gate rows),
 //                                                                      dY read in place ([b][co][p]); then dx[b][ci][ih][iw] gathers its <= 4 taps
 //   weight grad.   dW[co][k]    = sum_n  dYt[n][co] * XcolT[n][k]       both operands pixel-major; K-split slabs, then dw += sum of slabs
 //
-// Below that batch the products have too few columns to fill the chip and the weight-streaming direct kernels stay in charge.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,8 +22,9 @@ struct SGemmArgs {
     float* c; float* c2; int m_split; long long ldc; int cseg; long long c_sn;
     const float* bias;        // [M] added to every column, or nullptr
     int M, N, K;              // M % 64 == 0, K % (32 * nsplit) == 0, N % 4 == 0
-    int nsplit;               // K-split: split s handles rows [s*K/nsplit, (s+1)*K/nsplit) and writes C + s*c_split (k_split / m_split unused then)
-    long long c_split;
+    // K-split: split s handles rows [s*K/nsplit, (s+1)*K/nsplit); split 0 writes C (+ bias), split s > 0 writes the same layout at
+    // c_slab + (s - 1) * c_split (c2 / m_split apply to split 0 only; use them with nsplit = 1)
+    int nsplit; float* c_slab; long long c_split;
     int nt, mt;               // (filled by the launcher)
 };
 int mcvc_sgemm_launch(const SGemmArgs& a, hipStream_t s);
@@ -41,7 +41,8 @@ int mcvc_im2col_s2_launch(const StageArgs& a, hipStream_t s);
 int mcvc_im2col_s2_t_launch(const StageArgs& a, hipStream_t s);
 // Yt[n][c] from y[b][c][p] (H x W = the plane of y; OH/OW unused), ld = C
 int mcvc_planes_t_launch(const StageArgs& a, hipStream_t s);
-// dx[b][ci][ih][iw] (=|+=) sum over the taps that reach it of dXcol[9*ci + tap][n]     (x / x_* = the dx view; out = dXcol, read)
-int mcvc_col2im_s2_launch(const StageArgs& a, int accumulate, hipStream_t s);
+// dx[b][ci][ih][iw] (=|+=) sum over the taps that reach it of dXcol[9*ci + tap][n], summed over nslab K-split slabs of dXcol
+// (x / x_* = the dx view; out = dXcol, read)
+int mcvc_col2im_s2_launch(const StageArgs& a, int nslab, long long slab_stride, int accumulate, hipStream_t s);
 // g0[co][k] += sum_s slabs[s][co][k] (co < Cout), g1[co - Cout][k] += ... (co >= Cout; g1 may be null when rows == Cout)
 int mcvc_dw_accum_launch(const float* slabs, int nslab, long long slab_stride, float* g0, float* g1, int Cout, int rows, int K9, hipStream_t s);

@@ -91,10 +91,12 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SGemmArgs a)
     }
     const int n = n0 + wn * 32 + l31;
     if (n < a.N) {
-        const long long coff = (long long)(n / a.cseg) * a.c_sn + (n % a.cseg) + (long long)ks * a.c_split;
+        const long long coff = (long long)(n / a.cseg) * a.c_sn + (n % a.cseg);
+        float* const slab = ks ? a.c_slab + (long long)(ks - 1) * a.c_split : nullptr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (ks) { slab[(long long)m * a.ldc + coff] = acc[r]; continue; }
             float* row = (m < a.m_split) ? a.c + (long long)m * a.ldc : a.c2 + (long long)(m - a.m_split) * a.ldc;
             row[coff] = a.bias ? acc[r] + a.bias[m] : acc[r];
         }
@@ -183,7 +185,7 @@ __global__ void __launch_bounds__(256) planes_t_kernel(const StageArgs a)
 }
 
 // dx[b][ci][ih][iw] (=|+=) the taps that reach it: kh = ih + 1 - 2*oh in [0, 3)
-__global__ void __launch_bounds__(256) col2im_s2_kernel(const StageArgs a, int accumulate)
+__global__ void __launch_bounds__(256) col2im_s2_kernel(const StageArgs a, int nslab, long long slab_stride, int accumulate)
 {
     const int HW = a.H * a.W, P = a.OH * a.OW;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -205,7 +207,8 @@ __global__ void __launch_bounds__(256) col2im_s2_kernel(const StageArgs a, int a
             if (u < 0 || (u & 1)) continue;
             const int ow = u >> 1;
             if (ow >= a.OW) continue;
-            s += col[(long long)(3 * kh + kw) * a.ld + oh * a.OW + ow];
+            const float* cp = col + (long long)(3 * kh + kw) * a.ld + oh * a.OW + ow;
+            for (int k = 0; k < nslab; ++k) s += cp[(long long)k * slab_stride];
         }
     }
     float* d = const_cast<float*>(a.x) + (long long)b * a.x_sb + (long long)ci * a.x_sc + (long long)ih * a.x_sh + iw;
@@ -240,6 +243,7 @@ int mcvc_sgemm_launch(const SGemmArgs& a0, hipStream_t s)
         return MCVC_ERR_INVALID;
     if (!a.a2) { a.a2 = a.a; a.k_split = a.K; }
     if (!a.c2) { a.c2 = a.c; a.m_split = a.M; }
+    if (a.nsplit > 1 && !a.c_slab) return MCVC_ERR_INVALID;
     a.nt = cdiv_i(a.N, BN); a.mt = a.M / BM;
     constexpr size_t lds = (size_t)ST * STAGE * sizeof(float);
     static bool done = false;
@@ -275,11 +279,11 @@ int mcvc_planes_t_launch(const StageArgs& a, hipStream_t s)
     return (int)hipGetLastError();
 }
 
-int mcvc_col2im_s2_launch(const StageArgs& a, int accumulate, hipStream_t s)
+int mcvc_col2im_s2_launch(const StageArgs& a, int nslab, long long slab_stride, int accumulate, hipStream_t s)
 {
     const long long NE = (long long)a.NB * a.H * a.W;
-    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((accumulate ? 2.0 : 1.0) * a.NB * a.C * a.H * a.W + 9.0 * a.C * a.NB * a.OH * a.OW));
-    hipLaunchKernelGGL(col2im_s2_kernel, dim3((unsigned)((NE + 255) / 256), (unsigned)a.C), dim3(256), 0, s, a, accumulate);
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((accumulate ? 2.0 : 1.0) * a.NB * a.C * a.H * a.W + 9.0 * nslab * a.C * a.NB * a.OH * a.OW));
+    hipLaunchKernelGGL(col2im_s2_kernel, dim3((unsigned)((NE + 255) / 256), (unsigned)a.C), dim3(256), 0, s, a, nslab, slab_stride, accumulate);
     return (int)hipGetLastError();
 }
 

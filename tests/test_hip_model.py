@@ -225,12 +225,12 @@ def _launches(kind_name, fn):
     return int(buf[4 * names.index(kind_name)])
 
 
-@pytest.mark.parametrize("B,T", [(8, 64), (9, 64), (8, 72)])
-def test_discriminator_large_batch_gemm_path_vs_oracle(B, T, nets, meta):
-    """From 8 samples per pass the discriminators' stride-2 3x3 layers run as staged GEMMs (csrc/sgemm.h: tap planes -> batched-GEMM
-    pipeline -> gather), forward, data gradient and weight gradient: whole discriminator, every gradient, vs the CPU oracle (model.py:
-    298-349).  B = 9: a pixel count that is not a multiple of the K-split unit (zero rows); T = 72: the last strided layer's plane is
-    not a multiple of 4 and stays on the direct kernels."""
+@pytest.mark.parametrize("B,T", [(1, 64), (2, 64), (8, 64), (9, 64), (8, 72)])
+def test_discriminator_gemm_path_vs_oracle(B, T, nets, meta):
+    """The discriminators' stride-2 3x3 layers run as staged GEMMs (csrc/sgemm.h: tap planes -> batched-GEMM pipeline -> gather),
+    forward, data gradient and weight gradient: whole discriminator, every gradient, vs the CPU oracle (model.py:298-349).
+    B = 1, 2: K-split products whose slabs the consumers sum; B = 9: a pixel count that is not a multiple of the K-split unit (zero
+    rows); T = 72: the last strided layer's plane is not a multiple of 4 and stays on the direct kernels."""
     _, d = nets
     dp = orc.filler_params("D", meta["filler_seeds"]["D"])
     dn = orc.discriminator_param_names()
