@@ -55,7 +55,8 @@ struct Exec {
     long long wino_cap;            // floats available in each
     float* wv2; float* wm2; float* wu;   // the weight-gradient's own set (it runs on the auxiliary stream beside the dgrad): Vt, dMt, dU
     long long wu_cap;
-    float* sg; long long sg_cap, sg_need;    // staging region of the large-batch GEMM path of the strided 3x3 convs (sgemm.h)
+    float* sg; long long sg_cap, sg_need;    // staging region of the staged-GEMM convolutions (sgemm.h): forward / data gradient (main stream)
+    float* sgw; long long sgw_cap, sgw_need; // ... and the weight gradients' own (they may run on the auxiliary stream beside a data gradient)
     const float* const* params;    // the pass's parameter table (that path's data gradient multiplies the OIHW tensors themselves)
     int pack_skips;                // what the last re-pack of `packed` left stale: bit 0 = generic trunk copies, bit 1 = direct copies of the Winograd layers
     unsigned* sync;                // arrival counters of the persistent trunk kernels (MCVC_TRUNK_SYNC_WORDS words of the scratch)
@@ -329,18 +330,26 @@ static bool conv_wino(Exec& ex, const ConvSpec& c, const float* packed, int dgra
     return true;
 }
 
-// The discriminators' stride-2 3x3 layers as staged GEMMs (sgemm.h).  MCVC_SGEMM_NB = smallest batch per pass (0 = never): measured
-// at bs = 1 / 2 / 4 / 8 / 32 the GEMM form wins everywhere (7.64 vs 8.79, 12.3 vs 14.6, 20.8 vs 22.0, 35.3 vs 43.6, 132.5 vs 161.5 ms/step)
-static int sgemm_min_nb()
+// Convolutions that run as staged GEMMs on the LDS-DMA GEMM pipeline (sgemm.h):
+//   kind 1: 3x3 stride 2 padding 1 (the discriminators' downSample1-3) -- MCVC_SGEMM_NB = smallest batch per pass (0 = never): measured
+//           at bs = 1 / 2 / 4 / 8 / 32 the GEMM form wins everywhere (7.64 vs 8.79, 12.3 vs 14.6, 20.8 vs 22.0, 35.3 vs 43.6, 132.5 vs 161.5 ms/step)
+//   kind 2: 1 x KW stride 1 (KW = 1, 3) over an image of rows -- the 1-D trunk beyond the fused small-batch kernels (more than 32 columns);
+//           MCVC_SGEMM1D_COLS = smallest column count (0 = never)
+struct SgKind { int kind, taps, OH, OW; };
+static SgKind sgemm_kind(const ConvSpec& c, int NB, int H, int W)
 {
-    static const int v = [] { const char* e = getenv("MCVC_SGEMM_NB"); return e ? atoi(e) : 1; }();
-    return v;
-}
-static bool sgemm_applies(const ConvSpec& c, int NB, int H, int W)
-{
-    const int P = ((H + 1) / 2) * ((W + 1) / 2);
-    return sgemm_min_nb() > 0 && NB >= sgemm_min_nb() && c.KH == 3 && c.KW == 3 && c.stride == 2 && c.ph == 1 && c.pw == 1 && c.nbr <= 2 &&
-           (c.cout_tot % 64) == 0 && ((c.Cin * 9) % 64) == 0 && (c.Cout % 32) == 0 && c.cin_pad == c.Cin && (P % 4) == 0;
+    static const int min_nb = [] { const char* e = getenv("MCVC_SGEMM_NB"); return e ? atoi(e) : 1; }();
+    static const int min_cols = [] { const char* e = getenv("MCVC_SGEMM1D_COLS"); return e ? atoi(e) : 64; }();
+    SgKind k{0, 0, 0, 0};
+    if (c.nbr > 2 || (c.cout_tot % 64) != 0 || (c.Cout % 32) != 0 || c.cin_pad != c.Cin) return k;
+    if (c.KH == 3 && c.KW == 3 && c.stride == 2 && c.ph == 1 && c.pw == 1) {
+        k.OH = (H + 1) / 2; k.OW = (W + 1) / 2; k.taps = 9;
+        if (min_nb > 0 && NB >= min_nb && ((c.Cin * 9) % 64) == 0 && ((k.OH * k.OW) % 4) == 0) k.kind = 1;
+    } else if (c.KH == 1 && (c.KW == 1 || c.KW == 3) && c.stride == 1 && c.ph == 0 && c.pw == (c.KW - 1) / 2) {
+        k.OH = H; k.OW = W; k.taps = c.KW;
+        if (min_cols > 0 && (long long)NB * H * W >= min_cols && ((c.Cin * c.KW) % 64) == 0 && ((H * W) % 4) == 0) k.kind = 2;
+    }
+    return k;
 }
 static void sgemm_want(Exec& ex, long long floats) { if (floats > ex.sg_need) ex.sg_need = floats; }
 // K-split of a product with M x N outputs: enough 64 x 64 tiles x splits to occupy the chip, at least two 32-deep stages per split
@@ -355,21 +364,29 @@ static int sgemm_split(int M, long long N, int K)
 static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, int H, int W, CView x, View y, long long y_total,
                      int shuffle, int allow_split, int* nsplit)
 {
-    if (!shuffle && sgemm_applies(c, NB, H, W)) {
-        const int OH = (H + 1) / 2, OW = (W + 1) / 2, P = OH * OW, K9 = 9 * c.Cin;
+    const SgKind sk = shuffle ? SgKind{0, 0, 0, 0} : sgemm_kind(c, NB, H, W);
+    if (sk.kind) {
+        const int P = sk.OH * sk.OW, KT = sk.taps * c.Cin;
         const long long NT = (long long)NB * P;
-        const int sp = (allow_split && nsplit) ? sgemm_split(c.cout_tot, NT, K9) : 1;       // slabs 1.. are summed by the consumer (norm / act)
+        const bool b_in_place = sk.kind == 2 && c.KW == 1;                                   // a 1x1 conv multiplies x itself
+        const long long stage = b_in_place ? 0 : KT * NT;
+        const int sp = (allow_split && nsplit) ? sgemm_split(c.cout_tot, NT, KT) : 1;       // slabs 1.. are summed by the consumer (norm / act)
         const long long slab_need = (long long)(sp - 1) * y_total;
-        if (ex.dry) { sgemm_want(ex, K9 * NT); if (slab_need > ex.slab_need) ex.slab_need = slab_need; if (nsplit) *nsplit = sp; return; }
-        if (ex.sg && K9 * NT <= ex.sg_cap && slab_need <= ex.slab_cap && y.sh == OW && y.sc == P && y.sb == (long long)c.cout_tot * P) {
-            StageArgs sa{x.p, x.sb, x.sc, x.sh, NB, c.Cin, H, W, OH, OW, ex.sg, NT, 0};
-            ex.fail(mcvc_im2col_s2_launch(sa, ex.s));
+        if (ex.dry) { sgemm_want(ex, stage); if (slab_need > ex.slab_need) ex.slab_need = slab_need; if (nsplit) *nsplit = sp; return; }
+        if (sk.kind == 2 && (ex.pack_skips & 1) && c.off_tk >= 0) { ex.fail(MCVC_ERR_INVALID); return; }     // stale K-major copy
+        if ((b_in_place ? (x.sh == W && x.sc == P) : (ex.sg && stage <= ex.sg_cap)) && slab_need <= ex.slab_cap && y.sh == sk.OW && y.sc == P &&
+            (NB == 1 || y.sb == (long long)c.cout_tot * P)) {
+            if (!b_in_place) {
+                StageArgs sa{x.p, x.sb, x.sc, x.sh, NB, c.Cin, H, W, sk.OH, sk.OW, ex.sg, NT, 0};
+                ex.fail(sk.kind == 1 ? mcvc_im2col_s2_launch(sa, ex.s) : mcvc_im2col_1d_launch(sa, c.KW, ex.s));
+            }
             SGemmArgs g{};
-            g.a = packed + c.off_fwd; g.lda = c.cout_pk;                       // Wt[k = 9*ci + tap][co] (value | gate columns)
-            g.b = ex.sg; g.ldb = NT; g.bseg = (int)NT; g.b_sn = 0;
+            g.a = packed + c.off_fwd; g.lda = c.cout_pk;                       // Wt[k = taps*ci + tap][co] (value | gate columns)
+            if (b_in_place) { g.b = x.p; g.ldb = x.sc; g.bseg = P; g.b_sn = x.sb; }
+            else { g.b = ex.sg; g.ldb = NT; g.bseg = (int)NT; g.b_sn = 0; }
             g.c = y.p; g.ldc = y.sc; g.cseg = P; g.c_sn = y.sb;
             g.bias = packed + c.off_bias;
-            g.M = c.cout_tot; g.N = (int)NT; g.K = K9; g.nsplit = sp; g.c_slab = ex.slabs; g.c_split = y_total;
+            g.M = c.cout_tot; g.N = (int)NT; g.K = KT; g.nsplit = sp; g.c_slab = ex.slabs; g.c_split = y_total;
             ex.fail(mcvc_sgemm_launch(g, ex.s));
             if (nsplit) *nsplit = sp;
             return;
@@ -426,21 +443,29 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
     if (conv_wino(ex, c, packed, 1, NB, H, W, dy, dx, 0, accumulate)) { if (nsplit) *nsplit = 1; return; }
     const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
     const int st = c.stride;
-    if (sgemm_applies(c, NB, H, W) && (ex.dry || ex.params)) {
-        const int P = OH * OW, K9 = 9 * c.Cin;
+    const SgKind sk = sgemm_kind(c, NB, H, W);
+    if (sk.kind && (ex.dry || ex.params)) {
+        const int P = sk.OH * sk.OW, KT = sk.taps * c.Cin;
         const long long NT = (long long)NB * P;
-        const int sp = c.nbr == 1 ? sgemm_split(K9, NT, c.cout_tot) : 1;
-        if (ex.dry) { sgemm_want(ex, sp * K9 * NT); if (nsplit) *nsplit = 1; return; }
-        if (ex.sg && sp * K9 * NT <= ex.sg_cap && dy.sh == OW && dy.sc == P && ex.params[c.wi[0]] && (c.nbr == 1 || ex.params[c.wi[1]])) {
+        const int sp = sgemm_split(KT, NT, c.cout_tot);
+        const bool c_in_place = sk.kind == 2 && c.KW == 1 && sp == 1;                      // a 1x1 conv's product IS dx
+        const long long stage = c_in_place ? 0 : sp * KT * NT;
+        if (ex.dry) { sgemm_want(ex, stage); if (nsplit) *nsplit = 1; return; }
+        if ((c_in_place ? (dx.sh == W && dx.sc == P) : (ex.sg && stage <= ex.sg_cap)) && dy.sh == sk.OW && dy.sc == P && ex.params[c.wi[0]] &&
+            (c.nbr == 1 || ex.params[c.wi[1]])) {
             SGemmArgs g{};
-            g.a = ex.params[c.wi[0]]; g.lda = K9;                                                      // W[co][k]: the OIHW tensors themselves
+            g.a = ex.params[c.wi[0]]; g.lda = KT;                                                      // W[co][k]: the OIHW tensors themselves
             if (c.nbr == 2) { g.a2 = ex.params[c.wi[1]]; g.k_split = c.Cout; }                         // (value | gate rows)
             g.b = dy.p; g.ldb = dy.sc; g.bseg = P; g.b_sn = dy.sb;                                      // dY[co][n] read in place
-            g.c = ex.sg; g.ldc = NT; g.cseg = (int)NT; g.c_sn = 0;                                       // dXcol[k][n]
-            g.M = K9; g.N = (int)NT; g.K = c.cout_tot; g.nsplit = sp; g.c_slab = ex.sg + K9 * NT; g.c_split = K9 * NT;
+            g.M = KT; g.N = (int)NT; g.K = c.cout_tot; g.nsplit = sp;
+            if (c_in_place) { g.c = dx.p; g.ldc = dx.sc; g.cseg = P; g.c_sn = dx.sb; g.accumulate = accumulate; }
+            else { g.c = ex.sg; g.ldc = NT; g.cseg = (int)NT; g.c_sn = 0; g.c_slab = ex.sg + KT * NT; g.c_split = KT * NT; }     // dXcol[k][n]
             ex.fail(mcvc_sgemm_launch(g, ex.s));
-            StageArgs sa{dx.p, dx.sb, dx.sc, dx.sh, NB, c.Cin, H, W, OH, OW, ex.sg, NT, 0};
-            ex.fail(mcvc_col2im_s2_launch(sa, sp, K9 * NT, accumulate, ex.s));
+            if (!c_in_place) {
+                StageArgs sa{dx.p, dx.sb, dx.sc, dx.sh, NB, c.Cin, H, W, sk.OH, sk.OW, ex.sg, NT, 0};
+                ex.fail(sk.kind == 1 ? mcvc_col2im_s2_launch(sa, sp, KT * NT, accumulate, ex.s)
+                                     : mcvc_col2im_1d_launch(sa, c.KW, sp, KT * NT, accumulate, ex.s));
+            }
             if (nsplit) *nsplit = 1;
             return;
         }
@@ -529,39 +554,25 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
 {
     const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
     ConvProblem p{c.Cin, H, W, c.Cout, OH, OW, c.KH, c.KW, c.stride, c.ph, c.pw};
-    // large-batch GEMM form of the strided 3x3 layers (sgemm.h): pixel-major operands, K-split slabs, then dw += slabs
+    // GEMM form (sgemm.h): pixel-major operands in the weight gradients' own staging region, K-split slabs, then dw += slabs
+    const SgKind sk = sgemm_kind(c, NB, H, W);
+    const int KT = sk.taps * c.Cin;
     int sg_split = 1; long long sg_rows = 0;
-    const bool sg = sgemm_applies(c, NB, H, W) && !ex.s2;
-    if (sg) {
-        const int tiles = (c.cout_tot / 64) * (9 * c.Cin / 64);
+    if (sk.kind) {
+        const int tiles = (c.cout_tot / 64) * (KT / 64);
         while (sg_split < 8 && tiles * sg_split < 512) sg_split *= 2;
-        const long long unit = 32LL * sg_split, NT = (long long)NB * OH * OW;
+        const long long unit = 32LL * sg_split, NT = (long long)NB * sk.OH * sk.OW;
         sg_rows = (NT + unit - 1) / unit * unit;
+        while (sg_split > 1 && sg_rows / sg_split < 64) { sg_split /= 2; sg_rows = (NT + 32LL * sg_split - 1) / (32LL * sg_split) * (32LL * sg_split); }
     }
-    const long long sg_floats = sg ? sg_rows * (9LL * c.Cin + c.cout_tot) + (long long)sg_split * c.cout_tot * 9 * c.Cin : 0;
+    const long long sg_floats = sk.kind ? sg_rows * ((long long)KT + c.cout_tot) + (long long)sg_split * c.cout_tot * KT : 0;
     if (ex.dry) {          // K-split slabs: their own region, so they never alias the data-gradient slabs of the main stream
-        if (sg) sgemm_want(ex, sg_floats);                 // (and the direct kernel's slabs: a pass with an auxiliary stream takes that path)
+        if (sk.kind && sg_floats > ex.sgw_need) ex.sgw_need = sg_floats;          // (the direct kernel's slabs stay reserved as the fallback)
         const long long need = mcvc_wgrad_plan_slab_floats(p, NB);
         if (need > ex.wslab_need) ex.wslab_need = need;
         return;
     }
     if (!grads) return;
-    if (sg && ex.sg && sg_floats <= ex.sg_cap && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]])) {
-        const int K9 = 9 * c.Cin;
-        float* xt = ex.sg; float* dyt = xt + sg_rows * K9; float* slabs = dyt + sg_rows * c.cout_tot;
-        StageArgs sx{x.p, x.sb, x.sc, x.sh, NB, c.Cin, H, W, OH, OW, xt, K9, (int)sg_rows};
-        ex.fail(mcvc_im2col_s2_t_launch(sx, ex.s));
-        StageArgs sy{dy.p, dy.sb, dy.sc, dy.sh, NB, c.cout_tot, OH, OW, OH, OW, dyt, c.cout_tot, (int)sg_rows};
-        ex.fail(mcvc_planes_t_launch(sy, ex.s));
-        SGemmArgs g{};
-        g.a = dyt; g.lda = c.cout_tot;                                        // dYt[n][co]
-        g.b = xt; g.ldb = K9; g.bseg = K9; g.b_sn = 0;                        // XcolT[n][k]
-        g.c = slabs; g.ldc = K9; g.cseg = K9; g.c_sn = 0; g.c_split = (long long)c.cout_tot * K9; g.c_slab = slabs + g.c_split;
-        g.M = c.cout_tot; g.N = K9; g.K = (int)sg_rows; g.nsplit = sg_split;
-        ex.fail(mcvc_sgemm_launch(g, ex.s));
-        ex.fail(mcvc_dw_accum_launch(slabs, sg_split, g.c_split, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.cout_tot, K9, ex.s));
-        return;
-    }
     hipStream_t ws = ex.s;
     if (ex.s2) {           // dY (and x) are complete on the main stream at this point
         hipEvent_t e = pool_event();
@@ -570,7 +581,22 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         ws = ex.s2;
     }
     bool done = false;
-    if (c.wino && wino_enabled() && ex.wu && c.nbr == 1 && grads[c.wi[0]]) {
+    if (sk.kind && ex.sgw && sg_floats <= ex.sgw_cap && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]])) {
+        float* xt = ex.sgw; float* dyt = xt + sg_rows * KT; float* slabs = dyt + sg_rows * c.cout_tot;
+        StageArgs sx{x.p, x.sb, x.sc, x.sh, NB, c.Cin, H, W, sk.OH, sk.OW, xt, KT, (int)sg_rows};
+        ex.fail(sk.kind == 1 ? mcvc_im2col_s2_t_launch(sx, ws) : mcvc_im2col_1d_t_launch(sx, c.KW, ws));
+        StageArgs sy{dy.p, dy.sb, dy.sc, dy.sh, NB, c.cout_tot, sk.OH, sk.OW, sk.OH, sk.OW, dyt, c.cout_tot, (int)sg_rows};
+        ex.fail(mcvc_planes_t_launch(sy, ws));
+        SGemmArgs g{};
+        g.a = dyt; g.lda = c.cout_tot;                                        // dYt[n][co]
+        g.b = xt; g.ldb = KT; g.bseg = KT; g.b_sn = 0;                        // XcolT[n][k]
+        g.c = slabs; g.ldc = KT; g.cseg = KT; g.c_sn = 0; g.c_split = (long long)c.cout_tot * KT; g.c_slab = slabs + g.c_split;
+        g.M = c.cout_tot; g.N = KT; g.K = (int)sg_rows; g.nsplit = sg_split;
+        ex.fail(mcvc_sgemm_launch(g, ws));
+        ex.fail(mcvc_dw_accum_launch(slabs, sg_split, g.c_split, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.cout_tot, KT, ws));
+        done = true;
+    }
+    if (!done && c.wino && wino_enabled() && ex.wu && c.nbr == 1 && grads[c.wi[0]]) {
         // Winograd weight gradient: dU[xi] = dM[xi] V[xi]^T over the tiles, then dW += G^T dU G.  Operands tile-major.
         static const int en = [] { const char* e = getenv("MCVC_WINO_WGRAD"); return e ? atoi(e) : 1; }();
         const int TH = (H + 1) / 2, TW = (W + 1) / 2;
@@ -1053,6 +1079,7 @@ static GenScratch gen_scratch(const GenDims& d)
 static void gen_forward_impl(Exec& ex, const float* const* P, const float* packed, const float* x, const float* mask, float* out,
                              float* st, const GenDims& d)
 {
+    ex.params = P;
     const GenNet& g = gen_net();
     const GenStash o = gen_stash(d);
     const int B = d.B, T = d.T, W2 = d.W2, W4 = d.W4, Wu1 = d.Wu1, Wu2 = d.Wu2;
@@ -1161,6 +1188,7 @@ static void record_milestone(Exec& ex, void* ev)
 static void gen_backward_impl(Exec& ex, const float* const* P, const float* packed, float* const* G, const float* mask, const float* dout,
                               float* dx, int accumulate_dx, const float* stc, float* sc, const GenDims& d, void* const* milestones = nullptr)
 {
+    ex.params = P;
     const GenNet& g = gen_net();
     const GenStash o = gen_stash(d);
     const GenScratch q = gen_scratch(d);
@@ -1466,7 +1494,7 @@ static void disc_backward_impl(Exec& ex, const float* const* P, const float* pac
     join_aux(ex);
 }
 
-struct Needs { long long slab, wslab, sg; };
+struct Needs { long long slab, wslab, sg, sgw; };
 
 // split of the scratch tail into [conv slabs | wgrad slabs]: from a dry run of the schedule, cached per (net, B, T)
 template <class F>
@@ -1482,7 +1510,7 @@ static Needs cached_needs(int kind, int B, int T, F&& dry_run)
     }
     Exec ex{}; ex.dry = true;
     dry_run(ex);
-    Needs n{(ex.slab_need + 3) & ~3LL, (ex.wslab_need + 3) & ~3LL, (ex.sg_need + 3) & ~3LL};
+    Needs n{(ex.slab_need + 3) & ~3LL, (ex.wslab_need + 3) & ~3LL, (ex.sg_need + 3) & ~3LL, (ex.sgw_need + 3) & ~3LL};
     std::lock_guard<std::mutex> lk(mu);
     cache[key] = n;
     return n;
@@ -1496,8 +1524,10 @@ static Exec make_exec(void* stream, void* aux_stream, float* scratch, long long 
     ex.slab_cap = nd.slab;
     ex.sg = nd.sg ? scratch + slab_off + nd.slab : nullptr;
     ex.sg_cap = nd.sg;
-    ex.wslabs = scratch + slab_off + nd.slab + nd.sg;
-    ex.wslab_cap = scratch_floats - slab_off - nd.slab - nd.sg;
+    ex.sgw = nd.sgw ? scratch + slab_off + nd.slab + nd.sg : nullptr;
+    ex.sgw_cap = nd.sgw;
+    ex.wslabs = scratch + slab_off + nd.slab + nd.sg + nd.sgw;
+    ex.wslab_cap = scratch_floats - slab_off - nd.slab - nd.sg - nd.sgw;
     return ex;
 }
 
@@ -1544,7 +1574,7 @@ long long mcvc_gen_stash_floats(int B, int T) { return gen_stash(gen_dims(B, T))
 long long mcvc_gen_scratch_floats(int B, int T)
 {
     const Needs nd = gen_needs(B, T);
-    return gen_scratch(gen_dims(B, T)).slabs + nd.slab + nd.sg + nd.wslab + 64;
+    return gen_scratch(gen_dims(B, T)).slabs + nd.slab + nd.sg + nd.sgw + nd.wslab + 64;
 }
 
 long long mcvc_disc_stash_floats(int B, int T)
@@ -1556,7 +1586,7 @@ long long mcvc_disc_stash_floats(int B, int T)
 long long mcvc_disc_scratch_floats(int B, int T)
 {
     const Needs nd = disc_needs(B, T);
-    return disc_scratch(disc_dims(B, T)).slabs + nd.slab + nd.sg + nd.wslab + 64;
+    return disc_scratch(disc_dims(B, T)).slabs + nd.slab + nd.sg + nd.sgw + nd.wslab + 64;
 }
 
 int mcvc_gen_pack(const float* const* params, float* packed, void* stream)

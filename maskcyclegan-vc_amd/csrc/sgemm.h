@@ -21,6 +21,7 @@ struct SGemmArgs {
     // C: [M][N]:  C(m, n) = (m < m_split ? c : c2)[m' * ldc + (n / cseg) * c_sn + n % cseg], m' = m (c) or m - m_split (c2)
     float* c; float* c2; int m_split; long long ldc; int cseg; long long c_sn;
     const float* bias;        // [M] added to every column, or nullptr
+    int accumulate;           // C += (split 0; no atomics: one workgroup owns a tile)
     int M, N, K;              // M % 64 == 0, K % (32 * nsplit) == 0, N % 4 == 0
     // K-split: split s handles rows [s*K/nsplit, (s+1)*K/nsplit); split 0 writes C (+ bias), split s > 0 writes the same layout at
     // c_slab + (s - 1) * c_split (c2 / m_split apply to split 0 only; use them with nsplit = 1)
@@ -44,5 +45,10 @@ int mcvc_planes_t_launch(const StageArgs& a, hipStream_t s);
 // dx[b][ci][ih][iw] (=|+=) sum over the taps that reach it of dXcol[9*ci + tap][n], summed over nslab K-split slabs of dXcol
 // (x / x_* = the dx view; out = dXcol, read)
 int mcvc_col2im_s2_launch(const StageArgs& a, int nslab, long long slab_stride, int accumulate, hipStream_t s);
+// The same for 1 x KW convolutions along w (KW = 1, 3; stride 1, padding (KW-1)/2) over an image of NB*H rows -- the 1-D trunk at more
+// than 32 columns (model.py:47-76, 142-189): k = KW*ci + tap, n = (b*H + h)*W + w
+int mcvc_im2col_1d_launch(const StageArgs& a, int KW, hipStream_t s);
+int mcvc_im2col_1d_t_launch(const StageArgs& a, int KW, hipStream_t s);
+int mcvc_col2im_1d_launch(const StageArgs& a, int KW, int nslab, long long slab_stride, int accumulate, hipStream_t s);
 // g0[co][k] += sum_s slabs[s][co][k] (co < Cout), g1[co - Cout][k] += ... (co >= Cout; g1 may be null when rows == Cout)
 int mcvc_dw_accum_launch(const float* slabs, int nslab, long long slab_stride, float* g0, float* g1, int Cout, int rows, int K9, hipStream_t s);

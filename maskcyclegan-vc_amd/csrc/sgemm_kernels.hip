@@ -98,7 +98,8 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SGemmArgs a)
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (ks) { slab[(long long)m * a.ldc + coff] = acc[r]; continue; }
             float* row = (m < a.m_split) ? a.c + (long long)m * a.ldc : a.c2 + (long long)(m - a.m_split) * a.ldc;
-            row[coff] = a.bias ? acc[r] + a.bias[m] : acc[r];
+            const float v = a.bias ? acc[r] + a.bias[m] : acc[r];
+            row[coff] = a.accumulate ? row[coff] + v : v;
         }
     }
 }
@@ -215,6 +216,84 @@ __global__ void __launch_bounds__(256) col2im_s2_kernel(const StageArgs a, int n
     *d = accumulate ? *d + s : s;
 }
 
+
+// ---- 1 x KW convolutions along w (stride 1, padding (KW-1)/2) over rows (b, h): the 1-D trunk run as an image of B rows -------------
+// Xcol[KW*ci + tap][n] = x[b][ci][h][w + tap - pw],  n = (b*H + h)*W + w
+template <int KW>
+__global__ void __launch_bounds__(256) im2col_1d_kernel(const StageArgs a)
+{
+    constexpr int PW = (KW - 1) / 2;
+    const int P = a.H * a.W;
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int ci = blockIdx.y;
+    if (n >= (long long)a.NB * P) return;
+    const int b = (int)(n / P), p = (int)(n - (long long)b * P);
+    const int h = p / a.W, w = p - h * a.W;
+    const float* xp = a.x + (long long)b * a.x_sb + (long long)ci * a.x_sc + (long long)h * a.x_sh;
+    float* o = a.out + (long long)ci * KW * a.ld + n;
+#pragma unroll
+    for (int t = 0; t < KW; ++t) {
+        const int iw = w + t - PW;
+        o[(long long)t * a.ld] = (iw >= 0 && iw < a.W) ? xp[iw] : 0.f;
+    }
+}
+
+// XcolT[n][KW*ci + tap]
+template <int KW>
+__global__ void __launch_bounds__(256) im2col_1d_t_kernel(const StageArgs a)
+{
+    constexpr int PW = (KW - 1) / 2;
+    __shared__ float tile[32][32 * KW + 1];
+    const int P = a.H * a.W;
+    const long long NT = (long long)a.NB * P;
+    const long long n0 = (long long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int nl = threadIdx.x & 31, cw = threadIdx.x >> 5;
+    const long long n = n0 + nl;
+    const bool live = n < NT;
+    int b = 0, h = 0, w = 0;
+    if (live) { b = (int)(n / P); const int p = (int)(n - (long long)b * P); h = p / a.W; w = p - h * a.W; }
+    for (int cl = cw; cl < 32; cl += 8) {
+        const int ci = c0 + cl;
+        const float* xp = a.x + (long long)b * a.x_sb + (long long)ci * a.x_sc + (long long)h * a.x_sh;
+#pragma unroll
+        for (int t = 0; t < KW; ++t) {
+            const int iw = w + t - PW;
+            tile[nl][cl * KW + t] = (live && ci < a.C && iw >= 0 && iw < a.W) ? xp[iw] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int kmax = (a.C - c0 < 32 ? a.C - c0 : 32) * KW;
+    for (int e = threadIdx.x; e < 32 * 32 * KW; e += 256) {
+        const int r = e / (32 * KW), k = e - r * (32 * KW);
+        if (n0 + r < a.rows_pad && k < kmax) a.out[(n0 + r) * a.ld + (long long)c0 * KW + k] = tile[r][k];
+    }
+}
+
+// dx[b][ci][h][w] (=|+=) sum_tap dXcol[KW*ci + tap][(b, h, w - tap + pw)], summed over the K-split slabs
+template <int KW>
+__global__ void __launch_bounds__(256) col2im_1d_kernel(const StageArgs a, int nslab, long long slab_stride, int accumulate)
+{
+    constexpr int PW = (KW - 1) / 2;
+    const int P = a.H * a.W;
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int ci = blockIdx.y;
+    if (n >= (long long)a.NB * P) return;
+    const int b = (int)(n / P), p = (int)(n - (long long)b * P);
+    const int h = p / a.W, w = p - h * a.W;
+    const float* col = a.out + (long long)ci * KW * a.ld + n;
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < KW; ++t) {
+        const int ow = w - t + PW;
+        if (ow < 0 || ow >= a.W) continue;
+        const float* cp = col + (long long)t * a.ld + (ow - w);
+        for (int k = 0; k < nslab; ++k) s += cp[(long long)k * slab_stride];
+    }
+    float* d = const_cast<float*>(a.x) + (long long)b * a.x_sb + (long long)ci * a.x_sc + (long long)h * a.x_sh + w;
+    *d = accumulate ? *d + s : s;
+}
+
 __global__ void __launch_bounds__(256) dw_accum_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride, float* __restrict__ g0,
                                                        float* __restrict__ g1, int Cout, int rows, int K9)
 {
@@ -284,6 +363,39 @@ int mcvc_col2im_s2_launch(const StageArgs& a, int nslab, long long slab_stride, 
     const long long NE = (long long)a.NB * a.H * a.W;
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((accumulate ? 2.0 : 1.0) * a.NB * a.C * a.H * a.W + 9.0 * nslab * a.C * a.NB * a.OH * a.OW));
     hipLaunchKernelGGL(col2im_s2_kernel, dim3((unsigned)((NE + 255) / 256), (unsigned)a.C), dim3(256), 0, s, a, nslab, slab_stride, accumulate);
+    return (int)hipGetLastError();
+}
+
+
+int mcvc_im2col_1d_launch(const StageArgs& a, int KW, hipStream_t s)
+{
+    const long long NT = (long long)a.NB * a.H * a.W;
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (1.0 + KW) * a.C * NT);
+    const dim3 grid((unsigned)((NT + 255) / 256), (unsigned)a.C);
+    if (KW == 3) hipLaunchKernelGGL(im2col_1d_kernel<3>, grid, dim3(256), 0, s, a);
+    else if (KW == 1) hipLaunchKernelGGL(im2col_1d_kernel<1>, grid, dim3(256), 0, s, a);
+    else return MCVC_ERR_INVALID;
+    return (int)hipGetLastError();
+}
+
+int mcvc_im2col_1d_t_launch(const StageArgs& a, int KW, hipStream_t s)
+{
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.NB * a.C * a.H * a.W + (double)KW * a.C * a.rows_pad));
+    const dim3 grid((unsigned)((a.rows_pad + 31) / 32), (unsigned)cdiv_i(a.C, 32));
+    if (KW == 3) hipLaunchKernelGGL(im2col_1d_t_kernel<3>, grid, dim3(256), 0, s, a);
+    else if (KW == 1) hipLaunchKernelGGL(im2col_1d_t_kernel<1>, grid, dim3(256), 0, s, a);
+    else return MCVC_ERR_INVALID;
+    return (int)hipGetLastError();
+}
+
+int mcvc_col2im_1d_launch(const StageArgs& a, int KW, int nslab, long long slab_stride, int accumulate, hipStream_t s)
+{
+    const long long NT = (long long)a.NB * a.H * a.W;
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((accumulate ? 2.0 : 1.0) + (double)KW * nslab) * a.C * NT);
+    const dim3 grid((unsigned)((NT + 255) / 256), (unsigned)a.C);
+    if (KW == 3) hipLaunchKernelGGL(col2im_1d_kernel<3>, grid, dim3(256), 0, s, a, nslab, slab_stride, accumulate);
+    else if (KW == 1) hipLaunchKernelGGL(col2im_1d_kernel<1>, grid, dim3(256), 0, s, a, nslab, slab_stride, accumulate);
+    else return MCVC_ERR_INVALID;
     return (int)hipGetLastError();
 }
 
