@@ -66,6 +66,11 @@ int mcvc_gen_pack(const float* const* params, float* packed, void* stream);
  *      not refreshed.  Falls back to the full re-pack otherwise.                                                   */
 int mcvc_gen_trunk_fused(int B, int T);
 int mcvc_gen_pack_small_batch(const float* const* params, float* packed, int max_batch, int T, void* stream);
+/* The same in two parts: sets = 1 refreshes only what a FORWARD pass reads (K-major forward copies, biases, forward Winograd sets),
+ * sets = 2 only what a BACKWARD pass reads (data-gradient / transposed / data-gradient Winograd sets), 3 = both.  After sets = 1 a
+ * backward pass on this buffer returns MCVC_ERR_INVALID until sets = 2 has run (the trainer's discriminator phase needs the updated
+ * generators forward-only; the rest of the refresh runs beside it).                                    */
+int mcvc_gen_pack_sets(const float* const* params, float* packed, int max_batch, int T, int sets, void* stream);
 int mcvc_disc_pack(const float* const* params, float* packed, void* stream);
 
 /* ---- Generator: replaces Generator.forward (mask_cyclegan_vc/model.py:239-280) and its autograd

@@ -709,12 +709,16 @@ static void add_job(PackTable& t, PackJob j, int gx, int gy)
 
 // trunk_only: the layer runs on the fused trunk kernels (OIHW forward); only the transposed data-gradient copy is needed
 // wino_only: the layer runs on the Winograd kernels in every pass (forward, data-gradient); its direct K-major copies are skipped
-static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = false, bool wino_only = false)
+// sets: 1 = the copies a FORWARD pass reads (K-major forward copies, biases, forward Winograd sets), 2 = the copies only a BACKWARD pass
+// reads (data-gradient copies, transposed trunk copies, data-gradient Winograd sets), 3 = both
+static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = false, bool wino_only = false, int sets = 3)
 {
     const int K = c.Cin * c.KH * c.KW;
+    const bool fw = (sets & 1) != 0, bw = (sets & 2) != 0;
     for (int br = 0; br < c.nbr; ++br) {
         const bool skip_direct = wino_only && (c.wino || c.wino3);
         if (trunk_only && c.off_tk >= 0) {
+            if (!bw) continue;
             PackJob q{}; q.kind = PACK_TRUNK_T; q.param = c.wi[br]; q.dst = c.off_tk; q.Cout = c.Cout; q.Cin = c.Cin; q.KW = c.KW;
             q.ld = c.cout_tot * c.KW; q.co_off = br * c.Cout;
             add_job(t, q, cdiv_i(c.Cin, 32), cdiv_i(c.Cout, 32));
@@ -722,19 +726,19 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             continue;
         }
         PackJob f{}; f.kind = PACK_FWD; f.param = c.wi[br]; f.dst = c.off_fwd; f.Cout = c.Cout; f.K = K; f.ld = c.cout_pk; f.co_off = br * c.Cout;
-        if (!skip_direct) add_job(t, f, cdiv_i(K, 32), cdiv_i(c.Cout, 32));
+        if (!skip_direct && fw) add_job(t, f, cdiv_i(K, 32), cdiv_i(c.Cout, 32));
         PackJob b{}; b.kind = PACK_COPY; b.param = c.bi[br]; b.dst = c.off_bias + br * c.Cout; b.Cout = c.Cout;
-        add_job(t, b, cdiv_i(c.Cout, 256), 1);
+        if (fw) add_job(t, b, cdiv_i(c.Cout, 256), 1);
         PackDgradArgs a{};
         a.Cin = c.Cin; a.KH = c.KH; a.KW = c.KW; a.step = c.stride; a.ld = c.merged ? c.mg_ld : c.cin_pk; a.co_off = br * c.Cout; a.ncls = c.ncls;
         a.merged = c.merged; a.mg_kh = c.mg_kh; a.mg_kw = c.mg_kw;
         for (int k = 0; k < c.ncls; ++k) a.cls[k] = c.cls[k];
         PackJob d{}; d.kind = PACK_DGRAD; d.param = c.wi[br]; d.dst = c.off_dgrad; d.dg = (int)t.dga.size();
-        if (!skip_direct) {
+        if (!skip_direct && bw) {
             t.dga.push_back(a);
             add_job(t, d, cdiv_i(c.Cin, 32), c.Cout);
         }
-        if (c.off_dcls >= 0) {          // exact per-class copies (large-batch data-gradient of the 3x3 stride-2 layers)
+        if (c.off_dcls >= 0 && bw) {          // exact per-class copies (large-batch data-gradient of the 3x3 stride-2 layers)
             PackDgradArgs u = a;
             u.merged = 0; u.ld = c.cin_pk;
             for (int k = 0; k < c.ncls; ++k) u.cls[k] = c.ucls[k];
@@ -743,7 +747,7 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             add_job(t, du, cdiv_i(c.Cin, 32), c.Cout);
             t.bytes += 4.0 * 2.0 * c.Cout * K;
         }
-        if (c.off_tk >= 0) {
+        if (c.off_tk >= 0 && bw) {
             PackJob q{}; q.kind = PACK_TRUNK_T; q.param = c.wi[br]; q.dst = c.off_tk; q.Cout = c.Cout; q.Cin = c.Cin; q.KW = c.KW;
             q.ld = c.cout_tot * c.KW; q.co_off = br * c.Cout;
             add_job(t, q, cdiv_i(c.Cin, 32), cdiv_i(c.Cout, 32));
@@ -751,20 +755,20 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
         if (c.wino3) {
             PackJob w3{}; w3.kind = PACK_WINO3_D; w3.param = c.wi[br]; w3.dst = c.off_w3; w3.Cout = c.Cout; w3.Cin = c.Cin; w3.ld = c.mg_ld;
             w3.xi_stride = c.w3_xi; w3.co_off = br * c.Cout;
-            add_job(t, w3, cdiv_i(c.Cin, 256), c.Cout);
+            if (bw) add_job(t, w3, cdiv_i(c.Cin, 256), c.Cout);
             PackJob w3f{}; w3f.kind = PACK_WINO3_F; w3f.param = c.wi[br]; w3f.dst = c.off_w3f; w3f.Cout = c.Cout; w3f.Cin = c.Cin; w3f.ld = c.cout_pk;
             w3f.xi_stride = c.w3f_xi; w3f.co_off = br * c.Cout;
-            add_job(t, w3f, cdiv_i(c.Cout, 256), c.Cin);
-            t.bytes += 4.0 * 2.0 * (25.0 + 64.0) * c.Cout * c.Cin;
+            if (fw) add_job(t, w3f, cdiv_i(c.Cout, 256), c.Cin);
+            t.bytes += 4.0 * (fw + bw) * (25.0 + 64.0) * c.Cout * c.Cin;
         }
         if (c.wino) {
             PackJob wf{}; wf.kind = PACK_WINO_F; wf.param = c.wi[br]; wf.dst = c.off_wf; wf.Cout = c.Cout; wf.Cin = c.Cin; wf.ld = c.cout_pk;
             wf.xi_stride = c.wf_xi; wf.co_off = br * c.Cout;
-            add_job(t, wf, cdiv_i(c.Cout, 256), c.Cin);
+            if (fw) add_job(t, wf, cdiv_i(c.Cout, 256), c.Cin);
             PackJob wd{}; wd.kind = PACK_WINO_D; wd.param = c.wi[br]; wd.dst = c.off_wd; wd.Cout = c.Cout; wd.Cin = c.Cin; wd.ld = c.cin_pk;
             wd.xi_stride = c.wd_xi; wd.co_off = br * c.Cout;
-            add_job(t, wd, cdiv_i(c.Cin, 256), c.Cout);
-            t.bytes += 4.0 * 2.0 * (25.0 + 36.0) * c.Cout * c.Cin;
+            if (bw) add_job(t, wd, cdiv_i(c.Cin, 256), c.Cout);
+            t.bytes += 4.0 * (fw + bw) * (25.0 + 36.0) * c.Cout * c.Cin;
         }
         t.bytes += 4.0 * ((c.off_tk >= 0 ? 6.0 : 4.0) * c.Cout * K + 2.0 * c.Cout);
     }
@@ -1624,28 +1628,41 @@ int mcvc_gen_trunk_fused(int B, int T)
     return ok ? 1 : 0;
 }
 
-int mcvc_gen_pack_small_batch(const float* const* params, float* packed, int max_batch, int T, void* stream)
+// `sets`: 1 = only what a forward pass reads, 2 = only what a backward pass reads, 3 = both (see add_spec_jobs).  After a forward-only
+// refresh the backward sets are marked stale (bit 2 of the registry) and a backward pass on this buffer fails until sets = 2 has run.
+int mcvc_gen_pack_sets(const float* const* params, float* packed, int max_batch, int T, int sets, void* stream)
 {
+    if (sets < 1 || sets > 3) return MCVC_ERR_INVALID;
+    bool fused = true;
     for (int b = 1; b <= max_batch; ++b)
-        if (!mcvc_gen_trunk_fused(b, T)) return mcvc_gen_pack(params, packed, stream);
+        if (!mcvc_gen_trunk_fused(b, T)) fused = false;
     // every 5x5 layer of every such pass runs on the Winograd kernels (conv_wino / the wino3 branches take no fallback) when
     // the frame count keeps all image sizes even, the tile counts are inside the kernels' range and nothing was switched
     // off through the MCVC_WINO* knobs: then their direct K-major copies are not refreshed either
     static const bool knobs_default = !getenv("MCVC_WINO") && !getenv("MCVC_WINO3") && !getenv("MCVC_WINO3_FWD") && !getenv("MCVC_WINO_GEMM");
     const GenDims dm = gen_dims(max_batch, T);
-    const bool wino_only = knobs_default && (T % 4) == 0 && T >= 32 && (long long)max_batch * 20 * dm.W4 <= 16384;
+    const bool wino_only = fused && knobs_default && (T % 4) == 0 && T >= 32 && (long long)max_batch * 20 * dm.W4 <= 16384;
     int err = 0;
-    auto build = [wino_only](PackTable& pt) {
+    auto build = [wino_only, fused, sets](PackTable& pt) {
         const GenNet& g = gen_net();
         const ConvSpec* full[] = {&g.conv1, &g.ds1, &g.ds2, &g.up1, &g.up2, &g.last};
-        for (const ConvSpec* c : full) add_spec_jobs(pt, *c, false, wino_only);
-        add_spec_jobs(pt, g.c2d1d, true); add_spec_jobs(pt, g.c1d2d, true);
-        for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i], true); add_spec_jobs(pt, g.res_out[i], true); }
+        for (const ConvSpec* c : full) add_spec_jobs(pt, *c, false, wino_only, sets);
+        add_spec_jobs(pt, g.c2d1d, fused, false, sets); add_spec_jobs(pt, g.c1d2d, fused, false, sets);
+        for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i], fused, false, sets); add_spec_jobs(pt, g.res_out[i], fused, false, sets); }
     };
-    const DevPackTable* t = dev_pack_table(wino_only ? 3 : 2, build, &err);
+    const DevPackTable* t = dev_pack_table(16 + 4 * sets + (fused ? (wino_only ? 3 : 2) : 0), build, &err);
     if (!t) return err;
-    set_pack_skips(packed, wino_only ? 3 : 1);
+    const int skipped = fused ? (wino_only ? 3 : 1) : 0;
+    if (sets == 1) set_pack_skips(packed, skipped | 4);
+    else if (sets == 2) set_pack_skips(packed, get_pack_skips(packed) & ~4);
+    else set_pack_skips(packed, skipped);
+    if (t->njobs == 0) return 0;
     return pack_net(t, params, packed, (hipStream_t)stream);
+}
+
+int mcvc_gen_pack_small_batch(const float* const* params, float* packed, int max_batch, int T, void* stream)
+{
+    return mcvc_gen_pack_sets(params, packed, max_batch, T, 3, stream);
 }
 
 int mcvc_disc_pack(const float* const* params, float* packed, void* stream)
@@ -1686,6 +1703,7 @@ int mcvc_gen_backward_overlap(const float* const* params, const float* packed, f
     { const GenScratch q = gen_scratch(d); ex.wv = scratch + q.wv; ex.wm = scratch + q.wm; ex.wino_cap = q.wino_floats;
       ex.wv2 = scratch + q.wv2; ex.wm2 = scratch + q.wm2; ex.wu = scratch + q.wu; ex.wu_cap = q.wu_floats; }
     ex.pack_skips = get_pack_skips(packed);
+    if (ex.pack_skips & 4) return MCVC_ERR_INVALID;          // forward-only re-pack: the backward sets are stale (mcvc_gen_pack_sets)
     gen_backward_impl(ex, params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, d, milestones);
     return ex.err;
 }

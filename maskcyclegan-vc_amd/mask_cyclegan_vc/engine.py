@@ -146,6 +146,8 @@ class TrainEngine:
         # the discriminators' weight re-pack after their Adam step is needed only ~1.5 ms later (after the next iteration's
         # four generator forwards): it runs on its own stream and the discriminator forwards wait for its event
         self._task_events = {}
+        self._g_fwd_packed = False
+        self.fuse_g_update = os.environ.get("MCVC_FUSE_G_UPDATE", "1") != "0"
         self._timeline = None
         self._pack_stream = torch.cuda.Stream(device=dev)
         self._d_pack_event = None
@@ -220,11 +222,12 @@ class TrainEngine:
             setattr(self, k, v)
 
     # ---- thin call helpers ------------------------------------------------------------------------
-    def _repack1(self, n):
+    def _repack1(self, n, sets=3):
         if n in G_NAMES:
             # every generator pass of this engine has batch <= 2B at T frames: at small batch the trunk layers run on the
-            # fused kernels and their generic K-major copies need no refresh (the library falls back to the full pack)
-            check(self.L.mcvc_gen_pack_small_batch(self._p_tab[n], ptr(self.packed[n]), 2 * self._max_B, self.T, stream()), "pack " + n)
+            # fused kernels and their generic K-major copies need no refresh (the library falls back to the full pack).
+            # sets: 1 = what a forward pass reads, 2 = what only a backward pass reads (mcvc_gen_pack_sets)
+            check(self.L.mcvc_gen_pack_sets(self._p_tab[n], ptr(self.packed[n]), 2 * self._max_B, self.T, sets, stream()), "pack " + n)
         else:
             check(self.L.mcvc_disc_pack(self._p_tab[n], ptr(self.packed[n]), stream()), "pack " + n)
 
@@ -359,9 +362,20 @@ class TrainEngine:
             self.nets[n]._packed_version = None
             self.nets[n]._bf16_version = None
 
+    def _adam_generator(self, name, step, lr):
+        """Adam on ONE generator's slice of the flat buffer (both slices of an iteration share the step count)."""
+        grp = self.g_group
+        lo, hi = self._g_ranges[name][2][0], self._g_ranges[name][0][1]
+        check(self.L.mcvc_adam_step(ptr(grp.flat[lo:hi]), ptr(grp.grad[lo:hi]), ptr(grp.exp_avg[lo:hi]), ptr(grp.exp_avg_sq[lo:hi]), hi - lo,
+                                    float(lr), self.betas[0], self.betas[1], self.eps, step, self.reducer.grad_scale, stream()), "adam_step")
+        self.nets[name]._packed_version = None
+        self.nets[name]._bf16_version = None
+
     # ---- the two phases -------------------------------------------------------------------------------
-    def generator_phase(self, real_A, mask_A, real_B, mask_B):
-        """train.py:195-242."""
+    def generator_phase(self, real_A, mask_A, real_B, mask_B, fuse_update=False):
+        """train.py:195-242.  ``fuse_update`` (what ``step()`` uses on one rank): each lane also applies Adam to the generator whose last
+        backward pass it ran and refreshes that generator's FORWARD weight copies (train.py:242 + re-pack) -- no join, one optimizer
+        launch per generator, and the backward-only copies are refreshed later, beside the discriminator phase."""
         B, B2 = self.B, 2 * self.B
         m = self.mel
         sc = self.sched
@@ -405,6 +419,15 @@ class TrainEngine:
         def finish_d(ln):                      # data parallel: the D gradient all-reduce of the previous iteration runs behind the
             self._finish_d_update()            # generator forwards; lane 2 is the first to need the discriminators
         ov = self.overlap_g_reduce
+        if fuse_update:
+            self.g_group.step += 1
+        g_step, g_lr = self.g_group.step, sc.g_opt_lr
+
+        def update(name):
+            def run(ln):
+                self._adam_generator(name, g_step, g_lr)
+                self._repack1(name, 1)
+            return run
         self._run_tasks([
             (0, lambda ln: self._G("generator_A2B", self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], B2, ln), (), "g0"),   # :203, :209-210
             (1, lambda ln: self._G("generator_B2A", self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], B2, ln), (), "g1"),   # :205, :207-208
@@ -421,7 +444,8 @@ class TrainEngine:
             # the last pass over each generator: its gradient ranges become final one after the other (milestone events)
             (0, lambda ln: self._G_bwd("generator_A2B", self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2, ln, ov), ("c1",), None),
             (1, lambda ln: self._G_bwd("generator_B2A", self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2, ln, ov), ("c0",), None),
-        ])
+        ] + ([(0, update("generator_A2B"), (), None), (1, update("generator_B2A"), (), None)] if fuse_update else []))
+        self._g_fwd_packed = bool(fuse_update)
         self._d_pack_event = None
         self._combine(0, self._comb_g)          # g_loss and its terms, summed in the reference's order (:233-237)
 
@@ -468,23 +492,39 @@ class TrainEngine:
                 self._lsgan(do[i][B:], 0.0, 0.25, 9 + 2 * i, dl[i][B:])
                 self._D_bwd(name, dl[i], None, 0, ds[i], True, B2, ln)
             return run
-        # Same shape as the generator phase: lanes 0/1 carry real_B -> generated_A -> cycled_B -> D_B2 and real_A -> generated_B ->
-        # cycled_A -> D_A2; D_A / D_B need only the generated batches and run on lanes 2/3 while lanes 0/1 are in the cycle forwards.
-        # A lane re-packs the generator it runs first; the other lane's second pass waits for that re-pack (p0 / p1).
-        gens = [
-            (0, lambda ln: self._repack1("generator_B2A"), (), "p0"),
-            (1, lambda ln: self._repack1("generator_A2B"), (), "p1"),
-            (0, lambda ln: self._G("generator_B2A", real_B, mask_B, gen_A, self.g_stash1[0], B, ln), (), "gA"),      # :259 generated_A
-            (1, lambda ln: self._G("generator_A2B", real_A, mask_A, gen_B, self.g_stash1[1], B, ln), (), "gB"),      # :267 generated_B
-            (0, lambda ln: self._G("generator_A2B", gen_A, None, cyc_B, self.g_stash1[0], B, ln), ("p1",), None),    # :263 cycled_B
-            (1, lambda ln: self._G("generator_B2A", gen_B, None, cyc_A, self.g_stash1[1], B, ln), ("p0",), None),    # :271 cycled_A
-            (2, disc("discriminator_A"), ("gA",), None),
-            (3, disc("discriminator_B"), ("gB",), None),
-        ]
-        self._run_tasks(gens + [
-            (0, disc("discriminator_B2"), (), None),
-            (1, disc("discriminator_A2"), (), None),
-        ])
+        # Same shape as the generator phase: lanes 0/1 carry the two generator chains, D_A / D_B need only the generated batches and run
+        # on lanes 2/3 while lanes 0/1 are in the cycle forwards; the second-step discriminators follow the cycle forwards on lanes 0/1.
+        if self._g_fwd_packed:
+            # the generator phase left lane 0 with generator_A2B updated + its forward copies fresh, lane 1 with generator_B2A: each lane
+            # starts with its own generator; the backward-only copies are refreshed on lanes 2/3 while those wait for the generated batches
+            self._g_fwd_packed = False
+            tasks = [
+                (0, lambda ln: self._G("generator_A2B", real_A, mask_A, gen_B, self.g_stash1[0], B, ln), (), "gB"),      # :267 generated_B
+                (1, lambda ln: self._G("generator_B2A", real_B, mask_B, gen_A, self.g_stash1[1], B, ln), (), "gA"),      # :259 generated_A
+                (2, lambda ln: self._repack1("generator_B2A", 2), (), None),
+                (3, lambda ln: self._repack1("generator_A2B", 2), (), None),
+                (0, lambda ln: self._G("generator_B2A", gen_B, None, cyc_A, self.g_stash1[0], B, ln), (), None),         # :271 cycled_A
+                (1, lambda ln: self._G("generator_A2B", gen_A, None, cyc_B, self.g_stash1[1], B, ln), (), None),         # :263 cycled_B
+                (2, disc("discriminator_A"), ("gA",), None),
+                (3, disc("discriminator_B"), ("gB",), None),
+                (0, disc("discriminator_A2"), (), None),
+                (1, disc("discriminator_B2"), (), None),
+            ]
+        else:
+            # (phase called on its own: a lane re-packs the generator it runs first; the other lane's second pass waits for that re-pack)
+            tasks = [
+                (0, lambda ln: self._repack1("generator_B2A"), (), "p0"),
+                (1, lambda ln: self._repack1("generator_A2B"), (), "p1"),
+                (0, lambda ln: self._G("generator_B2A", real_B, mask_B, gen_A, self.g_stash1[0], B, ln), (), "gA"),      # :259 generated_A
+                (1, lambda ln: self._G("generator_A2B", real_A, mask_A, gen_B, self.g_stash1[1], B, ln), (), "gB"),      # :267 generated_B
+                (0, lambda ln: self._G("generator_A2B", gen_A, None, cyc_B, self.g_stash1[0], B, ln), ("p1",), None),    # :263 cycled_B
+                (1, lambda ln: self._G("generator_B2A", gen_B, None, cyc_A, self.g_stash1[1], B, ln), ("p0",), None),    # :271 cycled_A
+                (2, disc("discriminator_A"), ("gA",), None),
+                (3, disc("discriminator_B"), ("gB",), None),
+                (0, disc("discriminator_B2"), (), None),
+                (1, disc("discriminator_A2"), (), None),
+            ]
+        self._run_tasks(tasks)
         self._combine(8, self._comb_d)
 
     def discriminator_update(self):
@@ -552,8 +592,11 @@ class TrainEngine:
         return self._step_static()
 
     def _step_static(self):
-        self._run_phase("G")
-        self.generator_update()
+        if self.reducer.world == 1 and not self.use_graphs and self.fuse_g_update:
+            self.generator_phase(*self.static_in, fuse_update=True)       # includes the generator update (per lane, no join)
+        else:
+            self._run_phase("G")
+            self.generator_update()
         self._run_phase("D")
         self.discriminator_update()
         self.sched.end_iteration()
