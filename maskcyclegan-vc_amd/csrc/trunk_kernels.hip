@@ -247,14 +247,25 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const TrunkA
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 if (sg0 + c < sgroups) {
+                    // all operand reads of the super-group first, pinned in front of its MFMAs: left alone the scheduler emits
+                    // ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma per product, i.e. one LDS latency (~150 cycles) per 32-cycle MFMA
+                    float xv[NQ][4][NA];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int h = 0; h < NA; ++h) xv[q][j][h] = xs[off[h][q][j]];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         const float av[4] = {wb[c][q].x, wb[c][q].y, wb[c][q].z, wb[c][q].w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int h = 0; h < NA; ++h) acc[h] = MFMA16(av[j], xs[off[h][q][j]], acc[h]);
+                            for (int h = 0; h < NA; ++h) acc[h] = MFMA16(av[j], xv[q][j][h], acc[h]);
                     }
+                    __builtin_amdgcn_sched_group_barrier(0x100, NQ * 4 * NA, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NQ * 4 * NA, 0);
                     xs += (GK / KW) * RS;
                 }
             }
@@ -462,9 +473,35 @@ __device__ __forceinline__ void net_load_w(const TrunkLayerDesc& d, int tile, Ne
 }
 
 // one tile of output rows of one layer: conv (K split over the 8 waves) + bias + IN + GLU / residual, stores included
+// Epilogue operands of one tile, one output element per thread: requested together with the weights, BEFORE the wait for the previous
+// layer's activations -- bias / gamma / beta / the residual input are 1-1.5 us of dependent global-load latency otherwise (measured with
+// an in-kernel clock: the epilogue was 5-6 us of a 10 us layer, the arrival wait 0.4 us)
+struct NetE { float bias, g0, b0, g1, b1, res; };
+__device__ __forceinline__ void net_load_e(const TrunkLayerDesc& d, int B, int T4, int tile, NetE& e)
+{
+    const int tid = threadIdx.x;
+    const int N = B * T4;
+    const int glu = (d.mode == TRUNK_IN_GLU);
+    const int rows = d.rows, rows_tot = glu ? 2 * rows : rows, r0 = tile * rows;
+    e = NetE{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (tid < rows_tot * N) {
+        const int mrow = tid / N;
+        e.bias = glu ? ((mrow < rows) ? d.bias0[r0 + mrow] : d.bias1[r0 + mrow - rows]) : d.bias0[r0 + mrow];
+    }
+    if (tid < rows * N) {
+        const int row = tid / N, col = tid - row * N, c = r0 + row;
+        e.g0 = d.gamma0[c]; e.b0 = d.beta0[c];
+        if (glu) { e.g1 = d.gamma1[c]; e.b1 = d.beta1[c]; }
+        if (d.res) {
+            const int b = col / T4, t = col - b * T4;
+            e.res = __hip_atomic_load(d.res + (long long)b * d.y_sn + (long long)c * d.y_sc + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (this workgroup's own rows, two layers back)
+        }
+    }
+}
+
 template <int KW, int NA>
 __device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4, float eps, int tile, const float* Xs, float* epi, bool wt,
-                                         NetW<KW>& pre)
+                                         NetW<KW>& pre, const NetE& pe)
 {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -523,14 +560,23 @@ __device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4,
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 if (sg0 + c < sgroups) {
+                    float xv[NQ][4][NA];          // all operand reads of the super-group first: one LDS latency instead of one per MFMA
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int h = 0; h < NA; ++h) xv[q][j][h] = xs[off[h][q][j]];
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
                         const float av[4] = {wb[c][q].x, wb[c][q].y, wb[c][q].z, wb[c][q].w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int h = 0; h < NA; ++h) acc[h] = MFMA16(av[j], xs[off[h][q][j]], acc[h]);
+                            for (int h = 0; h < NA; ++h) acc[h] = MFMA16(av[j], xv[q][j][h], acc[h]);
                     }
+                    __builtin_amdgcn_sched_group_barrier(0x100, NQ * 4 * NA, 0);       // (left alone the scheduler sinks every read to its MFMA)
+                    __builtin_amdgcn_sched_group_barrier(0x008, NQ * 4 * NA, 0);
                     xs += (GK / KW) * RS;
                 }
             }
@@ -545,56 +591,63 @@ __device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4,
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[((wave * NA + h) * 4 + r) * 64 + lane] = acc[h][r];
     __syncthreads();
-    for (int e = tid; e < NA * 256; e += kNetThreads) {
-        const int h = e >> 8, r = (e >> 6) & 3, ln = e & 63;
+    // one thread per MFMA output element (mrow, col), a row's N columns in consecutive threads: sum of the 8 waves' partials + bias
+    auto row_cx = [&](int row) { return glu ? ((row < rows) ? (r0 + row) : (d.M + r0 + row - rows)) : (r0 + row); };
+    if (tid < rows_tot * N) {
+        const int mrow = tid / N, col = tid - mrow * N;
+        const int h = col >> 4, ln = ((mrow >> 2) << 4) + (col & 15), r = mrow & 3;
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < kNetWaves; ++w) v += red[((w * NA + h) * 4 + r) * 64 + ln];
-        const int row = 4 * (ln >> 4) + r, col = (ln & 15) + 16 * h;
-        tl[row * 33 + col] = v;
+        v += pe.bias;
+        tl[mrow * 33 + col] = v;
+        d.conv_out[(long long)row_cx(mrow) * N + col] = v;
     }
     __syncthreads();
-    auto row_cx = [&](int row) { return glu ? ((row < rows) ? (r0 + row) : (d.M + r0 + row - rows)) : (r0 + row); };
-    for (int e = tid; e < rows_tot * N; e += kNetThreads) {
-        const int row = e / N, nn = e - row * N;
-        const int cx = row_cx(row);
-        const float bias = glu ? ((row < rows) ? d.bias0[r0 + row] : d.bias1[r0 + row - rows]) : d.bias0[r0 + row];
-        const float v = tl[row * 33 + nn] + bias;
-        tl[row * 33 + nn] = v;
-        d.conv_out[(long long)cx * N + nn] = v;
-    }
-    __syncthreads();
-    if (tid < rows_tot * B) {
-        const int row = tid / B, b = tid - row * B;
-        const float* p = tl + row * 33 + b * T4;
-        float s = 0.f;
-        for (int t = 0; t < T4; ++t) s += p[t];
-        const float mean = s / (float)T4;
-        float q = 0.f;
-        for (int t = 0; t < T4; ++t) { const float dd = p[t] - mean; q += dd * dd; }
-        const float rstd = 1.0f / sqrtf(q / (float)T4 + eps);
-        sstat[(row * B + b) * 2] = mean; sstat[(row * B + b) * 2 + 1] = rstd;
-        float* st = d.stats + ((long long)b * Mtot + row_cx(row)) * 2;
-        st[0] = mean; st[1] = rstd;
-    }
-    __syncthreads();
-    for (int e = tid; e < rows * N; e += kNetThreads) {
-        const int row = e / N, nn = e - row * N;
+    // statistics of (row, sample) over its T4 columns, computed by every thread of the segment (LDS broadcast reads) instead of by
+    // one thread per row behind two more barriers
+    if (tid < rows * N) {
+        const int row = tid / N, col = tid - row * N;
         const int c = r0 + row;
-        const int b = nn / T4, t = nn - b * T4;
-        const float m0 = sstat[(row * B + b) * 2], s0 = sstat[(row * B + b) * 2 + 1];
-        const float z0 = (tl[row * 33 + nn] - m0) * s0 * d.gamma0[c] + d.beta0[c];
+        const int b = col / T4, t = col - b * T4;
+        const bool pow2 = (T4 & (T4 - 1)) == 0;            // (uniform) the T4 lanes of a (row, sample) segment are consecutive and aligned
+        auto stats_of = [&](int mrow, float& mean, float& rstd) {
+            const float* p = tl + mrow * 33 + b * T4;
+            float sum, q;
+            if (pow2) {                                   // butterfly over the segment's lanes: 2 log2(T4) shuffles instead of 2 T4 LDS reads
+                sum = p[t];
+                for (int m = T4 >> 1; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+                mean = sum / (float)T4;
+                const float dd = p[t] - mean;
+                q = dd * dd;
+                for (int m = T4 >> 1; m >= 1; m >>= 1) q += __shfl_xor(q, m);
+            } else {
+                sum = 0.f;
+                for (int u = 0; u < T4; ++u) sum += p[u];
+                mean = sum / (float)T4;
+                q = 0.f;
+                for (int u = 0; u < T4; ++u) { const float dd = p[u] - mean; q += dd * dd; }
+            }
+            rstd = 1.0f / sqrtf(q / (float)T4 + eps);
+            if (t == 0) {
+                float* st = d.stats + ((long long)b * Mtot + row_cx(mrow)) * 2;
+                st[0] = mean; st[1] = rstd;
+            }
+        };
+        float m0, s0;
+        stats_of(row, m0, s0);
+        const float z0 = (tl[row * 33 + col] - m0) * s0 * pe.g0 + pe.b0;
         float y;
         if (glu) {
-            const int rg = row + rows;
-            const float m1 = sstat[(rg * B + b) * 2], s1 = sstat[(rg * B + b) * 2 + 1];
-            const float z1 = (tl[rg * 33 + nn] - m1) * s1 * d.gamma1[c] + d.beta1[c];
+            float m1, s1;
+            stats_of(row + rows, m1, s1);
+            const float z1 = (tl[(row + rows) * 33 + col] - m1) * s1 * pe.g1 + pe.b1;
             y = z0 * sigmoidf_(z1);
         } else {
             y = z0;
         }
         const long long yo = (long long)b * d.y_sn + (long long)c * d.y_sc + t;
-        if (d.res) y += __hip_atomic_load(d.res + yo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (this workgroup's own rows, two layers back)
+        if (d.res) y += pe.res;
         if (wt) st_wt(d.y + yo, y); else d.y[yo] = y;
     }
 }
@@ -611,25 +664,28 @@ __global__ void __launch_bounds__(kNetThreads) trunk_fwd_net_kernel(const TrunkF
         const TrunkLayerDesc& d = a.L[l];
         const int ntiles = d.M / d.rows;
         // this layer's weights do not depend on the previous layer: request them BEFORE waiting for its activations
-        NetW<3> w3; NetW<1> w1;
+        NetW<3> w3; NetW<1> w1; NetE pe;
         const bool mine = (int)blockIdx.x < ntiles;
-        if (mine) { if (d.KW == 3) net_load_w<3>(d, blockIdx.x, w3); else net_load_w<1>(d, blockIdx.x, w1); }
+        if (mine) { if (d.KW == 3) net_load_w<3>(d, blockIdx.x, w3); else net_load_w<1>(d, blockIdx.x, w1); net_load_e(d, a.B, a.T4, blockIdx.x, pe); }
         if (l > 0) {
             if (tid == 0) {
                 const bool ok = wait_arrivals(a.sync + (l - 1), gridDim.x);
                 if (!ok) __hip_atomic_store(a.sync + MCVC_TRUNK_SYNC_WORDS - 1, 1u + (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 flag[0] = ok ? 1.f : 0.f;
             }
-            __syncthreads();
+            // barrier WITHOUT the vmcnt(0) that __syncthreads() implies: the weight / operand loads requested above stay in flight while
+            // the activations are staged (their latencies overlap instead of adding up)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             if (flag[0] == 0.f) return;            // (uniform) a workgroup never arrived: give up instead of hanging the device
         }
         if (d.KW == 3) net_stage_x<3>(d.x, Xs, d.Cin, a.B, a.T4, tid, l > 0); else net_stage_x<1>(d.x, Xs, d.Cin, a.B, a.T4, tid, l > 0);
         __syncthreads();
         const bool wt = (l + 1 < a.nlayers);       // the last layer's output is consumed after the kernel boundary
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-            if (tile != (int)blockIdx.x) { if (d.KW == 3) net_load_w<3>(d, tile, w3); else net_load_w<1>(d, tile, w1); }
-            if (d.KW == 3) net_tile<3, NA>(d, a.B, a.T4, a.eps, tile, Xs, epi, wt, w3);
-            else net_tile<1, NA>(d, a.B, a.T4, a.eps, tile, Xs, epi, wt, w1);
+            if (tile != (int)blockIdx.x) { if (d.KW == 3) net_load_w<3>(d, tile, w3); else net_load_w<1>(d, tile, w1); net_load_e(d, a.B, a.T4, tile, pe); }
+            if (d.KW == 3) net_tile<3, NA>(d, a.B, a.T4, a.eps, tile, Xs, epi, wt, w3, pe);
+            else net_tile<1, NA>(d, a.B, a.T4, a.eps, tile, Xs, epi, wt, w1, pe);
         }
         if (wt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // EVERY storing wave drains its write-through stores

@@ -173,11 +173,12 @@ def test_inference_config_bs16_512_frames(nets, meta):
 
 
 @pytest.mark.parametrize("B,T", [(1, 64), (2, 64), (1, 32), (4, 32), (1, 128)])
-def test_persistent_trunk_forward_is_bit_identical_to_the_per_layer_launches(B, T):
-    """The 13 dependent trunk layers (model.py:258-271) run as ONE persistent launch whose workgroups hand activations to each
-    other inside the kernel (write-through stores, arrival counter, agent-scope acquire).  Same arithmetic as the per-layer
-    fused kernels -> outputs AND every stashed intermediate must be bit-identical; repeated with fresh inputs into the SAME
-    buffers so that a stale L1 / L2 line from the previous pass (the hazard of an in-kernel hand-off) would show up."""
+def test_persistent_trunk_forward_matches_the_per_layer_launches(B, T):
+    """The 12 dependent residual trunk layers (model.py:258-271) run as ONE persistent launch whose workgroups hand activations to each
+    other inside the kernel (write-through stores, arrival counter, sc1 loads).  Same products as the per-layer fused kernels; only
+    the InstanceNorm statistics are summed in a different order (lane butterfly vs serial) -> outputs AND every stashed intermediate
+    agree to 1e-5 of their range; repeated with fresh inputs into the SAME buffers so that a stale L1 / L2 line from the previous pass
+    (the hazard of an in-kernel hand-off: a wrong value, not a rounding difference) would show up."""
     from mask_cyclegan_vc._hip import check, lib, ptr, ptr_table, stream
     L = lib()
     g = Generator()
@@ -200,8 +201,8 @@ def test_persistent_trunk_forward_is_bit_identical_to_the_per_layer_launches(B, 
                 L.mcvc_set_trunk_persistent(on)
                 check(L.mcvc_gen_forward(tab, ptr(packed), ptr(x), ptr(m), ptr(out[k]), ptr(stash[k]), ptr(scratch), n_scr, B, T, stream()), "fwd")
             torch.cuda.synchronize()
-            assert torch.equal(out[0], out[1]), it
-            assert torch.equal(stash[0], stash[1]), it           # conv outputs, statistics, activations of every layer
+            for a_, b_ in ((out[0], out[1]), (stash[0], stash[1])):         # stash: conv outputs, statistics, activations of every layer
+                assert float((a_ - b_).abs().max()) <= 1e-5 * float(b_.abs().max()), it
     finally:
         L.mcvc_set_trunk_persistent(was)
 
