@@ -264,3 +264,47 @@ def test_discriminator_gemm_path_vs_oracle(B, T, nets, meta):
         e = rel_l2(ddict[k].grad, r); worst = max(worst, e)
         assert e < TOL, (k, e)
     print("B=%d T=%d staged-GEMM discriminator: worst parameter-gradient rel-L2 vs oracle %.3e" % (B, T, worst))
+
+
+def test_generator_repack_in_two_parts_and_its_guard():
+    """mcvc_gen_pack_sets: a forward-only refresh (sets = 1) must give the same forward as the full re-pack and must make a backward pass
+    on that buffer FAIL (stale data-gradient copies) until the backward sets (sets = 2) have been refreshed; afterwards the gradients
+    equal those of the full re-pack bit for bit."""
+    from mask_cyclegan_vc._hip import check, lib, ptr, ptr_table, stream
+    L = lib()
+    B, T = 1, 64
+    g = Generator()
+    g.load_state_dict(orc.filler_params("G", 41), strict=True)
+    g = g.cuda()
+    ps = list(g.parameters())
+    tab = ptr_table(ps)
+    n_stash, n_scr = L.mcvc_gen_stash_floats(B, T), L.mcvc_gen_scratch_floats(B, T)
+    x = torch.randn(B, 80, T, device="cuda"); m = torch.ones_like(x)
+    dout = torch.randn(B, 80, T, device="cuda")
+
+    def run(packed, expect_bwd_rc=0):
+        stash = torch.zeros(n_stash, device="cuda"); scr = torch.zeros(n_scr, device="cuda")
+        out = torch.empty(B, 80, T, device="cuda")
+        grads = [torch.zeros_like(p) for p in ps]
+        check(L.mcvc_gen_forward(tab, ptr(packed), ptr(x), ptr(m), ptr(out), ptr(stash), ptr(scr), n_scr, B, T, stream()), "fwd")
+        rc = L.mcvc_gen_backward(tab, ptr(packed), ptr_table(grads), ptr(m), ptr(dout), None, 0, ptr(stash), ptr(scr), n_scr, B, T, stream(), None)
+        torch.cuda.synchronize()
+        assert (rc == 0) == (expect_bwd_rc == 0), rc
+        return out, grads
+
+    full = torch.zeros(L.mcvc_gen_packed_floats(), device="cuda")
+    check(L.mcvc_gen_pack_sets(tab, ptr(full), 2 * B, T, 3, stream()), "pack")
+    out_ref, grads_ref = run(full)
+    two = torch.zeros_like(full)
+    check(L.mcvc_gen_pack_sets(tab, ptr(two), 2 * B, T, 1, stream()), "pack fwd")
+    out_fwd, _ = run(two, expect_bwd_rc=1)                      # backward refused: its weight copies were not refreshed
+    assert torch.equal(out_fwd, out_ref)
+    check(L.mcvc_gen_pack_sets(tab, ptr(two), 2 * B, T, 2, stream()), "pack bwd")
+    out2, grads2 = run(two)
+    assert torch.equal(out2, out_ref)
+    L.mcvc_set_deterministic(1)
+    try:
+        _, ga = run(full); _, gb = run(two)
+        assert all(torch.equal(a, b) for a, b in zip(ga, gb))
+    finally:
+        L.mcvc_set_deterministic(0)
