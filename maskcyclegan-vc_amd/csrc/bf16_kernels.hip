@@ -95,36 +95,34 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     unsigned char* Xs = smem;                                             // [patch_px][64 B]
     const int wbuf_bytes = BM * KW * 64;
     unsigned char* Ws = smem + (((size_t)patch_px * 64 + 255) & ~(size_t)255);   // wbufs x [BM][KW][64 B]
-    const bool wdouble = a.wbufs > 1;
 
     const int ncc = a.Cin >> 5;
     const int nstage = ncc * a.KH;                                        // stage = (cc, kh): KW taps x 32 input channels
     const int w_pieces = BM * KW * 4;                                     // 16-byte pieces per weight stage
-    uint4 wreg[kMaxWP];
+    // Weights go HBM / L2 -> LDS by direct DMA (global_load_lds, 16 B per lane, no registers) into a double buffer: the copy of stage s+1
+    // is in flight during the MFMAs of stage s.  (Round 2 staged them through a register array that the compiler had placed in SCRATCH
+    // memory -- global load -> wait -> scratch store -> scratch load -> LDS store per stage, the load latency fully exposed: an in-kernel
+    // clock showed 1.3 us of store + 4.8 us "MFMA" phase per stage for 1.1 us of MFMA work.)
+    constexpr int NWP = KWT > 0 ? (BM * KWT * 4 + kConvThreads - 1) / kConvThreads : kMaxWP;
     // piece -> (weight row, tap, swizzled chunk) is stage-invariant: element offsets computed once
-    int woff[kMaxWP];
+    int woff[NWP];
 #pragma unroll
-    for (int i = 0; i < kMaxWP; ++i) {
+    for (int i = 0; i < NWP; ++i) {
         const int q = tid + i * kConvThreads;
         const int row = q / (KW * 4), rem = q - row * (KW * 4);
         const int tap = rem >> 2, pos = rem & 3;
-        const int lc = pos ^ ((row >> 2) & 3);
+        const int lc = pos ^ ((row >> 1) & 3);
         woff[i] = (q < w_pieces) ? ((co0 + row) * a.KH * ncc * KW + tap) * 32 + lc * 8 : -1;
     }
-    auto load_w = [&](int stage) {
+    auto issue_w = [&](int stage, int buf) {
         const int cc = stage / a.KH, kh = stage - cc * a.KH;
         const bf16_t* base = a.w + (long long)(kh * ncc + cc) * KW * 32;
-#pragma unroll
-        for (int i = 0; i < kMaxWP; ++i)
-            if (woff[i] >= 0) wreg[i] = *reinterpret_cast<const uint4*>(base + woff[i]);
-    };
-    auto store_w = [&](int buf) {
         unsigned char* dst = Ws + buf * wbuf_bytes;
 #pragma unroll
-        for (int i = 0; i < kMaxWP; ++i) {
-            const int q = tid + i * kConvThreads;
-            if (q < w_pieces) *reinterpret_cast<uint4*>(dst + (size_t)q * 16) = wreg[i];
-        }
+        for (int i = 0; i < NWP; ++i)
+            if (woff[i] >= 0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + woff[i]),
+                                                 (__attribute__((address_space(3))) void*)(dst + (size_t)(wave * 64 + i * kConvThreads) * 16), 16, 0, 0);
     };
     // ---- input patch: small patches (<= kMaxPP pieces per thread) are prefetched through registers one chunk ahead; large ones
     //      (stride-2 layers) are staged synchronously, four loads in flight per thread
@@ -142,16 +140,16 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
         const int pr = pp / a.PW, pc = pp - pr * a.PW;
         const int ih = ih0 + pr, iw = iw0 + patch_col(pc);
         const bool ok = p_pref && q < patch_pieces && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        poff[i] = ok ? ((long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 2) & 3)) * 8) : -1;
+        poff[i] = ok ? ((long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 1) & 3)) * 8) : -1;
     }
     const bf16_t* ximg = a.x + (long long)n_img * a.x_sn;
     uint4 preg[kMaxPP];
-    auto load_patch = [&](int cc) {
+    auto load_patch = [&](int cc) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < kMaxPP; ++i)
             preg[i] = (poff[i] >= 0) ? *reinterpret_cast<const uint4*>(ximg + cc * 32 + poff[i]) : make_uint4(0u, 0u, 0u, 0u);
     };
-    auto store_patch = [&]() {
+    auto store_patch = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < kMaxPP; ++i) {
             const int q = tid + i * kConvThreads;
@@ -170,7 +168,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
                 const int ih = ih0 + pr, iw = iw0 + patch_col(pc);
                 v[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (q < patch_pieces && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-                    v[u] = *reinterpret_cast<const uint4*>(xb + (long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 2) & 3)) * 8);
+                    v[u] = *reinterpret_cast<const uint4*>(xb + (long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 1) & 3)) * 8);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -183,7 +181,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     // ---- per-lane operand coordinates
     int rowA[MT], gA[MT], ppB[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { rowA[mt] = (wm * MT + mt) * 32 + l31; gA[mt] = (rowA[mt] >> 2) & 3; }
+    for (int mt = 0; mt < MT; ++mt) { rowA[mt] = (wm * MT + mt) * 32 + l31; gA[mt] = (rowA[mt] >> 1) & 3; }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = (wn * NT + nt) * 32 + l31;
@@ -198,46 +196,62 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    load_w(0);
+    issue_w(0, 0);
     if (p_pref) load_patch(0);
     for (int stage = 0; stage < nstage; ++stage) {
         const int cc = stage / a.KH, kh = stage - cc * a.KH;
-        const int buf = wdouble ? (stage & 1) : 0;
-        if (kh == 0 || !wdouble) {
-            if (stage > 0) __syncthreads();                 // every wave is done reading the previous patch / the single weight buffer
-        }
-        if (kh == 0) { if (p_pref) store_patch(); else stage_patch_sync(cc); }
-        store_w(buf);
+        const int buf = stage & 1;
+        // everything requested during the previous stage (this stage's weights, the next chunk's patch registers) has had that stage's
+        // MFMAs to land; the barrier also says every wave is done reading the buffer the next copy overwrites
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (stage + 1 < nstage) load_w(stage + 1);          // in flight during the MFMAs below
+        if (kh == 0) {
+            if (p_pref) store_patch(); else stage_patch_sync(cc);
+            __syncthreads();
+        }
+        if (stage + 1 < nstage) issue_w(stage + 1, buf ^ 1);          // in flight during the MFMAs below
         if (p_pref && kh == a.KH - 1 && cc + 1 < ncc) load_patch(cc + 1);
         const unsigned char* Wb = Ws + buf * wbuf_bytes;
         const int pk = kh * a.PW;
-        auto tap_step = [&](int tap) {
+        // one step = (tap, 16-channel half) = MT + NT operand reads (ds_read_b128) and MT * NT MFMAs
+        auto load_step = [&](int step, bf16x8 (&av)[MT], bf16x8 (&bv)[NT]) {
+            const int tap = step >> 1, lc = (step & 1) * 2 + half;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int lc = ks * 2 + half;
-                bf16x8 av[MT], bv[NT];
+            for (int mt = 0; mt < MT; ++mt)
+                av[mt] = *reinterpret_cast<const bf16x8*>(Wb + (size_t)(((rowA[mt] * KW + tap) << 2) + (lc ^ gA[mt])) * 16);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    av[mt] = *reinterpret_cast<const bf16x8*>(Wb + (size_t)(((rowA[mt] * KW + tap) << 2) + (lc ^ gA[mt])) * 16);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int pp = ppB[nt] + pk + (s2 ? (tap >> 1) + (tap & 1) * PWe : tap);
-                    bv[nt] = *reinterpret_cast<const bf16x8*>(Xs + (size_t)((pp << 2) + (lc ^ ((pp >> 2) & 3))) * 16);
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+                const int pp = ppB[nt] + pk + (s2 ? (tap >> 1) + (tap & 1) * PWe : tap);
+                bv[nt] = *reinterpret_cast<const bf16x8*>(Xs + (size_t)((pp << 2) + (lc ^ ((pp >> 1) & 3))) * 16);
             }
         };
-        if constexpr (KWT > 0) {
+        auto mfma_step = [&](const bf16x8 (&av)[MT], const bf16x8 (&bv)[NT]) {
 #pragma unroll
-            for (int tap = 0; tap < KWT; ++tap) tap_step(tap);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        };
+        if constexpr (KWT > 0) {
+            // software pipeline over the 2 * KW steps of the stage: the operands of step s+1 are read while step s multiplies, and the
+            // order is pinned (left alone the scheduler sinks reads next to their MFMAs: ds_read_b128 -> s_waitcnt lgkmcnt(0) -> v_mfma,
+            // an LDS round trip per few MFMAs, which a single wave per SIMD cannot hide)
+            bf16x8 av[2][MT], bv[2][NT];
+            load_step(0, av[0], bv[0]);
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+#pragma unroll
+            for (int step = 0; step < 2 * KWT; ++step) {
+                if (step + 1 < 2 * KWT) load_step(step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
+                mfma_step(av[step & 1], bv[step & 1]);
+                if (step + 1 < 2 * KWT) __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+            }
         } else {
-            for (int tap = 0; tap < KW; ++tap) tap_step(tap);
+            for (int step = 0; step < 2 * KW; ++step) {
+                bf16x8 av[MT], bv[NT];
+                load_step(step, av, bv);
+                mfma_step(av, bv);
+            }
         }
     }
 
@@ -319,7 +333,7 @@ int conv_launch_kw(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
 
 }  // namespace
 
-// tile configuration: 0 = 128 channels x 128 pixels, 1 = 64 x 64 (few pixels: more workgroups), 2 = 32 x 128 (few output channels),
+// tile configuration: 4 = 128 channels x 256 pixels (large stride-1 layers), 0 = 128 channels x 128 pixels, 1 = 64 x 64 (few pixels: more workgroups), 2 = 32 x 128 (few output channels),
 // 3 = 128 x 64 (tried for the stride-2 layers -- two workgroups per CU instead of one: measured SLOWER, 187 vs 206 TF/s, so it is
 // only reachable through MCVC_BF16_CFG=3 for experiments)
 static int conv_config(const Bf16ConvArgs& a)
@@ -328,6 +342,9 @@ static int conv_config(const Bf16ConvArgs& a)
     if (a.Cout_pad % 64 != 0) return 2;
     if (knob == 3 && a.stride == 2 && a.Cout_pad % 128 == 0 && !a.glu) return 3;
     const long long px = (long long)a.N * a.OH * a.OW;
+    // 128 channels x 256 pixels: a workgroup streams its 128 x KH x KW x Cin weight slice once per PIXEL tile, and on the large stride-1
+    // layers that L2 -> LDS weight stream (16 GB per launch at 128 pixels per tile) is the limit: twice the pixels, half the stream
+    if (a.Cout_pad % 128 == 0 && a.stride == 1 && a.KW >= 3 && knob != 0 && (knob == 4 || (a.Cout_pad / 128) * ((px + 255) / 256) >= 1024)) return 4;
     if (a.Cout_pad % 128 != 0 || a.glu == 0) {
         // small problems: 128 x 128 tiles would leave most of the 256 CUs idle
         const long long wg128 = (a.Cout_pad / 128) * ((px + 127) / 128);
@@ -357,23 +374,23 @@ int mcvc_bf16_conv_launch(const Bf16ConvArgs& a0, hipStream_t s)
     Bf16ConvArgs a = a0;
     if ((a.Cin & 31) || (a.Cout & 3) || a.KW < 1 || a.KH < 1) return MCVC_ERR_INVALID;
     const int cfg = conv_config(a);
-    const int BM = (cfg == 0 || cfg == 3) ? 128 : (cfg == 1 ? 64 : 32), BN = (cfg == 1 || cfg == 3) ? 64 : 128;
+    const int BM = (cfg == 0 || cfg == 3 || cfg == 4) ? 128 : (cfg == 1 ? 64 : 32), BN = (cfg == 4) ? 256 : ((cfg == 1 || cfg == 3) ? 64 : 128);
     if (a.Cout_pad % BM) return MCVC_ERR_INVALID;
-    if (a.glu && cfg != 0) return MCVC_ERR_INVALID;
+    if (a.glu && cfg != 0 && cfg != 4) return MCVC_ERR_INVALID;
     mcvc_bf16_conv_tile(a.OH, a.OW, a.KH, a.KW, a.stride, BN, &a.TH, &a.tw_log2);
     const int TW = 1 << a.tw_log2;
     a.tiles_h = cdiv_i(a.OH, a.TH); a.tiles_w = cdiv_i(a.OW, TW);
     a.PH = (a.TH - 1) * a.stride + a.KH; a.PW = (TW - 1) * a.stride + a.KW;
     if (BM * a.KW * 4 > kMaxWP * kConvThreads) return MCVC_ERR_INVALID;
     const size_t patch = ((size_t)a.PH * a.PW * 64 + 255) & ~(size_t)255, wb = (size_t)BM * a.KW * 64;
-    // two workgroups per CU hide each other's barriers and load latencies: single weight buffer when that is what makes two fit
-    a.wbufs = (patch + 2 * wb <= 80 * 1024) ? 2 : ((patch + wb <= 80 * 1024) ? 1 : 2);
+    a.wbufs = 2;                    // weight stages alternate between two LDS buffers (DMA of the next one during the MFMAs)
     const size_t lds = patch + a.wbufs * wb;
     if (lds > 160 * 1024) return MCVC_ERR_INVALID;
     const double px = (double)a.N * a.OH * a.OW;
     TraceScope ts(K_CONV_L, s, 2.0 * px * a.Cout_pad * a.Cin * a.KH * a.KW,
                   2.0 * ((double)a.N * a.H * a.W * a.Cin + px * a.Cout + (double)a.Cout_pad * a.Cin * a.KH * a.KW));
     if (cfg == 0) return conv_launch_kw<2, 2, 2, 2>(a, lds, s);
+    if (cfg == 4) return conv_launch_kw<2, 2, 2, 4>(a, lds, s);
     if (cfg == 1) return conv_launch_kw<2, 2, 1, 1>(a, lds, s);
     if (cfg == 3) return conv_launch_kw<2, 2, 2, 1>(a, lds, s);
     return conv_launch_kw<1, 4, 1, 1>(a, lds, s);
