@@ -8,8 +8,9 @@
 //   * LDS rows are 64 bytes (32 channels) per pixel / per (weight row, tap); the four 16-byte chunks of a row are XOR-swizzled
 //     with bits 2-3 of the row index, which makes the 16-lane groups of ds_read_b128 hit 16 distinct 16-byte bank slots
 //     (stride-1 pixels and odd KW; stride-2 pixel reads are 2-way).
-//   * weights stream per (kh, ci-chunk) stage through registers into a double buffer: the global loads of stage s+1 are in
-//     flight while the MFMAs of stage s run; one __syncthreads() per stage.
+//   * weights stream per (kh, ci-chunk) stage by LDS-DMA (global_load_lds, 16 B per lane) into a double buffer: the copy of stage
+//     s+1 is in flight while the MFMAs of stage s run; one s_waitcnt vmcnt(0) + __syncthreads() per stage.  A stage's 2*KW
+//     (tap, 16-channel) steps are software-pipelined: the operands of step s+1 are read while step s multiplies.
 #include "mcvc_common.h"
 #include "bf16.h"
 #include "trace.h"
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
         const int q = tid + i * kConvThreads;
         const int row = q / (KW * 4), rem = q - row * (KW * 4);
         const int tap = rem >> 2, pos = rem & 3;
-        const int lc = pos ^ ((row >> 1) & 3);
+        const int lc = pos ^ ((row >> 2) & 3);
         woff[i] = (q < w_pieces) ? ((co0 + row) * a.KH * ncc * KW + tap) * 32 + lc * 8 : -1;
     }
     auto issue_w = [&](int stage, int buf) {
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
         const int pr = pp / a.PW, pc = pp - pr * a.PW;
         const int ih = ih0 + pr, iw = iw0 + patch_col(pc);
         const bool ok = p_pref && q < patch_pieces && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        poff[i] = ok ? ((long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 1) & 3)) * 8) : -1;
+        poff[i] = ok ? ((long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 2) & 3)) * 8) : -1;
     }
     const bf16_t* ximg = a.x + (long long)n_img * a.x_sn;
     uint4 preg[kMaxPP];
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
                 const int ih = ih0 + pr, iw = iw0 + patch_col(pc);
                 v[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (q < patch_pieces && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W)
-                    v[u] = *reinterpret_cast<const uint4*>(xb + (long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 1) & 3)) * 8);
+                    v[u] = *reinterpret_cast<const uint4*>(xb + (long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 2) & 3)) * 8);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     // ---- per-lane operand coordinates
     int rowA[MT], gA[MT], ppB[NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { rowA[mt] = (wm * MT + mt) * 32 + l31; gA[mt] = (rowA[mt] >> 1) & 3; }
+    for (int mt = 0; mt < MT; ++mt) { rowA[mt] = (wm * MT + mt) * 32 + l31; gA[mt] = (rowA[mt] >> 2) & 3; }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = (wn * NT + nt) * 32 + l31;
@@ -222,7 +223,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int pp = ppB[nt] + pk + (s2 ? (tap >> 1) + (tap & 1) * PWe : tap);
-                bv[nt] = *reinterpret_cast<const bf16x8*>(Xs + (size_t)((pp << 2) + (lc ^ ((pp >> 1) & 3))) * 16);
+                bv[nt] = *reinterpret_cast<const bf16x8*>(Xs + (size_t)((pp << 2) + (lc ^ ((pp >> 2) & 3))) * 16);
             }
         };
         auto mfma_step = [&](const bf16x8 (&av)[MT], const bf16x8 (&bv)[NT]) {
