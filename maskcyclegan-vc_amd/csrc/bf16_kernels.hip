@@ -345,6 +345,10 @@ static int conv_config(const Bf16ConvArgs& a)
     const long long px = (long long)a.N * a.OH * a.OW;
     // 128 channels x 256 pixels: a workgroup streams its 128 x KH x KW x Cin weight slice once per PIXEL tile, and on the large stride-1
     // layers that L2 -> LDS weight stream (16 GB per launch at 128 pixels per tile) is the limit: twice the pixels, half the stream
+    // 128 channels x 512 pixels, four waves side by side with 4 x 4 accumulators each: 0.5 operand reads (ds_read_b128) per MFMA instead
+    // of 0.75 -- at one wave per SIMD the LDS read port, not the matrix pipe, sets the pace of a stage
+    if (a.Cout_pad % 128 == 0 && a.stride == 1 && a.KW >= 3 && !a.glu && knob != 0 && knob != 4 && (knob == 5 || (a.Cout_pad / 128) * ((px + 511) / 512) >= 512))
+        return 5;
     if (a.Cout_pad % 128 == 0 && a.stride == 1 && a.KW >= 3 && knob != 0 && (knob == 4 || (a.Cout_pad / 128) * ((px + 255) / 256) >= 1024)) return 4;
     if (a.Cout_pad % 128 != 0 || a.glu == 0) {
         // small problems: 128 x 128 tiles would leave most of the 256 CUs idle
@@ -375,7 +379,8 @@ int mcvc_bf16_conv_launch(const Bf16ConvArgs& a0, hipStream_t s)
     Bf16ConvArgs a = a0;
     if ((a.Cin & 31) || (a.Cout & 3) || a.KW < 1 || a.KH < 1) return MCVC_ERR_INVALID;
     const int cfg = conv_config(a);
-    const int BM = (cfg == 0 || cfg == 3 || cfg == 4) ? 128 : (cfg == 1 ? 64 : 32), BN = (cfg == 4) ? 256 : ((cfg == 1 || cfg == 3) ? 64 : 128);
+    const int BM = (cfg == 0 || cfg == 3 || cfg == 4 || cfg == 5) ? 128 : (cfg == 1 ? 64 : 32);
+    const int BN = (cfg == 5) ? 512 : ((cfg == 4) ? 256 : ((cfg == 1 || cfg == 3) ? 64 : 128));
     if (a.Cout_pad % BM) return MCVC_ERR_INVALID;
     if (a.glu && cfg != 0 && cfg != 4) return MCVC_ERR_INVALID;
     mcvc_bf16_conv_tile(a.OH, a.OW, a.KH, a.KW, a.stride, BN, &a.TH, &a.tw_log2);
@@ -392,6 +397,7 @@ int mcvc_bf16_conv_launch(const Bf16ConvArgs& a0, hipStream_t s)
                   2.0 * ((double)a.N * a.H * a.W * a.Cin + px * a.Cout + (double)a.Cout_pad * a.Cin * a.KH * a.KW));
     if (cfg == 0) return conv_launch_kw<2, 2, 2, 2>(a, lds, s);
     if (cfg == 4) return conv_launch_kw<2, 2, 2, 4>(a, lds, s);
+    if (cfg == 5) return conv_launch_kw<1, 4, 4, 4>(a, lds, s);
     if (cfg == 1) return conv_launch_kw<2, 2, 1, 1>(a, lds, s);
     if (cfg == 3) return conv_launch_kw<2, 2, 2, 1>(a, lds, s);
     return conv_launch_kw<1, 4, 1, 1>(a, lds, s);
@@ -487,33 +493,29 @@ __global__ void __launch_bounds__(256) bf16_apply_kernel(const Bf16NormArgs a)
     const int C = a.shuffle ? a.Cx / 4 : (a.act == BF16_ACT_GLU ? a.Cx / 2 : a.Cx);      // output channels
     const int noct = C >> 3;
     const int P = a.H * a.W;
-    const long long total = (long long)a.N * P * noct;
-    const long long stride = (long long)gridDim.x * 256;
-    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int c0 = (int)(idx % noct) * 8;
+    // grid (x, n): one image per blockIdx.y, 32-bit index arithmetic (the 64-bit divisions of a flat (n, pixel, octet) index made this
+    // pass ALU-bound at ~1.5 TB/s); the launcher makes the x stride a multiple of the octet count, so a thread keeps its channel octet
+    const int n = blockIdx.y;
+    const int stride = (int)gridDim.x * 256;
+    const int pstep = stride / noct;
+    int idx = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int c0 = (idx % noct) * 8;
     const int Cs = (a.act == BF16_ACT_GLU) ? 2 * C : C;                                    // channels of the statistics table
-    float g0[8], b0[8], g1[8], b1[8], sc0[8], sh0[8], sc1[8], sh1[8];                      // z = x * sc + sh
+    float sc0[8], sh0[8], sc1[8], sh1[8];                                                  // z = x * sc + sh
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        g0[j] = a.has_norm ? a.gamma[0][c0 + j] : 1.f; b0[j] = a.has_norm ? a.beta[0][c0 + j] : 0.f;
-        g1[j] = (a.has_norm && a.act == BF16_ACT_GLU) ? a.gamma[1][c0 + j] : 1.f;
-        b1[j] = (a.has_norm && a.act == BF16_ACT_GLU) ? a.beta[1][c0 + j] : 0.f;
-        sc0[j] = g0[j]; sh0[j] = b0[j]; sc1[j] = g1[j]; sh1[j] = b1[j];
-    }
-    int n_cached = -1;
-    for (; idx < total; idx += stride) {
-        const long long pix = idx / noct;
-        const int n = (int)(pix / P), p = (int)(pix - (long long)n * P);
-        const int h = p / a.W, w = p - h * a.W;
-        if (a.has_norm && n != n_cached) {
-            n_cached = n;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float* st = a.stats + ((long long)n * Cs + c0 + j) * 2;
-                sc0[j] = st[1] * g0[j]; sh0[j] = b0[j] - st[0] * sc0[j];
-                if (a.act == BF16_ACT_GLU) { const float* sg = st + 2 * C; sc1[j] = sg[1] * g1[j]; sh1[j] = b1[j] - sg[0] * sc1[j]; }
-            }
+        const float g0 = a.has_norm ? a.gamma[0][c0 + j] : 1.f, b0 = a.has_norm ? a.beta[0][c0 + j] : 0.f;
+        const float g1 = (a.has_norm && a.act == BF16_ACT_GLU) ? a.gamma[1][c0 + j] : 1.f;
+        const float b1 = (a.has_norm && a.act == BF16_ACT_GLU) ? a.beta[1][c0 + j] : 0.f;
+        sc0[j] = g0; sh0[j] = b0; sc1[j] = g1; sh1[j] = b1;
+        if (a.has_norm) {
+            const float* st = a.stats + ((long long)n * Cs + c0 + j) * 2;
+            sc0[j] = st[1] * g0; sh0[j] = b0 - st[0] * sc0[j];
+            if (a.act == BF16_ACT_GLU) { const float* sg = st + 2 * C; sc1[j] = sg[1] * g1; sh1[j] = b1 - sg[0] * sc1[j]; }
         }
+    }
+    for (int p = idx / noct; p < P; p += pstep) {
+        const int h = p / a.W, w = p - h * a.W;
         const bf16_t* xp = a.x + (long long)n * a.x_sn + (long long)h * a.x_sh + (long long)w * a.x_sw;
         auto out_ptr = [&](int oh, int ow) {
             long long o = (long long)n * a.y_sn + (long long)oh * a.y_sh + (long long)ow * a.y_sw;
@@ -596,9 +598,10 @@ int mcvc_bf16_norm_launch(const Bf16NormArgs& a, hipStream_t s)
         const int Cn = a.shuffle ? a.Cx / 4 : a.Cx;
         hipLaunchKernelGGL(bf16_finalize_kernel, dim3((unsigned)cdiv_ll((long long)a.N * Cn, 256)), dim3(256), 0, s, a);
     }
-    const long long work = (long long)a.N * a.H * a.W * (C >> 3);
+    const long long work = (long long)a.H * a.W * (C >> 3);           // per image (grid.y = image)
     long long blocks = cdiv_ll(work, 256 * 4);              // ~4 pixels per thread
-    if (blocks > 4096) blocks = 4096;
+    const long long cap = 4096 / (a.N < 1 ? 1 : a.N) + 1;
+    if (blocks > cap) blocks = cap;
     {   // grid stride a multiple of the octet count: a thread keeps its channel octet (statistics stay in registers)
         const int noct = C >> 3;
         int g = noct, r = 256;
@@ -607,7 +610,7 @@ int mcvc_bf16_norm_launch(const Bf16NormArgs& a, hipStream_t s)
         blocks = cdiv_ll(blocks, unit) * unit;
     }
     TraceScope ts(K_NORM_FWD, s, 0.0, 2.0 * (el + (double)a.N * a.H * a.W * C * (a.shuffle ? 4.0 : 1.0)));
-    hipLaunchKernelGGL(bf16_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bf16_apply_kernel, dim3((unsigned)blocks, (unsigned)a.N), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
