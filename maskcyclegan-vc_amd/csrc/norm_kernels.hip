@@ -301,7 +301,13 @@ __global__ void __launch_bounds__(256) norm_bwd_reg_kernel(const NormBwdArgs a)
     float gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f};
     for (int br = 0; br < nbr; ++br) { gam[br] = a.gamma[br][c]; bet[br] = a.beta[br][c]; }
     float dgam[2] = {0.f, 0.f}, dbet[2] = {0.f, 0.f};
-    for (int n = 0; n < a.N; ++n) {
+    // blockIdx.y = a chunk of samples (large batches: the per-sample work is independent, only dgamma / dbeta are sums over samples;
+    // with more than one chunk they are added with atomics -- the launcher uses one chunk in deterministic mode)
+    const int nchunk = (int)gridDim.y;
+    const int n_per = (a.N + nchunk - 1) / nchunk;
+    const int n_begin = (int)blockIdx.y * n_per;
+    const int n_end = (n_begin + n_per < a.N) ? n_begin + n_per : a.N;
+    for (int n = n_begin; n < n_end; ++n) {
         float xh[2][E], dz[2][E], dyv[E];
         int hh[E], ww[E];
         const long long yoff0 = (long long)n * a.y_sn + (long long)c * a.y_sc;
@@ -382,10 +388,15 @@ __global__ void __launch_bounds__(256) norm_bwd_reg_kernel(const NormBwdArgs a)
             }
         }
     }
-    if (l == 0) {
+    if (l == 0 && n_begin < n_end) {
         for (int br = 0; br < nbr; ++br) {
-            if (a.dgamma[br]) a.dgamma[br][c] += dgam[br];
-            if (a.dbeta[br]) a.dbeta[br][c] += dbet[br];
+            if (nchunk > 1) {
+                if (a.dgamma[br]) unsafeAtomicAdd(&a.dgamma[br][c], dgam[br]);
+                if (a.dbeta[br]) unsafeAtomicAdd(&a.dbeta[br][c], dbet[br]);
+            } else {
+                if (a.dgamma[br]) a.dgamma[br][c] += dgam[br];
+                if (a.dbeta[br]) a.dbeta[br][c] += dbet[br];
+            }
         }
     }
 }
@@ -484,7 +495,14 @@ int mcvc_norm_bwd_launch(const NormBwdArgs& a, hipStream_t s)
     const unsigned blocks = (unsigned)cdiv_i(a.C, 256 / G);
     const double el = (double)a.N * a.C * P;
     TraceScope ts(K_NORM_BWD, s, 0.0, 4.0 * el * ((a.act == ACT_GLU ? 4 : 2) + a.nslab));
-#define MCVC_BWD_REG(GG, EE) { hipLaunchKernelGGL((norm_bwd_reg_kernel<GG, EE>), dim3((unsigned)cdiv_i(a.C, 256 / GG)), dim3(256), 0, s, a); return (int)hipGetLastError(); }
+    // sample chunks: enough workgroups for the chip when the channel blocks alone are few (one chunk = the deterministic order)
+    auto chunks = [&](int cblocks) {
+        int nc = 1;
+        if (!mcvc_deterministic())
+            while (2 * nc <= a.N && nc < 32 && cblocks * nc < 768) nc *= 2;
+        return nc;
+    };
+#define MCVC_BWD_REG(GG, EE) { const int cb = cdiv_i(a.C, 256 / GG); hipLaunchKernelGGL((norm_bwd_reg_kernel<GG, EE>), dim3((unsigned)cb, (unsigned)chunks(cb)), dim3(256), 0, s, a); return (int)hipGetLastError(); }
     if (P <= 16) MCVC_BWD_REG(16, 1)
     if (P <= 64) MCVC_BWD_REG(16, 4)
     if (P <= 128) MCVC_BWD_REG(64, 2)
