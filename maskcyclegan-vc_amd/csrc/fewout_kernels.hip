@@ -222,3 +222,97 @@ int mcvc_fewout_launch(const ConvProblem& p, int NB, const ConvIO& io, const flo
     if (p.KW == 15) return co == 1 ? few_launch_t<1, 15>(a, grid, lds, s) : co == 2 ? few_launch_t<2, 15>(a, grid, lds, s) : few_launch_t<4, 15>(a, grid, lds, s);
     return co == 1 ? few_launch_t<1, 3>(a, grid, lds, s) : co == 2 ? few_launch_t<2, 3>(a, grid, lds, s) : few_launch_t<4, 3>(a, grid, lds, s);
 }
+
+// ---- weight gradient of a convolution with ONE output channel (stride 1) ----------------------------------------------------------
+// lastConvLayer (128 -> 1, 5x15) and the discriminator's output conv (1024 -> 1, 1x3): dW[ci][kh][kw] += sum over samples and pixels of
+// dy[oh][ow] * x[ci][oh + kh - ph][ow + kw - pw].  On the MFMA weight-gradient kernel one of 32 rows did useful work (66-80 us per launch
+// at bs=1, 2 ms at 64 samples).  Here a workgroup owns one input channel (and a chunk of the samples): the dy plane and the haloed x plane
+// sit in LDS, thread (tap, row group) slides its tap over its rows -- dy reads are broadcasts, x reads walk consecutive columns -- and
+// the row groups are summed through LDS.  With more than one sample chunk the result is added with atomics (one chunk in deterministic mode).
+namespace {
+
+struct FewWgradArgs {
+    const float* x; long long x_sn, x_sc; int x_sh;
+    const float* dy; long long dy_sn; int dy_sh;
+    float* dw;                    // [Cin][KH][KW]
+    int N, Cin, H, W, KH, KW, ph, pw;
+    int XW;                       // LDS pitch of the haloed x plane
+};
+
+__global__ void __launch_bounds__(256) wgrad_cout1_kernel(const FewWgradArgs a)
+{
+    extern __shared__ float sm[];
+    const int XH = a.H + a.KH - 1;
+    float* xs = sm;                              // [XH][XW]
+    float* dys = sm + XH * a.XW;                 // [H][W]
+    float* red = dys + a.H * a.W;                // [groups][taps]
+    const int tid = threadIdx.x;
+    const int ci = blockIdx.x;
+    const int ntap = a.KH * a.KW;
+    const int ngr = 256 / ntap;
+    const int tap = tid % ntap, rg = tid / ntap;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int nchunk = (int)gridDim.y;
+    const int n_per = (a.N + nchunk - 1) / nchunk;
+    const int n_begin = (int)blockIdx.y * n_per;
+    const int n_end = (n_begin + n_per < a.N) ? n_begin + n_per : a.N;
+    float acc = 0.f;
+    for (int n = n_begin; n < n_end; ++n) {
+        const float* xp = a.x + (long long)n * a.x_sn + (long long)ci * a.x_sc;
+        for (int i = tid; i < XH * a.XW; i += 256) {
+            const int r = i / a.XW, c = i - r * a.XW;
+            const int ih = r - a.ph, iw = c - a.pw;
+            xs[i] = (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) ? xp[(long long)ih * a.x_sh + iw] : 0.f;
+        }
+        const float* dp = a.dy + (long long)n * a.dy_sn;
+        for (int i = tid; i < a.H * a.W; i += 256) { const int r = i / a.W, c = i - r * a.W; dys[i] = dp[(long long)r * a.dy_sh + c]; }
+        __syncthreads();
+        if (rg < ngr) {
+            for (int oh = rg; oh < a.H; oh += ngr) {
+                const float* d = dys + oh * a.W;
+                const float* xr = xs + (oh + kh) * a.XW + kw;
+                float s0 = 0.f, s1 = 0.f;
+                int ow = 0;
+                for (; ow + 1 < a.W; ow += 2) { s0 += d[ow] * xr[ow]; s1 += d[ow + 1] * xr[ow + 1]; }
+                if (ow < a.W) s0 += d[ow] * xr[ow];
+                acc += s0 + s1;
+            }
+        }
+        __syncthreads();
+    }
+    if (rg < ngr) red[rg * ntap + tap] = acc;
+    __syncthreads();
+    if (tid < ntap && n_begin < n_end) {
+        float s = 0.f;
+        for (int g = 0; g < ngr; ++g) s += red[g * ntap + tid];
+        float* d = a.dw + (long long)ci * ntap + tid;
+        if (nchunk > 1) unsafeAtomicAdd(d, s); else *d += s;
+    }
+}
+
+}  // namespace
+
+bool mcvc_wgrad_cout1_applies(const ConvProblem& p)
+{
+    if (p.Cout != 1 || p.stride != 1 || p.KH * p.KW > 128 || p.OH != p.H || p.OW != p.W) return false;
+    const int XW = p.W + p.KW - 1;
+    const size_t lds = ((size_t)(p.H + p.KH - 1) * XW + (size_t)p.H * p.W + 256) * sizeof(float);
+    return lds <= 64 * 1024;
+}
+
+int mcvc_wgrad_cout1_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, hipStream_t s)
+{
+    if (!mcvc_wgrad_cout1_applies(p)) return MCVC_ERR_INVALID;
+    FewWgradArgs a{};
+    a.x = io.x; a.x_sn = io.x_sb; a.x_sc = io.x_sc; a.x_sh = io.x_sh;
+    a.dy = io.dy; a.dy_sn = io.dy_sb; a.dy_sh = io.dy_sh;
+    a.dw = dw; a.N = NB; a.Cin = p.Cin; a.H = p.H; a.W = p.W; a.KH = p.KH; a.KW = p.KW; a.ph = p.pad_h; a.pw = p.pad_w;
+    a.XW = p.W + p.KW - 1;
+    int nchunk = 1;
+    if (!mcvc_deterministic())
+        while (2 * nchunk <= NB && nchunk < 32 && p.Cin * nchunk < 768) nchunk *= 2;
+    const size_t lds = ((size_t)(p.H + p.KH - 1) * a.XW + (size_t)p.H * p.W + 256) * sizeof(float);
+    TraceScope ts(K_WGRAD_SMALLK, s, 2.0 * NB * p.H * p.W * p.Cin * p.KH * p.KW, 4.0 * ((double)NB * p.Cin * p.H * p.W + (double)NB * p.H * p.W * p.Cin));
+    hipLaunchKernelGGL(wgrad_cout1_kernel, dim3((unsigned)p.Cin, (unsigned)nchunk), dim3(256), lds, s, a);
+    return (int)hipGetLastError();
+}

@@ -658,6 +658,11 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
             done = true;
         }
     }
+    if (!done && c.cout_tot == 1 && mcvc_wgrad_cout1_applies(p) && grads[c.wi[0]]) {       // one output channel: VALU kernel
+        WgradIO io{x.p, x.sb, x.sc, x.sh, dy.p, dy.sb, dy.sc, dy.sh};
+        ex.fail(mcvc_wgrad_cout1_launch(p, NB, io, grads[c.wi[0]], ws));
+        done = true;
+    }
     for (int br = 0; br < c.nbr && !done; ++br) {
         float* dw = grads[c.wi[br]];
         if (!dw) continue;
