@@ -147,6 +147,7 @@ class TrainEngine:
         # four generator forwards): it runs on its own stream and the discriminator forwards wait for its event
         self._task_events = {}
         self._g_fwd_packed = False
+        self._g_grad_clean = self._d_grad_clean = False
         self.fuse_g_update = os.environ.get("MCVC_FUSE_G_UPDATE", "1") != "0"
         self._timeline = None
         self._pack_stream = torch.cuda.Stream(device=dev)
@@ -380,7 +381,10 @@ class TrainEngine:
         m = self.mel
         sc = self.sched
         self.slots[:_BLOCK].zero_()
-        self.g_group.grad.zero_()
+        if self._g_grad_clean:
+            self._g_grad_clean = False           # (zeroed on an idle lane during the previous discriminator phase)
+        else:
+            self.g_group.grad.zero_()
         # batched inputs (device-to-device copies; the batch dimension is outermost, so halves are contiguous views)
         self.in_A2B[:B].copy_(real_A); self.in_A2B[B:].copy_(real_B)
         self.in_B2A[:B].copy_(real_B); self.in_B2A[B:].copy_(real_A)
@@ -418,6 +422,11 @@ class TrainEngine:
 
         def finish_d(ln):                      # data parallel: the D gradient all-reduce of the previous iteration runs behind the
             self._finish_d_update()            # generator forwards; lane 2 is the first to need the discriminators
+            if fuse_update and not self._d_grad_clean:
+                # the discriminator gradients are free once their Adam step is queued: clear them here, on an idle lane, instead of
+                # on the caller's stream at the top of the discriminator phase (99 MB memset)
+                self.d_group.grad.zero_()
+                self._d_grad_clean = True
         ov = self.overlap_g_reduce
         if fuse_update:
             self.g_group.step += 1
@@ -471,7 +480,10 @@ class TrainEngine:
         m = self.mel
         sc = self.sched
         self.slots[_BLOCK:].zero_()
-        self.d_group.grad.zero_()
+        if self._d_grad_clean:
+            self._d_grad_clean = False
+        else:
+            self.d_group.grad.zero_()
         di = self.d_in
         # generators run with their UPDATED weights and no gradient (train.py:259-273); outputs land directly in the
         # second half of the discriminators' batched inputs
@@ -498,10 +510,14 @@ class TrainEngine:
             # the generator phase left lane 0 with generator_A2B updated + its forward copies fresh, lane 1 with generator_B2A: each lane
             # starts with its own generator; the backward-only copies are refreshed on lanes 2/3 while those wait for the generated batches
             self._g_fwd_packed = False
+
+            def clear_g():                     # the generator gradients are free (their Adam step ended the generator phase):
+                self.g_group.grad.zero_()      # 196 MB memset on an idle lane instead of at the top of the next iteration
+                self._g_grad_clean = True
             tasks = [
                 (0, lambda ln: self._G("generator_A2B", real_A, mask_A, gen_B, self.g_stash1[0], B, ln), (), "gB"),      # :267 generated_B
                 (1, lambda ln: self._G("generator_B2A", real_B, mask_B, gen_A, self.g_stash1[1], B, ln), (), "gA"),      # :259 generated_A
-                (2, lambda ln: self._repack1("generator_B2A", 2), (), None),
+                (2, lambda ln: (self._repack1("generator_B2A", 2), clear_g()), (), None),
                 (3, lambda ln: self._repack1("generator_A2B", 2), (), None),
                 (0, lambda ln: self._G("generator_B2A", gen_B, None, cyc_A, self.g_stash1[0], B, ln), (), None),         # :271 cycled_A
                 (1, lambda ln: self._G("generator_A2B", gen_A, None, cyc_B, self.g_stash1[1], B, ln), (), None),         # :263 cycled_B
