@@ -386,9 +386,8 @@ class TrainEngine:
         else:
             self.g_group.grad.zero_()
         # batched inputs (device-to-device copies; the batch dimension is outermost, so halves are contiguous views)
-        self.in_A2B[:B].copy_(real_A); self.in_A2B[B:].copy_(real_B)
-        self.in_B2A[:B].copy_(real_B); self.in_B2A[B:].copy_(real_A)
-        self.mask_A2B[:B].copy_(mask_A); self.mask_B2A[:B].copy_(mask_B)       # second halves stay all-ones
+        torch._foreach_copy_([self.in_A2B[:B], self.in_A2B[B:], self.in_B2A[:B], self.in_B2A[B:], self.mask_A2B[:B], self.mask_B2A[:B]],
+                             [real_A, real_B, real_B, real_A, mask_A, mask_B])     # one launch; the masks' second halves stay all-ones
         fake_B, identity_B = self.out_A2B[:B], self.out_A2B[B:]
         fake_A, identity_A = self.out_B2A[:B], self.out_B2A[B:]
         g_fake_B, g_identity_B = self.gout_A2B[:B], self.gout_A2B[B:]
@@ -489,8 +488,8 @@ class TrainEngine:
         # second half of the discriminators' batched inputs
         gen_A, gen_B = di["discriminator_A"][B:], di["discriminator_B"][B:]
         cyc_A, cyc_B = di["discriminator_A2"][B:], di["discriminator_B2"][B:]
-        di["discriminator_A"][:B].copy_(real_A); di["discriminator_A2"][:B].copy_(real_A)
-        di["discriminator_B"][:B].copy_(real_B); di["discriminator_B2"][:B].copy_(real_B)
+        torch._foreach_copy_([di["discriminator_A"][:B], di["discriminator_A2"][:B], di["discriminator_B"][:B], di["discriminator_B2"][:B]],
+                             [real_A, real_A, real_B, real_B])
         do, dl, ds = self.dout2, self.dlogit2, self.d_stash2
         idx = {n: i for i, n in enumerate(D_NAMES)}
 
@@ -594,8 +593,7 @@ class TrainEngine:
         if real_A.shape[0] != self.B:
             self._use(int(real_A.shape[0]))
         # static input buffers (graph replays read fixed addresses)
-        for dst, src in zip(self.static_in, (real_A, mask_A, real_B, mask_B)):
-            dst.copy_(src)
+        torch._foreach_copy_(list(self.static_in), [real_A, mask_A, real_B, mask_B])
         return self._step_static()
 
     def step_sampled(self, sampler, batch_size=None):
