@@ -510,13 +510,14 @@ class TrainEngine:
             # starts with its own generator; the backward-only copies are refreshed on lanes 2/3 while those wait for the generated batches
             self._g_fwd_packed = False
 
-            def clear_g():                     # the generator gradients are free (their Adam step ended the generator phase):
-                self.g_group.grad.zero_()      # 196 MB memset on an idle lane instead of at the top of the next iteration
-                self._g_grad_clean = True
+            def refresh_b2a(ln):
+                self._repack1("generator_B2A", 2)
+                self.g_group.grad.zero_()      # the generator gradients are free (their Adam step ended the generator phase): 196 MB
+                self._g_grad_clean = True      # memset on an idle lane instead of at the top of the next iteration
             tasks = [
                 (0, lambda ln: self._G("generator_A2B", real_A, mask_A, gen_B, self.g_stash1[0], B, ln), (), "gB"),      # :267 generated_B
                 (1, lambda ln: self._G("generator_B2A", real_B, mask_B, gen_A, self.g_stash1[1], B, ln), (), "gA"),      # :259 generated_A
-                (2, lambda ln: (self._repack1("generator_B2A", 2), clear_g()), (), None),
+                (2, refresh_b2a, (), None),
                 (3, lambda ln: self._repack1("generator_A2B", 2), (), None),
                 (0, lambda ln: self._G("generator_B2A", gen_B, None, cyc_A, self.g_stash1[0], B, ln), (), None),         # :271 cycled_A
                 (1, lambda ln: self._G("generator_A2B", gen_A, None, cyc_B, self.g_stash1[1], B, ln), (), None),         # :263 cycled_B
