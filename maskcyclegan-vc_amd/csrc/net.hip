@@ -58,6 +58,9 @@ struct Exec {
     float* sg; long long sg_cap, sg_need;    // staging region of the staged-GEMM convolutions (sgemm.h): forward / data gradient (main stream)
     float* sgw; long long sgw_cap, sgw_need; // ... and the weight gradients' own (they may run on the auxiliary stream beside a data gradient)
     const float* const* params;    // the pass's parameter table (that path's data gradient multiplies the OIHW tensors themselves)
+    int fuse_next = 0;             // the caller's next step is a norm that can absorb a Winograd output transform (set before conv_fwd)
+    int pend_pts = 0;              // 16 / 36: the output transform in `pend` has not run yet -- norm_fwd runs it (fused when it fits)
+    WinoOutArgs pend;
     int pack_skips;                // what the last re-pack of `packed` left stale: bit 0 = generic trunk copies, bit 1 = direct copies of the Winograd layers
     unsigned* sync;                // arrival counters of the persistent trunk kernels (MCVC_TRUNK_SYNC_WORDS words of the scratch)
     std::vector<std::pair<const void*, hipEvent_t>> readers;
@@ -325,7 +328,8 @@ static bool conv_wino(Exec& ex, const ConvSpec& c, const float* packed, int dgra
         oa.y = y.p + (long long)b0 * y.sb; oa.y_sb = y.sb; oa.y_sc = y.sc; oa.y_sh = y.sh;
         oa.N = nb; oa.Cout = M; oa.OH = H; oa.OW = W; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
         oa.shuffle = shuffle; oa.YH = 2 * H; oa.YW = 2 * W; oa.accumulate = accumulate;
-        ex.fail(mcvc_wino_output_launch(oa, ex.s));
+        if (ex.fuse_next && !dgrad && shuffle && nbc == NB) { ex.pend = oa; ex.pend_pts = 36; }
+        else ex.fail(mcvc_wino_output_launch(oa, ex.s));
     }
     return true;
 }
@@ -421,7 +425,8 @@ static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, i
                 oa.y = y.p + (long long)b0 * y.sb; oa.y_sb = y.sb; oa.y_sc = y.sc; oa.y_sh = y.sh;
                 oa.N = nb; oa.Cout = M; oa.OH = OH; oa.OW = OW; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
                 oa.shuffle = 0; oa.YH = OH; oa.YW = OW; oa.accumulate = 0;
-                ex.fail(mcvc_wino3_output_launch(oa, ex.s));
+                if (ex.fuse_next && nbc == NB) { ex.pend = oa; ex.pend_pts = 16; }
+                else ex.fail(mcvc_wino3_output_launch(oa, ex.s));
             }
             return;
         }
@@ -938,6 +943,12 @@ static NormP normp(const float* const* params, float* const* grads, int g0, int 
     return n;
 }
 
+static int fuse_wino_norm()
+{
+    static const int en = [] { const char* e = getenv("MCVC_FUSE_WINO_NORM"); return e ? atoi(e) : 1; }();
+    return en;
+}
+
 static void norm_fwd(Exec& ex, float* x, long long x_sn, long long x_sc, long long x_total, int nslab, const NormP& np, float* stats,
                      float* y, long long y_sn, long long y_sc, int y_sh, const float* res, int N, int C, int H, int W, int act)
 {
@@ -947,6 +958,12 @@ static void norm_fwd(Exec& ex, float* x, long long x_sn, long long x_sc, long lo
     a.gamma[0] = np.g[0]; a.gamma[1] = np.g[1]; a.beta[0] = np.b[0]; a.beta[1] = np.b[1];
     a.stats = stats; a.y = y; a.res = res; a.y_sn = y_sn; a.y_sc = y_sc; a.y_sh = y_sh;
     a.N = N; a.C = C; a.H = H; a.W = W; a.act = act; a.eps = kInEps;
+    if (ex.pend_pts) {
+        const int pts = ex.pend_pts;
+        ex.pend_pts = 0;
+        if (mcvc_norm_fwd_wino_applies(a, ex.pend, pts)) { ex.fail(mcvc_norm_fwd_wino_launch(a, ex.pend, pts, ex.s)); return; }
+        ex.fail(pts == 16 ? mcvc_wino3_output_launch(ex.pend, ex.s) : mcvc_wino_output_launch(ex.pend, ex.s));
+    }
     ex.fail(mcvc_norm_fwd_launch(a, ex.s));
 }
 
@@ -1100,13 +1117,17 @@ static void gen_forward_impl(Exec& ex, const float* const* P, const float* packe
              (long long)B * 256 * 80 * T, 0, 1, &ns);
     act_fwd(ex, st + o.c1, (long long)B * 256 * 80 * T, ns, st + o.y1, B, 128, 80 * T, ACT_GLU);
     // ---- :245  downSample1 (5x5 s2, IN, GLU)
+    ex.fuse_next = fuse_wino_norm();
     conv_fwd(ex, g.ds1, packed, B, 80, T, CView{st + o.y1, 128LL * 80 * T, 80LL * T, T}, View{st + o.c2, 512LL * 40 * W2, 40LL * W2, W2},
              (long long)B * 512 * 40 * W2, 0, 1, &ns);
+    ex.fuse_next = 0;
     norm_fwd(ex, st + o.c2, 512LL * 40 * W2, 40LL * W2, (long long)B * 512 * 40 * W2, ns, normp(P, nullptr, 6, 7, 10, 11), st + o.s2,
              st + o.y2, 256LL * 40 * W2, 40LL * W2, W2, nullptr, B, 256, 40, W2, ACT_GLU);
     // ---- :246  downSample2; output written straight in trunk layout [c*20+h][b][w]  (:249-251)
+    ex.fuse_next = fuse_wino_norm();
     conv_fwd(ex, g.ds2, packed, B, 40, W2, CView{st + o.y2, 256LL * 40 * W2, 40LL * W2, W2}, View{st + o.c3, 512LL * 20 * W4, 20LL * W4, W4},
              (long long)B * 512 * 20 * W4, 0, 1, &ns);
+    ex.fuse_next = 0;
     norm_fwd(ex, st + o.c3, 512LL * 20 * W4, 20LL * W4, (long long)B * 512 * 20 * W4, ns, normp(P, nullptr, 14, 15, 18, 19), st + o.s3,
              st + o.y3, W4, 20LL * BT4, (int)BT4, nullptr, B, 256, 20, W4, ACT_GLU);
     // ---- :254-255  1x1 5120->256 + IN ; image = [5120][B rows][W4]
@@ -1164,13 +1185,17 @@ static void gen_forward_impl(Exec& ex, const float* const* P, const float* packe
     }
     }
     // ---- :274  upSample1: conv 5x5 -> PixelShuffle(2) (fused into the store) -> IN -> x*sigmoid(x)
+    ex.fuse_next = fuse_wino_norm();
     conv_fwd(ex, g.up1, packed, B, 20, W4, CView{st + o.y6, 256LL * 20 * W4, 20LL * W4, W4}, View{st + o.c7, 256LL * 40 * Wu1, 40LL * Wu1, Wu1},
              (long long)B * 256 * 40 * Wu1, 1, 1, &ns);
+    ex.fuse_next = 0;
     norm_fwd(ex, st + o.c7, 256LL * 40 * Wu1, 40LL * Wu1, (long long)B * 256 * 40 * Wu1, ns, normp(P, nullptr, 106, 107), st + o.s7,
              st + o.y7, 256LL * 40 * Wu1, 40LL * Wu1, Wu1, nullptr, B, 256, 40, Wu1, ACT_SILU);
     // ---- :275  upSample2
+    ex.fuse_next = fuse_wino_norm();
     conv_fwd(ex, g.up2, packed, B, 40, Wu1, CView{st + o.y7, 256LL * 40 * Wu1, 40LL * Wu1, Wu1}, View{st + o.c8, 128LL * 80 * Wu2, 80LL * Wu2, Wu2},
              (long long)B * 128 * 80 * Wu2, 1, 1, &ns);
+    ex.fuse_next = 0;
     norm_fwd(ex, st + o.c8, 128LL * 80 * Wu2, 80LL * Wu2, (long long)B * 128 * 80 * Wu2, ns, normp(P, nullptr, 102, 103), st + o.s8,
              st + o.y8, 128LL * 80 * Wu2, 80LL * Wu2, Wu2, nullptr, B, 128, 80, Wu2, ACT_SILU);
     // ---- :278-279  last 5x15 conv to one channel

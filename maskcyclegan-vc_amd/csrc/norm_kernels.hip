@@ -12,6 +12,7 @@
 // (the "launch-boundary reduce"), so the conv never needs atomics for its K split.
 #include "mcvc_common.h"
 #include "trace.h"
+#include "wino.h"
 
 namespace {
 
@@ -462,9 +463,172 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const ActBwdArgs a)
     }
 }
 
+// Output transform of a Winograd convolution + instance norm + activation in one pass: the products M[xi][co][tile] are turned into the
+// 2x2 outputs of each tile in registers (+ bias), the plane statistics are taken over them, and both the conv output (the backward pass
+// reads it) and the normalised / activated plane are stored -- the separate output-transform launch and the norm's re-read of the conv
+// output go away (4 launches per generator forward: downSample1/2, upSample1/2, model.py:245-246, 274-275).
+//   PTS = 16: F(2x2,3x3) (the stride-2 5x5 layers in phase form), plane (n, c) = conv channel c (value) and C + c (gate, GLU)
+//   PTS = 36: F(2x2,5x5) with PixelShuffle(2): plane (n, c) = conv channels 4c .. 4c+3 interleaved; items = (sub-channel, tile)
+// G threads share one plane, every thread owns TT items.
+template <int G, int TT, int PTS>
+__global__ void __launch_bounds__(256) norm_fwd_wino_kernel(const NormArgs a, const WinoOutArgs w)
+{
+    __shared__ float red[4];
+    constexpr bool SHUF = PTS == 36;
+    constexpr int R = SHUF ? 6 : 4;
+    constexpr int GPB = 256 / G;
+    const int g = threadIdx.x / G, l = threadIdx.x % G;
+    const long long plane_id = (long long)blockIdx.x * GPB + g;
+    if (plane_id >= (long long)a.N * a.C) return;
+    const int n = (int)(plane_id / a.C), c = (int)(plane_id - (long long)n * a.C);
+    const int tiles = w.TH * w.TW;
+    const int items = SHUF ? 4 * tiles : tiles;
+    const int nbr = (!SHUF && a.act == ACT_GLU) ? 2 : 1;
+    const int Cx = a.C * nbr;
+    const long long xs = (long long)w.Cout * w.NTp;
+    const float invP = 1.0f / (float)(a.H * a.W);
+    float xv[2][TT][4];
+    int pos[TT];                                     // plane offset h * W + w of the item's first output (-1: no item)
+#pragma unroll
+    for (int k = 0; k < TT; ++k) {
+        const int item = l + k * G;
+        const int sub = SHUF ? item / tiles : 0;
+        const int t = item - sub * tiles;
+        const int ty = t / w.TW, tx = t - ty * w.TW;
+        pos[k] = item < items ? (SHUF ? (4 * ty + (sub >> 1)) * a.W + 4 * tx + (sub & 1) : 2 * ty * a.W + 2 * tx) : -1;
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+            if (br < nbr) {
+                const int co = SHUF ? 4 * c + sub : c + br * a.C;
+                float o[4] = {0.f, 0.f, 0.f, 0.f};
+                if (item < items) {
+                    const float* src = w.m + (long long)co * w.NTp + (long long)n * tiles + t;
+                    float u[2][R];
+#pragma unroll
+                    for (int b = 0; b < R; ++b) {
+                        float m[R];
+#pragma unroll
+                        for (int aa = 0; aa < R; ++aa) m[aa] = src[(long long)(aa * R + b) * xs];
+                        if constexpr (SHUF) { u[0][b] = m[0] + m[1] + m[2] + m[3] + m[4]; u[1][b] = m[1] - m[2] + 2.f * (m[3] - m[4]) + m[R - 1]; }
+                        else { u[0][b] = m[0] + m[1] + m[2]; u[1][b] = m[1] - m[2] - m[3]; }
+                    }
+                    const float bias = w.bias ? w.bias[co] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        if constexpr (SHUF) {
+                            o[2 * i] = u[i][0] + u[i][1] + u[i][2] + u[i][3] + u[i][4] + bias;
+                            o[2 * i + 1] = u[i][1] - u[i][2] + 2.f * (u[i][3] - u[i][4]) + u[i][R - 1] + bias;
+                        } else {
+                            o[2 * i] = u[i][0] + u[i][1] + u[i][2] + bias;
+                            o[2 * i + 1] = u[i][1] - u[i][2] - u[i][3] + bias;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[br][k][e] = o[e];
+            }
+        }
+    }
+    const float g0 = a.gamma[0][c], b0 = a.beta[0][c];
+    float g1 = 0.f, b1 = 0.f;
+    if (nbr == 2) { g1 = a.gamma[1][c]; b1 = a.beta[1][c]; }
+    // outputs of one item: rows dh apart, columns dw apart in the plane
+    const int dh = (SHUF ? 2 : 1) * a.W, dw = SHUF ? 2 : 1;
+    float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+        if (br < nbr) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < TT; ++k) s += (xv[br][k][0] + xv[br][k][1]) + (xv[br][k][2] + xv[br][k][3]);
+            s = gsum<G>(s, red);
+            const float m = s * invP;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < TT; ++k) {
+                if (pos[k] >= 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = xv[br][k][e] - m; q += d * d; }
+                }
+            }
+            q = gsum<G>(q, red);
+            const float r = 1.0f / sqrtf(q * invP + a.eps);
+            mean[br] = m; rstd[br] = r;
+            if (l == 0) {
+                float* st = a.stats + ((long long)n * Cx + c + br * a.C) * 2;
+                st[0] = m; st[1] = r;
+            }
+            float* xp = a.x + (long long)n * a.x_sn + (long long)(c + br * a.C) * a.x_sc;
+#pragma unroll
+            for (int k = 0; k < TT; ++k) {
+                if (pos[k] >= 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xp[pos[k] + (e >> 1) * dh + (e & 1) * dw] = xv[br][k][e];
+                }
+            }
+        }
+    }
+    float* yp = a.y + (long long)n * a.y_sn + (long long)c * a.y_sc;
+#pragma unroll
+    for (int k = 0; k < TT; ++k) {
+        if (pos[k] >= 0) {
+            const int h0 = pos[k] / a.W, w0 = pos[k] - h0 * a.W;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float z0 = (xv[0][k][e] - mean[0]) * rstd[0] * g0 + b0;
+                float y;
+                if (a.act == ACT_GLU) y = z0 * sigmoidf_((xv[1][k][e] - mean[1]) * rstd[1] * g1 + b1);
+                else if (a.act == ACT_SILU) y = z0 * sigmoidf_(z0);
+                else y = z0;
+                yp[(long long)(h0 + (e >> 1) * (SHUF ? 2 : 1)) * a.y_sh + w0 + (e & 1) * dw] = y;
+            }
+        }
+    }
+}
+
 static int pick_group(int P) { return P <= 32 ? 16 : (P <= 640 ? 64 : 256); }
 
 }  // namespace
+
+// items per plane the fused output-transform + norm kernel would see, or 0 when the pair does not fit it
+static int wino_norm_items(const NormArgs& a, const WinoOutArgs& w, int pts)
+{
+    if (a.nslab != 1 || a.res != nullptr || w.accumulate || w.N != a.N || (w.OH & 1) || (w.OW & 1) || w.NT != w.N * w.TH * w.TW) return 0;
+    if (pts == 16) {
+        if (w.shuffle || a.H != w.OH || a.W != w.OW || w.Cout != a.C * (a.act == ACT_GLU ? 2 : 1) || a.x_sc != (long long)a.H * a.W) return 0;
+        return w.TH * w.TW;
+    }
+    if (pts == 36) {
+        if (!w.shuffle || a.act == ACT_GLU || a.H != 2 * w.OH || a.W != 2 * w.OW || w.Cout != 4 * a.C || a.x_sc != (long long)a.H * a.W) return 0;
+        return 4 * w.TH * w.TW;
+    }
+    return 0;
+}
+
+bool mcvc_norm_fwd_wino_applies(const NormArgs& a, const WinoOutArgs& w, int pts)
+{
+    const int items = wino_norm_items(a, w, pts);
+    return items > 0 && items <= 1280;
+}
+
+int mcvc_norm_fwd_wino_launch(const NormArgs& a, const WinoOutArgs& w, int pts, hipStream_t s)
+{
+    const int items = wino_norm_items(a, w, pts);
+    if (items <= 0 || items > 1280) return MCVC_ERR_INVALID;
+    const long long planes = (long long)a.N * a.C;
+    const int nbr = (pts == 16 && a.act == ACT_GLU) ? 2 : 1;
+    const double el = (double)planes * a.H * a.W * nbr;
+    TraceScope ts(K_NORM_FWD, s, 0.0, 4.0 * (el * pts / 4 + el + (double)planes * a.H * a.W));
+#define MCVC_FWD_WINO(GG, TT) { \
+        if (pts == 16) hipLaunchKernelGGL((norm_fwd_wino_kernel<GG, TT, 16>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, a, w); \
+        else hipLaunchKernelGGL((norm_fwd_wino_kernel<GG, TT, 36>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, a, w); \
+        return (int)hipGetLastError(); }
+    if (items <= 128) MCVC_FWD_WINO(64, 2)
+    if (items <= 512 && planes < 2048) MCVC_FWD_WINO(256, 2)
+    if (items <= 320) MCVC_FWD_WINO(64, 5)
+    MCVC_FWD_WINO(256, 5)
+#undef MCVC_FWD_WINO
+}
 
 int mcvc_norm_fwd_launch(const NormArgs& a, hipStream_t s)
 {

@@ -23,6 +23,10 @@ struct WinoOutArgs {
 };
 
 int mcvc_wino_input_launch(const WinoXformArgs& a, hipStream_t s);
+// output transform + instance norm + activation in one launch (norm_kernels.hip); pts = 16: F(2x2,3x3), 36: F(2x2,5x5) + PixelShuffle
+struct NormArgs;
+bool mcvc_norm_fwd_wino_applies(const NormArgs& a, const WinoOutArgs& w, int pts);
+int mcvc_norm_fwd_wino_launch(const NormArgs& a, const WinoOutArgs& w, int pts, hipStream_t s);
 // F(2x2,3x3) variants (4x4 tiles, 16 points, padding 1): the merged data-gradient of the stride-2 5x5 convs is a 3x3 conv
 int mcvc_wino3_input_launch(const WinoXformArgs& a, hipStream_t s);
 int mcvc_wino3_output_launch(const WinoOutArgs& a, hipStream_t s);
