@@ -159,6 +159,54 @@ __global__ void __launch_bounds__(256) conv_fewout_kernel(const FewArgs a)
     }
 }
 
+// ---- the discriminators' output layer (1 x 3 conv, C channels -> 1, padding (0,1), + sigmoid; model.py:322-327, 348) -------------------
+// 80 output values per sample from C = 1024 channels: as a split-K job of the kernel above it took 21 us + 17 us for the consumer that folded
+// 64 slabs.  One wave per output value instead: the lanes stride over the channels (all loads independent), a butterfly sums them, lane 0
+// stores the logit (+ bias) and its sigmoid.  w = the OIHW parameter itself ([1][C][1][3]).
+__global__ void __launch_bounds__(256) disc_out_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ logit, float* __restrict__ out, int NB, int C, int H, int W)
+{
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int HW = H * W;
+    if (o >= NB * HW) return;
+    const int n = o / HW, p = o - n * HW, wc = p % W;
+    const float* xp = x + (long long)n * C * HW + p;
+    const bool hasl = wc > 0, hasr = wc + 1 < W;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int c = lane; c < C; c += 64) {
+        const float* xc = xp + (long long)c * HW;
+        const float x0 = hasl ? xc[-1] : 0.f, x1 = xc[0], x2 = hasr ? xc[1] : 0.f;
+        acc = fmaf(w[3 * c], x0, fmaf(w[3 * c + 1], x1, fmaf(w[3 * c + 2], x2, acc)));
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if (lane == 0) {
+        const float v = acc + bias[0];
+        logit[o] = v;
+        out[o] = 1.0f / (1.0f + __expf(-v));
+    }
+}
+
+// its data-gradient: dx[n][c][h][w] = sum_kw w[c][kw] * dlogit[n][h][w + 1 - kw]
+__global__ void __launch_bounds__(256) disc_out_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ w, float* __restrict__ dx,
+                                                             int NB, int C, int H, int W)
+{
+    const long long total = (long long)NB * C * H * W;
+    const int HW = H * W;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        const long long nc = i / HW;
+        const int c = (int)(nc % C), n = (int)(nc / C);
+        const int wc = p % W;
+        const float* d = dl + (long long)n * HW + p;
+        float v = w[3 * c + 1] * d[0];
+        if (wc + 1 < W) v = fmaf(w[3 * c], d[1], v);
+        if (wc > 0) v = fmaf(w[3 * c + 2], d[-1], v);
+        dx[i] = v;
+    }
+}
+
 static int few_enabled()
 {
     static const int v = [] { const char* e = getenv("MCVC_FEWOUT"); return e ? atoi(e) : 1; }();
@@ -185,6 +233,24 @@ static int few_launch_t(const FewArgs& a, dim3 grid, size_t lds, hipStream_t s)
 }
 
 }  // namespace
+
+int mcvc_disc_out_fwd_launch(const float* x, const float* w, const float* bias, float* logit, float* out, int NB, int C, int H, int W, hipStream_t s)
+{
+    const int outs = NB * H * W;
+    TraceScope ts(K_CONV_FEW, s, 2.0 * 3 * C * outs, 4.0 * ((double)outs * C + 2.0 * outs));
+    hipLaunchKernelGGL(disc_out_fwd_kernel, dim3((unsigned)cdiv_i(outs, 4)), dim3(256), 0, s, x, w, bias, logit, out, NB, C, H, W);
+    return (int)hipGetLastError();
+}
+
+int mcvc_disc_out_dgrad_launch(const float* dlogit, const float* w, float* dx, int NB, int C, int H, int W, hipStream_t s)
+{
+    const long long total = (long long)NB * C * H * W;
+    TraceScope ts(K_CONV_FEW, s, 2.0 * 3 * (double)total, 4.0 * (double)total);
+    long long blocks = cdiv_ll(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(disc_out_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dlogit, w, dx, NB, C, H, W);
+    return (int)hipGetLastError();
+}
 
 bool mcvc_fewout_applies(const ConvProblem& p)
 {

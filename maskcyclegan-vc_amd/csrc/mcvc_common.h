@@ -181,6 +181,9 @@ int mcvc_conv_plan_nsplit(const ConvProblem& p, int NB, int allow_split);
 bool mcvc_fewout_applies(const ConvProblem& p);
 int mcvc_fewout_plan_nsplit(const ConvProblem& p, int NB, int allow_split);
 int mcvc_fewout_launch(const ConvProblem& p, int NB, const ConvIO& io, const float* wpk, int w_cout, const float* bias, hipStream_t s);
+// the discriminators' output layer (1x3, C -> 1, + sigmoid) and its data-gradient; w / bias = the parameters themselves
+int mcvc_disc_out_fwd_launch(const float* x, const float* w, const float* bias, float* logit, float* out, int NB, int C, int H, int W, hipStream_t s);
+int mcvc_disc_out_dgrad_launch(const float* dlogit, const float* w, float* dx, int NB, int C, int H, int W, hipStream_t s);
 
 struct WgradIO {
     const float* x; long long x_sb, x_sc; int x_sh;

@@ -1444,6 +1444,13 @@ static DiscScratch disc_scratch(const DiscDims& d)
     return s;
 }
 
+// the output layer on its own two kernels (fewout_kernels.hip) instead of the generic few-output conv + slab-folding activation
+static int disc_out_direct()
+{
+    static const int en = [] { const char* e = getenv("MCVC_DISC_OUT"); return e ? atoi(e) : 1; }();
+    return en;
+}
+
 static void disc_forward_impl(Exec& ex, const float* const* P, const float* packed, const float* x, float* out, float* st, const DiscDims& d)
 {
     ex.params = P;
@@ -1466,6 +1473,10 @@ static void disc_forward_impl(Exec& ex, const float* const* P, const float* pack
     }
     // :348  1x3 conv to one channel + sigmoid
     const int H3 = d.H[3], W3 = d.W[3];
+    if (disc_out_direct() && !ex.dry) {
+        ex.fail(mcvc_disc_out_fwd_launch(h, P[n.outc.wi[0]], P[n.outc.bi[0]], st + o.logit, out, B, 1024, H3, W3, ex.s));
+        return;
+    }
     conv_fwd(ex, n.outc, packed, B, H3, W3, CView{h, 1024LL * H3 * W3, (long long)H3 * W3, W3}, View{st + o.logit, (long long)H3 * W3, (long long)H3 * W3, W3},
              (long long)B * H3 * W3, 0, 1, &ns);
     act_fwd(ex, st + o.logit, (long long)B * H3 * W3, ns, out, B, 1, H3 * W3, ACT_SIGMOID);
@@ -1500,7 +1511,8 @@ static void disc_backward_impl(Exec& ex, const float* const* P, const float* pac
         CView xv{st + o.y[2], 1024LL * H3 * W3, (long long)H3 * W3, W3};
         conv_wgrad(ex, n.outc, G, B, H3, W3, xv, dyv);
         conv_bias_grad(ex, n.outc, G, B, dyv, H3 * W3);
-        conv_dgrad(ex, n.outc, packed, B, H3, W3, dyv, View{GA, 1024LL * H3 * W3, (long long)H3 * W3, W3}, (long long)B * 1024 * H3 * W3, 0, 1, &ns);
+        if (disc_out_direct() && !ex.dry) ex.fail(mcvc_disc_out_dgrad_launch(dlogit, P[n.outc.wi[0]], GA, B, 1024, H3, W3, ex.s));
+        else conv_dgrad(ex, n.outc, packed, B, H3, W3, dyv, View{GA, 1024LL * H3 * W3, (long long)H3 * W3, W3}, (long long)B * 1024 * H3 * W3, 0, 1, &ns);
     }
     for (int i = 2; i >= 0; --i) {
         const int Ci = kDC[i], Co = kDC[i + 1], Hi = d.H[i], Wi = d.W[i], Ho = d.H[i + 1], Wo = d.W[i + 1];

@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(256) act_fwd_kernel(const ActArgs a)
             const long long xo = ((n * nbr * a.C) + c + br * a.C) * a.P + i;
             float t = a.x[xo];
             if (a.nslab > 1) {
+#pragma unroll 8
                 for (int sl = 1; sl < a.nslab; ++sl) t += a.x_slabs[(long long)(sl - 1) * a.slab_stride + xo];
                 a.x[xo] = t;
             }
@@ -441,6 +442,7 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const ActBwdArgs a)
         const long long n = nc / a.C;
         float dyv = a.dy[idx];
         if (a.nslab > 1) {
+#pragma unroll 8
             for (int sl = 1; sl < a.nslab; ++sl) dyv += a.dy_slabs[(long long)(sl - 1) * a.slab_stride + idx];
             a.dy[idx] = dyv;
         }
