@@ -356,6 +356,65 @@ __global__ void __launch_bounds__(256) wgrad_cout1_kernel(const FewWgradArgs a)
     }
 }
 
+
+// One INPUT channel, 3x3, stride 1, padding 1 (the discriminators' first conv, model.py:290-295): dw[co][kh][kw] = sum over samples and
+// pixels of dy[n][co][h][w] * x[n][h+kh-1][w+kw-1].  The matrix kernel ran this 9-column problem at 0.6 TF/s (36 us, last launch of every
+// discriminator backward pass).  Here a workgroup owns one output channel and a share of (sample, band of rows) units: the haloed band of x
+// sits in LDS, a thread multiplies its dy values with the nine neighbours, the nine sums are folded over the workgroup.
+constexpr int kCin1Band = 20;
+__global__ void __launch_bounds__(256) wgrad_cin1_kernel(const float* __restrict__ x, long long x_sn, int x_sh, const float* __restrict__ dy, long long dy_sn,
+                                                         long long dy_sc, int dy_sh, float* __restrict__ dw, int NB, int H, int W)
+{
+    extern __shared__ float sm[];
+    const int XW = W + 2;
+    float* xs = sm;                                   // [kCin1Band + 2][XW]
+    float* red = sm + (kCin1Band + 2) * XW;           // [4][9]
+    const int tid = threadIdx.x, co = blockIdx.x;
+    const int bands = (H + kCin1Band - 1) / kCin1Band;
+    const int units = NB * bands;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int u = blockIdx.y; u < units; u += gridDim.y) {
+        const int n = u / bands, h0 = (u - n * bands) * kCin1Band;
+        const int rows = (H - h0 < kCin1Band) ? H - h0 : kCin1Band;
+        const float* xp = x + (long long)n * x_sn;
+        __syncthreads();
+        for (int i = tid; i < (rows + 2) * XW; i += 256) {
+            const int r = i / XW, c = i - r * XW;
+            const int ih = h0 + r - 1, iw = c - 1;
+            xs[i] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? xp[(long long)ih * x_sh + iw] : 0.f;
+        }
+        __syncthreads();
+        const float* dp = dy + (long long)n * dy_sn + (long long)co * dy_sc + (long long)h0 * dy_sh;
+        for (int i = tid; i < rows * W; i += 256) {
+            const int r = i / W, c = i - r * W;
+            const float d = dp[(long long)r * dy_sh + c];
+            const float* xr = xs + r * XW + c;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] = fmaf(d, xr[kh * XW + kw], acc[kh * 3 + kw]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[t] += __shfl_xor(acc[t], o, 64);
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[(tid >> 6) * 9 + t] = acc[t];
+    }
+    __syncthreads();
+    if (tid < 9 && (int)blockIdx.y < units) {
+        const float v = (red[tid] + red[9 + tid]) + (red[18 + tid] + red[27 + tid]);
+        float* d = dw + co * 9 + tid;
+        if (gridDim.y > 1) unsafeAtomicAdd(d, v); else *d += v;
+    }
+}
+
 }  // namespace
 
 bool mcvc_wgrad_cout1_applies(const ConvProblem& p)
@@ -380,5 +439,24 @@ int mcvc_wgrad_cout1_launch(const ConvProblem& p, int NB, const WgradIO& io, flo
     const size_t lds = ((size_t)(p.H + p.KH - 1) * a.XW + (size_t)p.H * p.W + 256) * sizeof(float);
     TraceScope ts(K_WGRAD_SMALLK, s, 2.0 * NB * p.H * p.W * p.Cin * p.KH * p.KW, 4.0 * ((double)NB * p.Cin * p.H * p.W + (double)NB * p.H * p.W * p.Cin));
     hipLaunchKernelGGL(wgrad_cout1_kernel, dim3((unsigned)p.Cin, (unsigned)nchunk), dim3(256), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+bool mcvc_wgrad_cin1_applies(const ConvProblem& p)
+{
+    return p.Cin == 1 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad_h == 1 && p.pad_w == 1 && p.OH == p.H && p.OW == p.W && p.W <= 512;
+}
+
+int mcvc_wgrad_cin1_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, hipStream_t s)
+{
+    if (!mcvc_wgrad_cin1_applies(p)) return MCVC_ERR_INVALID;
+    const int units = NB * cdiv_i(p.H, kCin1Band);
+    int nchunk = 1;
+    if (!mcvc_deterministic())
+        while (2 * nchunk <= units && p.Cout * nchunk < 1024) nchunk *= 2;
+    const size_t lds = ((size_t)(kCin1Band + 2) * (p.W + 2) + 36) * sizeof(float);
+    TraceScope ts(K_WGRAD_SMALLK, s, 2.0 * NB * p.H * p.W * p.Cout * 9, 4.0 * ((double)NB * p.Cout * p.H * p.W + (double)NB * p.H * p.W));
+    hipLaunchKernelGGL(wgrad_cin1_kernel, dim3((unsigned)p.Cout, (unsigned)nchunk), dim3(256), lds, s, io.x, io.x_sb, io.x_sh, io.dy, io.dy_sb, io.dy_sc,
+                       io.dy_sh, dw, NB, p.H, p.W);
     return (int)hipGetLastError();
 }

@@ -192,6 +192,9 @@ struct WgradIO {
 int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, float* slabs, long long slab_cap_floats, hipStream_t s);
 // one-output-channel weight gradient on the VALU (fewout_kernels.hip): lastConvLayer, the discriminator's output conv
 bool mcvc_wgrad_cout1_applies(const ConvProblem& p);
+// one-INPUT-channel 3x3 weight gradient (the discriminators' first conv)
+bool mcvc_wgrad_cin1_applies(const ConvProblem& p);
+int mcvc_wgrad_cin1_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, hipStream_t s);
 int mcvc_wgrad_cout1_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, hipStream_t s);
 // scratch floats the K-split of this weight gradient wants (0 = no split)
 long long mcvc_wgrad_plan_slab_floats(const ConvProblem& p, int NB);

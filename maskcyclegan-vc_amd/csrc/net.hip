@@ -555,6 +555,12 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
     if (nsplit) *nsplit = ns_all;
 }
 
+static int wgrad_cin1_enabled()
+{
+    static const int en = [] { const char* e = getenv("MCVC_WGRAD_CIN1"); return e ? atoi(e) : 1; }();
+    return en;
+}
+
 static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB, int H, int W, CView x, CView dy)
 {
     const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
@@ -672,6 +678,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         float* dw = grads[c.wi[br]];
         if (!dw) continue;
         WgradIO io{x.p, x.sb, x.sc, x.sh, dy.p + (long long)br * c.Cout * dy.sc, dy.sb, dy.sc, dy.sh};
+        if (mcvc_wgrad_cin1_applies(p) && wgrad_cin1_enabled()) { ex.fail(mcvc_wgrad_cin1_launch(p, NB, io, dw, ws)); continue; }
         ex.fail(mcvc_wgrad_launch(p, NB, io, dw, ex.wslabs, ex.wslab_cap, ws));
     }
     if (ex.s2) {
