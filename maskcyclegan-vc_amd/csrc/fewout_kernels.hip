@@ -207,6 +207,40 @@ __global__ void __launch_bounds__(256) disc_out_dgrad_kernel(const float* __rest
     }
 }
 
+// ---- the discriminators' first layer: 3x3 conv from ONE channel + x*sigmoid(x) (model.py:290-295, 343-344) -----------------------------
+// 9 multiplies per output: on the matrix kernel + a separate activation pass it was 12 + 7 us.  A thread keeps the 3x3 neighbourhood of its
+// pixel in registers and walks COB output channels (weights: wave-uniform scalar loads); it stores the pre-activation (backward) and the
+// activation, both coalesced along the pixels.  w = the OIHW parameter ([Cout][1][3][3]).
+constexpr int kDiscC1Cob = 16;
+__global__ void __launch_bounds__(256) disc_conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ c0, float* __restrict__ y0, int Cout, int H, int W)
+{
+    const int HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.z, co0 = blockIdx.y * kDiscC1Cob;
+    if (p >= HW) return;
+    const int h = p / W, wc = p - h * W;
+    const float* xp = x + (long long)n * HW;
+    float xv[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ih = h + kh - 1, iw = wc + kw - 1;
+            xv[kh * 3 + kw] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? xp[ih * W + iw] : 0.f;
+        }
+    const long long o0 = ((long long)n * Cout + co0) * HW + p;
+#pragma unroll 4
+    for (int j = 0; j < kDiscC1Cob; ++j) {
+        if (co0 + j >= Cout) break;
+        const float* wr = w + (co0 + j) * 9;
+        float v = bias[co0 + j];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v = fmaf(wr[t], xv[t], v);
+        c0[o0 + (long long)j * HW] = v;
+        y0[o0 + (long long)j * HW] = v / (1.0f + __expf(-v));
+    }
+}
+
 static int few_enabled()
 {
     static const int v = [] { const char* e = getenv("MCVC_FEWOUT"); return e ? atoi(e) : 1; }();
@@ -249,6 +283,15 @@ int mcvc_disc_out_dgrad_launch(const float* dlogit, const float* w, float* dx, i
     long long blocks = cdiv_ll(total, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(disc_out_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dlogit, w, dx, NB, C, H, W);
+    return (int)hipGetLastError();
+}
+
+int mcvc_disc_conv1_fwd_launch(const float* x, const float* w, const float* bias, float* c0, float* y0, int NB, int Cout, int H, int W, hipStream_t s)
+{
+    const double outs = (double)NB * Cout * H * W;
+    TraceScope ts(K_CONV_FEW, s, 2.0 * 9 * outs, 4.0 * (2.0 * outs + (double)NB * H * W));
+    hipLaunchKernelGGL(disc_conv1_fwd_kernel, dim3((unsigned)cdiv_i(H * W, 256), (unsigned)cdiv_i(Cout, kDiscC1Cob), (unsigned)NB), dim3(256), 0, s,
+                       x, w, bias, c0, y0, Cout, H, W);
     return (int)hipGetLastError();
 }
 

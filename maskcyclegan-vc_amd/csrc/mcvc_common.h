@@ -183,6 +183,8 @@ int mcvc_fewout_plan_nsplit(const ConvProblem& p, int NB, int allow_split);
 int mcvc_fewout_launch(const ConvProblem& p, int NB, const ConvIO& io, const float* wpk, int w_cout, const float* bias, hipStream_t s);
 // the discriminators' output layer (1x3, C -> 1, + sigmoid) and its data-gradient; w / bias = the parameters themselves
 int mcvc_disc_out_fwd_launch(const float* x, const float* w, const float* bias, float* logit, float* out, int NB, int C, int H, int W, hipStream_t s);
+// the discriminators' first layer (3x3 from one channel) + x*sigmoid(x): c0 = pre-activation, y0 = activation, dense [NB][Cout][H][W]
+int mcvc_disc_conv1_fwd_launch(const float* x, const float* w, const float* bias, float* c0, float* y0, int NB, int Cout, int H, int W, hipStream_t s);
 int mcvc_disc_out_dgrad_launch(const float* dlogit, const float* w, float* dx, int NB, int C, int H, int W, hipStream_t s);
 
 struct WgradIO {

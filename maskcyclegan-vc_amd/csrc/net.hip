@@ -1451,7 +1451,8 @@ static DiscScratch disc_scratch(const DiscDims& d)
     return s;
 }
 
-// the output layer on its own two kernels (fewout_kernels.hip) instead of the generic few-output conv + slab-folding activation
+// the first (one input channel) and the output (one output channel) layer on their own kernels (fewout_kernels.hip) instead of the generic
+// conv + activation pairs
 static int disc_out_direct()
 {
     static const int en = [] { const char* e = getenv("MCVC_DISC_OUT"); return e ? atoi(e) : 1; }();
@@ -1466,9 +1467,13 @@ static void disc_forward_impl(Exec& ex, const float* const* P, const float* pack
     const int B = d.B, T = d.T;
     int ns = 1;
     // model.py:343-344  unsqueeze(1) -> conv 3x3 -> x*sigmoid(x)
-    conv_fwd(ex, n.conv1, packed, B, 80, T, CView{x, 80LL * T, 80LL * T, T}, View{st + o.c0, 128LL * 80 * T, 80LL * T, T},
-             (long long)B * 128 * 80 * T, 0, 1, &ns);
-    act_fwd(ex, st + o.c0, (long long)B * 128 * 80 * T, ns, st + o.y0, B, 128, 80 * T, ACT_SILU);
+    if (disc_out_direct() && !ex.dry) {
+        ex.fail(mcvc_disc_conv1_fwd_launch(x, P[n.conv1.wi[0]], P[n.conv1.bi[0]], st + o.c0, st + o.y0, B, 128, 80, T, ex.s));
+    } else {
+        conv_fwd(ex, n.conv1, packed, B, 80, T, CView{x, 80LL * T, 80LL * T, T}, View{st + o.c0, 128LL * 80 * T, 80LL * T, T},
+                 (long long)B * 128 * 80 * T, 0, 1, &ns);
+        act_fwd(ex, st + o.c0, (long long)B * 128 * 80 * T, ns, st + o.y0, B, 128, 80 * T, ACT_SILU);
+    }
     const float* h = st + o.y0;
     for (int i = 0; i < 3; ++i) {                       // :345-347
         const int Ci = kDC[i], Co = kDC[i + 1], Hi = d.H[i], Wi = d.W[i], Ho = d.H[i + 1], Wo = d.W[i + 1];
