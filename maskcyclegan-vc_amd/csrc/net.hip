@@ -360,8 +360,10 @@ static void sgemm_want(Exec& ex, long long floats) { if (floats > ex.sg_need) ex
 static int sgemm_split(int M, long long N, int K)
 {
     const long long tiles = (long long)(M / 64) * ((N + 63) / 64);
+    static const int wgs = [] { const char* e = getenv("MCVC_SGEMM_WGS"); return e ? atoi(e) : 256; }();
+    static const int maxsp = [] { const char* e = getenv("MCVC_SGEMM_MAXSPLIT"); return e ? atoi(e) : 8; }();
     int sp = 1;
-    while (sp < 8 && tiles * sp < 256 && (K % (64 * sp)) == 0 && K / (2 * sp) >= 64) sp *= 2;
+    while (sp < maxsp && tiles * sp < wgs && (K % (64 * sp)) == 0 && K / (2 * sp) >= 64) sp *= 2;
     return sp;
 }
 
