@@ -58,6 +58,7 @@ struct Exec {
     float* sg; long long sg_cap, sg_need;    // staging region of the staged-GEMM convolutions (sgemm.h): forward / data gradient (main stream)
     float* sgw; long long sgw_cap, sgw_need; // ... and the weight gradients' own (they may run on the auxiliary stream beside a data gradient)
     const float* const* params;    // the pass's parameter table (that path's data gradient multiplies the OIHW tensors themselves)
+    int br1_on_main = 0;           // conv_wgrad: run the gate branch's generic weight gradient on the main stream (see there)
     int fuse_next = 0;             // the caller's next step is a norm that can absorb a Winograd output transform (set before conv_fwd)
     int pend_pts = 0;              // 16 / 36: the output transform in `pend` has not run yet -- norm_fwd runs it (fused when it fits)
     WinoOutArgs pend;
@@ -681,7 +682,10 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         if (!dw) continue;
         WgradIO io{x.p, x.sb, x.sc, x.sh, dy.p + (long long)br * c.Cout * dy.sc, dy.sb, dy.sc, dy.sh};
         if (mcvc_wgrad_cin1_applies(p) && wgrad_cin1_enabled()) { ex.fail(mcvc_wgrad_cin1_launch(p, NB, io, dw, ws)); continue; }
-        ex.fail(mcvc_wgrad_launch(p, NB, io, dw, ex.wslabs, ex.wslab_cap, ws));
+        // last layer of a backward pass with nothing left for the main stream (conv1 without an input gradient): the gate branch runs
+        // there, beside the value branch on the auxiliary stream (atomic accumulation into its own tensor, no slabs to share)
+        const bool on_main = br == 1 && ex.br1_on_main && ex.s2 && !mcvc_deterministic() && (long long)c.Cout * c.Cin * c.KH * c.KW <= 65536;
+        ex.fail(mcvc_wgrad_launch(p, NB, io, dw, ex.wslabs, ex.wslab_cap, on_main ? ex.s : ws));
     }
     if (ex.s2) {
         hipEvent_t e = pool_event();
@@ -1387,7 +1391,9 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
     act_bwd(ex, st + o.c1, GA, (long long)B * 128 * 80 * T, ns, GB, B, 128, 80 * T, ACT_GLU);
     {
         CView dyv{GB, 256LL * 80 * T, 80LL * T, T};
+        ex.br1_on_main = (dx == nullptr) ? 1 : 0;
         conv_wgrad(ex, g.conv1, G, B, 80, T, CView{st + o.xin, 2LL * 80 * T, 80LL * T, T}, dyv);
+        ex.br1_on_main = 0;
         conv_bias_grad(ex, g.conv1, G, B, dyv, 80 * T);
         if (dx) {
             conv_dgrad(ex, g.conv1, packed, B, 80, T, dyv, View{GA, 2LL * 80 * T, 80LL * T, T}, (long long)B * 2 * 80 * T, 0, 1, &ns);
