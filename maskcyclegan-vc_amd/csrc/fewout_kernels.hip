@@ -346,38 +346,41 @@ struct FewWgradArgs {
     float* dw;                    // [Cin][KH][KW]
     int N, Cin, H, W, KH, KW, ph, pw;
     int XW;                       // LDS pitch of the haloed x plane
+    int band;                     // output rows per (sample, band) unit
 };
 
 __global__ void __launch_bounds__(256) wgrad_cout1_kernel(const FewWgradArgs a)
 {
     extern __shared__ float sm[];
-    const int XH = a.H + a.KH - 1;
+    const int BH = a.band;                       // output rows per unit; units = (sample, band), shared out over gridDim.y workgroups
+    const int XH = BH + a.KH - 1;
     float* xs = sm;                              // [XH][XW]
-    float* dys = sm + XH * a.XW;                 // [H][W]
-    float* red = dys + a.H * a.W;                // [groups][taps]
+    float* dys = sm + XH * a.XW;                 // [BH][W]
+    float* red = dys + BH * a.W;                 // [groups][taps]
     const int tid = threadIdx.x;
     const int ci = blockIdx.x;
     const int ntap = a.KH * a.KW;
     const int ngr = 256 / ntap;
     const int tap = tid % ntap, rg = tid / ntap;
     const int kh = tap / a.KW, kw = tap - kh * a.KW;
-    const int nchunk = (int)gridDim.y;
-    const int n_per = (a.N + nchunk - 1) / nchunk;
-    const int n_begin = (int)blockIdx.y * n_per;
-    const int n_end = (n_begin + n_per < a.N) ? n_begin + n_per : a.N;
+    const int nbands = (a.H + BH - 1) / BH;
+    const int units = a.N * nbands;
     float acc = 0.f;
-    for (int n = n_begin; n < n_end; ++n) {
+    for (int u = blockIdx.y; u < units; u += gridDim.y) {
+        const int n = u / nbands, h0 = (u - n * nbands) * BH;
+        const int rows = (a.H - h0 < BH) ? a.H - h0 : BH;
         const float* xp = a.x + (long long)n * a.x_sn + (long long)ci * a.x_sc;
-        for (int i = tid; i < XH * a.XW; i += 256) {
+        __syncthreads();
+        for (int i = tid; i < (rows + a.KH - 1) * a.XW; i += 256) {
             const int r = i / a.XW, c = i - r * a.XW;
-            const int ih = r - a.ph, iw = c - a.pw;
+            const int ih = h0 + r - a.ph, iw = c - a.pw;
             xs[i] = (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) ? xp[(long long)ih * a.x_sh + iw] : 0.f;
         }
-        const float* dp = a.dy + (long long)n * a.dy_sn;
-        for (int i = tid; i < a.H * a.W; i += 256) { const int r = i / a.W, c = i - r * a.W; dys[i] = dp[(long long)r * a.dy_sh + c]; }
+        const float* dp = a.dy + (long long)n * a.dy_sn + (long long)h0 * a.dy_sh;
+        for (int i = tid; i < rows * a.W; i += 256) { const int r = i / a.W, c = i - r * a.W; dys[i] = dp[(long long)r * a.dy_sh + c]; }
         __syncthreads();
         if (rg < ngr) {
-            for (int oh = rg; oh < a.H; oh += ngr) {
+            for (int oh = rg; oh < rows; oh += ngr) {
                 const float* d = dys + oh * a.W;
                 const float* xr = xs + (oh + kh) * a.XW + kw;
                 float s0 = 0.f, s1 = 0.f;
@@ -387,18 +390,17 @@ __global__ void __launch_bounds__(256) wgrad_cout1_kernel(const FewWgradArgs a)
                 acc += s0 + s1;
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     if (rg < ngr) red[rg * ntap + tap] = acc;
     __syncthreads();
-    if (tid < ntap && n_begin < n_end) {
+    if (tid < ntap && (int)blockIdx.y < units) {
         float s = 0.f;
         for (int g = 0; g < ngr; ++g) s += red[g * ntap + tid];
         float* d = a.dw + (long long)ci * ntap + tid;
-        if (nchunk > 1) unsafeAtomicAdd(d, s); else *d += s;
+        if (gridDim.y > 1) unsafeAtomicAdd(d, s); else *d += s;
     }
 }
-
 
 // One INPUT channel, 3x3, stride 1, padding 1 (the discriminators' first conv, model.py:290-295): dw[co][kh][kw] = sum over samples and
 // pixels of dy[n][co][h][w] * x[n][h+kh-1][w+kw-1].  The matrix kernel ran this 9-column problem at 0.6 TF/s (36 us, last launch of every
@@ -476,10 +478,16 @@ int mcvc_wgrad_cout1_launch(const ConvProblem& p, int NB, const WgradIO& io, flo
     a.dy = io.dy; a.dy_sn = io.dy_sb; a.dy_sh = io.dy_sh;
     a.dw = dw; a.N = NB; a.Cin = p.Cin; a.H = p.H; a.W = p.W; a.KH = p.KH; a.KW = p.KW; a.ph = p.pad_h; a.pw = p.pad_w;
     a.XW = p.W + p.KW - 1;
+    // (sample, band of rows) units over gridDim.y workgroups that add their partial sums atomically; deterministic mode: one workgroup per
+    // input channel walks whole planes in a fixed order
     int nchunk = 1;
-    if (!mcvc_deterministic())
-        while (2 * nchunk <= NB && nchunk < 32 && p.Cin * nchunk < 768) nchunk *= 2;
-    const size_t lds = ((size_t)(p.H + p.KH - 1) * a.XW + (size_t)p.H * p.W + 256) * sizeof(float);
+    a.band = p.H;
+    if (!mcvc_deterministic()) {
+        while (a.band > 20 && p.Cin * NB * cdiv_i(p.H, a.band) < 512) a.band = (a.band + 1) / 2;
+        const int units = NB * cdiv_i(p.H, a.band);
+        while (2 * nchunk <= units && nchunk < 32 && p.Cin * nchunk < 768) nchunk *= 2;
+    }
+    const size_t lds = ((size_t)(a.band + p.KH - 1) * a.XW + (size_t)a.band * p.W + 256) * sizeof(float);
     TraceScope ts(K_WGRAD_SMALLK, s, 2.0 * NB * p.H * p.W * p.Cin * p.KH * p.KW, 4.0 * ((double)NB * p.Cin * p.H * p.W + (double)NB * p.H * p.W * p.Cin));
     hipLaunchKernelGGL(wgrad_cout1_kernel, dim3((unsigned)p.Cin, (unsigned)nchunk), dim3(256), lds, s, a);
     return (int)hipGetLastError();
