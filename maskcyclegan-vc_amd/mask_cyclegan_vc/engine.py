@@ -155,7 +155,11 @@ class TrainEngine:
         self._d_pack_event = None
         # data parallel: start the discriminator gradient all-reduce at the end of an iteration and finish the update
         # (wait + Adam + re-pack) where the discriminators are next used, i.e. after the next generator forwards
-        self.defer_d_update = self.reducer.world > 1
+        # With more than one rank the discriminators' Adam step (+ re-pack) is queued where they are next needed (lane 2 of the next generator
+        # phase) so that the gradient exchange hides behind the generator forwards.  On one GPU the same deferral is SLOWER (MCVC_DEFER_D=1:
+        # 6.91 -> 7.26 ms at bs=1, 30.4 -> 31.3 at bs=8): Adam's 0.7 GB of traffic beside the two generator forwards costs them more than
+        # the 0.11 ms it takes alone between two iterations.
+        self.defer_d_update = self.reducer.world > 1 or os.environ.get("MCVC_DEFER_D", "0") != "0"
         self._pending_d_lr = None
         # ... and the generator gradient all-reduce starts per parameter range while the last backward passes are still
         # running: the library records an event when a range's gradients are complete (mcvc_gen_backward_overlap)
@@ -578,7 +582,7 @@ class TrainEngine:
     def discriminator_update(self):
         """train.py:299.  With more than one rank the all-reduce is only *started* here; Adam runs when the discriminators
         are next needed (``_finish_d_update``), so the exchange overlaps the next iteration's generator forwards."""
-        if self.defer_d_update:
+        if self.defer_d_update and (self.reducer.world > 1 or not self.use_graphs):
             self.reducer.reduce_async_(self.d_group.grad)
             self._pending_d_lr = self.sched.d_opt_lr          # the value torch.optim would have used now
             return
@@ -619,7 +623,9 @@ class TrainEngine:
 
     def step(self, real_A, mask_A, real_B, mask_B):
         """One full iteration.  Inputs: float32 [B,80,T] on the engine's device.  Returns the loss-slot
-        tensor (device); ``losses()`` does the host read the reference does with ``.item()`` (train.py:303)."""
+        tensor (device); ``losses()`` does the host read the reference does with ``.item()`` (train.py:303).
+        With more than one rank the discriminators' Adam step of this iteration is queued by the next ``step()`` (or by ``flush()``):
+        call ``flush()`` before reading parameters or optimizer state from outside the engine."""
         _hip.require_cuda_f32(real_A, mask_A, real_B, mask_B)
         if tuple(real_A.shape[1:]) != (80, self.T):
             raise ValueError("batch shape %s does not match the engine (B, 80, %d)" % (tuple(real_A.shape), self.T))

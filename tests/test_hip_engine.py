@@ -51,6 +51,7 @@ def _run_against_golden(golden_dir, tag, n_it):
         lr_before = (sched.g_opt_lr, sched.d_opt_lr)
         eng.step(*batch)
         lo = eng.losses()
+        eng.flush()                          # the discriminators' Adam step is deferred to the next use: land it before reading parameters
         ref = js["losses"][it]
         assert abs(lo["g_loss"] - ref["g_loss"]) < 1e-3 * abs(ref["g_loss"]), (it, lo, ref)
         assert abs(lo["d_loss"] - ref["d_loss"]) < 1e-3 * abs(ref["d_loss"]), (it, lo, ref)
@@ -139,6 +140,7 @@ def test_step_full_tensor_parity_vs_oracle(golden_dir, B, T):
             p.data.copy_(onets[name][k].to(p.device))
     eng._run_phase("D")
     eng.discriminator_update()
+    eng.flush()
     eng.sched.end_iteration()
     lo = eng.losses()
     assert abs(lo["g_loss"] - g_ref) < 1e-4 * abs(g_ref) and abs(lo["d_loss"] - d_ref) < 1e-4 * abs(d_ref)

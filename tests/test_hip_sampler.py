@@ -105,6 +105,7 @@ def test_engine_step_sampled_equals_step_on_the_same_minibatch():
                     ref, _ = so.draw_batch(dA, dB, 2, 64, 25, seed=77, step=it)
                     eng.step(*[torch.from_numpy(a).cuda() for a in ref])
                 losses.append(tuple(sorted(eng.losses().items())))
+            eng.flush()
             finals.append((losses, [p.detach().clone() for n in G_NAMES + D_NAMES for p in nets[n].parameters()]))
         assert finals[0][0] == finals[1][0]
         assert all(torch.equal(a, b) for a, b in zip(finals[0][1], finals[1][1]))
