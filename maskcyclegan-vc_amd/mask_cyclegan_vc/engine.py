@@ -436,11 +436,24 @@ class TrainEngine:
             self.g_group.step += 1
         g_step, g_lr = self.g_group.step, sc.g_opt_lr
 
+        def queue_reduce(ln):
+            # data parallel: the generator gradients are exchanged range by range BEHIND the last backward passes (their milestone events;
+            # the tails behind the passes themselves), on the communication stream, in the same order on every rank
+            for k in range(2):
+                for n in G_NAMES:
+                    lo, hi = self._g_ranges[n][k]
+                    self.reducer.reduce_range_after_(self.g_group.grad, lo, hi, self._ms[n][0][k])
+            for n, ev in zip(G_NAMES, ("fA2B", "fB2A")):
+                lo, hi = self._g_ranges[n][2]
+                self.reducer.reduce_range_after_(self.g_group.grad, lo, hi, self._task_events[ev])
+
         def update(name):
             def run(ln):
+                self.reducer.wait(self.device)             # (no-op on one GPU)
                 self._adam_generator(name, g_step, g_lr)
                 self._repack1(name, 1)
             return run
+        assert G_NAMES[0] == "generator_A2B"
         self._run_tasks([
             (0, lambda ln: self._G("generator_A2B", self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], B2, ln), (), "g0"),   # :203, :209-210
             (1, lambda ln: self._G("generator_B2A", self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], B2, ln), (), "g1"),   # :205, :207-208
@@ -455,9 +468,10 @@ class TrainEngine:
             (0, lambda ln: self._G_bwd("generator_B2A", None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B, ln), ("dB",), "c0"),
             (1, lambda ln: self._G_bwd("generator_A2B", None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, ln), ("dA",), "c1"),
             # the last pass over each generator: its gradient ranges become final one after the other (milestone events)
-            (0, lambda ln: self._G_bwd("generator_A2B", self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2, ln, ov), ("c1",), None),
-            (1, lambda ln: self._G_bwd("generator_B2A", self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2, ln, ov), ("c0",), None),
-        ] + ([(0, update("generator_A2B"), (), None), (1, update("generator_B2A"), (), None)] if fuse_update else []))
+            (0, lambda ln: self._G_bwd("generator_A2B", self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2, ln, ov), ("c1",), "fA2B"),
+            (1, lambda ln: self._G_bwd("generator_B2A", self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2, ln, ov), ("c0",), "fB2A"),
+        ] + ([(2, queue_reduce, (), None)] if (fuse_update and ov) else [])
+          + ([(0, update("generator_A2B"), (), None), (1, update("generator_B2A"), (), None)] if fuse_update else []))
         self._g_fwd_packed = bool(fuse_update)
         self._d_pack_event = None
         self._combine(0, self._comb_g)          # g_loss and its terms, summed in the reference's order (:233-237)
@@ -645,7 +659,7 @@ class TrainEngine:
         return self._step_static()
 
     def _step_static(self):
-        if self.reducer.world == 1 and not self.use_graphs and self.fuse_g_update:
+        if (self.reducer.world == 1 or self.overlap_g_reduce) and not self.use_graphs and self.fuse_g_update:
             self.generator_phase(*self.static_in, fuse_update=True)       # includes the generator update (per lane, no join)
         else:
             self._run_phase("G")

@@ -108,11 +108,31 @@ def main():
     del eng
     eng2 = TrainEngine(nets_for(800), PER_RANK, 64, schedule=StepSchedule(batch_size=PER_RANK, n_samples=64, world_size=world),
                        reducer=FlatGradReducer())
+    mean_losses = []
     for it in range(3):
         eng2.step(*batch_of(range(100 + 16 * it + 8 * rank, 100 + 16 * it + 8 * rank + PER_RANK)))
         lo = eng2.losses()
         assert np.isfinite(lo["g_loss"]) and np.isfinite(lo["d_loss"])
+        t = torch.tensor([lo["g_loss"], lo["d_loss"]], dtype=torch.float64)
+        dist.all_reduce(t)
+        mean_losses.append((t / world).tolist())
     eng2.flush()
+    # ---- (3) the same three iterations in ONE process on the concatenated minibatches: the losses (means over the global batch) must
+    # agree -- exactly the arithmetic before the first update, and closely after two (Adam's first steps amplify rounding)
+    if rank == 0:
+        solo = FlatGradReducer()
+        solo.world = 1
+        ref = TrainEngine(nets_for(800), 2 * PER_RANK, 64, schedule=StepSchedule(batch_size=2 * PER_RANK, n_samples=64), reducer=solo)
+        for it in range(3):
+            ref.step(*batch_of(range(100 + 16 * it, 100 + 16 * it + 2 * PER_RANK)))
+            lo = ref.losses()
+            for a, b in zip(mean_losses[it], (lo["g_loss"], lo["d_loss"])):
+                tol = 1e-4 if it == 0 else 5e-2
+                if abs(a - b) > tol * abs(b):
+                    print("iteration %d: 2-rank mean loss %.6f vs single-process %.6f" % (it, a, b), flush=True)
+                    ok = False
+        print("2-rank losses vs single process: %s" % ("match" if ok else "MISMATCH"), flush=True)
+        del ref
     for grp in (eng2.g_group, eng2.d_group):
         hi, lo_ = grp.flat.clone(), grp.flat.clone()
         dist.all_reduce(hi, op=dist.ReduceOp.MAX); dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
