@@ -76,20 +76,21 @@ def build_nets(device):
 
 
 def pmc_traffic(kernel, B):
-    """(HBM bytes per launch, source) of this kernel family from the committed rocprofv3 PMC passes of THIS round's binary
-    (two separate --pmc passes, FETCH_SIZE x2 + WRITE_SIZE, summarised by tools/pmc_traffic.py into
-    profiles/r02_pmc_traffic_bs<B>.json together with the git revision they were taken at).  The counters cannot be read
-    from inside the bench, so this is a labelled constant, not a live measurement; (None, None) when there is no summary."""
-    name = "r02_pmc_traffic_bs%d.json" % B
-    try:
-        with open(os.path.join(ROOT, "profiles", name)) as fh:
-            js = json.load(fh)
-        fam = js["families"].get(kernel)
-        if fam is None:
-            return None, None
-        return fam["hbm_bytes_per_launch"], "profiles/%s@%s" % (name, js.get("git_rev", "?"))
-    except (OSError, ValueError, KeyError):
-        return None, None
+    """(HBM bytes per launch, source) of this kernel family from the committed rocprofv3 PMC passes (two separate --pmc passes,
+    FETCH_SIZE x2 + WRITE_SIZE, summarised by tools/pmc_traffic.py into profiles/r<NN>_pmc_traffic_bs<B>.json together with the git
+    revision they were taken at; the newest round's file wins).  The counters cannot be read from inside the bench, so this is a
+    labelled constant, not a live measurement: `traffic_source` names file and revision; (None, None) when there is no summary."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic_bs%d.json" % B)), reverse=True):
+        try:
+            with open(path) as fh:
+                js = json.load(fh)
+            fam = js["families"].get(kernel)
+            if fam is not None:
+                return fam["hbm_bytes_per_launch"], "profiles/%s@%s" % (os.path.basename(path), js.get("git_rev", "?"))
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
 
 
 def trace_one_step(engine, batch):
@@ -114,8 +115,10 @@ def trace_one_step(engine, batch):
     return rows
 
 
-def cpu_baseline(B, T, n_timed, first_losses, threads=0):
-    """The oracle (CPU restatement pinned to the reference, tests/test_oracle_golden.py) on the host cores."""
+def cpu_baseline(B, T, n_timed, first_losses, threads=0, warm=True):
+    """The oracle (CPU restatement pinned to the reference, tests/test_oracle_golden.py) on the host cores.  ``warm=False`` (the extra
+    configs of the default run, after the bs=1 baseline has warmed the process): no separate warm-up iteration -- the FIRST timed iteration
+    doubles as the parity probe -- so that a bs=32 sample costs one iteration (~16 s), not two."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mcvc_oracle as orc
     # mkldnn oversubscribes badly on a 256-core host (one iteration did not finish in 10 minutes);
@@ -124,32 +127,31 @@ def cpu_baseline(B, T, n_timed, first_losses, threads=0):
     log("cpu baseline: %d threads" % torch.get_num_threads())
     nets = orc.default_init_nets(0)
     so = orc.StepOracle(nets)
-    batches = synthetic_batches(1 + n_timed, B, T, 0, "cpu")
+    batches = synthetic_batches((1 if warm else 0) + n_timed, B, T, 0, "cpu")
     t0 = time.perf_counter()
     g0, d0 = so.step(*batches[0])                     # warm-up iteration (also the parity probe)
     t_first = time.perf_counter() - t0
-    log("cpu warm-up iteration %.1f s" % t_first)
+    log("cpu %s iteration %.1f s" % ("warm-up" if warm else "first timed", t_first))
     t0 = time.perf_counter()
     for b in batches[1:]:
         so.step(*b)
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0 + (0.0 if warm else t_first)
     parity = None
     if first_losses is not None:
         parity = {"g_loss_rel": abs(first_losses[0] - g0) / abs(g0), "d_loss_rel": abs(first_losses[1] - d0) / abs(d0)}
     return {"value": n_timed / dt, "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": cpu_model(),
-            "sample": "%d timed full G+D iterations at bs=%d 80x%d after 1 warm-up (%.1f s); oracle/mcvc_oracle.StepOracle, "
-                      "reference autograd semantics incl. its discarded work" % (n_timed, B, T, t_first),
+            "sample": "%d timed full G+D iterations at bs=%d 80x%d %s (%.1f s); oracle/mcvc_oracle.StepOracle, "
+                      "reference autograd semantics incl. its discarded work"
+                      % (n_timed, B, T, "after 1 warm-up" if warm else "in a process already warm from the bs=1 sample, first iteration", t_first),
             "host_cpus": os.cpu_count()}, parity
 
 
-def infer_main(args, rank, world, device):
+def infer_record(args, rank, world, device, dtype, B, T, steps, warmup):
     """BASELINE configs[4]: generator_A2B inference (test.py path), bs=16, 80 mel x 512 frames, all-ones mask, weights = the seeded
     default init cast to the compute dtype.  A step = one batched forward; value = mel-frames/s = 16*512 / latency, summed over ranks
-    (independent replicas: inference has no exchange step)."""
+    (independent replicas: inference has no exchange step).  Returns the record on rank 0 (None elsewhere)."""
     from mask_cyclegan_vc.model import Generator
-    dtype = args.dtype or "bf16"
-    B = args.batch_size if args.batch_size != 1 else 16
-    T = args.frames if args.frames != 64 else 512
+    args = argparse.Namespace(**dict(vars(args), steps=steps, warmup=warmup))
     torch.manual_seed(0)
     gen = Generator().to(device)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -227,10 +229,8 @@ def infer_main(args, rank, world, device):
                                    "sample": "oracle.generator_forward (fp32) on %d of the %d samples x %d frames (%.1f s)" % (nb, B, T, cdt)}
             res["parity_vs_cpu_rel_l2"] = float((got.double() - ref.double()).norm() / ref.double().norm())
             res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
-        print(json.dumps(res))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        return res
+    return None
 
 
 _T0 = time.perf_counter()
@@ -240,7 +240,7 @@ def log(msg):
     print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -254,34 +254,35 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--cpu-iters", type=int, default=-1, help="timed CPU-baseline iterations (0 = skip; default: about 10-30 s of CPU work)")
     ap.add_argument("--no-trace", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="default single-GPU run: skip the nested records of BASELINE configs[2..4]")
     ap.add_argument("--serial", action="store_true", help="one stream: no lanes, no auxiliary weight-gradient stream (A/B comparison, per-kernel profiling)")
     ap.add_argument("--graphs", action="store_true", help="replay HIP graphs of the two phases (experimental; not faster on ROCm 7.2)")
     ap.add_argument("--no-pass-graphs", action="store_true", help="launch every network pass eagerly instead of replaying its HIP graph (A/B)")
     ap.add_argument("--graphs-aux", action="store_true", help="with --graphs: keep the auxiliary weight-gradient streams inside the capture")
     ap.add_argument("--dump-trace", default=None, help="write one traced step's per-launch records (launch order) to this file")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def dist_info(world, device):
+    """What the gradient exchange actually ran on: an all-reduce of ones proves that `world` ranks took part in a collective on the
+    benchmark's own backend (RCCL when one GPU per rank is visible)."""
+    if world <= 1:
+        return {"backend": None, "world": 1, "rccl_ranks_seen": 1}
+    ones = torch.ones(1, device=device)
+    dist.all_reduce(ones)
+    return {"backend": dist.get_backend(), "world": world, "rccl_ranks_seen": int(round(float(ones.item()))),
+            "gpus_visible": torch.cuda.device_count()}
+
+
+def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_batches, cpu_warm=True, config_id=None):
+    """One timed training configuration (a full G+D iteration at per-GPU batch B): W warm-up + exactly K timed steps between
+    barrier + synchronize pairs, max over ranks; then one traced step (per-kernel HIP events) for the roofline of the dominant kernel
+    family and the CPU oracle on a bounded sample of the same workload.  Returns the record on rank 0 (None elsewhere)."""
     from mask_cyclegan_vc.engine import TrainEngine
-    from mask_cyclegan_vc.parallel import FlatGradReducer, init_from_env
+    from mask_cyclegan_vc.parallel import FlatGradReducer
     from mask_cyclegan_vc.schedule import StepSchedule
-
-    rank, world, local_rank = init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    local_rank %= max(torch.cuda.device_count(), 1)      # (only differs on a box with fewer GPUs than ranks: gloo test runs)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if args.mode == "infer":
-        return infer_main(args, rank, world, device)
-    B, T = args.batch_size, args.frames
-    if args.cpu_iters < 0:                 # bounded CPU sample: ~1 s per bs=1 iteration on 32 threads of the GPU box's host
-        args.cpu_iters = max(2, min(12, 12 // B))
-    if args.deterministic:
-        from mask_cyclegan_vc import _hip
-        _hip.lib().mcvc_set_deterministic(1)
-
-    log("building nets")
+    log("bs=%d: building nets" % B)
     nets = build_nets(device)
     sched = StepSchedule(generator_lr=2e-4, discriminator_lr=1e-4, num_epochs=6172, n_samples=81, batch_size=B,
                          decay_after=2e5, stop_identity_after=1e4, world_size=world)     # bash_scripts/mask_cyclegan_train.sh
@@ -294,7 +295,7 @@ def main():
         engine.pass_graphs = False          # (phase-level capture and per-pass capture do not nest)
     if args.graphs and not args.graphs_aux:
         engine.aux_wgrad = False            # lanes + auxiliary streams in one capture crash hipStreamEndCapture (ROCm 7.2)
-    batches = synthetic_batches(args.n_batches, B, T, rank, device)
+    batches = synthetic_batches(n_batches, B, T, rank, device)
     log("engine ready; warm-up")
 
     # the whole benchmark runs on a non-default stream when asked (experiment: the legacy NULL stream has its own ordering rules)
@@ -302,7 +303,7 @@ def main():
     run_ctx = torch.cuda.stream(torch.cuda.Stream(device=device)) if os.environ.get("MCVC_BENCH_STREAM") == "1" else contextlib.nullcontext()
     run_ctx.__enter__()
     first = None
-    for i in range(args.warmup):
+    for i in range(warmup):
         engine.step(*batches[i % len(batches)])
         if i == 0:
             lo = engine.losses()
@@ -311,10 +312,10 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    log("timing %d steps" % args.steps)
+    log("timing %d steps" % steps)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        engine.step(*batches[(args.warmup + i) % len(batches)])
+    for i in range(steps):
+        engine.step(*batches[(warmup + i) % len(batches)])
         engine.losses()                    # the reference reads both losses every iteration (train.py:303)
     engine.flush()                         # ... and the last one to the timed region: exactly K complete iterations
     if world > 1:
@@ -327,11 +328,12 @@ def main():
         dt = float(t.item())
 
     run_ctx.__exit__(None, None, None)
-    log("timed region done: %.2f ms/step" % (1e3 * dt / args.steps))
+    log("timed region done: %.2f ms/step" % (1e3 * dt / steps))
+    engine.check_faults()
     final = engine.losses()
     finite = all(np.isfinite(v) for v in final.values())
     rows = [] if args.no_trace else trace_one_step(engine, batches[0])
-    if args.dump_trace and rank == 0:
+    if args.dump_trace and rank == 0 and config_id is None:
         from mask_cyclegan_vc import _hip
         L = _hip.lib()
         buf = (ctypes.c_double * (4 * 8192))()
@@ -348,46 +350,98 @@ def main():
                 k, ms, fl, by = buf[4 * i:4 * i + 4]
                 fh.write("%4d %-24s %9.4f ms %10.4f GF %9.3f MB %8.2f TF/s %8.1f GB/s\n" % (
                     i, L.mcvc_trace_kind_name(int(k)).decode(), ms, fl / 1e9, by / 1e6, fl / 1e9 / max(ms, 1e-6), by / 1e6 / max(ms, 1e-6)))
+    del engine, nets
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    ms = 1e3 * dt / steps
+    value = world * steps / dt
+    sample_iters = world * B * steps / dt
+    res = {
+        "metric": "train iters/s (full G+D step), 80x%d mel bs=%d" % (T, B),
+        "value": value, "unit": "iters/s (per-GPU bs=%d iterations, summed over GPUs)" % B,
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "MaskCycleGAN-VC full G+D iteration, VCC2018-shaped synthetic mels, bs=%d/GPU, 80 mel x %d frames, fp32, "
+                               "default-init weights (seed 0)" % (B, T),
+                   "global_batch": world * B, "parallelism": "dp%d" % world},
+        "mel_frames_per_s": sample_iters * T,
+        "step_mfma_fraction": sample_iters * ALG_GFLOP_PER_SAMPLE_ITER / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world),
+        "losses_finite": finite, "last_losses": final, "n_batches": len(batches), "deterministic": bool(args.deterministic),
+    }
+    if config_id:
+        res["config_id"] = config_id
+    if rows:
+        conv = [r for r in rows if r["gflop"] > 0]
+        dom = max(conv, key=lambda r: r["ms"])
+        total_ms = sum(r["ms"] for r in rows)
+        ach = dom["gflop"] / dom["ms"]          # GFLOP/ms == TFLOP/s
+        traffic, traffic_src = pmc_traffic(dom["kernel"], B)
+        res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dom["kernel"],
+                           "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
+                           "share_of_kernel_time": dom["ms"] / total_ms, "flops": "executed (as launched)",
+                           "executed_gflop_per_step": round(dom["gflop"], 2)}
+        res["kernel_time_ms_per_step"] = {r["kernel"]: round(r["ms"], 4) for r in rows}
+        res["kernel_launches_per_step"] = int(sum(r["launches"] for r in rows))
+        res["all_conv_tflops"] = sum(r["gflop"] for r in conv) / sum(r["ms"] for r in conv)
+        # step_mfma_fraction counts the ALGORITHMIC (direct-convolution) FLOPs of SURVEY 8d; the 5x5 layers execute 0.36x / 0.44x of
+        # theirs as Winograd products, so at large batch that figure approaches (and may pass) 1 -- the executed one cannot
+        res["executed_gflop_per_sample_iter"] = round(sum(r["gflop"] for r in conv) / B, 1)
+        res["algorithmic_gflop_per_sample_iter"] = ALG_GFLOP_PER_SAMPLE_ITER
+        res["step_executed_mfma_fraction"] = sum(r["gflop"] for r in conv) / ms / PEAK_FP32_MFMA_TFLOPS
+    log("trace done")
+    if world == 1 and cpu_iters > 0:
+        cb, parity = cpu_baseline(B, T, cpu_iters, first, args.cpu_threads, warm=cpu_warm)
+        res["cpu_baseline"] = cb
+        res["parity_first_iteration_vs_cpu"] = parity
+        res["speedup_vs_cpu"] = value / cb["value"]
+    return res
 
-    if rank == 0:
-        ms = 1e3 * dt / args.steps
-        value = world * args.steps / dt
-        sample_iters = world * B * args.steps / dt
-        res = {
-            "metric": "train iters/s (full G+D step), 80x%d mel bs=%d" % (T, B),
-            "value": value, "unit": "iters/s (per-GPU bs=%d iterations, summed over GPUs)" % B,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "MaskCycleGAN-VC full G+D iteration, VCC2018-shaped synthetic mels, bs=%d/GPU, 80 mel x %d frames, fp32, "
-                                   "default-init weights (seed 0)" % (B, T),
-                       "global_batch": world * B, "parallelism": "dp%d" % world},
-            "mel_frames_per_s": sample_iters * T,
-            "step_mfma_fraction": sample_iters * ALG_GFLOP_PER_SAMPLE_ITER / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world),
-            "losses_finite": finite, "last_losses": final, "n_batches": len(batches), "deterministic": bool(args.deterministic),
-        }
-        if rows:
-            conv = [r for r in rows if r["gflop"] > 0]
-            dom = max(conv, key=lambda r: r["ms"])
-            total_ms = sum(r["ms"] for r in rows)
-            ach = dom["gflop"] / dom["ms"]          # GFLOP/ms == TFLOP/s
-            traffic, traffic_src = pmc_traffic(dom["kernel"], B)
-            res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dom["kernel"],
-                               "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
-                               "share_of_kernel_time": dom["ms"] / total_ms}
-            res["kernel_time_ms_per_step"] = {r["kernel"]: round(r["ms"], 4) for r in rows}
-            res["kernel_launches_per_step"] = int(sum(r["launches"] for r in rows))
-            res["all_conv_tflops"] = sum(r["gflop"] for r in conv) / sum(r["ms"] for r in conv)
-            # step_mfma_fraction counts the ALGORITHMIC (direct-convolution) FLOPs of SURVEY 8d; the 5x5 layers execute 0.36x / 0.44x of
-            # theirs as Winograd products, so at large batch that figure approaches (and may pass) 1 -- the executed one cannot
-            res["executed_gflop_per_sample_iter"] = round(sum(r["gflop"] for r in conv) / B, 1)
-            res["step_executed_mfma_fraction"] = sum(r["gflop"] for r in conv) / ms / PEAK_FP32_MFMA_TFLOPS
-        log("trace done")
-        if world == 1 and args.cpu_iters > 0:
-            cb, parity = cpu_baseline(B, T, args.cpu_iters, first, args.cpu_threads)
-            res["cpu_baseline"] = cb
-            res["parity_first_iteration_vs_cpu"] = parity
-            res["speedup_vs_cpu"] = value / cb["value"]
+
+def main():
+    args = parse_args()
+    from mask_cyclegan_vc.parallel import init_from_env
+
+    rank, world, local_rank = init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    local_rank %= max(torch.cuda.device_count(), 1)      # (only differs on a box with fewer GPUs than ranks: gloo test runs)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if args.deterministic:
+        from mask_cyclegan_vc import _hip
+        _hip.lib().mcvc_set_deterministic(1)
+    if args.mode == "infer":
+        res = infer_record(args, rank, world, device, args.dtype or "bf16", args.batch_size if args.batch_size != 1 else 16,
+                           args.frames if args.frames != 64 else 512, args.steps, args.warmup)
+    else:
+        B, T = args.batch_size, args.frames
+        cpu_iters = args.cpu_iters
+        if cpu_iters < 0:                  # bounded CPU sample: ~1 s per bs=1 iteration on 32 threads of the GPU box's host
+            cpu_iters = max(2, min(12, 12 // B))
+        res = train_record(args, rank, world, device, B, T, args.steps, args.warmup, cpu_iters, args.n_batches)
+        # The default single-GPU invocation (the one the driver runs) also measures the other BASELINE configs, each as a nested record
+        # with its own roofline and CPU sample: configs[2] = the bs=32 step, the per-GPU shape of configs[3] = the bs=8 step, configs[4] =
+        # generator_A2B bf16 inference at 16 x 512 frames.  The headline line above them is unchanged (configs[1], bs=1).
+        if world == 1 and B == 1 and T == 64 and not args.no_extra_configs and not (args.serial or args.graphs):
+            extra = []
+            sub = argparse.Namespace(**dict(vars(args), dump_trace=None))
+            skip_cpu = args.cpu_iters == 0
+            extra.append(train_record(sub, rank, world, device, 32, 64, 8, 3, 0 if skip_cpu else 1, 8, cpu_warm=False,
+                                      config_id="configs[2]: bs=32, 1 GPU"))
+            extra.append(train_record(sub, rank, world, device, 8, 64, 20, 5, 0 if skip_cpu else 2, 16, cpu_warm=False,
+                                      config_id="configs[3] per-GPU shape: bs=8 (the 8-GPU run itself is the driver's)"))
+            sub_i = argparse.Namespace(**dict(vars(sub), cpu_iters=0 if skip_cpu else -1))
+            rec = infer_record(sub_i, rank, world, device, "bf16", 16, 512, 30, 5)
+            if rec is not None:
+                rec["config_id"] = "configs[4]: generator_A2B inference, bs=16 x 512 frames, bf16"
+            extra.append(rec)
+            if res is not None:
+                res["configs"] = [r for r in extra if r is not None]
+    info = dist_info(world, device)
+    if rank == 0 and res is not None:
+        res["dist"] = info
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -93,6 +93,16 @@ int mcvc_gen_backward_overlap(const float* const* params, const float* packed, f
                               float* scratch, long long scratch_floats, int B, int T, void* stream, void* aux_stream,
                               void* const* milestones);
 
+/*      The small-batch passes run the residual trunk as ONE persistent launch whose 64 workgroups hand activations to each other inside
+ *      the kernel (bounded spins).  Should a workgroup ever give up (the device cannot keep all 64 resident: more than four such passes in
+ *      flight at once), the pass's output is poisoned with NaN -- so every loss of the step turns non-finite -- and an error word in the
+ *      scratch buffer records the layer.  mcvc_gen_trunk_fault reads that word (0 = none, 1 + layer otherwise, negative = call failed) and
+ *      optionally clears it; it SYNCHRONISES `stream`.  Call it with reset != 0 once after allocating a scratch buffer (the word is not
+ *      initialised by the passes), then e.g. once per logging interval.  mcvc_debug_trunk_fault_inject(1) makes the following persistent
+ *      launches lose one arrival (test hook for exactly this path); returns the previous setting.             */
+int mcvc_gen_trunk_fault(float* scratch, int B, int T, int reset, void* stream);
+int mcvc_debug_trunk_fault_inject(int on);
+
 /* ---- Generator inference in bf16 (BASELINE configs[4]: generator_A2B, bs=16, 80 x 512 frames).  Replaces the call
  *      `generator(real, ones_like(real))` of the reference's inference driver (mask_cyclegan_vc/test.py:92, 107 ->
  *      Generator.forward, model.py:239-280) when the caller asks for bf16: NHWC bf16 activations, bf16 MFMA with fp32

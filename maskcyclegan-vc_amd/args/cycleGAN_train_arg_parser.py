@@ -16,7 +16,9 @@ class CycleGANTrainArgParser(TrainArgParser):
         ("--num_frames", dict(type=int, default=64, help="Num frames per training sample.")),
         ("--num_frames_validation", dict(type=int, default=320, help="Num frames per validation sample.")),
         ("--max_mask_len", dict(type=int, default=32, help="Maximum length of mask for Mask-CycleGAN-VC.")),
-        # (new) MI355X / data-parallel knobs -- additive, defaults keep the reference behaviour
+        # (new) MI355X / data-parallel knobs -- additive.  NOTE the default input path is the on-device sampler: the reference's
+        # distributions from a counter-based random stream, NOT the reference's numpy draws -- pass --host_sampler for minibatches that
+        # are bit-identical to the reference's for a given --seed (dataset/vc_dataset.py)
         ("--allreduce_bucket_mb", dict(type=int, default=64, help="(new) RCCL gradient all-reduce bucket size in MiB.")),
         ("--max_iters", dict(type=int, default=0, help="(new) stop after this many iterations (0 = run all epochs).")),
         ("--host_sampler", dict(action="store_true", help="(new) draw minibatches on the host with the reference's RNG-exact VCDataset + DataLoader "

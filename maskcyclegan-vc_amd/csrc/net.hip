@@ -1754,6 +1754,21 @@ int mcvc_gen_forward(const float* const* params, const float* packed, const floa
     return ex.err;
 }
 
+// Error word of the persistent trunk kernels in a generator scratch buffer (sticky until reset): 0 = no fault, 1 + l = a workgroup gave
+// up waiting for the arrivals of layer l (the pass's output was poisoned with NaN).  SYNCHRONOUS (a 4-byte device-to-host copy on `stream`).
+int mcvc_gen_trunk_fault(float* scratch, int B, int T, int reset, void* stream)
+{
+    if (!scratch || B < 1 || T < 1) return -MCVC_ERR_INVALID;
+    unsigned* w = reinterpret_cast<unsigned*>(scratch + gen_scratch(gen_dims(B, T)).sync) + MCVC_TRUNK_SYNC_WORDS - 1;
+    unsigned v = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(&v, w, sizeof(v), hipMemcpyDeviceToHost, s) != hipSuccess) return -MCVC_ERR_INVALID;
+    if (reset && hipMemsetAsync(w, 0, sizeof(v), s) != hipSuccess) return -MCVC_ERR_INVALID;
+    if (hipStreamSynchronize(s) != hipSuccess) return -MCVC_ERR_INVALID;
+    return (int)v;
+}
+int mcvc_debug_trunk_fault_inject(int on) { return mcvc_trunk_set_fault_inject(on); }
+
 int mcvc_gen_backward_overlap(const float* const* params, const float* packed, float* const* grads, const float* mask, const float* dout,
                               float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T,
                               void* stream, void* aux_stream, void* const* milestones)

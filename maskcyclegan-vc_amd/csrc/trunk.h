@@ -62,7 +62,14 @@ struct TrunkFwdNetArgs {
     int x_floats;                            // LDS floats reserved for the staged input (max over the layers)
     float eps;
     unsigned* sync;                          // [nlayers + 2] arrival counters + error word, zeroed by the launcher
+    int fault_inject;                        // test hook: workgroup 0 skips its first arrival (set by the launcher)
 };
+int mcvc_trunk_set_fault_inject(int on);
+// Co-residency: the kernel's 64 workgroups wait for each other, so all 64 must be resident at once -- each takes a whole CU (up to 160 KB
+// of LDS).  With P persistent passes in flight on different streams the device needs 64 * P <= 256 CUs for every pass to be guaranteed
+// progress; the trainer runs at most two generator passes at a time (one grouped launch = 128 workgroups, or two lanes of 64).  Beyond that
+// a pass can only be delayed, not deadlocked, as long as the over-subscribing passes are not ALL partially resident; the bounded spin in
+// wait_arrivals turns even that case into a reported fault (NaN result + error word) instead of a hang.
 // true when the persistent forward handles (B, T4) -- same regime as the per-layer fused kernels (N = B*T4 <= 32)
 bool mcvc_trunk_net_applies(int B, int T4);
 int mcvc_trunk_fwd_net_launch(TrunkFwdNetArgs& a, hipStream_t s);

@@ -677,7 +677,19 @@ __global__ void __launch_bounds__(kNetThreads) trunk_fwd_net_kernel(const TrunkF
             // the activations are staged (their latencies overlap instead of adding up)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (flag[0] == 0.f) return;            // (uniform) a workgroup never arrived: give up instead of hanging the device
+            if (flag[0] == 0.f) {                  // (uniform) a workgroup never arrived: give up instead of hanging the device ...
+                // ... and make the failure VISIBLE: the pass's result (the last layer's output rows this workgroup owns) becomes NaN, which
+                // reaches every loss term of the step; the error word (read by mcvc_gen_trunk_fault) names the layer.  A missing arrival
+                // stalls every workgroup at the same layer, so all of them take this path and the whole output is poisoned.
+                const TrunkLayerDesc& dl = a.L[a.nlayers - 1];
+                const int N = a.B * a.T4;
+                for (int tile = blockIdx.x; tile < dl.M / dl.rows; tile += gridDim.x)
+                    for (int i = tid; i < dl.rows * N; i += kNetThreads) {
+                        const int row = i / N, col = i - row * N, b = col / a.T4, t = col - b * a.T4;
+                        dl.y[(long long)b * dl.y_sn + (long long)(tile * dl.rows + row) * dl.y_sc + t] = __builtin_nanf("");
+                    }
+                return;
+            }
         }
         if (d.KW == 3) net_stage_x<3>(d.x, Xs, d.Cin, a.B, a.T4, tid, l > 0); else net_stage_x<1>(d.x, Xs, d.Cin, a.B, a.T4, tid, l > 0);
         __syncthreads();
@@ -690,7 +702,8 @@ __global__ void __launch_bounds__(kNetThreads) trunk_fwd_net_kernel(const TrunkF
         if (wt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // EVERY storing wave drains its write-through stores
             __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(a.sync + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !(a.fault_inject && l == 0 && blockIdx.x == 0))      // (test hook: workgroup 0 "never arrives" at layer 0)
+                __hip_atomic_fetch_add(a.sync + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -782,6 +795,10 @@ bool mcvc_trunk_net_applies(int B, int T4)
     return (x + kNetEpiFloats) * 4 <= 156 * 1024;
 }
 
+// test hook (mcvc_debug_trunk_fault_inject): the next persistent launches lose one arrival, so that the give-up path can be exercised
+static int g_trunk_fault_inject = 0;
+int mcvc_trunk_set_fault_inject(int on) { const int was = g_trunk_fault_inject; g_trunk_fault_inject = on ? 1 : 0; return was; }
+
 int mcvc_trunk_fwd_net_launch(TrunkFwdNetArgs& a, hipStream_t s)
 {
     if (!mcvc_trunk_net_applies(a.B, a.T4) || a.nlayers < 1 || a.nlayers > MCVC_TRUNK_NET_LAYERS || !a.sync) return MCVC_ERR_INVALID;
@@ -802,9 +819,10 @@ int mcvc_trunk_fwd_net_launch(TrunkFwdNetArgs& a, hipStream_t s)
         bytes += 4.0 * (mt * K + (double)d.Cin * N + 3.0 * mt * N);
     }
     a.x_floats = (int)((xmax + 3) & ~3LL);
+    a.fault_inject = g_trunk_fault_inject;
     const size_t lds = ((size_t)a.x_floats + kNetEpiFloats) * sizeof(float);
     if (lds > 160 * 1024) return MCVC_ERR_INVALID;
-    hipError_t e = hipMemsetAsync(a.sync, 0, MCVC_TRUNK_SYNC_WORDS * sizeof(unsigned), s);
+    hipError_t e = hipMemsetAsync(a.sync, 0, (MCVC_TRUNK_SYNC_WORDS - 1) * sizeof(unsigned), s);      // (the error word is sticky: mcvc_gen_trunk_fault)
     if (e != hipSuccess) return (int)e;
     TraceScope ts(K_TRUNK, s, flops, bytes);
     const bool wide = N > 16;

@@ -223,6 +223,9 @@ class TrainEngine:
                 dout2=[f(B2, 1, 10, T8) for _ in range(4)], dlogit2=[f(B2, 1, 10, T8) for _ in range(4)],
             )
             self._workspaces[B] = ws
+            for sc in ws["g_scratch"]:      # the persistent trunk kernels' error word is sticky and not initialised by the passes
+                for nb in (B, B2):
+                    self.L.mcvc_gen_trunk_fault(ptr(sc), nb, T, 1, stream())
         self.B = B
         for k, v in ws.items():
             setattr(self, k, v)
@@ -445,7 +448,9 @@ class TrainEngine:
                     self.reducer.reduce_range_after_(self.g_group.grad, lo, hi, self._ms[n][0][k])
             for n, ev in zip(G_NAMES, ("fA2B", "fB2A")):
                 lo, hi = self._g_ranges[n][2]
-                self.reducer.reduce_range_after_(self.g_group.grad, lo, hi, self._task_events[ev])
+                # serial mode records no task events (one stream: everything queued so far is the dependency); a stale event of an
+                # earlier concurrent iteration must not be used either
+                self.reducer.reduce_range_after_(self.g_group.grad, lo, hi, self._task_events.get(ev) if self.concurrent else None)
 
         def update(name):
             def run(ln):
@@ -704,6 +709,17 @@ class TrainEngine:
                 return
             self._graphs[key] = g
         g.replay()
+
+    def check_faults(self):
+        """Raise if a persistent trunk launch of this engine ever gave up waiting for its workgroups (its result was poisoned with NaN, so
+        the losses are non-finite as well).  Synchronises the device: call it per logging interval, not per step."""
+        for B, ws in self._workspaces.items():
+            for lane, sc in enumerate(ws["g_scratch"]):
+                for nb in (B, 2 * B):
+                    code = self.L.mcvc_gen_trunk_fault(ptr(sc), nb, self.T, 0, stream())
+                    if code != 0:
+                        raise RuntimeError("persistent trunk kernel fault %d (layer %d) in lane %d at batch %d: more concurrent generator "
+                                           "passes than the device can keep resident" % (code, code - 1, lane, nb))
 
     def losses(self):
         v = self.slots.tolist()      # device sync, like the reference's .item()

@@ -51,6 +51,18 @@ class MaskCycleGANVCTesting(object):
         streams = [torch.cuda.Stream(device=self.device) for _ in range(2)]
         pending = []
         k = 0
+
+        def drain(keep):
+            """Write out the oldest groups until at most ``keep`` are in flight: device memory stays bounded by a few groups whatever the
+            dataset size (the reference holds one utterance at a time, test.py:85-119)."""
+            while len(pending) > keep:
+                grp, fake, _real, ev = pending.pop(0)
+                ev.synchronize()                              # the group's own stream is done with `fake` and `_real`
+                host = fake.cpu().numpy()
+                for j, i in enumerate(grp):
+                    path = os.path.join(self.converted_dir, "%d-converted_%s.npy" % (i, tag))
+                    np.save(path, denormalize_mel(host[j], mean, std).astype(np.float32))
+                    outs[i] = path
         with torch.no_grad():
             for T in sorted(buckets, reverse=True):
                 ids = buckets[T]
@@ -61,16 +73,13 @@ class MaskCycleGANVCTesting(object):
                     with torch.cuda.stream(st):
                         real = torch.from_numpy(np.stack([np.asarray(src[i], dtype=np.float32) for i in grp])).to(self.device, non_blocking=True)
                         fake = self.generator.infer(real, None, dtype=self.args.dtype).float()      # all-ones mask (test.py:92)
-                    pending.append((grp, fake, real))         # keep `real` alive until the stream is done with it
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                    pending.append((grp, fake, real, ev))     # keep `real` alive until the stream is done with it
+                    drain(4)                                  # two groups per stream in flight
+            drain(0)
             for st in streams:
                 torch.cuda.current_stream(self.device).wait_stream(st)
-            torch.cuda.synchronize(self.device)
-            for grp, fake, _ in pending:
-                host = fake.cpu().numpy()
-                for j, i in enumerate(grp):
-                    path = os.path.join(self.converted_dir, "%d-converted_%s.npy" % (i, tag))
-                    np.save(path, denormalize_mel(host[j], mean, std).astype(np.float32))
-                    outs[i] = path
         print("wrote %d converted mel-spectrograms to %s" % (len(outs), self.converted_dir))
         return outs
 

@@ -69,6 +69,11 @@ class MaskCycleGANVCTraining(object):
         else:
             self.sampler = DeviceSampler(self.dataset_A, self.dataset_B, n_frames=args.num_frames, max_mask_len=args.max_mask_len,
                                          device=self.device, seed=args.seed + 7919 * self.rank)
+            # the sampler's random stream is keyed by (seed, minibatch number): a resumed run continues with the minibatch the
+            # uninterrupted run would have drawn next (epochs have ceil(len(dataset) / batch_size) iterations), so
+            # `--continue_train --start_epoch k` reproduces epochs k.. of a straight run exactly (tests/test_hip_cli.py)
+            iters_per_epoch = -(-len(self.dataset) // self.mini_batch_size)
+            self.sampler.step = (args.start_epoch - 1) * iters_per_epoch
         # validation pair (reference train.py:86-96: VCDataset(valid=True), batch_size 1, no shuffle -> the first utterances, whole)
         self.validation_dataset = VCDataset(datasetA=self.dataset_A, datasetB=self.dataset_B, n_frames=args.num_frames_validation,
                                             max_mask_len=args.max_mask_len, valid=True)

@@ -73,10 +73,16 @@ PER_RANK = 8          # BASELINE configs[3]: bs=8 per GPU
 def main():
     import faulthandler
     faulthandler.dump_traceback_later(300, exit=True)      # a mismatched collective would otherwise hang the GPU box
-    os.environ["MCVC_DIST_BACKEND"] = "gloo"
-    rank, world, _ = init_from_env()
-    assert world == 2
-    torch.cuda.set_device(0)
+    # MCVC_TEST_DDP_BACKEND=nccl: RCCL with one GPU per rank (needs >= 2 GPUs); default gloo with both ranks on cuda:0 (a dev box has one)
+    backend = os.environ.get("MCVC_TEST_DDP_BACKEND", "gloo")
+    os.environ["MCVC_DIST_BACKEND"] = backend
+    rank, world, local_rank = init_from_env()
+    assert world == 2 and dist.get_backend() == backend
+    dev = local_rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    cdev = torch.device("cuda", dev) if backend == "nccl" else torch.device("cpu")      # where small collectives' tensors live
+    if rank == 0:
+        print("backend %s, ranks on %s" % (backend, "one GPU each" if backend == "nccl" else "cuda:0 (shared)"), flush=True)
     # ---- (1) gradient equivalence of the generator phase at bs=8 per rank
     eng = TrainEngine(nets_for(700 + 10 * 0), PER_RANK, 64, schedule=StepSchedule(batch_size=PER_RANK, n_samples=64, world_size=world),
                       reducer=FlatGradReducer())
@@ -113,7 +119,7 @@ def main():
         eng2.step(*batch_of(range(100 + 16 * it + 8 * rank, 100 + 16 * it + 8 * rank + PER_RANK)))
         lo = eng2.losses()
         assert np.isfinite(lo["g_loss"]) and np.isfinite(lo["d_loss"])
-        t = torch.tensor([lo["g_loss"], lo["d_loss"]], dtype=torch.float64)
+        t = torch.tensor([lo["g_loss"], lo["d_loss"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(t)
         mean_losses.append((t / world).tolist())
     eng2.flush()
@@ -141,8 +147,9 @@ def main():
             print("parameter spread across ranks %.3e" % spread, flush=True)
         ok = ok and spread == 0.0
     assert eng2.d_group.step == 3 and eng2.g_group.step == 3
-    flag = torch.tensor([1.0 if ok else 0.0])
+    flag = torch.tensor([1.0 if ok else 0.0], device=cdev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    torch.cuda.synchronize()
     dist.destroy_process_group()
     sys.exit(0 if float(flag) == 1.0 else 1)
 

@@ -27,7 +27,27 @@ def test_bench_under_torchrun_two_ranks():
     assert res["config"]["global_batch"] == 2 and res["config"]["parallelism"] == "dp2"
     assert res["losses_finite"] and res["value"] > 0
     assert abs(res["value"] - 2 * 1e3 / res["ms_per_step"]) < 1e-6 * res["value"]        # whole-job rate = ranks x per-rank rate
-    assert "cpu_baseline" not in res                           # N=1 only
+    assert "cpu_baseline" not in res and "configs" not in res   # N=1 only
+    assert res["dist"]["backend"] == "gloo" and res["dist"]["world"] == 2 and res["dist"]["rccl_ranks_seen"] == 2
+
+
+def test_default_single_gpu_bench_carries_every_baseline_config():
+    """The invocation the driver runs (`python bench.py --gpus 1 ...`) must measure BASELINE configs[2], the per-GPU shape of configs[3]
+    and configs[4] besides the bs=1 headline, each as a nested record with its own roofline (CPU samples skipped here for time)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "3", "--cpu-iters", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["config"]["global_batch"] == 1 and res["n_gpus"] == 1 and res["steps"] == 5 and res["losses_finite"]
+    assert res["roofline"]["frac"] > 0 and res["dist"] == {"backend": None, "world": 1, "rccl_ranks_seen": 1}
+    ids = [c["config_id"] for c in res["configs"]]
+    assert len(ids) == 3 and ids[0].startswith("configs[2]") and ids[1].startswith("configs[3]") and ids[2].startswith("configs[4]")
+    assert [c["config"]["global_batch"] for c in res["configs"]] == [32, 8, 16]
+    for c in res["configs"]:
+        assert c["value"] > 0 and c["ms_per_step"] > 0 and 0 < c["roofline"]["frac"] < 1 and c["roofline"]["kernel"]
+    assert res["configs"][2]["dtype"] == "bf16" and res["configs"][2]["outputs_finite"]
 
 
 def test_nccl_backend_refuses_fewer_gpus_than_ranks():

@@ -308,3 +308,31 @@ def test_generator_repack_in_two_parts_and_its_guard():
         assert all(torch.equal(a, b) for a, b in zip(ga, gb))
     finally:
         L.mcvc_set_deterministic(0)
+
+
+def test_persistent_trunk_fault_is_reported_not_silent():
+    """The persistent trunk kernel's workgroups wait for each other with bounded spins.  If one never arrives (test hook: workgroup 0 skips
+    its first arrival) the pass must not hand garbage on: its output is NaN and the scratch buffer's error word names the layer; the
+    next healthy pass is bit-identical to the one before the fault."""
+    from mask_cyclegan_vc._hip import lib, ptr, stream
+    L = lib()
+    torch.manual_seed(3)
+    g = Generator().cuda()
+    x = torch.randn(1, 80, 64, device="cuda")
+    y0 = g.infer(x).clone()
+    (_stash, scratch), = [v for v in g._iws.values() if isinstance(v, tuple)]
+    assert L.mcvc_gen_trunk_fault(ptr(scratch), 1, 64, 1, stream()) >= 0          # (first read clears whatever torch.empty left there)
+    assert L.mcvc_gen_trunk_fault(ptr(scratch), 1, 64, 0, stream()) == 0
+    assert torch.isfinite(y0).all()
+    was = L.mcvc_debug_trunk_fault_inject(1)
+    try:
+        y1 = g.infer(x).clone()
+        torch.cuda.synchronize()
+    finally:
+        L.mcvc_debug_trunk_fault_inject(was)
+    assert torch.isnan(y1).all(), "a lost arrival must poison the pass's result"
+    assert L.mcvc_gen_trunk_fault(ptr(scratch), 1, 64, 0, stream()) == 2           # 1 + layer 1: its input (layer 0's rows) never became complete
+    assert L.mcvc_gen_trunk_fault(ptr(scratch), 1, 64, 1, stream()) == 2           # sticky until reset ...
+    assert L.mcvc_gen_trunk_fault(ptr(scratch), 1, 64, 0, stream()) == 0
+    y2 = g.infer(x)
+    assert torch.equal(y2, y0) and L.mcvc_gen_trunk_fault(ptr(scratch), 1, 64, 0, stream()) == 0

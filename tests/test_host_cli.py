@@ -226,3 +226,78 @@ def test_logger_counters(tmp_path):
     assert lg.epoch == 4 and not lg.is_finished_training()
     text = open(tmp_path / "n" / "n.log").read()
     assert "[start of epoch 3]" in text and "g_loss: 1.000" in text
+
+
+REF_ROOT = "/root/reference"
+
+
+def _load_reference_module(name, rel):
+    """The unmodified reference file as a private module (build container only; nothing of it is copied or shipped)."""
+    import importlib.util
+    sys.dont_write_bytecode = True
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF_ROOT, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_ROOT), reason="needs the reference checkout (build container only)")
+def test_checkpoints_interchange_with_the_reference_saver(tmp_path):
+    """SURVEY.md section 8 f1, both directions, with the REFERENCE's own code on the other side: a file written by the reference's
+    ``ModelSaver.save`` (saver/model_saver.py:46-93) from reference modules + torch.optim.Adam loads through this repo's
+    ``ModelSaver.load_model`` into this repo's modules (strict key set, bit-equal tensors, optimizer state), and a file written
+    by this repo's saver loads through the reference's ``load_model`` (:95-123) into reference modules."""
+    from argparse import Namespace
+    from mask_cyclegan_vc.model import Discriminator, Generator
+    ref_model = _load_reference_module("_ref_model_for_ckpt_test", "mask_cyclegan_vc/model.py")
+    ref_saver_mod = _load_reference_module("_ref_saver_for_ckpt_test", "saver/model_saver.py")
+    d_ref, d_ours = tmp_path / "ref", tmp_path / "ours"
+    d_ref.mkdir(); d_ours.mkdir()
+    ref_saver = ref_saver_mod.ModelSaver(Namespace(ckpt_dir=str(d_ref), load_epoch=5, gpu_ids=["cpu"]))
+    our_saver = ModelSaver(Namespace(ckpt_dir=str(d_ref), load_epoch=5, gpu_ids=["cpu"]))
+
+    def adam_with_state(model, lr, dead_prefix=None):
+        opt = torch.optim.Adam(model.parameters(), lr=lr, betas=(0.5, 0.999))
+        g = torch.Generator().manual_seed(11)
+        for n, p in model.named_parameters():
+            if dead_prefix is None or not n.startswith(dead_prefix):
+                p.grad = torch.randn(p.shape, generator=g)
+        opt.step()
+        return opt
+
+    def same_opt(a, b):
+        sa, sb = a.state_dict(), b.state_dict()
+        assert sorted(sa["state"]) == sorted(sb["state"])
+        for k in sa["state"]:
+            for f in ("step", "exp_avg", "exp_avg_sq"):
+                assert torch.equal(torch.as_tensor(sa["state"][k][f]), torch.as_tensor(sb["state"][k][f])), (k, f)
+        ga, gb = sa["param_groups"][0], sb["param_groups"][0]
+        assert ga["lr"] == gb["lr"] and tuple(ga["betas"]) == tuple(gb["betas"]) and ga["params"] == gb["params"]
+
+    for name, RefCls, OurCls, lr, dead in (("generator_A2B", ref_model.Generator, Generator, 2e-4, None),
+                                           ("discriminator_A", ref_model.Discriminator, Discriminator, 1e-4, "downSample4.")):
+        # ---- reference writes, we read
+        torch.manual_seed(1)
+        src = RefCls()
+        opt_src = adam_with_state(src, lr, dead)
+        ref_saver.save(5, src, opt_src, None, "cpu", name)
+        torch.manual_seed(2)
+        dst = OurCls()
+        opt_dst = torch.optim.Adam(dst.parameters(), lr=9.0, betas=(0.9, 0.9))
+        ck = our_saver.load_model(dst, name, None, opt_dst)
+        assert ck["ckpt_info"] == {"epoch": 5} and ck["model_class"] == RefCls.__name__
+        assert list(dst.state_dict()) == list(src.state_dict())
+        assert all(torch.equal(a, b) for a, b in zip(dst.state_dict().values(), src.state_dict().values()))
+        same_opt(opt_dst, opt_src)
+        # ---- we write, the reference reads
+        torch.manual_seed(3)
+        mine = OurCls()
+        opt_mine = adam_with_state(mine, lr, dead)
+        ModelSaver(Namespace(ckpt_dir=str(d_ours), load_epoch=6, gpu_ids=["cpu"])).save(6, mine, opt_mine, None, "cpu", name)
+        torch.manual_seed(4)
+        theirs = RefCls()
+        opt_theirs = torch.optim.Adam(theirs.parameters(), lr=9.0, betas=(0.9, 0.9))
+        ref_saver_mod.ModelSaver(Namespace(ckpt_dir=str(d_ours), load_epoch=6, gpu_ids=["cpu"])).load_model(theirs, name, None, opt_theirs)
+        assert list(theirs.state_dict()) == list(mine.state_dict())
+        assert all(torch.equal(a, b) for a, b in zip(theirs.state_dict().values(), mine.state_dict().values()))
+        same_opt(opt_theirs, opt_mine)
