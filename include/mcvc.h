@@ -48,6 +48,21 @@ int mcvc_get_deterministic(void);
  * bit-identical either way; the switch exists for A/B timing and tests.  Returns the previous setting.                 */
 int mcvc_set_trunk_persistent(int on);
 
+/* ---- grouped launches: two networks of the same architecture in one grid (new; the reference runs G_A2B / G_B2A and the discriminator
+ *      pairs one after the other, train.py:203-216, 255-273).  Bracket TWO identical sequences of library calls that differ in pointers
+ *      only (weights, activations, workspaces, destinations -- same B, T, flags, streams):
+ *          mcvc_twin_begin();   <sequence on network 0>   mcvc_twin_switch();   <the same sequence on network 1>   rc = mcvc_twin_end();
+ *      Between begin and switch nothing reaches the stream (the launches are recorded); the second sequence launches every kernel ONCE
+ *      with gridDim.z = 2, one z-slice per network: half the launches, twice the workgroups per launch.  Any call that launches kernels
+ *      may appear inside (passes, losses, packs, Adam); calls keep their meaning and return codes.  mcvc_twin_end returns MCVC_ERR_INVALID
+ *      if the two sequences did not issue the same kernels with the same grids (nothing is repaired: treat the buffers as undefined).
+ *      The bracket is per host thread; do not enqueue other work on the same streams between begin and switch (it would run BEFORE the
+ *      grouped kernels).  The trace (mcvc_trace_*) counts a grouped launch once, with both networks' FLOPs and bytes.      */
+int mcvc_twin_begin(void);
+int mcvc_twin_switch(void);
+int mcvc_twin_end(void);
+int mcvc_twin_launches(void);           /* kernels recorded by the last bracket of this thread */
+
 /* ---- sizes (floats) -------------------------------------------------------------------------- */
 long long mcvc_gen_packed_floats(void);
 long long mcvc_disc_packed_floats(void);

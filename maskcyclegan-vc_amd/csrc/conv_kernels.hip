@@ -7,6 +7,7 @@
 // re-packed weights, see pack_kernels.hip) and weight-gradient.
 #include "mcvc_common.h"
 #include "trace.h"
+#include "launch.h"
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -63,8 +64,9 @@ __device__ __forceinline__ void glds16(const float* g, float* l)
 // ds_read immediates.  (With runtime kh/kw/stride arithmetic each tap cost ~30 SALU instructions; the scalar unit
 // is shared by the CU's 8 resident waves, which made the loop SALU-bound at ~2x the MFMA time.)
 template <int WM, int WN, int BMW, int BNW, int KW, bool S2>
-__global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const ConvArgs a)
+__global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const Twin<ConvArgs> tw)
 {
+    const ConvArgs& a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int COT = 32 * WM * BMW;
     constexpr int NSUB = WN * BNW;
@@ -517,7 +519,7 @@ static hipError_t launch_cfg_kw(const ConvPlan& pl, hipStream_t s)
     const double px = (double)nb * a.OH * a.OW;
     TraceScope ts(kCfg[pl.cfg].kind, s, 2.0 * px * a.Cout * a.Cin * a.KH * a.KW,
                   4.0 * ((double)nb * a.Cin * a.H * a.W + (double)a.Cin * a.KH * a.KW * a.Cout + px * a.Cout * a.nsplit));
-    hipLaunchKernelGGL(kern, pl.grid, dim3(256), pl.lds_bytes, s, pl.a);
+    mcvc_launch(kern, pl.grid, dim3(256), pl.lds_bytes, s, pl.a);
     return hipGetLastError();
 }
 
@@ -597,8 +599,9 @@ int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float
 // `dw +=` directly (ksplit == 1, deterministic) or to this K-split's private slab, which
 // wgrad_reduce_kernel then folds into dw (no atomics anywhere).
 template <int MS, int KWT, int MAXT, int MINW>
-__global__ void __launch_bounds__(MAXT, MINW) conv_wgrad_kernel(const WgradArgs a)
+__global__ void __launch_bounds__(MAXT, MINW) conv_wgrad_kernel(const Twin<WgradArgs> tw)
 {
+    const WgradArgs& a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int lane = tid & 63;
@@ -756,9 +759,16 @@ __global__ void __launch_bounds__(MAXT, MINW) conv_wgrad_kernel(const WgradArgs 
 }
 
 // dw[i] += sum_z slabs[z][i]   (slab z starts at z*stride; stride % 4 == 0; vec: dw is 16-byte aligned)
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(float* __restrict__ dw, const float* __restrict__ slabs, long long n,
-                                                           long long stride, int ksplit, int vec)
+struct WgradReduceKArgs { float* dw; const float* slabs; long long n; long long stride; int ksplit; int vec; };
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const Twin<WgradReduceKArgs> tw)
 {
+    const WgradReduceKArgs& ka_ = tw.v[blockIdx.z];
+    float* __restrict__ dw = ka_.dw;
+    const float* __restrict__ slabs = ka_.slabs;
+    long long n = ka_.n;
+    long long stride = ka_.stride;
+    int ksplit = ka_.ksplit;
+    int vec = ka_.vec;
     if (!vec) {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
             float acc = dw[i];
@@ -797,8 +807,9 @@ struct SmallKArgs {
 };
 
 template <int KW, int COB>
-__global__ void __launch_bounds__(256) wgrad_smallk_kernel(const SmallKArgs a)
+__global__ void __launch_bounds__(256) wgrad_smallk_kernel(const Twin<SmallKArgs> tw)
 {
+    const SmallKArgs& a = tw.v[blockIdx.z];
     __shared__ float dys[COB * 128];
     const int tid = threadIdx.x;
     const int co0 = blockIdx.x * COB;
@@ -852,8 +863,9 @@ __global__ void __launch_bounds__(256) wgrad_smallk_kernel(const SmallKArgs a)
 // ---- the same, batched over layers (k = 3, trunk layout [C][B][T4], B*T4 <= 128): block -> (job, 4 output channels, 256 input channels)
 struct SmallKBatch { SmallKJob job[MCVC_SMALLK_MAX_JOBS]; int first[MCVC_SMALLK_MAX_JOBS + 1]; int njobs, B, T4; };
 
-__global__ void __launch_bounds__(256) wgrad_smallk_batch_kernel(const SmallKBatch bt)
+__global__ void __launch_bounds__(256) wgrad_smallk_batch_kernel(const Twin<SmallKBatch> tw)
 {
+    const SmallKBatch& bt = tw.v[blockIdx.z];
     constexpr int KW = 3, COB = 4;
     __shared__ float dys[COB * 128];
     const int tid = threadIdx.x;
@@ -923,7 +935,7 @@ int mcvc_wgrad_smallk_batch_launch(const SmallKJob* jobs, int njobs, int B, int 
     }
     bt.first[njobs] = total; bt.njobs = njobs; bt.B = B; bt.T4 = T4;
     TraceScope ts(K_WGRAD_SMALLK, s, flops, bytes);
-    hipLaunchKernelGGL(wgrad_smallk_batch_kernel, dim3((unsigned)total), dim3(256), 0, s, bt);
+    mcvc_launch(wgrad_smallk_batch_kernel, dim3((unsigned)total), dim3(256), 0, s, bt);
     return (int)hipGetLastError();
 }
 
@@ -944,7 +956,7 @@ static hipError_t launch_wgrad(const WgradArgs& a, dim3 grid, int nwaves, size_t
     const double px = (double)a.NB * a.OH * a.OW;
     TraceScope ts(kind, s, 2.0 * px * a.Cout * a.Cin * a.KH * a.KW,
                   4.0 * ((double)a.NB * a.Cin * a.H * a.W + px * a.Cout + (double)a.Cout * a.Cin * a.KH * a.KW * (a.ksplit > 1 ? a.ksplit : 2)));
-    hipLaunchKernelGGL(kern, grid, dim3(64 * nwaves), lds, s, a);
+    mcvc_launch(kern, grid, dim3(64 * nwaves), lds, s, a);
     return hipGetLastError();
 }
 
@@ -1106,8 +1118,8 @@ int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw
         dim3 grid((unsigned)cdiv_i(p.Cout, COB), (unsigned)cdiv_i(p.Cin, 256));
         const double px = (double)NB * p.OH * p.OW;
         TraceScope ts(K_WGRAD_SMALLK, s, 2.0 * px * p.Cout * p.Cin * p.KW, 4.0 * (2.0 * p.Cout * p.Cin * p.KW + px * (p.Cin + p.Cout)));
-        if (p.KW == 3) hipLaunchKernelGGL((wgrad_smallk_kernel<3, COB>), grid, dim3(256), 0, s, k);
-        else hipLaunchKernelGGL((wgrad_smallk_kernel<1, COB>), grid, dim3(256), 0, s, k);
+        if (p.KW == 3) mcvc_launch((wgrad_smallk_kernel<3, COB>), grid, dim3(256), 0, s, k);
+        else mcvc_launch((wgrad_smallk_kernel<1, COB>), grid, dim3(256), 0, s, k);
         return (int)hipGetLastError();
     }
     WgradPlan pl;
@@ -1132,7 +1144,7 @@ int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw
         if (b < 1) b = 1;
         TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (double)a.dw_floats * (a.ksplit + 2));
         const int vec = (((uintptr_t)dw | (uintptr_t)slabs) & 15) == 0;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, s, dw, slabs, a.dw_floats, a.slab_stride, a.ksplit, vec);
+        mcvc_launch(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, s, WgradReduceKArgs{dw, slabs, a.dw_floats, a.slab_stride, a.ksplit, vec});
         e = hipGetLastError();
     }
     return (int)e;

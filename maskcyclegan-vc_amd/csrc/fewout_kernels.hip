@@ -12,6 +12,7 @@
 // through the same split-K slab / accumulate conventions as conv_direct_kernel (the consumer kernel folds the slabs).
 #include "mcvc_common.h"
 #include "trace.h"
+#include "launch.h"
 #include <stdlib.h>
 
 namespace {
@@ -36,19 +37,20 @@ struct FewArgs {
     int Cin, H, W, Cout, OH, OW, KH, pad_h, pad_w;
     int w_cout;                  // row pitch of the packed weight matrix
     int tiles_w, tiles_h;
-    int nsplit, ch_per_split;
+    int nsplit, ch_per_split, NB;
     int PH, PWp;                 // LDS patch rows / pitch (multiple of 4)
     int accumulate;
 };
 
 template <int CO, int KW>
-__global__ void __launch_bounds__(256) conv_fewout_kernel(const FewArgs a)
+__global__ void __launch_bounds__(256) conv_fewout_kernel(const Twin<FewArgs> tw)
 {
+    const FewArgs& a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float xs[];          // [2 buffers][kFewCC][PH][PWp]
     constexpr int NV = (4 + KW - 1 + 3) / 4;                            // float4 reads per row window
     const int tid = threadIdx.x;
     const int tx = tid & 15, ty = tid >> 4;
-    const int tile = blockIdx.x, n = blockIdx.y, split = blockIdx.z;
+    const int tile = blockIdx.x, split = blockIdx.y / a.NB, n = blockIdx.y - split * a.NB;      // (blockIdx.z selects the network of a grouped launch)
     const int oh0 = (tile / a.tiles_w) * kFewTH, ow0 = (tile % a.tiles_w) * kFewTW;
     const int ih0 = oh0 - a.pad_h, iw0 = ow0 - a.pad_w;
     const int plane = a.PH * a.PWp;
@@ -163,9 +165,19 @@ __global__ void __launch_bounds__(256) conv_fewout_kernel(const FewArgs a)
 // 80 output values per sample from C = 1024 channels: as a split-K job of the kernel above it took 21 us + 17 us for the consumer that folded
 // 64 slabs.  One wave per output value instead: the lanes stride over the channels (all loads independent), a butterfly sums them, lane 0
 // stores the logit (+ bias) and its sigmoid.  w = the OIHW parameter itself ([1][C][1][3]).
-__global__ void __launch_bounds__(256) disc_out_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                           float* __restrict__ logit, float* __restrict__ out, int NB, int C, int H, int W)
+struct DiscOutFwdKArgs { const float* x; const float* w; const float* bias; float* logit; float* out; int NB; int C; int H; int W; };
+__global__ void __launch_bounds__(256) disc_out_fwd_kernel(const Twin<DiscOutFwdKArgs> tw)
 {
+    const DiscOutFwdKArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ x = ka_.x;
+    const float* __restrict__ w = ka_.w;
+    const float* __restrict__ bias = ka_.bias;
+    float* __restrict__ logit = ka_.logit;
+    float* __restrict__ out = ka_.out;
+    int NB = ka_.NB;
+    int C = ka_.C;
+    int H = ka_.H;
+    int W = ka_.W;
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int HW = H * W;
     if (o >= NB * HW) return;
@@ -189,9 +201,17 @@ __global__ void __launch_bounds__(256) disc_out_fwd_kernel(const float* __restri
 }
 
 // its data-gradient: dx[n][c][h][w] = sum_kw w[c][kw] * dlogit[n][h][w + 1 - kw]
-__global__ void __launch_bounds__(256) disc_out_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ w, float* __restrict__ dx,
-                                                             int NB, int C, int H, int W)
+struct DiscOutDgradKArgs { const float* dl; const float* w; float* dx; int NB; int C; int H; int W; };
+__global__ void __launch_bounds__(256) disc_out_dgrad_kernel(const Twin<DiscOutDgradKArgs> tw)
 {
+    const DiscOutDgradKArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ dl = ka_.dl;
+    const float* __restrict__ w = ka_.w;
+    float* __restrict__ dx = ka_.dx;
+    int NB = ka_.NB;
+    int C = ka_.C;
+    int H = ka_.H;
+    int W = ka_.W;
     const long long total = (long long)NB * C * H * W;
     const int HW = H * W;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -212,11 +232,21 @@ __global__ void __launch_bounds__(256) disc_out_dgrad_kernel(const float* __rest
 // pixel in registers and walks COB output channels (weights: wave-uniform scalar loads); it stores the pre-activation (backward) and the
 // activation, both coalesced along the pixels.  w = the OIHW parameter ([Cout][1][3][3]).
 constexpr int kDiscC1Cob = 16;
-__global__ void __launch_bounds__(256) disc_conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                             float* __restrict__ c0, float* __restrict__ y0, int Cout, int H, int W)
+struct DiscConv1FwdKArgs { const float* x; const float* w; const float* bias; float* c0; float* y0; int Cout; int H; int W; };
+__global__ void __launch_bounds__(256) disc_conv1_fwd_kernel(const Twin<DiscConv1FwdKArgs> tw)
 {
+    const DiscConv1FwdKArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ x = ka_.x;
+    const float* __restrict__ w = ka_.w;
+    const float* __restrict__ bias = ka_.bias;
+    float* __restrict__ c0 = ka_.c0;
+    float* __restrict__ y0 = ka_.y0;
+    int Cout = ka_.Cout;
+    int H = ka_.H;
+    int W = ka_.W;
     const int HW = H * W;
-    const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.z, co0 = blockIdx.y * kDiscC1Cob;
+    const int cbs = (Cout + kDiscC1Cob - 1) / kDiscC1Cob;          // (blockIdx.z selects the network of a grouped launch: the sample rides in y)
+    const int p = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y / cbs, co0 = (blockIdx.y - n * cbs) * kDiscC1Cob;
     if (p >= HW) return;
     const int h = p / W, wc = p - h * W;
     const float* xp = x + (long long)n * HW;
@@ -262,7 +292,7 @@ static int few_nsplit(const ConvProblem& p, int NB, int allow_split)
 template <int CO, int KW>
 static int few_launch_t(const FewArgs& a, dim3 grid, size_t lds, hipStream_t s)
 {
-    hipLaunchKernelGGL((conv_fewout_kernel<CO, KW>), grid, dim3(256), lds, s, a);
+    mcvc_launch((conv_fewout_kernel<CO, KW>), grid, dim3(256), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -272,7 +302,7 @@ int mcvc_disc_out_fwd_launch(const float* x, const float* w, const float* bias, 
 {
     const int outs = NB * H * W;
     TraceScope ts(K_CONV_FEW, s, 2.0 * 3 * C * outs, 4.0 * ((double)outs * C + 2.0 * outs));
-    hipLaunchKernelGGL(disc_out_fwd_kernel, dim3((unsigned)cdiv_i(outs, 4)), dim3(256), 0, s, x, w, bias, logit, out, NB, C, H, W);
+    mcvc_launch(disc_out_fwd_kernel, dim3((unsigned)cdiv_i(outs, 4)), dim3(256), 0, s, DiscOutFwdKArgs{x, w, bias, logit, out, NB, C, H, W});
     return (int)hipGetLastError();
 }
 
@@ -282,7 +312,7 @@ int mcvc_disc_out_dgrad_launch(const float* dlogit, const float* w, float* dx, i
     TraceScope ts(K_CONV_FEW, s, 2.0 * 3 * (double)total, 4.0 * (double)total);
     long long blocks = cdiv_ll(total, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(disc_out_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dlogit, w, dx, NB, C, H, W);
+    mcvc_launch(disc_out_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, DiscOutDgradKArgs{dlogit, w, dx, NB, C, H, W});
     return (int)hipGetLastError();
 }
 
@@ -290,8 +320,7 @@ int mcvc_disc_conv1_fwd_launch(const float* x, const float* w, const float* bias
 {
     const double outs = (double)NB * Cout * H * W;
     TraceScope ts(K_CONV_FEW, s, 2.0 * 9 * outs, 4.0 * (2.0 * outs + (double)NB * H * W));
-    hipLaunchKernelGGL(disc_conv1_fwd_kernel, dim3((unsigned)cdiv_i(H * W, 256), (unsigned)cdiv_i(Cout, kDiscC1Cob), (unsigned)NB), dim3(256), 0, s,
-                       x, w, bias, c0, y0, Cout, H, W);
+    mcvc_launch(disc_conv1_fwd_kernel, dim3((unsigned)cdiv_i(H * W, 256), (unsigned)(cdiv_i(Cout, kDiscC1Cob) * NB)), dim3(256), 0, s, DiscConv1FwdKArgs{x, w, bias, c0, y0, Cout, H, W});
     return (int)hipGetLastError();
 }
 
@@ -316,12 +345,12 @@ int mcvc_fewout_launch(const ConvProblem& p, int NB, const ConvIO& io, const flo
     a.w = wpk; a.w_cout = w_cout; a.bias = bias;
     a.Cin = p.Cin; a.H = p.H; a.W = p.W; a.Cout = p.Cout; a.OH = p.OH; a.OW = p.OW; a.KH = p.KH; a.pad_h = p.pad_h; a.pad_w = p.pad_w;
     a.tiles_w = cdiv_i(p.OW, kFewTW); a.tiles_h = cdiv_i(p.OH, kFewTH);
-    a.nsplit = io.nsplit;
+    a.nsplit = io.nsplit; a.NB = NB;
     a.ch_per_split = round_up_i(cdiv_i(p.Cin, io.nsplit), 1);
     a.PH = kFewTH + p.KH - 1;
     a.PWp = round_up_i(kFewTW + p.KW - 1 + 3, 4);           // (+3: the last float4 of a row window may read past PW)
     a.accumulate = io.accumulate;
-    dim3 grid((unsigned)(a.tiles_w * a.tiles_h), (unsigned)NB, (unsigned)io.nsplit);
+    dim3 grid((unsigned)(a.tiles_w * a.tiles_h), (unsigned)(NB * io.nsplit));
     const int co_t = p.Cout <= 1 ? 1 : (p.Cout <= 2 ? 2 : 4);
     const size_t lds = (size_t)2 * (kFewCC * a.PH * a.PWp + kFewCC * p.KH * co_t * ((p.KW + 3) & ~3) + 4) * sizeof(float);
     const double px = (double)NB * p.OH * p.OW;
@@ -349,8 +378,9 @@ struct FewWgradArgs {
     int band;                     // output rows per (sample, band) unit
 };
 
-__global__ void __launch_bounds__(256) wgrad_cout1_kernel(const FewWgradArgs a)
+__global__ void __launch_bounds__(256) wgrad_cout1_kernel(const Twin<FewWgradArgs> tw)
 {
+    const FewWgradArgs& a = tw.v[blockIdx.z];
     extern __shared__ float sm[];
     const int BH = a.band;                       // output rows per unit; units = (sample, band), shared out over gridDim.y workgroups
     const int XH = BH + a.KH - 1;
@@ -407,9 +437,21 @@ __global__ void __launch_bounds__(256) wgrad_cout1_kernel(const FewWgradArgs a)
 // discriminator backward pass).  Here a workgroup owns one output channel and a share of (sample, band of rows) units: the haloed band of x
 // sits in LDS, a thread multiplies its dy values with the nine neighbours, the nine sums are folded over the workgroup.
 constexpr int kCin1Band = 20;
-__global__ void __launch_bounds__(256) wgrad_cin1_kernel(const float* __restrict__ x, long long x_sn, int x_sh, const float* __restrict__ dy, long long dy_sn,
-                                                         long long dy_sc, int dy_sh, float* __restrict__ dw, int NB, int H, int W)
+struct WgradCin1KArgs { const float* x; long long x_sn; int x_sh; const float* dy; long long dy_sn; long long dy_sc; int dy_sh; float* dw; int NB; int H; int W; };
+__global__ void __launch_bounds__(256) wgrad_cin1_kernel(const Twin<WgradCin1KArgs> tw)
 {
+    const WgradCin1KArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ x = ka_.x;
+    long long x_sn = ka_.x_sn;
+    int x_sh = ka_.x_sh;
+    const float* __restrict__ dy = ka_.dy;
+    long long dy_sn = ka_.dy_sn;
+    long long dy_sc = ka_.dy_sc;
+    int dy_sh = ka_.dy_sh;
+    float* __restrict__ dw = ka_.dw;
+    int NB = ka_.NB;
+    int H = ka_.H;
+    int W = ka_.W;
     extern __shared__ float sm[];
     const int XW = W + 2;
     float* xs = sm;                                   // [kCin1Band + 2][XW]
@@ -489,7 +531,7 @@ int mcvc_wgrad_cout1_launch(const ConvProblem& p, int NB, const WgradIO& io, flo
     }
     const size_t lds = ((size_t)(a.band + p.KH - 1) * a.XW + (size_t)a.band * p.W + 256) * sizeof(float);
     TraceScope ts(K_WGRAD_SMALLK, s, 2.0 * NB * p.H * p.W * p.Cin * p.KH * p.KW, 4.0 * ((double)NB * p.Cin * p.H * p.W + (double)NB * p.H * p.W * p.Cin));
-    hipLaunchKernelGGL(wgrad_cout1_kernel, dim3((unsigned)p.Cin, (unsigned)nchunk), dim3(256), lds, s, a);
+    mcvc_launch(wgrad_cout1_kernel, dim3((unsigned)p.Cin, (unsigned)nchunk), dim3(256), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -507,7 +549,6 @@ int mcvc_wgrad_cin1_launch(const ConvProblem& p, int NB, const WgradIO& io, floa
         while (2 * nchunk <= units && p.Cout * nchunk < 1024) nchunk *= 2;
     const size_t lds = ((size_t)(kCin1Band + 2) * (p.W + 2) + 36) * sizeof(float);
     TraceScope ts(K_WGRAD_SMALLK, s, 2.0 * NB * p.H * p.W * p.Cout * 9, 4.0 * ((double)NB * p.Cout * p.H * p.W + (double)NB * p.H * p.W));
-    hipLaunchKernelGGL(wgrad_cin1_kernel, dim3((unsigned)p.Cout, (unsigned)nchunk), dim3(256), lds, s, io.x, io.x_sb, io.x_sh, io.dy, io.dy_sb, io.dy_sc,
-                       io.dy_sh, dw, NB, p.H, p.W);
+    mcvc_launch(wgrad_cin1_kernel, dim3((unsigned)p.Cout, (unsigned)nchunk), dim3(256), lds, s, WgradCin1KArgs{io.x, io.x_sb, io.x_sh, io.dy, io.dy_sb, io.dy_sc, io.dy_sh, dw, NB, p.H, p.W});
     return (int)hipGetLastError();
 }

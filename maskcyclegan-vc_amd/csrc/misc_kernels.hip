@@ -6,6 +6,7 @@
 #include "mcvc_common.h"
 #include "misc.h"
 #include "trace.h"
+#include "launch.h"
 
 namespace {
 
@@ -23,8 +24,15 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red)
 }
 
 // xin[n][0] = x*mask ; xin[n][1] = mask          (model.py:241)
-__global__ void prep_input_kernel(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ xin, int N, int P)
+struct PrepInputKArgs { const float* x; const float* mask; float* xin; int N; int P; };
+__global__ void prep_input_kernel(const Twin<PrepInputKArgs> tw)
 {
+    const PrepInputKArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ x = ka_.x;
+    const float* __restrict__ mask = ka_.mask;
+    float* __restrict__ xin = ka_.xin;
+    int N = ka_.N;
+    int P = ka_.P;
     const long long total = (long long)N * P;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const long long n = idx / P;
@@ -36,9 +44,20 @@ __global__ void prep_input_kernel(const float* __restrict__ x, const float* __re
 }
 
 // dx[n][i] (+)= mask * sum_slabs dxin[n][0][i]
-__global__ void mask_grad_kernel(const float* __restrict__ dxin, const float* __restrict__ dxin_slabs, long long slab_stride, int nslab,
-                                 const float* __restrict__ mask, float* __restrict__ dx, int N, int P, int C, int accumulate)
+struct MaskGradKArgs { const float* dxin; const float* dxin_slabs; long long slab_stride; int nslab; const float* mask; float* dx; int N; int P; int C; int accumulate; };
+__global__ void mask_grad_kernel(const Twin<MaskGradKArgs> tw)
 {
+    const MaskGradKArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ dxin = ka_.dxin;
+    const float* __restrict__ dxin_slabs = ka_.dxin_slabs;
+    long long slab_stride = ka_.slab_stride;
+    int nslab = ka_.nslab;
+    const float* __restrict__ mask = ka_.mask;
+    float* __restrict__ dx = ka_.dx;
+    int N = ka_.N;
+    int P = ka_.P;
+    int C = ka_.C;
+    int accumulate = ka_.accumulate;
     const long long total = (long long)N * P;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const long long n = idx / P;
@@ -55,8 +74,16 @@ __global__ void mask_grad_kernel(const float* __restrict__ dxin, const float* __
 // db[c] += sum over (n, pixel) of dy: one workgroup of 1024 threads per channel, 16-byte loads, four independent partial sums per thread
 // (a 256-thread scalar loop took 200-500 us per launch at 32-64 samples: the Cout = 1 layers reduce 330 k elements in ONE workgroup).
 // Fixed summation order: deterministic.
-__global__ void __launch_bounds__(1024) bias_grad_kernel(const float* __restrict__ dy, long long sn, long long sc, int N, int P, float* __restrict__ db)
+struct BiasGradKArgs { const float* dy; long long sn; long long sc; int N; int P; float* db; };
+__global__ void __launch_bounds__(1024) bias_grad_kernel(const Twin<BiasGradKArgs> tw)
 {
+    const BiasGradKArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ dy = ka_.dy;
+    long long sn = ka_.sn;
+    long long sc = ka_.sc;
+    int N = ka_.N;
+    int P = ka_.P;
+    float* __restrict__ db = ka_.db;
     __shared__ float red[16];
     const int c = blockIdx.x;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -84,10 +111,18 @@ __global__ void __launch_bounds__(1024) bias_grad_kernel(const float* __restrict
 }
 
 // L1: loss[slot] += weight * mean|a - b| ;  grad_a (=/+=) weight * sign(a - b) / n     (single block, deterministic)
-__global__ void __launch_bounds__(1024) l1_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float weight,
-                                                       float* __restrict__ loss_slot, float* __restrict__ term_slot,
-                                                       float* __restrict__ grad_a, int accumulate)
+struct L1LossKArgs { const float* a; const float* b; long long n; float weight; float* loss_slot; float* term_slot; float* grad_a; int accumulate; };
+__global__ void __launch_bounds__(1024) l1_loss_kernel(const Twin<L1LossKArgs> tw)
 {
+    const L1LossKArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ a = ka_.a;
+    const float* __restrict__ b = ka_.b;
+    long long n = ka_.n;
+    float weight = ka_.weight;
+    float* __restrict__ loss_slot = ka_.loss_slot;
+    float* __restrict__ term_slot = ka_.term_slot;
+    float* __restrict__ grad_a = ka_.grad_a;
+    int accumulate = ka_.accumulate;
     __shared__ float red[16];
     float s = 0.f;
     const float gs = weight / (float)n;
@@ -109,10 +144,17 @@ __global__ void __launch_bounds__(1024) l1_loss_kernel(const float* __restrict__
 
 // LSGAN on the discriminator's sigmoid output d: loss += weight*mean((target-d)^2);
 // grad wrt the PRE-sigmoid logit: weight * 2 (d - target)/n * d (1-d)
-__global__ void __launch_bounds__(1024) lsgan_loss_kernel(const float* __restrict__ d, long long n, float target, float weight,
-                                                          float* __restrict__ loss_slot, float* __restrict__ term_slot,
-                                                          float* __restrict__ grad_logit)
+struct LsganLossKArgs { const float* d; long long n; float target; float weight; float* loss_slot; float* term_slot; float* grad_logit; };
+__global__ void __launch_bounds__(1024) lsgan_loss_kernel(const Twin<LsganLossKArgs> tw)
 {
+    const LsganLossKArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ d = ka_.d;
+    long long n = ka_.n;
+    float target = ka_.target;
+    float weight = ka_.weight;
+    float* __restrict__ loss_slot = ka_.loss_slot;
+    float* __restrict__ term_slot = ka_.term_slot;
+    float* __restrict__ grad_logit = ka_.grad_logit;
     __shared__ float red[16];
     float s = 0.f;
     const float gs = 2.0f * weight / (float)n;
@@ -134,8 +176,13 @@ __global__ void __launch_bounds__(1024) lsgan_loss_kernel(const float* __restric
 // thread adds them to the public slots in a FIXED order (the reference's: train.py:233-237, 276-294), so the sums are reproducible
 // whatever the streams' relative timing was.
 struct LossCombineArgs { int n; int loss_dst[16]; int term_dst[16]; };
-__global__ void loss_combine_kernel(const float* __restrict__ pairs, float* __restrict__ slots, const LossCombineArgs c)
+struct LossCombineKArgs { const float* pairs; float* slots; LossCombineArgs c; };
+__global__ void loss_combine_kernel(const Twin<LossCombineKArgs> tw)
 {
+    const LossCombineKArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ pairs = ka_.pairs;
+    float* __restrict__ slots = ka_.slots;
+    const LossCombineArgs& c = ka_.c;
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (int k = 0; k < c.n; ++k) {
         if (c.term_dst[k] >= 0) slots[c.term_dst[k]] += pairs[2 * k + 1];
@@ -145,10 +192,22 @@ __global__ void loss_combine_kernel(const float* __restrict__ pairs, float* __re
 
 // torch.optim.Adam single-tensor math on a flat buffer (weight_decay 0, amsgrad off):
 //   m = lerp(m, g, 1-b1); v = b2*v + (1-b2) g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
-__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                                                   float bc1, float sqrt_bc2, float grad_scale)
+struct AdamKArgs { float* p; const float* g; float* m; float* v; long long n; float lr; float b1; float b2; float eps; float bc1; float sqrt_bc2; float grad_scale; };
+__global__ void __launch_bounds__(256) adam_kernel(const Twin<AdamKArgs> tw)
 {
+    const AdamKArgs& ka_ = tw.v[blockIdx.z];
+    float* __restrict__ p = ka_.p;
+    const float* __restrict__ g = ka_.g;
+    float* __restrict__ m = ka_.m;
+    float* __restrict__ v = ka_.v;
+    long long n = ka_.n;
+    float lr = ka_.lr;
+    float b1 = ka_.b1;
+    float b2 = ka_.b2;
+    float eps = ka_.eps;
+    float bc1 = ka_.bc1;
+    float sqrt_bc2 = ka_.sqrt_bc2;
+    float grad_scale = ka_.grad_scale;
     const float step_size = lr / bc1;
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -184,8 +243,14 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
-__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float alpha, long long n)
+struct AxpyKArgs { float* y; const float* x; float alpha; long long n; };
+__global__ void axpy_kernel(const Twin<AxpyKArgs> tw)
 {
+    const AxpyKArgs& ka_ = tw.v[blockIdx.z];
+    float* __restrict__ y = ka_.y;
+    const float* __restrict__ x = ka_.x;
+    float alpha = ka_.alpha;
+    long long n = ka_.n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] += alpha * x[i];
 }
 
@@ -202,7 +267,7 @@ static unsigned ew_blocks(long long total, int bs)
 int mcvc_prep_input_launch(const float* x, const float* mask, float* xin, int N, int P, hipStream_t s)
 {
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 16.0 * N * P);
-    hipLaunchKernelGGL(prep_input_kernel, dim3(ew_blocks((long long)N * P, 256)), dim3(256), 0, s, x, mask, xin, N, P);
+    mcvc_launch(prep_input_kernel, dim3(ew_blocks((long long)N * P, 256)), dim3(256), 0, s, PrepInputKArgs{x, mask, xin, N, P});
     return (int)hipGetLastError();
 }
 
@@ -210,14 +275,14 @@ int mcvc_mask_grad_launch(const float* dxin, const float* slabs, long long slab_
                           int N, int P, int C, int accumulate, hipStream_t s)
 {
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * N * P * (nslab + 2));
-    hipLaunchKernelGGL(mask_grad_kernel, dim3(ew_blocks((long long)N * P, 256)), dim3(256), 0, s, dxin, slabs, slab_stride, nslab, mask, dx, N, P, C, accumulate);
+    mcvc_launch(mask_grad_kernel, dim3(ew_blocks((long long)N * P, 256)), dim3(256), 0, s, MaskGradKArgs{dxin, slabs, slab_stride, nslab, mask, dx, N, P, C, accumulate});
     return (int)hipGetLastError();
 }
 
 int mcvc_bias_grad_launch(const float* dy, long long sn, long long sc, int N, int C, int P, float* db, hipStream_t s)
 {
     TraceScope ts(K_BIAS_GRAD, s, 0.0, 4.0 * (double)N * C * P);
-    hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)C), dim3(1024), 0, s, dy, sn, sc, N, P, db);
+    mcvc_launch(bias_grad_kernel, dim3((unsigned)C), dim3(1024), 0, s, BiasGradKArgs{dy, sn, sc, N, P, db});
     return (int)hipGetLastError();
 }
 
@@ -225,7 +290,7 @@ int mcvc_l1_loss_launch(const float* a, const float* b, long long n, float weigh
                         float* grad_a, int accumulate, hipStream_t s)
 {
     TraceScope ts(K_LOSS, s, 0.0, 12.0 * n);
-    hipLaunchKernelGGL(l1_loss_kernel, dim3(1), dim3(1024), 0, s, a, b, n, weight, loss_slot, term_slot, grad_a, accumulate);
+    mcvc_launch(l1_loss_kernel, dim3(1), dim3(1024), 0, s, L1LossKArgs{a, b, n, weight, loss_slot, term_slot, grad_a, accumulate});
     return (int)hipGetLastError();
 }
 
@@ -233,7 +298,7 @@ int mcvc_lsgan_loss_launch(const float* d, long long n, float target, float weig
                            float* grad_logit, hipStream_t s)
 {
     TraceScope ts(K_LOSS, s, 0.0, 8.0 * n);
-    hipLaunchKernelGGL(lsgan_loss_kernel, dim3(1), dim3(1024), 0, s, d, n, target, weight, loss_slot, term_slot, grad_logit);
+    mcvc_launch(lsgan_loss_kernel, dim3(1), dim3(1024), 0, s, LsganLossKArgs{d, n, target, weight, loss_slot, term_slot, grad_logit});
     return (int)hipGetLastError();
 }
 
@@ -244,7 +309,7 @@ int mcvc_loss_combine_launch(const float* pairs, int n, const int* loss_dst, con
     c.n = n;
     for (int k = 0; k < n; ++k) { c.loss_dst[k] = loss_dst[k]; c.term_dst[k] = term_dst[k]; }
     TraceScope ts(K_LOSS, s, 0.0, 16.0 * n);
-    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, s, pairs, slots, c);
+    mcvc_launch(loss_combine_kernel, dim3(1), dim3(64), 0, s, LossCombineKArgs{pairs, slots, c});
     return (int)hipGetLastError();
 }
 
@@ -256,13 +321,13 @@ int mcvc_adam_launch(float* p, const float* g, float* m, float* v, long long n, 
     const double bc1 = 1.0 - pow((double)b1, (double)step);
     const double bc2 = 1.0 - pow((double)b2, (double)step);
     TraceScope ts(K_ADAM, s, 0.0, 28.0 * n);
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n >> 2, 256)), dim3(256), 0, s, p, g, m, v, n, (float)((double)lr / bc1), b1, b2, eps, 1.0f, (float)sqrt(bc2), grad_scale);
+    mcvc_launch(adam_kernel, dim3(ew_blocks(n >> 2, 256)), dim3(256), 0, s, AdamKArgs{p, g, m, v, n, (float)((double)lr / bc1), b1, b2, eps, 1.0f, (float)sqrt(bc2), grad_scale});
     return (int)hipGetLastError();
 }
 
 int mcvc_axpy_launch(float* y, const float* x, float alpha, long long n, hipStream_t s)
 {
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 12.0 * n);
-    hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n, 256)), dim3(256), 0, s, y, x, alpha, n);
+    mcvc_launch(axpy_kernel, dim3(ew_blocks(n, 256)), dim3(256), 0, s, AxpyKArgs{y, x, alpha, n});
     return (int)hipGetLastError();
 }

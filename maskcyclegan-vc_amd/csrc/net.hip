@@ -14,6 +14,7 @@
 //                    (:270-271) become pure stride changes folded into the producing kernels.
 //   value|gate pairs are one convolution with concatenated output channels [value C | gate C].
 #include "mcvc_common.h"
+#include "twin.h"
 #include "pack.h"
 #include "misc.h"
 #include "trunk.h"
@@ -102,7 +103,7 @@ static void wait_readers(Exec& ex, const void* buf)
 {
     if (!ex.s2 || ex.dry) return;
     for (auto it = ex.readers.begin(); it != ex.readers.end();) {
-        if (it->first == buf) { ex.fail((int)hipStreamWaitEvent(ex.s, it->second, 0)); it = ex.readers.erase(it); }
+        if (it->first == buf) { ex.fail(mcvc_stream_wait(ex.s, it->second)); it = ex.readers.erase(it); }
         else ++it;
     }
 }
@@ -111,8 +112,8 @@ static void join_aux(Exec& ex)
 {
     if (!ex.s2 || ex.dry) return;
     hipEvent_t e = pool_event();
-    ex.fail((int)hipEventRecord(e, ex.s2));
-    ex.fail((int)hipStreamWaitEvent(ex.s, e, 0));
+    ex.fail(mcvc_event_record(e, ex.s2));
+    ex.fail(mcvc_stream_wait(ex.s, e));
     ex.readers.clear();
 }
 
@@ -590,8 +591,8 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
     hipStream_t ws = ex.s;
     if (ex.s2) {           // dY (and x) are complete on the main stream at this point
         hipEvent_t e = pool_event();
-        ex.fail((int)hipEventRecord(e, ex.s));
-        ex.fail((int)hipStreamWaitEvent(ex.s2, e, 0));
+        ex.fail(mcvc_event_record(e, ex.s));
+        ex.fail(mcvc_stream_wait(ex.s2, e));
         ws = ex.s2;
     }
     bool done = false;
@@ -689,7 +690,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
     }
     if (ex.s2) {
         hipEvent_t e = pool_event();
-        ex.fail((int)hipEventRecord(e, ex.s2));
+        ex.fail(mcvc_event_record(e, ex.s2));
         ex.readers.emplace_back((const void*)dy.p, e);
     }
 }
@@ -1093,6 +1094,9 @@ static GenScratch gen_scratch(const GenDims& d)
     GenScratch s{};
     long long cur = 0;
     auto take = [&](long long n) { const long long o = cur; cur += (n + 3) & ~3LL; return o; };
+    // first, so that its place does not depend on the batch size: callers share one scratch buffer between passes of different batch
+    // (the trainer's B and 2B passes), and the sticky error word (mcvc_gen_trunk_fault) must not land inside another layout's data
+    s.sync = take(2 * MCVC_TRUNK_SYNC_WORDS);            // forward | backward persistent trunk kernels
     s.ga = take(d.big); s.gb = take(d.big); s.gb2 = take(d.big);
     s.dh = take((long long)256 * d.B * d.W4); s.dt1 = take((long long)1024 * d.B * d.W4); s.dt1b = take((long long)1024 * d.B * d.W4);
     s.dt2 = take((long long)512 * d.B * d.W4); s.dt3 = take((long long)256 * d.B * d.W4); s.dt3b = take((long long)256 * d.B * d.W4);
@@ -1110,7 +1114,6 @@ static GenScratch gen_scratch(const GenDims& d)
         s.wu_floats = wino_enabled() ? 36LL * 1024 * 256 : 0;          // dU of upSample1 (the larger weight tensor)
         s.wu = take(s.wu_floats);
     }
-    s.sync = take(2 * MCVC_TRUNK_SYNC_WORDS);            // forward | backward persistent trunk kernels
     s.slabs = cur;
     return s;
 }
@@ -1225,11 +1228,11 @@ static void record_milestone(Exec& ex, void* ev)
     hipStream_t on = ex.s;
     if (ex.s2) {
         hipEvent_t e = pool_event();
-        ex.fail((int)hipEventRecord(e, ex.s));
-        ex.fail((int)hipStreamWaitEvent(ex.s2, e, 0));
+        ex.fail(mcvc_event_record(e, ex.s));
+        ex.fail(mcvc_stream_wait(ex.s2, e));
         on = ex.s2;
     }
-    ex.fail((int)hipEventRecord((hipEvent_t)ev, on));
+    ex.fail(mcvc_event_record((hipEvent_t)ev, on));
 }
 
 static void gen_backward_impl(Exec& ex, const float* const* P, const float* packed, float* const* G, const float* mask, const float* dout,
@@ -1351,8 +1354,8 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         hipStream_t ws = ex.s;
         if (ex.s2) {
             hipEvent_t e = pool_event();
-            ex.fail((int)hipEventRecord(e, ex.s));
-            ex.fail((int)hipStreamWaitEvent(ex.s2, e, 0));
+            ex.fail(mcvc_event_record(e, ex.s));
+            ex.fail(mcvc_stream_wait(ex.s2, e));
             ws = ex.s2;
         }
         ex.fail(mcvc_wgrad_smallk_batch_launch(wjobs, nwjobs, B, W4, ws));
@@ -1625,6 +1628,35 @@ static Needs disc_needs(int B, int T)
 extern "C" {
 
 int mcvc_version(void) { return MCVC_ABI_VERSION; }
+
+// ---- grouped ("twin") launches (twin.h): the caller brackets two identical call sequences on different networks -------------------
+static thread_local TwinCtx t_twin_ctx;
+int mcvc_twin_begin(void)
+{
+    if (g_mcvc_twin) return MCVC_ERR_INVALID;
+    t_twin_ctx.recs.clear(); t_twin_ctx.args.clear(); t_twin_ctx.next = 0; t_twin_ctx.err = 0; t_twin_ctx.phase = 1;
+    g_mcvc_twin = &t_twin_ctx;
+    return 0;
+}
+int mcvc_twin_switch(void)
+{
+    if (!g_mcvc_twin || g_mcvc_twin->phase != 1) return MCVC_ERR_INVALID;
+    g_mcvc_twin->phase = 2;
+    g_mcvc_twin->next = 0;
+    return g_mcvc_twin->err;
+}
+int mcvc_twin_end(void)
+{
+    if (!g_mcvc_twin) return MCVC_ERR_INVALID;
+    TwinCtx* t = g_mcvc_twin;
+    g_mcvc_twin = nullptr;
+    const int phase = t->phase;
+    t->phase = 0;
+    if (t->err) return t->err;
+    if (phase != 2 || t->next != t->recs.size()) return MCVC_ERR_INVALID;     // the second walk issued fewer launches than the first
+    return 0;
+}
+int mcvc_twin_launches(void) { return (int)t_twin_ctx.recs.size(); }
 
 int mcvc_set_deterministic(int on) { const int was = g_deterministic; g_deterministic = on ? 1 : 0; return was; }
 int mcvc_get_deterministic(void) { return g_deterministic; }

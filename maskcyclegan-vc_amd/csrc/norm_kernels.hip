@@ -12,6 +12,7 @@
 // (the "launch-boundary reduce"), so the conv never needs atomics for its K split.
 #include "mcvc_common.h"
 #include "trace.h"
+#include "launch.h"
 #include "wino.h"
 
 namespace {
@@ -36,8 +37,9 @@ __device__ __forceinline__ float gsum(float v, float* red)
 }
 
 template <int G>
-__global__ void __launch_bounds__(256) norm_fwd_kernel(const NormArgs a)
+__global__ void __launch_bounds__(256) norm_fwd_kernel(const Twin<NormArgs> tw)
 {
+    const NormArgs& a = tw.v[blockIdx.z];
     __shared__ float red[4];
     constexpr int GPB = 256 / G;
     const int g = threadIdx.x / G, l = threadIdx.x % G;
@@ -101,8 +103,9 @@ __global__ void __launch_bounds__(256) norm_fwd_kernel(const NormArgs a)
 // one group per channel c, looping over n: d(gamma), d(beta) are owned by the group -> no atomics,
 // deterministic accumulation order.
 template <int G>
-__global__ void __launch_bounds__(256) norm_bwd_kernel(const NormBwdArgs a)
+__global__ void __launch_bounds__(256) norm_bwd_kernel(const Twin<NormBwdArgs> tw)
 {
+    const NormBwdArgs& a = tw.v[blockIdx.z];
     __shared__ float red[4];
     constexpr int GPB = 256 / G;
     const int g = threadIdx.x / G, l = threadIdx.x % G;
@@ -203,8 +206,9 @@ __global__ void __launch_bounds__(256) norm_bwd_kernel(const NormBwdArgs a)
 // back-to-back), statistics by shuffles, one write.  At bs=1 these kernels are pure latency, so the number
 // of dependent memory round trips (1 here vs 5-6 in the streaming kernels above) is what matters.
 template <int G, int E>
-__global__ void __launch_bounds__(256) norm_fwd_reg_kernel(const NormArgs a)
+__global__ void __launch_bounds__(256) norm_fwd_reg_kernel(const Twin<NormArgs> tw)
 {
+    const NormArgs& a = tw.v[blockIdx.z];
     __shared__ float red[4];
     constexpr int GPB = 256 / G;
     const int g = threadIdx.x / G, l = threadIdx.x % G;
@@ -288,8 +292,9 @@ __global__ void __launch_bounds__(256) norm_fwd_reg_kernel(const NormArgs a)
 }
 
 template <int G, int E>
-__global__ void __launch_bounds__(256) norm_bwd_reg_kernel(const NormBwdArgs a)
+__global__ void __launch_bounds__(256) norm_bwd_reg_kernel(const Twin<NormBwdArgs> tw)
 {
+    const NormBwdArgs& a = tw.v[blockIdx.z];
     __shared__ float red[4];
     constexpr int GPB = 256 / G;
     const int g = threadIdx.x / G, l = threadIdx.x % G;
@@ -402,8 +407,9 @@ __global__ void __launch_bounds__(256) norm_bwd_reg_kernel(const NormBwdArgs a)
     }
 }
 
-__global__ void __launch_bounds__(256) act_fwd_kernel(const ActArgs a)
+__global__ void __launch_bounds__(256) act_fwd_kernel(const Twin<ActArgs> tw)
 {
+    const ActArgs& a = tw.v[blockIdx.z];
     const long long total = (long long)a.N * a.C * a.P;
     const int nbr = (a.act == ACT_GLU) ? 2 : 1;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -431,8 +437,9 @@ __global__ void __launch_bounds__(256) act_fwd_kernel(const ActArgs a)
     }
 }
 
-__global__ void __launch_bounds__(256) act_bwd_kernel(const ActBwdArgs a)
+__global__ void __launch_bounds__(256) act_bwd_kernel(const Twin<ActBwdArgs> tw)
 {
+    const ActBwdArgs& a = tw.v[blockIdx.z];
     const long long total = (long long)a.N * a.C * a.P;
     const int nbr = (a.act == ACT_GLU) ? 2 : 1;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -471,8 +478,9 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 add4(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-__global__ void __launch_bounds__(256) act_fwd_vec_kernel(const ActArgs a)
+__global__ void __launch_bounds__(256) act_fwd_vec_kernel(const Twin<ActArgs> tw)
 {
+    const ActArgs& a = tw.v[blockIdx.z];
     const unsigned p4 = (unsigned)a.P >> 2;
     const unsigned total4 = (unsigned)a.N * (unsigned)a.C * p4;
     const int nbr = (a.act == ACT_GLU) ? 2 : 1;
@@ -503,8 +511,9 @@ __global__ void __launch_bounds__(256) act_fwd_vec_kernel(const ActArgs a)
     }
 }
 
-__global__ void __launch_bounds__(256) act_bwd_vec_kernel(const ActBwdArgs a)
+__global__ void __launch_bounds__(256) act_bwd_vec_kernel(const Twin<ActBwdArgs> tw)
 {
+    const ActBwdArgs& a = tw.v[blockIdx.z];
     const unsigned p4 = (unsigned)a.P >> 2;
     const unsigned total4 = (unsigned)a.N * (unsigned)a.C * p4;
     const int nbr = (a.act == ACT_GLU) ? 2 : 1;
@@ -548,9 +557,13 @@ __global__ void __launch_bounds__(256) act_bwd_vec_kernel(const ActBwdArgs a)
 //   PTS = 16: F(2x2,3x3) (the stride-2 5x5 layers in phase form), plane (n, c) = conv channel c (value) and C + c (gate, GLU)
 //   PTS = 36: F(2x2,5x5) with PixelShuffle(2): plane (n, c) = conv channels 4c .. 4c+3 interleaved; items = (sub-channel, tile)
 // G threads share one plane, every thread owns TT items.
+struct NormFwdWinoKArgs { NormArgs a; WinoOutArgs w; };
 template <int G, int TT, int PTS>
-__global__ void __launch_bounds__(256) norm_fwd_wino_kernel(const NormArgs a, const WinoOutArgs w)
+__global__ void __launch_bounds__(256) norm_fwd_wino_kernel(const Twin<NormFwdWinoKArgs> tw)
 {
+    const NormFwdWinoKArgs& ka_ = tw.v[blockIdx.z];
+    const NormArgs& a = ka_.a;
+    const WinoOutArgs& w = ka_.w;
     __shared__ float red[4];
     constexpr bool SHUF = PTS == 36;
     constexpr int R = SHUF ? 6 : 4;
@@ -698,8 +711,8 @@ int mcvc_norm_fwd_wino_launch(const NormArgs& a, const WinoOutArgs& w, int pts, 
     const double el = (double)planes * a.H * a.W * nbr;
     TraceScope ts(K_NORM_FWD, s, 0.0, 4.0 * (el * pts / 4 + el + (double)planes * a.H * a.W));
 #define MCVC_FWD_WINO(GG, TT) { \
-        if (pts == 16) hipLaunchKernelGGL((norm_fwd_wino_kernel<GG, TT, 16>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, a, w); \
-        else hipLaunchKernelGGL((norm_fwd_wino_kernel<GG, TT, 36>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, a, w); \
+        if (pts == 16) mcvc_launch((norm_fwd_wino_kernel<GG, TT, 16>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, NormFwdWinoKArgs{a, w}); \
+        else mcvc_launch((norm_fwd_wino_kernel<GG, TT, 36>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, NormFwdWinoKArgs{a, w}); \
         return (int)hipGetLastError(); }
     if (items <= 128) MCVC_FWD_WINO(64, 2)
     if (items <= 512 && planes < 2048) MCVC_FWD_WINO(256, 2)
@@ -716,7 +729,7 @@ int mcvc_norm_fwd_launch(const NormArgs& a, hipStream_t s)
     const unsigned blocks = (unsigned)cdiv_ll(planes, 256 / G);
     const double el = (double)planes * P * (a.act == ACT_GLU ? 2 : 1);
     TraceScope ts(K_NORM_FWD, s, 0.0, 4.0 * (el * (a.nslab + 1) + (double)planes * P));
-#define MCVC_FWD_REG(GG, EE) { hipLaunchKernelGGL((norm_fwd_reg_kernel<GG, EE>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, a); return (int)hipGetLastError(); }
+#define MCVC_FWD_REG(GG, EE) { mcvc_launch((norm_fwd_reg_kernel<GG, EE>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, a); return (int)hipGetLastError(); }
     if (P <= 16) MCVC_FWD_REG(16, 1)
     if (P <= 64) MCVC_FWD_REG(16, 4)
     if (P <= 128) MCVC_FWD_REG(64, 2)
@@ -724,9 +737,9 @@ int mcvc_norm_fwd_launch(const NormArgs& a, hipStream_t s)
     if (P <= 1280) MCVC_FWD_REG(256, 5)
     if (P <= 5120) MCVC_FWD_REG(256, 20)
 #undef MCVC_FWD_REG
-    if (G == 16) hipLaunchKernelGGL(norm_fwd_kernel<16>, dim3(blocks), dim3(256), 0, s, a);
-    else if (G == 64) hipLaunchKernelGGL(norm_fwd_kernel<64>, dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(norm_fwd_kernel<256>, dim3(blocks), dim3(256), 0, s, a);
+    if (G == 16) mcvc_launch(norm_fwd_kernel<16>, dim3(blocks), dim3(256), 0, s, a);
+    else if (G == 64) mcvc_launch(norm_fwd_kernel<64>, dim3(blocks), dim3(256), 0, s, a);
+    else mcvc_launch(norm_fwd_kernel<256>, dim3(blocks), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -744,7 +757,7 @@ int mcvc_norm_bwd_launch(const NormBwdArgs& a, hipStream_t s)
             while (2 * nc <= a.N && nc < 32 && cblocks * nc < 768) nc *= 2;
         return nc;
     };
-#define MCVC_BWD_REG(GG, EE) { const int cb = cdiv_i(a.C, 256 / GG); hipLaunchKernelGGL((norm_bwd_reg_kernel<GG, EE>), dim3((unsigned)cb, (unsigned)chunks(cb)), dim3(256), 0, s, a); return (int)hipGetLastError(); }
+#define MCVC_BWD_REG(GG, EE) { const int cb = cdiv_i(a.C, 256 / GG); mcvc_launch((norm_bwd_reg_kernel<GG, EE>), dim3((unsigned)cb, (unsigned)chunks(cb)), dim3(256), 0, s, a); return (int)hipGetLastError(); }
     if (P <= 16) MCVC_BWD_REG(16, 1)
     if (P <= 64) MCVC_BWD_REG(16, 4)
     if (P <= 128) MCVC_BWD_REG(64, 2)
@@ -752,9 +765,9 @@ int mcvc_norm_bwd_launch(const NormBwdArgs& a, hipStream_t s)
     if (P <= 1280) MCVC_BWD_REG(256, 5)
     if (P <= 5120) MCVC_BWD_REG(256, 20)
 #undef MCVC_BWD_REG
-    if (G == 16) hipLaunchKernelGGL(norm_bwd_kernel<16>, dim3(blocks), dim3(256), 0, s, a);
-    else if (G == 64) hipLaunchKernelGGL(norm_bwd_kernel<64>, dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(norm_bwd_kernel<256>, dim3(blocks), dim3(256), 0, s, a);
+    if (G == 16) mcvc_launch(norm_bwd_kernel<16>, dim3(blocks), dim3(256), 0, s, a);
+    else if (G == 64) mcvc_launch(norm_bwd_kernel<64>, dim3(blocks), dim3(256), 0, s, a);
+    else mcvc_launch(norm_bwd_kernel<256>, dim3(blocks), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -771,8 +784,8 @@ int mcvc_act_fwd_launch(const ActArgs& a, hipStream_t s)
     TraceScope ts(K_ACT_FWD, s, 0.0, 4.0 * (double)a.N * a.C * a.P * ((a.act == ACT_GLU ? 2 : 1) * a.nslab + 1));
     const long long total = (long long)a.N * a.C * a.P;
     const bool al = ((((uintptr_t)a.x | (uintptr_t)a.x_slabs | (uintptr_t)a.y) & 15) == 0) && (a.slab_stride & 3) == 0;
-    if ((a.P & 3) == 0 && al && total < (1LL << 33)) hipLaunchKernelGGL(act_fwd_vec_kernel, dim3(ew_blocks(total >> 2)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, a);
+    if ((a.P & 3) == 0 && al && total < (1LL << 33)) mcvc_launch(act_fwd_vec_kernel, dim3(ew_blocks(total >> 2)), dim3(256), 0, s, a);
+    else mcvc_launch(act_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -781,7 +794,7 @@ int mcvc_act_bwd_launch(const ActBwdArgs& a, hipStream_t s)
     TraceScope ts(K_ACT_BWD, s, 0.0, 4.0 * (double)a.N * a.C * a.P * ((a.act == ACT_GLU ? 4 : 2) + a.nslab));
     const long long total = (long long)a.N * a.C * a.P;
     const bool al = ((((uintptr_t)a.x | (uintptr_t)a.dy | (uintptr_t)a.dy_slabs | (uintptr_t)a.dx) & 15) == 0) && (a.slab_stride & 3) == 0;
-    if ((a.P & 3) == 0 && al && total < (1LL << 33)) hipLaunchKernelGGL(act_bwd_vec_kernel, dim3(ew_blocks(total >> 2)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, a);
+    if ((a.P & 3) == 0 && al && total < (1LL << 33)) mcvc_launch(act_bwd_vec_kernel, dim3(ew_blocks(total >> 2)), dim3(256), 0, s, a);
+    else mcvc_launch(act_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }

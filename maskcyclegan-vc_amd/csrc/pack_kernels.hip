@@ -13,6 +13,7 @@
 #include "mcvc_common.h"
 #include "pack.h"
 #include "trace.h"
+#include "launch.h"
 #include "wino.h"
 
 // [R=Cout][K] -> dst[k*ld + co_off + co], 32x32 LDS tiles, both sides coalesced
@@ -102,17 +103,28 @@ __global__ void __launch_bounds__(256) pack_trunk_t_kernel(const float* __restri
     pack_trunk_t_tile(w, dst, Cout, Cin, KW, ld, co_off, blockIdx.x, blockIdx.y, smem);
 }
 
-__global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int n)
+struct CopyKArgs { const float* src; float* dst; int n; };
+__global__ void copy_kernel(const Twin<CopyKArgs> tw)
 {
+    const CopyKArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ src = ka_.src;
+    float* __restrict__ dst = ka_.dst;
+    int n = ka_.n;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
 }
 
 // Whole-network re-pack in ONE launch: a device-resident job table maps each workgroup to (job, tile).  Replaces ~130
 // tiny launches per generator (and their launch gaps) after every optimizer step.
-__global__ void __launch_bounds__(256) pack_net_kernel(const PackJob* __restrict__ jobs, int njobs, const PackDgradArgs* __restrict__ dga,
-                                                       const PackPtrs ptrs, float* __restrict__ packed)
+struct PackNetKArgs { const PackJob* jobs; int njobs; const PackDgradArgs* dga; PackPtrs ptrs; float* packed; };
+__global__ void __launch_bounds__(256) pack_net_kernel(const Twin<PackNetKArgs> tw)
 {
+    const PackNetKArgs& ka_ = tw.v[blockIdx.z];
+    const PackJob* __restrict__ jobs = ka_.jobs;
+    int njobs = ka_.njobs;
+    const PackDgradArgs* __restrict__ dga = ka_.dga;
+    const PackPtrs& ptrs = ka_.ptrs;
+    float* __restrict__ packed = ka_.packed;
     extern __shared__ float lds[];
     const int blk = blockIdx.x;
     int lo = 0, hi = njobs - 1;                       // last job with block0 <= blk
@@ -138,7 +150,7 @@ int mcvc_pack_net_launch(const PackJob* d_jobs, int njobs, int nblocks, const Pa
                          double bytes, hipStream_t s)
 {
     TraceScope ts(K_PACK, s, 0.0, bytes);
-    hipLaunchKernelGGL(pack_net_kernel, dim3((unsigned)nblocks), dim3(256), kPackNetLds, s, d_jobs, njobs, d_dga, ptrs, packed);
+    mcvc_launch(pack_net_kernel, dim3((unsigned)nblocks), dim3(256), kPackNetLds, s, PackNetKArgs{d_jobs, njobs, d_dga, ptrs, packed});
     return (int)hipGetLastError();
 }
 
@@ -170,6 +182,6 @@ int mcvc_pack_dgrad_launch(const float* w, float* dst, const PackDgradArgs& a, i
 int mcvc_copy_launch(const float* src, float* dst, int n, hipStream_t s)
 {
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 8.0 * n);
-    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)cdiv_i(n, 256)), dim3(256), 0, s, src, dst, n);
+    mcvc_launch(copy_kernel, dim3((unsigned)cdiv_i(n, 256)), dim3(256), 0, s, CopyKArgs{src, dst, n});
     return (int)hipGetLastError();
 }

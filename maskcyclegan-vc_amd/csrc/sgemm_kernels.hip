@@ -2,6 +2,7 @@
 #include "sgemm.h"
 #include "mcvc_common.h"
 #include "trace.h"
+#include "launch.h"
 
 namespace {
 
@@ -20,8 +21,9 @@ constexpr int BM = 64, BN = 64, GK = 32, ST = 4;
 constexpr int SA = GK * BM, SB = GK * BN, STAGE = SA + SB;
 constexpr int NA = SA / 4 / 256, NBI = SB / 4 / 256, ND = NA + NBI;          // DMA instructions per wave and stage (2 + 2)
 
-__global__ void __launch_bounds__(256) sgemm_kernel(const SGemmArgs a)
+__global__ void __launch_bounds__(256) sgemm_kernel(const Twin<SGemmArgs> tw)
 {
+    const SGemmArgs& a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -106,8 +108,9 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const SGemmArgs a)
 
 // ---- staging ----------------------------------------------------------------------------------------------------------------
 // tap (kh, kw) of output pixel (oh, ow) reads x[2*oh + kh - 1][2*ow + kw - 1]
-__global__ void __launch_bounds__(256) im2col_s2_kernel(const StageArgs a)
+__global__ void __launch_bounds__(256) im2col_s2_kernel(const Twin<StageArgs> tw)
 {
+    const StageArgs& a = tw.v[blockIdx.z];
     const int P = a.OH * a.OW;
     const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
     const int ci = blockIdx.y;
@@ -129,8 +132,9 @@ __global__ void __launch_bounds__(256) im2col_s2_kernel(const StageArgs a)
 }
 
 // XcolT[n][9*ci + tap]: 32 pixels x 32 channels per workgroup through LDS (reads along pixels, writes along k)
-__global__ void __launch_bounds__(256) im2col_s2_t_kernel(const StageArgs a)
+__global__ void __launch_bounds__(256) im2col_s2_t_kernel(const Twin<StageArgs> tw)
 {
+    const StageArgs& a = tw.v[blockIdx.z];
     __shared__ float tile[32][32 * 9 + 1];
     const int P = a.OH * a.OW;
     const long long NT = (long long)a.NB * P;
@@ -164,8 +168,9 @@ __global__ void __launch_bounds__(256) im2col_s2_t_kernel(const StageArgs a)
 }
 
 // Yt[n][c] from y[b][c][p]
-__global__ void __launch_bounds__(256) planes_t_kernel(const StageArgs a)
+__global__ void __launch_bounds__(256) planes_t_kernel(const Twin<StageArgs> tw)
 {
+    const StageArgs& a = tw.v[blockIdx.z];
     __shared__ float tile[32][33];
     const int P = a.H * a.W;
     const long long NT = (long long)a.NB * P;
@@ -186,8 +191,14 @@ __global__ void __launch_bounds__(256) planes_t_kernel(const StageArgs a)
 }
 
 // dx[b][ci][ih][iw] (=|+=) the taps that reach it: kh = ih + 1 - 2*oh in [0, 3)
-__global__ void __launch_bounds__(256) col2im_s2_kernel(const StageArgs a, int nslab, long long slab_stride, int accumulate)
+struct Col2imS2KArgs { StageArgs a; int nslab; long long slab_stride; int accumulate; };
+__global__ void __launch_bounds__(256) col2im_s2_kernel(const Twin<Col2imS2KArgs> tw)
 {
+    const Col2imS2KArgs& ka_ = tw.v[blockIdx.z];
+    const StageArgs& a = ka_.a;
+    int nslab = ka_.nslab;
+    long long slab_stride = ka_.slab_stride;
+    int accumulate = ka_.accumulate;
     const int HW = a.H * a.W, P = a.OH * a.OW;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     const int ci = blockIdx.y;
@@ -220,8 +231,9 @@ __global__ void __launch_bounds__(256) col2im_s2_kernel(const StageArgs a, int n
 // ---- 1 x KW convolutions along w (stride 1, padding (KW-1)/2) over rows (b, h): the 1-D trunk run as an image of B rows -------------
 // Xcol[KW*ci + tap][n] = x[b][ci][h][w + tap - pw],  n = (b*H + h)*W + w
 template <int KW>
-__global__ void __launch_bounds__(256) im2col_1d_kernel(const StageArgs a)
+__global__ void __launch_bounds__(256) im2col_1d_kernel(const Twin<StageArgs> tw)
 {
+    const StageArgs& a = tw.v[blockIdx.z];
     constexpr int PW = (KW - 1) / 2;
     const int P = a.H * a.W;
     const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -240,8 +252,9 @@ __global__ void __launch_bounds__(256) im2col_1d_kernel(const StageArgs a)
 
 // XcolT[n][KW*ci + tap]
 template <int KW>
-__global__ void __launch_bounds__(256) im2col_1d_t_kernel(const StageArgs a)
+__global__ void __launch_bounds__(256) im2col_1d_t_kernel(const Twin<StageArgs> tw)
 {
+    const StageArgs& a = tw.v[blockIdx.z];
     constexpr int PW = (KW - 1) / 2;
     __shared__ float tile[32][32 * KW + 1];
     const int P = a.H * a.W;
@@ -271,9 +284,15 @@ __global__ void __launch_bounds__(256) im2col_1d_t_kernel(const StageArgs a)
 }
 
 // dx[b][ci][h][w] (=|+=) sum_tap dXcol[KW*ci + tap][(b, h, w - tap + pw)], summed over the K-split slabs
+struct Col2im1dKArgs { StageArgs a; int nslab; long long slab_stride; int accumulate; };
 template <int KW>
-__global__ void __launch_bounds__(256) col2im_1d_kernel(const StageArgs a, int nslab, long long slab_stride, int accumulate)
+__global__ void __launch_bounds__(256) col2im_1d_kernel(const Twin<Col2im1dKArgs> tw)
 {
+    const Col2im1dKArgs& ka_ = tw.v[blockIdx.z];
+    const StageArgs& a = ka_.a;
+    int nslab = ka_.nslab;
+    long long slab_stride = ka_.slab_stride;
+    int accumulate = ka_.accumulate;
     constexpr int PW = (KW - 1) / 2;
     const int P = a.H * a.W;
     const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -294,9 +313,18 @@ __global__ void __launch_bounds__(256) col2im_1d_kernel(const StageArgs a, int n
     *d = accumulate ? *d + s : s;
 }
 
-__global__ void __launch_bounds__(256) dw_accum_kernel(const float* __restrict__ slabs, int nslab, long long slab_stride, float* __restrict__ g0,
-                                                       float* __restrict__ g1, int Cout, int rows, int K9)
+struct DwAccumKArgs { const float* slabs; int nslab; long long slab_stride; float* g0; float* g1; int Cout; int rows; int K9; };
+__global__ void __launch_bounds__(256) dw_accum_kernel(const Twin<DwAccumKArgs> tw)
 {
+    const DwAccumKArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ slabs = ka_.slabs;
+    int nslab = ka_.nslab;
+    long long slab_stride = ka_.slab_stride;
+    float* __restrict__ g0 = ka_.g0;
+    float* __restrict__ g1 = ka_.g1;
+    int Cout = ka_.Cout;
+    int rows = ka_.rows;
+    int K9 = ka_.K9;
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= (long long)rows * K9) return;
     float4 s = *reinterpret_cast<const float4*>(slabs + i);
@@ -332,7 +360,7 @@ int mcvc_sgemm_launch(const SGemmArgs& a0, hipStream_t s)
         done = true;
     }
     TraceScope ts(K_SGEMM, s, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.K * a.M + (double)a.K * a.N + (double)a.M * a.N * a.nsplit));
-    hipLaunchKernelGGL(sgemm_kernel, dim3((unsigned)(a.nt * a.mt * a.nsplit)), dim3(256), lds, s, a);
+    mcvc_launch(sgemm_kernel, dim3((unsigned)(a.nt * a.mt * a.nsplit)), dim3(256), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -340,21 +368,21 @@ int mcvc_im2col_s2_launch(const StageArgs& a, hipStream_t s)
 {
     const long long NT = (long long)a.NB * a.OH * a.OW;
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.NB * a.C * a.H * a.W + 9.0 * a.C * NT));
-    hipLaunchKernelGGL(im2col_s2_kernel, dim3((unsigned)((NT + 255) / 256), (unsigned)a.C), dim3(256), 0, s, a);
+    mcvc_launch(im2col_s2_kernel, dim3((unsigned)((NT + 255) / 256), (unsigned)a.C), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
 int mcvc_im2col_s2_t_launch(const StageArgs& a, hipStream_t s)
 {
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.NB * a.C * a.H * a.W + 9.0 * a.C * a.rows_pad));
-    hipLaunchKernelGGL(im2col_s2_t_kernel, dim3((unsigned)((a.rows_pad + 31) / 32), (unsigned)cdiv_i(a.C, 32)), dim3(256), 0, s, a);
+    mcvc_launch(im2col_s2_t_kernel, dim3((unsigned)((a.rows_pad + 31) / 32), (unsigned)cdiv_i(a.C, 32)), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
 int mcvc_planes_t_launch(const StageArgs& a, hipStream_t s)
 {
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.NB * a.C * a.H * a.W + (double)a.C * a.rows_pad));
-    hipLaunchKernelGGL(planes_t_kernel, dim3((unsigned)((a.rows_pad + 31) / 32), (unsigned)cdiv_i(a.C, 32)), dim3(256), 0, s, a);
+    mcvc_launch(planes_t_kernel, dim3((unsigned)((a.rows_pad + 31) / 32), (unsigned)cdiv_i(a.C, 32)), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -362,7 +390,7 @@ int mcvc_col2im_s2_launch(const StageArgs& a, int nslab, long long slab_stride, 
 {
     const long long NE = (long long)a.NB * a.H * a.W;
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((accumulate ? 2.0 : 1.0) * a.NB * a.C * a.H * a.W + 9.0 * nslab * a.C * a.NB * a.OH * a.OW));
-    hipLaunchKernelGGL(col2im_s2_kernel, dim3((unsigned)((NE + 255) / 256), (unsigned)a.C), dim3(256), 0, s, a, nslab, slab_stride, accumulate);
+    mcvc_launch(col2im_s2_kernel, dim3((unsigned)((NE + 255) / 256), (unsigned)a.C), dim3(256), 0, s, Col2imS2KArgs{a, nslab, slab_stride, accumulate});
     return (int)hipGetLastError();
 }
 
@@ -372,8 +400,8 @@ int mcvc_im2col_1d_launch(const StageArgs& a, int KW, hipStream_t s)
     const long long NT = (long long)a.NB * a.H * a.W;
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (1.0 + KW) * a.C * NT);
     const dim3 grid((unsigned)((NT + 255) / 256), (unsigned)a.C);
-    if (KW == 3) hipLaunchKernelGGL(im2col_1d_kernel<3>, grid, dim3(256), 0, s, a);
-    else if (KW == 1) hipLaunchKernelGGL(im2col_1d_kernel<1>, grid, dim3(256), 0, s, a);
+    if (KW == 3) mcvc_launch(im2col_1d_kernel<3>, grid, dim3(256), 0, s, a);
+    else if (KW == 1) mcvc_launch(im2col_1d_kernel<1>, grid, dim3(256), 0, s, a);
     else return MCVC_ERR_INVALID;
     return (int)hipGetLastError();
 }
@@ -382,8 +410,8 @@ int mcvc_im2col_1d_t_launch(const StageArgs& a, int KW, hipStream_t s)
 {
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.NB * a.C * a.H * a.W + (double)KW * a.C * a.rows_pad));
     const dim3 grid((unsigned)((a.rows_pad + 31) / 32), (unsigned)cdiv_i(a.C, 32));
-    if (KW == 3) hipLaunchKernelGGL(im2col_1d_t_kernel<3>, grid, dim3(256), 0, s, a);
-    else if (KW == 1) hipLaunchKernelGGL(im2col_1d_t_kernel<1>, grid, dim3(256), 0, s, a);
+    if (KW == 3) mcvc_launch(im2col_1d_t_kernel<3>, grid, dim3(256), 0, s, a);
+    else if (KW == 1) mcvc_launch(im2col_1d_t_kernel<1>, grid, dim3(256), 0, s, a);
     else return MCVC_ERR_INVALID;
     return (int)hipGetLastError();
 }
@@ -393,8 +421,8 @@ int mcvc_col2im_1d_launch(const StageArgs& a, int KW, int nslab, long long slab_
     const long long NT = (long long)a.NB * a.H * a.W;
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((accumulate ? 2.0 : 1.0) + (double)KW * nslab) * a.C * NT);
     const dim3 grid((unsigned)((NT + 255) / 256), (unsigned)a.C);
-    if (KW == 3) hipLaunchKernelGGL(col2im_1d_kernel<3>, grid, dim3(256), 0, s, a, nslab, slab_stride, accumulate);
-    else if (KW == 1) hipLaunchKernelGGL(col2im_1d_kernel<1>, grid, dim3(256), 0, s, a, nslab, slab_stride, accumulate);
+    if (KW == 3) mcvc_launch(col2im_1d_kernel<3>, grid, dim3(256), 0, s, Col2im1dKArgs{a, nslab, slab_stride, accumulate});
+    else if (KW == 1) mcvc_launch(col2im_1d_kernel<1>, grid, dim3(256), 0, s, Col2im1dKArgs{a, nslab, slab_stride, accumulate});
     else return MCVC_ERR_INVALID;
     return (int)hipGetLastError();
 }
@@ -404,6 +432,6 @@ int mcvc_dw_accum_launch(const float* slabs, int nslab, long long slab_stride, f
     const long long n = (long long)rows * K9;
     if ((n & 3) || (((long long)Cout * K9) & 3) || (rows > Cout && !g1)) return MCVC_ERR_INVALID;
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * n * (nslab + 2.0));
-    hipLaunchKernelGGL(dw_accum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, slabs, nslab, slab_stride, g0, g1, Cout, rows, K9);
+    mcvc_launch(dw_accum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, DwAccumKArgs{slabs, nslab, slab_stride, g0, g1, Cout, rows, K9});
     return (int)hipGetLastError();
 }

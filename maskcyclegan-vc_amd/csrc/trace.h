@@ -3,6 +3,7 @@
 // Used by bench.py for the `roofline` object; not part of the compute path.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "twin.h"
 
 enum KernelKind {
     K_CONV_L = 0, K_CONV_M, K_CONV_N, K_CONV_T, K_CONV_S, K_CONV_S2, K_CONV_Q, K_CONV_FEW, K_WINO_GEMM,
@@ -15,8 +16,12 @@ extern bool g_mcvc_trace_on;
 void mcvc_trace_begin_(int kind, hipStream_t s, double flops, double bytes);
 void mcvc_trace_end_(hipStream_t s);
 
+// (grouped launches, launch.h: nothing is launched while a pass is being recorded; the launching walk counts both networks' work)
 struct TraceScope {
     hipStream_t s; bool on;
-    TraceScope(int kind, hipStream_t st, double flops, double bytes) : s(st), on(g_mcvc_trace_on) { if (on) mcvc_trace_begin_(kind, s, flops, bytes); }
+    TraceScope(int kind, hipStream_t st, double flops, double bytes) : s(st), on(g_mcvc_trace_on && mcvc_twin_phase() != 1)
+    {
+        if (on) { const double k = mcvc_twin_phase() == 2 ? 2.0 : 1.0; mcvc_trace_begin_(kind, s, k * flops, k * bytes); }
+    }
     ~TraceScope() { if (on) mcvc_trace_end_(s); }
 };

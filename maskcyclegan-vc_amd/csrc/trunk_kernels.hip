@@ -22,6 +22,7 @@
 // The same kernel with mode 0 is the data-gradient of these layers (weights transposed+flipped by pack_trunk_t).
 #include "mcvc_common.h"
 #include "trace.h"
+#include "launch.h"
 #include "trunk.h"
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -37,8 +38,9 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 // column l & 15.  A float4 of consecutive k per lane feeds four MFMAs (any 4 distinct k per instruction are fine as long as
 // the B operand uses the same ones).
 template <int KW, int NA, bool PRE>
-__global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const TrunkArgs a)
+__global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<TrunkArgs> tw)
 {
+    const TrunkArgs& a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -653,8 +655,9 @@ __device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4,
 }
 
 template <int NA>
-__global__ void __launch_bounds__(kNetThreads) trunk_fwd_net_kernel(const TrunkFwdNetArgs a)
+__global__ void __launch_bounds__(kNetThreads) trunk_fwd_net_kernel(const Twin<TrunkFwdNetArgs> tw)
 {
+    const TrunkFwdNetArgs& a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;
     float* epi = smem + a.x_floats;
@@ -708,9 +711,22 @@ __global__ void __launch_bounds__(kNetThreads) trunk_fwd_net_kernel(const TrunkF
     }
 }
 
-// dst[c][0..per_row) = bias ? bias[c] : 0   (initial value of an atomically accumulated K-split trunk layer)
-__global__ void __launch_bounds__(256) fill_rows_kernel(float* __restrict__ dst, const float* __restrict__ bias, int C, int per_row)
+struct ZeroWordsKArgs { unsigned* p; int n; };
+__global__ void zero_words_kernel(const Twin<ZeroWordsKArgs> tw)
 {
+    const ZeroWordsKArgs& a = tw.v[blockIdx.z];
+    if ((int)threadIdx.x < a.n) a.p[threadIdx.x] = 0u;
+}
+
+// dst[c][0..per_row) = bias ? bias[c] : 0   (initial value of an atomically accumulated K-split trunk layer)
+struct FillRowsKArgs { float* dst; const float* bias; int C; int per_row; };
+__global__ void __launch_bounds__(256) fill_rows_kernel(const Twin<FillRowsKArgs> tw)
+{
+    const FillRowsKArgs& ka_ = tw.v[blockIdx.z];
+    float* __restrict__ dst = ka_.dst;
+    const float* __restrict__ bias = ka_.bias;
+    int C = ka_.C;
+    int per_row = ka_.per_row;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= C * per_row) return;
     dst[i] = bias ? bias[i / per_row] : 0.f;
@@ -721,7 +737,7 @@ __global__ void __launch_bounds__(256) fill_rows_kernel(float* __restrict__ dst,
 int mcvc_fill_rows_launch(float* dst, const float* bias, int C, int per_row, hipStream_t s)
 {
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * C * per_row);
-    hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)cdiv_i(C * per_row, 256)), dim3(256), 0, s, dst, bias, C, per_row);
+    mcvc_launch(fill_rows_kernel, dim3((unsigned)cdiv_i(C * per_row, 256)), dim3(256), 0, s, FillRowsKArgs{dst, bias, C, per_row});
     return (int)hipGetLastError();
 }
 
@@ -757,7 +773,7 @@ static int trunk_launch_p(const TrunkArgs& a, dim3 grid, size_t lds, hipStream_t
         if (e != hipSuccess) return (int)e;
         done = true;
     }
-    hipLaunchKernelGGL((trunk_layer_kernel<KW, NA, PRE>), grid, dim3(kTrunkThreads), lds, s, a);
+    mcvc_launch((trunk_layer_kernel<KW, NA, PRE>), grid, dim3(kTrunkThreads), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -822,8 +838,9 @@ int mcvc_trunk_fwd_net_launch(TrunkFwdNetArgs& a, hipStream_t s)
     a.fault_inject = g_trunk_fault_inject;
     const size_t lds = ((size_t)a.x_floats + kNetEpiFloats) * sizeof(float);
     if (lds > 160 * 1024) return MCVC_ERR_INVALID;
-    hipError_t e = hipMemsetAsync(a.sync, 0, (MCVC_TRUNK_SYNC_WORDS - 1) * sizeof(unsigned), s);      // (the error word is sticky: mcvc_gen_trunk_fault)
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;
+    // arrival counters back to zero (a kernel, not a memset: it takes part in grouped launches); the error word is sticky (mcvc_gen_trunk_fault)
+    mcvc_launch(zero_words_kernel, dim3(1), dim3(64), 0, s, ZeroWordsKArgs{a.sync, MCVC_TRUNK_SYNC_WORDS - 1});
     TraceScope ts(K_TRUNK, s, flops, bytes);
     const bool wide = N > 16;
     static bool done[2] = {false, false};
@@ -833,7 +850,7 @@ int mcvc_trunk_fwd_net_launch(TrunkFwdNetArgs& a, hipStream_t s)
         if (e != hipSuccess) return (int)e;
         done[wide] = true;
     }
-    if (wide) hipLaunchKernelGGL(trunk_fwd_net_kernel<2>, dim3(kNetGrid), dim3(kNetThreads), lds, s, a);
-    else hipLaunchKernelGGL(trunk_fwd_net_kernel<1>, dim3(kNetGrid), dim3(kNetThreads), lds, s, a);
+    if (wide) mcvc_launch(trunk_fwd_net_kernel<2>, dim3(kNetGrid), dim3(kNetThreads), lds, s, a);
+    else mcvc_launch(trunk_fwd_net_kernel<1>, dim3(kNetGrid), dim3(kNetThreads), lds, s, a);
     return (int)hipGetLastError();
 }

@@ -10,6 +10,7 @@
 // The data-gradient of these layers is the same pipeline on flipped, transposed weights.
 #include "mcvc_common.h"
 #include "trace.h"
+#include "launch.h"
 #include "wino.h"
 
 namespace {
@@ -26,8 +27,9 @@ __device__ __forceinline__ void bt6(const float d[6], float o[6])
 }
 
 // one thread = one (channel, tile): 36 loads (rows of 6 consecutive floats), 72 small dot products, 36 coalesced stores
-__global__ void __launch_bounds__(256) wino_input_kernel(const WinoXformArgs a)
+__global__ void __launch_bounds__(256) wino_input_kernel(const Twin<WinoXformArgs> tw)
 {
+    const WinoXformArgs& a = tw.v[blockIdx.z];
     const int tile = blockIdx.x * 256 + threadIdx.x;
     const int c = blockIdx.y;
     if (tile >= a.NT) return;
@@ -69,8 +71,9 @@ __device__ __forceinline__ void bt4(const float d[4], float o[4])
     o[0] = d[0] - d[2]; o[1] = d[1] + d[2]; o[2] = d[2] - d[1]; o[3] = d[1] - d[3];
 }
 
-__global__ void __launch_bounds__(256) wino3_input_kernel(const WinoXformArgs a)
+__global__ void __launch_bounds__(256) wino3_input_kernel(const Twin<WinoXformArgs> tw)
 {
+    const WinoXformArgs& a = tw.v[blockIdx.z];
     const int tile = blockIdx.x * 256 + threadIdx.x;
     const int c = blockIdx.y;
     if (tile >= a.NT) return;
@@ -106,8 +109,13 @@ __global__ void __launch_bounds__(256) wino3_input_kernel(const WinoXformArgs a)
 }
 
 // phase-plane variant: channel k = 4ci + 2p + q reads x[ci][2i+p][2j+q] of an XH x XW image
-__global__ void __launch_bounds__(256) wino3_input_phase_kernel(const WinoXformArgs a, int XH, int XW)
+struct Wino3InputPhaseKArgs { WinoXformArgs a; int XH; int XW; };
+__global__ void __launch_bounds__(256) wino3_input_phase_kernel(const Twin<Wino3InputPhaseKArgs> tw)
 {
+    const Wino3InputPhaseKArgs& ka_ = tw.v[blockIdx.z];
+    const WinoXformArgs& a = ka_.a;
+    int XH = ka_.XH;
+    int XW = ka_.XW;
     const int tile = blockIdx.x * 256 + threadIdx.x;
     const int k = blockIdx.y;
     if (tile >= a.NT) return;
@@ -144,8 +152,13 @@ __global__ void __launch_bounds__(256) wino3_input_phase_kernel(const WinoXformA
 }
 
 // tile-major twins for the weight gradient (16 tiles x 16 channels per workgroup, channel fastest)
-__global__ void __launch_bounds__(256) wino3_input_phase_t_kernel(const WinoXformArgs a, int XH, int XW)
+struct Wino3InputPhaseTKArgs { WinoXformArgs a; int XH; int XW; };
+__global__ void __launch_bounds__(256) wino3_input_phase_t_kernel(const Twin<Wino3InputPhaseTKArgs> tw)
 {
+    const Wino3InputPhaseTKArgs& ka_ = tw.v[blockIdx.z];
+    const WinoXformArgs& a = ka_.a;
+    int XH = ka_.XH;
+    int XW = ka_.XW;
     const int k = blockIdx.y * 16 + (threadIdx.x & 15);
     const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (tile >= a.NTp || k >= a.C) return;
@@ -189,8 +202,9 @@ __global__ void __launch_bounds__(256) wino3_input_phase_t_kernel(const WinoXfor
 // A3 (4x2) = [[1,0],[1,1],[1,-1],[0,-1]]:  dM = A3 dy A3^T
 __device__ __forceinline__ void a42(float d0, float d1, float o[4]) { o[0] = d0; o[1] = d0 + d1; o[2] = d0 - d1; o[3] = -d1; }
 
-__global__ void __launch_bounds__(256) wino3_dy_t_kernel(const WinoXformArgs a)
+__global__ void __launch_bounds__(256) wino3_dy_t_kernel(const Twin<WinoXformArgs> tw)
 {
+    const WinoXformArgs& a = tw.v[blockIdx.z];
     const int c = blockIdx.y * 16 + (threadIdx.x & 15);
     const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (tile >= a.NTp || c >= a.C) return;
@@ -226,9 +240,16 @@ __global__ void __launch_bounds__(256) wino3_dy_t_kernel(const WinoXformArgs a)
 }
 
 // dg' = G3^T dU G3 (3x3 per (co, k = 4ci+2p+q)), scattered into the OIHW gradient: dw[co][ci][2u'+p][2v'+q] += dg'[u'][v']
-__global__ void __launch_bounds__(256) wino3_dw_kernel(const float* __restrict__ du, float* __restrict__ dw0, float* __restrict__ dw1,
-                                                       int Cout, int nbr, int Cin)
+struct Wino3DwKArgs { const float* du; float* dw0; float* dw1; int Cout; int nbr; int Cin; };
+__global__ void __launch_bounds__(256) wino3_dw_kernel(const Twin<Wino3DwKArgs> tw)
 {
+    const Wino3DwKArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ du = ka_.du;
+    float* __restrict__ dw0 = ka_.dw0;
+    float* __restrict__ dw1 = ka_.dw1;
+    int Cout = ka_.Cout;
+    int nbr = ka_.nbr;
+    int Cin = ka_.Cin;
     const int k = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y;
     const int K = 4 * Cin;
     if (k >= K) return;
@@ -266,8 +287,9 @@ __global__ void __launch_bounds__(256) wino3_dw_kernel(const float* __restrict__
     }
 }
 
-__global__ void __launch_bounds__(256) wino3_output_kernel(const WinoOutArgs a)
+__global__ void __launch_bounds__(256) wino3_output_kernel(const Twin<WinoOutArgs> tw)
 {
+    const WinoOutArgs& a = tw.v[blockIdx.z];
     const int tile = blockIdx.x * 256 + threadIdx.x;
     const int co = blockIdx.y;
     if (tile >= a.NT) return;
@@ -312,8 +334,9 @@ __global__ void __launch_bounds__(256) wino3_output_kernel(const WinoOutArgs a)
 // dU[xi][co][ci] = sum_tile dM[xi][co][tile] * V[xi][ci][tile]: the tile index is the contraction dimension, so both
 // operands are stored tile-major ([xi][tile][channel]) -- the K-major layout the batched GEMM streams.  A workgroup
 // covers 16 tiles x 16 channels with the channel fastest, so every store is a 64-byte run.
-__global__ void __launch_bounds__(256) wino_input_t_kernel(const WinoXformArgs a)
+__global__ void __launch_bounds__(256) wino_input_t_kernel(const Twin<WinoXformArgs> tw)
 {
+    const WinoXformArgs& a = tw.v[blockIdx.z];
     const int c = blockIdx.y * 16 + (threadIdx.x & 15);
     const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (tile >= a.NTp || c >= a.C) return;
@@ -359,8 +382,9 @@ __device__ __forceinline__ void a62(float d0, float d1, float o[6])
     o[0] = d0; o[1] = d0 + d1; o[2] = d0 - d1; o[3] = d0 + 2.f * d1; o[4] = d0 - 2.f * d1; o[5] = d1;
 }
 
-__global__ void __launch_bounds__(256) wino_dy_t_kernel(const WinoXformArgs a)      // x = dY [N][C][H][W], H x W = conv output
+__global__ void __launch_bounds__(256) wino_dy_t_kernel(const Twin<WinoXformArgs> tw)      // x = dY [N][C][H][W], H x W = conv output
 {
+    const WinoXformArgs& a = tw.v[blockIdx.z];
     const int c = blockIdx.y * 16 + (threadIdx.x & 15);
     const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (tile >= a.NTp || c >= a.C) return;
@@ -396,8 +420,14 @@ __global__ void __launch_bounds__(256) wino_dy_t_kernel(const WinoXformArgs a)  
 }
 
 // dg = G^T dU G, accumulated into the OIHW gradient.  One thread per (co, ci), ci fastest (coalesced reads of dU).
-__global__ void __launch_bounds__(256) wino_dw_kernel(const float* __restrict__ du, float* __restrict__ dw, int Cout, int Cin)
+struct WinoDwKArgs { const float* du; float* dw; int Cout; int Cin; };
+__global__ void __launch_bounds__(256) wino_dw_kernel(const Twin<WinoDwKArgs> tw)
 {
+    const WinoDwKArgs& ka_ = tw.v[blockIdx.z];
+    const float* __restrict__ du = ka_.du;
+    float* __restrict__ dw = ka_.dw;
+    int Cout = ka_.Cout;
+    int Cin = ka_.Cin;
     const int ci = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y;
     if (ci >= Cin) return;
     const long long xs = (long long)Cout * Cin;
@@ -438,8 +468,9 @@ __device__ __forceinline__ void at6(const float m[6], float& o0, float& o1)
     o1 = m[1] - m[2] + 2.f * (m[3] - m[4]) + m[5];
 }
 
-__global__ void __launch_bounds__(256) wino_output_kernel(const WinoOutArgs a)
+__global__ void __launch_bounds__(256) wino_output_kernel(const Twin<WinoOutArgs> tw)
 {
+    const WinoOutArgs& a = tw.v[blockIdx.z];
     const int tile = blockIdx.x * 256 + threadIdx.x;
     const int co = blockIdx.y;
     if (tile >= a.NT) return;
@@ -503,8 +534,9 @@ __device__ __forceinline__ void wg_glds16(const float* g, float* l)
 // was padding and 576 workgroups of 6.8 us left a third of the chip idle in the last round; 32-column tiles are exact, half the size,
 // and four of them fit a CU (40 KB of LDS each).
 template <int BN>
-__global__ void __launch_bounds__(256, (BN == 64 ? 3 : 4)) wino_gemm_kernel(const WinoGemmArgs a)
+__global__ void __launch_bounds__(256, (BN == 64 ? 3 : 4)) wino_gemm_kernel(const Twin<WinoGemmArgs> tw)
 {
+    const WinoGemmArgs& a = tw.v[blockIdx.z];
     constexpr int kGB = kGK * BN;
     constexpr int kGStage = kGA + kGB;
     constexpr int NACC = (BN == 64) ? 2 : 1;
@@ -615,8 +647,9 @@ __global__ void __launch_bounds__(256, (BN == 64 ? 3 : 4)) wino_gemm_kernel(cons
 template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
 
 template <int BM, int BN, int GK, int ST>
-__global__ void __launch_bounds__(256) gemm2_kernel(const WinoGemmArgs a)
+__global__ void __launch_bounds__(256) gemm2_kernel(const Twin<WinoGemmArgs> tw)
 {
+    const WinoGemmArgs& a = tw.v[blockIdx.z];
     constexpr int SA = GK * BM, SB = GK * BN, STAGE = SA + SB;
     constexpr int NACC = (BM == 128 && BN == 64) ? 2 : 1;
     constexpr int NA = (SA / 4 + 255) / 256, NB = (SB / 4 + 255) / 256, ND = NA + NB;     // DMA instructions per wave and stage
@@ -715,7 +748,7 @@ static int gemm2_launch(WinoGemmArgs b, int nxi, hipStream_t s)
         if (e != hipSuccess) return (int)e;
         done = true;
     }
-    hipLaunchKernelGGL((gemm2_kernel<BM, BN, GK, ST>), dim3((unsigned)(b.nt * b.mt * nxi)), dim3(256), lds, s, b);
+    mcvc_launch((gemm2_kernel<BM, BN, GK, ST>), dim3((unsigned)(b.nt * b.mt * nxi)), dim3(256), lds, s, b);
     return (int)hipGetLastError();
 }
 
@@ -725,7 +758,7 @@ int mcvc_wino_input_launch(const WinoXformArgs& a, hipStream_t s)
 {
     dim3 grid((unsigned)cdiv_i(a.NT, 256), (unsigned)a.C);
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NT));
-    hipLaunchKernelGGL(wino_input_kernel, grid, dim3(256), 0, s, a);
+    mcvc_launch(wino_input_kernel, grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -733,7 +766,7 @@ int mcvc_wino_output_launch(const WinoOutArgs& a, hipStream_t s)
 {
     dim3 grid((unsigned)cdiv_i(a.NT, 256), (unsigned)a.Cout);
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (36.0 * a.Cout * a.NT + 4.0 * a.Cout * a.NT));
-    hipLaunchKernelGGL(wino_output_kernel, grid, dim3(256), 0, s, a);
+    mcvc_launch(wino_output_kernel, grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -775,10 +808,10 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
             if (e != hipSuccess) return (int)e;
             done = true;
         }
-        hipLaunchKernelGGL(wino_gemm_kernel<32>, dim3((unsigned)(b.nt * b.mt * nxi)), dim3(256), (size_t)kGStages * (kGA + kGK * 32) * sizeof(float), s, b);
+        mcvc_launch(wino_gemm_kernel<32>, dim3((unsigned)(b.nt * b.mt * nxi)), dim3(256), (size_t)kGStages * (kGA + kGK * 32) * sizeof(float), s, b);
     } else {
         b.nt = cdiv_i(a.N, 64);
-        hipLaunchKernelGGL(wino_gemm_kernel<64>, dim3((unsigned)(b.nt * b.mt * nxi)), dim3(256), (size_t)kGStages * (kGA + kGK * 64) * sizeof(float), s, b);
+        mcvc_launch(wino_gemm_kernel<64>, dim3((unsigned)(b.nt * b.mt * nxi)), dim3(256), (size_t)kGStages * (kGA + kGK * 64) * sizeof(float), s, b);
     }
     return (int)hipGetLastError();
 }
@@ -787,7 +820,7 @@ int mcvc_wino_input_t_launch(const WinoXformArgs& a, hipStream_t s)
 {
     dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp));
-    hipLaunchKernelGGL(wino_input_t_kernel, grid, dim3(256), 0, s, a);
+    mcvc_launch(wino_input_t_kernel, grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -795,7 +828,7 @@ int mcvc_wino_dy_t_launch(const WinoXformArgs& a, hipStream_t s)
 {
     dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp));
-    hipLaunchKernelGGL(wino_dy_t_kernel, grid, dim3(256), 0, s, a);
+    mcvc_launch(wino_dy_t_kernel, grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -803,7 +836,7 @@ int mcvc_wino_dw_launch(const float* du, float* dw, int Cout, int Cin, hipStream
 {
     dim3 grid((unsigned)cdiv_i(Cin, 256), (unsigned)Cout);
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (36.0 + 50.0) * Cout * Cin);
-    hipLaunchKernelGGL(wino_dw_kernel, grid, dim3(256), 0, s, du, dw, Cout, Cin);
+    mcvc_launch(wino_dw_kernel, grid, dim3(256), 0, s, WinoDwKArgs{du, dw, Cout, Cin});
     return (int)hipGetLastError();
 }
 
@@ -811,7 +844,7 @@ int mcvc_wino3_input_launch(const WinoXformArgs& a, hipStream_t s)
 {
     dim3 grid((unsigned)cdiv_i(a.NT, 256), (unsigned)a.C);
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 16.0 * a.C * a.NT));
-    hipLaunchKernelGGL(wino3_input_kernel, grid, dim3(256), 0, s, a);
+    mcvc_launch(wino3_input_kernel, grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -819,7 +852,7 @@ int mcvc_wino3_output_launch(const WinoOutArgs& a, hipStream_t s)
 {
     dim3 grid((unsigned)cdiv_i(a.NT, 256), (unsigned)a.Cout);
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (16.0 * a.Cout * a.NT + 4.0 * a.Cout * a.NT));
-    hipLaunchKernelGGL(wino3_output_kernel, grid, dim3(256), 0, s, a);
+    mcvc_launch(wino3_output_kernel, grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -827,7 +860,7 @@ int mcvc_wino3_input_phase_launch(const WinoXformArgs& a, int XH, int XW, hipStr
 {
     dim3 grid((unsigned)cdiv_i(a.NT, 256), (unsigned)a.C);
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * (a.C / 4) * XH * XW + 16.0 * a.C * a.NT));
-    hipLaunchKernelGGL(wino3_input_phase_kernel, grid, dim3(256), 0, s, a, XH, XW);
+    mcvc_launch(wino3_input_phase_kernel, grid, dim3(256), 0, s, Wino3InputPhaseKArgs{a, XH, XW});
     return (int)hipGetLastError();
 }
 
@@ -835,7 +868,7 @@ int mcvc_wino3_input_phase_t_launch(const WinoXformArgs& a, int XH, int XW, hipS
 {
     dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * (a.C / 4) * XH * XW + 16.0 * a.C * a.NTp));
-    hipLaunchKernelGGL(wino3_input_phase_t_kernel, grid, dim3(256), 0, s, a, XH, XW);
+    mcvc_launch(wino3_input_phase_t_kernel, grid, dim3(256), 0, s, Wino3InputPhaseTKArgs{a, XH, XW});
     return (int)hipGetLastError();
 }
 
@@ -843,7 +876,7 @@ int mcvc_wino3_dy_t_launch(const WinoXformArgs& a, hipStream_t s)
 {
     dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 16.0 * a.C * a.NTp));
-    hipLaunchKernelGGL(wino3_dy_t_kernel, grid, dim3(256), 0, s, a);
+    mcvc_launch(wino3_dy_t_kernel, grid, dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 
@@ -851,6 +884,6 @@ int mcvc_wino3_dw_launch(const float* du, float* dw0, float* dw1, int Cout, int 
 {
     dim3 grid((unsigned)cdiv_i(4 * Cin, 256), (unsigned)(Cout * nbr));
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (16.0 * 4.0 + 2.0 * 25.0) * Cout * nbr * Cin);
-    hipLaunchKernelGGL(wino3_dw_kernel, grid, dim3(256), 0, s, du, dw0, dw1, Cout, nbr, Cin);
+    mcvc_launch(wino3_dw_kernel, grid, dim3(256), 0, s, Wino3DwKArgs{du, dw0, dw1, Cout, nbr, Cin});
     return (int)hipGetLastError();
 }

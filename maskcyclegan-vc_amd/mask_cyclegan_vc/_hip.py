@@ -28,6 +28,10 @@ _SIGS = {
     "mcvc_set_deterministic": (c_int, [c_int]),
     "mcvc_get_deterministic": (c_int, []),
     "mcvc_set_trunk_persistent": (c_int, [c_int]),
+    "mcvc_twin_begin": (c_int, []),
+    "mcvc_twin_switch": (c_int, []),
+    "mcvc_twin_end": (c_int, []),
+    "mcvc_twin_launches": (c_int, []),
     "mcvc_gen_packed_floats": (c_longlong, []),
     "mcvc_disc_packed_floats": (c_longlong, []),
     "mcvc_gen_stash_floats": (c_longlong, [c_int, c_int]),
@@ -104,6 +108,24 @@ def lib():
             raise RuntimeError("libmcvc_hip.so ABI version mismatch")
         _lib = L
     return _lib
+
+
+class twin(object):
+    """``with twin() as tw: <calls on network 0>; tw.switch(); <the same calls on network 1>`` -- the two sequences go out as ONE set of
+    grouped launches (include/mcvc.h, mcvc_twin_*).  An exception inside the block abandons the bracket."""
+
+    def __enter__(self):
+        check(lib().mcvc_twin_begin(), "mcvc_twin_begin")
+        return self
+
+    def switch(self):
+        check(lib().mcvc_twin_switch(), "mcvc_twin_switch")
+
+    def __exit__(self, et, ev, tb):
+        rc = lib().mcvc_twin_end()
+        if et is None:
+            check(rc, "mcvc_twin_end (the two call sequences of a grouped pass differ)")
+        return False
 
 
 def check(rc: int, what: str = "mcvc call"):

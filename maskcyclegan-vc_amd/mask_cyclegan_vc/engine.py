@@ -149,6 +149,13 @@ class TrainEngine:
         self._g_fwd_packed = False
         self._g_grad_clean = self._d_grad_clean = False
         self.fuse_g_update = os.environ.get("MCVC_FUSE_G_UPDATE", "1") != "0"
+        # Grouped launches (csrc/twin.h): G_A2B / G_B2A -- and the discriminator pairs -- run the same layer schedule on different weights,
+        # so every kernel of a pair of passes goes out ONCE with gridDim.z = 2 instead of twice on two lanes: half the launches, twice the
+        # workgroups per launch, the two chains in lock-step.  Lane 0 then carries the generator chain (both generators), lane 1 the
+        # first-step discriminator pair.  MCVC_GROUPED=0 restores the four-lane schedule; MCVC_GROUPED_MAX_B: largest per-pass batch B for
+        # which the grouped schedule is used (large batches fill the chip per network anyway).
+        self.grouped = os.environ.get("MCVC_GROUPED", "1") != "0"
+        self.grouped_max_b = int(os.environ.get("MCVC_GROUPED_MAX_B", "1024"))
         self.split_d_min_batch = int(os.environ.get("MCVC_SPLIT_D_MIN_BATCH", "4"))
         self._timeline = None
         self._pack_stream = torch.cuda.Stream(device=dev)
@@ -316,20 +323,30 @@ class TrainEngine:
             torch.cuda.current_stream(self.device).wait_stream(self._capture_stream)
         ent[1].replay()
 
+    def _twin(self, f0, f1):
+        """Two identical call sequences on different networks as ONE set of grouped launches (gridDim.z = 2; _hip.twin)."""
+        with _hip.twin() as tw:
+            f0()
+            tw.switch()
+            f1()
+
     def _G(self, name, x, mask, out, stash, nb, lane=0):
         sc = self.g_scratch[lane]
         self._pass(("G", name, x.data_ptr(), 0 if mask is None else mask.data_ptr(), out.data_ptr(), stash.data_ptr(), nb, lane),
                    lambda: check(self.L.mcvc_gen_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(mask), ptr(out), ptr(stash),
                                                          ptr(sc), sc.numel(), nb, self.T, stream()), "gen_forward"))
 
-    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0, milestones=False):
+    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0, milestones=False, aux_lane=None, ms_of=None):
+        """``lane`` picks the scratch buffer; ``aux_lane`` (default: the same) the auxiliary weight-gradient stream -- the two halves of a
+        grouped pass use different scratch buffers but the same streams and milestone events (``ms_of``)."""
         sc = self.g_scratch[lane]
-        ms = self._ms[name][1] if milestones else None
+        ms = self._ms[ms_of or name][1] if milestones else None
+        aux = self._aux_ptr(lane if aux_lane is None else aux_lane)
         self._pass(("Gb", name, 0 if mask is None else mask.data_ptr(), dout.data_ptr(), 0 if dx is None else dx.data_ptr(), acc, stash.data_ptr(),
                     nb, lane, bool(milestones), self.aux_wgrad),
                    lambda: check(self.L.mcvc_gen_backward_overlap(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name], ptr(mask), ptr(dout),
                                                                   ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(),
-                                                                  self._aux_ptr(lane), ms), "gen_backward"))
+                                                                  aux, ms), "gen_backward"))
 
     def _D(self, name, x, out, stash, nb, lane=0):
         sc = self.d_scratch[lane]
@@ -480,6 +497,177 @@ class TrainEngine:
         self._g_fwd_packed = bool(fuse_update)
         self._d_pack_event = None
         self._combine(0, self._comb_g)          # g_loss and its terms, summed in the reference's order (:233-237)
+
+    def _use_grouped(self):
+        return self.grouped and self.B <= self.grouped_max_b and not self.use_graphs and not self.pass_graphs
+
+    def generator_phase_grouped(self, real_A, mask_A, real_B, mask_B, fuse_update=False):
+        """train.py:195-242 with the two generators (and each discriminator pair) in grouped launches: the same dataflow as
+        ``generator_phase``, two lanes instead of four.  Lane 0: both translation + identity passes, both cycle passes, the second-step
+        discriminators, both backward rounds, the update.  Lane 1: the first-step adversarial pair D_A(fake_A) | D_B(fake_B), which needs
+        only the translated batches and runs beside the cycle forwards."""
+        B, B2 = self.B, 2 * self.B
+        m = self.mel
+        sc = self.sched
+        self.slots[:_BLOCK].zero_()
+        if self._g_grad_clean:
+            self._g_grad_clean = False
+        else:
+            self.g_group.grad.zero_()
+        torch._foreach_copy_([self.in_A2B[:B], self.in_A2B[B:], self.in_B2A[:B], self.in_B2A[B:], self.mask_A2B[:B], self.mask_B2A[:B]],
+                             [real_A, real_B, real_B, real_A, mask_A, mask_B])
+        fake_B, identity_B = self.out_A2B[:B], self.out_A2B[B:]
+        fake_A, identity_A = self.out_B2A[:B], self.out_B2A[B:]
+        g_fake_B, g_identity_B = self.gout_A2B[:B], self.gout_A2B[B:]
+        g_fake_A, g_identity_A = self.gout_B2A[:B], self.gout_B2A[B:]
+        do, dl, ds = self.dout1, self.dlogit1, self.d_stash1
+        cl, il = sc.cycle_loss_lambda, sc.identity_loss_lambda
+        A2B, B2A = G_NAMES
+        ov = self.overlap_g_reduce
+
+        def fwd2(ln):                                                                                       # :203, :205, :207-210
+            self._twin(lambda: self._G(A2B, self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], B2, 0),
+                       lambda: self._G(B2A, self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], B2, 1))
+
+        def cycle_half(k):
+            if k == 0:
+                self._G(B2A, fake_B, None, m["cycle_A"], self.g_stash1[0], B, 0)                           # :204 (mask of ones)
+                self._l1(m["cycle_A"], real_A, cl, m["g_cycle_A"], 0)                                       # :219
+                self._l1(identity_B, real_B, il, g_identity_B, 3)                                           # :224
+            else:
+                self._G(A2B, fake_A, None, m["cycle_B"], self.g_stash1[1], B, 1)                           # :206
+                self._l1(m["cycle_B"], real_B, cl, m["g_cycle_B"], 1)                                       # :220
+                self._l1(identity_A, real_A, il, g_identity_A, 2)                                           # :223
+
+        def adv_half(name, i, x, gx, acc):
+            self._D(name, x, do[i], ds[i], B, i)                                                            # :211-216
+            self._lsgan(do[i], 1.0, 1.0, 4 + i, dl[i])                                                      # :227-231
+            self._D_bwd(name, dl[i], gx, acc, ds[i], False, B, i)          # discriminators contribute data-gradients only
+
+        def adv1(ln):
+            self._finish_d_update()            # data parallel: the D all-reduce of the previous iteration hides behind the generator forwards
+            self._wait_d_pack()                # discriminator weights changed at the end of the previous iteration
+            self._twin(lambda: adv_half("discriminator_A", 0, fake_A, g_fake_A, 0), lambda: adv_half("discriminator_B", 1, fake_B, g_fake_B, 0))
+            if fuse_update and not self._d_grad_clean:
+                self.d_group.grad.zero_()      # free once their Adam step is queued: cleared here, on the side lane (99 MB memset)
+                self._d_grad_clean = True
+
+        def adv2(ln):
+            self._wait_d_pack()
+            self._twin(lambda: adv_half("discriminator_A2", 2, m["cycle_A"], m["g_cycle_A"], 1),
+                       lambda: adv_half("discriminator_B2", 3, m["cycle_B"], m["g_cycle_B"], 1))
+
+        def bwd_cycle(ln):      # cycle_A = G_B2A(fake_B) adds to d(fake_B), cycle_B = G_A2B(fake_A) to d(fake_A)
+            self._twin(lambda: self._G_bwd(B2A, None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B, 0, aux_lane=0),
+                       lambda: self._G_bwd(A2B, None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, 1, aux_lane=0))
+
+        def bwd_final(ln):      # the last pass over each generator; its gradient ranges become final one after the other (milestone events)
+            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2, 0, ov, aux_lane=0, ms_of=A2B),
+                       lambda: self._G_bwd(B2A, self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2, 1, ov, aux_lane=0, ms_of=A2B))
+        if fuse_update:
+            g_lr = sc.g_opt_lr
+
+        def queue_reduce(ln):
+            # data parallel: range k of BOTH generators is final at milestone k of the grouped pass; same collective order on every rank
+            for k in range(2):
+                for n in G_NAMES:
+                    lo, hi = self._g_ranges[n][k]
+                    self.reducer.reduce_range_after_(self.g_group.grad, lo, hi, self._ms[A2B][0][k])
+            for n in G_NAMES:
+                lo, hi = self._g_ranges[n][2]
+                self.reducer.reduce_range_after_(self.g_group.grad, lo, hi, self._task_events.get("f") if self.concurrent else None)
+
+        def update(ln):
+            self.reducer.wait(self.device)             # (no-op on one GPU)
+            self._adam(self.g_group, g_lr)             # one launch over both generators
+            self._twin(lambda: self._repack1(A2B, 1), lambda: self._repack1(B2A, 1))
+        self._run_tasks([
+            (0, fwd2, (), "g"),
+            (0, lambda ln: self._twin(lambda: cycle_half(0), lambda: cycle_half(1)), (), None),
+            (1, adv1, ("g",), "d1"),
+            (0, adv2, (), None),
+            (0, bwd_cycle, ("d1",), None),
+            (0, bwd_final, (), "f"),
+        ] + ([(1, queue_reduce, (), None)] if (fuse_update and ov) else [])
+          + ([(0, update, (), None)] if fuse_update else []))
+        self._g_fwd_packed = bool(fuse_update)
+        self._d_pack_event = None
+        self._combine(0, self._comb_g)
+
+    def discriminator_phase_grouped(self, real_A, mask_A, real_B, mask_B):
+        """train.py:247-299, grouped like ``generator_phase_grouped``: lane 0 runs both generators' forwards (translation, then cycle) and
+        the second-step discriminator pair, lane 1 refreshes the backward-only weight copies and runs D_A | D_B."""
+        B, B2 = self.B, 2 * self.B
+        self.slots[_BLOCK:].zero_()
+        if self._d_grad_clean:
+            self._d_grad_clean = False
+        else:
+            self.d_group.grad.zero_()
+        di = self.d_in
+        gen_A, gen_B = di["discriminator_A"][B:], di["discriminator_B"][B:]
+        cyc_A, cyc_B = di["discriminator_A2"][B:], di["discriminator_B2"][B:]
+        torch._foreach_copy_([di["discriminator_A"][:B], di["discriminator_A2"][:B], di["discriminator_B"][:B], di["discriminator_B2"][:B]],
+                             [real_A, real_A, real_B, real_B])
+        do, dl, ds = self.dout2, self.dlogit2, self.d_stash2
+        idx = {n: i for i, n in enumerate(D_NAMES)}
+        A2B, B2A = G_NAMES
+        packed = self._g_fwd_packed
+        self._g_fwd_packed = False
+
+        def disc_full(name):
+            i = idx[name]
+            self._D(name, di[name], do[i], ds[i], B2, i)                       # :255-258 real half, :260-273 generated half
+            self._lsgan(do[i][:B], 1.0, 0.25, 8 + 2 * i, dl[i][:B])            # every term of d_loss weighs 1/4 (:276-294)
+            self._lsgan(do[i][B:], 0.0, 0.25, 9 + 2 * i, dl[i][B:])
+            self._D_bwd(name, dl[i], None, 0, ds[i], True, B2, i)
+
+        def disc_half(name, fake):
+            i = idx[name]
+            sl = slice(B, B2) if fake else slice(0, B)
+            st = ds[i] if fake else self.d_stash1[i]
+            self._D(name, di[name][sl], do[i][sl], st, B, i)
+            self._lsgan(do[i][sl], 0.0 if fake else 1.0, 0.25, 8 + 2 * i + int(fake), dl[i][sl])
+            self._D_bwd(name, dl[i][sl], None, 0, st, True, B, i)
+
+        def pair(fn, a, b, *args):
+            return lambda ln: self._twin(lambda: fn(a, *args), lambda: fn(b, *args))
+
+        def gen_fwd(ln):
+            if not packed:                     # phase called on its own: full refresh first
+                self._twin(lambda: self._repack1(A2B), lambda: self._repack1(B2A))
+            self._twin(lambda: self._G(A2B, real_A, mask_A, gen_B, self.g_stash1[0], B, 0),                 # :267 generated_B
+                       lambda: self._G(B2A, real_B, mask_B, gen_A, self.g_stash1[1], B, 1))                 # :259 generated_A
+
+        def cycles(ln):
+            self._twin(lambda: self._G(B2A, gen_B, None, cyc_A, self.g_stash1[0], B, 0),                    # :271 cycled_A
+                       lambda: self._G(A2B, gen_A, None, cyc_B, self.g_stash1[1], B, 1))                    # :263 cycled_B
+
+        def refresh(ln):                       # the backward-only copies, beside the generator forwards; the generator gradients are free
+            if packed:
+                self._twin(lambda: self._repack1(A2B, 2), lambda: self._repack1(B2A, 2))
+                self.g_group.grad.zero_()      # (196 MB memset on the side lane instead of at the top of the next iteration)
+                self._g_grad_clean = True
+        if B >= self.split_d_min_batch:
+            # the real halves need nothing from the generators: lane 1 runs them while lane 0 is in the generator forwards
+            tasks = [
+                (0, gen_fwd, (), "gen"),
+                (1, refresh, (), None),
+                (1, pair(disc_half, "discriminator_A", "discriminator_B", False), (), None),
+                (1, pair(disc_half, "discriminator_A2", "discriminator_B2", False), (), "r2"),
+                (0, cycles, (), None),
+                (1, pair(disc_half, "discriminator_A", "discriminator_B", True), ("gen",), None),
+                (0, pair(disc_half, "discriminator_A2", "discriminator_B2", True), ("r2",), None),
+            ]
+        else:
+            tasks = [
+                (0, gen_fwd, (), "gen"),
+                (1, refresh, (), None),
+                (0, cycles, (), None),
+                (1, pair(disc_full, "discriminator_A", "discriminator_B"), ("gen",), None),
+                (0, pair(disc_full, "discriminator_A2", "discriminator_B2"), (), None),
+            ]
+        self._run_tasks(tasks)
+        self._combine(8, self._comb_d)
 
     def generator_update(self):
         """All-reduce (data parallel) + Adam on the flat generator buffer (train.py:242); eager: its scalars change per step."""
@@ -665,7 +853,8 @@ class TrainEngine:
 
     def _step_static(self):
         if (self.reducer.world == 1 or self.overlap_g_reduce) and not self.use_graphs and self.fuse_g_update:
-            self.generator_phase(*self.static_in, fuse_update=True)       # includes the generator update (per lane, no join)
+            phase = self.generator_phase_grouped if self._use_grouped() else self.generator_phase
+            phase(*self.static_in, fuse_update=True)                      # includes the generator update (no join of the lanes)
         else:
             self._run_phase("G")
             self.generator_update()
@@ -676,7 +865,10 @@ class TrainEngine:
 
     # ---- HIP graphs: each phase's ~500 launches (two lanes + auxiliary streams included) are captured once and replayed
     def _run_phase(self, which):
-        fn = self.generator_phase if which == "G" else self.discriminator_phase
+        if self._use_grouped():
+            fn = self.generator_phase_grouped if which == "G" else self.discriminator_phase_grouped
+        else:
+            fn = self.generator_phase if which == "G" else self.discriminator_phase
         if not self.use_graphs:
             fn(*self.static_in)
             return

@@ -1,0 +1,137 @@
+"""GPU: grouped ("twin") launches -- two networks of the same architecture in one grid (csrc/twin.h, include/mcvc.h mcvc_twin_*).
+
+The reference runs G_A2B / G_B2A and the discriminator pairs one after the other (train.py:203-216, 255-273); the four-lane schedule ran
+them on separate streams; the grouped schedule launches every kernel of a pair of passes once with gridDim.z = 2.  Every kernel computes
+exactly what it computes alone, so in bit-reproducible mode the grouped step must equal the four-lane step BIT FOR BIT."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import mcvc_oracle as orc  # noqa: E402  (parameter filler only)
+from mask_cyclegan_vc import _hip  # noqa: E402
+from mask_cyclegan_vc._hip import check, lib, ptr, ptr_table, stream  # noqa: E402
+from mask_cyclegan_vc.engine import D_NAMES, G_NAMES, TrainEngine  # noqa: E402
+from mask_cyclegan_vc.model import Discriminator, Generator  # noqa: E402
+from mask_cyclegan_vc.schedule import StepSchedule  # noqa: E402
+
+
+def _nets(seed0):
+    nets = {}
+    for i, n in enumerate(orc.NET_ORDER):
+        m = Generator() if i < 2 else Discriminator()
+        m.load_state_dict(orc.filler_params("G" if i < 2 else "D", seed0 + i), strict=True)
+        nets[n] = m.cuda()
+    return nets
+
+
+def _batch(B, seed):
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(2):
+        out.append(torch.from_numpy(rs.randn(B, 80, 64).astype(np.float32)).cuda())
+        out.append(torch.from_numpy(orc.fif_mask(rs, B, 80, 64, 25)).cuda())
+    return out
+
+
+@pytest.fixture
+def deterministic_mode():
+    L = lib()
+    was = L.mcvc_set_deterministic(1)
+    yield
+    L.mcvc_set_deterministic(was)
+
+
+def _steps(grouped, B, n_it=2):
+    nets = _nets(610)
+    eng = TrainEngine(nets, B, 64, schedule=StepSchedule(batch_size=B, n_samples=4 * B))
+    eng.grouped = grouped
+    losses = []
+    for it in range(n_it):
+        eng.step(*_batch(B, 70 + it))
+        losses.append(eng.losses())
+    eng.flush()
+    eng.check_faults()
+    return losses, {n: [p.detach().clone() for p in nets[n].parameters()] for n in G_NAMES + D_NAMES}
+
+
+@pytest.mark.parametrize("B", [1, 2, 4])
+def test_grouped_step_is_bit_identical_to_the_four_lane_step(deterministic_mode, B):
+    (l0, p0), (l1, p1) = _steps(False, B), _steps(True, B)
+    assert l0 == l1, (l0, l1)
+    for n in p0:
+        for i, (a, b) in enumerate(zip(p0[n], p1[n])):
+            assert torch.equal(a, b), (n, i)
+
+
+def test_grouped_step_default_mode_close_and_halves_the_launches():
+    """Default (atomics) mode: the two schedules agree to rounding; and the point of the exercise -- a traced grouped step issues
+    about half the kernel launches of the four-lane step."""
+    import ctypes
+    L = lib()
+    (l0, p0), (l1, p1) = _steps(False, 1), _steps(True, 1)
+    for a, b in zip(l0, l1):
+        for k in ("g_loss", "d_loss"):
+            assert abs(a[k] - b[k]) < 2e-3 * abs(a[k]), (k, a, b)
+    counts = {}
+    for grouped in (False, True):
+        eng = TrainEngine(_nets(610), 1, 64, schedule=StepSchedule(batch_size=1, n_samples=4))
+        eng.grouped = grouped
+        eng.step(*_batch(1, 5))
+        torch.cuda.synchronize()
+        eng.concurrent = False
+        eng.aux_wgrad = False
+        nk = L.mcvc_trace_kinds()
+        buf = (ctypes.c_double * (4 * nk))()
+        L.mcvc_trace_enable(1)
+        eng.step(*_batch(1, 6))
+        L.mcvc_trace_collect(buf)
+        L.mcvc_trace_enable(0)
+        counts[grouped] = (int(sum(buf[4 * k] for k in range(nk))), sum(buf[4 * k + 2] for k in range(nk)))
+    print("launches per step: four-lane %d, grouped %d" % (counts[False][0], counts[True][0]))
+    assert counts[True][0] <= 0.6 * counts[False][0]
+    assert abs(counts[True][1] - counts[False][1]) < 1e-6 * counts[False][1]        # same executed FLOPs, counted once per network
+
+
+def test_twin_bracket_on_the_c_abi_and_its_mismatch_guard():
+    """Two generator forwards through mcvc_twin_begin / switch / end equal the two single calls bit for bit; two sequences that do not
+    issue the same launches (different batch) are refused with an error instead of being paired up wrongly."""
+    L = lib()
+    torch.manual_seed(0)
+    gens = [Generator().cuda(), Generator().cuda()]
+    B, T = 2, 64
+    xs = [torch.randn(B, 80, T, device="cuda") for _ in range(2)]
+    ms = [torch.ones(B, 80, T, device="cuda") for _ in range(2)]
+    ms[0][:, :, 10:20] = 0.0
+    tabs = [ptr_table(list(g.parameters())) for g in gens]
+    packed = [g.packed_weights() for g in gens]
+
+    def fwd(i, out, stash, scratch, nb=B):
+        check(L.mcvc_gen_forward(tabs[i], ptr(packed[i]), ptr(xs[i]), ptr(ms[i]), ptr(out), ptr(stash), ptr(scratch), scratch.numel(), nb, T,
+                                 stream()), "gen_forward")
+    mk = lambda: (torch.zeros(B, 80, T, device="cuda"), torch.zeros(L.mcvc_gen_stash_floats(B, T), device="cuda"),      # noqa: E731
+                  torch.zeros(L.mcvc_gen_scratch_floats(B, T), device="cuda"))
+    single = [mk(), mk()]
+    for i in range(2):
+        fwd(i, *single[i])
+    twin = [mk(), mk()]
+    with _hip.twin() as tw:
+        fwd(0, *twin[0])
+        tw.switch()
+        fwd(1, *twin[1])
+    n_single = L.mcvc_twin_launches()
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(twin[i][0], single[i][0]) and torch.equal(twin[i][1], single[i][1]), i
+    assert n_single > 20
+    assert not torch.equal(single[0][0], single[1][0])
+    # mismatch: the second sequence runs a different batch size -> different grids
+    assert L.mcvc_twin_begin() == 0
+    fwd(0, *twin[0])
+    assert L.mcvc_twin_switch() == 0
+    L.mcvc_gen_forward(tabs[1], ptr(packed[1]), ptr(xs[1]), ptr(ms[1]), ptr(twin[1][0]), ptr(twin[1][1]), ptr(twin[1][2]), twin[1][2].numel(), 1, T,
+                       stream())
+    assert L.mcvc_twin_end() != 0
+    assert L.mcvc_twin_end() != 0 and L.mcvc_twin_begin() == 0 and L.mcvc_twin_switch() == 0 and L.mcvc_twin_end() == 0      # bracket state is clean again
+    torch.cuda.synchronize()
