@@ -286,6 +286,9 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
     nets = build_nets(device)
     sched = StepSchedule(generator_lr=2e-4, discriminator_lr=1e-4, num_epochs=6172, n_samples=81, batch_size=B,
                          decay_after=2e5, stop_identity_after=1e4, world_size=world)     # bash_scripts/mask_cyclegan_train.sh
+    import contextlib
+    run_ctx = torch.cuda.stream(torch.cuda.Stream(device=device)) if os.environ.get("MCVC_BENCH_STREAM") == "1" else contextlib.nullcontext()
+    run_ctx.__enter__()                    # (before the engine is built: its lanes are chosen against the stream it will be called on)
     engine = TrainEngine(nets, B, T, schedule=sched, reducer=FlatGradReducer())
     engine.concurrent = not args.serial
     if args.serial:
@@ -298,10 +301,6 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
     batches = synthetic_batches(n_batches, B, T, rank, device)
     log("engine ready; warm-up")
 
-    # the whole benchmark runs on a non-default stream when asked (experiment: the legacy NULL stream has its own ordering rules)
-    import contextlib
-    run_ctx = torch.cuda.stream(torch.cuda.Stream(device=device)) if os.environ.get("MCVC_BENCH_STREAM") == "1" else contextlib.nullcontext()
-    run_ctx.__enter__()
     first = None
     for i in range(warmup):
         engine.step(*batches[i % len(batches)])
@@ -316,7 +315,9 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
     t0 = time.perf_counter()
     for i in range(steps):
         engine.step(*batches[(warmup + i) % len(batches)])
-        engine.losses()                    # the reference reads both losses every iteration (train.py:303)
+        # the reference reads both losses every iteration (train.py:303).  So do we; with the pipelined step they are the losses of the
+        # last COMPLETE iteration (the previous one: its discriminator phase runs beside this iteration's generator phase)
+        engine.losses(lagged=True)
     engine.flush()                         # ... and the last one to the timed region: exactly K complete iterations
     if world > 1:
         dist.barrier()
@@ -350,6 +351,8 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
                 k, ms, fl, by = buf[4 * i:4 * i + 4]
                 fh.write("%4d %-24s %9.4f ms %10.4f GF %9.3f MB %8.2f TF/s %8.1f GB/s\n" % (
                     i, L.mcvc_trace_kind_name(int(k)).decode(), ms, fl / 1e9, by / 1e6, fl / 1e9 / max(ms, 1e-6), by / 1e6 / max(ms, 1e-6)))
+    schedule = {"grouped_launches": bool(engine._use_grouped()), "pipelined": bool(engine._use_pipeline()), "queue_probe": getattr(engine, "queue_probe", None),
+                "loss_readback": "both losses every iteration; with the pipelined step those of the last complete iteration (one step behind)"}
     del engine, nets
     torch.cuda.empty_cache()
     if rank != 0:
@@ -367,7 +370,7 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
                    "global_batch": world * B, "parallelism": "dp%d" % world},
         "mel_frames_per_s": sample_iters * T,
         "step_mfma_fraction": sample_iters * ALG_GFLOP_PER_SAMPLE_ITER / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world),
-        "losses_finite": finite, "last_losses": final, "n_batches": len(batches), "deterministic": bool(args.deterministic),
+        "losses_finite": finite, "last_losses": final, "schedule": schedule, "n_batches": len(batches), "deterministic": bool(args.deterministic),
     }
     if config_id:
         res["config_id"] = config_id

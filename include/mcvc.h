@@ -172,6 +172,11 @@ int mcvc_loss_combine(const float* pairs, int n, const int* loss_dst, const int*
 /* ---- optimizer: torch.optim.Adam(betas, eps, weight_decay=0) on a flat buffer (train.py:119-122) */
 int mcvc_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                    float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/*      The same step on the gradient g + g2 (g2 nullable: a second buffer that independent backward passes accumulated into, so that they need
+ *      not be ordered against the passes that write g), optionally clearing the gradient buffer(s) behind the read (zero_grads != 0: what
+ *      reset_grad / zero_grad, train.py:157-161, does before the next accumulation -- here without a separate pass over the buffers).   */
+int mcvc_adam_step2(float* p, float* g, float* g2, int zero_grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                    float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
 int mcvc_axpy(float* y, const float* x, float alpha, long long n, void* stream);
 
 /* ---- on-device input pipeline: replaces VCDataset.__getitem__ + DataLoader collate + 4 H2D copies per iteration

@@ -10,6 +10,6 @@ int mcvc_l1_loss_launch(const float* a, const float* b, long long n, float weigh
 int mcvc_lsgan_loss_launch(const float* d, long long n, float target, float weight, float* loss_slot, float* term_slot,
                            float* grad_logit, hipStream_t s);
 int mcvc_loss_combine_launch(const float* pairs, int n, const int* loss_dst, const int* term_dst, float* slots, hipStream_t s);
-int mcvc_adam_launch(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+int mcvc_adam_launch(float* p, float* g, float* g2, int zero_grads, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
                      int step, float grad_scale, hipStream_t s);
 int mcvc_axpy_launch(float* y, const float* x, float alpha, long long n, hipStream_t s);

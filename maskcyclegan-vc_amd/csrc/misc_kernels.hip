@@ -192,12 +192,15 @@ __global__ void loss_combine_kernel(const Twin<LossCombineKArgs> tw)
 
 // torch.optim.Adam single-tensor math on a flat buffer (weight_decay 0, amsgrad off):
 //   m = lerp(m, g, 1-b1); v = b2*v + (1-b2) g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
-struct AdamKArgs { float* p; const float* g; float* m; float* v; long long n; float lr; float b1; float b2; float eps; float bc1; float sqrt_bc2; float grad_scale; };
+struct AdamKArgs { float* p; float* g; float* m; float* v; long long n; float lr; float b1; float b2; float eps; float bc1; float sqrt_bc2; float grad_scale;
+                   float* g2; int zero; };      // g2 (nullable): a second gradient buffer, added to g; zero: clear the gradient buffer(s) behind the read
 __global__ void __launch_bounds__(256) adam_kernel(const Twin<AdamKArgs> tw)
 {
     const AdamKArgs& ka_ = tw.v[blockIdx.z];
     float* __restrict__ p = ka_.p;
-    const float* __restrict__ g = ka_.g;
+    float* __restrict__ g = ka_.g;
+    float* __restrict__ g2 = ka_.g2;
+    const int zero = ka_.zero;
     float* __restrict__ m = ka_.m;
     float* __restrict__ v = ka_.v;
     long long n = ka_.n;
@@ -213,6 +216,11 @@ __global__ void __launch_bounds__(256) adam_kernel(const Twin<AdamKArgs> tw)
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         float4 gg = reinterpret_cast<const float4*>(g)[i];
+        if (g2) { const float4 h = reinterpret_cast<const float4*>(g2)[i]; gg.x += h.x; gg.y += h.y; gg.z += h.z; gg.w += h.w; }
+        if (zero) {
+            reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g2) reinterpret_cast<float4*>(g2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         float4 mm = reinterpret_cast<float4*>(m)[i];
         float4 vv = reinterpret_cast<float4*>(v)[i];
         float* pf = reinterpret_cast<float*>(&pp);
@@ -235,7 +243,8 @@ __global__ void __launch_bounds__(256) adam_kernel(const Twin<AdamKArgs> tw)
     const long long base = n4 << 2;
     const long long t = base + (long long)blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x == 0 && t < n) {
-        const float gr = g[t] * grad_scale;
+        const float gr = (g[t] + (g2 ? g2[t] : 0.f)) * grad_scale;
+        if (zero) { g[t] = 0.f; if (g2) g2[t] = 0.f; }
         const float mn = m[t] + (gr - m[t]) * (1.0f - b1);
         const float vn = v[t] * b2 + (1.0f - b2) * gr * gr;
         m[t] = mn; v[t] = vn;
@@ -313,15 +322,16 @@ int mcvc_loss_combine_launch(const float* pairs, int n, const int* loss_dst, con
     return (int)hipGetLastError();
 }
 
-int mcvc_adam_launch(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+int mcvc_adam_launch(float* p, float* g, float* g2, int zero_grads, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
                      int step, float grad_scale, hipStream_t s)
 {
-    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return MCVC_ERR_INVALID;
+    if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)g2 | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return MCVC_ERR_INVALID;
     // bias corrections in double like torch.optim.Adam's python scalars, then rounded once
     const double bc1 = 1.0 - pow((double)b1, (double)step);
     const double bc2 = 1.0 - pow((double)b2, (double)step);
-    TraceScope ts(K_ADAM, s, 0.0, 28.0 * n);
-    mcvc_launch(adam_kernel, dim3(ew_blocks(n >> 2, 256)), dim3(256), 0, s, AdamKArgs{p, g, m, v, n, (float)((double)lr / bc1), b1, b2, eps, 1.0f, (float)sqrt(bc2), grad_scale});
+    TraceScope ts(K_ADAM, s, 0.0, (28.0 + (g2 ? 4.0 : 0.0) + (zero_grads ? (g2 ? 8.0 : 4.0) : 0.0)) * n);
+    mcvc_launch(adam_kernel, dim3(ew_blocks(n >> 2, 256)), dim3(256), 0, s,
+                AdamKArgs{p, g, m, v, n, (float)((double)lr / bc1), b1, b2, eps, 1.0f, (float)sqrt(bc2), grad_scale, g2, zero_grads});
     return (int)hipGetLastError();
 }
 

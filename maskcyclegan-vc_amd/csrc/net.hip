@@ -1870,7 +1870,13 @@ int mcvc_lsgan_loss(const float* d, long long n, float target, float weight, flo
 int mcvc_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
                    float eps, int step, float grad_scale, void* stream)
 {
-    return mcvc_adam_launch(p, g, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream);
+    return mcvc_adam_launch(p, const_cast<float*>(g), nullptr, 0, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream);
+}
+
+int mcvc_adam_step2(float* p, float* g, float* g2, int zero_grads, float* exp_avg, float* exp_avg_sq, long long n, float lr, float beta1, float beta2,
+                    float eps, int step, float grad_scale, void* stream)
+{
+    return mcvc_adam_launch(p, g, g2, zero_grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream);
 }
 
 int mcvc_draw_batch(const float* bank_A, const int* offs_A, int n_A, long long frames_A, const float* bank_B, const int* offs_B, int n_B,

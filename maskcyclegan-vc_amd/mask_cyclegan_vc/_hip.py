@@ -64,6 +64,7 @@ _SIGS = {
     "mcvc_lsgan_loss": (c_int, [c_void_p, c_longlong, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcvc_loss_combine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcvc_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
+    "mcvc_adam_step2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
     "mcvc_draw_batch": (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_int,
                                 ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcvc_axpy": (c_int, [c_void_p, c_void_p, c_float, c_longlong, c_void_p]),

@@ -75,6 +75,21 @@ class _FlatGroup:
                 off += _align4(n)
             self.views.append(vs); self.grad_views.append(gs)
         self.numel = total
+        self.grad2 = None
+        self.offsets = []                 # flat-buffer offset of every tensor, per module
+        off = 0
+        for ps in param_lists:
+            o = []
+            for p in ps:
+                o.append(off)
+                off += _align4(p.numel())
+            self.offsets.append(o)
+
+    def second_grad_views(self):
+        """A second gradient buffer with the same layout (backward passes that must not race with the writers of ``grad``)."""
+        if self.grad2 is None:
+            self.grad2 = torch.zeros_like(self.grad)
+        return [[self.grad2[o:o + g.numel()].view(g.shape) for o, g in zip(os_, gs)] for os_, gs in zip(self.offsets, self.grad_views)]
 
 
 class TrainEngine:
@@ -105,6 +120,14 @@ class TrainEngine:
             self._p_tab[n] = ptr_table(ps)
             it = iter(gv)
             self._g_tab[n] = ptr_table([None if i in _DEAD else next(it) for i in range(len(ps))])
+        self._g_tab2 = {}
+        for n, gv in zip(G_NAMES, self.g_group.second_grad_views()):
+            self._g_tab2[n] = ptr_table(gv)
+        # flat-buffer range of each discriminator's live parameters (the discriminator pairs are updated separately when pipelined)
+        self._d_ranges = {}
+        d_off = [o[0] for o in self.d_group.offsets] + [self.d_group.numel]
+        for i, n in enumerate(D_NAMES):
+            self._d_ranges[n] = (d_off[i], d_off[i + 1])
         # ---- packed weights
         self.packed = {n: torch.zeros(L.mcvc_gen_packed_floats(), device=dev) for n in G_NAMES}
         self.packed.update({n: torch.zeros(L.mcvc_disc_packed_floats(), device=dev) for n in D_NAMES})
@@ -118,7 +141,7 @@ class TrainEngine:
         # kernels are latency-bound and far from filling 256 CUs, so the two chains run as two "lanes" on two HIP
         # streams (lane 0 = the caller's stream) and overlap on the chip; join points are stream-event waits.
         self.concurrent = True
-        self._sides = [torch.cuda.Stream(device=dev) for _ in range(3)]
+        self._sides = self._pick_side_streams(dev)
         # inside a backward pass the weight-gradient kernels are off the critical path: one auxiliary stream per lane
         self._aux = [torch.cuda.Stream(device=dev) for _ in range(4)]
         self.aux_wgrad = os.environ.get("MCVC_AUX_WGRAD", "1") != "0"
@@ -156,6 +179,18 @@ class TrainEngine:
         # which the grouped schedule is used (large batches fill the chip per network anyway).
         self.grouped = os.environ.get("MCVC_GROUPED", "1") != "0"
         self.grouped_max_b = int(os.environ.get("MCVC_GROUPED_MAX_B", "1024"))
+        # ... with the identity passes G(real, ones) as their own chain (forward, loss, backward on lane 2, beside the translation ->
+        # cycle chain) instead of inside batched 2B passes: they depend on nothing else, and their weight gradients are ordered in front
+        # of the cycle backward by one event
+        self.grouped_ident = os.environ.get("MCVC_GROUPED_IDENT", "1") != "0"
+        # Pipelined step (needs the grouped schedule): iteration t's discriminator phase is issued together with iteration t+1's
+        # generator phase, as one task graph (_pipelined_step); MCVC_PIPELINE=0 keeps the two phases of an iteration back to back.
+        self.pipelined = os.environ.get("MCVC_PIPELINE", "1") != "0"
+        self._pending_D = None                  # (input set, discriminator lr) of the iteration whose discriminator phase is still to run
+        self.slots_done = torch.zeros(2 * _BLOCK, device=dev)          # loss slots of the last COMPLETE iteration
+        self._done_host = torch.zeros(2 * _BLOCK).pin_memory()
+        self._done_event = torch.cuda.Event()
+        self._done_valid = False
         self.split_d_min_batch = int(os.environ.get("MCVC_SPLIT_D_MIN_BATCH", "4"))
         self._timeline = None
         self._pack_stream = torch.cuda.Stream(device=dev)
@@ -190,6 +225,56 @@ class TrainEngine:
         self.reducer.broadcast_(self.d_group.flat)
         self.repack(G_NAMES + D_NAMES)
 
+    # ---- lanes on distinct hardware queues -----------------------------------------------------------------------------
+    def _pick_side_streams(self, dev, want=3):
+        """Three side streams that share a hardware queue neither with each other nor with the caller's stream.
+
+        ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and two streams on one queue serialise: a
+        kernel on one waits for everything queued earlier on the other -- a false dependency between lanes that the task graph does
+        not contain (tools/queue_probe.py prints the classes; PyTorch's pooled streams land on the queues in no simple order).  So the
+        lanes are CHOSEN: candidates are probed against the streams already picked (a ~0.25 ms spin on one, a tiny kernel on the other;
+        the tiny kernel finishing only with the spin = same queue) and kept when independent.  MCVC_STREAM_PROBE=0: take the first
+        three pool streams as before."""
+        cands = [torch.cuda.Stream(device=dev) for _ in range(16)]
+        if os.environ.get("MCVC_STREAM_PROBE", "1") == "0":
+            return cands[:want]
+        main = torch.cuda.current_stream(dev)
+        x = torch.zeros(256, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        spin = 2_000_000
+        torch.cuda.synchronize(dev)
+        e0.record(); torch.cuda._sleep(spin); e1.record(); torch.cuda.synchronize(dev)
+        spin = max(1000, int(spin * 0.25 / max(e0.elapsed_time(e1), 1e-3)))
+        e0.record(); torch.cuda._sleep(spin); e1.record(); torch.cuda.synchronize(dev)
+        spin_ms = e0.elapsed_time(e1)
+
+        def delays(a, b):          # does a spin on stream a hold back a kernel queued afterwards on stream b?
+            torch.cuda.synchronize(dev)
+            start, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with torch.cuda.stream(a):
+                start.record(a)
+                torch.cuda._sleep(spin)
+            with torch.cuda.stream(b):
+                x.add_(1.0)
+                done.record(b)
+            torch.cuda.synchronize(dev)
+            return start.elapsed_time(done) > 0.6 * spin_ms
+        picked = []
+        for c in cands:
+            # (work queued on ANY stream after null-stream work waits for it -- the legacy default-stream rule -- so against a null main
+            # stream only the other direction identifies a shared queue)
+            indep = delays(c, main) is False and (main.cuda_stream == 0 or not delays(main, c))
+            indep = indep and all(not delays(c, p) and not delays(p, c) for p in picked)
+            if indep:
+                picked.append(c)
+                if len(picked) == want:
+                    break
+        self.queue_probe = {"independent_lanes": len(picked), "spin_ms": spin_ms, "main_is_null_stream": main.cuda_stream == 0}
+        for c in cands:                # fewer than `want` independent queues (GPU_MAX_HW_QUEUES < 4): fill up with what there is
+            if len(picked) < want and c not in picked:
+                picked.append(c)
+        return picked
+
     # ---- activations / workspaces: static shapes per batch size (graph-capturable), created on first use -----------
     def _use(self, B):
         """Bind the workspace set for per-GPU batch size ``B`` (the reference's DataLoader has drop_last=False, so the
@@ -199,6 +284,8 @@ class TrainEngine:
         every op is per-sample).  Generator phase: G_A2B on [real_A|mask_A ; real_B|ones] and G_B2A on
         [real_B|mask_B ; real_A|ones] (translation + identity), then the two cycle passes.  Discriminator phase:
         each discriminator sees [real ; generated] in one pass."""
+        if getattr(self, "_pending_D", None) is not None:
+            self.flush()                    # a pending discriminator phase belongs to the old batch size's buffers
         if B > self._max_B:                 # a larger batch than any so far may leave the fused-trunk regime: full re-pack
             self._max_B = B
             if hasattr(self, "packed"):
@@ -217,9 +304,11 @@ class TrainEngine:
                 g_stash1=[f(L.mcvc_gen_stash_floats(B, T)) for _ in range(2)],       # cycle passes
                 d_stash1=[f(L.mcvc_disc_stash_floats(B, T)) for _ in range(4)],
                 d_stash2=[f(L.mcvc_disc_stash_floats(B2, T)) for _ in range(4)],
-                g_scratch=[f(max(L.mcvc_gen_scratch_floats(B, T), L.mcvc_gen_scratch_floats(B2, T))) for _ in range(2)],   # one per lane
+                g_stash3=[f(L.mcvc_gen_stash_floats(B, T)) for _ in range(2)],       # identity passes as their own chain (grouped schedule)
+                g_scratch=[f(max(L.mcvc_gen_scratch_floats(B, T), L.mcvc_gen_scratch_floats(B2, T))) for _ in range(6)],   # one per concurrent pass
                 d_scratch=[f(max(L.mcvc_disc_scratch_floats(B, T), L.mcvc_disc_scratch_floats(B2, T))) for _ in range(4)],
-                static_in=[f(B, 80, T) for _ in range(4)],                             # real_A, mask_A, real_B, mask_B
+                static_sets=[[f(B, 80, T) for _ in range(4)] for _ in range(2)],       # real_A, mask_A, real_B, mask_B (x2: pipelined step)
+                g_stashD=[f(L.mcvc_gen_stash_floats(B, T)) for _ in range(2)],         # the discriminator phase's generator forwards, when pipelined
                 in_A2B=mel2(), in_B2A=mel2(),                                          # [real_A ; real_B] and [real_B ; real_A]
                 mask_A2B=torch.ones(B2, 80, T, device=dev), mask_B2A=torch.ones(B2, 80, T, device=dev),   # [mask ; ones]
                 out_A2B=mel2(), out_B2A=mel2(),                                        # [fake_B ; identity_B], [fake_A ; identity_A]
@@ -236,6 +325,8 @@ class TrainEngine:
         self.B = B
         for k, v in ws.items():
             setattr(self, k, v)
+        self._cur_set = 0
+        self.static_in = self.static_sets[0]
 
     # ---- thin call helpers ------------------------------------------------------------------------
     def _repack1(self, n, sets=3):
@@ -299,7 +390,13 @@ class TrainEngine:
         only = os.environ.get("MCVC_AUX_LANES")            # experiment knob: comma list of lanes that get an auxiliary stream
         if only is not None and str(lane) not in only.split(","):
             return None
-        return ctypes.c_void_p(self._aux[lane].cuda_stream) if self.aux_wgrad else None
+        if not self.aux_wgrad:
+            return None
+        if self._use_grouped():
+            # grouped schedules: the generator chain's weight gradients (lane 0, the two backward rounds) run on lane 3's stream, idle by
+            # then and on a hardware queue of its own; the identity chain (aux lane 1) keeps its weight gradients on its own stream
+            return ctypes.c_void_p(self._sides[2].cuda_stream) if lane == 0 else None
+        return ctypes.c_void_p(self._aux[lane].cuda_stream)
 
     def _pass(self, key, fn):
         """Run one network pass (a library call with static arguments): eagerly the first two times (lazy kernel attributes, event pool),
@@ -336,15 +433,16 @@ class TrainEngine:
                    lambda: check(self.L.mcvc_gen_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(mask), ptr(out), ptr(stash),
                                                          ptr(sc), sc.numel(), nb, self.T, stream()), "gen_forward"))
 
-    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0, milestones=False, aux_lane=None, ms_of=None):
+    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0, milestones=False, aux_lane=None, ms_of=None, second=False):
         """``lane`` picks the scratch buffer; ``aux_lane`` (default: the same) the auxiliary weight-gradient stream -- the two halves of a
         grouped pass use different scratch buffers but the same streams and milestone events (``ms_of``)."""
         sc = self.g_scratch[lane]
         ms = self._ms[ms_of or name][1] if milestones else None
         aux = self._aux_ptr(lane if aux_lane is None else aux_lane)
+        gtab = self._g_tab2[name] if second else self._g_tab[name]          # second: weight gradients into the second buffer
         self._pass(("Gb", name, 0 if mask is None else mask.data_ptr(), dout.data_ptr(), 0 if dx is None else dx.data_ptr(), acc, stash.data_ptr(),
-                    nb, lane, bool(milestones), self.aux_wgrad),
-                   lambda: check(self.L.mcvc_gen_backward_overlap(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name], ptr(mask), ptr(dout),
+                    nb, lane, bool(milestones), self.aux_wgrad, second),
+                   lambda: check(self.L.mcvc_gen_backward_overlap(self._p_tab[name], ptr(self.packed[name]), gtab, ptr(mask), ptr(dout),
                                                                   ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(),
                                                                   aux, ms), "gen_backward"))
 
@@ -387,6 +485,13 @@ class TrainEngine:
         for n in (G_NAMES if grp is self.g_group else D_NAMES):
             self.nets[n]._packed_version = None
             self.nets[n]._bf16_version = None
+
+    def _adam_range(self, grp, lo, hi, lr, step, second=False):
+        """Adam on ``[lo, hi)`` of a flat group with step count ``step``, clearing the gradients it has consumed (the next iteration
+        accumulates into clean buffers without a separate memset); ``second``: the gradient is grad + grad2."""
+        g2 = grp.grad2[lo:hi] if (second and grp.grad2 is not None) else None
+        check(self.L.mcvc_adam_step2(ptr(grp.flat[lo:hi]), ptr(grp.grad[lo:hi]), ptr(g2), 1, ptr(grp.exp_avg[lo:hi]), ptr(grp.exp_avg_sq[lo:hi]),
+                                     hi - lo, float(lr), self.betas[0], self.betas[1], self.eps, step, self.reducer.grad_scale, stream()), "adam_step2")
 
     def _adam_generator(self, name, step, lr):
         """Adam on ONE generator's slice of the flat buffer (both slices of an iteration share the step count)."""
@@ -501,21 +606,15 @@ class TrainEngine:
     def _use_grouped(self):
         return self.grouped and self.B <= self.grouped_max_b and not self.use_graphs and not self.pass_graphs
 
-    def generator_phase_grouped(self, real_A, mask_A, real_B, mask_B, fuse_update=False):
-        """train.py:195-242 with the two generators (and each discriminator pair) in grouped launches: the same dataflow as
-        ``generator_phase``, two lanes instead of four.  Lane 0: both translation + identity passes, both cycle passes, the second-step
-        discriminators, both backward rounds, the update.  Lane 1: the first-step adversarial pair D_A(fake_A) | D_B(fake_B), which needs
-        only the translated batches and runs beside the cycle forwards."""
+    # ---- grouped schedule: the two phases as parts that the plain and the pipelined step assemble into task graphs ----------------
+    def _g_parts(self, inp, fuse_update, own_d_update=True, ident_second=False, zeroing_update=False):
+        """Closures of the generator phase (train.py:195-242) in grouped launches.  ``own_d_update``: the first-step adversarial pair
+        completes a deferred discriminator update / waits for the asynchronous re-pack itself (plain step); the pipelined step orders
+        the discriminators' update in front of the adversarial pairs through the task graph instead."""
+        real_A, mask_A, real_B, mask_B = inp
         B, B2 = self.B, 2 * self.B
         m = self.mel
         sc = self.sched
-        self.slots[:_BLOCK].zero_()
-        if self._g_grad_clean:
-            self._g_grad_clean = False
-        else:
-            self.g_group.grad.zero_()
-        torch._foreach_copy_([self.in_A2B[:B], self.in_A2B[B:], self.in_B2A[:B], self.in_B2A[B:], self.mask_A2B[:B], self.mask_B2A[:B]],
-                             [real_A, real_B, real_B, real_A, mask_A, mask_B])
         fake_B, identity_B = self.out_A2B[:B], self.out_A2B[B:]
         fake_A, identity_A = self.out_B2A[:B], self.out_B2A[B:]
         g_fake_B, g_identity_B = self.gout_A2B[:B], self.gout_A2B[B:]
@@ -524,20 +623,52 @@ class TrainEngine:
         cl, il = sc.cycle_loss_lambda, sc.identity_loss_lambda
         A2B, B2A = G_NAMES
         ov = self.overlap_g_reduce
+        ident = self.grouped_ident
+        g_lr = sc.g_opt_lr
+        P = {}
+
+        def pre(zero_grads=True):              # on the caller's stream, before the lanes fork
+            self.slots[:_BLOCK].zero_()
+            if zero_grads:
+                if self._g_grad_clean:
+                    self._g_grad_clean = False
+                else:
+                    self.g_group.grad.zero_()
+            torch._foreach_copy_([self.in_A2B[:B], self.in_A2B[B:], self.in_B2A[:B], self.in_B2A[B:], self.mask_A2B[:B], self.mask_B2A[:B]],
+                                 [real_A, real_B, real_B, real_A, mask_A, mask_B])     # one launch; the masks' second halves stay all-ones
 
         def fwd2(ln):                                                                                       # :203, :205, :207-210
-            self._twin(lambda: self._G(A2B, self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], B2, 0),
-                       lambda: self._G(B2A, self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], B2, 1))
+            nb = B if ident else B2                    # (the halves of the batched buffers are contiguous: translation first, identity second)
+            self._twin(lambda: self._G(A2B, self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], nb, 0),
+                       lambda: self._G(B2A, self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], nb, 1))
+
+        def ident_fwd(ln):                             # identity_B = G_A2B(real_B, ones), identity_A = G_B2A(real_A, ones): forward, loss
+            self._twin(lambda: self._G(A2B, self.in_A2B[B:], self.mask_A2B[B:], identity_B, self.g_stash3[0], B, 2),
+                       lambda: self._G(B2A, self.in_B2A[B:], self.mask_B2A[B:], identity_A, self.g_stash3[1], B, 3))
+            self._twin(lambda: self._l1(identity_B, real_B, il, g_identity_B, 3), lambda: self._l1(identity_A, real_A, il, g_identity_A, 2))   # :223-224
+
+        def ident_bwd(ln):
+            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B[B:], g_identity_B, None, 0, self.g_stash3[0], B, 2, aux_lane=1, second=ident_second),
+                       lambda: self._G_bwd(B2A, self.mask_B2A[B:], g_identity_A, None, 0, self.g_stash3[1], B, 3, aux_lane=1, second=ident_second))
+
+        def ident_chain(ln):
+            ident_fwd(ln)
+            ident_bwd(ln)
 
         def cycle_half(k):
             if k == 0:
                 self._G(B2A, fake_B, None, m["cycle_A"], self.g_stash1[0], B, 0)                           # :204 (mask of ones)
                 self._l1(m["cycle_A"], real_A, cl, m["g_cycle_A"], 0)                                       # :219
-                self._l1(identity_B, real_B, il, g_identity_B, 3)                                           # :224
+                if not ident:
+                    self._l1(identity_B, real_B, il, g_identity_B, 3)                                       # :224
             else:
                 self._G(A2B, fake_A, None, m["cycle_B"], self.g_stash1[1], B, 1)                           # :206
                 self._l1(m["cycle_B"], real_B, cl, m["g_cycle_B"], 1)                                       # :220
-                self._l1(identity_A, real_A, il, g_identity_A, 2)                                           # :223
+                if not ident:
+                    self._l1(identity_A, real_A, il, g_identity_A, 2)                                       # :223
+
+        def cycle(ln):
+            self._twin(lambda: cycle_half(0), lambda: cycle_half(1))
 
         def adv_half(name, i, x, gx, acc):
             self._D(name, x, do[i], ds[i], B, i)                                                            # :211-216
@@ -545,15 +676,17 @@ class TrainEngine:
             self._D_bwd(name, dl[i], gx, acc, ds[i], False, B, i)          # discriminators contribute data-gradients only
 
         def adv1(ln):
-            self._finish_d_update()            # data parallel: the D all-reduce of the previous iteration hides behind the generator forwards
-            self._wait_d_pack()                # discriminator weights changed at the end of the previous iteration
+            if own_d_update:
+                self._finish_d_update()        # data parallel: the D all-reduce of the previous iteration hides behind the generator forwards
+                self._wait_d_pack()            # discriminator weights changed at the end of the previous iteration
             self._twin(lambda: adv_half("discriminator_A", 0, fake_A, g_fake_A, 0), lambda: adv_half("discriminator_B", 1, fake_B, g_fake_B, 0))
-            if fuse_update and not self._d_grad_clean:
+            if own_d_update and fuse_update and not self._d_grad_clean:
                 self.d_group.grad.zero_()      # free once their Adam step is queued: cleared here, on the side lane (99 MB memset)
                 self._d_grad_clean = True
 
         def adv2(ln):
-            self._wait_d_pack()
+            if own_d_update:
+                self._wait_d_pack()
             self._twin(lambda: adv_half("discriminator_A2", 2, m["cycle_A"], m["g_cycle_A"], 1),
                        lambda: adv_half("discriminator_B2", 3, m["cycle_B"], m["g_cycle_B"], 1))
 
@@ -562,10 +695,9 @@ class TrainEngine:
                        lambda: self._G_bwd(A2B, None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, 1, aux_lane=0))
 
         def bwd_final(ln):      # the last pass over each generator; its gradient ranges become final one after the other (milestone events)
-            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2, 0, ov, aux_lane=0, ms_of=A2B),
-                       lambda: self._G_bwd(B2A, self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2, 1, ov, aux_lane=0, ms_of=A2B))
-        if fuse_update:
-            g_lr = sc.g_opt_lr
+            nb = B if ident else B2
+            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], nb, 0, ov, aux_lane=0, ms_of=A2B),
+                       lambda: self._G_bwd(B2A, self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], nb, 1, ov, aux_lane=0, ms_of=A2B))
 
         def queue_reduce(ln):
             # data parallel: range k of BOTH generators is final at milestone k of the grouped pass; same collective order on every rank
@@ -579,40 +711,75 @@ class TrainEngine:
 
         def update(ln):
             self.reducer.wait(self.device)             # (no-op on one GPU)
-            self._adam(self.g_group, g_lr)             # one launch over both generators
+            if zeroing_update:                         # (pipelined step: the gradients are cleared as they are consumed)
+                self.g_group.step += 1
+                self._adam_range(self.g_group, 0, self.g_group.numel, g_lr, self.g_group.step, second=ident_second)
+                for n in G_NAMES:
+                    self.nets[n]._packed_version = None
+                    self.nets[n]._bf16_version = None
+            else:
+                self._adam(self.g_group, g_lr)         # one launch over both generators
             self._twin(lambda: self._repack1(A2B, 1), lambda: self._repack1(B2A, 1))
-        self._run_tasks([
-            (0, fwd2, (), "g"),
-            (0, lambda ln: self._twin(lambda: cycle_half(0), lambda: cycle_half(1)), (), None),
-            (1, adv1, ("g",), "d1"),
-            (0, adv2, (), None),
-            (0, bwd_cycle, ("d1",), None),
-            (0, bwd_final, (), "f"),
-        ] + ([(1, queue_reduce, (), None)] if (fuse_update and ov) else [])
-          + ([(0, update, (), None)] if fuse_update else []))
-        self._g_fwd_packed = bool(fuse_update)
-        self._d_pack_event = None
-        self._combine(0, self._comb_g)
 
-    def discriminator_phase_grouped(self, real_A, mask_A, real_B, mask_B):
-        """train.py:247-299, grouped like ``generator_phase_grouped``: lane 0 runs both generators' forwards (translation, then cycle) and
-        the second-step discriminator pair, lane 1 refreshes the backward-only weight copies and runs D_A | D_B."""
+        def post():
+            self._g_fwd_packed = bool(fuse_update)
+            self._combine(0, self._comb_g)
+        P.update(pre=pre, fwd2=fwd2, ident_chain=ident_chain, ident_fwd=ident_fwd, ident_bwd=ident_bwd, cycle=cycle, adv1=adv1, adv2=adv2, bwd_cycle=bwd_cycle, bwd_final=bwd_final,
+                 queue_reduce=queue_reduce, update=update, post=post, ident=ident, ov=ov)
+        return P
+
+    def generator_phase_grouped(self, real_A, mask_A, real_B, mask_B, fuse_update=False):
+        """train.py:195-242 with the two generators (and each discriminator pair) in grouped launches: the same dataflow as
+        ``generator_phase`` on three lanes.  Lane 0: both translation passes, both cycle passes, the second-step discriminators, both
+        backward rounds, the update.  Lane 1: the first-step adversarial pair D_A(fake_A) | D_B(fake_B), which needs only the translated
+        batches and runs beside the cycle forwards.  Lane 2: the identity chain (forward, loss, backward), which needs nothing; its
+        weight gradients add into the same tensors as the other backward passes', so it is complete ("i") before the first of them."""
+        # with the update inside the phase, the identity chain's weight gradients go to the second gradient buffer and Adam consumes the
+        # sum, clearing both (same arithmetic as the pipelined step, which runs that chain beside the backward rounds)
+        second = bool(fuse_update) and self.reducer.world == 1 and self.grouped_ident
+        p = self._g_parts((real_A, mask_A, real_B, mask_B), fuse_update, ident_second=second, zeroing_update=bool(fuse_update))
+        p["pre"]()
+        ident, ov = p["ident"], p["ov"]
+        self._run_tasks([
+            (0, p["fwd2"], (), "g"),
+        ] + ([(2, p["ident_chain"], (), "i")] if ident else []) + [
+            (0, p["cycle"], (), None),
+            (1, p["adv1"], ("g",), "d1"),
+            (0, p["adv2"], (), None),
+            (0, p["bwd_cycle"], ("d1", "i") if ident else ("d1",), None),
+            (0, p["bwd_final"], (), "f"),
+        ] + ([(1, p["queue_reduce"], (), None)] if (fuse_update and ov) else [])
+          + ([(0, p["update"], (), None)] if fuse_update else []))
+        self._d_pack_event = None
+        if fuse_update:
+            self._g_grad_clean = True          # (cleared by the Adam launch that consumed them)
+        p["post"]()
+
+    def _d_parts(self, inp, gi=0):
+        """Closures of the discriminator phase (train.py:247-299) in grouped launches.  ``gi``: index of the (stash, scratch) pair its two
+        generator forwards use -- 0 = the cycle passes' (plain step: the phases run one after the other), 2 = their own (pipelined step:
+        they run beside the next iteration's generator phase)."""
+        real_A, mask_A, real_B, mask_B = inp
         B, B2 = self.B, 2 * self.B
-        self.slots[_BLOCK:].zero_()
-        if self._d_grad_clean:
-            self._d_grad_clean = False
-        else:
-            self.d_group.grad.zero_()
         di = self.d_in
         gen_A, gen_B = di["discriminator_A"][B:], di["discriminator_B"][B:]
         cyc_A, cyc_B = di["discriminator_A2"][B:], di["discriminator_B2"][B:]
-        torch._foreach_copy_([di["discriminator_A"][:B], di["discriminator_A2"][:B], di["discriminator_B"][:B], di["discriminator_B2"][:B]],
-                             [real_A, real_A, real_B, real_B])
         do, dl, ds = self.dout2, self.dlogit2, self.d_stash2
         idx = {n: i for i, n in enumerate(D_NAMES)}
         A2B, B2A = G_NAMES
-        packed = self._g_fwd_packed
-        self._g_fwd_packed = False
+        gst = self.g_stash1 if gi == 0 else self.g_stashD
+        s0, s1 = (0, 1) if gi == 0 else (4, 5)
+        P = {}
+
+        def pre(zero_grads=True):
+            self.slots[_BLOCK:].zero_()
+            if zero_grads:
+                if self._d_grad_clean:
+                    self._d_grad_clean = False
+                else:
+                    self.d_group.grad.zero_()
+            torch._foreach_copy_([di["discriminator_A"][:B], di["discriminator_A2"][:B], di["discriminator_B"][:B], di["discriminator_B2"][:B]],
+                                 [real_A, real_A, real_B, real_B])
 
         def disc_full(name):
             i = idx[name]
@@ -633,41 +800,167 @@ class TrainEngine:
             return lambda ln: self._twin(lambda: fn(a, *args), lambda: fn(b, *args))
 
         def gen_fwd(ln):
-            if not packed:                     # phase called on its own: full refresh first
-                self._twin(lambda: self._repack1(A2B), lambda: self._repack1(B2A))
-            self._twin(lambda: self._G(A2B, real_A, mask_A, gen_B, self.g_stash1[0], B, 0),                 # :267 generated_B
-                       lambda: self._G(B2A, real_B, mask_B, gen_A, self.g_stash1[1], B, 1))                 # :259 generated_A
+            self._twin(lambda: self._G(A2B, real_A, mask_A, gen_B, gst[0], B, s0),                          # :267 generated_B
+                       lambda: self._G(B2A, real_B, mask_B, gen_A, gst[1], B, s1))                          # :259 generated_A
 
         def cycles(ln):
-            self._twin(lambda: self._G(B2A, gen_B, None, cyc_A, self.g_stash1[0], B, 0),                    # :271 cycled_A
-                       lambda: self._G(A2B, gen_A, None, cyc_B, self.g_stash1[1], B, 1))                    # :263 cycled_B
+            self._twin(lambda: self._G(B2A, gen_B, None, cyc_A, gst[0], B, s0),                             # :271 cycled_A
+                       lambda: self._G(A2B, gen_A, None, cyc_B, gst[1], B, s1))                             # :263 cycled_B
 
-        def refresh(ln):                       # the backward-only copies, beside the generator forwards; the generator gradients are free
+        def repack_full(ln):
+            self._twin(lambda: self._repack1(A2B), lambda: self._repack1(B2A))
+
+        def repack_bwd(ln):                    # the backward-only copies (the generator update refreshed the forward ones only)
+            self._twin(lambda: self._repack1(A2B, 2), lambda: self._repack1(B2A, 2))
+
+        def post():
+            self._combine(8, self._comb_d)
+        P.update(pre=pre, gen_fwd=gen_fwd, cycles=cycles, repack_full=repack_full, repack_bwd=repack_bwd, post=post,
+                 full1=pair(disc_full, "discriminator_A", "discriminator_B"), full2=pair(disc_full, "discriminator_A2", "discriminator_B2"),
+                 real1=pair(disc_half, "discriminator_A", "discriminator_B", False), real2=pair(disc_half, "discriminator_A2", "discriminator_B2", False),
+                 fake1=pair(disc_half, "discriminator_A", "discriminator_B", True), fake2=pair(disc_half, "discriminator_A2", "discriminator_B2", True))
+        return P
+
+    def discriminator_phase_grouped(self, real_A, mask_A, real_B, mask_B):
+        """train.py:247-299, grouped like ``generator_phase_grouped``: lane 0 runs both generators' forwards (translation, then cycle) and
+        the second-step discriminator pair, lane 1 refreshes the backward-only weight copies and runs D_A | D_B."""
+        p = self._d_parts((real_A, mask_A, real_B, mask_B))
+        p["pre"]()
+        packed = self._g_fwd_packed
+        self._g_fwd_packed = False
+
+        def gen_fwd(ln):
+            if not packed:                     # phase called on its own: full refresh first
+                p["repack_full"](ln)
+            p["gen_fwd"](ln)
+
+        def refresh(ln):                       # beside the generator forwards; the generator gradients are free by now
             if packed:
-                self._twin(lambda: self._repack1(A2B, 2), lambda: self._repack1(B2A, 2))
-                self.g_group.grad.zero_()      # (196 MB memset on the side lane instead of at the top of the next iteration)
-                self._g_grad_clean = True
-        if B >= self.split_d_min_batch:
+                p["repack_bwd"](ln)
+                if not self._g_grad_clean:
+                    self.g_group.grad.zero_()  # (196 MB memset on the side lane instead of at the top of the next iteration)
+                    self._g_grad_clean = True
+        if self.B >= self.split_d_min_batch:
             # the real halves need nothing from the generators: lane 1 runs them while lane 0 is in the generator forwards
             tasks = [
                 (0, gen_fwd, (), "gen"),
                 (1, refresh, (), None),
-                (1, pair(disc_half, "discriminator_A", "discriminator_B", False), (), None),
-                (1, pair(disc_half, "discriminator_A2", "discriminator_B2", False), (), "r2"),
-                (0, cycles, (), None),
-                (1, pair(disc_half, "discriminator_A", "discriminator_B", True), ("gen",), None),
-                (0, pair(disc_half, "discriminator_A2", "discriminator_B2", True), ("r2",), None),
+                (1, p["real1"], (), None),
+                (1, p["real2"], (), "r2"),
+                (0, p["cycles"], (), None),
+                (1, p["fake1"], ("gen",), None),
+                (0, p["fake2"], ("r2",), None),
             ]
         else:
             tasks = [
                 (0, gen_fwd, (), "gen"),
                 (1, refresh, (), None),
-                (0, cycles, (), None),
-                (1, pair(disc_full, "discriminator_A", "discriminator_B"), ("gen",), None),
-                (0, pair(disc_full, "discriminator_A2", "discriminator_B2"), (), None),
+                (0, p["cycles"], (), None),
+                (1, p["full1"], ("gen",), None),
+                (0, p["full2"], (), None),
             ]
         self._run_tasks(tasks)
-        self._combine(8, self._comb_d)
+        p["post"]()
+
+    # ---- pipelined step ------------------------------------------------------------------------------------------------------------
+    def _pipelined_step(self):
+        """Iteration t+1's generator phase beside iteration t's discriminator phase.
+
+        The discriminator phase of an iteration (train.py:247-299) reads the generators as updated by that iteration's generator phase
+        and writes the discriminators; the NEXT iteration's generator forwards (translation, identity, cycle: train.py:203-210) read the
+        same generator weights and no discriminator at all -- only its adversarial passes (:211-216) need the updated discriminators,
+        and each pair only its own two networks.  So a step issues, as ONE task graph:
+            lane 1:  D-phase(t): generator forwards -> cycle forwards -> D_A2 | D_B2 -> [all-reduce] Adam on their slice, re-pack -> "dupd2"
+            lane 3:  backward-only weight copies; D_A | D_B of D-phase(t) -> Adam on their slice, re-pack                          -> "dupd1"
+            lane 0:  G-phase(t+1): translation -> cycle -> (dupd2) D_A2 | D_B2 adversarial -> backward x 2 -> Adam(G) + re-pack
+            lane 2:  (dupd1) the first-step adversarial pair of G-phase(t+1); then its identity chain (forward, loss, backward)
+        The identity chain depends on nothing but the generator weights, so it fills the tail of the step, where the two backward rounds
+        are alone on the chip; its weight gradients go to a SECOND gradient buffer (they would race with the backward rounds' otherwise)
+        and Adam consumes the sum -- clearing both buffers as it reads them, which also removes the per-iteration gradient memsets.
+        Every quantity is computed from exactly the weights and inputs the reference uses (the order of the optimizers' steps is kept:
+        a discriminator's Adam step (t) is complete before it is read by iteration t+1; Adam(G)(t+1) waits for D-phase(t)'s generator
+        forwards); two generator-forward latencies leave the critical path of every iteration.  ``d_loss`` of an iteration becomes
+        available one ``step()`` later (``losses(lagged=True)``); ``flush()`` / ``losses()`` complete a pending phase."""
+        cur = self.static_in
+        prev, d_lr = self._pending_D if self._pending_D is not None else (None, None)
+        second = self.reducer.world == 1 and self.grouped_ident          # (data parallel: one gradient buffer is exchanged)
+        g = self._g_parts(cur, True, own_d_update=prev is None, ident_second=second, zeroing_update=True)
+        ident, ov = g["ident"], g["ov"]
+        tail = [(2, g["ident_chain"], (), "i")] if (ident and second) else []
+        head = [(2, g["ident_chain"], (), "i")] if (ident and not second) else []
+        upd_waits = ("i",) if (ident and second) else ()
+        bwd_waits = ("d1", "i") if (ident and not second) else ("d1",)
+        if prev is None:                       # first iteration (or the first after a flush): there is no discriminator phase to run beside it
+            g["pre"](zero_grads=True)
+            tasks = [(0, g["fwd2"], (), "g")] + head + [
+                (0, g["cycle"], (), None), (2, g["adv1"], ("g",), "d1")] + tail + [(0, g["adv2"], (), None),
+                (0, g["bwd_cycle"], bwd_waits, None), (0, g["bwd_final"], (), "f")]
+            tasks += ([(3, g["queue_reduce"], (), None)] if ov else []) + [(0, g["update"], upd_waits, None)]
+            self._run_tasks(tasks)
+            self._d_pack_event = None
+            self._g_grad_clean = True          # (cleared by the Adam launch that consumed them)
+            g["post"]()
+            return
+        self.slots_done[:_BLOCK].copy_(self.slots[:_BLOCK])           # g_loss and its terms of iteration t, before the block is reused
+        d = self._d_parts(prev, gi=2)
+        g["pre"](zero_grads=False)             # (all gradient buffers were cleared by the Adam steps that consumed them)
+        d["pre"](zero_grads=False)
+        packed = self._g_fwd_packed
+        d_step = self.d_group.step + 1
+
+        def side_head(ln):                     # lane 3
+            if packed:
+                d["repack_bwd"](ln)
+
+        def d_update(pair):                    # Adam on one discriminator pair's slice of the flat buffer + its re-pack
+            lo, hi = self._d_ranges[pair[0]][0], self._d_ranges[pair[1]][1]
+
+            def run(ln):
+                if self.reducer.world > 1:
+                    self.reducer.reduce_range_after_(self.d_group.grad, lo, hi, None)
+                    self.reducer.wait(self.device)
+                self._adam_range(self.d_group, lo, hi, d_lr, d_step)
+                for n in pair:
+                    self.nets[n]._packed_version = None
+                self._twin(lambda: self._repack1(pair[0]), lambda: self._repack1(pair[1]))
+            return run
+        split = self.B >= self.split_d_min_batch
+        tasks = [
+            (3, side_head, (), "rf"),          # (first: a backward pass refuses to run on a buffer whose backward copies are marked stale)
+            (1, (lambda ln: (None if packed else d["repack_full"](ln), d["gen_fwd"](ln))), (), "gen"),
+            (0, g["fwd2"], (), "g"),
+        ] + head
+        if split:
+            tasks += [(3, d["real1"], (), None), (3, d["real2"], (), "r2")]
+        tasks += [
+            (1, d["cycles"], (), "cyc"),
+            (0, g["cycle"], (), None),
+            (3, d["fake1"] if split else d["full1"], ("gen",), None),
+            (3, d_update(("discriminator_A", "discriminator_B")), (), "dupd1"),
+            (1, d["fake2"] if split else d["full2"], ("r2",) if split else (), None),
+            (1, d_update(("discriminator_A2", "discriminator_B2")), (), "dupd2"),
+            (2, g["adv1"], ("g", "dupd1"), "d1"),
+        ] + tail + [
+            (0, g["adv2"], ("dupd2",), None),
+            (0, g["bwd_cycle"], bwd_waits + ("rf",), None),
+            (0, g["bwd_final"], (), "f"),
+        ] + ([(3, g["queue_reduce"], (), None)] if ov else []) + [
+            (0, g["update"], upd_waits + ("cyc",), None),
+        ]
+        self._run_tasks(tasks)
+        self.d_group.step = d_step
+        self._d_pack_event = None
+        self._g_grad_clean = self._d_grad_clean = True
+        g["post"]()
+        d["post"]()
+        self.slots_done[_BLOCK:].copy_(self.slots[_BLOCK:])           # d_loss and its terms of iteration t: the iteration is complete
+        self._publish_done()
+
+    def _publish_done(self):
+        """Losses of the last COMPLETE iteration to pinned host memory (asynchronous copy + event; ``losses(lagged=True)`` waits for it)."""
+        self._done_host.copy_(self.slots_done, non_blocking=True)
+        self._done_event.record()
+        self._done_valid = True
 
     def generator_update(self):
         """All-reduce (data parallel) + Adam on the flat generator buffer (train.py:242); eager: its scalars change per step."""
@@ -822,8 +1115,31 @@ class TrainEngine:
         if self._d_pack_event is not None:
             torch.cuda.current_stream(self.device).wait_event(self._d_pack_event)
 
+    def _use_pipeline(self):
+        return self.pipelined and self._use_grouped() and self.fuse_g_update and self.concurrent and (self.reducer.world == 1 or self.overlap_g_reduce)
+
+    def _next_input_set(self):
+        """The static input buffers the coming iteration writes its minibatch into: the other set while the previous iteration's
+        discriminator phase (which still reads its own minibatch) is pending."""
+        if self._pending_D is not None:
+            self._cur_set ^= 1
+            self.static_in = self.static_sets[self._cur_set]
+
     def flush(self):
-        """Complete a deferred discriminator update (call before reading parameters / optimizer state from outside)."""
+        """Complete what ``step()`` left pending -- the pipelined discriminator phase of the last iteration, a deferred discriminator
+        update -- so that parameters, optimizer state and both losses belong to the same, complete iteration."""
+        if self._pending_D is not None:
+            inp, d_lr = self._pending_D
+            self._pending_D = None
+            self.slots_done[:_BLOCK].copy_(self.slots[:_BLOCK])
+            self.discriminator_phase_grouped(*inp)
+            self.reducer.reduce_(self.d_group.grad)
+            self._adam(self.d_group, d_lr)
+            self.d_group.grad.zero_()
+            self._d_grad_clean = True
+            self._repack_d_async()
+            self.slots_done[_BLOCK:].copy_(self.slots[_BLOCK:])
+            self._publish_done()
         self._finish_d_update()
         self._wait_d_pack()
         self._d_pack_event = None
@@ -839,6 +1155,7 @@ class TrainEngine:
         if real_A.shape[0] != self.B:
             self._use(int(real_A.shape[0]))
         # static input buffers (graph replays read fixed addresses)
+        self._next_input_set()
         torch._foreach_copy_(list(self.static_in), [real_A, mask_A, real_B, mask_B])
         return self._step_static()
 
@@ -848,10 +1165,19 @@ class TrainEngine:
         B = self.B if batch_size is None else int(batch_size)
         if B != self.B:
             self._use(B)
+        self._next_input_set()
         sampler.draw_into(*self.static_in)
         return self._step_static()
 
     def _step_static(self):
+        if self._use_pipeline():
+            d_lr = self.sched.d_opt_lr           # what torch.optim would use for THIS iteration's discriminator step
+            self._pipelined_step()               # generator phase of this iteration (+ the previous one's discriminator phase)
+            self._pending_D = (self.static_in, d_lr)
+            self.sched.end_iteration()
+            return self.slots
+        if self._pending_D is not None:
+            self.flush()
         if (self.reducer.world == 1 or self.overlap_g_reduce) and not self.use_graphs and self.fuse_g_update:
             phase = self.generator_phase_grouped if self._use_grouped() else self.generator_phase
             phase(*self.static_in, fuse_update=True)                      # includes the generator update (no join of the lanes)
@@ -913,7 +1239,24 @@ class TrainEngine:
                         raise RuntimeError("persistent trunk kernel fault %d (layer %d) in lane %d at batch %d: more concurrent generator "
                                            "passes than the device can keep resident" % (code, code - 1, lane, nb))
 
-    def losses(self):
+    def losses(self, lagged=False):
+        """Host read of the loss slots, like the reference's ``.item()`` calls (train.py:303).  Default: the losses of the iteration
+        just issued -- a pending pipelined discriminator phase is completed first, so calling this every iteration runs the two phases
+        back to back.  ``lagged=True`` (the pipelined training loop, bench.py): the losses of the last COMPLETE iteration -- after
+        ``step()`` number t+1 that is iteration t (None before there is one) -- waiting only for the small asynchronous copy that
+        published them, never for work still in flight."""
+        if lagged:
+            if self._pending_D is None:
+                lagged = False                   # nothing in flight: the latest iteration is complete
+            elif not self._done_valid:
+                return None
+            else:
+                self._done_event.synchronize()
+                v = self._done_host.tolist()
+                return {"g_loss": v[SLOT_G], "d_loss": v[SLOT_D], "cycle_loss": v[SLOT_CYCLE], "identity_loss": v[SLOT_IDENT],
+                        "adv_loss": v[SLOT_ADV_G]}
+        if self._pending_D is not None:
+            self.flush()
         v = self.slots.tolist()      # device sync, like the reference's .item()
         return {"g_loss": v[SLOT_G], "d_loss": v[SLOT_D], "cycle_loss": v[SLOT_CYCLE], "identity_loss": v[SLOT_IDENT],
                 "adv_loss": v[SLOT_ADV_G]}

@@ -43,10 +43,11 @@ def deterministic_mode():
     L.mcvc_set_deterministic(was)
 
 
-def _steps(grouped, B, n_it=2):
+def _steps(grouped, B, n_it=2, ident=False):
     nets = _nets(610)
     eng = TrainEngine(nets, B, 64, schedule=StepSchedule(batch_size=B, n_samples=4 * B))
     eng.grouped = grouped
+    eng.grouped_ident = ident
     losses = []
     for it in range(n_it):
         eng.step(*_batch(B, 70 + it))
@@ -59,6 +60,58 @@ def _steps(grouped, B, n_it=2):
 @pytest.mark.parametrize("B", [1, 2, 4])
 def test_grouped_step_is_bit_identical_to_the_four_lane_step(deterministic_mode, B):
     (l0, p0), (l1, p1) = _steps(False, B), _steps(True, B)
+    assert l0 == l1, (l0, l1)
+    for n in p0:
+        for i, (a, b) in enumerate(zip(p0[n], p1[n])):
+            assert torch.equal(a, b), (n, i)
+
+
+def test_identity_chain_variant_matches_the_batched_form(deterministic_mode):
+    """The grouped schedule runs the identity passes G(real, ones) as their own B-sized chain instead of inside batched 2B passes: same
+    mathematics (every op is per sample), a different summation order of the weight gradients over the samples -> agreement to rounding
+    with the batched form, and bit-reproducible run to run."""
+    (l0, p0), (l1, p1), (l2, p2) = _steps(True, 2, ident=False), _steps(True, 2, ident=True), _steps(True, 2, ident=True)
+    assert l1 == l2 and all(torch.equal(a, b) for n in p1 for a, b in zip(p1[n], p2[n]))
+    assert abs(l0[0]["g_loss"] - l1[0]["g_loss"]) <= 1e-6 * abs(l0[0]["g_loss"])          # (first iteration: identical forward arithmetic)
+    for a, b in zip(l0, l1):
+        for k in a:
+            assert abs(a[k] - b[k]) < 1e-3 * abs(a[k]) + 1e-7, (k, a, b)
+    for n in p0:
+        for a, b in zip(p0[n], p1[n]):
+            assert float((a - b).norm()) <= 0.1 * 2 * 2e-4 * float(a.numel()) ** 0.5 + 1e-7, n      # 10 % of "every element moved by lr" per step
+
+
+@pytest.mark.parametrize("B", [1, 4])
+def test_pipelined_steps_equal_back_to_back_phases(deterministic_mode, B):
+    """The pipelined step issues iteration t's discriminator phase together with iteration t+1's generator phase (engine._pipelined_step).
+    Every quantity is computed from the weights and inputs the reference uses, so K pipelined steps + flush == K steps with the two phases
+    back to back: losses of every iteration and all parameters bit-equal (deterministic mode), Adam step counts equal."""
+    def run(pipelined, K=4):
+        nets = _nets(640)
+        eng = TrainEngine(nets, B, 64, schedule=StepSchedule(batch_size=B, n_samples=4 * B, decay_after=2 * B, stop_identity_after=3 * B, num_epochs=3))
+        eng.pipelined = pipelined
+        seen = []
+        for it in range(K):
+            eng.step(*_batch(B, 90 + it))
+            if pipelined:
+                assert eng._pending_D is not None
+                lo = eng.losses(lagged=True)              # iteration it-1 (None at the first step)
+                assert (lo is None) == (it == 0)
+                if lo is not None:
+                    seen.append((lo["g_loss"], lo["d_loss"]))
+            else:
+                lo = eng.losses()
+                seen.append((lo["g_loss"], lo["d_loss"]))
+        if pipelined:
+            lo = eng.losses()                             # completes the last iteration
+            seen.append((lo["g_loss"], lo["d_loss"]))
+            assert eng._pending_D is None
+        eng.flush()
+        eng.check_faults()
+        return seen, {n: [p.detach().clone() for p in nets[n].parameters()] for n in G_NAMES + D_NAMES}, (eng.g_group.step, eng.d_group.step), \
+            (eng.sched.g_opt_lr, eng.sched.d_opt_lr, eng.sched.global_step)
+    (l0, p0, s0, h0), (l1, p1, s1, h1) = run(False), run(True)
+    assert s0 == s1 == (4, 4) and h0 == h1
     assert l0 == l1, (l0, l1)
     for n in p0:
         for i, (a, b) in enumerate(zip(p0[n], p1[n])):
@@ -78,7 +131,9 @@ def test_grouped_step_default_mode_close_and_halves_the_launches():
     for grouped in (False, True):
         eng = TrainEngine(_nets(610), 1, 64, schedule=StepSchedule(batch_size=1, n_samples=4))
         eng.grouped = grouped
+        eng.grouped_ident = False          # (the batched form: exactly the four-lane schedule's passes, pairwise grouped)
         eng.step(*_batch(1, 5))
+        eng.flush()                        # (a pending pipelined discriminator phase would otherwise be counted with the traced step)
         torch.cuda.synchronize()
         eng.concurrent = False
         eng.aux_wgrad = False
