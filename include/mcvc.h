@@ -86,7 +86,15 @@ int mcvc_gen_pack_small_batch(const float* const* params, float* packed, int max
  * backward pass on this buffer returns MCVC_ERR_INVALID until sets = 2 has run (the trainer's discriminator phase needs the updated
  * generators forward-only; the rest of the refresh runs beside it).                                    */
 int mcvc_gen_pack_sets(const float* const* params, float* packed, int max_batch, int T, int sets, void* stream);
+/* ... and restricted to parameter ranges (range_mask bit 0: parameters [100,110), bit 1: [24,100), bit 2: [0,24); 7 = all): the ranges
+ * whose gradients mcvc_gen_backward_overlap reports final one after the other, so that a range's optimizer step + re-pack can run beside the
+ * rest of the backward pass.                                                                              */
+int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batch, int T, int sets, int range_mask, void* stream);
 int mcvc_disc_pack(const float* const* params, float* packed, void* stream);
+/*      The same restricted to what passes at n_frames T read when the three stride-2 layers run as staged GEMMs (the default at every batch
+ *      size): their K-major forward copies + biases only -- 4x fewer bytes than the full re-pack; falls back to it otherwise.  A pass that
+ *      would need one of the stale copies returns MCVC_ERR_INVALID instead of reading it.                         */
+int mcvc_disc_pack_small(const float* const* params, float* packed, int T, void* stream);
 
 /* ---- Generator: replaces Generator.forward (mask_cyclegan_vc/model.py:239-280) and its autograd
  *      x, mask: [B,80,T] (mask NULL = all ones, test.py:92); out: [B,80,T']                        */

@@ -513,6 +513,7 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
         }
     }
     if (!ex.dry && (((ex.pack_skips & 1) && c.off_tk >= 0) || ((ex.pack_skips & 2) && (c.wino || c.wino3)))) { ex.fail(MCVC_ERR_INVALID); return; }
+    if (!ex.dry && (ex.pack_skips & 8) && c.stride == 2) { ex.fail(MCVC_ERR_INVALID); return; }      // (mcvc_disc_pack_small: these copies are stale)
     static const int ucls_nb = [] { const char* e = getenv("MCVC_DGRAD_CLASSES_NB"); return e ? atoi(e) : 8; }();
     const bool per_class = c.merged && c.off_dcls >= 0 && NB >= ucls_nb;
     if (c.merged && !per_class) {
@@ -1726,7 +1727,15 @@ int mcvc_gen_trunk_fused(int B, int T)
 // refresh the backward sets are marked stale (bit 2 of the registry) and a backward pass on this buffer fails until sets = 2 has run.
 int mcvc_gen_pack_sets(const float* const* params, float* packed, int max_batch, int T, int sets, void* stream)
 {
-    if (sets < 1 || sets > 3) return MCVC_ERR_INVALID;
+    return mcvc_gen_pack_ranges(params, packed, max_batch, T, sets, 7, stream);
+}
+
+// ... restricted to the layers of some parameter ranges (bit 0: upSample1/2 + lastConvLayer = parameters [100,110); bit 1: the residual
+// blocks + conv1dto2d = [24,100); bit 2: conv1, downSample1/2, conv2dto1d = [0,24) -- the ranges whose gradients become final one after the
+// other during a backward pass, mcvc_gen_backward_overlap): the optimizer step + re-pack of a range can then run beside the rest of the pass
+int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batch, int T, int sets, int range_mask, void* stream)
+{
+    if (sets < 1 || sets > 3 || range_mask < 1 || range_mask > 7) return MCVC_ERR_INVALID;
     bool fused = true;
     for (int b = 1; b <= max_batch; ++b)
         if (!mcvc_gen_trunk_fused(b, T)) fused = false;
@@ -1737,14 +1746,23 @@ int mcvc_gen_pack_sets(const float* const* params, float* packed, int max_batch,
     const GenDims dm = gen_dims(max_batch, T);
     const bool wino_only = fused && knobs_default && (T % 4) == 0 && T >= 32 && (long long)max_batch * 20 * dm.W4 <= 16384;
     int err = 0;
-    auto build = [wino_only, fused, sets](PackTable& pt) {
+    auto build = [wino_only, fused, sets, range_mask](PackTable& pt) {
         const GenNet& g = gen_net();
-        const ConvSpec* full[] = {&g.conv1, &g.ds1, &g.ds2, &g.up1, &g.up2, &g.last};
-        for (const ConvSpec* c : full) add_spec_jobs(pt, *c, false, wino_only, sets);
-        add_spec_jobs(pt, g.c2d1d, fused, false, sets); add_spec_jobs(pt, g.c1d2d, fused, false, sets);
-        for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i], fused, false, sets); add_spec_jobs(pt, g.res_out[i], fused, false, sets); }
+        if (range_mask & 4) {
+            const ConvSpec* head[] = {&g.conv1, &g.ds1, &g.ds2};
+            for (const ConvSpec* c : head) add_spec_jobs(pt, *c, false, wino_only, sets);
+            add_spec_jobs(pt, g.c2d1d, fused, false, sets);
+        }
+        if (range_mask & 1) {
+            const ConvSpec* up[] = {&g.up1, &g.up2, &g.last};
+            for (const ConvSpec* c : up) add_spec_jobs(pt, *c, false, wino_only, sets);
+        }
+        if (range_mask & 2) {
+            add_spec_jobs(pt, g.c1d2d, fused, false, sets);
+            for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i], fused, false, sets); add_spec_jobs(pt, g.res_out[i], fused, false, sets); }
+        }
     };
-    const DevPackTable* t = dev_pack_table(16 + 4 * sets + (fused ? (wino_only ? 3 : 2) : 0), build, &err);
+    const DevPackTable* t = dev_pack_table(16 + 4 * sets + (fused ? (wino_only ? 3 : 2) : 0) + 64 * range_mask, build, &err);
     if (!t) return err;
     const int skipped = fused ? (wino_only ? 3 : 1) : 0;
     if (sets == 1) set_pack_skips(packed, skipped | 4);
@@ -1769,6 +1787,30 @@ int mcvc_disc_pack(const float* const* params, float* packed, void* stream)
         add_spec_jobs(pt, n.outc);
     }, &err);
     if (!t) return err;
+    set_pack_skips(packed, 0);
+    return pack_net(t, params, packed, (hipStream_t)stream);
+}
+
+// Discriminator re-pack restricted to what the staged-GEMM schedule reads: of the three stride-2 layers (99.9 % of the weights) only the
+// K-major FORWARD copy + bias -- their data gradient multiplies the OIHW parameters themselves and their weight gradient reads no weights
+// at all; the first / output layers (tiny) are refreshed in full.  Falls back to the full pack when a layer would not take that path at
+// (B = 1, T).  The direct kernels' data-gradient copies are then marked stale (bit 8) and refuse to run.
+int mcvc_disc_pack_small(const float* const* params, float* packed, int T, void* stream)
+{
+    const DiscNet& n = disc_net();
+    const DiscDims d = disc_dims(1, T);
+    bool staged = true;
+    for (int i = 0; i < 3; ++i) staged = staged && sgemm_kind(n.ds[i], 1, d.H[i], d.W[i]).kind == 1;
+    if (!staged) { set_pack_skips(packed, 0); return mcvc_disc_pack(params, packed, stream); }
+    int err = 0;
+    const DevPackTable* t = dev_pack_table(2, [](PackTable& pt) {
+        const DiscNet& n = disc_net();
+        add_spec_jobs(pt, n.conv1);
+        for (int i = 0; i < 3; ++i) add_spec_jobs(pt, n.ds[i], false, false, 1);
+        add_spec_jobs(pt, n.outc);
+    }, &err);
+    if (!t) return err;
+    set_pack_skips(packed, 8);
     return pack_net(t, params, packed, (hipStream_t)stream);
 }
 
@@ -1832,6 +1874,7 @@ int mcvc_disc_forward(const float* const* params, const float* packed, const flo
     const DiscDims d = disc_dims(B, T);
     Exec ex = make_exec(stream, nullptr, scratch, scratch_floats, disc_scratch(d).slabs, disc_needs(B, T));
     if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
+    ex.pack_skips = get_pack_skips(packed);
     // keep the input for the first layer's weight gradient
     ex.fail(mcvc_copy_launch(x, stash + disc_stash(d).total, B * 80 * T, ex.s));
     disc_forward_impl(ex, params, packed, x, out, stash, d);
@@ -1846,6 +1889,7 @@ int mcvc_disc_backward(const float* const* params, const float* packed, float* c
     const DiscDims d = disc_dims(B, T);
     Exec ex = make_exec(stream, aux_stream, scratch, scratch_floats, disc_scratch(d).slabs, disc_needs(B, T));
     if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
+    ex.pack_skips = get_pack_skips(packed);
     disc_backward_impl(ex, params, packed, grads, dout, dout_is_logit_grad, dx, accumulate_dx, stash, scratch, d);
     return ex.err;
 }

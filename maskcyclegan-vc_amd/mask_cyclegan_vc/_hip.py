@@ -44,7 +44,9 @@ _SIGS = {
     "mcvc_gen_trunk_fused": (c_int, [c_int, c_int]),
     "mcvc_gen_pack_small_batch": (c_int, [_PP, c_void_p, c_int, c_int, c_void_p]),
     "mcvc_gen_pack_sets": (c_int, [_PP, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mcvc_gen_pack_ranges": (c_int, [_PP, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mcvc_disc_pack": (c_int, [_PP, c_void_p, c_void_p]),
+    "mcvc_disc_pack_small": (c_int, [_PP, c_void_p, c_int, c_void_p]),
     "mcvc_gen_forward": (c_int, [_PP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "mcvc_gen_backward": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p]),
     "mcvc_gen_backward_overlap": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int,

@@ -178,7 +178,9 @@ class TrainEngine:
         # first-step discriminator pair.  MCVC_GROUPED=0 restores the four-lane schedule; MCVC_GROUPED_MAX_B: largest per-pass batch B for
         # which the grouped schedule is used (large batches fill the chip per network anyway).
         self.grouped = os.environ.get("MCVC_GROUPED", "1") != "0"
-        self.grouped_max_b = int(os.environ.get("MCVC_GROUPED_MAX_B", "1024"))
+        # measured (r03, ms per iteration, four-lane / grouped + pipelined): bs=1 6.99 / 6.74, bs=2 10.95 / 10.98, bs=4 17.81 / 17.73,
+        # bs=8 31.2 / 32.0, bs=32 117.8 / 118.0 -- from 8 samples per pass the kernels fill the chip per network and the four-lane schedule stays
+        self.grouped_max_b = int(os.environ.get("MCVC_GROUPED_MAX_B", "4"))
         # ... with the identity passes G(real, ones) as their own chain (forward, loss, backward on lane 2, beside the translation ->
         # cycle chain) instead of inside batched 2B passes: they depend on nothing else, and their weight gradients are ordered in front
         # of the cycle backward by one event
@@ -186,6 +188,7 @@ class TrainEngine:
         # Pipelined step (needs the grouped schedule): iteration t's discriminator phase is issued together with iteration t+1's
         # generator phase, as one task graph (_pipelined_step); MCVC_PIPELINE=0 keeps the two phases of an iteration back to back.
         self.pipelined = os.environ.get("MCVC_PIPELINE", "1") != "0"
+        self.ranged_update = os.environ.get("MCVC_RANGED_UPDATE", "1") != "0"
         self._pending_D = None                  # (input set, discriminator lr) of the iteration whose discriminator phase is still to run
         self.slots_done = torch.zeros(2 * _BLOCK, device=dev)          # loss slots of the last COMPLETE iteration
         self._done_host = torch.zeros(2 * _BLOCK).pin_memory()
@@ -329,14 +332,14 @@ class TrainEngine:
         self.static_in = self.static_sets[0]
 
     # ---- thin call helpers ------------------------------------------------------------------------
-    def _repack1(self, n, sets=3):
+    def _repack1(self, n, sets=3, ranges=7):
         if n in G_NAMES:
             # every generator pass of this engine has batch <= 2B at T frames: at small batch the trunk layers run on the
             # fused kernels and their generic K-major copies need no refresh (the library falls back to the full pack).
             # sets: 1 = what a forward pass reads, 2 = what only a backward pass reads (mcvc_gen_pack_sets)
-            check(self.L.mcvc_gen_pack_sets(self._p_tab[n], ptr(self.packed[n]), 2 * self._max_B, self.T, sets, stream()), "pack " + n)
+            check(self.L.mcvc_gen_pack_ranges(self._p_tab[n], ptr(self.packed[n]), 2 * self._max_B, self.T, sets, ranges, stream()), "pack " + n)
         else:
-            check(self.L.mcvc_disc_pack(self._p_tab[n], ptr(self.packed[n]), stream()), "pack " + n)
+            check(self.L.mcvc_disc_pack_small(self._p_tab[n], ptr(self.packed[n]), self.T, stream()), "pack " + n)
 
     def repack(self, names):
         """Refresh the K-major weight copies (one lane per network when running concurrently)."""
@@ -607,7 +610,7 @@ class TrainEngine:
         return self.grouped and self.B <= self.grouped_max_b and not self.use_graphs and not self.pass_graphs
 
     # ---- grouped schedule: the two phases as parts that the plain and the pipelined step assemble into task graphs ----------------
-    def _g_parts(self, inp, fuse_update, own_d_update=True, ident_second=False, zeroing_update=False):
+    def _g_parts(self, inp, fuse_update, own_d_update=True, ident_second=False, zeroing_update=False, ranged=False):
         """Closures of the generator phase (train.py:195-242) in grouped launches.  ``own_d_update``: the first-step adversarial pair
         completes a deferred discriminator update / waits for the asynchronous re-pack itself (plain step); the pipelined step orders
         the discriminators' update in front of the adversarial pairs through the task graph instead."""
@@ -623,6 +626,7 @@ class TrainEngine:
         cl, il = sc.cycle_loss_lambda, sc.identity_loss_lambda
         A2B, B2A = G_NAMES
         ov = self.overlap_g_reduce
+        ms_on = ov or ranged                   # milestone events of the last backward pass: gradient exchange and / or ranged update
         ident = self.grouped_ident
         g_lr = sc.g_opt_lr
         P = {}
@@ -696,8 +700,8 @@ class TrainEngine:
 
         def bwd_final(ln):      # the last pass over each generator; its gradient ranges become final one after the other (milestone events)
             nb = B if ident else B2
-            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], nb, 0, ov, aux_lane=0, ms_of=A2B),
-                       lambda: self._G_bwd(B2A, self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], nb, 1, ov, aux_lane=0, ms_of=A2B))
+            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], nb, 0, ms_on, aux_lane=0, ms_of=A2B),
+                       lambda: self._G_bwd(B2A, self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], nb, 1, ms_on, aux_lane=0, ms_of=A2B))
 
         def queue_reduce(ln):
             # data parallel: range k of BOTH generators is final at milestone k of the grouped pass; same collective order on every rank
@@ -721,10 +725,30 @@ class TrainEngine:
                 self._adam(self.g_group, g_lr)         # one launch over both generators
             self._twin(lambda: self._repack1(A2B, 1), lambda: self._repack1(B2A, 1))
 
+        def update_range(k, last):
+            """Adam + forward re-pack of parameter range k of both generators (0: up-sampling blocks + last conv, 1: residual trunk,
+            2: the head) as grouped launches.  Ranges 0 / 1 wait for the backward pass's milestone event: their gradients are final while
+            the pass is still running (mcvc_gen_backward_overlap)."""
+            def run(ln):
+                if k < 2:
+                    torch.cuda.current_stream(self.device).wait_event(self._ms[A2B][0][k])
+                if k == 0:
+                    self.g_group.step += 1
+                step = self.g_group.step
+                (a0, a1), (b0, b1) = self._g_ranges[A2B][k], self._g_ranges[B2A][k]
+                self._twin(lambda: self._adam_range(self.g_group, a0, a1, g_lr, step, second=ident_second),
+                           lambda: self._adam_range(self.g_group, b0, b1, g_lr, step, second=ident_second))
+                self._twin(lambda: self._repack1(A2B, 1, 1 << k), lambda: self._repack1(B2A, 1, 1 << k))
+                if last:
+                    for n in G_NAMES:
+                        self.nets[n]._packed_version = None
+                        self.nets[n]._bf16_version = None
+            return run
+
         def post():
             self._g_fwd_packed = bool(fuse_update)
             self._combine(0, self._comb_g)
-        P.update(pre=pre, fwd2=fwd2, ident_chain=ident_chain, ident_fwd=ident_fwd, ident_bwd=ident_bwd, cycle=cycle, adv1=adv1, adv2=adv2, bwd_cycle=bwd_cycle, bwd_final=bwd_final,
+        P.update(update_range=update_range, pre=pre, fwd2=fwd2, ident_chain=ident_chain, ident_fwd=ident_fwd, ident_bwd=ident_bwd, cycle=cycle, adv1=adv1, adv2=adv2, bwd_cycle=bwd_cycle, bwd_final=bwd_final,
                  queue_reduce=queue_reduce, update=update, post=post, ident=ident, ov=ov)
         return P
 
@@ -884,7 +908,8 @@ class TrainEngine:
         cur = self.static_in
         prev, d_lr = self._pending_D if self._pending_D is not None else (None, None)
         second = self.reducer.world == 1 and self.grouped_ident          # (data parallel: one gradient buffer is exchanged)
-        g = self._g_parts(cur, True, own_d_update=prev is None, ident_second=second, zeroing_update=True)
+        ranged = self.ranged_update and self.reducer.world == 1
+        g = self._g_parts(cur, True, own_d_update=prev is None, ident_second=second, zeroing_update=True, ranged=ranged)
         ident, ov = g["ident"], g["ov"]
         tail = [(2, g["ident_chain"], (), "i")] if (ident and second) else []
         head = [(2, g["ident_chain"], (), "i")] if (ident and not second) else []
@@ -944,9 +969,16 @@ class TrainEngine:
             (0, g["adv2"], ("dupd2",), None),
             (0, g["bwd_cycle"], bwd_waits + ("rf",), None),
             (0, g["bwd_final"], (), "f"),
-        ] + ([(3, g["queue_reduce"], (), None)] if ov else []) + [
-            (0, g["update"], upd_waits + ("cyc",), None),
-        ]
+        ] + ([(3, g["queue_reduce"], (), None)] if ov else [])
+        if ranged:
+            # the generator update range by range: the up-sampling blocks' and the trunk's Adam step + forward re-pack run on lane 1 beside
+            # the rest of the last backward pass (behind its milestone events; after everything that still reads the old weights: the
+            # identity chain "i" and D-phase(t)'s generator forwards "cyc"); only the head's is left for the end of the chain
+            # (lane 1, idle since "dupd2" -- lane 3's stream carries the backward rounds' weight gradients)
+            tasks += [(1, g["update_range"](0, False), upd_waits + ("cyc",), None), (1, g["update_range"](1, False), (), "u01"),
+                      (0, g["update_range"](2, True), upd_waits + ("cyc",), None)]
+        else:
+            tasks += [(0, g["update"], upd_waits + ("cyc",), None)]
         self._run_tasks(tasks)
         self.d_group.step = d_step
         self._d_pack_event = None

@@ -153,18 +153,33 @@ class MaskCycleGANVCTraining(object):
         return self.logger.log_spectrograms(os.path.join(self.args.save_dir, self.args.name, "validation"), arrays)
 
     def train(self):
+        """The reference's loop (train.py:175-315).  The engine's pipelined step completes an iteration's discriminator phase beside the
+        NEXT iteration's generator phase, so an iteration's losses reach the host one ``step()`` later: the logger is fed iteration t's
+        losses (both of them, like the reference's ``.item()`` reads at :303) right after iteration t+1 has been issued, and the last
+        iteration of an epoch after the epoch's flush -- the log lines are the reference's, line for line."""
         done = 0
         for epoch in range(self.start_epoch, self.num_epochs + 1):
             self.logger.start_epoch()
-            for run_step in self._epoch_batches():
-                self.logger.start_iter()
-                run_step()                                                 # G phase, D phase, lr / lambda bookkeeping
-                lo = self.engine.losses()                                  # host read, like .item() in train.py:303
+            owed = 0                                                       # iterations issued whose losses are not logged yet
+
+            def log_one(lo):
                 self.logger.log_iter(loss_dict={"g_loss": lo["g_loss"], "d_loss": lo["d_loss"]})
                 self.logger.end_iter()
+            for run_step in self._epoch_batches():
+                self.logger.start_iter()
+                run_step()                                                 # G phase, (previous) D phase, lr / lambda bookkeeping
+                owed += 1
+                lo = self.engine.losses(lagged=True)                       # host read of the last COMPLETE iteration
+                in_flight = 1 if self.engine._pending_D is not None else 0   # pipelined: this iteration's discriminator phase is still to run
+                if lo is not None and owed > in_flight:
+                    log_one(lo)
+                    owed -= 1
                 done += 1
                 if self.args.max_iters and done >= self.args.max_iters:
                     break
+            if owed:
+                log_one(self.engine.losses())                              # completes the epoch's last iteration (flush) and reads it
+                owed -= 1
             if done and self.epochs_per_plot and epoch % self.epochs_per_plot == 0 and self.rank == 0:
                 self.validate()                                            # train.py:317
             if epoch % self.epochs_per_save == 0:
