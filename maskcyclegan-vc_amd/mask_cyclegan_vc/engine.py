@@ -276,6 +276,10 @@ class TrainEngine:
         for c in cands:                # fewer than `want` independent queues (GPU_MAX_HW_QUEUES < 4): fill up with what there is
             if len(picked) < want and c not in picked:
                 picked.append(c)
+        prio = os.environ.get("MCVC_LANE_PRIO")      # experiment: comma list of side lanes (1..3) that get a high-priority stream
+        if prio:
+            for ln in prio.split(","):
+                picked[int(ln) - 1] = torch.cuda.Stream(device=dev, priority=-1)
         return picked
 
     # ---- activations / workspaces: static shapes per batch size (graph-capturable), created on first use -----------
