@@ -45,7 +45,11 @@ int mcvc_set_deterministic(int on);
 int mcvc_get_deterministic(void);
 /* Small-batch generator passes (B * T/4 <= 32) run the 1-D trunk (six residual blocks + conv1dto2d, model.py:258-271) as ONE
  * persistent launch per direction instead of one fused launch per layer (default on; env MCVC_TRUNK_NET=0).  Results are
- * bit-identical either way; the switch exists for A/B timing and tests.  Returns the previous setting.                 */
+ * bit-identical either way; the switch exists for A/B timing and tests.  Returns the previous setting.
+ * The BACKWARD pass's data-gradient chain through the six blocks is one persistent launch as well (B * T/4 <= 16 at the 1024 staged
+ * channels; env MCVC_TRUNK_BWD_NET=0): on = 1 both directions, 2 forward only, 0 neither.  The persistent backward sums every K range in a
+ * fixed order, so -- unlike the per-layer launches' atomic K-split -- its gradients are bit-reproducible in every mode; they agree with the
+ * per-layer path to rounding.                                                                                  */
 int mcvc_set_trunk_persistent(int on);
 
 /* ---- grouped launches: two networks of the same architecture in one grid (new; the reference runs G_A2B / G_B2A and the discriminator

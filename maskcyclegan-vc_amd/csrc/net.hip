@@ -842,6 +842,7 @@ static bool trunk_enabled()
 // persistent 13-layer forward (trunk_fwd_net_kernel) instead of one fused launch per layer; knob MCVC_TRUNK_NET=0 for A/B runs
 static int g_trunk_net = [] { const char* e = getenv("MCVC_TRUNK_NET"); return e ? (atoi(e) != 0) : 1; }();
 static bool trunk_net_enabled() { return g_trunk_net != 0; }
+static bool trunk_bwd_net_enabled() { return g_trunk_net == 1; }          // (2 = forward only)
 
 // conv1d + bias + IN (+GLU | +residual); input / conv_out in trunk layout [C][B][W4]; y plane (b, c) at y + b*y_sn + c*y_sc
 static bool trunk_fwd(Exec& ex, const ConvSpec& c, const float* const* P, int g0, int be0, int g1, int be1, const float* x, float* conv_out,
@@ -1308,7 +1309,42 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
     SmallKJob wjobs[MCVC_SMALLK_MAX_JOBS];
     int nwjobs = 0;
     const bool batch_w = batch_knob && mcvc_wgrad_smallk_batch_applies(B, W4) && (W4 <= 128);
-    for (int i = 5; i >= 0; --i) {
+    // Persistent backward (trunk.h): the 12 dependent data-gradient layers of the six blocks in ONE launch, when every layer would take the
+    // fused path anyway, the gradient arriving from conv1dto2d is not split into slabs and the staged gradients fit the LDS
+    static const int bwd_net_knob = [] { const char* e = getenv("MCVC_TRUNK_BWD_NET"); return e ? atoi(e) : 1; }();
+    bool bwd_net = bwd_net_knob && trunk_bwd_net_enabled() && fuse_knob && trunk_enabled() && batch_w && !ex.dry && G && ex.sync &&
+                   mcvc_trunk_bwd_net_applies(B, W4);
+    for (int i = 0; i < 6 && bwd_net; ++i)
+        bwd_net = g.res_out[i].off_tk >= 0 && g.res_vg[i].off_tk >= 0 && mcvc_trunk_applies(g.res_out[i].cout_tot, 3, g.res_out[i].Cin, B, W4, TRUNK_PLAIN, 1);
+    if (bwd_net) {
+        TrunkBwdNetArgs na{};
+        int l = 0;
+        for (int i = 5; i >= 0; --i) {
+            const int b = 24 + 12 * i;
+            const float* hin = (i == 0) ? (st + o.y4) : (st + o.r[i - 1].y);
+            float* dt3 = sc + q.dtx3 + (long long)i * 256 * BT4;
+            float* dt1 = sc + q.dtx1 + (long long)i * 1024 * BT4;
+            TrunkBwdLayerDesc& da = na.L[l++];           // conv1d_out_layer (512 -> 256) + its InstanceNorm: d(h_out) -> d(GLU output)
+            da.wt = packed + g.res_out[i].off_tk; da.dy = DH; da.px = st + o.r[i].cb; da.stats = st + o.r[i].sb;
+            da.g0 = P[b + 10]; da.b0 = P[b + 11]; da.xout = dt3; da.dg0 = G[b + 10]; da.db0 = G[b + 11];
+            da.out = DT2; da.pre = 1; da.C = 256; da.M = 512; da.rows = 8;
+            da.flags = (i < 5 ? TBWD_DY_FRESH : 0) | ((i == 5 && ns > 1) ? TBWD_SLAB_DY : 0);            // (conv1dto2d's K-split slabs)
+            TrunkBwdLayerDesc& db = na.L[l++];           // value | gate convs (256 -> 512 each) + norms + GLU: d(GLU output) -> d(h_in), added to the skip path
+            db.wt = packed + g.res_vg[i].off_tk; db.dy = DT2; db.px = st + o.r[i].ca; db.stats = st + o.r[i].sa;
+            db.g0 = P[b + 2]; db.b0 = P[b + 3]; db.g1 = P[b + 6]; db.b1 = P[b + 7]; db.xout = dt1;
+            db.dg0 = G[b + 2]; db.db0 = G[b + 3]; db.dg1 = G[b + 6]; db.db1 = G[b + 7];
+            db.out = DH; db.pre = 2; db.C = 512; db.M = 256; db.rows = 4;
+            db.flags = TBWD_ACCUMULATE | TBWD_DY_FRESH | ((i == 5 && ns > 1) ? TBWD_SLAB_OUT : 0);
+            wjobs[nwjobs++] = SmallKJob{st + o.r[i].ya, dt3, G[g.res_out[i].wi[0]], 512, 256};
+            wjobs[nwjobs++] = SmallKJob{hin, dt1, G[g.res_vg[i].wi[0]], 256, 512};
+            wjobs[nwjobs++] = SmallKJob{hin, dt1 + 512LL * BT4, G[g.res_vg[i].wi[1]], 256, 512};
+        }
+        na.nlayers = l; na.B = B; na.T4 = W4; na.slabs = ex.slabs; na.slab_stride = 256 * BT4; na.nslab = ns; na.sync = ex.sync + MCVC_TRUNK_SYNC_WORDS; na.err = ex.sync + MCVC_TRUNK_SYNC_WORDS - 1;
+        for (int i = 0; i < 6; ++i) { wait_readers(ex, sc + q.dtx3 + (long long)i * 256 * BT4); wait_readers(ex, sc + q.dtx1 + (long long)i * 1024 * BT4); }
+        ex.fail(mcvc_trunk_bwd_net_launch(na, ex.s));
+        ns = 1;
+    }
+    for (int i = 5; i >= 0 && !bwd_net; --i) {
         const int b = 24 + 12 * i;
         const float* hin = (i == 0) ? (st + o.y4) : (st + o.r[i - 1].y);
         DT3 = DT3s[i & 1]; DT1 = DT1s[i & 1];
@@ -1661,7 +1697,7 @@ int mcvc_twin_launches(void) { return (int)t_twin_ctx.recs.size(); }
 
 int mcvc_set_deterministic(int on) { const int was = g_deterministic; g_deterministic = on ? 1 : 0; return was; }
 int mcvc_get_deterministic(void) { return g_deterministic; }
-int mcvc_set_trunk_persistent(int on) { const int was = g_trunk_net; g_trunk_net = on ? 1 : 0; return was; }
+int mcvc_set_trunk_persistent(int on) { const int was = g_trunk_net; g_trunk_net = (on == 2) ? 2 : (on ? 1 : 0); return was; }
 
 long long mcvc_gen_packed_floats(void) { return gen_net().packed_floats; }
 long long mcvc_disc_packed_floats(void) { return disc_net().packed_floats; }
@@ -1852,7 +1888,8 @@ int mcvc_gen_backward_overlap(const float* const* params, const float* packed, f
     Exec ex = make_exec(stream, aux_stream, scratch, scratch_floats, gen_scratch(d).slabs, gen_needs(B, T));
     if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
     { const GenScratch q = gen_scratch(d); ex.wv = scratch + q.wv; ex.wm = scratch + q.wm; ex.wino_cap = q.wino_floats;
-      ex.wv2 = scratch + q.wv2; ex.wm2 = scratch + q.wm2; ex.wu = scratch + q.wu; ex.wu_cap = q.wu_floats; }
+      ex.wv2 = scratch + q.wv2; ex.wm2 = scratch + q.wm2; ex.wu = scratch + q.wu; ex.wu_cap = q.wu_floats;
+      ex.sync = reinterpret_cast<unsigned*>(scratch + q.sync); }
     ex.pack_skips = get_pack_skips(packed);
     if (ex.pack_skips & 4) return MCVC_ERR_INVALID;          // forward-only re-pack: the backward sets are stale (mcvc_gen_pack_sets)
     gen_backward_impl(ex, params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, d, milestones);

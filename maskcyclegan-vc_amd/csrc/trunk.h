@@ -74,3 +74,37 @@ int mcvc_trunk_set_fault_inject(int on);
 bool mcvc_trunk_net_applies(int B, int T4);
 int mcvc_trunk_fwd_net_launch(TrunkFwdNetArgs& a, hipStream_t s);
 #define MCVC_TRUNK_SYNC_WORDS 32
+
+// ---- persistent trunk BACKWARD: the data-gradient chain through the six residual blocks (12 dependent layers) in ONE launch ---------
+// Layer = InstanceNorm(+GLU) backward of the layer's input gradient, recomputed by every workgroup for all staged channels (a few hundred
+// flops per row), then the transposed 1x3 convolution on the fused kernels' weight copy -- what trunk_layer_kernel<3, 1, PRE> does per
+// launch -- with the hand-off of trunk_fwd_net_kernel between layers (write-through stores, one arrival counter per layer, sc1 loads).
+// The channel's owner (channel mod workgroups) also stores X' = the gradient w.r.t. the conv output (the batched weight-gradient kernel
+// reads it after the launch) and adds d(gamma), d(beta).  Every reduction runs in a fixed order: the result does not depend on timing.
+struct TrunkBwdLayerDesc {
+    const float* wt;                         // data-gradient weights [M][Cx*KW] (transposed + flipped copy, pack.h PACK_TRUNK_T)
+    const float* dy;                         // gradient w.r.t. the norm (+GLU) output [C][B][T4]
+    const float* px;                         // the forward pass's pre-norm conv output [Cx][B][T4]
+    const float* stats;                      // [B][Cx][2] mean, rstd
+    const float* g0; const float* b0; const float* g1; const float* b1;      // affine parameters (value | gate)
+    float* xout;                             // X' [Cx][B][T4]
+    float* dg0; float* db0; float* dg1; float* db1;                          // accumulated (+=); nullable
+    float* out;                              // [M][B][T4]
+    int pre, C, M, rows;                     // pre 1: plain IN (Cx = C), 2: IN + gated GLU (Cx = 2C)
+    int flags;                               // TBWD_* bits
+};
+enum { TBWD_ACCUMULATE = 1,                  // out += result (the skip connection's gradient is already there)
+       TBWD_DY_FRESH = 2,                    // dy was written by the previous layer of this launch: sc1 loads
+       TBWD_SLAB_DY = 4, TBWD_SLAB_OUT = 8 };// the chain's entering gradient arrives as K-split slabs (TrunkBwdNetArgs::slabs): add them to
+                                             // every read of dy / of the accumulated-onto out
+#define MCVC_TRUNK_BWD_LAYERS 12
+struct TrunkBwdNetArgs {
+    TrunkBwdLayerDesc L[MCVC_TRUNK_BWD_LAYERS];
+    int nlayers, B, T4, x_floats;
+    const float* slabs; long long slab_stride; int nslab;      // nslab - 1 further slabs of the entering gradient, slab_stride floats apart
+    unsigned* sync;                          // arrival counters (MCVC_TRUNK_SYNC_WORDS - 1 words, zeroed by the launcher)
+    unsigned* err;                           // sticky error word (shared with the forward kernel: mcvc_gen_trunk_fault)
+    int fault_inject;
+};
+bool mcvc_trunk_bwd_net_applies(int B, int T4);
+int mcvc_trunk_bwd_net_launch(TrunkBwdNetArgs& a, hipStream_t s);

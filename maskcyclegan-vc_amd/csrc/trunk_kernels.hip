@@ -711,6 +711,340 @@ __global__ void __launch_bounds__(kNetThreads) trunk_fwd_net_kernel(const Twin<T
     }
 }
 
+// =====================================================================================================================
+// Persistent trunk backward (see trunk.h)
+// =====================================================================================================================
+// stage X' = InstanceNorm (+ gated GLU) backward of dy for ALL Cx channels into Xs (zero halo, k = 3), same arithmetic and the same
+// 4-lanes-per-row decomposition as the PRE path of trunk_layer_kernel; owner workgroups store X' and add d(gamma), d(beta)
+__device__ __forceinline__ void bnet_stage_pre(const TrunkBwdNetArgs& a, const TrunkBwdLayerDesc& d, float* Xs, float* rsum, int B, int T4, int tid)
+{
+    constexpr int PW = 1;
+    const int TP = T4 + 2 * PW, RS = B * TP + 1;
+    const int C = d.C;
+    const bool pglu = (d.pre == 2);
+    const int Cx = pglu ? 2 * C : C;
+    const float invT = 1.0f / (float)T4;
+    const int E = (T4 + 3) >> 2;
+    const int items = Cx * B * 4;
+    const int nwg = (int)gridDim.x, me = (int)blockIdx.x;
+    if (T4 == 16 && !(d.flags & TBWD_SLAB_DY) && ((reinterpret_cast<unsigned long long>(d.dy) | reinterpret_cast<unsigned long long>(d.px) |
+                                                   reinterpret_cast<unsigned long long>(d.xout)) & 15ull) == 0) {
+        // the trainer's shape (64 frames): a lane's four elements are ONE 16-byte load per tensor, and the loads of four items per thread
+        // are all in flight before the first is used -- every workgroup stages every channel, so this loop IS the layer's latency
+        constexpr int U = 4;
+        const bool fresh = (d.flags & TBWD_DY_FRESH) != 0;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.dy), 0, C * B * 16 * 4, 0x00020000);
+        for (int it0 = 0; it0 < items; it0 += U * kNetThreads) {
+            float4 vd[U], v0[U], v1[U];
+            float g0[U], b0[U], g1[U], b1[U], m0[U], r0[U], m1[U], r1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int item = it0 + u * kNetThreads + tid;
+                const bool live = item < items;
+                const int q4 = item & 3, row = live ? (item >> 2) : 0;
+                const int cx = row / B, b = row - cx * B;
+                const bool gate = pglu && cx >= C;
+                const int c = gate ? cx - C : cx;
+                const long long ro = ((long long)c * B + b) * 16 + q4 * 4;
+                vd[u] = fresh ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro * 4), 0, 16))
+                              : *reinterpret_cast<const float4*>(d.dy + ro);
+                v0[u] = *reinterpret_cast<const float4*>(d.px + ro);
+                v1[u] = pglu ? *reinterpret_cast<const float4*>(d.px + ro + (long long)C * B * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                g0[u] = d.g0[c]; b0[u] = d.b0[c];
+                g1[u] = pglu ? d.g1[c] : 0.f; b1[u] = pglu ? d.b1[c] : 0.f;
+                const float* st = d.stats + (long long)b * Cx * 2;
+                m0[u] = st[2 * c]; r0[u] = st[2 * c + 1];
+                m1[u] = pglu ? st[2 * (c + C)] : 0.f; r1[u] = pglu ? st[2 * (c + C) + 1] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int item = it0 + u * kNetThreads + tid;
+                const bool live = item < items;
+                const int q4 = item & 3, row = live ? (item >> 2) : 0;
+                const int cx = row / B, b = row - cx * B;
+                const bool gate = pglu && cx >= C;
+                const float dv[4] = {vd[u].x, vd[u].y, vd[u].z, vd[u].w};
+                const float x0[4] = {v0[u].x, v0[u].y, v0[u].z, v0[u].w};
+                const float x1[4] = {v1[u].x, v1[u].y, v1[u].z, v1[u].w};
+                float dzv[4], xhv[4];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh0 = (x0[e] - m0[u]) * r0[u];
+                    float dz, xh;
+                    if (pglu) {
+                        const float xh1 = (x1[e] - m1[u]) * r1[u];
+                        const float sg = sigmoidf_(xh1 * g1[u] + b1[u]);
+                        if (gate) { dz = dv[e] * (xh0 * g0[u] + b0[u]) * sg * (1.0f - sg); xh = xh1; }
+                        else { dz = dv[e] * sg; xh = xh0; }
+                    } else { dz = dv[e]; xh = xh0; }
+                    dzv[e] = live ? dz : 0.f; xhv[e] = live ? xh : 0.f;
+                    s1 += dzv[e]; s2 += dzv[e] * xhv[e];
+                }
+                s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+                s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+                if (live) {
+                    const bool mine = (cx % nwg) == me;
+                    const float gr = gate ? g1[u] * r1[u] : g0[u] * r0[u];
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = gr * (dzv[e] - s1 * invT - xhv[e] * (s2 * invT));
+                    float* xrow = Xs + cx * RS + b * TP + PW + q4 * 4;
+                    xrow[0] = o[0]; xrow[1] = o[1]; xrow[2] = o[2]; xrow[3] = o[3];
+                    if (mine) *reinterpret_cast<float4*>(d.xout + ((long long)cx * B + b) * 16 + q4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (q4 == 0) {
+                        float* xr = Xs + cx * RS + b * TP;
+                        xr[0] = 0.f; xr[PW + 16] = 0.f;
+                        if (b == 0) Xs[cx * RS + B * TP] = 0.f;
+                        if (mine) { rsum[((cx / nwg) * B + b) * 2] = s1; rsum[((cx / nwg) * B + b) * 2 + 1] = s2; }
+                    }
+                }
+            }
+        }
+    } else
+    for (int it0 = 0; it0 < items; it0 += kNetThreads) {
+        const int item = it0 + tid;
+        const bool live = item < items;
+        const int q4 = item & 3, row = live ? (item >> 2) : 0;
+        const int cx = row / B, b = row - cx * B;
+        const bool gate = pglu && cx >= C;
+        const int c = gate ? cx - C : cx;
+        const float g0 = d.g0[c], b0 = d.b0[c];
+        const float g1 = pglu ? d.g1[c] : 0.f, b1 = pglu ? d.b1[c] : 0.f;
+        const float* st = d.stats + (long long)b * Cx * 2;
+        const float m0 = st[2 * c], r0 = st[2 * c + 1];
+        const float m1 = pglu ? st[2 * (c + C)] : 0.f, r1 = pglu ? st[2 * (c + C) + 1] : 1.f;
+        const int t0 = q4 * E;
+        const float* dyr = d.dy + ((long long)c * B + b) * T4 + t0;
+        const float* x0r = d.px + ((long long)c * B + b) * T4 + t0;
+        const float* x1r = d.px + ((long long)(c + C) * B + b) * T4 + t0;
+        float vd[8], v0[8], v1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = live && e < E && (t0 + e) < T4;
+            // dy written by other workgroups of this launch (write-through): sc1 loads, never this CU's possibly stale L1
+            vd[e] = ok ? ((d.flags & TBWD_DY_FRESH) ? __hip_atomic_load(dyr + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : dyr[e]) : 0.f;
+            if (ok && (d.flags & TBWD_SLAB_DY))
+                for (int sl = 1; sl < a.nslab; ++sl) vd[e] += a.slabs[(long long)(sl - 1) * a.slab_stride + ((long long)c * B + b) * T4 + t0 + e];
+            v0[e] = ok ? x0r[e] : 0.f; v1[e] = (ok && pglu) ? x1r[e] : 0.f;
+        }
+        float dzv[8], xhv[8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool ok = e < E && (t0 + e) < T4;
+            const float xh0 = (v0[e] - m0) * r0;
+            float dz, xh;
+            if (pglu) {
+                const float xh1 = (v1[e] - m1) * r1;
+                const float sg = sigmoidf_(xh1 * g1 + b1);
+                if (gate) { dz = vd[e] * (xh0 * g0 + b0) * sg * (1.0f - sg); xh = xh1; }
+                else { dz = vd[e] * sg; xh = xh0; }
+            } else { dz = vd[e]; xh = xh0; }
+            dzv[e] = ok ? dz : 0.f; xhv[e] = ok ? xh : 0.f;
+            s1 += dzv[e]; s2 += dzv[e] * xhv[e];
+        }
+        s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+        s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+        if (live) {
+            const bool mine = (cx % nwg) == me;
+            const float gr = gate ? g1 * r1 : g0 * r0;
+            float* xrow = Xs + cx * RS + b * TP;
+            float* od = mine ? (d.xout + ((long long)cx * B + b) * T4 + t0) : nullptr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (e < E && (t0 + e) < T4) {
+                    const float dxv = gr * (dzv[e] - s1 * invT - xhv[e] * (s2 * invT));
+                    xrow[PW + t0 + e] = dxv;
+                    if (od) od[e] = dxv;
+                }
+            }
+            if (q4 == 0) {
+                xrow[0] = 0.f; xrow[PW + T4] = 0.f;
+                if (b == 0) Xs[cx * RS + B * TP] = 0.f;
+                if (mine) { rsum[((cx / nwg) * B + b) * 2] = s1; rsum[((cx / nwg) * B + b) * 2 + 1] = s2; }
+            }
+        }
+    }
+    __syncthreads();
+    // d(gamma), d(beta) of the owned channels: sums over the samples in a fixed order
+    for (int j = tid; j * nwg + me < Cx; j += kNetThreads) {
+        const int cx = j * nwg + me;
+        const bool gate = pglu && cx >= C;
+        const int c = gate ? cx - C : cx;
+        float dgam = 0.f, dbet = 0.f;
+        for (int b = 0; b < B; ++b) { dbet += rsum[(j * B + b) * 2]; dgam += rsum[(j * B + b) * 2 + 1]; }
+        float* dg = gate ? d.dg1 : d.dg0;
+        float* db = gate ? d.db1 : d.db0;
+        if (dg) dg[c] += dgam;
+        if (db) db[c] += dbet;
+    }
+}
+
+// one tile of `rows` output rows: transposed conv over the staged X' (K split over the 8 waves), summed in a fixed order, stored
+// write-through (+ the old value when the layer accumulates onto the skip connection's gradient)
+template <int NA>
+__device__ __forceinline__ void bnet_tile(const TrunkBwdLayerDesc& d, int B, int T4, int tile, const float* Xs, float* epi, bool wt,
+                                          NetW<3>& pre, float old)
+{
+    constexpr int KW = 3, PW = 1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int TP = T4 + 2 * PW, RS = B * TP + 1;
+    const int N = B * T4;
+    const int Cx = (d.pre == 2) ? 2 * d.C : d.C;
+    const int K = Cx * KW;
+    const int rows = d.rows, r0 = tile * rows;
+    const int k_count = K / kNetWaves;
+    const int k_begin = wave * k_count;
+    const float* arow = d.wt + (long long)(r0 + (l15 < rows ? l15 : rows - 1)) * K;
+    constexpr int NQ = 3, GK = 48, CH = 4;
+    const int sgroups = k_count / GK;
+    const float* ap = arow + k_begin + 4 * kq;
+    float4 (&wb)[CH][NQ] = pre.wb;
+    int off[NA][NQ][4];
+#pragma unroll
+    for (int h = 0; h < NA; ++h) {
+        const int n = l15 + 16 * h;
+        int xcol = B * TP, live = 0;
+        if (n < N) { const int b = n / T4, t = n - b * T4; xcol = b * TP + t; live = 1; }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kr = 16 * q + 4 * kq + j;
+                off[h][q][j] = (kr / KW) * RS + xcol + (live ? (kr % KW) : 0);
+            }
+    }
+    f32x4 acc[NA];
+#pragma unroll
+    for (int h = 0; h < NA; ++h) acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const float* xs = Xs + (k_begin / KW) * RS;
+        for (int sg0 = 0; sg0 < sgroups; sg0 += CH) {
+            if (sg0 > 0) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const float* pp = ap + (long long)(sg0 + c < sgroups ? sg0 + c : 0) * GK;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) wb[c][q] = *reinterpret_cast<const float4*>(pp + 16 * q);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (sg0 + c < sgroups) {
+                    float xv[NQ][4][NA];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int h = 0; h < NA; ++h) xv[q][j][h] = xs[off[h][q][j]];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const float av[4] = {wb[c][q].x, wb[c][q].y, wb[c][q].z, wb[c][q].w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int h = 0; h < NA; ++h) acc[h] = MFMA16(av[j], xv[q][j][h], acc[h]);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, NQ * 4 * NA, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NQ * 4 * NA, 0);
+                    xs += (GK / KW) * RS;
+                }
+            }
+        }
+    }
+    float* red = epi;
+#pragma unroll
+    for (int h = 0; h < NA; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * NA + h) * 4 + r) * 64 + lane] = acc[h][r];
+    __syncthreads();
+    if (tid < rows * N) {
+        const int mrow = tid / N, col = tid - mrow * N;
+        const int h = col >> 4, ln = ((mrow >> 2) << 4) + (col & 15), r = mrow & 3;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < kNetWaves; ++w) v += red[((w * NA + h) * 4 + r) * 64 + ln];
+        if (d.flags & TBWD_ACCUMULATE) v += old;
+        float* dst = d.out + (long long)(r0 + mrow) * N + col;
+        if (wt) st_wt(dst, v); else *dst = v;
+    }
+}
+
+static_assert(sizeof(Twin<TrunkBwdNetArgs>) <= 4096 && sizeof(Twin<TrunkFwdNetArgs>) <= 4096, "kernel arguments are limited to 4 KB");
+template <int NA>
+__global__ void __launch_bounds__(kNetThreads) trunk_bwd_net_kernel(const Twin<TrunkBwdNetArgs> tw)
+{
+    const TrunkBwdNetArgs& a = tw.v[blockIdx.z];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;
+    float* rsum = smem + a.x_floats;                       // [ceil(Cx / workgroups)][B][2]
+    float* epi = rsum + 16 * 8 * 2 * 2;                    // (Cx <= 1024, 64 workgroups, B <= 8)
+    float* flag = epi + kNetWaves * 2 * 4 * 64;
+    const int tid = threadIdx.x;
+    const int N = a.B * a.T4;
+    for (int l = 0; l < a.nlayers; ++l) {
+        const TrunkBwdLayerDesc& d = a.L[l];
+        const int ntiles = d.M / d.rows;
+        const int Cx = (d.pre == 2) ? 2 * d.C : d.C;
+        // this layer's weights (and the value it accumulates onto: this workgroup's own rows) do not depend on the previous layer
+        NetW<3> w3;
+        TrunkLayerDesc wd{};
+        wd.a0 = d.wt; wd.Cin = Cx; wd.KW = 3; wd.M = d.M; wd.mode = TRUNK_PLAIN; wd.rows = d.rows;
+        const bool mine = (int)blockIdx.x < ntiles;
+        float old = 0.f;
+        auto load_old = [&](int tile) {
+            float v = 0.f;
+            if ((d.flags & TBWD_ACCUMULATE) && tid < d.rows * N) {
+                const long long idx = (long long)(tile * d.rows) * N + tid;
+                v = __hip_atomic_load(d.out + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (d.flags & TBWD_SLAB_OUT)
+                    for (int sl = 1; sl < a.nslab; ++sl) v += a.slabs[(long long)(sl - 1) * a.slab_stride + idx];
+            }
+            return v;
+        };
+        if (mine) {
+            net_load_w<3>(wd, blockIdx.x, w3);
+            old = load_old(blockIdx.x);
+        }
+        if (l > 0) {
+            if (tid == 0) {
+                const bool ok = wait_arrivals(a.sync + (l - 1), gridDim.x);
+                if (!ok) __hip_atomic_store(a.err, 0x100u + (unsigned)l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                flag[0] = ok ? 1.f : 0.f;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (flag[0] == 0.f) {                  // a workgroup never arrived: poison the result (the trunk's input gradient) and give up
+                const TrunkBwdLayerDesc& dl = a.L[a.nlayers - 1];
+                for (int tile = blockIdx.x; tile < dl.M / dl.rows; tile += gridDim.x)
+                    for (int i = tid; i < dl.rows * N; i += kNetThreads) dl.out[(long long)(tile * dl.rows) * N + i] = __builtin_nanf("");
+                return;
+            }
+        }
+        bnet_stage_pre(a, d, Xs, rsum, a.B, a.T4, tid);
+        __syncthreads();
+        const bool wt = (l + 1 < a.nlayers);
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            if (tile != (int)blockIdx.x) {
+                net_load_w<3>(wd, tile, w3);
+                old = load_old(tile);
+            }
+            bnet_tile<NA>(d, a.B, a.T4, tile, Xs, epi, wt, w3, old);
+        }
+        if (wt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0 && !(a.fault_inject && l == 0 && blockIdx.x == 0))
+                __hip_atomic_fetch_add(a.sync + l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 struct ZeroWordsKArgs { unsigned* p; int n; };
 __global__ void zero_words_kernel(const Twin<ZeroWordsKArgs> tw)
 {
@@ -811,6 +1145,13 @@ bool mcvc_trunk_net_applies(int B, int T4)
     return (x + kNetEpiFloats) * 4 <= 156 * 1024;
 }
 
+bool mcvc_trunk_bwd_net_applies(int B, int T4)
+{
+    if (B < 1 || B > 8 || T4 < 4 || T4 > 32 || B * T4 > 32) return false;
+    const long long x = (long long)1024 * (B * (T4 + 2) + 1);          // widest staged gradient: 1024 channels (value | gate), k = 3
+    return (x + 16 * 8 * 2 * 2 + kNetWaves * 2 * 4 * 64 + 16) * 4 <= 156 * 1024;
+}
+
 // test hook (mcvc_debug_trunk_fault_inject): the next persistent launches lose one arrival, so that the give-up path can be exercised
 static int g_trunk_fault_inject = 0;
 int mcvc_trunk_set_fault_inject(int on) { const int was = g_trunk_fault_inject; g_trunk_fault_inject = on ? 1 : 0; return was; }
@@ -852,5 +1193,41 @@ int mcvc_trunk_fwd_net_launch(TrunkFwdNetArgs& a, hipStream_t s)
     }
     if (wide) mcvc_launch(trunk_fwd_net_kernel<2>, dim3(kNetGrid), dim3(kNetThreads), lds, s, a);
     else mcvc_launch(trunk_fwd_net_kernel<1>, dim3(kNetGrid), dim3(kNetThreads), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_trunk_bwd_net_launch(TrunkBwdNetArgs& a, hipStream_t s)
+{
+    if (!mcvc_trunk_bwd_net_applies(a.B, a.T4) || a.nlayers < 1 || a.nlayers > MCVC_TRUNK_BWD_LAYERS || !a.sync || !a.err) return MCVC_ERR_INVALID;
+    long long xmax = 0;
+    double flops = 0.0, bytes = 0.0;
+    const int N = a.B * a.T4;
+    for (int l = 0; l < a.nlayers; ++l) {
+        const TrunkBwdLayerDesc& d = a.L[l];
+        const int Cx = (d.pre == 2) ? 2 * d.C : d.C;
+        const int K = Cx * 3;
+        if ((d.pre != 1 && d.pre != 2) || Cx > 1024 || K % (48 * kNetWaves) != 0 || d.rows < 1 || d.rows > 16 || d.M % d.rows != 0 || d.rows * N > kNetThreads)
+            return MCVC_ERR_INVALID;
+        const long long x = (long long)Cx * (a.B * (a.T4 + 2) + 1);
+        if (x > xmax) xmax = x;
+        flops += 2.0 * d.M * K * N;
+        bytes += 4.0 * ((double)d.M * K + 3.0 * Cx * N + 2.0 * d.M * N);
+    }
+    a.x_floats = (int)((xmax + 3) & ~3LL);
+    a.fault_inject = g_trunk_fault_inject;
+    const size_t lds = ((size_t)a.x_floats + 16 * 8 * 2 * 2 + kNetWaves * 2 * 4 * 64 + 16) * sizeof(float);
+    if (lds > 160 * 1024) return MCVC_ERR_INVALID;
+    mcvc_launch(zero_words_kernel, dim3(1), dim3(64), 0, s, ZeroWordsKArgs{a.sync, MCVC_TRUNK_SYNC_WORDS - 1});
+    TraceScope ts(K_TRUNK, s, flops, bytes);
+    const bool wide = N > 16;
+    static bool done[2] = {false, false};
+    if (!done[wide]) {
+        const void* fn = wide ? reinterpret_cast<const void*>(trunk_bwd_net_kernel<2>) : reinterpret_cast<const void*>(trunk_bwd_net_kernel<1>);
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done[wide] = true;
+    }
+    if (wide) mcvc_launch(trunk_bwd_net_kernel<2>, dim3(kNetGrid), dim3(kNetThreads), lds, s, a);
+    else mcvc_launch(trunk_bwd_net_kernel<1>, dim3(kNetGrid), dim3(kNetThreads), lds, s, a);
     return (int)hipGetLastError();
 }

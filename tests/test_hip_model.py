@@ -207,6 +207,67 @@ def test_persistent_trunk_forward_matches_the_per_layer_launches(B, T):
         L.mcvc_set_trunk_persistent(was)
 
 
+@pytest.mark.parametrize("B,T", [(1, 64), (1, 32)])
+def test_persistent_trunk_backward_matches_the_per_layer_launches(B, T):
+    """The backward pass's data-gradient chain through the six residual blocks (12 dependent layers, reference model.py:47-76 under
+    autograd) as ONE persistent launch (trunk.h) against one fused launch per layer: the input gradient and EVERY parameter gradient agree
+    to rounding (the persistent kernel sums each K range in a fixed order, the per-layer path K-splits with atomics); repeated with fresh
+    inputs into the same buffers (a stale line of the in-kernel hand-off would be a wrong value, not a rounding difference); and the
+    persistent result is bit-reproducible run to run.  The launch count of the trunk family drops by the 11 saved boundaries."""
+    from mask_cyclegan_vc._hip import check, lib, ptr, ptr_table, stream
+    L = lib()
+    g = Generator()
+    g.load_state_dict(orc.filler_params("G", 37), strict=True)
+    g = g.cuda()
+    ps = list(g.parameters())
+    packed = g.packed_weights(ps, force=True)
+    n_stash, n_scr = L.mcvc_gen_stash_floats(B, T), L.mcvc_gen_scratch_floats(B, T)
+    stash = torch.zeros(n_stash, device="cuda")
+    scratch = torch.zeros(n_scr, device="cuda")
+    out = torch.empty(B, 80, L.mcvc_gen_out_frames(T), device="cuda")
+    tab = ptr_table(ps)
+    grads = [[torch.zeros_like(p) for p in ps] for _ in range(3)]
+    gtabs = [ptr_table(gs) for gs in grads]
+    dxs = [torch.zeros(B, 80, T, device="cuda") for _ in range(3)]
+    was = L.mcvc_set_trunk_persistent(1)
+    was_det = L.mcvc_set_deterministic(1)
+    counts = {}
+    try:
+        for it in range(6):
+            x = torch.randn(B, 80, T, device="cuda") * (1.0 + it)
+            m = torch.ones_like(x)
+            m[:, :, 3 * it:3 * it + 5] = 0
+            dout = torch.randn(B, 80, T, device="cuda")
+            L.mcvc_set_trunk_persistent(1)
+            check(L.mcvc_gen_forward(tab, ptr(packed), ptr(x), ptr(m), ptr(out), ptr(stash), ptr(scratch), n_scr, B, T, stream()), "fwd")
+            for k, on in enumerate((1, 2, 1)):             # persistent backward, per-layer backward, persistent again
+                L.mcvc_set_trunk_persistent(on)
+                for gt in grads[k]:
+                    gt.zero_()
+
+                def bwd(k=k):
+                    check(L.mcvc_gen_backward(tab, ptr(packed), gtabs[k], ptr(m), ptr(dout), ptr(dxs[k]), 0, ptr(stash), ptr(scratch), n_scr, B, T,
+                                              stream(), None), "bwd")
+                if it == 0 and k < 2:
+                    counts[on] = _launches("trunk_layer", bwd)
+                else:
+                    bwd()
+            torch.cuda.synchronize()
+            assert float((dxs[0] - dxs[1]).norm()) <= 2e-5 * float(dxs[1].norm()), it
+            for i, (a_, b_) in enumerate(zip(grads[0], grads[1])):
+                nb = float(b_.norm())
+                if nb < 1e-4:                                  # conv biases in front of an InstanceNorm: mathematically zero, rounding noise
+                    continue
+                assert float((a_ - b_).norm()) <= 2e-5 * nb + 1e-9, (it, i, float((a_ - b_).norm()), nb)
+            assert torch.equal(dxs[0], dxs[2])             # (deterministic mode: the layers around the trunk take fixed-order paths too)
+            for i in range(len(ps)):
+                assert torch.equal(grads[0][i], grads[2][i]), (it, i)
+        assert counts[1] == counts[2] - 11, counts
+    finally:
+        L.mcvc_set_trunk_persistent(was)
+        L.mcvc_set_deterministic(was_det)
+
+
 def _launches(kind_name, fn):
     """Run fn() with the library's per-launch trace on; returns the number of launches of one kernel family."""
     import ctypes
