@@ -67,7 +67,7 @@ def kink_free_seeds(eng, n, seed0, margin=3e-5):
     return keep
 
 
-PER_RANK = 8          # BASELINE configs[3]: bs=8 per GPU
+PER_RANK = int(os.environ.get("MCVC_TEST_DDP_PER_RANK", "8"))          # BASELINE configs[3]: bs=8 per GPU (2: the grouped + pipelined schedule)
 
 
 def main():
@@ -114,15 +114,25 @@ def main():
     del eng
     eng2 = TrainEngine(nets_for(800), PER_RANK, 64, schedule=StepSchedule(batch_size=PER_RANK, n_samples=64, world_size=world),
                        reducer=FlatGradReducer())
-    mean_losses = []
+    mean_losses, mine_losses = [], []
     for it in range(3):
-        eng2.step(*batch_of(range(100 + 16 * it + 8 * rank, 100 + 16 * it + 8 * rank + PER_RANK)))
-        lo = eng2.losses()
+        eng2.step(*batch_of(range(100 + 2 * PER_RANK * it + PER_RANK * rank, 100 + 2 * PER_RANK * it + PER_RANK * rank + PER_RANK)))
+        # pipelined schedule (small batch): the losses of the last COMPLETE iteration, one step behind -- reading the current ones every
+        # iteration would complete the pending discriminator phase and never exercise the pipelined graph
+        lo = eng2.losses(lagged=True)
+        if lo is not None and (eng2._pending_D is None or it > 0):
+            mine_losses.append(lo)
+    if eng2._pending_D is not None:
+        mine_losses.append(eng2.losses())
+    eng2.flush()
+    assert len(mine_losses) == 3
+    if rank == 0:
+        print("pipelined schedule: %s" % bool(eng2._use_pipeline()), flush=True)
+    for lo in mine_losses:
         assert np.isfinite(lo["g_loss"]) and np.isfinite(lo["d_loss"])
         t = torch.tensor([lo["g_loss"], lo["d_loss"]], dtype=torch.float64, device=cdev)
         dist.all_reduce(t)
         mean_losses.append((t / world).tolist())
-    eng2.flush()
     # ---- (3) the same three iterations in ONE process on the concatenated minibatches: the losses (means over the global batch) must
     # agree -- exactly the arithmetic before the first update, and closely after two (Adam's first steps amplify rounding)
     if rank == 0:
@@ -130,7 +140,7 @@ def main():
         solo.world = 1
         ref = TrainEngine(nets_for(800), 2 * PER_RANK, 64, schedule=StepSchedule(batch_size=2 * PER_RANK, n_samples=64), reducer=solo)
         for it in range(3):
-            ref.step(*batch_of(range(100 + 16 * it, 100 + 16 * it + 2 * PER_RANK)))
+            ref.step(*batch_of(range(100 + 2 * PER_RANK * it, 100 + 2 * PER_RANK * it + 2 * PER_RANK)))
             lo = ref.losses()
             for a, b in zip(mean_losses[it], (lo["g_loss"], lo["d_loss"])):
                 tol = 1e-4 if it == 0 else 5e-2

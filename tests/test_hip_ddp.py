@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(backend, port):
-    env = dict(os.environ, MCVC_TEST_DDP_BACKEND=backend, MCVC_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run(backend, port, per_rank=8):
+    env = dict(os.environ, MCVC_TEST_DDP_BACKEND=backend, MCVC_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               MCVC_TEST_DDP_PER_RANK=str(per_rank))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(HERE, "ddp_worker.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
@@ -35,3 +36,14 @@ def test_two_ranks_match_one_process_and_each_other():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (this box has fewer than two)")
 def test_two_ranks_over_rccl_one_gpu_each():
     _run("nccl", 29535)
+
+
+def test_two_ranks_small_batch_grouped_pipelined_schedule():
+    """bs=2 per rank: the ranks run the grouped launches and the pipelined step (engine._pipelined_step: per-pair discriminator exchanges
+    inside the task graph, generator ranges behind the milestone events of the grouped last backward pass)."""
+    _run("gloo", 29537, per_rank=2)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (this box has fewer than two)")
+def test_two_ranks_over_rccl_small_batch():
+    _run("nccl", 29539, per_rank=2)
