@@ -130,6 +130,17 @@ int mcvc_gen_backward_overlap(const float* const* params, const float* packed, f
 int mcvc_gen_trunk_fault(float* scratch, int B, int T, int reset, void* stream);
 int mcvc_debug_trunk_fault_inject(int on);
 
+/*      Same with flags.  MCVC_BWD_NO_JOIN (1): return WITHOUT ordering `stream` after the weight-gradient kernels still running on aux_stream
+ *      (the data-gradient result dx is complete on `stream`).  The caller then owes: (i) the next pass that accumulates into the same gradient
+ *      tensors uses the SAME aux_stream (in-order) or waits for it, (ii) `scratch` and `stash` of this pass stay untouched until aux_stream
+ *      has drained (the next pass uses other buffers), (iii) a later pass on that aux_stream joins (flags = 0) before the gradients are read.
+ *      The trainer runs the cycle pass's backward this way: the translation pass's data-gradient chain starts ~0.2 ms earlier.       */
+#define MCVC_BWD_NO_JOIN 1
+int mcvc_gen_backward_flags(const float* const* params, const float* packed, float* const* grads, const float* mask,
+                            const float* dout, float* dx, int accumulate_dx, const float* stash,
+                            float* scratch, long long scratch_floats, int B, int T, void* stream, void* aux_stream,
+                            void* const* milestones, int flags);
+
 /* ---- Generator inference in bf16 (BASELINE configs[4]: generator_A2B, bs=16, 80 x 512 frames).  Replaces the call
  *      `generator(real, ones_like(real))` of the reference's inference driver (mask_cyclegan_vc/test.py:92, 107 ->
  *      Generator.forward, model.py:239-280) when the caller asks for bf16: NHWC bf16 activations, bf16 MFMA with fp32

@@ -60,6 +60,7 @@ struct Exec {
     float* sgw; long long sgw_cap, sgw_need; // ... and the weight gradients' own (they may run on the auxiliary stream beside a data gradient)
     const float* const* params;    // the pass's parameter table (that path's data gradient multiplies the OIHW tensors themselves)
     int br1_on_main = 0;           // conv_wgrad: run the gate branch's generic weight gradient on the main stream (see there)
+    int no_join = 0;               // backward pass: leave the auxiliary stream un-joined at the end (mcvc_gen_backward_flags)
     int fuse_next = 0;             // the caller's next step is a norm that can absorb a Winograd output transform (set before conv_fwd)
     int pend_pts = 0;              // 16 / 36: the output transform in `pend` has not run yet -- norm_fwd runs it (fused when it fits)
     WinoOutArgs pend;
@@ -1440,7 +1441,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
             if (!ex.dry) ex.fail(mcvc_mask_grad_launch(GA, ex.slabs, (long long)B * 2 * 80 * T, ns, mask, dx, B, 80 * T, 2, accumulate_dx, ex.s));
         }
     }
-    join_aux(ex);
+    if (ex.no_join) ex.readers.clear(); else join_aux(ex);
 }
 
 // =================================================================================================
@@ -1883,6 +1884,14 @@ int mcvc_gen_backward_overlap(const float* const* params, const float* packed, f
                               float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T,
                               void* stream, void* aux_stream, void* const* milestones)
 {
+    return mcvc_gen_backward_flags(params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, scratch_floats, B, T, stream, aux_stream,
+                                   milestones, 0);
+}
+
+int mcvc_gen_backward_flags(const float* const* params, const float* packed, float* const* grads, const float* mask, const float* dout,
+                            float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T,
+                            void* stream, void* aux_stream, void* const* milestones, int flags)
+{
     if (B < 1 || T < 1 || !params || !packed || !dout || !stash || !scratch) return MCVC_ERR_INVALID;
     const GenDims d = gen_dims(B, T);
     Exec ex = make_exec(stream, aux_stream, scratch, scratch_floats, gen_scratch(d).slabs, gen_needs(B, T));
@@ -1892,6 +1901,7 @@ int mcvc_gen_backward_overlap(const float* const* params, const float* packed, f
       ex.sync = reinterpret_cast<unsigned*>(scratch + q.sync); }
     ex.pack_skips = get_pack_skips(packed);
     if (ex.pack_skips & 4) return MCVC_ERR_INVALID;          // forward-only re-pack: the backward sets are stale (mcvc_gen_pack_sets)
+    ex.no_join = (flags & 1) && aux_stream;
     gen_backward_impl(ex, params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, d, milestones);
     return ex.err;
 }

@@ -189,6 +189,7 @@ class TrainEngine:
         # generator phase, as one task graph (_pipelined_step); MCVC_PIPELINE=0 keeps the two phases of an iteration back to back.
         self.pipelined = os.environ.get("MCVC_PIPELINE", "1") != "0"
         self.ranged_update = os.environ.get("MCVC_RANGED_UPDATE", "1") != "0"
+        self.bwd_no_join = os.environ.get("MCVC_BWD_NO_JOIN", "1") != "0"
         self._pending_D = None                  # (input set, discriminator lr) of the iteration whose discriminator phase is still to run
         self.slots_done = torch.zeros(2 * _BLOCK, device=dev)          # loss slots of the last COMPLETE iteration
         self._done_host = torch.zeros(2 * _BLOCK).pin_memory()
@@ -440,7 +441,7 @@ class TrainEngine:
                    lambda: check(self.L.mcvc_gen_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(mask), ptr(out), ptr(stash),
                                                          ptr(sc), sc.numel(), nb, self.T, stream()), "gen_forward"))
 
-    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0, milestones=False, aux_lane=None, ms_of=None, second=False):
+    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0, milestones=False, aux_lane=None, ms_of=None, second=False, no_join=False):
         """``lane`` picks the scratch buffer; ``aux_lane`` (default: the same) the auxiliary weight-gradient stream -- the two halves of a
         grouped pass use different scratch buffers but the same streams and milestone events (``ms_of``)."""
         sc = self.g_scratch[lane]
@@ -448,10 +449,10 @@ class TrainEngine:
         aux = self._aux_ptr(lane if aux_lane is None else aux_lane)
         gtab = self._g_tab2[name] if second else self._g_tab[name]          # second: weight gradients into the second buffer
         self._pass(("Gb", name, 0 if mask is None else mask.data_ptr(), dout.data_ptr(), 0 if dx is None else dx.data_ptr(), acc, stash.data_ptr(),
-                    nb, lane, bool(milestones), self.aux_wgrad, second),
-                   lambda: check(self.L.mcvc_gen_backward_overlap(self._p_tab[name], ptr(self.packed[name]), gtab, ptr(mask), ptr(dout),
-                                                                  ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(),
-                                                                  aux, ms), "gen_backward"))
+                    nb, lane, bool(milestones), self.aux_wgrad, second, no_join),
+                   lambda: check(self.L.mcvc_gen_backward_flags(self._p_tab[name], ptr(self.packed[name]), gtab, ptr(mask), ptr(dout),
+                                                                ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(),
+                                                                aux, ms, 1 if no_join else 0), "gen_backward"))
 
     def _D(self, name, x, out, stash, nb, lane=0):
         sc = self.d_scratch[lane]
@@ -459,12 +460,13 @@ class TrainEngine:
                    lambda: check(self.L.mcvc_disc_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(out), ptr(stash), ptr(sc),
                                                           sc.numel(), nb, self.T, stream()), "disc_forward"))
 
-    def _D_bwd(self, name, dlogit, dx, acc, stash, with_weight_grads, nb, lane=0):
+    def _D_bwd(self, name, dlogit, dx, acc, stash, with_weight_grads, nb, lane=0, aux_stream=None):
         sc = self.d_scratch[lane]
+        aux = ctypes.c_void_p(aux_stream.cuda_stream) if (aux_stream is not None and with_weight_grads and self.aux_wgrad) else \
+            (self._aux_ptr(lane) if (with_weight_grads and self.aux_wgrad_d) else None)
         self._pass(("Db", name, dlogit.data_ptr(), 0 if dx is None else dx.data_ptr(), acc, stash.data_ptr(), bool(with_weight_grads), nb, lane),
                    lambda: check(self.L.mcvc_disc_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name] if with_weight_grads else None,
-                                                           ptr(dlogit), 1, ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(),
-                                                           self._aux_ptr(lane) if (with_weight_grads and self.aux_wgrad_d) else None),
+                                                           ptr(dlogit), 1, ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(), aux),
                                  "disc_backward"))
 
     def _slot(self, i):
@@ -698,14 +700,21 @@ class TrainEngine:
             self._twin(lambda: adv_half("discriminator_A2", 2, m["cycle_A"], m["g_cycle_A"], 1),
                        lambda: adv_half("discriminator_B2", 3, m["cycle_B"], m["g_cycle_B"], 1))
 
+        # The cycle pass's weight gradients (auxiliary stream) outlast its data-gradient chain by ~0.2 ms; the translation pass needs only
+        # the data gradient, so it starts without that join: its own weight gradients queue behind them on the same auxiliary stream
+        # (same tensors, in order), it works in other scratch buffers (4, 5: free since D-phase(t)'s generator forwards), and its final
+        # join covers both passes.  (MCVC_BWD_NO_JOIN=0: join after every pass.)
+        nj = self.bwd_no_join and ident
+        fs = (4, 5) if nj else (0, 1)
+
         def bwd_cycle(ln):      # cycle_A = G_B2A(fake_B) adds to d(fake_B), cycle_B = G_A2B(fake_A) to d(fake_A)
-            self._twin(lambda: self._G_bwd(B2A, None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B, 0, aux_lane=0),
-                       lambda: self._G_bwd(A2B, None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, 1, aux_lane=0))
+            self._twin(lambda: self._G_bwd(B2A, None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B, 0, aux_lane=0, no_join=nj),
+                       lambda: self._G_bwd(A2B, None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, 1, aux_lane=0, no_join=nj))
 
         def bwd_final(ln):      # the last pass over each generator; its gradient ranges become final one after the other (milestone events)
             nb = B if ident else B2
-            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], nb, 0, ms_on, aux_lane=0, ms_of=A2B),
-                       lambda: self._G_bwd(B2A, self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], nb, 1, ms_on, aux_lane=0, ms_of=A2B))
+            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], nb, fs[0], ms_on, aux_lane=0, ms_of=A2B),
+                       lambda: self._G_bwd(B2A, self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], nb, fs[1], ms_on, aux_lane=0, ms_of=A2B))
 
         def queue_reduce(ln):
             # data parallel: range k of BOTH generators is final at milestone k of the grouped pass; same collective order on every rank
@@ -783,7 +792,7 @@ class TrainEngine:
             self._g_grad_clean = True          # (cleared by the Adam launch that consumed them)
         p["post"]()
 
-    def _d_parts(self, inp, gi=0):
+    def _d_parts(self, inp, gi=0, aux2=None):
         """Closures of the discriminator phase (train.py:247-299) in grouped launches.  ``gi``: index of the (stash, scratch) pair its two
         generator forwards use -- 0 = the cycle passes' (plain step: the phases run one after the other), 2 = their own (pipelined step:
         they run beside the next iteration's generator phase)."""
@@ -814,7 +823,8 @@ class TrainEngine:
             self._D(name, di[name], do[i], ds[i], B2, i)                       # :255-258 real half, :260-273 generated half
             self._lsgan(do[i][:B], 1.0, 0.25, 8 + 2 * i, dl[i][:B])            # every term of d_loss weighs 1/4 (:276-294)
             self._lsgan(do[i][B:], 0.0, 0.25, 9 + 2 * i, dl[i][B:])
-            self._D_bwd(name, dl[i], None, 0, ds[i], True, B2, i)
+            # (pipelined step: the second-step pair closes the critical chain; its weight gradients run on an idle lane's stream)
+            self._D_bwd(name, dl[i], None, 0, ds[i], True, B2, i, aux_stream=aux2 if i >= 2 else None)
 
         def disc_half(name, fake):
             i = idx[name]
@@ -931,7 +941,7 @@ class TrainEngine:
             g["post"]()
             return
         self.slots_done[:_BLOCK].copy_(self.slots[:_BLOCK])           # g_loss and its terms of iteration t, before the block is reused
-        d = self._d_parts(prev, gi=2)
+        d = self._d_parts(prev, gi=2, aux2=self._sides[1] if os.environ.get("MCVC_D2_AUX", "1") != "0" else None)   # (lane 2: idle until "dupd1")
         g["pre"](zero_grads=False)             # (all gradient buffers were cleared by the Adam steps that consumed them)
         d["pre"](zero_grads=False)
         packed = self._g_fwd_packed
