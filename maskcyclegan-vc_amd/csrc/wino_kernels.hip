@@ -419,6 +419,156 @@ __global__ void __launch_bounds__(256) wino_dy_t_kernel(const Twin<WinoXformArgs
     }
 }
 
+// ---- tile-major operands through an LDS transpose (r3) ---------------------------------------------------------------------------
+// The kernels above give a lane one (tile, channel) and let 16 lanes walk the channels: 64-byte stores and reads scattered over 16
+// channel planes (1.7 TB/s at bs=1, 2-3 TB/s at bs=32 for outputs 9x / 4x the size of their input).  Here a workgroup owns 8 consecutive
+// tiles x 64 channels: lanes walk the TILES while reading (a channel's 8 tiles are one 64-byte run of a row), the transformed values
+// go through LDS [point][tile][channel], and every store is a 256-byte run of 64 channels.
+//   KIND 0: V^T of the F(2x2,5x5) input (6x6 window, pad)      1: dM^T = A dY A^T, 36 points
+//   KIND 2: V^T of the phase-plane F(2x2,3x3) input            3: dM^T, 16 points
+struct XformTKArgs { WinoXformArgs a; int XH; int XW; };
+constexpr int kXT = 8, kXC = 64, kXPitch = 68;
+
+template <int KIND>
+__device__ __forceinline__ void xform_t_compute(const WinoXformArgs& a, int XH, int XW, int tile, int c, float* o)
+{
+    const int per = a.TH * a.TW;
+    const int n = tile / per, r = tile - n * per;
+    const int ty = r / a.TW, tx = r - ty * a.TW;
+    if constexpr (KIND == 0) {
+        const int ih0 = 2 * ty - a.pad, iw0 = 2 * tx - a.pad;
+        const float* src = a.x + (long long)n * a.x_sb + (long long)c * a.x_sc;
+        float t[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float d[6];
+            const int ih = ih0 + i;
+            const bool rok = (ih >= 0) && (ih < a.H);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int iw = iw0 + j;
+                d[j] = (rok && iw >= 0 && iw < a.W) ? src[(long long)ih * a.x_sh + iw] : 0.f;
+            }
+            bt6(d, t[i]);
+        }
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            float col[6], q[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) col[i] = t[i][b];
+            bt6(col, q);
+#pragma unroll
+            for (int aa = 0; aa < 6; ++aa) o[aa * 6 + b] = q[aa];
+        }
+    } else if constexpr (KIND == 2) {
+        const int ci = c >> 2, p = (c >> 1) & 1, q = c & 1;
+        const int i0 = 2 * ty - 1, j0 = 2 * tx - 1;
+        const float* src = a.x + (long long)n * a.x_sb + (long long)ci * a.x_sc;
+        float t[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float d[4];
+            const int ih = 2 * (i0 + i) + p;
+            const bool rok = (i0 + i >= 0) && (ih < XH);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iw = 2 * (j0 + j) + q;
+                d[j] = (rok && j0 + j >= 0 && iw < XW) ? src[(long long)ih * a.x_sh + iw] : 0.f;
+            }
+            bt4(d, t[i]);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            float col[4], w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) col[i] = t[i][b];
+            bt4(col, w);
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) o[aa * 4 + b] = w[aa];
+        }
+    } else {
+        const float* src = a.x + (long long)n * a.x_sb + (long long)c * a.x_sc;
+        float dy[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int oh = 2 * ty + i, ow = 2 * tx + j;
+                dy[i][j] = (oh < a.H && ow < a.W) ? src[(long long)oh * a.x_sh + ow] : 0.f;
+            }
+        if constexpr (KIND == 1) {
+            float t0[6], t1[6];
+            a62(dy[0][0], dy[1][0], t0);
+            a62(dy[0][1], dy[1][1], t1);
+#pragma unroll
+            for (int aa = 0; aa < 6; ++aa) a62(t0[aa], t1[aa], o + aa * 6);
+        } else {
+            float t0[4], t1[4];
+            a42(dy[0][0], dy[1][0], t0);
+            a42(dy[0][1], dy[1][1], t1);
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) a42(t0[aa], t1[aa], o + aa * 4);
+        }
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) xform_t_kernel(const Twin<XformTKArgs> tw)
+{
+    const XformTKArgs& ka_ = tw.v[blockIdx.z];
+    const WinoXformArgs& a = ka_.a;
+    constexpr int P = (KIND < 2) ? 36 : 16;
+    extern __shared__ __attribute__((aligned(16))) float xbuf[];          // [P][kXT][kXPitch]
+    const int tid = threadIdx.x;
+    const int tile0 = blockIdx.x * kXT, c0 = blockIdx.y * kXC;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int tl = tid & 7, cl = (tid >> 3) + 32 * it;
+        const int tile = tile0 + tl, c = c0 + cl;
+        float o[P];
+        if (tile < a.NT && c < a.C) xform_t_compute<KIND>(a, ka_.XH, ka_.XW, tile, c, o);
+        else {
+#pragma unroll
+            for (int q = 0; q < P; ++q) o[q] = 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < P; ++q) xbuf[(q * kXT + tl) * kXPitch + cl] = o[q];
+    }
+    __syncthreads();
+    const int cl = tid & 63, c = c0 + cl;
+    if (c < a.C) {
+#pragma unroll 4
+        for (int q = 0; q < P; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int tl = (tid >> 6) + 4 * h, tile = tile0 + tl;
+                if (tile < a.NTp) a.v[((long long)q * a.NTp + tile) * a.C + c] = xbuf[(q * kXT + tl) * kXPitch + cl];
+            }
+    }
+}
+
+template <int KIND>
+static int xform_t_launch(const WinoXformArgs& a, int XH, int XW, double bytes, hipStream_t s)
+{
+    constexpr int P = (KIND < 2) ? 36 : 16;
+    constexpr size_t lds = (size_t)P * kXT * kXPitch * sizeof(float);
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xform_t_kernel<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    dim3 grid((unsigned)cdiv_i(a.NTp, kXT), (unsigned)cdiv_i(a.C, kXC));
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, bytes);
+    mcvc_launch(xform_t_kernel<KIND>, grid, dim3(256), lds, s, XformTKArgs{a, XH, XW});
+    return (int)hipGetLastError();
+}
+static bool xform_t_on()
+{
+    static const int en = [] { const char* e = getenv("MCVC_XFORM_T_LDS"); return e ? atoi(e) : 1; }();
+    return en != 0;
+}
+
 // dg = G^T dU G, accumulated into the OIHW gradient.  One thread per (co, ci), ci fastest (coalesced reads of dU).
 struct WinoDwKArgs { const float* du; float* dw; int Cout; int Cin; };
 __global__ void __launch_bounds__(256) wino_dw_kernel(const Twin<WinoDwKArgs> tw)
@@ -818,6 +968,7 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
 
 int mcvc_wino_input_t_launch(const WinoXformArgs& a, hipStream_t s)
 {
+    if (xform_t_on()) return xform_t_launch<0>(a, 0, 0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp), s);
     dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp));
     mcvc_launch(wino_input_t_kernel, grid, dim3(256), 0, s, a);
@@ -826,6 +977,7 @@ int mcvc_wino_input_t_launch(const WinoXformArgs& a, hipStream_t s)
 
 int mcvc_wino_dy_t_launch(const WinoXformArgs& a, hipStream_t s)
 {
+    if (xform_t_on()) return xform_t_launch<1>(a, 0, 0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp), s);
     dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp));
     mcvc_launch(wino_dy_t_kernel, grid, dim3(256), 0, s, a);
@@ -866,6 +1018,7 @@ int mcvc_wino3_input_phase_launch(const WinoXformArgs& a, int XH, int XW, hipStr
 
 int mcvc_wino3_input_phase_t_launch(const WinoXformArgs& a, int XH, int XW, hipStream_t s)
 {
+    if (xform_t_on()) return xform_t_launch<2>(a, XH, XW, 4.0 * ((double)a.N * (a.C / 4) * XH * XW + 16.0 * a.C * a.NTp), s);
     dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * (a.C / 4) * XH * XW + 16.0 * a.C * a.NTp));
     mcvc_launch(wino3_input_phase_t_kernel, grid, dim3(256), 0, s, Wino3InputPhaseTKArgs{a, XH, XW});
@@ -874,6 +1027,7 @@ int mcvc_wino3_input_phase_t_launch(const WinoXformArgs& a, int XH, int XW, hipS
 
 int mcvc_wino3_dy_t_launch(const WinoXformArgs& a, hipStream_t s)
 {
+    if (xform_t_on()) return xform_t_launch<3>(a, 0, 0, 4.0 * ((double)a.N * a.C * a.H * a.W + 16.0 * a.C * a.NTp), s);
     dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
     TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 16.0 * a.C * a.NTp));
     mcvc_launch(wino3_dy_t_kernel, grid, dim3(256), 0, s, a);
