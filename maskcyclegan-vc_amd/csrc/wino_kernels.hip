@@ -950,6 +950,14 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
     // long-K products (the F(2x2,3x3) layers: K = 4*Cin or Cout >= 512): 64x64 tiles with 32-deep stages measured 10-20 % faster than
     // 128x64 / 128x32 with 16-deep stages (profiles/r02_gemm_tune.log) -- twice the workgroups and half the barriers per k
     if (cfg2 == 0 && a.K >= 512 && (a.K % 32) == 0 && (a.M % 64) == 0) return gemm2_launch<64, 64, 32, 4>(b, nxi, s);
+    // short-K products (the Winograd weight gradients at one or two samples per pass: K = tiles = 96 ... 128): every stage of the tile in
+    // flight at once (six 16-deep stages) instead of a four-stage ring that is mostly fill and drain
+    static const int shortk = [] { const char* e = getenv("MCVC_GEMM_SHORTK"); return e ? atoi(e) : 0; }();
+    if (cfg2 == 0 && shortk && a.K <= 16 * 6) {
+        if (shortk == 1) return gemm2_launch<128, 64, 16, 6>(b, nxi, s);
+        if (shortk == 2) return gemm2_launch<64, 64, 16, 6>(b, nxi, s);
+        if (shortk == 3) return gemm2_launch<128, 32, 16, 6>(b, nxi, s);
+    }
     if (narrow) {
         b.nt = cdiv_i(a.N, 32);
         static bool done = false;

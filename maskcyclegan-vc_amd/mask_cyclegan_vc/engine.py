@@ -141,9 +141,19 @@ class TrainEngine:
         # kernels are latency-bound and far from filling 256 CUs, so the two chains run as two "lanes" on two HIP
         # streams (lane 0 = the caller's stream) and overlap on the chip; join points are stream-event waits.
         self.concurrent = True
-        self._sides = self._pick_side_streams(dev)
+        # two sets of side lanes: the four-lane schedule keeps the streams (and the auxiliary streams created right behind them) it was
+        # tuned on -- with probed lanes its auxiliary streams land on the lanes' queues: bs=8 30.5 -> 32.3 ms, bs=32 116.5 -> 118.0 -- the
+        # grouped / pipelined schedule uses lanes probed onto distinct hardware queues (_pick_side_streams)
+        self._sides_legacy = [torch.cuda.Stream(device=dev) for _ in range(3)]
         # inside a backward pass the weight-gradient kernels are off the critical path: one auxiliary stream per lane
         self._aux = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        # (a stream gets its hardware queue at first USE: touch these in creation order before the probe puts work on its candidates)
+        _t = torch.zeros(64, device=dev)
+        for st in self._sides_legacy + self._aux:
+            with torch.cuda.stream(st):
+                _t.add_(1.0)
+        torch.cuda.synchronize(dev)
+        self._sides_probed = self._pick_side_streams(dev)
         self.aux_wgrad = os.environ.get("MCVC_AUX_WGRAD", "1") != "0"
         # ... for the generators only: the four discriminator lanes already occupy the four hardware queues, and giving each a
         # second stream for its weight gradients measured 1.2 % slower (101.5 vs 102.8 it/s)
@@ -228,6 +238,10 @@ class TrainEngine:
         self.reducer.broadcast_(self.g_group.flat)
         self.reducer.broadcast_(self.d_group.flat)
         self.repack(G_NAMES + D_NAMES)
+
+    @property
+    def _sides(self):
+        return self._sides_probed if self._use_grouped() else self._sides_legacy
 
     # ---- lanes on distinct hardware queues -----------------------------------------------------------------------------
     def _pick_side_streams(self, dev, want=3):
