@@ -19,6 +19,7 @@
 #include "misc.h"
 #include "trunk.h"
 #include "wino.h"
+#include "wino4.h"
 #include "sgemm.h"
 #include "sampler.h"
 #include "../../include/mcvc.h"
@@ -128,6 +129,7 @@ struct ConvSpec {
     long long off_fwd, off_bias, off_dgrad;
     // 5x5 stride-1 single-branch convs (upSample1/2): Winograd F(2x2,5x5) weight sets U[36][K+1][ld], forward and data-gradient
     int wino; long long off_wf, off_wd, wf_xi, wd_xi;
+    long long off_w4f, off_w4d;    // ... and their F(4x4,5x5) twins U[64][...] (wino4.h; same row / column conventions and strides per point)
     // 5x5 stride-2 convs (downSample1/2): their merged 3x3 data-gradient as Winograd F(2x2,3x3): U[16][co (+1)][mg_ld]
     int wino3; long long off_w3, w3_xi;
     long long off_w3f, w3f_xi;     // forward twin over the four input phases: U[16][4*Cin (+1)][cout_pk]
@@ -203,12 +205,15 @@ static void spec_finalize(ConvSpec& c, long long& cur)
     }
     cur = (cur + 3) & ~3LL;
     c.wino = (c.KH == 5 && c.KW == 5 && st == 1 && c.nbr == 1 && c.Cin >= 64 && c.Cout >= 64) ? 1 : 0;
-    c.off_wf = c.off_wd = -1; c.wf_xi = c.wd_xi = 0;
+    c.off_wf = c.off_wd = c.off_w4f = c.off_w4d = -1; c.wf_xi = c.wd_xi = 0;
     if (c.wino) {
         c.wf_xi = (long long)(c.cin_pad + 1) * c.cout_pk;                          // rows ci (+ zero pad row), columns co
         c.off_wf = cur; cur += 36 * c.wf_xi;
         c.wd_xi = (long long)(c.dg_rows_co + 1) * c.cin_pk;                       // rows co, columns ci
         c.off_wd = cur; cur += 36 * c.wd_xi;
+        cur = (cur + 3) & ~3LL;
+        c.off_w4f = cur; cur += 64 * c.wf_xi;
+        c.off_w4d = cur; cur += 64 * c.wd_xi;
         cur = (cur + 3) & ~3LL;
     }
     c.wino3 = (c.merged && c.KH == 5 && c.KW == 5 && c.ph == 2 && c.pw == 2 && (4 * c.Cin) % 128 == 0 && c.cout_tot % 16 == 0) ? 1 : 0;
@@ -288,10 +293,64 @@ static long long wino_chunk_tiles(int NB, long long tiles_per_sample)          /
 // 5x5 stride-1 conv as Winograd F(2x2,5x5): input transform -> 36 batched [M x K] x [K x tiles] products (one launch of the
 // direct-conv kernel as a 1x1 conv over 36 images with per-image weights) -> output transform (+bias, PixelShuffle store).
 // dgrad: the same on the flipped / transposed weight set; K = conv output channels, M = conv input channels.
+// F(4x4,5x5) (wino4.h) from `MCVC_WINO4_NB` samples per pass on images whose sides are multiples of 4, when the packed buffer holds the
+// 64-point weight sets (pack_skips bit 16 clear): 2.25x fewer multiplies and 2.25x smaller V / M than F(2x2,5x5)
+static int wino4_min_nb()
+{
+    static const int nb = [] { const char* e = getenv("MCVC_WINO4_NB"); return e ? atoi(e) : 4; }();
+    return nb;
+}
+static bool wino4_applies(const Exec& ex, const ConvSpec& c, int NB, int H, int W)
+{
+    return c.wino && c.off_w4f >= 0 && wino4_min_nb() > 0 && NB >= wino4_min_nb() && (H & 3) == 0 && (W & 3) == 0 && !(ex.pack_skips & 16);
+}
+// samples per F(4x4) pass: V / M hold 64 * max(K, M) * tiles floats
+static int wino4_chunk(const Exec& ex, int NB, long long tiles_per_sample, int KM)
+{
+    const long long cap_tiles = (ex.wino_cap / (64LL * KM)) & ~31LL;
+    if (tiles_per_sample <= 0 || cap_tiles < tiles_per_sample) return 0;
+    const long long nbmax = cap_tiles / tiles_per_sample;
+    if (NB <= nbmax) return NB;
+    const long long nch = (NB + nbmax - 1) / nbmax;
+    return (int)((NB + nch - 1) / nch);
+}
+
+static bool conv_wino4(Exec& ex, const ConvSpec& c, const float* packed, int dgrad, int NB, int H, int W, CView x, View y, int shuffle, int accumulate)
+{
+    const int K = dgrad ? c.cout_tot : c.Cin, M = dgrad ? c.Cin : c.cout_tot;
+    const int TH = H / 4, TW = W / 4;
+    if ((M % 128) != 0 || (K % 16) != 0) return false;
+    const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, K > M ? K : M);
+    if (!nbc || (long long)nbc * TH * TW < 64) return false;
+    if (ex.dry) return true;
+    for (int b0 = 0; b0 < NB; b0 += nbc) {
+        const int nb = NB - b0 < nbc ? NB - b0 : nbc;
+        const long long NT = (long long)nb * TH * TW, NTp = (NT + 31) & ~31LL;
+        WinoXformArgs xi{};
+        xi.x = x.p + (long long)b0 * x.sb; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv;
+        xi.N = nb; xi.C = K; xi.H = H; xi.W = W; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 2;
+        ex.fail(mcvc_wino4_input_launch(xi, ex.s));
+        WinoGemmArgs ga{};
+        ga.a = packed + (dgrad ? c.off_w4d : c.off_w4f); ga.a_xi = dgrad ? c.wd_xi : c.wf_xi; ga.lda = dgrad ? c.cin_pk : c.cout_pk;
+        ga.b = ex.wv; ga.b_xi = (long long)K * NTp; ga.ldb = (int)NTp;
+        ga.c = ex.wm; ga.c_xi = (long long)M * NTp; ga.ldc = (int)NTp;
+        ga.M = M; ga.N = (int)NTp; ga.K = K; ga.nxi = 64;
+        ex.fail(mcvc_wino_gemm_launch(ga, ex.s));
+        WinoOutArgs oa{};
+        oa.m = ex.wm; oa.bias = dgrad ? nullptr : packed + c.off_bias;
+        oa.y = y.p + (long long)b0 * y.sb; oa.y_sb = y.sb; oa.y_sc = y.sc; oa.y_sh = y.sh;
+        oa.N = nb; oa.Cout = M; oa.OH = H; oa.OW = W; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
+        oa.shuffle = shuffle; oa.YH = 2 * H; oa.YW = 2 * W; oa.accumulate = accumulate;
+        ex.fail(mcvc_wino4_output_launch(oa, ex.s));
+    }
+    return true;
+}
+
 static bool conv_wino(Exec& ex, const ConvSpec& c, const float* packed, int dgrad, int NB, int H, int W, CView x, View y, int shuffle,
                       int accumulate)
 {
     if (!c.wino || !wino_enabled() || !ex.wv) return false;
+    if (wino4_applies(ex, c, NB, H, W) && conv_wino4(ex, c, packed, dgrad, NB, H, W, x, y, shuffle, accumulate)) return true;
     const int K = dgrad ? c.cout_tot : c.Cin, M = dgrad ? c.Cin : c.cout_tot;
     const int TH = (H + 1) / 2, TW = (W + 1) / 2;
     const int nbc = wino_chunk(NB, (long long)TH * TW);
@@ -613,6 +672,34 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         ex.fail(mcvc_dw_accum_launch(slabs, sg_split, g.c_split, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.cout_tot, KT, ws));
         done = true;
     }
+    if (!done && wino_enabled() && ex.wu && c.nbr == 1 && grads[c.wi[0]] && wino4_applies(ex, c, NB, H, W) && (c.Cout % 128) == 0 && (c.Cin % 64) == 0 &&
+        64LL * c.Cout * c.Cin <= ex.wu_cap) {
+        // F(4x4,5x5) weight gradient: the same three steps on 8x8 tiles and 64 points
+        const int TH = H / 4, TW = W / 4;
+        const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, c.Cout > c.Cin ? c.Cout : c.Cin);
+        if (nbc && (long long)nbc * TH * TW >= 32) {
+            for (int b0 = 0; b0 < NB; b0 += nbc) {
+                const int nb = NB - b0 < nbc ? NB - b0 : nbc;
+                const long long NT = (long long)nb * TH * TW, NTp = (NT + 31) & ~31LL;
+                WinoXformArgs xi{};
+                xi.x = x.p + (long long)b0 * x.sb; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv2;
+                xi.N = nb; xi.C = c.Cin; xi.H = H; xi.W = W; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 2;
+                ex.fail(mcvc_wino4_input_t_launch(xi, ws));
+                WinoXformArgs di{};
+                di.x = dy.p + (long long)b0 * dy.sb; di.x_sb = dy.sb; di.x_sc = dy.sc; di.x_sh = dy.sh; di.v = ex.wm2;
+                di.N = nb; di.C = c.Cout; di.H = H; di.W = W; di.TH = TH; di.TW = TW; di.NT = (int)NT; di.NTp = (int)NTp; di.pad = 0;
+                ex.fail(mcvc_wino4_dy_t_launch(di, ws));
+                WinoGemmArgs ga{};
+                ga.a = ex.wm2; ga.a_xi = NTp * c.Cout; ga.lda = c.Cout;
+                ga.b = ex.wv2; ga.b_xi = NTp * c.Cin; ga.ldb = c.Cin;
+                ga.c = ex.wu; ga.c_xi = (long long)c.Cout * c.Cin; ga.ldc = c.Cin;
+                ga.M = c.Cout; ga.N = c.Cin; ga.K = (int)NTp; ga.nxi = 64;
+                ex.fail(mcvc_wino_gemm_launch(ga, ws));
+                ex.fail(mcvc_wino4_dw_launch(ex.wu, grads[c.wi[0]], c.Cout, c.Cin, ws));
+            }
+            done = true;
+        }
+    }
     if (!done && c.wino && wino_enabled() && ex.wu && c.nbr == 1 && grads[c.wi[0]]) {
         // Winograd weight gradient: dU[xi] = dM[xi] V[xi]^T over the tiles, then dW += G^T dU G.  Operands tile-major.
         static const int en = [] { const char* e = getenv("MCVC_WINO_WGRAD"); return e ? atoi(e) : 1; }();
@@ -737,7 +824,7 @@ static void add_job(PackTable& t, PackJob j, int gx, int gy)
 // wino_only: the layer runs on the Winograd kernels in every pass (forward, data-gradient); its direct K-major copies are skipped
 // sets: 1 = the copies a FORWARD pass reads (K-major forward copies, biases, forward Winograd sets), 2 = the copies only a BACKWARD pass
 // reads (data-gradient copies, transposed trunk copies, data-gradient Winograd sets), 3 = both
-static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = false, bool wino_only = false, int sets = 3)
+static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = false, bool wino_only = false, int sets = 3, bool w4 = true)
 {
     const int K = c.Cin * c.KH * c.KW;
     const bool fw = (sets & 1) != 0, bw = (sets & 2) != 0;
@@ -785,6 +872,15 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             PackJob w3f{}; w3f.kind = PACK_WINO3_F; w3f.param = c.wi[br]; w3f.dst = c.off_w3f; w3f.Cout = c.Cout; w3f.Cin = c.Cin; w3f.ld = c.cout_pk;
             w3f.xi_stride = c.w3f_xi; w3f.co_off = br * c.Cout;
             if (fw) add_job(t, w3f, cdiv_i(c.Cout, 256), c.Cin);
+            t.bytes += 4.0 * (fw + bw) * (25.0 + 64.0) * c.Cout * c.Cin;
+        }
+        if (c.wino && w4) {
+            PackJob wf{}; wf.kind = PACK_WINO4_F; wf.param = c.wi[br]; wf.dst = c.off_w4f; wf.Cout = c.Cout; wf.Cin = c.Cin; wf.ld = c.cout_pk;
+            wf.xi_stride = c.wf_xi; wf.co_off = br * c.Cout;
+            if (fw) add_job(t, wf, cdiv_i(c.Cout, 256), c.Cin);
+            PackJob wd{}; wd.kind = PACK_WINO4_D; wd.param = c.wi[br]; wd.dst = c.off_w4d; wd.Cout = c.Cout; wd.Cin = c.Cin; wd.ld = c.cin_pk;
+            wd.xi_stride = c.wd_xi; wd.co_off = br * c.Cout;
+            if (bw) add_job(t, wd, cdiv_i(c.Cin, 256), c.Cout);
             t.bytes += 4.0 * (fw + bw) * (25.0 + 64.0) * c.Cout * c.Cin;
         }
         if (c.wino) {
@@ -1114,7 +1210,7 @@ static GenScratch gen_scratch(const GenDims& d)
         s.wino_floats = wino_enabled() ? (a1 > a2 ? a1 : a2) : 0;
         s.wv = take(s.wino_floats); s.wm = take(s.wino_floats);
         s.wv2 = take(s.wino_floats); s.wm2 = take(s.wino_floats);
-        s.wu_floats = wino_enabled() ? 36LL * 1024 * 256 : 0;          // dU of upSample1 (the larger weight tensor)
+        s.wu_floats = wino_enabled() ? 64LL * 1024 * 256 : 0;          // dU of upSample1 (the larger weight tensor), 64 points of F(4x4,5x5)
         s.wu = take(s.wu_floats);
     }
     s.slabs = cur;
@@ -1783,7 +1879,9 @@ int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batc
     const GenDims dm = gen_dims(max_batch, T);
     const bool wino_only = fused && knobs_default && (T % 4) == 0 && T >= 32 && (long long)max_batch * 20 * dm.W4 <= 16384;
     int err = 0;
-    auto build = [wino_only, fused, sets, range_mask](PackTable& pt) {
+    // the 64-point weight sets of upSample1/2 only when some pass can take the F(4x4,5x5) path (wino4_applies); otherwise marked absent (bit 16)
+    const bool w4 = knobs_default && wino4_min_nb() > 0 && max_batch >= wino4_min_nb() && (T % 16) == 0;
+    auto build = [wino_only, fused, sets, range_mask, w4](PackTable& pt) {
         const GenNet& g = gen_net();
         if (range_mask & 4) {
             const ConvSpec* head[] = {&g.conv1, &g.ds1, &g.ds2};
@@ -1792,16 +1890,16 @@ int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batc
         }
         if (range_mask & 1) {
             const ConvSpec* up[] = {&g.up1, &g.up2, &g.last};
-            for (const ConvSpec* c : up) add_spec_jobs(pt, *c, false, wino_only, sets);
+            for (const ConvSpec* c : up) add_spec_jobs(pt, *c, false, wino_only, sets, w4);
         }
         if (range_mask & 2) {
             add_spec_jobs(pt, g.c1d2d, fused, false, sets);
             for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i], fused, false, sets); add_spec_jobs(pt, g.res_out[i], fused, false, sets); }
         }
     };
-    const DevPackTable* t = dev_pack_table(16 + 4 * sets + (fused ? (wino_only ? 3 : 2) : 0) + 64 * range_mask, build, &err);
+    const DevPackTable* t = dev_pack_table(16 + 4 * sets + (fused ? (wino_only ? 3 : 2) : 0) + 64 * range_mask + (w4 ? 1024 : 0), build, &err);
     if (!t) return err;
-    const int skipped = fused ? (wino_only ? 3 : 1) : 0;
+    const int skipped = (fused ? (wino_only ? 3 : 1) : 0) | (w4 ? 0 : 16);
     if (sets == 1) set_pack_skips(packed, skipped | 4);
     else if (sets == 2) set_pack_skips(packed, get_pack_skips(packed) & ~4);
     else set_pack_skips(packed, skipped);

@@ -15,6 +15,7 @@
 #include "trace.h"
 #include "launch.h"
 #include "wino.h"
+#include "wino4.h"
 
 // [R=Cout][K] -> dst[k*ld + co_off + co], 32x32 LDS tiles, both sides coalesced
 __device__ __forceinline__ void pack_fwd_tile(const float* __restrict__ w, float* __restrict__ dst, int Cout, int K, int ld, int co_off,
@@ -142,6 +143,8 @@ __global__ void __launch_bounds__(256) pack_net_kernel(const Twin<PackNetKArgs> 
     case PACK_WINO_D: wino_weight_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, 1, bx, by); break;
     case PACK_WINO3_D: wino3_weight_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, bx, by); break;
     case PACK_WINO3_F: wino3_weight_fwd_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, bx, by); break;
+    case PACK_WINO4_F: wino4_weight_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, 0, bx, by); break;
+    case PACK_WINO4_D: wino4_weight_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, 1, bx, by); break;
     default: { const int i = rel * 256 + threadIdx.x; if (i < j.Cout) dst[i] = w[i]; } break;     // PACK_COPY
     }
 }

@@ -44,6 +44,15 @@ def init_from_env(backend=None):
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+            if torch.cuda.is_available() and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+                # Ranks SHARING a GPU (the single-GPU choreography tests only): the persistent trunk kernels wait inside the kernel for
+                # workgroups that must all be resident (csrc/trunk.h) -- that holds for the passes one process keeps in flight, not for
+                # two processes' worth of them on one device.  Run the trunk as per-layer launches there.
+                from . import _hip
+                _hip.lib().mcvc_set_trunk_persistent(0)
+                if rank == 0:
+                    import sys
+                    print("[mcvc] ranks share a GPU: persistent trunk kernels off (per-layer launches)", file=sys.stderr, flush=True)
     return rank, world, local_rank
 
 
