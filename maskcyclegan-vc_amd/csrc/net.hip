@@ -133,6 +133,7 @@ struct ConvSpec {
     // 5x5 stride-2 convs (downSample1/2): their merged 3x3 data-gradient as Winograd F(2x2,3x3): U[16][co (+1)][mg_ld]
     int wino3; long long off_w3, w3_xi;
     long long off_w3f, w3f_xi;     // forward twin over the four input phases: U[16][4*Cin (+1)][cout_pk]
+    long long off_w43, off_w43f;   // ... and the 36-point F(4x4,3x3) sets of both (wino43_kernels.hip), same strides per point
     long long off_tk;          // KH == 1 convs: transposed + flipped [Cin][cout_tot*KW] copy for the fused small-batch trunk dgrad
     int ncls;
     DgradClass cls[4];
@@ -219,9 +220,12 @@ static void spec_finalize(ConvSpec& c, long long& cur)
     c.wino3 = (c.merged && c.KH == 5 && c.KW == 5 && c.ph == 2 && c.pw == 2 && (4 * c.Cin) % 128 == 0 && c.cout_tot % 16 == 0) ? 1 : 0;
     c.off_w3 = -1; c.w3_xi = 0;
     c.off_w3f = -1; c.w3f_xi = 0;
+    c.off_w43 = c.off_w43f = -1;
     if (c.wino3) {
         c.w3_xi = (long long)(c.dg_rows_co + 1) * c.mg_ld; c.off_w3 = cur; cur += 16 * c.w3_xi; cur = (cur + 3) & ~3LL;
         c.w3f_xi = (long long)(4 * c.Cin + 1) * c.cout_pk; c.off_w3f = cur; cur += 16 * c.w3f_xi; cur = (cur + 3) & ~3LL;
+        c.off_w43 = cur; cur += 36 * c.w3_xi; cur = (cur + 3) & ~3LL;
+        c.off_w43f = cur; cur += 36 * c.w3f_xi; cur = (cur + 3) & ~3LL;
     }
     c.off_tk = -1;
     if (c.KH == 1 && st == 1) { c.off_tk = cur; cur += (long long)c.Cin * c.cout_tot * c.KW; cur = (cur + 3) & ~3LL; }
@@ -294,20 +298,32 @@ static long long wino_chunk_tiles(int NB, long long tiles_per_sample)          /
 // direct-conv kernel as a 1x1 conv over 36 images with per-image weights) -> output transform (+bias, PixelShuffle store).
 // dgrad: the same on the flipped / transposed weight set; K = conv output channels, M = conv input channels.
 // F(4x4,5x5) (wino4.h) from `MCVC_WINO4_NB` samples per pass on images whose sides are multiples of 4, when the packed buffer holds the
-// 64-point weight sets (pack_skips bit 16 clear): 2.25x fewer multiplies and 2.25x smaller V / M than F(2x2,5x5)
+// 64-point weight sets (pack_skips bit 16 clear): 2.25x fewer multiplies and 2.25x smaller V / M than F(2x2,5x5).  Measured (ms/step, off vs on):
+// bs=1 6.77 / 6.64 (upSample2 only: upSample1 has 20 tiles per sample), bs=2 10.8 / 10.3, bs=4 17.5 / 15.1, bs=8 31.1 / 24.3, bs=32 118.1 / 84.5
+// (the last three with F(4x4,3x3) on downSample1/2 as well, MCVC_WINO43_NB: at one sample per pass that one costs 0.3 ms)
 static int wino4_min_nb()
 {
-    static const int nb = [] { const char* e = getenv("MCVC_WINO4_NB"); return e ? atoi(e) : 4; }();
+    static const int nb = [] { const char* e = getenv("MCVC_WINO4_NB"); return e ? atoi(e) : 1; }();
+    return nb;
+}
+static int wino43_min_nb()
+{
+    static const int nb = [] { const char* e = getenv("MCVC_WINO43_NB"); return e ? atoi(e) : 4; }();
     return nb;
 }
 static bool wino4_applies(const Exec& ex, const ConvSpec& c, int NB, int H, int W)
 {
     return c.wino && c.off_w4f >= 0 && wino4_min_nb() > 0 && NB >= wino4_min_nb() && (H & 3) == 0 && (W & 3) == 0 && !(ex.pack_skips & 16);
 }
-// samples per F(4x4) pass: V / M hold 64 * max(K, M) * tiles floats
-static int wino4_chunk(const Exec& ex, int NB, long long tiles_per_sample, int KM)
+// F(4x4,3x3) for the stride-2 5x5 layers in phase form (wino43_kernels.hip) under the same conditions (OH x OW = the conv's output size)
+static bool wino43_applies(const Exec& ex, const ConvSpec& c, int NB, int OH, int OW)
 {
-    const long long cap_tiles = (ex.wino_cap / (64LL * KM)) & ~31LL;
+    return c.wino3 && c.off_w43 >= 0 && wino43_min_nb() > 0 && NB >= wino43_min_nb() && (OH & 3) == 0 && (OW & 3) == 0 && !(ex.pack_skips & 32);
+}
+// samples per F(4x4) pass: V / M hold pts * max(K, M) * tiles floats
+static int wino4_chunk(const Exec& ex, int NB, long long tiles_per_sample, int KM, int pts = 64)
+{
+    const long long cap_tiles = (ex.wino_cap / ((long long)pts * KM)) & ~31LL;
     if (tiles_per_sample <= 0 || cap_tiles < tiles_per_sample) return 0;
     const long long nbmax = cap_tiles / tiles_per_sample;
     if (NB <= nbmax) return NB;
@@ -461,6 +477,38 @@ static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, i
         }
     }
     if (conv_wino(ex, c, packed, 0, NB, H, W, x, y, shuffle, 0)) { if (nsplit) *nsplit = 1; return; }
+    if (c.wino3 && wino_enabled() && ex.wv && !shuffle && (H & 1) == 0 && (W & 1) == 0 && (c.cout_tot % 128) == 0 && wino43_applies(ex, c, NB, H / 2, W / 2)) {
+        // ... as F(4x4,3x3): 36 points per 16 outputs
+        static const int en = [] { const char* e = getenv("MCVC_WINO3_FWD"); return e ? atoi(e) : 1; }();
+        const int OH = H / 2, OW = W / 2, K = 4 * c.Cin, M = c.cout_tot;
+        const int TH = OH / 4, TW = OW / 4;
+        const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, K > M ? K : M, 36);
+        if (en && nbc && (long long)nbc * TH * TW >= 64) {
+            if (nsplit) *nsplit = 1;
+            if (ex.dry) return;
+            for (int b0 = 0; b0 < NB; b0 += nbc) {
+                const int nb = NB - b0 < nbc ? NB - b0 : nbc;
+                const long long NT = (long long)nb * TH * TW, NTp = (NT + 31) & ~31LL;
+                WinoXformArgs xi{};
+                xi.x = x.p + (long long)b0 * x.sb; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv;
+                xi.N = nb; xi.C = K; xi.H = OH; xi.W = OW; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 1;
+                ex.fail(mcvc_wino43_input_phase_launch(xi, H, W, ex.s));
+                WinoGemmArgs ga{};
+                ga.a = packed + c.off_w43f; ga.a_xi = c.w3f_xi; ga.lda = c.cout_pk;
+                ga.b = ex.wv; ga.b_xi = (long long)K * NTp; ga.ldb = (int)NTp;
+                ga.c = ex.wm; ga.c_xi = (long long)M * NTp; ga.ldc = (int)NTp;
+                ga.M = M; ga.N = (int)NTp; ga.K = K; ga.nxi = 36;
+                ex.fail(mcvc_wino_gemm_launch(ga, ex.s));
+                WinoOutArgs oa{};
+                oa.m = ex.wm; oa.bias = packed + c.off_bias;
+                oa.y = y.p + (long long)b0 * y.sb; oa.y_sb = y.sb; oa.y_sc = y.sc; oa.y_sh = y.sh;
+                oa.N = nb; oa.Cout = M; oa.OH = OH; oa.OW = OW; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
+                oa.shuffle = 0; oa.YH = OH; oa.YW = OW; oa.accumulate = 0;
+                ex.fail(mcvc_wino43_output_launch(oa, ex.s));
+            }
+            return;
+        }
+    }
     if (c.wino3 && wino_enabled() && ex.wv && !shuffle && (H & 1) == 0 && (W & 1) == 0 && (c.cout_tot % 128) == 0) {
         // stride-2 5x5 forward = 3x3 stride-1 conv over the four input phases: Winograd F(2x2,3x3), K = 4*Cin
         static const int en = [] { const char* e = getenv("MCVC_WINO3_FWD"); return e ? atoi(e) : 1; }();
@@ -536,6 +584,38 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
                                      : mcvc_col2im_1d_launch(sa, c.KW, sp, KT * NT, accumulate, ex.s));
             }
             if (nsplit) *nsplit = 1;
+            return;
+        }
+    }
+    if (c.wino3 && wino_enabled() && ex.wv && wino43_applies(ex, c, NB, OH, OW) && 2 * OH == H && 2 * OW == W) {
+        // ... as F(4x4,3x3)
+        static const int en = [] { const char* e = getenv("MCVC_WINO3"); return e ? atoi(e) : 1; }();
+        const int K = c.cout_tot, M = 4 * c.Cin;
+        const int TH = OH / 4, TW = OW / 4;
+        const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, K > M ? K : M, 36);
+        if (en && nbc && (long long)nbc * TH * TW >= 64 && (M % 128) == 0 && (K % 16) == 0) {
+            if (nsplit) *nsplit = 1;
+            if (ex.dry) return;
+            for (int b0 = 0; b0 < NB; b0 += nbc) {
+                const int nb = NB - b0 < nbc ? NB - b0 : nbc;
+                const long long NT = (long long)nb * TH * TW, NTp = (NT + 31) & ~31LL;
+                WinoXformArgs xi{};
+                xi.x = dy.p + (long long)b0 * dy.sb; xi.x_sb = dy.sb; xi.x_sc = dy.sc; xi.x_sh = dy.sh; xi.v = ex.wv;
+                xi.N = nb; xi.C = K; xi.H = OH; xi.W = OW; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 1;
+                ex.fail(mcvc_wino43_input_launch(xi, ex.s));
+                WinoGemmArgs ga{};
+                ga.a = packed + c.off_w43; ga.a_xi = c.w3_xi; ga.lda = c.mg_ld;
+                ga.b = ex.wv; ga.b_xi = (long long)K * NTp; ga.ldb = (int)NTp;
+                ga.c = ex.wm; ga.c_xi = (long long)M * NTp; ga.ldc = (int)NTp;
+                ga.M = M; ga.N = (int)NTp; ga.K = K; ga.nxi = 36;
+                ex.fail(mcvc_wino_gemm_launch(ga, ex.s));
+                WinoOutArgs oa{};
+                oa.m = ex.wm; oa.bias = nullptr;
+                oa.y = dx.p + (long long)b0 * dx.sb; oa.y_sb = dx.sb; oa.y_sc = dx.sc; oa.y_sh = dx.sh;
+                oa.N = nb; oa.Cout = M; oa.OH = OH; oa.OW = OW; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
+                oa.shuffle = 1; oa.YH = H; oa.YW = W; oa.accumulate = accumulate;
+                ex.fail(mcvc_wino43_output_launch(oa, ex.s));
+            }
             return;
         }
     }
@@ -730,6 +810,36 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
             done = true;
         }
     }
+    if (!done && c.wino3 && wino_enabled() && ex.wu && (H & 1) == 0 && (W & 1) == 0 && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]]) &&
+        wino43_applies(ex, c, NB, OH, OW)) {
+        // ... as F(4x4,3x3)
+        static const int en = [] { const char* e = getenv("MCVC_WINO3_WGRAD"); return e ? atoi(e) : 1; }();
+        const int K4 = 4 * c.Cin, M = c.cout_tot;
+        const int TH = OH / 4, TW = OW / 4;
+        const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, M > K4 ? M : K4, 36);
+        if (en && nbc && (long long)nbc * TH * TW >= 32 && (M % 128) == 0 && (K4 % 64) == 0 && 36LL * M * K4 <= ex.wu_cap) {
+            for (int b0 = 0; b0 < NB; b0 += nbc) {
+                const int nb = NB - b0 < nbc ? NB - b0 : nbc;
+                const long long NT = (long long)nb * TH * TW, NTp = (NT + 31) & ~31LL;
+                WinoXformArgs xi{};
+                xi.x = x.p + (long long)b0 * x.sb; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv2;
+                xi.N = nb; xi.C = K4; xi.H = OH; xi.W = OW; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 1;
+                ex.fail(mcvc_wino43_input_phase_t_launch(xi, H, W, ws));
+                WinoXformArgs di{};
+                di.x = dy.p + (long long)b0 * dy.sb; di.x_sb = dy.sb; di.x_sc = dy.sc; di.x_sh = dy.sh; di.v = ex.wm2;
+                di.N = nb; di.C = M; di.H = OH; di.W = OW; di.TH = TH; di.TW = TW; di.NT = (int)NT; di.NTp = (int)NTp; di.pad = 0;
+                ex.fail(mcvc_wino43_dy_t_launch(di, ws));
+                WinoGemmArgs ga{};
+                ga.a = ex.wm2; ga.a_xi = NTp * M; ga.lda = M;
+                ga.b = ex.wv2; ga.b_xi = NTp * K4; ga.ldb = K4;
+                ga.c = ex.wu; ga.c_xi = (long long)M * K4; ga.ldc = K4;
+                ga.M = M; ga.N = K4; ga.K = (int)NTp; ga.nxi = 36;
+                ex.fail(mcvc_wino_gemm_launch(ga, ws));
+                ex.fail(mcvc_wino43_dw_launch(ex.wu, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.nbr, c.Cin, ws));
+            }
+            done = true;
+        }
+    }
     if (!done && c.wino3 && wino_enabled() && ex.wu && (H & 1) == 0 && (W & 1) == 0 && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]])) {
         // stride-2 5x5 weight gradient in the phase formulation (see conv_fwd): dU[xi][co][4ci+2p+q] over the tiles, both
         // branches (value | gate) in one product, then the 3x3 blocks are scattered back into the two 5x5 gradients
@@ -824,7 +934,7 @@ static void add_job(PackTable& t, PackJob j, int gx, int gy)
 // wino_only: the layer runs on the Winograd kernels in every pass (forward, data-gradient); its direct K-major copies are skipped
 // sets: 1 = the copies a FORWARD pass reads (K-major forward copies, biases, forward Winograd sets), 2 = the copies only a BACKWARD pass
 // reads (data-gradient copies, transposed trunk copies, data-gradient Winograd sets), 3 = both
-static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = false, bool wino_only = false, int sets = 3, bool w4 = true)
+static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = false, bool wino_only = false, int sets = 3, bool w4 = true, bool w43 = true)
 {
     const int K = c.Cin * c.KH * c.KW;
     const bool fw = (sets & 1) != 0, bw = (sets & 2) != 0;
@@ -873,6 +983,15 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             w3f.xi_stride = c.w3f_xi; w3f.co_off = br * c.Cout;
             if (fw) add_job(t, w3f, cdiv_i(c.Cout, 256), c.Cin);
             t.bytes += 4.0 * (fw + bw) * (25.0 + 64.0) * c.Cout * c.Cin;
+        }
+        if (c.wino3 && w43) {
+            PackJob w3{}; w3.kind = PACK_WINO43_D; w3.param = c.wi[br]; w3.dst = c.off_w43; w3.Cout = c.Cout; w3.Cin = c.Cin; w3.ld = c.mg_ld;
+            w3.xi_stride = c.w3_xi; w3.co_off = br * c.Cout;
+            if (bw) add_job(t, w3, cdiv_i(c.Cin, 256), c.Cout);
+            PackJob w3f{}; w3f.kind = PACK_WINO43_F; w3f.param = c.wi[br]; w3f.dst = c.off_w43f; w3f.Cout = c.Cout; w3f.Cin = c.Cin; w3f.ld = c.cout_pk;
+            w3f.xi_stride = c.w3f_xi; w3f.co_off = br * c.Cout;
+            if (fw) add_job(t, w3f, cdiv_i(c.Cout, 256), c.Cin);
+            t.bytes += 4.0 * (fw + bw) * (25.0 + 144.0) * c.Cout * c.Cin;
         }
         if (c.wino && w4) {
             PackJob wf{}; wf.kind = PACK_WINO4_F; wf.param = c.wi[br]; wf.dst = c.off_w4f; wf.Cout = c.Cout; wf.Cin = c.Cin; wf.ld = c.cout_pk;
@@ -1210,7 +1329,7 @@ static GenScratch gen_scratch(const GenDims& d)
         s.wino_floats = wino_enabled() ? (a1 > a2 ? a1 : a2) : 0;
         s.wv = take(s.wino_floats); s.wm = take(s.wino_floats);
         s.wv2 = take(s.wino_floats); s.wm2 = take(s.wino_floats);
-        s.wu_floats = wino_enabled() ? 64LL * 1024 * 256 : 0;          // dU of upSample1 (the larger weight tensor), 64 points of F(4x4,5x5)
+        s.wu_floats = wino_enabled() ? 36LL * 1024 * 1024 : 0;        // dU of downSample2 in phase form, 36 points of F(4x4,3x3) (> upSample1's 64 x 1024 x 256)
         s.wu = take(s.wu_floats);
     }
     s.slabs = cur;
@@ -1881,25 +2000,26 @@ int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batc
     int err = 0;
     // the 64-point weight sets of upSample1/2 only when some pass can take the F(4x4,5x5) path (wino4_applies); otherwise marked absent (bit 16)
     const bool w4 = knobs_default && wino4_min_nb() > 0 && max_batch >= wino4_min_nb() && (T % 16) == 0;
-    auto build = [wino_only, fused, sets, range_mask, w4](PackTable& pt) {
+    const bool w43 = knobs_default && wino43_min_nb() > 0 && max_batch >= wino43_min_nb() && (T % 16) == 0;      // (bit 32)
+    auto build = [wino_only, fused, sets, range_mask, w4, w43](PackTable& pt) {
         const GenNet& g = gen_net();
         if (range_mask & 4) {
             const ConvSpec* head[] = {&g.conv1, &g.ds1, &g.ds2};
-            for (const ConvSpec* c : head) add_spec_jobs(pt, *c, false, wino_only, sets);
+            for (const ConvSpec* c : head) add_spec_jobs(pt, *c, false, wino_only, sets, w4, w43);
             add_spec_jobs(pt, g.c2d1d, fused, false, sets);
         }
         if (range_mask & 1) {
             const ConvSpec* up[] = {&g.up1, &g.up2, &g.last};
-            for (const ConvSpec* c : up) add_spec_jobs(pt, *c, false, wino_only, sets, w4);
+            for (const ConvSpec* c : up) add_spec_jobs(pt, *c, false, wino_only, sets, w4, w43);
         }
         if (range_mask & 2) {
             add_spec_jobs(pt, g.c1d2d, fused, false, sets);
             for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i], fused, false, sets); add_spec_jobs(pt, g.res_out[i], fused, false, sets); }
         }
     };
-    const DevPackTable* t = dev_pack_table(16 + 4 * sets + (fused ? (wino_only ? 3 : 2) : 0) + 64 * range_mask + (w4 ? 1024 : 0), build, &err);
+    const DevPackTable* t = dev_pack_table(16 + 4 * sets + (fused ? (wino_only ? 3 : 2) : 0) + 64 * range_mask + (w4 ? 1024 : 0) + (w43 ? 2048 : 0), build, &err);
     if (!t) return err;
-    const int skipped = (fused ? (wino_only ? 3 : 1) : 0) | (w4 ? 0 : 16);
+    const int skipped = (fused ? (wino_only ? 3 : 1) : 0) | (w4 ? 0 : 16) | (w43 ? 0 : 32);
     if (sets == 1) set_pack_skips(packed, skipped | 4);
     else if (sets == 2) set_pack_skips(packed, get_pack_skips(packed) & ~4);
     else set_pack_skips(packed, skipped);

@@ -27,7 +27,7 @@ int mcvc_pack_dgrad_launch(const float* w, float* dst, const PackDgradArgs& a, i
 int mcvc_copy_launch(const float* src, float* dst, int n, hipStream_t s);
 
 // ---- whole-network re-pack (one launch): device-resident job table
-enum PackKind { PACK_FWD = 0, PACK_DGRAD = 1, PACK_COPY = 2, PACK_TRUNK_T = 3, PACK_WINO_F = 4, PACK_WINO_D = 5, PACK_WINO3_D = 6, PACK_WINO3_F = 7, PACK_WINO4_F = 8, PACK_WINO4_D = 9 };
+enum PackKind { PACK_FWD = 0, PACK_DGRAD = 1, PACK_COPY = 2, PACK_TRUNK_T = 3, PACK_WINO_F = 4, PACK_WINO_D = 5, PACK_WINO3_D = 6, PACK_WINO3_F = 7, PACK_WINO4_F = 8, PACK_WINO4_D = 9, PACK_WINO43_D = 10, PACK_WINO43_F = 11 };
 struct PackJob {
     int kind, param;       // param = index into the parameter-pointer table
     int block0, gx;        // first workgroup of this job in the flat grid; tile (bx, by) = (rel % gx, rel / gx)

@@ -145,6 +145,8 @@ __global__ void __launch_bounds__(256) pack_net_kernel(const Twin<PackNetKArgs> 
     case PACK_WINO3_F: wino3_weight_fwd_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, bx, by); break;
     case PACK_WINO4_F: wino4_weight_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, 0, bx, by); break;
     case PACK_WINO4_D: wino4_weight_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, 1, bx, by); break;
+    case PACK_WINO43_D: wino3_weight_tile_p<6>(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, bx, by); break;
+    case PACK_WINO43_F: wino3_weight_fwd_tile_p<6>(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, bx, by); break;
     default: { const int i = rel * 256 + threadIdx.x; if (i < j.Cout) dst[i] = w[i]; } break;     // PACK_COPY
     }
 }

@@ -103,12 +103,25 @@ struct WinoGemmArgs {
 };
 int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s);
 
+// G of the 3-tap transforms: P = 4: F(2x2,3x3), points {0, 1, -1, inf};  P = 6: F(4x4,3x3), points {0, 1, -1, 2, -2, inf}
+template <int P>
+static __device__ __forceinline__ void wino_g3(float v0, float v1, float v2, float* o)
+{
+    if constexpr (P == 4) { o[0] = v0; o[1] = 0.5f * (v0 + v1 + v2); o[2] = 0.5f * (v0 - v1 + v2); o[3] = v2; }
+    else {
+        const float e = v0 + v2, e2 = v0 * (1.0f / 24.0f) + v2 * (1.0f / 6.0f);
+        o[0] = 0.25f * v0; o[1] = -(e + v1) * (1.0f / 6.0f); o[2] = -(e - v1) * (1.0f / 6.0f);
+        o[3] = e2 + v1 * (1.0f / 12.0f); o[4] = e2 - v1 * (1.0f / 12.0f); o[5] = v2;
+    }
+}
+
 // Weight transform for the F(2x2,3x3) data-gradient of a stride-2 5x5 conv (padding 2).  The data-gradient is ONE stride-1
 // 3x3 conv over dY with 4*Cin output channels (column 4*ci + 2*qh + qw = output parity class), whose taps are
 //   g'[u'][v'] = W[co][ci][kh(u',qh)][kw(v',qw)],  kh(u',0) = 4 - 2u',  kh(u',1) = 5 - 2u' (u' >= 1, else no tap)
 // (pack_dgrad_tile builds the same matrix for the direct kernel).  U = G g' G^T with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
 // One thread per (co, ci), ci fastest: stores 4 consecutive columns x 16 points.
-static __device__ __forceinline__ void wino3_weight_tile(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int bx, int by)
+template <int P>
+static __device__ __forceinline__ void wino3_weight_tile_p(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int bx, int by)
 {
     const int ci = bx * 256 + threadIdx.x, co = by;
     if (co >= Cout || ci >= Cin) return;
@@ -116,14 +129,11 @@ static __device__ __forceinline__ void wino3_weight_tile(const float* w, float* 
     float gg[5][5];
 #pragma unroll
     for (int k = 0; k < 25; ++k) gg[k / 5][k % 5] = g[k];
-    auto g3 = [](float v0, float v1, float v2, float o[4]) {
-        o[0] = v0; o[1] = 0.5f * (v0 + v1 + v2); o[2] = 0.5f * (v0 - v1 + v2); o[3] = v2;
-    };
 #pragma unroll
     for (int qh = 0; qh < 2; ++qh)
 #pragma unroll
         for (int qw = 0; qw < 2; ++qw) {
-            float t[3][4];                       // t[u'][b] = sum_v' g'[u'][v'] G[b][v']
+            float t[3][P];                       // t[u'][b] = sum_v' g'[u'][v'] G[b][v']
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int kh = qh ? 5 - 2 * u : 4 - 2 * u;          // qh = 1, u = 0 -> 5: no such tap
@@ -132,15 +142,15 @@ static __device__ __forceinline__ void wino3_weight_tile(const float* w, float* 
                     if (qw) { r1 = gg[kh][3]; r2 = gg[kh][1]; }
                     else { r0 = gg[kh][4]; r1 = gg[kh][2]; r2 = gg[kh][0]; }
                 }
-                g3(r0, r1, r2, t[u]);
+                wino_g3<P>(r0, r1, r2, t[u]);
             }
             float* d0 = dst + (long long)(co_off + co) * ld + 4 * ci + 2 * qh + qw;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                float o[4];
-                g3(t[0][b], t[1][b], t[2][b], o);                   // U[a][b] = sum_u' G[a][u'] t[u'][b]
+            for (int b = 0; b < P; ++b) {
+                float o[P];
+                wino_g3<P>(t[0][b], t[1][b], t[2][b], o);            // U[a][b] = sum_u' G[a][u'] t[u'][b]
 #pragma unroll
-                for (int aa = 0; aa < 4; ++aa) d0[(long long)(aa * 4 + b) * xi_stride] = o[aa];
+                for (int aa = 0; aa < P; ++aa) d0[(long long)(aa * P + b) * xi_stride] = o[aa];
             }
         }
 }
@@ -148,7 +158,8 @@ static __device__ __forceinline__ void wino3_weight_tile(const float* w, float* 
 // Forward twin: y[oh][ow] = sum w[kh][kw] x[2oh+kh-2][2ow+kw-2] = 3x3 stride-1 pad-1 correlation over the phase planes
 // X[4ci+2p+q][i][j] = x[ci][2i+p][2j+q] with taps g'[u'][v'] = w[co][ci][2u'+p][2v'+q] (absent when the index exceeds 4).
 // U[xi][k = 4ci+2p+q][col = co_off + co].  One thread per (co, ci), co fastest.
-static __device__ __forceinline__ void wino3_weight_fwd_tile(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int bx, int by)
+template <int P>
+static __device__ __forceinline__ void wino3_weight_fwd_tile_p(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int bx, int by)
 {
     const int co = bx * 256 + threadIdx.x, ci = by;
     if (co >= Cout || ci >= Cin) return;
@@ -156,28 +167,39 @@ static __device__ __forceinline__ void wino3_weight_fwd_tile(const float* w, flo
     float gg[5][5];
 #pragma unroll
     for (int k = 0; k < 25; ++k) gg[k / 5][k % 5] = g[k];
-    auto g3 = [](float v0, float v1, float v2, float o[4]) {
-        o[0] = v0; o[1] = 0.5f * (v0 + v1 + v2); o[2] = 0.5f * (v0 - v1 + v2); o[3] = v2;
-    };
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            float t[3][4];
+            float t[3][P];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int kh = 2 * u + p;
                 float r0 = 0.f, r1 = 0.f, r2 = 0.f;
                 if (kh <= 4) { r0 = gg[kh][q]; r1 = gg[kh][2 + q]; r2 = q ? 0.f : gg[kh][4]; }
-                g3(r0, r1, r2, t[u]);
+                wino_g3<P>(r0, r1, r2, t[u]);
             }
             float* d0 = dst + (long long)(4 * ci + 2 * p + q) * ld + co_off + co;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                float o[4];
-                g3(t[0][b], t[1][b], t[2][b], o);
+            for (int b = 0; b < P; ++b) {
+                float o[P];
+                wino_g3<P>(t[0][b], t[1][b], t[2][b], o);
 #pragma unroll
-                for (int aa = 0; aa < 4; ++aa) d0[(long long)(aa * 4 + b) * xi_stride] = o[aa];
+                for (int aa = 0; aa < P; ++aa) d0[(long long)(aa * P + b) * xi_stride] = o[aa];
             }
         }
 }
+
+static __device__ __forceinline__ void wino3_weight_tile(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int bx, int by)
+{ wino3_weight_tile_p<4>(w, dst, Cout, Cin, ld, xi_stride, co_off, bx, by); }
+static __device__ __forceinline__ void wino3_weight_fwd_tile(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int bx, int by)
+{ wino3_weight_fwd_tile_p<4>(w, dst, Cout, Cin, ld, xi_stride, co_off, bx, by); }
+
+// ---- F(4x4,3x3) twins of the wino3 family (wino43_kernels.hip): 6x6 windows at stride 4, 36 points, 4x4 outputs per tile; the same operand
+// layouts with 36 matrices (weights: wino3_weight_tile_p<6> / wino3_weight_fwd_tile_p<6>)
+int mcvc_wino43_input_launch(const WinoXformArgs& a, hipStream_t s);
+int mcvc_wino43_input_phase_launch(const WinoXformArgs& a, int XH, int XW, hipStream_t s);
+int mcvc_wino43_output_launch(const WinoOutArgs& a, hipStream_t s);
+int mcvc_wino43_input_phase_t_launch(const WinoXformArgs& a, int XH, int XW, hipStream_t s);
+int mcvc_wino43_dy_t_launch(const WinoXformArgs& a, hipStream_t s);
+int mcvc_wino43_dw_launch(const float* du, float* dw0, float* dw1, int Cout, int nbr, int Cin, hipStream_t s);
