@@ -801,13 +801,13 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const Twin<WinoGemmArgs> tw)
 {
     const WinoGemmArgs& a = tw.v[blockIdx.z];
     constexpr int SA = GK * BM, SB = GK * BN, STAGE = SA + SB;
-    constexpr int NACC = (BM == 128 && BN == 64) ? 2 : 1;
+    constexpr int NBM = (BN >= 64) ? BM / 64 : 1, NBN = (BN >= 64) ? BN / 64 : 1, NACC = NBM * NBN;     // 32x32 blocks per wave (rows x columns)
     constexpr int NA = (SA / 4 + 255) / 256, NB = (SB / 4 + 255) / 256, ND = NA + NB;     // DMA instructions per wave and stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm = (BN == 64) ? (wave >> 1) : wave, wn = (BN == 64) ? (wave & 1) : 0;
+    const int wm = (BN >= 64) ? (wave >> 1) : wave, wn = (BN >= 64) ? (wave & 1) : 0;
     int lid;
     {
         const int total = (int)gridDim.x, linear = (int)blockIdx.x;
@@ -853,35 +853,50 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const Twin<WinoGemmArgs> tw)
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
         if (s < nst) issue(s, s);
-    const int a_lane = half * BM + wm * (32 * NACC) + l31;
-    const int b_lane = SA + half * BN + wn * 32 + l31;
+    const int a_lane = half * BM + wm * (32 * NBM) + l31;
+    const int b_lane = SA + half * BN + wn * (32 * NBN) + l31;
     for (int st = 0; st < nst; ++st) {
         const int newer = (nst - 1 - st) < (ST - 2) ? (nst - 1 - st) : (ST - 2);
         if (newer >= 2) wait_vm<2 * ND>(); else if (newer == 1) wait_vm<ND>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         if (st + ST - 1 < nst) issue(st + ST - 1, (st + ST - 1) % ST);
         const float* sb = smem + (st % ST) * STAGE;
-        float a0 = sb[a_lane], a1 = (NACC == 2) ? sb[a_lane + 32] : 0.f, b0 = sb[b_lane];
+        float av[NBM], bv[NBN];
+#pragma unroll
+        for (int i = 0; i < NBM; ++i) av[i] = sb[a_lane + 32 * i];
+#pragma unroll
+        for (int j = 0; j < NBN; ++j) bv[j] = sb[b_lane + 32 * j];
 #pragma unroll
         for (int p = 0; p < GK / 2; ++p) {
             const int q = (p + 1 < GK / 2) ? p + 1 : p;
-            const float na0 = sb[a_lane + q * 2 * BM], na1 = (NACC == 2) ? sb[a_lane + q * 2 * BM + 32] : 0.f, nb0 = sb[b_lane + q * 2 * BN];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
-            if constexpr (NACC == 2) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, NACC + 1, 0);
+            float na[NBM], nb[NBN];
+#pragma unroll
+            for (int i = 0; i < NBM; ++i) na[i] = sb[a_lane + q * 2 * BM + 32 * i];
+#pragma unroll
+            for (int j = 0; j < NBN; ++j) nb[j] = sb[b_lane + q * 2 * BN + 32 * j];
+#pragma unroll
+            for (int i = 0; i < NBM; ++i)
+#pragma unroll
+                for (int j = 0; j < NBN; ++j) acc[i * NBN + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i * NBN + j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NBM + NBN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, NACC, 0);
-            a0 = na0; a1 = na1; b0 = nb0;
+#pragma unroll
+            for (int i = 0; i < NBM; ++i) av[i] = na[i];
+#pragma unroll
+            for (int j = 0; j < NBN; ++j) bv[j] = nb[j];
         }
     }
-    const int n = n0 + wn * 32 + l31;
-    if (n < a.N) {
+#pragma unroll
+    for (int j = 0; j < NBN; ++j) {
+        const int n = n0 + wn * (32 * NBN) + 32 * j + l31;
+        if (n >= a.N) continue;
         float* C = a.c + (long long)xi * a.c_xi + n;
 #pragma unroll
-        for (int i = 0; i < NACC; ++i)
+        for (int i = 0; i < NBM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (32 * NACC) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < a.M) C[(long long)m * a.ldc] = acc[i][r];
+                const int m = m0 + wm * (32 * NBM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m < a.M) C[(long long)m * a.ldc] = acc[i * NBN + j][r];
             }
     }
 }
@@ -945,6 +960,10 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
         case 9: return gemm2_launch<64, 64, 16, 6>(b, nxi, s);
         case 10: return gemm2_launch<128, 64, 32, 4>(b, nxi, s);
         case 11: return gemm2_launch<64, 64, 32, 4>(b, nxi, s);
+        case 12: return gemm2_launch<128, 128, 16, 4>(b, nxi, s);
+        case 13: return gemm2_launch<128, 128, 32, 3>(b, nxi, s);
+        case 14: return gemm2_launch<128, 128, 16, 6>(b, nxi, s);
+        case 15: return gemm2_launch<128, 128, 32, 2>(b, nxi, s);
         default: break;
     }
     // long-K products (the F(2x2,3x3) layers: K = 4*Cin or Cout >= 512): 64x64 tiles with 32-deep stages measured 10-20 % faster than
