@@ -63,7 +63,7 @@ struct Exec {
     int br1_on_main = 0;           // conv_wgrad: run the gate branch's generic weight gradient on the main stream (see there)
     int no_join = 0;               // backward pass: leave the auxiliary stream un-joined at the end (mcvc_gen_backward_flags)
     int fuse_next = 0;             // the caller's next step is a norm that can absorb a Winograd output transform (set before conv_fwd)
-    int pend_pts = 0;              // 16 / 36: the output transform in `pend` has not run yet -- norm_fwd runs it (fused when it fits)
+    int pend_pts = 0;              // 16 / 36 / 43 (= F(4x4,3x3)) / 64: the output transform in `pend` has not run yet -- norm_fwd runs it (fused when it fits)
     WinoOutArgs pend;
     int pack_skips;                // what the last re-pack of `packed` left stale: bit 0 = generic trunk copies, bit 1 = direct copies of the Winograd layers
     unsigned* sync;                // arrival counters of the persistent trunk kernels (MCVC_TRUNK_SYNC_WORDS words of the scratch)
@@ -357,7 +357,8 @@ static bool conv_wino4(Exec& ex, const ConvSpec& c, const float* packed, int dgr
         oa.y = y.p + (long long)b0 * y.sb; oa.y_sb = y.sb; oa.y_sc = y.sc; oa.y_sh = y.sh;
         oa.N = nb; oa.Cout = M; oa.OH = H; oa.OW = W; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
         oa.shuffle = shuffle; oa.YH = 2 * H; oa.YW = 2 * W; oa.accumulate = accumulate;
-        ex.fail(mcvc_wino4_output_launch(oa, ex.s));
+        if (ex.fuse_next && !dgrad && shuffle && nbc == NB) { ex.pend = oa; ex.pend_pts = 64; }
+        else ex.fail(mcvc_wino4_output_launch(oa, ex.s));
     }
     return true;
 }
@@ -504,7 +505,8 @@ static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, i
                 oa.y = y.p + (long long)b0 * y.sb; oa.y_sb = y.sb; oa.y_sc = y.sc; oa.y_sh = y.sh;
                 oa.N = nb; oa.Cout = M; oa.OH = OH; oa.OW = OW; oa.TH = TH; oa.TW = TW; oa.NT = (int)NT; oa.NTp = (int)NTp;
                 oa.shuffle = 0; oa.YH = OH; oa.YW = OW; oa.accumulate = 0;
-                ex.fail(mcvc_wino43_output_launch(oa, ex.s));
+                if (ex.fuse_next && nbc == NB) { ex.pend = oa; ex.pend_pts = 43; }
+                else ex.fail(mcvc_wino43_output_launch(oa, ex.s));
             }
             return;
         }
@@ -1194,7 +1196,8 @@ static void norm_fwd(Exec& ex, float* x, long long x_sn, long long x_sc, long lo
         const int pts = ex.pend_pts;
         ex.pend_pts = 0;
         if (mcvc_norm_fwd_wino_applies(a, ex.pend, pts)) { ex.fail(mcvc_norm_fwd_wino_launch(a, ex.pend, pts, ex.s)); return; }
-        ex.fail(pts == 16 ? mcvc_wino3_output_launch(ex.pend, ex.s) : mcvc_wino_output_launch(ex.pend, ex.s));
+        ex.fail(pts == 16 ? mcvc_wino3_output_launch(ex.pend, ex.s) : pts == 36 ? mcvc_wino_output_launch(ex.pend, ex.s)
+                : pts == 43 ? mcvc_wino43_output_launch(ex.pend, ex.s) : mcvc_wino4_output_launch(ex.pend, ex.s));
     }
     ex.fail(mcvc_norm_fwd_launch(a, ex.s));
 }
@@ -2001,7 +2004,8 @@ int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batc
     // the 64-point weight sets of upSample1/2 only when some pass can take the F(4x4,5x5) path (wino4_applies); otherwise marked absent (bit 16)
     const bool w4 = knobs_default && wino4_min_nb() > 0 && max_batch >= wino4_min_nb() && (T % 16) == 0;
     const bool w43 = knobs_default && wino43_min_nb() > 0 && max_batch >= wino43_min_nb() && (T % 16) == 0;      // (bit 32)
-    auto build = [wino_only, fused, sets, range_mask, w4, w43](PackTable& pt) {
+    const bool up1_w4 = (long long)max_batch * 5 * (T / 16) >= 64;             // upSample1 runs on 20 x T/4 images: 5 x T/16 tiles per sample
+    auto build = [wino_only, fused, sets, range_mask, w4, w43, up1_w4](PackTable& pt) {
         const GenNet& g = gen_net();
         if (range_mask & 4) {
             const ConvSpec* head[] = {&g.conv1, &g.ds1, &g.ds2};
@@ -2010,14 +2014,15 @@ int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batc
         }
         if (range_mask & 1) {
             const ConvSpec* up[] = {&g.up1, &g.up2, &g.last};
-            for (const ConvSpec* c : up) add_spec_jobs(pt, *c, false, wino_only, sets, w4, w43);
+            // (a layer whose largest pass has fewer than 64 F(4x4) tiles never takes that path, conv_wino4: its 64-point sets are not written)
+            for (const ConvSpec* c : up) add_spec_jobs(pt, *c, false, wino_only, sets, w4 && (c != &g.up1 || up1_w4), w43);
         }
         if (range_mask & 2) {
             add_spec_jobs(pt, g.c1d2d, fused, false, sets);
             for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i], fused, false, sets); add_spec_jobs(pt, g.res_out[i], fused, false, sets); }
         }
     };
-    const DevPackTable* t = dev_pack_table(16 + 4 * sets + (fused ? (wino_only ? 3 : 2) : 0) + 64 * range_mask + (w4 ? 1024 : 0) + (w43 ? 2048 : 0), build, &err);
+    const DevPackTable* t = dev_pack_table(16 + 4 * sets + (fused ? (wino_only ? 3 : 2) : 0) + 64 * range_mask + (w4 ? 1024 : 0) + (w43 ? 2048 : 0) + (up1_w4 ? 4096 : 0), build, &err);
     if (!t) return err;
     const int skipped = (fused ? (wino_only ? 3 : 1) : 0) | (w4 ? 0 : 16) | (w43 ? 0 : 32);
     if (sets == 1) set_pack_skips(packed, skipped | 4);

@@ -551,12 +551,34 @@ __global__ void __launch_bounds__(256) act_bwd_vec_kernel(const Twin<ActBwdArgs>
 }
 
 // Output transform of a Winograd convolution + instance norm + activation in one pass: the products M[xi][co][tile] are turned into the
-// 2x2 outputs of each tile in registers (+ bias), the plane statistics are taken over them, and both the conv output (the backward pass
+// S x S outputs of each tile in registers (+ bias), the plane statistics are taken over them, and both the conv output (the backward pass
 // reads it) and the normalised / activated plane are stored -- the separate output-transform launch and the norm's re-read of the conv
 // output go away (4 launches per generator forward: downSample1/2, upSample1/2, model.py:245-246, 274-275).
 //   PTS = 16: F(2x2,3x3) (the stride-2 5x5 layers in phase form), plane (n, c) = conv channel c (value) and C + c (gate, GLU)
 //   PTS = 36: F(2x2,5x5) with PixelShuffle(2): plane (n, c) = conv channels 4c .. 4c+3 interleaved; items = (sub-channel, tile)
+//   PTS = 43: F(4x4,3x3) (36 points, 4x4 outputs), planes as PTS = 16          PTS = 64: F(4x4,5x5) (4x4 outputs), planes as PTS = 36
 // G threads share one plane, every thread owns TT items.
+template <int PTS> struct WinoOutT;
+template <> struct WinoOutT<16> { static constexpr int R = 4, S = 2; static constexpr bool SHUF = false;
+    static __device__ __forceinline__ void at(const float* m, float* o) { o[0] = m[0] + m[1] + m[2]; o[1] = m[1] - m[2] - m[3]; } };
+template <> struct WinoOutT<36> { static constexpr int R = 6, S = 2; static constexpr bool SHUF = true;
+    static __device__ __forceinline__ void at(const float* m, float* o) { o[0] = m[0] + m[1] + m[2] + m[3] + m[4]; o[1] = m[1] - m[2] + 2.f * (m[3] - m[4]) + m[5]; } };
+template <> struct WinoOutT<43> { static constexpr int R = 6, S = 4; static constexpr bool SHUF = false;
+    static __device__ __forceinline__ void at(const float* m, float* o)
+    {
+        const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+        o[0] = m[0] + s12 + s34; o[1] = d12 + 2.f * d34; o[2] = s12 + 4.f * s34; o[3] = d12 + 8.f * d34 + m[5];
+    } };
+template <> struct WinoOutT<64> { static constexpr int R = 8, S = 4; static constexpr bool SHUF = true;
+    static __device__ __forceinline__ void at(const float* m, float* o)          // A^T of wino4.h: points {0, 1, -1, 2, -2, 1/2, -1/2, inf}
+    {
+        const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
+        o[0] = m[0] + s12 + s34 + s56;
+        o[1] = d12 + 2.f * d34 + 0.5f * d56;
+        o[2] = s12 + 4.f * s34 + 0.25f * s56;
+        o[3] = d12 + 8.f * d34 + 0.125f * d56 + m[7];
+    } };
+
 struct NormFwdWinoKArgs { NormArgs a; WinoOutArgs w; };
 template <int G, int TT, int PTS>
 __global__ void __launch_bounds__(256) norm_fwd_wino_kernel(const Twin<NormFwdWinoKArgs> tw)
@@ -565,8 +587,9 @@ __global__ void __launch_bounds__(256) norm_fwd_wino_kernel(const Twin<NormFwdWi
     const NormArgs& a = ka_.a;
     const WinoOutArgs& w = ka_.w;
     __shared__ float red[4];
-    constexpr bool SHUF = PTS == 36;
-    constexpr int R = SHUF ? 6 : 4;
+    using WT = WinoOutT<PTS>;
+    constexpr bool SHUF = WT::SHUF;
+    constexpr int R = WT::R, S = WT::S, E = S * S;
     constexpr int GPB = 256 / G;
     const int g = threadIdx.x / G, l = threadIdx.x % G;
     const long long plane_id = (long long)blockIdx.x * GPB + g;
@@ -578,7 +601,7 @@ __global__ void __launch_bounds__(256) norm_fwd_wino_kernel(const Twin<NormFwdWi
     const int Cx = a.C * nbr;
     const long long xs = (long long)w.Cout * w.NTp;
     const float invP = 1.0f / (float)(a.H * a.W);
-    float xv[2][TT][4];
+    float xv[2][TT][E];
     int pos[TT];                                     // plane offset h * W + w of the item's first output (-1: no item)
 #pragma unroll
     for (int k = 0; k < TT; ++k) {
@@ -586,37 +609,37 @@ __global__ void __launch_bounds__(256) norm_fwd_wino_kernel(const Twin<NormFwdWi
         const int sub = SHUF ? item / tiles : 0;
         const int t = item - sub * tiles;
         const int ty = t / w.TW, tx = t - ty * w.TW;
-        pos[k] = item < items ? (SHUF ? (4 * ty + (sub >> 1)) * a.W + 4 * tx + (sub & 1) : 2 * ty * a.W + 2 * tx) : -1;
+        pos[k] = item < items ? (SHUF ? (2 * S * ty + (sub >> 1)) * a.W + 2 * S * tx + (sub & 1) : S * ty * a.W + S * tx) : -1;
 #pragma unroll
         for (int br = 0; br < 2; ++br) {
             if (br < nbr) {
                 const int co = SHUF ? 4 * c + sub : c + br * a.C;
-                float o[4] = {0.f, 0.f, 0.f, 0.f};
+                float o[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) o[e] = 0.f;
                 if (item < items) {
                     const float* src = w.m + (long long)co * w.NTp + (long long)n * tiles + t;
-                    float u[2][R];
+                    float u[S][R];
 #pragma unroll
                     for (int b = 0; b < R; ++b) {
-                        float m[R];
+                        float m[R], q[S];
 #pragma unroll
                         for (int aa = 0; aa < R; ++aa) m[aa] = src[(long long)(aa * R + b) * xs];
-                        if constexpr (SHUF) { u[0][b] = m[0] + m[1] + m[2] + m[3] + m[4]; u[1][b] = m[1] - m[2] + 2.f * (m[3] - m[4]) + m[R - 1]; }
-                        else { u[0][b] = m[0] + m[1] + m[2]; u[1][b] = m[1] - m[2] - m[3]; }
+                        WT::at(m, q);
+#pragma unroll
+                        for (int i = 0; i < S; ++i) u[i][b] = q[i];
                     }
                     const float bias = w.bias ? w.bias[co] : 0.f;
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        if constexpr (SHUF) {
-                            o[2 * i] = u[i][0] + u[i][1] + u[i][2] + u[i][3] + u[i][4] + bias;
-                            o[2 * i + 1] = u[i][1] - u[i][2] + 2.f * (u[i][3] - u[i][4]) + u[i][R - 1] + bias;
-                        } else {
-                            o[2 * i] = u[i][0] + u[i][1] + u[i][2] + bias;
-                            o[2 * i + 1] = u[i][1] - u[i][2] - u[i][3] + bias;
-                        }
+                    for (int i = 0; i < S; ++i) {
+                        float q[S];
+                        WT::at(u[i], q);
+#pragma unroll
+                        for (int j = 0; j < S; ++j) o[i * S + j] = q[j] + bias;
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xv[br][k][e] = o[e];
+                for (int e = 0; e < E; ++e) xv[br][k][e] = o[e];
             }
         }
     }
@@ -631,7 +654,12 @@ __global__ void __launch_bounds__(256) norm_fwd_wino_kernel(const Twin<NormFwdWi
         if (br < nbr) {
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < TT; ++k) s += (xv[br][k][0] + xv[br][k][1]) + (xv[br][k][2] + xv[br][k][3]);
+            for (int k = 0; k < TT; ++k) {
+                float sk = 0.f;
+#pragma unroll
+                for (int e = 0; e < E; e += 4) sk += (xv[br][k][e] + xv[br][k][e + 1]) + (xv[br][k][e + 2] + xv[br][k][e + 3]);
+                s += sk;
+            }
             s = gsum<G>(s, red);
             const float m = s * invP;
             float q = 0.f;
@@ -639,7 +667,7 @@ __global__ void __launch_bounds__(256) norm_fwd_wino_kernel(const Twin<NormFwdWi
             for (int k = 0; k < TT; ++k) {
                 if (pos[k] >= 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float d = xv[br][k][e] - m; q += d * d; }
+                    for (int e = 0; e < E; ++e) { const float d = xv[br][k][e] - m; q += d * d; }
                 }
             }
             q = gsum<G>(q, red);
@@ -654,7 +682,7 @@ __global__ void __launch_bounds__(256) norm_fwd_wino_kernel(const Twin<NormFwdWi
             for (int k = 0; k < TT; ++k) {
                 if (pos[k] >= 0) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) xp[pos[k] + (e >> 1) * dh + (e & 1) * dw] = xv[br][k][e];
+                    for (int e = 0; e < E; ++e) xp[pos[k] + (e / S) * dh + (e % S) * dw] = xv[br][k][e];
                 }
             }
         }
@@ -665,13 +693,13 @@ __global__ void __launch_bounds__(256) norm_fwd_wino_kernel(const Twin<NormFwdWi
         if (pos[k] >= 0) {
             const int h0 = pos[k] / a.W, w0 = pos[k] - h0 * a.W;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < E; ++e) {
                 const float z0 = (xv[0][k][e] - mean[0]) * rstd[0] * g0 + b0;
                 float y;
                 if (a.act == ACT_GLU) y = z0 * sigmoidf_((xv[1][k][e] - mean[1]) * rstd[1] * g1 + b1);
                 else if (a.act == ACT_SILU) y = z0 * sigmoidf_(z0);
                 else y = z0;
-                yp[(long long)(h0 + (e >> 1) * (SHUF ? 2 : 1)) * a.y_sh + w0 + (e & 1) * dw] = y;
+                yp[(long long)(h0 + (e / S) * (SHUF ? 2 : 1)) * a.y_sh + w0 + (e % S) * dw] = y;
             }
         }
     }
@@ -685,35 +713,47 @@ static int pick_group(int P) { return P <= 32 ? 16 : (P <= 640 ? 64 : 256); }
 static int wino_norm_items(const NormArgs& a, const WinoOutArgs& w, int pts)
 {
     if (a.nslab != 1 || a.res != nullptr || w.accumulate || w.N != a.N || (w.OH & 1) || (w.OW & 1) || w.NT != w.N * w.TH * w.TW) return 0;
-    if (pts == 16) {
+    if ((pts == 43 || pts == 64) && ((w.OH & 3) || (w.OW & 3))) return 0;
+    if (pts == 16 || pts == 43) {
         if (w.shuffle || a.H != w.OH || a.W != w.OW || w.Cout != a.C * (a.act == ACT_GLU ? 2 : 1) || a.x_sc != (long long)a.H * a.W) return 0;
         return w.TH * w.TW;
     }
-    if (pts == 36) {
+    if (pts == 36 || pts == 64) {
         if (!w.shuffle || a.act == ACT_GLU || a.H != 2 * w.OH || a.W != 2 * w.OW || w.Cout != 4 * a.C || a.x_sc != (long long)a.H * a.W) return 0;
         return 4 * w.TH * w.TW;
     }
     return 0;
 }
+// (registers: an item holds 4 outputs at 2x2 tiles, 16 at 4x4 -- times two branches with GLU)
+static int wino_norm_max_items(int pts) { return (pts == 43 || pts == 64) ? 320 : 1280; }
 
 bool mcvc_norm_fwd_wino_applies(const NormArgs& a, const WinoOutArgs& w, int pts)
 {
     const int items = wino_norm_items(a, w, pts);
-    return items > 0 && items <= 1280;
+    return items > 0 && items <= wino_norm_max_items(pts);
 }
 
 int mcvc_norm_fwd_wino_launch(const NormArgs& a, const WinoOutArgs& w, int pts, hipStream_t s)
 {
     const int items = wino_norm_items(a, w, pts);
-    if (items <= 0 || items > 1280) return MCVC_ERR_INVALID;
+    if (items <= 0 || items > wino_norm_max_items(pts)) return MCVC_ERR_INVALID;
     const long long planes = (long long)a.N * a.C;
-    const int nbr = (pts == 16 && a.act == ACT_GLU) ? 2 : 1;
+    const int nbr = ((pts == 16 || pts == 43) && a.act == ACT_GLU) ? 2 : 1;
     const double el = (double)planes * a.H * a.W * nbr;
-    TraceScope ts(K_NORM_FWD, s, 0.0, 4.0 * (el * pts / 4 + el + (double)planes * a.H * a.W));
+    const double m_per_out = pts == 16 ? 4.0 : (pts == 36 ? 9.0 : (pts == 43 ? 2.25 : 4.0));      // points per output
+    TraceScope ts(K_NORM_FWD, s, 0.0, 4.0 * (el * m_per_out + el + (double)planes * a.H * a.W));
 #define MCVC_FWD_WINO(GG, TT) { \
         if (pts == 16) mcvc_launch((norm_fwd_wino_kernel<GG, TT, 16>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, NormFwdWinoKArgs{a, w}); \
-        else mcvc_launch((norm_fwd_wino_kernel<GG, TT, 36>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, NormFwdWinoKArgs{a, w}); \
+        else if (pts == 36) mcvc_launch((norm_fwd_wino_kernel<GG, TT, 36>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, NormFwdWinoKArgs{a, w}); \
+        else if (pts == 43) mcvc_launch((norm_fwd_wino_kernel<GG, TT, 43>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, NormFwdWinoKArgs{a, w}); \
+        else mcvc_launch((norm_fwd_wino_kernel<GG, TT, 64>), dim3((unsigned)cdiv_ll(planes, 256 / GG)), dim3(256), 0, s, NormFwdWinoKArgs{a, w}); \
         return (int)hipGetLastError(); }
+    if (pts == 43 || pts == 64) {              // 4x4 outputs per item: a quarter of the items of the 2x2 schemes on the same plane
+        if (items <= 64) MCVC_FWD_WINO(64, 1)
+        if (items <= 128) MCVC_FWD_WINO(64, 2)
+        if (items <= 256 && planes < 2048) MCVC_FWD_WINO(256, 1)
+        MCVC_FWD_WINO(64, 5)
+    }
     if (items <= 128) MCVC_FWD_WINO(64, 2)
     if (items <= 512 && planes < 2048) MCVC_FWD_WINO(256, 2)
     if (items <= 320) MCVC_FWD_WINO(64, 5)

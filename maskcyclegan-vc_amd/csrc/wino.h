@@ -23,7 +23,8 @@ struct WinoOutArgs {
 };
 
 int mcvc_wino_input_launch(const WinoXformArgs& a, hipStream_t s);
-// output transform + instance norm + activation in one launch (norm_kernels.hip); pts = 16: F(2x2,3x3), 36: F(2x2,5x5) + PixelShuffle
+// output transform + instance norm + activation in one launch (norm_kernels.hip); pts = 16: F(2x2,3x3), 36: F(2x2,5x5) + PixelShuffle,
+// 43: F(4x4,3x3), 64: F(4x4,5x5) + PixelShuffle
 struct NormArgs;
 bool mcvc_norm_fwd_wino_applies(const NormArgs& a, const WinoOutArgs& w, int pts);
 int mcvc_norm_fwd_wino_launch(const NormArgs& a, const WinoOutArgs& w, int pts, hipStream_t s);

@@ -985,6 +985,12 @@ class TrainEngine:
         ] + head
         if split:
             tasks += [(3, d["real1"], (), None), (3, d["real2"], (), "r2")]
+        ident_pos = os.environ.get("MCVC_IDENT_POS", "tail") if (ident and second) else "tail"
+        adv1_lane = 2
+        if ident_pos in ("head", "head3"):     # experiment: the identity chain at the START of lane 2 (beside the forwards) instead of the tail
+            tail = []
+            tasks += [(2, g["ident_fwd"], (), None), (2, g["ident_bwd"], ("rf",), "i")]
+            adv1_lane = 3 if ident_pos == "head3" else 2
         tasks += [
             (1, d["cycles"], (), "cyc"),
             (0, g["cycle"], (), None),
@@ -992,7 +998,7 @@ class TrainEngine:
             (3, d_update(("discriminator_A", "discriminator_B")), (), "dupd1"),
             (1, d["fake2"] if split else d["full2"], ("r2",) if split else (), None),
             (1, d_update(("discriminator_A2", "discriminator_B2")), (), "dupd2"),
-            (2, g["adv1"], ("g", "dupd1"), "d1"),
+            (adv1_lane, g["adv1"], ("g", "dupd1"), "d1"),
         ] + tail + [
             (0, g["adv2"], ("dupd2",), None),
             (0, g["bwd_cycle"], bwd_waits + ("rf",), None),
