@@ -306,6 +306,12 @@ static int wino4_min_nb()
     static const int nb = [] { const char* e = getenv("MCVC_WINO4_NB"); return e ? atoi(e) : 1; }();
     return nb;
 }
+// fewest F(4x4,5x5) tiles in a pass (the GEMM's column count; 32-column granularity)
+static int wino4_min_tiles()
+{
+    static const int n = [] { const char* e = getenv("MCVC_WINO4_MIN_TILES"); return e ? atoi(e) : 64; }();
+    return n < 32 ? 32 : n;
+}
 static int wino43_min_nb()
 {
     static const int nb = [] { const char* e = getenv("MCVC_WINO43_NB"); return e ? atoi(e) : 4; }();
@@ -337,11 +343,11 @@ static bool conv_wino4(Exec& ex, const ConvSpec& c, const float* packed, int dgr
     const int TH = H / 4, TW = W / 4;
     if ((M % 128) != 0 || (K % 16) != 0) return false;
     const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, K > M ? K : M);
-    if (!nbc || (long long)nbc * TH * TW < 64) return false;
+    if (!nbc || (long long)nbc * TH * TW < wino4_min_tiles()) return false;
     if (ex.dry) return true;
     for (int b0 = 0; b0 < NB; b0 += nbc) {
         const int nb = NB - b0 < nbc ? NB - b0 : nbc;
-        const long long NT = (long long)nb * TH * TW, NTp = (NT + 31) & ~31LL;
+        const long long NT = (long long)nb * TH * TW, NTp = NT <= 64 ? 64 : ((NT + 31) & ~31LL);      // (the GEMM wants a pitch of 64+ columns)
         WinoXformArgs xi{};
         xi.x = x.p + (long long)b0 * x.sb; xi.x_sb = x.sb; xi.x_sc = x.sc; xi.x_sh = x.sh; xi.v = ex.wv;
         xi.N = nb; xi.C = K; xi.H = H; xi.W = W; xi.TH = TH; xi.TW = TW; xi.NT = (int)NT; xi.NTp = (int)NTp; xi.pad = 2;
@@ -2004,7 +2010,7 @@ int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batc
     // the 64-point weight sets of upSample1/2 only when some pass can take the F(4x4,5x5) path (wino4_applies); otherwise marked absent (bit 16)
     const bool w4 = knobs_default && wino4_min_nb() > 0 && max_batch >= wino4_min_nb() && (T % 16) == 0;
     const bool w43 = knobs_default && wino43_min_nb() > 0 && max_batch >= wino43_min_nb() && (T % 16) == 0;      // (bit 32)
-    const bool up1_w4 = (long long)max_batch * 5 * (T / 16) >= 64;             // upSample1 runs on 20 x T/4 images: 5 x T/16 tiles per sample
+    const bool up1_w4 = (long long)max_batch * 5 * (T / 16) >= wino4_min_tiles();             // upSample1 runs on 20 x T/4 images: 5 x T/16 tiles per sample
     auto build = [wino_only, fused, sets, range_mask, w4, w43, up1_w4](PackTable& pt) {
         const GenNet& g = gen_net();
         if (range_mask & 4) {

@@ -194,7 +194,7 @@ class TrainEngine:
         # ... with the identity passes G(real, ones) as their own chain (forward, loss, backward on lane 2, beside the translation ->
         # cycle chain) instead of inside batched 2B passes: they depend on nothing else, and their weight gradients are ordered in front
         # of the cycle backward by one event
-        self.grouped_ident = os.environ.get("MCVC_GROUPED_IDENT", "1") != "0"
+        self.grouped_ident = os.environ.get("MCVC_GROUPED_IDENT", "0") != "0"
         # Pipelined step (needs the grouped schedule): iteration t's discriminator phase is issued together with iteration t+1's
         # generator phase, as one task graph (_pipelined_step); MCVC_PIPELINE=0 keeps the two phases of an iteration back to back.
         self.pipelined = os.environ.get("MCVC_PIPELINE", "1") != "0"
@@ -852,10 +852,14 @@ class TrainEngine:
             return lambda ln: self._twin(lambda: fn(a, *args), lambda: fn(b, *args))
 
         def gen_fwd(ln):
+            if os.environ.get("MCVC_DEBUG_SKIP_DGEN") == "1":      # TIMING EXPERIMENT ONLY (wrong losses): what the D-phase generator forwards cost
+                return
             self._twin(lambda: self._G(A2B, real_A, mask_A, gen_B, gst[0], B, s0),                          # :267 generated_B
                        lambda: self._G(B2A, real_B, mask_B, gen_A, gst[1], B, s1))                          # :259 generated_A
 
         def cycles(ln):
+            if os.environ.get("MCVC_DEBUG_SKIP_DGEN") == "1":
+                return
             self._twin(lambda: self._G(B2A, gen_B, None, cyc_A, gst[0], B, s0),                             # :271 cycled_A
                        lambda: self._G(A2B, gen_A, None, cyc_B, gst[1], B, s1))                             # :263 cycled_B
 
