@@ -21,7 +21,7 @@ constexpr int kFewTW = 64;       // tile: 16 threads x 4 pixels wide
 constexpr int kFewTH = 16;       //       16 rows
 constexpr int kFewCC = 4;        // input channels staged per LDS round
 
-__device__ float g_few_zero[64];         // zero-initialised: DMA source for out-of-image elements
+__device__ __attribute__((aligned(16))) float g_few_zero[64];         // zero-initialised: DMA source for out-of-image elements
 
 __device__ __forceinline__ void glds4(const float* g, float* l)
 {
@@ -40,6 +40,7 @@ struct FewArgs {
     int nsplit, ch_per_split, NB;
     int PH, PWp;                 // LDS patch rows / pitch (multiple of 4)
     int accumulate;
+    int dbg;                     // timing experiments (MCVC_FEW_DBG): 1 = staging only, 2 = arithmetic only
 };
 
 template <int CO, int KW>
@@ -158,6 +159,173 @@ __global__ void __launch_bounds__(256) conv_fewout_kernel(const Twin<FewArgs> tw
             if (a.accumulate) { if (a.nsplit > 1) unsafeAtomicAdd(dst, v); else *dst += v; }
             else *dst = v;
         }
+    }
+}
+
+// ---- the same convolution on the matrix cores (KH x KW = 5 x 15: lastConvLayer forward, conv1's data gradient) --------------------------
+// With one or two output channels a (co, pixel) GEMM wastes 30 of 32 rows; here the KERNEL COLUMN is the row dimension instead:
+//     Z[kw][h][w'] = sum over (ci, kh) of W[ci][kh][kw] * x[ci][h + kh][w']          16 rows (15 taps + a zero row) x haloed pixels
+//     y[h][w]      = sum over kw of Z[kw][h][w + kw]
+// i.e. M = 16, K = Cin * KH, N = the haloed row (TW + 14 columns): v_mfma_f32_16x16x4_f32 with the four k of an instruction = four (ci, kh)
+// pairs, the B operand read straight from the staged planes (lane n of group k reads x[ci_k][h + kh_k][w0 + n]).  15/16 of the rows and
+// 64/80 of the columns are useful: 1.33x the direct FLOPs on a pipe with 4x the VALU kernel's rate.  A wave owns 4 output rows x 5 column
+// tiles (20 accumulators per output channel), so one A read serves 20 MFMAs; the anti-diagonal sum runs once per tile through LDS.
+// Staging, the split over input channels and the slab / accumulate conventions are those of conv_fewout_kernel.
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+constexpr int kFewMfmaPW = 84, kFewMfmaPH = kFewTH + 4;                 // patch pitch / rows for KH x KW = 5 x 15
+constexpr int kFewMfmaNCH = (kFewMfmaPH * (kFewMfmaPW / 4) + 63) / 64;  // 16-byte DMA instructions per plane (7)
+template <int CO>
+__global__ void __launch_bounds__(256, (CO == 1 ? 2 : 1)) conv_fewout_mfma_kernel(const Twin<FewArgs> tw)
+{
+    const FewArgs& a = tw.v[blockIdx.z];
+    extern __shared__ __attribute__((aligned(16))) float xs[];          // [2 buffers][kFewCC planes | weights]; reused by the epilogue
+    constexpr int KH = 5, KW = 15, KWP = 16, NTI = (kFewTW + KW - 1 + 15) / 16;      // 5 column tiles of 16 haloed pixels
+    constexpr int PWp = kFewMfmaPW, PH = kFewMfmaPH, P4 = PWp / 4, plane = PH * PWp, NCH = kFewMfmaNCH;
+    static_assert((kFewCC * KH) % 4 == 0 && kFewCC == 4, "k blocks of four; one wave stages one channel");
+    const int tid = threadIdx.x;
+    const int NB = a.NB, tiles_w = a.tiles_w;
+    const int tile = blockIdx.x, split = blockIdx.y / NB, n = blockIdx.y - split * NB;
+    const int oh0 = (tile / tiles_w) * kFewTH, ow0 = (tile % tiles_w) * kFewTW;
+    const int H = a.H, W = a.W, OH = a.OH, OW = a.OW, x_sh = a.x_sh, w_cout = a.w_cout, Cout = a.Cout;
+    const long long x_sc = a.x_sc;
+    const int ih0 = oh0 - a.pad_h, iw0 = ow0 - a.pad_w;
+    const int c_begin = split * a.ch_per_split;
+    int c_end = c_begin + a.ch_per_split;
+    if (c_end > a.Cin) c_end = a.Cin;
+    const float* xn = a.x + (long long)n * a.x_sb;
+    const float* wbase = a.w;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, kq = lane >> 4;
+    // The patch is shifted right by `shc` columns so that LDS column 4q holds an image column that is a multiple of 4: whole 16-byte pieces
+    // are inside or outside the image, and the planes stream in by 16-byte LDS-DMA (the 4-byte form moves 0.6 dword per clock and CU: 430 of
+    // the 516 us of a 64-sample lastConvLayer forward were staging).  Out-of-image pieces are never written: both buffers are cleared once and
+    // a tile's halo sits at the same places in every round.  Wave w stages channel w of the round; a piece's image offset is round-invariant.
+    const int shc = (4 - (a.pad_w & 3)) & 3;
+    int poff[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int idx = ch * 64 + lane;
+        const int r = idx / P4, c = idx - r * P4;
+        const int ih = ih0 + r, iw = iw0 - shc + 4 * c;
+        poff[ch] = (r < PH && ih >= 0 && ih < H && iw >= 0 && iw + 3 < W) ? ih * x_sh + iw : -1;
+    }
+    constexpr int wsz = kFewCC * KH * CO * KWP;                         // weights of one round: [ci][kh][co][16]
+    constexpr int NWD = (wsz + 255) / 256;                              // 4-byte DMA instructions per wave for them
+    constexpr int bufsz = kFewCC * plane + wsz;
+    int woff[NWD];
+#pragma unroll
+    for (int i = 0; i < NWD; ++i) {
+        const int d = (wave + 4 * i) * 64 + lane;
+        const int kw = d % KWP; int t = d / KWP;
+        const int co = t % CO; t /= CO;                                 // t = ci * KH + kh
+        woff[i] = (d < wsz && kw < KW && co < Cout) ? (t * KW + kw) * w_cout + co : -1;
+    }
+    for (int i = tid; i < (2 * bufsz) >> 2; i += 256) reinterpret_cast<float4*>(xs)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    auto stage = [&](int c0, float* dst) {
+        if (c0 + kFewCC > c_end) {                                      // partial last round: its missing channels read as zeros
+            for (int i = tid; i < kFewCC * plane; i += 256)
+                if (c0 + i / plane >= c_end) dst[i] = 0.f;
+            for (int i = tid; i < wsz; i += 256)
+                if (c0 + i / (KH * CO * KWP) >= c_end) dst[kFewCC * plane + i] = 0.f;
+        }
+        if (c0 + wave < c_end) {
+            const float* xc = xn + (long long)(c0 + wave) * x_sc;
+            float* pd = dst + wave * plane;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+                if (poff[ch] >= 0)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xc + poff[ch]),
+                                                     (__attribute__((address_space(3))) void*)(pd + ch * 256), 16, 0, 0);
+        }
+        const float* wr = wbase + (long long)c0 * KH * KW * w_cout;
+        float* wdst = dst + kFewCC * plane;
+#pragma unroll
+        for (int i = 0; i < NWD; ++i) {
+            const int d0 = (wave + 4 * i) * 64;                         // (rows of channels past c_end stay zero: cleared above)
+            if (woff[i] >= 0 && c0 + (d0 + lane) / (KH * CO * KWP) < c_end) glds4(wr + woff[i], wdst + d0);
+        }
+    };
+    f32x4_ acc[CO][4][NTI];
+#pragma unroll
+    for (int co = 0; co < CO; ++co)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < NTI; ++j) acc[co][r][j] = f32x4_{0.f, 0.f, 0.f, 0.f};
+    const int nrounds = (c_end > c_begin) ? (c_end - c_begin + kFewCC - 1) / kFewCC : 0;
+    const int dbg = a.dbg;
+    if (nrounds > 0 && !(dbg & 2)) stage(c_begin, xs);
+    for (int rd = 0; rd < nrounds; ++rd) {
+        float* cur = xs + (rd & 1) * bufsz;
+        __syncthreads();
+        if (rd + 1 < nrounds && !(dbg & 2)) stage(c_begin + (rd + 1) * kFewCC, xs + ((rd + 1) & 1) * bufsz);
+        if (dbg & 1) continue;
+        const float* wcur = cur + kFewCC * plane;
+        // software pipeline over the five k blocks of the round: the 20 B values (+ A) of block b+1 are read while block b multiplies; the
+        // order is pinned (left alone the scheduler pairs every ds_read with its MFMAs: an LDS round trip per two MFMAs)
+        constexpr int NBLK = kFewCC * KH / 4;
+        float av[2][CO], bv[2][4][NTI];
+        auto load_blk = [&](int blk, float (&a_)[CO], float (&b_)[4][NTI]) {
+            const int k = 4 * blk + kq;                                 // this lane group's (ci, kh)
+            const int ci = k / KH, kh = k - ci * KH;
+#pragma unroll
+            for (int co = 0; co < CO; ++co) a_[co] = wcur[(k * CO + co) * KWP + ln];
+            const float* xb = cur + ci * plane + (4 * wave + kh) * PWp + shc + ln;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < NTI; ++j) b_[r][j] = xb[r * PWp + 16 * j];
+        };
+        load_blk(0, av[0], bv[0]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NTI + CO, 0);
+#pragma unroll
+        for (int blk = 0; blk < NBLK; ++blk) {
+            if (blk + 1 < NBLK) load_blk(blk + 1, av[(blk + 1) & 1], bv[(blk + 1) & 1]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < NTI; ++j)
+#pragma unroll
+                    for (int co = 0; co < CO; ++co)
+                        acc[co][r][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[blk & 1][co], bv[blk & 1][r][j], acc[co][r][j], 0, 0, 0);
+            if (blk + 1 < NBLK) __builtin_amdgcn_sched_group_barrier(0x100, 4 * NTI + CO, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NTI * CO, 0);
+        }
+    }
+    // ---- anti-diagonal sums through LDS (per wave: [CO][16][NTI * 16]), then the epilogue of conv_fewout_kernel
+    __syncthreads();
+    constexpr int ZW = NTI * 16;
+    float* zs = xs + wave * (CO * 16 * ZW);
+    const int nsplit = a.nsplit, accumulate = a.accumulate, y_sh = a.y_sh, y_sw = a.y_sw;
+    const long long y_sc = a.y_sc;
+    const float* bias = a.bias;
+    float* base = (split == 0 || accumulate) ? a.y : (a.y_slabs + (long long)(split - 1) * a.slab_stride);
+    base += (long long)n * a.y_sb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int co = 0; co < CO; ++co)
+#pragma unroll
+            for (int j = 0; j < NTI; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) zs[(co * 16 + 4 * kq + q) * ZW + 16 * j + ln] = acc[co][r][j][q];
+        __syncthreads();
+        const int oh = oh0 + 4 * wave + r, ow = ow0 + lane;
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            float v = 0.f;
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) v += zs[(co * 16 + kw) * ZW + lane + kw];
+            if (co < Cout && oh < OH && ow < OW) {
+                if (bias != nullptr && split == 0) v += bias[co];
+                float* dst = base + (long long)oh * y_sh + (long long)co * y_sc + (long long)ow * y_sw;
+                if (accumulate) { if (nsplit > 1) unsafeAtomicAdd(dst, v); else *dst += v; }
+                else *dst = v;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -350,6 +518,8 @@ int mcvc_fewout_launch(const ConvProblem& p, int NB, const ConvIO& io, const flo
     a.PH = kFewTH + p.KH - 1;
     a.PWp = round_up_i(kFewTW + p.KW - 1 + 3, 4);           // (+3: the last float4 of a row window may read past PW)
     a.accumulate = io.accumulate;
+    static const int dbg = [] { const char* e = getenv("MCVC_FEW_DBG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
     dim3 grid((unsigned)(a.tiles_w * a.tiles_h), (unsigned)(NB * io.nsplit));
     const int co_t = p.Cout <= 1 ? 1 : (p.Cout <= 2 ? 2 : 4);
     const size_t lds = (size_t)2 * (kFewCC * a.PH * a.PWp + kFewCC * p.KH * co_t * ((p.KW + 3) & ~3) + 4) * sizeof(float);
@@ -357,6 +527,18 @@ int mcvc_fewout_launch(const ConvProblem& p, int NB, const ConvIO& io, const flo
     TraceScope ts(K_CONV_FEW, s, 2.0 * px * p.Cout * p.Cin * p.KH * p.KW,
                   4.0 * ((double)NB * p.Cin * p.H * p.W + (double)p.Cin * p.KH * p.KW * p.Cout + px * p.Cout * io.nsplit));
     const int co = co_t;
+    // 5 x 15 kernels with one or two output channels: the matrix-core form (MCVC_FEWOUT_MFMA=0: the VALU kernel)
+    static const int mfma = [] { const char* e = getenv("MCVC_FEWOUT_MFMA"); return e ? atoi(e) : 1; }();
+    const bool dma16 = ((a.x_sh & 3) == 0) && ((p.W & 3) == 0) && ((a.x_sc & 3) == 0) && ((a.x_sb & 3) == 0) &&
+                       ((reinterpret_cast<unsigned long long>(a.x) & 15ull) == 0) && (long long)p.H * a.x_sh < (1LL << 30);
+    if (mfma && p.KW == 15 && p.KH == 5 && co <= 2 && dma16 && a.PWp == kFewMfmaPW && a.PH == kFewMfmaPH) {
+        const size_t stg = (size_t)2 * (kFewCC * kFewMfmaPH * kFewMfmaPW + kFewCC * 5 * co * 16) * sizeof(float);
+        const size_t epi = (size_t)4 * co * 16 * 80 * sizeof(float);
+        const size_t need = stg > epi ? stg : epi;
+        if (co == 1) mcvc_launch(conv_fewout_mfma_kernel<1>, grid, dim3(256), need, s, a);
+        else mcvc_launch(conv_fewout_mfma_kernel<2>, grid, dim3(256), need, s, a);
+        return (int)hipGetLastError();
+    }
     if (p.KW == 15) return co == 1 ? few_launch_t<1, 15>(a, grid, lds, s) : co == 2 ? few_launch_t<2, 15>(a, grid, lds, s) : few_launch_t<4, 15>(a, grid, lds, s);
     return co == 1 ? few_launch_t<1, 3>(a, grid, lds, s) : co == 2 ? few_launch_t<2, 3>(a, grid, lds, s) : few_launch_t<4, 3>(a, grid, lds, s);
 }

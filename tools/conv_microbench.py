@@ -16,6 +16,7 @@ SHAPES = {  # Cin, Cout, KH, KW, stride, ph, pw, H, W, shuffle
     "up2": (256, 512, 5, 5, 1, 2, 2, 40, 32, True), "up1": (256, 1024, 5, 5, 1, 2, 2, 20, 16, True),
     "ds1": (128, 512, 5, 5, 2, 2, 2, 80, 64, False), "ds2": (256, 512, 5, 5, 2, 2, 2, 40, 32, False),
     "dds3": (512, 1024, 3, 3, 2, 1, 1, 20, 16, False), "res": (256, 1024, 1, 3, 1, 0, 1, 1, 16, False),
+    "last": (128, 1, 5, 15, 1, 2, 7, 80, 64, False), "conv1": (2, 256, 5, 15, 1, 2, 7, 80, 64, False),
 }
 
 ap = argparse.ArgumentParser()
