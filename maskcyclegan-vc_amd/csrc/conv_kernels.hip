@@ -66,7 +66,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l)
 template <int WM, int WN, int BMW, int BNW, int KW, bool S2>
 __global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const Twin<ConvArgs> tw)
 {
-    const ConvArgs& a = tw.v[blockIdx.z];
+    const ConvArgs a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int COT = 32 * WM * BMW;
     constexpr int NSUB = WN * BNW;
@@ -601,7 +601,7 @@ int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float
 template <int MS, int KWT, int MAXT, int MINW>
 __global__ void __launch_bounds__(MAXT, MINW) conv_wgrad_kernel(const Twin<WgradArgs> tw)
 {
-    const WgradArgs& a = tw.v[blockIdx.z];
+    const WgradArgs a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, nthreads = blockDim.x;
     const int lane = tid & 63;
@@ -762,7 +762,7 @@ __global__ void __launch_bounds__(MAXT, MINW) conv_wgrad_kernel(const Twin<Wgrad
 struct WgradReduceKArgs { float* dw; const float* slabs; long long n; long long stride; int ksplit; int vec; };
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const Twin<WgradReduceKArgs> tw)
 {
-    const WgradReduceKArgs& ka_ = tw.v[blockIdx.z];
+    const WgradReduceKArgs ka_ = tw.v[blockIdx.z];
     float* __restrict__ dw = ka_.dw;
     const float* __restrict__ slabs = ka_.slabs;
     long long n = ka_.n;
@@ -809,7 +809,7 @@ struct SmallKArgs {
 template <int KW, int COB>
 __global__ void __launch_bounds__(256) wgrad_smallk_kernel(const Twin<SmallKArgs> tw)
 {
-    const SmallKArgs& a = tw.v[blockIdx.z];
+    const SmallKArgs a = tw.v[blockIdx.z];
     __shared__ float dys[COB * 128];
     const int tid = threadIdx.x;
     const int co0 = blockIdx.x * COB;

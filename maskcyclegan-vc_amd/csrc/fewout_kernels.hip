@@ -46,7 +46,7 @@ struct FewArgs {
 template <int CO, int KW>
 __global__ void __launch_bounds__(256) conv_fewout_kernel(const Twin<FewArgs> tw)
 {
-    const FewArgs& a = tw.v[blockIdx.z];
+    const FewArgs a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float xs[];          // [2 buffers][kFewCC][PH][PWp]
     constexpr int NV = (4 + KW - 1 + 3) / 4;                            // float4 reads per row window
     const int tid = threadIdx.x;
@@ -177,7 +177,7 @@ constexpr int kFewMfmaNCH = (kFewMfmaPH * (kFewMfmaPW / 4) + 63) / 64;  // 16-by
 template <int CO>
 __global__ void __launch_bounds__(256, (CO == 1 ? 2 : 1)) conv_fewout_mfma_kernel(const Twin<FewArgs> tw)
 {
-    const FewArgs& a = tw.v[blockIdx.z];
+    const FewArgs a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float xs[];          // [2 buffers][kFewCC planes | weights]; reused by the epilogue
     constexpr int KH = 5, KW = 15, KWP = 16, NTI = (kFewTW + KW - 1 + 15) / 16;      // 5 column tiles of 16 haloed pixels
     constexpr int PWp = kFewMfmaPW, PH = kFewMfmaPH, P4 = PWp / 4, plane = PH * PWp, NCH = kFewMfmaNCH;
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256, (CO == 1 ? 2 : 1)) conv_fewout_mfma_kerne
 struct DiscOutFwdKArgs { const float* x; const float* w; const float* bias; float* logit; float* out; int NB; int C; int H; int W; };
 __global__ void __launch_bounds__(256) disc_out_fwd_kernel(const Twin<DiscOutFwdKArgs> tw)
 {
-    const DiscOutFwdKArgs& ka_ = tw.v[blockIdx.z];
+    const DiscOutFwdKArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ x = ka_.x;
     const float* __restrict__ w = ka_.w;
     const float* __restrict__ bias = ka_.bias;
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(256) disc_out_fwd_kernel(const Twin<DiscOutFwd
 struct DiscOutDgradKArgs { const float* dl; const float* w; float* dx; int NB; int C; int H; int W; };
 __global__ void __launch_bounds__(256) disc_out_dgrad_kernel(const Twin<DiscOutDgradKArgs> tw)
 {
-    const DiscOutDgradKArgs& ka_ = tw.v[blockIdx.z];
+    const DiscOutDgradKArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ dl = ka_.dl;
     const float* __restrict__ w = ka_.w;
     float* __restrict__ dx = ka_.dx;
@@ -403,7 +403,7 @@ constexpr int kDiscC1Cob = 16;
 struct DiscConv1FwdKArgs { const float* x; const float* w; const float* bias; float* c0; float* y0; int Cout; int H; int W; };
 __global__ void __launch_bounds__(256) disc_conv1_fwd_kernel(const Twin<DiscConv1FwdKArgs> tw)
 {
-    const DiscConv1FwdKArgs& ka_ = tw.v[blockIdx.z];
+    const DiscConv1FwdKArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ x = ka_.x;
     const float* __restrict__ w = ka_.w;
     const float* __restrict__ bias = ka_.bias;
@@ -562,7 +562,7 @@ struct FewWgradArgs {
 
 __global__ void __launch_bounds__(256) wgrad_cout1_kernel(const Twin<FewWgradArgs> tw)
 {
-    const FewWgradArgs& a = tw.v[blockIdx.z];
+    const FewWgradArgs a = tw.v[blockIdx.z];
     extern __shared__ float sm[];
     const int BH = a.band;                       // output rows per unit; units = (sample, band), shared out over gridDim.y workgroups
     const int XH = BH + a.KH - 1;
@@ -622,7 +622,7 @@ constexpr int kCin1Band = 20;
 struct WgradCin1KArgs { const float* x; long long x_sn; int x_sh; const float* dy; long long dy_sn; long long dy_sc; int dy_sh; float* dw; int NB; int H; int W; };
 __global__ void __launch_bounds__(256) wgrad_cin1_kernel(const Twin<WgradCin1KArgs> tw)
 {
-    const WgradCin1KArgs& ka_ = tw.v[blockIdx.z];
+    const WgradCin1KArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ x = ka_.x;
     long long x_sn = ka_.x_sn;
     int x_sh = ka_.x_sh;

@@ -27,7 +27,7 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red)
 struct PrepInputKArgs { const float* x; const float* mask; float* xin; int N; int P; };
 __global__ void prep_input_kernel(const Twin<PrepInputKArgs> tw)
 {
-    const PrepInputKArgs& ka_ = tw.v[blockIdx.z];
+    const PrepInputKArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ x = ka_.x;
     const float* __restrict__ mask = ka_.mask;
     float* __restrict__ xin = ka_.xin;
@@ -47,7 +47,7 @@ __global__ void prep_input_kernel(const Twin<PrepInputKArgs> tw)
 struct MaskGradKArgs { const float* dxin; const float* dxin_slabs; long long slab_stride; int nslab; const float* mask; float* dx; int N; int P; int C; int accumulate; };
 __global__ void mask_grad_kernel(const Twin<MaskGradKArgs> tw)
 {
-    const MaskGradKArgs& ka_ = tw.v[blockIdx.z];
+    const MaskGradKArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ dxin = ka_.dxin;
     const float* __restrict__ dxin_slabs = ka_.dxin_slabs;
     long long slab_stride = ka_.slab_stride;
@@ -77,7 +77,7 @@ __global__ void mask_grad_kernel(const Twin<MaskGradKArgs> tw)
 struct BiasGradKArgs { const float* dy; long long sn; long long sc; int N; int P; float* db; };
 __global__ void __launch_bounds__(1024) bias_grad_kernel(const Twin<BiasGradKArgs> tw)
 {
-    const BiasGradKArgs& ka_ = tw.v[blockIdx.z];
+    const BiasGradKArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ dy = ka_.dy;
     long long sn = ka_.sn;
     long long sc = ka_.sc;
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(1024) bias_grad_kernel(const Twin<BiasGradKArg
 struct L1LossKArgs { const float* a; const float* b; long long n; float weight; float* loss_slot; float* term_slot; float* grad_a; int accumulate; };
 __global__ void __launch_bounds__(1024) l1_loss_kernel(const Twin<L1LossKArgs> tw)
 {
-    const L1LossKArgs& ka_ = tw.v[blockIdx.z];
+    const L1LossKArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ a = ka_.a;
     const float* __restrict__ b = ka_.b;
     long long n = ka_.n;
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(1024) l1_loss_kernel(const Twin<L1LossKArgs> t
 struct LsganLossKArgs { const float* d; long long n; float target; float weight; float* loss_slot; float* term_slot; float* grad_logit; };
 __global__ void __launch_bounds__(1024) lsgan_loss_kernel(const Twin<LsganLossKArgs> tw)
 {
-    const LsganLossKArgs& ka_ = tw.v[blockIdx.z];
+    const LsganLossKArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ d = ka_.d;
     long long n = ka_.n;
     float target = ka_.target;
@@ -179,7 +179,7 @@ struct LossCombineArgs { int n; int loss_dst[16]; int term_dst[16]; };
 struct LossCombineKArgs { const float* pairs; float* slots; LossCombineArgs c; };
 __global__ void loss_combine_kernel(const Twin<LossCombineKArgs> tw)
 {
-    const LossCombineKArgs& ka_ = tw.v[blockIdx.z];
+    const LossCombineKArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ pairs = ka_.pairs;
     float* __restrict__ slots = ka_.slots;
     const LossCombineArgs& c = ka_.c;
@@ -196,7 +196,7 @@ struct AdamKArgs { float* p; float* g; float* m; float* v; long long n; float lr
                    float* g2; int zero; };      // g2 (nullable): a second gradient buffer, added to g; zero: clear the gradient buffer(s) behind the read
 __global__ void __launch_bounds__(256) adam_kernel(const Twin<AdamKArgs> tw)
 {
-    const AdamKArgs& ka_ = tw.v[blockIdx.z];
+    const AdamKArgs ka_ = tw.v[blockIdx.z];
     float* __restrict__ p = ka_.p;
     float* __restrict__ g = ka_.g;
     float* __restrict__ g2 = ka_.g2;
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256) adam_kernel(const Twin<AdamKArgs> tw)
 struct AxpyKArgs { float* y; const float* x; float alpha; long long n; };
 __global__ void axpy_kernel(const Twin<AxpyKArgs> tw)
 {
-    const AxpyKArgs& ka_ = tw.v[blockIdx.z];
+    const AxpyKArgs ka_ = tw.v[blockIdx.z];
     float* __restrict__ y = ka_.y;
     const float* __restrict__ x = ka_.x;
     float alpha = ka_.alpha;

@@ -39,7 +39,7 @@ __device__ __forceinline__ float gsum(float v, float* red)
 template <int G>
 __global__ void __launch_bounds__(256) norm_fwd_kernel(const Twin<NormArgs> tw)
 {
-    const NormArgs& a = tw.v[blockIdx.z];
+    const NormArgs a = tw.v[blockIdx.z];
     __shared__ float red[4];
     constexpr int GPB = 256 / G;
     const int g = threadIdx.x / G, l = threadIdx.x % G;
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) norm_fwd_kernel(const Twin<NormArgs> tw)
 template <int G>
 __global__ void __launch_bounds__(256) norm_bwd_kernel(const Twin<NormBwdArgs> tw)
 {
-    const NormBwdArgs& a = tw.v[blockIdx.z];
+    const NormBwdArgs a = tw.v[blockIdx.z];
     __shared__ float red[4];
     constexpr int GPB = 256 / G;
     const int g = threadIdx.x / G, l = threadIdx.x % G;
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) norm_bwd_kernel(const Twin<NormBwdArgs> t
 template <int G, int E>
 __global__ void __launch_bounds__(256) norm_fwd_reg_kernel(const Twin<NormArgs> tw)
 {
-    const NormArgs& a = tw.v[blockIdx.z];
+    const NormArgs a = tw.v[blockIdx.z];
     __shared__ float red[4];
     constexpr int GPB = 256 / G;
     const int g = threadIdx.x / G, l = threadIdx.x % G;
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256) norm_fwd_reg_kernel(const Twin<NormArgs> 
 template <int G, int E>
 __global__ void __launch_bounds__(256) norm_bwd_reg_kernel(const Twin<NormBwdArgs> tw)
 {
-    const NormBwdArgs& a = tw.v[blockIdx.z];
+    const NormBwdArgs a = tw.v[blockIdx.z];
     __shared__ float red[4];
     constexpr int GPB = 256 / G;
     const int g = threadIdx.x / G, l = threadIdx.x % G;
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(256) norm_bwd_reg_kernel(const Twin<NormBwdArg
 
 __global__ void __launch_bounds__(256) act_fwd_kernel(const Twin<ActArgs> tw)
 {
-    const ActArgs& a = tw.v[blockIdx.z];
+    const ActArgs a = tw.v[blockIdx.z];
     const long long total = (long long)a.N * a.C * a.P;
     const int nbr = (a.act == ACT_GLU) ? 2 : 1;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(256) act_fwd_kernel(const Twin<ActArgs> tw)
 
 __global__ void __launch_bounds__(256) act_bwd_kernel(const Twin<ActBwdArgs> tw)
 {
-    const ActBwdArgs& a = tw.v[blockIdx.z];
+    const ActBwdArgs a = tw.v[blockIdx.z];
     const long long total = (long long)a.N * a.C * a.P;
     const int nbr = (a.act == ACT_GLU) ? 2 : 1;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -480,7 +480,7 @@ __device__ __forceinline__ float4 add4(const float4& a, const float4& b) { retur
 
 __global__ void __launch_bounds__(256) act_fwd_vec_kernel(const Twin<ActArgs> tw)
 {
-    const ActArgs& a = tw.v[blockIdx.z];
+    const ActArgs a = tw.v[blockIdx.z];
     const unsigned p4 = (unsigned)a.P >> 2;
     const unsigned total4 = (unsigned)a.N * (unsigned)a.C * p4;
     const int nbr = (a.act == ACT_GLU) ? 2 : 1;
@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(256) act_fwd_vec_kernel(const Twin<ActArgs> tw
 
 __global__ void __launch_bounds__(256) act_bwd_vec_kernel(const Twin<ActBwdArgs> tw)
 {
-    const ActBwdArgs& a = tw.v[blockIdx.z];
+    const ActBwdArgs a = tw.v[blockIdx.z];
     const unsigned p4 = (unsigned)a.P >> 2;
     const unsigned total4 = (unsigned)a.N * (unsigned)a.C * p4;
     const int nbr = (a.act == ACT_GLU) ? 2 : 1;
@@ -583,7 +583,7 @@ struct NormFwdWinoKArgs { NormArgs a; WinoOutArgs w; };
 template <int G, int TT, int PTS>
 __global__ void __launch_bounds__(256) norm_fwd_wino_kernel(const Twin<NormFwdWinoKArgs> tw)
 {
-    const NormFwdWinoKArgs& ka_ = tw.v[blockIdx.z];
+    const NormFwdWinoKArgs ka_ = tw.v[blockIdx.z];
     const NormArgs& a = ka_.a;
     const WinoOutArgs& w = ka_.w;
     __shared__ float red[4];

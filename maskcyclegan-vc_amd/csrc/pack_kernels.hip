@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256) pack_trunk_t_kernel(const float* __restri
 struct CopyKArgs { const float* src; float* dst; int n; };
 __global__ void copy_kernel(const Twin<CopyKArgs> tw)
 {
-    const CopyKArgs& ka_ = tw.v[blockIdx.z];
+    const CopyKArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ src = ka_.src;
     float* __restrict__ dst = ka_.dst;
     int n = ka_.n;

@@ -23,7 +23,7 @@ constexpr int NA = SA / 4 / 256, NBI = SB / 4 / 256, ND = NA + NBI;          // 
 
 __global__ void __launch_bounds__(256) sgemm_kernel(const Twin<SGemmArgs> tw)
 {
-    const SGemmArgs& a = tw.v[blockIdx.z];
+    const SGemmArgs a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,17 +91,33 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const Twin<SGemmArgs> tw)
             a0 = na0; b0 = nb0;
         }
     }
+    // (every kernarg field the stores use is read once, in front of them: left inside the 16-way unrolled, branchy loop they were re-loaded
+    // with an s_waitcnt per row)
     const int n = n0 + wn * 32 + l31;
+    const long long ldc = a.ldc;
+    const int m_split = a.m_split, accumulate = a.accumulate;
+    const float* bias = a.bias;
+    float* const c1 = a.c; float* const c2 = a.c2;
     if (n < a.N) {
         const long long coff = (long long)(n / a.cseg) * a.c_sn + (n % a.cseg);
-        float* const slab = ks ? a.c_slab + (long long)(ks - 1) * a.c_split : nullptr;
+        const int mb = m0 + wm * 32 + 4 * half;
+        if (ks) {
+            float* slab = a.c_slab + (long long)(ks - 1) * a.c_split + (long long)mb * ldc + coff;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (ks) { slab[(long long)m * a.ldc + coff] = acc[r]; continue; }
-            float* row = (m < a.m_split) ? a.c + (long long)m * a.ldc : a.c2 + (long long)(m - a.m_split) * a.ldc;
-            const float v = a.bias ? acc[r] + a.bias[m] : acc[r];
-            row[coff] = a.accumulate ? row[coff] + v : v;
+            for (int r = 0; r < 16; ++r) slab[(long long)((r & 3) + 8 * (r >> 2)) * ldc] = acc[r];
+        } else {
+            // a 32-row block lies on one side of m_split (both are multiples of 32 where two destinations are used)
+            float* row0 = (mb < m_split) ? c1 + (long long)mb * ldc : c2 + (long long)(mb - m_split) * ldc;
+            row0 += coff;
+            float bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = bias ? bias[mb + (r & 3) + 8 * (r >> 2)] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* dst = row0 + (long long)((r & 3) + 8 * (r >> 2)) * ldc;
+                const float v = acc[r] + bv[r];
+                *dst = accumulate ? *dst + v : v;
+            }
         }
     }
 }
@@ -110,7 +126,7 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const Twin<SGemmArgs> tw)
 // tap (kh, kw) of output pixel (oh, ow) reads x[2*oh + kh - 1][2*ow + kw - 1]
 __global__ void __launch_bounds__(256) im2col_s2_kernel(const Twin<StageArgs> tw)
 {
-    const StageArgs& a = tw.v[blockIdx.z];
+    const StageArgs a = tw.v[blockIdx.z];
     const int P = a.OH * a.OW;
     const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
     const int ci = blockIdx.y;
@@ -134,7 +150,7 @@ __global__ void __launch_bounds__(256) im2col_s2_kernel(const Twin<StageArgs> tw
 // XcolT[n][9*ci + tap]: 32 pixels x 32 channels per workgroup through LDS (reads along pixels, writes along k)
 __global__ void __launch_bounds__(256) im2col_s2_t_kernel(const Twin<StageArgs> tw)
 {
-    const StageArgs& a = tw.v[blockIdx.z];
+    const StageArgs a = tw.v[blockIdx.z];
     __shared__ float tile[32][32 * 9 + 1];
     const int P = a.OH * a.OW;
     const long long NT = (long long)a.NB * P;
@@ -170,7 +186,7 @@ __global__ void __launch_bounds__(256) im2col_s2_t_kernel(const Twin<StageArgs> 
 // Yt[n][c] from y[b][c][p]
 __global__ void __launch_bounds__(256) planes_t_kernel(const Twin<StageArgs> tw)
 {
-    const StageArgs& a = tw.v[blockIdx.z];
+    const StageArgs a = tw.v[blockIdx.z];
     __shared__ float tile[32][33];
     const int P = a.H * a.W;
     const long long NT = (long long)a.NB * P;
@@ -194,7 +210,7 @@ __global__ void __launch_bounds__(256) planes_t_kernel(const Twin<StageArgs> tw)
 struct Col2imS2KArgs { StageArgs a; int nslab; long long slab_stride; int accumulate; };
 __global__ void __launch_bounds__(256) col2im_s2_kernel(const Twin<Col2imS2KArgs> tw)
 {
-    const Col2imS2KArgs& ka_ = tw.v[blockIdx.z];
+    const Col2imS2KArgs ka_ = tw.v[blockIdx.z];
     const StageArgs& a = ka_.a;
     int nslab = ka_.nslab;
     long long slab_stride = ka_.slab_stride;
@@ -233,7 +249,7 @@ __global__ void __launch_bounds__(256) col2im_s2_kernel(const Twin<Col2imS2KArgs
 template <int KW>
 __global__ void __launch_bounds__(256) im2col_1d_kernel(const Twin<StageArgs> tw)
 {
-    const StageArgs& a = tw.v[blockIdx.z];
+    const StageArgs a = tw.v[blockIdx.z];
     constexpr int PW = (KW - 1) / 2;
     const int P = a.H * a.W;
     const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -254,7 +270,7 @@ __global__ void __launch_bounds__(256) im2col_1d_kernel(const Twin<StageArgs> tw
 template <int KW>
 __global__ void __launch_bounds__(256) im2col_1d_t_kernel(const Twin<StageArgs> tw)
 {
-    const StageArgs& a = tw.v[blockIdx.z];
+    const StageArgs a = tw.v[blockIdx.z];
     constexpr int PW = (KW - 1) / 2;
     __shared__ float tile[32][32 * KW + 1];
     const int P = a.H * a.W;
@@ -288,7 +304,7 @@ struct Col2im1dKArgs { StageArgs a; int nslab; long long slab_stride; int accumu
 template <int KW>
 __global__ void __launch_bounds__(256) col2im_1d_kernel(const Twin<Col2im1dKArgs> tw)
 {
-    const Col2im1dKArgs& ka_ = tw.v[blockIdx.z];
+    const Col2im1dKArgs ka_ = tw.v[blockIdx.z];
     const StageArgs& a = ka_.a;
     int nslab = ka_.nslab;
     long long slab_stride = ka_.slab_stride;
@@ -316,7 +332,7 @@ __global__ void __launch_bounds__(256) col2im_1d_kernel(const Twin<Col2im1dKArgs
 struct DwAccumKArgs { const float* slabs; int nslab; long long slab_stride; float* g0; float* g1; int Cout; int rows; int K9; };
 __global__ void __launch_bounds__(256) dw_accum_kernel(const Twin<DwAccumKArgs> tw)
 {
-    const DwAccumKArgs& ka_ = tw.v[blockIdx.z];
+    const DwAccumKArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ slabs = ka_.slabs;
     int nslab = ka_.nslab;
     long long slab_stride = ka_.slab_stride;
@@ -351,6 +367,7 @@ int mcvc_sgemm_launch(const SGemmArgs& a0, hipStream_t s)
     if (!a.a2) { a.a2 = a.a; a.k_split = a.K; }
     if (!a.c2) { a.c2 = a.c; a.m_split = a.M; }
     if (a.nsplit > 1 && !a.c_slab) return MCVC_ERR_INVALID;
+    if (a.m_split & 31) return MCVC_ERR_INVALID;                 // (the store picks the destination per 32-row block)
     a.nt = cdiv_i(a.N, BN); a.mt = a.M / BM;
     constexpr size_t lds = (size_t)ST * STAGE * sizeof(float);
     static bool done = false;

@@ -40,7 +40,7 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 template <int KW, int NA, bool PRE>
 __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<TrunkArgs> tw)
 {
-    const TrunkArgs& a = tw.v[blockIdx.z];
+    const TrunkArgs a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1048,7 +1048,7 @@ __global__ void __launch_bounds__(kNetThreads) trunk_bwd_net_kernel(const Twin<T
 struct ZeroWordsKArgs { unsigned* p; int n; };
 __global__ void zero_words_kernel(const Twin<ZeroWordsKArgs> tw)
 {
-    const ZeroWordsKArgs& a = tw.v[blockIdx.z];
+    const ZeroWordsKArgs a = tw.v[blockIdx.z];
     if ((int)threadIdx.x < a.n) a.p[threadIdx.x] = 0u;
 }
 
@@ -1056,7 +1056,7 @@ __global__ void zero_words_kernel(const Twin<ZeroWordsKArgs> tw)
 struct FillRowsKArgs { float* dst; const float* bias; int C; int per_row; };
 __global__ void __launch_bounds__(256) fill_rows_kernel(const Twin<FillRowsKArgs> tw)
 {
-    const FillRowsKArgs& ka_ = tw.v[blockIdx.z];
+    const FillRowsKArgs ka_ = tw.v[blockIdx.z];
     float* __restrict__ dst = ka_.dst;
     const float* __restrict__ bias = ka_.bias;
     int C = ka_.C;

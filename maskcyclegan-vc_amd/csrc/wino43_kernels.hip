@@ -74,7 +74,7 @@ struct W43InKArgs { WinoXformArgs a; int XH; int XW; };
 template <bool PHASE>
 __global__ void __launch_bounds__(256) wino43_input_kernel(const Twin<W43InKArgs> tw)
 {
-    const W43InKArgs& ka_ = tw.v[blockIdx.z];
+    const W43InKArgs ka_ = tw.v[blockIdx.z];
     const WinoXformArgs& a = ka_.a;
     const int tile = blockIdx.x * 256 + threadIdx.x;
     const int c = blockIdx.y;
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) wino43_input_kernel(const Twin<W43InKArgs
 // M[36][Cout][tile] -> 4x4 outputs per tile (+ bias); `shuffle`: channel co = 4c + 2qh + qw is the parity class (qh, qw) of plane c
 __global__ void __launch_bounds__(256) wino43_output_kernel(const Twin<WinoOutArgs> tw)
 {
-    const WinoOutArgs& a = tw.v[blockIdx.z];
+    const WinoOutArgs a = tw.v[blockIdx.z];
     const int tile = blockIdx.x * 256 + threadIdx.x;
     const int co = blockIdx.y;
     if (tile >= a.NT) return;
@@ -141,7 +141,7 @@ constexpr int kXT = 8, kXC = 64, kXPitch = 68;
 template <int KIND>
 __global__ void __launch_bounds__(256) xform43_t_kernel(const Twin<W43InKArgs> tw)
 {
-    const W43InKArgs& ka_ = tw.v[blockIdx.z];
+    const W43InKArgs ka_ = tw.v[blockIdx.z];
     const WinoXformArgs& a = ka_.a;
     extern __shared__ __attribute__((aligned(16))) float xbuf[];          // [36][kXT][kXPitch]
     const int tid = threadIdx.x;
@@ -215,7 +215,7 @@ int xform43_t_launch(const WinoXformArgs& a, int XH, int XW, double bytes, hipSt
 struct W43DwKArgs { const float* du; float* dw0; float* dw1; int Cout; int nbr; int Cin; };
 __global__ void __launch_bounds__(256) wino43_dw_kernel(const Twin<W43DwKArgs> tw)
 {
-    const W43DwKArgs& ka_ = tw.v[blockIdx.z];
+    const W43DwKArgs ka_ = tw.v[blockIdx.z];
     const int Cout = ka_.Cout, nbr = ka_.nbr, Cin = ka_.Cin;
     const int k = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y;
     const int K = 4 * Cin;

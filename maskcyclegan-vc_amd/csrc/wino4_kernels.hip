@@ -78,7 +78,7 @@ __device__ __forceinline__ void w4_dy(const float* src, int x_sh, int oh0, int o
 // one thread = one (channel, tile): 64 loads, 64 coalesced stores
 __global__ void __launch_bounds__(256) wino4_input_kernel(const Twin<WinoXformArgs> tw)
 {
-    const WinoXformArgs& a = tw.v[blockIdx.z];
+    const WinoXformArgs a = tw.v[blockIdx.z];
     const int tile = blockIdx.x * 256 + threadIdx.x;
     const int c = blockIdx.y;
     if (tile >= a.NT) return;
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256) wino4_input_kernel(const Twin<WinoXformAr
 
 __global__ void __launch_bounds__(256) wino4_output_kernel(const Twin<WinoOutArgs> tw)
 {
-    const WinoOutArgs& a = tw.v[blockIdx.z];
+    const WinoOutArgs a = tw.v[blockIdx.z];
     const int tile = blockIdx.x * 256 + threadIdx.x;
     const int co = blockIdx.y;
     if (tile >= a.NT) return;
@@ -147,7 +147,7 @@ constexpr int kX4T = 4, kX4C = 64, kX4Pitch = 68;
 template <int KIND>
 __global__ void __launch_bounds__(256) xform4_t_kernel(const Twin<WinoXformArgs> tw)
 {
-    const WinoXformArgs& a = tw.v[blockIdx.z];
+    const WinoXformArgs a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float xbuf[];          // [64][kX4T][kX4Pitch]
     const int tid = threadIdx.x;
     const int tile0 = blockIdx.x * kX4T, c0 = blockIdx.y * kX4C;
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) xform4_t_kernel(const Twin<WinoXformArgs>
 struct Wino4DwKArgs { const float* du; float* dw; int Cout; int Cin; };
 __global__ void __launch_bounds__(256) wino4_dw_kernel(const Twin<Wino4DwKArgs> tw)
 {
-    const Wino4DwKArgs& a = tw.v[blockIdx.z];
+    const Wino4DwKArgs a = tw.v[blockIdx.z];
     const int ci = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y;
     if (ci >= a.Cin) return;
     const long long xs = (long long)a.Cout * a.Cin;

@@ -29,7 +29,7 @@ __device__ __forceinline__ void bt6(const float d[6], float o[6])
 // one thread = one (channel, tile): 36 loads (rows of 6 consecutive floats), 72 small dot products, 36 coalesced stores
 __global__ void __launch_bounds__(256) wino_input_kernel(const Twin<WinoXformArgs> tw)
 {
-    const WinoXformArgs& a = tw.v[blockIdx.z];
+    const WinoXformArgs a = tw.v[blockIdx.z];
     const int tile = blockIdx.x * 256 + threadIdx.x;
     const int c = blockIdx.y;
     if (tile >= a.NT) return;
@@ -73,7 +73,7 @@ __device__ __forceinline__ void bt4(const float d[4], float o[4])
 
 __global__ void __launch_bounds__(256) wino3_input_kernel(const Twin<WinoXformArgs> tw)
 {
-    const WinoXformArgs& a = tw.v[blockIdx.z];
+    const WinoXformArgs a = tw.v[blockIdx.z];
     const int tile = blockIdx.x * 256 + threadIdx.x;
     const int c = blockIdx.y;
     if (tile >= a.NT) return;
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) wino3_input_kernel(const Twin<WinoXformAr
 struct Wino3InputPhaseKArgs { WinoXformArgs a; int XH; int XW; };
 __global__ void __launch_bounds__(256) wino3_input_phase_kernel(const Twin<Wino3InputPhaseKArgs> tw)
 {
-    const Wino3InputPhaseKArgs& ka_ = tw.v[blockIdx.z];
+    const Wino3InputPhaseKArgs ka_ = tw.v[blockIdx.z];
     const WinoXformArgs& a = ka_.a;
     int XH = ka_.XH;
     int XW = ka_.XW;
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) wino3_input_phase_kernel(const Twin<Wino3
 struct Wino3InputPhaseTKArgs { WinoXformArgs a; int XH; int XW; };
 __global__ void __launch_bounds__(256) wino3_input_phase_t_kernel(const Twin<Wino3InputPhaseTKArgs> tw)
 {
-    const Wino3InputPhaseTKArgs& ka_ = tw.v[blockIdx.z];
+    const Wino3InputPhaseTKArgs ka_ = tw.v[blockIdx.z];
     const WinoXformArgs& a = ka_.a;
     int XH = ka_.XH;
     int XW = ka_.XW;
@@ -204,7 +204,7 @@ __device__ __forceinline__ void a42(float d0, float d1, float o[4]) { o[0] = d0;
 
 __global__ void __launch_bounds__(256) wino3_dy_t_kernel(const Twin<WinoXformArgs> tw)
 {
-    const WinoXformArgs& a = tw.v[blockIdx.z];
+    const WinoXformArgs a = tw.v[blockIdx.z];
     const int c = blockIdx.y * 16 + (threadIdx.x & 15);
     const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (tile >= a.NTp || c >= a.C) return;
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(256) wino3_dy_t_kernel(const Twin<WinoXformArg
 struct Wino3DwKArgs { const float* du; float* dw0; float* dw1; int Cout; int nbr; int Cin; };
 __global__ void __launch_bounds__(256) wino3_dw_kernel(const Twin<Wino3DwKArgs> tw)
 {
-    const Wino3DwKArgs& ka_ = tw.v[blockIdx.z];
+    const Wino3DwKArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ du = ka_.du;
     float* __restrict__ dw0 = ka_.dw0;
     float* __restrict__ dw1 = ka_.dw1;
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256) wino3_dw_kernel(const Twin<Wino3DwKArgs> 
 
 __global__ void __launch_bounds__(256) wino3_output_kernel(const Twin<WinoOutArgs> tw)
 {
-    const WinoOutArgs& a = tw.v[blockIdx.z];
+    const WinoOutArgs a = tw.v[blockIdx.z];
     const int tile = blockIdx.x * 256 + threadIdx.x;
     const int co = blockIdx.y;
     if (tile >= a.NT) return;
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) wino3_output_kernel(const Twin<WinoOutArg
 // covers 16 tiles x 16 channels with the channel fastest, so every store is a 64-byte run.
 __global__ void __launch_bounds__(256) wino_input_t_kernel(const Twin<WinoXformArgs> tw)
 {
-    const WinoXformArgs& a = tw.v[blockIdx.z];
+    const WinoXformArgs a = tw.v[blockIdx.z];
     const int c = blockIdx.y * 16 + (threadIdx.x & 15);
     const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (tile >= a.NTp || c >= a.C) return;
@@ -384,7 +384,7 @@ __device__ __forceinline__ void a62(float d0, float d1, float o[6])
 
 __global__ void __launch_bounds__(256) wino_dy_t_kernel(const Twin<WinoXformArgs> tw)      // x = dY [N][C][H][W], H x W = conv output
 {
-    const WinoXformArgs& a = tw.v[blockIdx.z];
+    const WinoXformArgs a = tw.v[blockIdx.z];
     const int c = blockIdx.y * 16 + (threadIdx.x & 15);
     const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (tile >= a.NTp || c >= a.C) return;
@@ -515,7 +515,7 @@ __device__ __forceinline__ void xform_t_compute(const WinoXformArgs& a, int XH, 
 template <int KIND>
 __global__ void __launch_bounds__(256) xform_t_kernel(const Twin<XformTKArgs> tw)
 {
-    const XformTKArgs& ka_ = tw.v[blockIdx.z];
+    const XformTKArgs ka_ = tw.v[blockIdx.z];
     const WinoXformArgs& a = ka_.a;
     constexpr int P = (KIND < 2) ? 36 : 16;
     extern __shared__ __attribute__((aligned(16))) float xbuf[];          // [P][kXT][kXPitch]
@@ -573,7 +573,7 @@ static bool xform_t_on()
 struct WinoDwKArgs { const float* du; float* dw; int Cout; int Cin; };
 __global__ void __launch_bounds__(256) wino_dw_kernel(const Twin<WinoDwKArgs> tw)
 {
-    const WinoDwKArgs& ka_ = tw.v[blockIdx.z];
+    const WinoDwKArgs ka_ = tw.v[blockIdx.z];
     const float* __restrict__ du = ka_.du;
     float* __restrict__ dw = ka_.dw;
     int Cout = ka_.Cout;
@@ -620,7 +620,7 @@ __device__ __forceinline__ void at6(const float m[6], float& o0, float& o1)
 
 __global__ void __launch_bounds__(256) wino_output_kernel(const Twin<WinoOutArgs> tw)
 {
-    const WinoOutArgs& a = tw.v[blockIdx.z];
+    const WinoOutArgs a = tw.v[blockIdx.z];
     const int tile = blockIdx.x * 256 + threadIdx.x;
     const int co = blockIdx.y;
     if (tile >= a.NT) return;
@@ -686,7 +686,7 @@ __device__ __forceinline__ void wg_glds16(const float* g, float* l)
 template <int BN>
 __global__ void __launch_bounds__(256, (BN == 64 ? 3 : 4)) wino_gemm_kernel(const Twin<WinoGemmArgs> tw)
 {
-    const WinoGemmArgs& a = tw.v[blockIdx.z];
+    const WinoGemmArgs a = tw.v[blockIdx.z];
     constexpr int kGB = kGK * BN;
     constexpr int kGStage = kGA + kGB;
     constexpr int NACC = (BN == 64) ? 2 : 1;
@@ -777,16 +777,16 @@ __global__ void __launch_bounds__(256, (BN == 64 ? 3 : 4)) wino_gemm_kernel(cons
         }
     }
     // ---- store: D register r of lane (l31, half) is row (r&3) + 8*(r>>2) + 4*half, column l31
+    // (M is a multiple of the row tile: no row check.  The row pitch is read ONCE, in front of the stores: with a per-row `m < M` test the
+    // compiler sank the kernarg load of ldc into each of the 16 conditional stores -- s_load + s_waitcnt per store, ~1 us of a short-K tile)
     const int n = n0 + wn * 32 + l31;
+    const long long ldc = a.ldc;
     if (n < a.N) {
-        float* C = a.c + (long long)xi * a.c_xi + n;
+        float* C = a.c + (long long)xi * a.c_xi + n + (long long)(m0 + wm * (32 * NACC) + 4 * half) * ldc;
 #pragma unroll
         for (int i = 0; i < NACC; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (32 * NACC) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < a.M) C[(long long)m * a.ldc] = acc[i][r];
-            }
+            for (int r = 0; r < 16; ++r) C[(long long)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc] = acc[i][r];
     }
 }
 
@@ -799,7 +799,7 @@ template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_
 template <int BM, int BN, int GK, int ST>
 __global__ void __launch_bounds__(256) gemm2_kernel(const Twin<WinoGemmArgs> tw)
 {
-    const WinoGemmArgs& a = tw.v[blockIdx.z];
+    const WinoGemmArgs a = tw.v[blockIdx.z];
     constexpr int SA = GK * BM, SB = GK * BN, STAGE = SA + SB;
     constexpr int NBM = (BN >= 64) ? BM / 64 : 1, NBN = (BN >= 64) ? BN / 64 : 1, NACC = NBM * NBN;     // 32x32 blocks per wave (rows x columns)
     constexpr int NA = (SA / 4 + 255) / 256, NB = (SB / 4 + 255) / 256, ND = NA + NB;     // DMA instructions per wave and stage
@@ -886,18 +886,18 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const Twin<WinoGemmArgs> tw)
             for (int j = 0; j < NBN; ++j) bv[j] = nb[j];
         }
     }
+    const long long ldc = a.ldc;                 // (read once; M % BM == 0: no row check -- see wino_gemm_kernel)
+    const int Nv = a.N;
+    float* Cb = a.c + (long long)xi * a.c_xi + (long long)(m0 + wm * (32 * NBM) + 4 * half) * ldc;
 #pragma unroll
     for (int j = 0; j < NBN; ++j) {
         const int n = n0 + wn * (32 * NBN) + 32 * j + l31;
-        if (n >= a.N) continue;
-        float* C = a.c + (long long)xi * a.c_xi + n;
+        if (n >= Nv) continue;
+        float* C = Cb + n;
 #pragma unroll
         for (int i = 0; i < NBM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (32 * NBM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < a.M) C[(long long)m * a.ldc] = acc[i * NBN + j][r];
-            }
+            for (int r = 0; r < 16; ++r) C[(long long)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc] = acc[i * NBN + j][r];
     }
 }
 
