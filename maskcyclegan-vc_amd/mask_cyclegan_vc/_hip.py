@@ -13,7 +13,8 @@ from ctypes import c_float, c_int, c_longlong, c_void_p
 import torch  # noqa: F401  (must be imported first so libamdhip64.so.7 is already resident)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libmcvc_hip.so")
+# MCVC_LIB: another build of the same library (same-box A/B of two kernel variants: tools/ab_lib.sh); it must export the same ABI version
+LIB_PATH = os.environ.get("MCVC_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libmcvc_hip.so")
 
 GEN_NPARAMS = 110
 DISC_NPARAMS = 20
