@@ -19,13 +19,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-__device__ __forceinline__ bf16_t f2bf(float f)
+// fp32 -> bf16, round to nearest even, NaN stays NaN: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two values per instruction;
+// the integer emulation it replaces cost ~12 instructions and an exec-mask branch per value -- a third of the conv epilogue)
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2bf(float a, float b)
 {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);      // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                               // round to nearest even
-    return (bf16_t)(u >> 16);
+    const bf16x2_ r = __builtin_convertvector(f32x2_{a, b}, bf16x2_);
+    return __builtin_bit_cast(unsigned, r);
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
@@ -39,7 +42,7 @@ __device__ __forceinline__ uint4 pack8(const float* f)
 {
     unsigned w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f2bf(f[2 * i]) | ((unsigned)f2bf(f[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = pack2bf(f[2 * i], f[2 * i + 1]);
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
@@ -256,6 +259,12 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
         }
     }
 
+    // the tile's BM bias values go through LDS once (per-store global loads, each behind its own `bias != nullptr` branch and vmcnt(0), were
+    // a latency chain of 64 round trips per workgroup)
+    __syncthreads();
+    float* sbias = reinterpret_cast<float*>(smem);
+    if (tid < BM) sbias[tid] = (a.bias && co0 + tid < a.Cout_pad) ? a.bias[co0 + tid] : 0.f;
+    __syncthreads();
     // ---- epilogue: bias (+ fused GLU), bf16 NHWC store.  Accumulator register r of a lane is output row
     //      (r & 3) + 8 * (r >> 2) + 4 * half of the 32-row tile, column l31: four consecutive channels per r >> 2 -> 8-byte stores.
 #pragma unroll
@@ -274,13 +283,13 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
                         float o[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            float v = acc[0][nt][4 * q + j], g = acc[1][nt][4 * q + j];
-                            if (a.bias) { v += a.bias[co0 + wm * 64 + 8 * q + 4 * half + j]; g += a.bias[co0 + wm * 64 + 32 + 8 * q + 4 * half + j]; }
+                            const float v = acc[0][nt][4 * q + j] + sbias[wm * 64 + 8 * q + 4 * half + j];
+                            const float g = acc[1][nt][4 * q + j] + sbias[wm * 64 + 32 + 8 * q + 4 * half + j];
                             o[j] = v * sigmoidf_(g);
                         }
                         uint2 pk2;
-                        pk2.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-                        pk2.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+                        pk2.x = pack2bf(o[0], o[1]);
+                        pk2.y = pack2bf(o[2], o[3]);
                         *reinterpret_cast<uint2*>(yp + c) = pk2;
                     }
                 }
@@ -294,10 +303,10 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
                     if (co < a.Cout) {                               // Cout % 4 == 0 (checked on the host)
                         float o[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = acc[mt][nt][4 * q + j] + (a.bias ? a.bias[co + j] : 0.f);
+                        for (int j = 0; j < 4; ++j) o[j] = acc[mt][nt][4 * q + j] + sbias[co - co0 + j];
                         uint2 pk2;
-                        pk2.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-                        pk2.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+                        pk2.x = pack2bf(o[0], o[1]);
+                        pk2.y = pack2bf(o[2], o[3]);
                         *reinterpret_cast<uint2*>(yp + co) = pk2;
                     }
                 }

@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(kNetThreads) trunk_fwd_net_kernel(const Twin<T
     float* flag = epi + kNetEpiFloats - 16;
     const int tid = threadIdx.x;
     for (int l = 0; l < a.nlayers; ++l) {
-        const TrunkLayerDesc& d = a.L[l];
+        const TrunkLayerDesc d = a.L[l];          // (by value: the fields are loaded once per layer, not inside the loops below)
         const int ntiles = d.M / d.rows;
         // this layer's weights do not depend on the previous layer: request them BEFORE waiting for its activations
         NetW<3> w3; NetW<1> w1; NetE pe;
@@ -988,7 +988,7 @@ __global__ void __launch_bounds__(kNetThreads) trunk_bwd_net_kernel(const Twin<T
     const int tid = threadIdx.x;
     const int N = a.B * a.T4;
     for (int l = 0; l < a.nlayers; ++l) {
-        const TrunkBwdLayerDesc& d = a.L[l];
+        const TrunkBwdLayerDesc d = a.L[l];       // (by value: loaded once per layer)
         const int ntiles = d.M / d.rows;
         const int Cx = (d.pre == 2) ? 2 * d.C : d.C;
         // this layer's weights (and the value it accumulates onto: this workgroup's own rows) do not depend on the previous layer
