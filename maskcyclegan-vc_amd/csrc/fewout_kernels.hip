@@ -686,6 +686,97 @@ __global__ void __launch_bounds__(256) wgrad_cin1_kernel(const Twin<WgradCin1KAr
 
 }  // namespace
 
+namespace {
+
+// ---- lastConvLayer's weight gradient on the matrix cores (KH x KW = 5 x 15, one output channel) -----------------------------------------
+//     dW[ci][kh][kw] = sum over (n, h, w) of dy[h][w] * x[ci][h + kh - 2][w + kw - 7]
+// With the KERNEL COLUMN as the row dimension and the INPUT CHANNEL as the column dimension this is a GEMM whose A operand is a Toeplitz
+// matrix of ONE dy row, shared by every channel and kernel row:
+//     Z(h, kh)[kw][ci] = sum over w' of  dy[h][w' - kw] * x[ci][h + kh - 2][w' - 7]          M = 16 (15 + a zero row), N = 16 channels, K = W + 14
+// v_mfma_f32_16x16x4_f32: lane (m = kw, k) of A reads the zero-padded dy row at w' - kw, lane (k, n = ci) of B reads the staged plane of
+// channel ci.  A workgroup owns 16 channels x a band of 8 rows of one sample; its four waves take two rows each and keep five accumulators
+// (one per kernel row), which are summed through LDS and added to dW (atomics when several workgroups share a channel tile).
+constexpr int kW1Band = 8, kW1Ch = 16, kW1PW = 84, kW1Plane = (kW1Band + 4) * kW1PW + 4;      // (+4: planes 20 banks apart, rows stay 16-byte aligned)
+constexpr int kW1DyW = 64 + 32;                                                             // a dy row with 16 zeros on either side
+struct W1Args {
+    const float* x; long long x_sn, x_sc; int x_sh;
+    const float* dy; long long dy_sn; int dy_sh;
+    float* dw;
+    int N, Cin, H, W, bands, units, atomic;
+};
+__global__ void __launch_bounds__(256, 2) wgrad_cout1_mfma_kernel(const Twin<W1Args> tw)
+{
+    const W1Args a = tw.v[blockIdx.z];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* xs = sm;                                   // [16 channels][kW1Plane]: rows h0-2 .. h0+band+1, image column c at LDS column c + 8
+    float* dys = sm + kW1Ch * kW1Plane;               // [band][kW1DyW]: dy[h][w] at column w + 16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, kq = lane >> 4;
+    const int c0 = blockIdx.x * kW1Ch;
+    typedef float f32x4w __attribute__((ext_vector_type(4)));
+    f32x4w acc[5];
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh) acc[kh] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    constexpr int P4 = kW1PW / 4;
+    for (int u = blockIdx.y; u < a.units; u += gridDim.y) {
+        const int n = u / a.bands, h0 = (u - n * a.bands) * kW1Band;
+        __syncthreads();
+        // stage: 16-byte pieces; whole pieces are inside or outside the image (W % 4 == 0, columns shifted by 8)
+        for (int i = tid; i < kW1Ch * (kW1Band + 4) * P4; i += 256) {
+            const int ci = i / ((kW1Band + 4) * P4), rem = i - ci * ((kW1Band + 4) * P4);
+            const int r = rem / P4, c4 = rem - r * P4;
+            const int ih = h0 - 2 + r, iw = 4 * c4 - 8;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c0 + ci < a.Cin && ih >= 0 && ih < a.H && iw >= 0 && iw + 3 < a.W)
+                v = *reinterpret_cast<const float4*>(a.x + (long long)n * a.x_sn + (long long)(c0 + ci) * a.x_sc + (long long)ih * a.x_sh + iw);
+            *reinterpret_cast<float4*>(xs + ci * kW1Plane + r * kW1PW + 4 * c4) = v;
+        }
+        for (int i = tid; i < kW1Band * (kW1DyW / 4); i += 256) {
+            const int r = i / (kW1DyW / 4), c4 = i - r * (kW1DyW / 4);
+            const int h = h0 + r, w = 4 * c4 - 16;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h < a.H && w >= 0 && w + 3 < a.W) v = *reinterpret_cast<const float4*>(a.dy + (long long)n * a.dy_sn + (long long)h * a.dy_sh + w);
+            *reinterpret_cast<float4*>(dys + r * kW1DyW + 4 * c4) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * wave + rr;                               // output row h0 + r
+            // A[m = ln][k]: dy[h][w' - 7 - m + 7 ... ]: with w' = 4 kb + kq the image column of x is w' - 7, and the tap kw = m pairs it with
+            // dy column (w' - 7) - (m - 7) = w' - m: LDS column w' - m + 16
+            const float* dr = dys + r * kW1DyW + 16 - ln + kq;
+            const float* xr = xs + ln * kW1Plane + r * kW1PW + 1 + kq;          // x[ci = ln][h0 - 2 + r + kh][w' - 7] at LDS column w' + 1
+#pragma unroll 4
+            for (int kb = 0; kb < 20; ++kb) {                          // w' = 0 .. 79 (64 + 14 columns, padded to 80)
+                const float av = dr[4 * kb];
+#pragma unroll
+                for (int kh = 0; kh < 5; ++kh)
+                    acc[kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xr[kh * kW1PW + 4 * kb], acc[kh], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the four waves' partial sums through LDS: red[wave][kh][kw = 4 kq + q][ci = ln]
+    __syncthreads();
+    float* red = sm;
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[((wave * 5 + kh) * 16 + 4 * kq + q) * 16 + ln] = acc[kh][q];
+    __syncthreads();
+    for (int i = tid; i < 5 * 15 * kW1Ch; i += 256) {
+        const int ci = i / 75, t = i - ci * 75, kh = t / 15, kw = t - kh * 15;
+        if (c0 + ci >= a.Cin) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) v += red[((wv * 5 + kh) * 16 + kw) * 16 + ci];
+        float* d = a.dw + (long long)(c0 + ci) * 75 + t;
+        if (a.atomic) unsafeAtomicAdd(d, v); else *d += v;
+    }
+}
+
+}  // namespace
+
 bool mcvc_wgrad_cout1_applies(const ConvProblem& p)
 {
     if (p.Cout != 1 || p.stride != 1 || p.KH * p.KW > 128 || p.OH != p.H || p.OW != p.W) return false;
@@ -704,6 +795,23 @@ int mcvc_wgrad_cout1_launch(const ConvProblem& p, int NB, const WgradIO& io, flo
     a.XW = p.W + p.KW - 1;
     // (sample, band of rows) units over gridDim.y workgroups that add their partial sums atomically; deterministic mode: one workgroup per
     // input channel walks whole planes in a fixed order
+    // 5 x 15 kernels on 16-byte aligned images: the matrix-core form (MCVC_WGRAD1_MFMA=0: the VALU kernel)
+    static const int mfma = [] { const char* e = getenv("MCVC_WGRAD1_MFMA"); return e ? atoi(e) : 1; }();
+    if (mfma && p.KH == 5 && p.KW == 15 && p.pad_h == 2 && p.pad_w == 7 && p.W == 64 && (io.x_sh & 3) == 0 && (io.x_sc & 3) == 0 && (io.x_sb & 3) == 0 &&
+        (io.dy_sh & 3) == 0 && (io.dy_sb & 3) == 0 && ((reinterpret_cast<unsigned long long>(io.x) | reinterpret_cast<unsigned long long>(io.dy)) & 15ull) == 0) {
+        W1Args w{};
+        w.x = io.x; w.x_sn = io.x_sb; w.x_sc = io.x_sc; w.x_sh = io.x_sh; w.dy = io.dy; w.dy_sn = io.dy_sb; w.dy_sh = io.dy_sh; w.dw = dw;
+        w.N = NB; w.Cin = p.Cin; w.H = p.H; w.W = p.W; w.bands = cdiv_i(p.H, kW1Band); w.units = NB * w.bands;
+        const int tiles = cdiv_i(p.Cin, kW1Ch);
+        int nch = 1;
+        if (!mcvc_deterministic())
+            while (2 * nch <= w.units && tiles * nch < 1024) nch *= 2;
+        w.atomic = nch > 1 ? 1 : 0;
+        const size_t lds1 = (size_t)(kW1Ch * kW1Plane + kW1Band * kW1DyW) * sizeof(float);
+        TraceScope ts(K_WGRAD_SMALLK, s, 2.0 * NB * p.H * p.W * p.Cin * p.KH * p.KW, 4.0 * ((double)NB * p.Cin * p.H * p.W + (double)NB * p.H * p.W * p.Cin));
+        mcvc_launch(wgrad_cout1_mfma_kernel, dim3((unsigned)tiles, (unsigned)nch), dim3(256), lds1, s, w);
+        return (int)hipGetLastError();
+    }
     int nchunk = 1;
     a.band = p.H;
     if (!mcvc_deterministic()) {

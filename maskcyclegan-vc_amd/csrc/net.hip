@@ -2297,6 +2297,8 @@ int mcvc_conv2d_wgrad(const float* x, const float* dy, float* dw, float* slabs, 
     const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
     ConvProblem p{Cin, H, W, Cout, OH, OW, KH, KW, stride, pad_h, pad_w};
     WgradIO io{x, (long long)Cin * H * W, (long long)H * W, W, dy, (long long)Cout * OH * OW, (long long)OH * OW, OW};
+    // (the same special cases the network planner takes, conv_wgrad: dw accumulates, the caller passes zeros)
+    if (Cout == 1 && mcvc_wgrad_cout1_applies(p)) return mcvc_wgrad_cout1_launch(p, N, io, dw, (hipStream_t)stream);
     return mcvc_wgrad_launch(p, N, io, dw, slabs, slab_floats, (hipStream_t)stream);
 }
 
