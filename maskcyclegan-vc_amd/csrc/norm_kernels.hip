@@ -752,7 +752,9 @@ int mcvc_norm_fwd_wino_launch(const NormArgs& a, const WinoOutArgs& w, int pts, 
         if (items <= 64) MCVC_FWD_WINO(64, 1)
         if (items <= 128) MCVC_FWD_WINO(64, 2)
         if (items <= 256 && planes < 2048) MCVC_FWD_WINO(256, 1)
-        if (items <= 512 && planes < 1024) MCVC_FWD_WINO(256, 2)      // few planes (one or two samples): a workgroup per plane fills the chip
+        // (16 outputs per item: five items per thread are 220 registers -- two waves per SIMD -- and measured 210 us against 160 for the
+        // separate transform + norm at 32 samples; two items per thread keep four waves resident)
+        if (items <= 512) MCVC_FWD_WINO(256, 2)
         MCVC_FWD_WINO(64, 5)
     }
     if (items <= 128) MCVC_FWD_WINO(64, 2)
