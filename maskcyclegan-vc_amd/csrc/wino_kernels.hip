@@ -801,13 +801,15 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const Twin<WinoGemmArgs> tw)
 {
     const WinoGemmArgs a = tw.v[blockIdx.z];
     constexpr int SA = GK * BM, SB = GK * BN, STAGE = SA + SB;
-    constexpr int NBM = (BN >= 64) ? BM / 64 : 1, NBN = (BN >= 64) ? BN / 64 : 1, NACC = NBM * NBN;     // 32x32 blocks per wave (rows x columns)
+    // waves 2 x 2 when BN is a multiple of 64, else 4 x 1 (every wave 32 rows x all BN columns: the one-tile-wide shapes for N = 96 / 160)
+    constexpr bool W22 = (BN % 64) == 0;
+    constexpr int NBM = W22 ? BM / 64 : BM / 128, NBN = W22 ? BN / 64 : BN / 32, NACC = NBM * NBN;     // 32x32 blocks per wave (rows x columns)
     constexpr int NA = (SA / 4 + 255) / 256, NB = (SB / 4 + 255) / 256, ND = NA + NB;     // DMA instructions per wave and stage
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int wm = (BN >= 64) ? (wave >> 1) : wave, wn = (BN >= 64) ? (wave & 1) : 0;
+    const int wm = W22 ? (wave >> 1) : wave, wn = W22 ? (wave & 1) : 0;
     int lid;
     {
         const int total = (int)gridDim.x, linear = (int)blockIdx.x;
@@ -964,6 +966,8 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
         case 13: return gemm2_launch<128, 128, 32, 3>(b, nxi, s);
         case 14: return gemm2_launch<128, 128, 16, 6>(b, nxi, s);
         case 15: return gemm2_launch<128, 128, 32, 2>(b, nxi, s);
+        case 16: return gemm2_launch<128, 96, 16, 4>(b, nxi, s);
+        case 17: return gemm2_launch<128, 160, 16, 4>(b, nxi, s);
         default: break;
     }
     // long-K products (the F(2x2,3x3) layers: K = 4*Cin or Cout >= 512): 64x64 tiles with 32-deep stages measured 10-20 % faster than
@@ -976,6 +980,13 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
         if (shortk == 1) return gemm2_launch<128, 64, 16, 6>(b, nxi, s);
         if (shortk == 2) return gemm2_launch<64, 64, 16, 6>(b, nxi, s);
         if (shortk == 3) return gemm2_launch<128, 32, 16, 6>(b, nxi, s);
+    }
+    // one-tile-wide shapes: N in (64, 96] / (128, 160] columns (the one- and two-sample passes): a 128 x N tile reads U once instead of once
+    // per 32-column tile and a third / a fifth of the workgroups carry the prologue + epilogue (MCVC_GEMM_WIDE=0: the narrow tiles)
+    static const int wide = [] { const char* e = getenv("MCVC_GEMM_WIDE"); return e ? atoi(e) : 0; }();
+    if (cfg2 == 0 && wide && (a.K % 16) == 0) {
+        if (a.N > 64 && a.N <= 96 && a.ldb >= 96) return gemm2_launch<128, 96, 16, 4>(b, nxi, s);
+        if (a.N > 128 && a.N <= 160 && a.ldb >= 160) return gemm2_launch<128, 160, 16, 4>(b, nxi, s);
     }
     if (narrow) {
         b.nt = cdiv_i(a.N, 32);
