@@ -982,10 +982,13 @@ class TrainEngine:
                 self._twin(lambda: self._repack1(pair[0]), lambda: self._repack1(pair[1]))
             return run
         split = self.B >= self.split_d_min_batch
+        # experiment (MCVC_STAGGER): bit 0 = the translation forwards wait for the D-phase's generator forwards, bit 1 = the cycle forwards
+        # for the D-phase's cycle forwards -- the D-phase chain is the critical one, the G-phase forwards have 0.7 ms of slack
+        stagger = int(os.environ.get("MCVC_STAGGER", "0"))
         tasks = [
             (3, side_head, (), "rf"),          # (first: a backward pass refuses to run on a buffer whose backward copies are marked stale)
             (1, (lambda ln: (None if packed else d["repack_full"](ln), d["gen_fwd"](ln))), (), "gen"),
-            (0, g["fwd2"], (), "g"),
+            (0, g["fwd2"], ("gen",) if stagger & 1 else (), "g"),
         ] + head
         if split:
             tasks += [(3, d["real1"], (), None), (3, d["real2"], (), "r2")]
@@ -997,7 +1000,7 @@ class TrainEngine:
             adv1_lane = 3 if ident_pos == "head3" else 2
         tasks += [
             (1, d["cycles"], (), "cyc"),
-            (0, g["cycle"], (), None),
+            (0, g["cycle"], ("cyc",) if stagger & 2 else (), None),
             (3, d["fake1"] if split else d["full1"], ("gen",), None),
             (3, d_update(("discriminator_A", "discriminator_B")), (), "dupd1"),
             (1, d["fake2"] if split else d["full2"], ("r2",) if split else (), None),
