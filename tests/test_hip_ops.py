@@ -39,6 +39,10 @@ CONV_CASES = [
     ("ragged.s1", 5, 33, 3, 3, 1, 1, 1, 2, 9, 7, False),
     ("ragged.wide", 4, 70, 1, 3, 1, 0, 1, 1, 5, 100, False),
     ("trunk.T4", 256, 1024, 1, 3, 1, 0, 1, 1, 2, 4, False),
+    # the 5x15 edge layers on the matrix cores (conv_fewout_mfma_kernel, wgrad_cout1_mfma_kernel): partial channel rounds (6 = 4 + 2
+    # channels, 10 = 4 + 4 + 2), a short last row tile (21 = 16 + 5 rows) and a short last band (21 = 8 + 8 + 5)
+    ("ragged.last", 6, 1, 5, 15, 1, 2, 7, 3, 21, 64, False),
+    ("ragged.conv1", 2, 10, 5, 15, 1, 2, 7, 2, 21, 64, False),
 ]
 
 
