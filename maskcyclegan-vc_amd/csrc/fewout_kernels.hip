@@ -723,14 +723,26 @@ __global__ void __launch_bounds__(256, 2) wgrad_cout1_mfma_kernel(const Twin<W1A
         const int n = u / a.bands, h0 = (u - n * a.bands) * kW1Band;
         __syncthreads();
         // stage: 16-byte pieces; whole pieces are inside or outside the image (W % 4 == 0, columns shifted by 8)
-        for (int i = tid; i < kW1Ch * (kW1Band + 4) * P4; i += 256) {
-            const int ci = i / ((kW1Band + 4) * P4), rem = i - ci * ((kW1Band + 4) * P4);
-            const int r = rem / P4, c4 = rem - r * P4;
-            const int ih = h0 - 2 + r, iw = 4 * c4 - 8;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c0 + ci < a.Cin && ih >= 0 && ih < a.H && iw >= 0 && iw + 3 < a.W)
-                v = *reinterpret_cast<const float4*>(a.x + (long long)n * a.x_sn + (long long)(c0 + ci) * a.x_sc + (long long)ih * a.x_sh + iw);
-            *reinterpret_cast<float4*>(xs + ci * kW1Plane + r * kW1PW + 4 * c4) = v;
+        {   // (all of a thread's loads in flight before the first LDS store)
+            constexpr int TOT = kW1Ch * (kW1Band + 4) * P4, NIT = (TOT + 255) / 256;
+            float4 v[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + it * 256;
+                const int ci = i / ((kW1Band + 4) * P4), rem = i - ci * ((kW1Band + 4) * P4);
+                const int r = rem / P4, c4 = rem - r * P4;
+                const int ih = h0 - 2 + r, iw = 4 * c4 - 8;
+                v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < TOT && c0 + ci < a.Cin && ih >= 0 && ih < a.H && iw >= 0 && iw + 3 < a.W)
+                    v[it] = *reinterpret_cast<const float4*>(a.x + (long long)n * a.x_sn + (long long)(c0 + ci) * a.x_sc + (long long)ih * a.x_sh + iw);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + it * 256;
+                const int ci = i / ((kW1Band + 4) * P4), rem = i - ci * ((kW1Band + 4) * P4);
+                const int r = rem / P4, c4 = rem - r * P4;
+                if (i < TOT) *reinterpret_cast<float4*>(xs + ci * kW1Plane + r * kW1PW + 4 * c4) = v[it];
+            }
         }
         for (int i = tid; i < kW1Band * (kW1DyW / 4); i += 256) {
             const int r = i / (kW1DyW / 4), c4 = i - r * (kW1DyW / 4);
@@ -747,12 +759,24 @@ __global__ void __launch_bounds__(256, 2) wgrad_cout1_mfma_kernel(const Twin<W1A
             // dy column (w' - 7) - (m - 7) = w' - m: LDS column w' - m + 16
             const float* dr = dys + r * kW1DyW + 16 - ln + kq;
             const float* xr = xs + ln * kW1Plane + r * kW1PW + 1 + kq;          // x[ci = ln][h0 - 2 + r + kh][w' - 7] at LDS column w' + 1
-#pragma unroll 4
+            // (software pipeline as in conv_fewout_mfma_kernel: the six operands of block kb + 1 are read while block kb multiplies)
+            float av[2], bw[2][5];
+            av[0] = dr[0];
+#pragma unroll
+            for (int kh = 0; kh < 5; ++kh) bw[0][kh] = xr[kh * kW1PW];
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
             for (int kb = 0; kb < 20; ++kb) {                          // w' = 0 .. 79 (64 + 14 columns, padded to 80)
-                const float av = dr[4 * kb];
+                if (kb + 1 < 20) {
+                    av[(kb + 1) & 1] = dr[4 * (kb + 1)];
+#pragma unroll
+                    for (int kh = 0; kh < 5; ++kh) bw[(kb + 1) & 1][kh] = xr[kh * kW1PW + 4 * (kb + 1)];
+                }
 #pragma unroll
                 for (int kh = 0; kh < 5; ++kh)
-                    acc[kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xr[kh * kW1PW + 4 * kb], acc[kh], 0, 0, 0);
+                    acc[kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb & 1], bw[kb & 1][kh], acc[kh], 0, 0, 0);
+                if (kb + 1 < 20) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
             }
         }
     }
@@ -776,6 +800,158 @@ __global__ void __launch_bounds__(256, 2) wgrad_cout1_mfma_kernel(const Twin<W1A
 }
 
 }  // namespace
+
+namespace {
+
+// ---- conv1's weight gradient on the matrix cores (Cin <= 2 input channels, KH x KW = 5 x 15) ----------------------------------------------
+//     dW[co][ci][kh][kw] = sum over (n, h, w) of dy[co][h][w] * x[ci][h + kh - 2][w + kw - 7]
+// The kernel column is the row dimension again, now with the OUTPUT channel as the column dimension; the Toeplitz operand comes from x:
+//     Z(h, ci, kh)[kw][co] = sum over w of  x[ci][h + kh - 2][w + kw - 7] * dy[co][h][w]            M = 16, N = 16 channels, K = W
+// A workgroup owns 64 output channels (16 per wave) and walks (sample, band of 4 rows) units; a wave keeps Cin * 5 accumulators.  One B
+// read (dy) serves the Cin * 5 MFMAs of a k block, every A read is 16 consecutive columns of a staged x row.
+constexpr int kW2Band = 4, kW2Co = 64, kW2DyP = kW2Band * 64 + 4;       // dy pitch per channel: 4 banks apart (2-way conflicts at most)
+constexpr int kW2XP = 84;
+struct W2Args {
+    const float* x; long long x_sn, x_sc; int x_sh;
+    const float* dy; long long dy_sn, dy_sc; int dy_sh;
+    float* dw;
+    int N, Cin, Cout, H, W, bands, units, atomic;
+};
+template <int CI>
+__global__ void __launch_bounds__(256, 2) wgrad_cin2_mfma_kernel(const Twin<W2Args> tw)
+{
+    const W2Args a = tw.v[blockIdx.z];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* dys = sm;                                      // [64 channels][kW2DyP]: dy[co][h0 + r][w] at r * 64 + w
+    float* xs = sm + kW2Co * kW2DyP;                      // [CI][band + 4][kW2XP]: rows h0 - 2 .., image column c at LDS column c + 8
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, kq = lane >> 4;
+    const int co0 = blockIdx.x * kW2Co;
+    typedef float f32x4w __attribute__((ext_vector_type(4)));
+    f32x4w acc[CI][5];
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 5; ++kh) acc[ci][kh] = f32x4w{0.f, 0.f, 0.f, 0.f};
+    constexpr int P4 = kW2XP / 4, XR = kW2Band + 4;
+    for (int u = blockIdx.y; u < a.units; u += gridDim.y) {
+        const int n = u / a.bands, h0 = (u - n * a.bands) * kW2Band;
+        __syncthreads();
+        {   // dy: 16-byte pieces, rows of 64; all of a thread's loads are in flight before the first LDS store (a plain load -> store loop
+            // serialises 16 global round trips per unit: it was 2/3 of the kernel)
+            constexpr int NIT = kW2Co * kW2Band * 16 / 256;
+            float4 v[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + it * 256;
+                const int co = i / (kW2Band * 16), rem = i - co * (kW2Band * 16);
+                const int r = rem >> 4, c4 = rem & 15;
+                v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (co0 + co < a.Cout && h0 + r < a.H)
+                    v[it] = *reinterpret_cast<const float4*>(a.dy + (long long)n * a.dy_sn + (long long)(co0 + co) * a.dy_sc + (long long)(h0 + r) * a.dy_sh + 4 * c4);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int i = tid + it * 256;
+                const int co = i / (kW2Band * 16), rem = i - co * (kW2Band * 16);
+                const int r = rem >> 4, c4 = rem & 15;
+                *reinterpret_cast<float4*>(dys + co * kW2DyP + r * 64 + 4 * c4) = v[it];
+            }
+        }
+        for (int i = tid; i < CI * XR * P4; i += 256) {
+            const int ci = i / (XR * P4), rem = i - ci * (XR * P4);
+            const int r = rem / P4, c4 = rem - r * P4;
+            const int ih = h0 - 2 + r, iw = 4 * c4 - 8;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < a.Cin && ih >= 0 && ih < a.H && iw >= 0 && iw + 3 < a.W)
+                v = *reinterpret_cast<const float4*>(a.x + (long long)n * a.x_sn + (long long)ci * a.x_sc + (long long)ih * a.x_sh + iw);
+            *reinterpret_cast<float4*>(xs + (ci * XR + r) * kW2XP + 4 * c4) = v;
+        }
+        __syncthreads();
+        const float* br = dys + (wave * 16 + ln) * kW2DyP + kq;           // B[k = kq][n = ln]: dy[co][h][w = 4 kb + kq]
+        const float* ar = xs + 1 + ln + kq;                               // A[m = ln][k = kq]: x[ci][h + kh - 2][w + kw - 7] at column w + kw + 1
+        // software pipeline over the k blocks: the CI * 5 + 1 operands of block kb + 1 are read while block kb multiplies (pinned order; left
+        // alone every MFMA waits for its own LDS round trip)
+        auto load_kb = [&](int r, int kb, float (&av)[CI][5], float& bv) {
+            bv = br[r * 64 + 4 * kb];
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                for (int kh = 0; kh < 5; ++kh) av[ci][kh] = ar[(ci * XR + r + kh) * kW2XP + 4 * kb];
+        };
+#pragma unroll 1
+        for (int r = 0; r < kW2Band; ++r) {
+            float av[2][CI][5], bv[2];
+            load_kb(r, 0, av[0], bv[0]);
+            __builtin_amdgcn_sched_group_barrier(0x100, CI * 5 + 1, 0);
+#pragma unroll
+            for (int kb = 0; kb < 16; ++kb) {
+                if (kb + 1 < 16) load_kb(r, kb + 1, av[(kb + 1) & 1], bv[(kb + 1) & 1]);
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+                    for (int kh = 0; kh < 5; ++kh)
+                        acc[ci][kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb & 1][ci][kh], bv[kb & 1], acc[ci][kh], 0, 0, 0);
+                if (kb + 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, CI * 5 + 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, CI * 5, 0);
+            }
+        }
+    }
+    // ---- write-out through LDS so that consecutive lanes add to consecutive addresses (the block's [64][Cin * 75] slice of dW is contiguous):
+    // acc register q of lane (ln, kq) is (kw = 4 kq + q, co = 16 wave + ln)
+    __syncthreads();
+    float* red = sm;                                      // [64][Cin * 75]
+    const int per = a.Cin * 75;
+#pragma unroll
+    for (int ci = 0; ci < CI; ++ci) {
+        if (ci >= a.Cin) break;
+#pragma unroll
+        for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kw = 4 * kq + q;
+                if (kw < 15) red[(wave * 16 + ln) * per + (ci * 5 + kh) * 15 + kw] = acc[ci][kh][q];
+            }
+    }
+    __syncthreads();
+    int nco = a.Cout - co0; if (nco > kW2Co) nco = kW2Co;
+    float* d0 = a.dw + (long long)co0 * per;
+    for (int i = tid; i < nco * per; i += 256) {
+        if (a.atomic) unsafeAtomicAdd(d0 + i, red[i]); else d0[i] += red[i];
+    }
+}
+
+}  // namespace
+
+bool mcvc_wgrad_cin2_applies(const ConvProblem& p, const WgradIO& io)
+{
+    static const int en = [] { const char* e = getenv("MCVC_WGRAD_CIN2_MFMA"); return e ? atoi(e) : 1; }();
+    return en && p.Cin >= 1 && p.Cin <= 2 && p.KH == 5 && p.KW == 15 && p.stride == 1 && p.pad_h == 2 && p.pad_w == 7 && p.W == 64 && p.OH == p.H &&
+           p.OW == p.W && (io.x_sh & 3) == 0 && (io.x_sc & 3) == 0 && (io.x_sb & 3) == 0 && (io.dy_sh & 3) == 0 && (io.dy_sc & 3) == 0 &&
+           (io.dy_sb & 3) == 0 && ((reinterpret_cast<unsigned long long>(io.x) | reinterpret_cast<unsigned long long>(io.dy)) & 15ull) == 0;
+}
+
+int mcvc_wgrad_cin2_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, hipStream_t s)
+{
+    if (!mcvc_wgrad_cin2_applies(p, io)) return MCVC_ERR_INVALID;
+    W2Args w{};
+    w.x = io.x; w.x_sn = io.x_sb; w.x_sc = io.x_sc; w.x_sh = io.x_sh;
+    w.dy = io.dy; w.dy_sn = io.dy_sb; w.dy_sc = io.dy_sc; w.dy_sh = io.dy_sh; w.dw = dw;
+    w.N = NB; w.Cin = p.Cin; w.Cout = p.Cout; w.H = p.H; w.W = p.W; w.bands = cdiv_i(p.H, kW2Band); w.units = NB * w.bands;
+    const int blocks = cdiv_i(p.Cout, kW2Co);
+    int nch = 1;
+    // (every workgroup ends with 64 x Cin x 75 atomic adds into the same dW block: enough workgroups to fill the chip, not more)
+    static const int wgs = [] { const char* e = getenv("MCVC_WGRAD_CIN2_WGS"); return e ? atoi(e) : 512; }();
+    if (!mcvc_deterministic())
+        while (2 * nch <= w.units && blocks * nch < wgs) nch *= 2;
+    w.atomic = nch > 1 ? 1 : 0;
+    const size_t lds = (size_t)(kW2Co * kW2DyP + 2 * (kW2Band + 4) * kW2XP) * sizeof(float);
+    TraceScope ts(K_WGRAD_4x1, s, 2.0 * NB * p.H * p.W * p.Cout * p.Cin * p.KH * p.KW, 4.0 * ((double)NB * p.Cout * p.H * p.W + (double)NB * p.Cin * p.H * p.W));
+    if (p.Cin == 1) mcvc_launch(wgrad_cin2_mfma_kernel<1>, dim3((unsigned)blocks, (unsigned)nch), dim3(256), lds, s, w);
+    else mcvc_launch(wgrad_cin2_mfma_kernel<2>, dim3((unsigned)blocks, (unsigned)nch), dim3(256), lds, s, w);
+    return (int)hipGetLastError();
+}
 
 bool mcvc_wgrad_cout1_applies(const ConvProblem& p)
 {

@@ -192,6 +192,9 @@ struct WgradIO {
     const float* dy; long long dy_sb, dy_sc; int dy_sh;
 };
 int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, float* slabs, long long slab_cap_floats, hipStream_t s);
+// conv1's weight gradient (Cin <= 2, 5 x 15) on the matrix cores (fewout_kernels.hip); dw accumulates
+bool mcvc_wgrad_cin2_applies(const ConvProblem& p, const WgradIO& io);
+int mcvc_wgrad_cin2_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw, hipStream_t s);
 // one-output-channel weight gradient on the VALU (fewout_kernels.hip): lastConvLayer, the discriminator's output conv
 bool mcvc_wgrad_cout1_applies(const ConvProblem& p);
 // one-INPUT-channel 3x3 weight gradient (the discriminators' first conv)

@@ -893,6 +893,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         // last layer of a backward pass with nothing left for the main stream (conv1 without an input gradient): the gate branch runs
         // there, beside the value branch on the auxiliary stream (atomic accumulation into its own tensor, no slabs to share)
         const bool on_main = br == 1 && ex.br1_on_main && ex.s2 && !mcvc_deterministic() && (long long)c.Cout * c.Cin * c.KH * c.KW <= 65536;
+        if (mcvc_wgrad_cin2_applies(p, io)) { ex.fail(mcvc_wgrad_cin2_launch(p, NB, io, dw, on_main ? ex.s : ws)); continue; }
         ex.fail(mcvc_wgrad_launch(p, NB, io, dw, ex.wslabs, ex.wslab_cap, on_main ? ex.s : ws));
     }
     if (ex.s2) {
@@ -2299,6 +2300,7 @@ int mcvc_conv2d_wgrad(const float* x, const float* dy, float* dw, float* slabs, 
     WgradIO io{x, (long long)Cin * H * W, (long long)H * W, W, dy, (long long)Cout * OH * OW, (long long)OH * OW, OW};
     // (the same special cases the network planner takes, conv_wgrad: dw accumulates, the caller passes zeros)
     if (Cout == 1 && mcvc_wgrad_cout1_applies(p)) return mcvc_wgrad_cout1_launch(p, N, io, dw, (hipStream_t)stream);
+    if (mcvc_wgrad_cin2_applies(p, io)) return mcvc_wgrad_cin2_launch(p, N, io, dw, (hipStream_t)stream);
     return mcvc_wgrad_launch(p, N, io, dw, slabs, slab_floats, (hipStream_t)stream);
 }
 
