@@ -7,33 +7,64 @@
 
 namespace {
 
-// out[b] = sum_j in[j] * BT[b][j]
-__device__ __forceinline__ void w4_bt(const float in[8], float out[8])
+// out = B^T in, factored through the even / odd symmetry of the points (26 operations instead of the 40 non-zero table entries: these
+// kernels are instruction-bound -- 1764 instructions per (channel, tile) thread in the table-driven form, 245 us of VALU issue at 64 samples)
+__device__ __forceinline__ void w4_bt(const float d[8], float o[8])
 {
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += in[j] * kW4BT[b][j];
-        out[b] = acc;
-    }
+    const float e1 = d[2] - 4.25f * d[4] + d[6], o1 = d[1] - 4.25f * d[3] + d[5];
+    const float e2 = 0.25f * d[2] - 1.25f * d[4] + d[6], o2 = 0.5f * d[1] - 2.5f * d[3] + 2.f * d[5];
+    const float e3 = 4.f * d[2] - 5.f * d[4] + d[6], o3 = 2.f * d[1] - 2.5f * d[3] + 0.5f * d[5];
+    o[0] = (d[6] - d[0]) + 5.25f * (d[2] - d[4]);
+    o[1] = e1 + o1; o[2] = e1 - o1;
+    o[3] = e2 + o2; o[4] = e2 - o2;
+    o[5] = e3 + o3; o[6] = e3 - o3;
+    o[7] = (d[7] - d[1]) + 5.25f * (d[3] - d[5]);
+}
+// out = A^T m (4 from 8) and out = A d (8 from 4), the same way
+__device__ __forceinline__ void w4_at(const float m[8], float o[4])
+{
+    const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4], s56 = m[5] + m[6], d56 = m[5] - m[6];
+    o[0] = m[0] + s12 + s34 + s56;
+    o[1] = d12 + 2.f * d34 + 0.5f * d56;
+    o[2] = s12 + 4.f * s34 + 0.25f * s56;
+    o[3] = d12 + 8.f * d34 + 0.125f * d56 + m[7];
+}
+__device__ __forceinline__ void w4_a(const float d[4], float o[8])
+{
+    const float e = d[0] + d[2], f = d[1] + d[3];
+    const float e4 = d[0] + 4.f * d[2], f4 = 2.f * d[1] + 8.f * d[3];
+    const float eh = d[0] + 0.25f * d[2], fh = 0.5f * d[1] + 0.125f * d[3];
+    o[0] = d[0]; o[1] = e + f; o[2] = e - f; o[3] = e4 + f4; o[4] = e4 - f4; o[5] = eh + fh; o[6] = eh - fh; o[7] = d[3];
 }
 
 // V = B^T d B of the 8x8 patch whose top-left input pixel is (ih0, iw0); o[a * 8 + b]
 __device__ __forceinline__ void w4_input(const float* src, int x_sh, int ih0, int iw0, int H, int W, float* o)
 {
     float t[8][8];
+    const float* rp = src + (long long)ih0 * x_sh + iw0;
+    if (ih0 >= 0 && ih0 + 7 < H && iw0 >= 0 && iw0 + 7 < W) {       // interior window: no per-element predicates
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        float d[8];
-        const int ih = ih0 + i;
-        const bool rok = (ih >= 0) && (ih < H);
+        for (int i = 0; i < 8; ++i) {
+            float d[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int iw = iw0 + j;
-            d[j] = (rok && iw >= 0 && iw < W) ? src[(long long)ih * x_sh + iw] : 0.f;
+            for (int j = 0; j < 8; ++j) d[j] = rp[j];
+            rp += x_sh;
+            w4_bt(d, t[i]);
         }
-        w4_bt(d, t[i]);                          // t[i][b] = sum_j d[i][j] BT[b][j]
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float d[8];
+            const int ih = ih0 + i;
+            const bool rok = (ih >= 0) && (ih < H);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int iw = iw0 + j;
+                d[j] = (rok && iw >= 0 && iw < W) ? rp[j] : 0.f;
+            }
+            rp += x_sh;
+            w4_bt(d, t[i]);                      // t[i][b] = sum_j d[i][j] BT[b][j]
+        }
     }
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -56,23 +87,15 @@ __device__ __forceinline__ void w4_dy(const float* src, int x_sh, int oh0, int o
 #pragma unroll
         for (int j = 0; j < 4; ++j) dy[i][j] = (oh0 + i < H && ow0 + j < W) ? src[(long long)(oh0 + i) * x_sh + ow0 + j] : 0.f;
 #pragma unroll
-    for (int aa = 0; aa < 8; ++aa)
+    for (int j = 0; j < 4; ++j) {
+        const float col[4] = {dy[0][j], dy[1][j], dy[2][j], dy[3][j]};
+        float q[8];
+        w4_a(col, q);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float acc = 0.f;
+        for (int aa = 0; aa < 8; ++aa) t[aa][j] = q[aa];
+    }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc += kW4AT[i][aa] * dy[i][j];
-            t[aa][j] = acc;
-        }
-#pragma unroll
-    for (int aa = 0; aa < 8; ++aa)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc += t[aa][j] * kW4AT[j][b];
-            o[aa * 8 + b] = acc;
-        }
+    for (int aa = 0; aa < 8; ++aa) w4_a(t[aa], o + aa * 8);          // o[aa][b] = sum_j t[aa][j] AT[j][b]
 }
 
 // one thread = one (channel, tile): 64 loads, 64 coalesced stores
@@ -110,23 +133,20 @@ __global__ void __launch_bounds__(256) wino4_output_kernel(const Twin<WinoOutArg
         float col[8];
 #pragma unroll
         for (int aa = 0; aa < 8; ++aa) col[aa] = src[(long long)(aa * 8 + b) * xs];
+        float q[4];
+        w4_at(col, q);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float acc = 0.f;
-#pragma unroll
-            for (int aa = 0; aa < 8; ++aa) acc += kW4AT[i][aa] * col[aa];
-            u[i][b] = acc;
-        }
+        for (int i = 0; i < 4; ++i) u[i][b] = q[i];
     }
     const float bias = a.bias ? a.bias[co] : 0.f;
     float* yn = a.y + (long long)n * a.y_sb;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        float row[4];
+        w4_at(u[i], row);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float acc = bias;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) acc += u[i][b] * kW4AT[j][b];
+            const float acc = row[j] + bias;
             const int oh = 4 * ty + i, ow = 4 * tx + j;
             if (oh >= a.OH || ow >= a.OW) continue;
             long long off;
@@ -139,6 +159,7 @@ __global__ void __launch_bounds__(256) wino4_output_kernel(const Twin<WinoOutArg
             }
             if (a.accumulate) yn[off] += acc; else yn[off] = acc;
         }
+    }
 }
 
 // tile-major operands of the weight gradient through an LDS transpose: 4 tiles x 64 channels per workgroup (see xform_t_kernel in
