@@ -806,16 +806,24 @@ struct SmallKArgs {
     int NB, Cin, Cout, OH, OW, pw;
 };
 
+// (r3: a thread owns ONE (ci, kw) element of COB consecutive dW rows instead of one ci with its KW taps: the dW read-modify-write -- the
+// whole cost of the layer -- is a run of 256 consecutive floats per row and instruction instead of every KW-th float, and x comes through LDS
+// with coalesced loads instead of 64 cache lines per load instruction.  5120 x 256 conv1dto2d gradient: 59 -> see DESIGN section 9.)
 template <int KW, int COB>
 __global__ void __launch_bounds__(256) wgrad_smallk_kernel(const Twin<SmallKArgs> tw)
 {
     const SmallKArgs a = tw.v[blockIdx.z];
-    __shared__ float dys[COB * 128];
+    extern __shared__ float smk[];                    // dy[COB][npix] | x[channels of the block][npix + 1]
     const int tid = threadIdx.x;
     const int co0 = blockIdx.x * COB;
-    const int ci = blockIdx.y * 256 + tid;
+    const int e0 = blockIdx.y * 256;                  // first (ci, kw) element of this block
     const int rows = a.NB * a.OH;
-    const int npix = rows * a.OW;
+    const int npix = rows * a.OW, xp = npix + 1;
+    float* dys = smk;
+    float* xs = smk + COB * npix;
+    const int ci0 = e0 / KW;
+    int nci = (e0 + 255) / KW - ci0 + 1;
+    if (ci0 + nci > a.Cin) nci = a.Cin - ci0;
     for (int i = tid; i < COB * npix; i += 256) {
         const int co = i / npix, p = i - co * npix;
         const int row = p / a.OW, ow = p - row * a.OW;
@@ -823,98 +831,90 @@ __global__ void __launch_bounds__(256) wgrad_smallk_kernel(const Twin<SmallKArgs
         const int cg = co0 + co;
         dys[co * npix + p] = (cg < a.Cout) ? a.dy[(long long)n * a.dy_sb + (long long)cg * a.dy_sc + (long long)oh * a.dy_sh + ow] : 0.f;
     }
-    __syncthreads();
-    if (ci >= a.Cin) return;
-    float acc[COB][KW];
-#pragma unroll
-    for (int c = 0; c < COB; ++c)
-#pragma unroll
-        for (int k = 0; k < KW; ++k) acc[c][k] = 0.f;
-    for (int row = 0; row < rows; ++row) {
+    for (int i = tid; i < nci * npix; i += 256) {
+        const int c = i / npix, p = i - c * npix;
+        const int row = p / a.OW, q = p - row * a.OW;
         const int n = row / a.OH, oh = row - n * a.OH;
-        const float* xr = a.x + (long long)n * a.x_sb + (long long)ci * a.x_sc + (long long)oh * a.x_sh;
+        xs[c * xp + p] = a.x[(long long)n * a.x_sb + (long long)(ci0 + c) * a.x_sc + (long long)oh * a.x_sh + q];
+    }
+    __syncthreads();
+    const int e = e0 + tid;
+    const int ci = e / KW, k = e - ci * KW;
+    if (ci >= a.Cin) return;
+    const float* xr = xs + (ci - ci0) * xp;
+    float acc[COB];
+#pragma unroll
+    for (int c = 0; c < COB; ++c) acc[c] = 0.f;
+    const int sh = k - a.pw;                          // dW[co][ci][k] pairs dy[ow] with x[ow + k - pw]
+    for (int row = 0; row < rows; ++row) {
         const float* dr = dys + row * a.OW;
-#pragma unroll 4
-        for (int q = 0; q < a.OW; ++q) {
-            const float xv = xr[q];
+        const float* xq = xr + row * a.OW;
+        const int lo = sh < 0 ? -sh : 0, hi = sh > 0 ? a.OW - sh : a.OW;
+        for (int ow = lo; ow < hi; ++ow) {
+            const float xv = xq[ow + sh];
 #pragma unroll
-            for (int k = 0; k < KW; ++k) {
-                const int ow = q - k + a.pw;
-                if (ow >= 0 && ow < a.OW) {
-#pragma unroll
-                    for (int c = 0; c < COB; ++c) acc[c][k] += dr[c * npix + ow] * xv;
-                }
-            }
+            for (int c = 0; c < COB; ++c) acc[c] += dr[c * npix + ow] * xv;
         }
     }
-    float old[COB][KW];
 #pragma unroll
     for (int c = 0; c < COB; ++c)
-#pragma unroll
-        for (int k = 0; k < KW; ++k)
-            old[c][k] = (co0 + c < a.Cout) ? a.dw[((long long)(co0 + c) * a.Cin + ci) * KW + k] : 0.f;
-#pragma unroll
-    for (int c = 0; c < COB; ++c)
-#pragma unroll
-        for (int k = 0; k < KW; ++k)
-            if (co0 + c < a.Cout) a.dw[((long long)(co0 + c) * a.Cin + ci) * KW + k] = old[c][k] + acc[c][k];
+        if (co0 + c < a.Cout) { float* d = a.dw + (long long)(co0 + c) * a.Cin * KW + e; *d += acc[c]; }
 }
 
 // ---- the same, batched over layers (k = 3, trunk layout [C][B][T4], B*T4 <= 128): block -> (job, 4 output channels, 256 input channels)
 struct SmallKBatch { SmallKJob job[MCVC_SMALLK_MAX_JOBS]; int first[MCVC_SMALLK_MAX_JOBS + 1]; int njobs, B, T4; };
 
+constexpr int kSmallKBatchCob = 8;
 __global__ void __launch_bounds__(256) wgrad_smallk_batch_kernel(const Twin<SmallKBatch> tw)
 {
     const SmallKBatch& bt = tw.v[blockIdx.z];
-    constexpr int KW = 3, COB = 4;
-    __shared__ float dys[COB * 128];
+    constexpr int KW = 3, COB = kSmallKBatchCob;
+    extern __shared__ float smk[];
     const int tid = threadIdx.x;
     int j = 0;
     while (j + 1 < bt.njobs && (int)blockIdx.x >= bt.first[j + 1]) ++j;
     const SmallKJob jb = bt.job[j];
     const int local = (int)blockIdx.x - bt.first[j];
-    const int ci_tiles = (jb.Cin + 255) >> 8;
-    const int co0 = (local / ci_tiles) * COB;
-    const int ci = (local % ci_tiles) * 256 + tid;
-    const int npix = bt.B * bt.T4;
+    const int e_tiles = (jb.Cin * KW + 255) >> 8;      // blocks along the (ci, kw) elements of a dW row
+    const int co0 = (local / e_tiles) * COB;
+    const int e0 = (local % e_tiles) * 256;
+    const int B = bt.B, T4 = bt.T4;
+    const int npix = B * T4, xp = npix + 1;
+    float* dys = smk;
+    float* xs = smk + COB * npix;
+    const int ci0 = e0 / KW;
+    int nci = (e0 + 255) / KW - ci0 + 1;
+    if (ci0 + nci > jb.Cin) nci = jb.Cin - ci0;
     for (int i = tid; i < COB * npix; i += 256) {
         const int co = i / npix, p = i - co * npix;
         dys[co * npix + p] = (co0 + co < jb.Cout) ? jb.dy[(long long)(co0 + co) * npix + p] : 0.f;
     }
+    for (int i = tid; i < nci * npix; i += 256) {       // x rows of the block's channels: consecutive addresses (trunk layout [C][B][T4])
+        const int c = i / npix, p = i - c * npix;
+        xs[c * xp + p] = jb.x[(long long)ci0 * npix + i];
+    }
     __syncthreads();
+    const int e = e0 + tid;
+    const int ci = e / KW, k = e - ci * KW;
     if (ci >= jb.Cin) return;
-    float acc[COB][KW];
+    const float* xr = xs + (ci - ci0) * xp;
+    float acc[COB];
 #pragma unroll
-    for (int c = 0; c < COB; ++c)
+    for (int c = 0; c < COB; ++c) acc[c] = 0.f;
+    const int sh = k - 1;
+    for (int b = 0; b < B; ++b) {
+        const float* dr = dys + b * T4;
+        const float* xq = xr + b * T4;
+        const int lo = sh < 0 ? 1 : 0, hi = sh > 0 ? T4 - 1 : T4;
+        for (int ow = lo; ow < hi; ++ow) {
+            const float xv = xq[ow + sh];
 #pragma unroll
-        for (int k = 0; k < KW; ++k) acc[c][k] = 0.f;
-    for (int b = 0; b < bt.B; ++b) {
-        const float* xr = jb.x + (long long)ci * npix + b * bt.T4;
-        const float* dr = dys + b * bt.T4;
-#pragma unroll 4
-        for (int q = 0; q < bt.T4; ++q) {
-            const float xv = xr[q];
-#pragma unroll
-            for (int k = 0; k < KW; ++k) {
-                const int ow = q - k + 1;
-                if (ow >= 0 && ow < bt.T4) {
-#pragma unroll
-                    for (int c = 0; c < COB; ++c) acc[c][k] += dr[c * npix + ow] * xv;
-                }
-            }
+            for (int c = 0; c < COB; ++c) acc[c] += dr[c * npix + ow] * xv;
         }
     }
-    float old[COB][KW];
 #pragma unroll
     for (int c = 0; c < COB; ++c)
-#pragma unroll
-        for (int k = 0; k < KW; ++k)
-            old[c][k] = (co0 + c < jb.Cout) ? jb.dw[((long long)(co0 + c) * jb.Cin + ci) * KW + k] : 0.f;
-#pragma unroll
-    for (int c = 0; c < COB; ++c)
-#pragma unroll
-        for (int k = 0; k < KW; ++k)
-            if (co0 + c < jb.Cout) jb.dw[((long long)(co0 + c) * jb.Cin + ci) * KW + k] = old[c][k] + acc[c][k];
+        if (co0 + c < jb.Cout) { float* d = jb.dw + (long long)(co0 + c) * jb.Cin * KW + e; *d += acc[c]; }
 }
 
 bool mcvc_wgrad_smallk_batch_applies(int B, int T4) { return B >= 1 && T4 >= 1 && (long long)B * T4 <= 128; }
@@ -929,13 +929,14 @@ int mcvc_wgrad_smallk_batch_launch(const SmallKJob* jobs, int njobs, int B, int 
     for (int j = 0; j < njobs; ++j) {
         bt.job[j] = jobs[j];
         bt.first[j] = total;
-        total += cdiv_i(jobs[j].Cout, 4) * cdiv_i(jobs[j].Cin, 256);
+        total += cdiv_i(jobs[j].Cout, kSmallKBatchCob) * cdiv_i(jobs[j].Cin * 3, 256);
         flops += 2.0 * px * jobs[j].Cout * jobs[j].Cin * 3;
         bytes += 4.0 * (2.0 * jobs[j].Cout * jobs[j].Cin * 3 + px * (jobs[j].Cin + jobs[j].Cout));
     }
     bt.first[njobs] = total; bt.njobs = njobs; bt.B = B; bt.T4 = T4;
     TraceScope ts(K_WGRAD_SMALLK, s, flops, bytes);
-    mcvc_launch(wgrad_smallk_batch_kernel, dim3((unsigned)total), dim3(256), 0, s, bt);
+    const size_t lds = (size_t)(kSmallKBatchCob * B * T4 + (256 / 3 + 2) * (B * T4 + 1)) * sizeof(float);
+    mcvc_launch(wgrad_smallk_batch_kernel, dim3((unsigned)total), dim3(256), lds, s, bt);
     return (int)hipGetLastError();
 }
 
@@ -1114,12 +1115,17 @@ int mcvc_wgrad_launch(const ConvProblem& p, int NB, const WgradIO& io, float* dw
         k.x_sb = io.x_sb; k.x_sc = io.x_sc; k.x_sh = io.x_sh;
         k.dy_sb = io.dy_sb; k.dy_sc = io.dy_sc; k.dy_sh = io.dy_sh;
         k.NB = NB; k.Cin = p.Cin; k.Cout = p.Cout; k.OH = p.OH; k.OW = p.OW; k.pw = p.pad_w;
-        constexpr int COB = 4;
-        dim3 grid((unsigned)cdiv_i(p.Cout, COB), (unsigned)cdiv_i(p.Cin, 256));
+        // output channels per workgroup: every workgroup stages the x rows of its 256 (ci, kw) elements, so layers with enough workgroups
+        // (conv1dto2d 5120 x 256, conv2dto1d 256 x 5120) take 16 rows per workgroup instead of 4 (a quarter of the x re-reads)
+        const int COB = (p.KW == 1 && cdiv_i(p.Cout, 16) * cdiv_i(p.Cin, 256) >= 256) ? 16 : 4;
+        dim3 grid((unsigned)cdiv_i(p.Cout, COB), (unsigned)cdiv_i(p.Cin * p.KW, 256));
         const double px = (double)NB * p.OH * p.OW;
         TraceScope ts(K_WGRAD_SMALLK, s, 2.0 * px * p.Cout * p.Cin * p.KW, 4.0 * (2.0 * p.Cout * p.Cin * p.KW + px * (p.Cin + p.Cout)));
-        if (p.KW == 3) mcvc_launch((wgrad_smallk_kernel<3, COB>), grid, dim3(256), 0, s, k);
-        else mcvc_launch((wgrad_smallk_kernel<1, COB>), grid, dim3(256), 0, s, k);
+        const int npix = NB * p.OH * p.OW;
+        const size_t lds = (size_t)(COB * npix + (256 / p.KW + 2) * (npix + 1)) * sizeof(float);       // <= 64 KB at 128 pixels
+        if (p.KW == 3) mcvc_launch((wgrad_smallk_kernel<3, 4>), grid, dim3(256), lds, s, k);
+        else if (COB == 16) mcvc_launch((wgrad_smallk_kernel<1, 16>), grid, dim3(256), lds, s, k);
+        else mcvc_launch((wgrad_smallk_kernel<1, 4>), grid, dim3(256), lds, s, k);
         return (int)hipGetLastError();
     }
     WgradPlan pl;
