@@ -203,10 +203,11 @@ struct Wino4DwKArgs { const float* du; float* dw; int Cout; int Cin; };
 __global__ void __launch_bounds__(256) wino4_dw_kernel(const Twin<Wino4DwKArgs> tw)
 {
     const Wino4DwKArgs a = tw.v[blockIdx.z];
+    __shared__ float wt[256 * 25];               // (coalesced read-modify-write of dW through LDS: see wino_dw_kernel)
     const int ci = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y;
-    if (ci >= a.Cin) return;
+    const bool live = ci < a.Cin;
     const long long xs = (long long)a.Cout * a.Cin;
-    const float* src = a.du + (long long)co * a.Cin + ci;
+    const float* src = a.du + (long long)co * a.Cin + (live ? ci : 0);
     float t[5][8];                               // t[k][b] = sum_a G[a][k] dU[a][b]
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -221,7 +222,6 @@ __global__ void __launch_bounds__(256) wino4_dw_kernel(const Twin<Wino4DwKArgs> 
             t[k][b] = acc;
         }
     }
-    float* dst = a.dw + ((long long)co * a.Cin + ci) * 25;
 #pragma unroll
     for (int k = 0; k < 5; ++k)
 #pragma unroll
@@ -229,8 +229,12 @@ __global__ void __launch_bounds__(256) wino4_dw_kernel(const Twin<Wino4DwKArgs> 
             float acc = 0.f;
 #pragma unroll
             for (int b = 0; b < 8; ++b) acc += t[k][b] * kW4G[b][l];
-            dst[k * 5 + l] += acc;
+            wt[threadIdx.x * 25 + k * 5 + l] = acc;
         }
+    __syncthreads();
+    int nci = a.Cin - (int)blockIdx.x * 256; if (nci > 256) nci = 256;
+    float* dst = a.dw + ((long long)co * a.Cin + (long long)blockIdx.x * 256) * 25;
+    for (int i = threadIdx.x; i < nci * 25; i += 256) dst[i] += wt[i];
 }
 
 }  // namespace

@@ -578,10 +578,13 @@ __global__ void __launch_bounds__(256) wino_dw_kernel(const Twin<WinoDwKArgs> tw
     float* __restrict__ dw = ka_.dw;
     int Cout = ka_.Cout;
     int Cin = ka_.Cin;
+    // (the 25 results of a thread go through LDS so that the read-modify-write of dW -- 256 input channels x 25 taps of one output channel
+    // are 6400 CONSECUTIVE floats -- runs over consecutive addresses instead of 25 accesses at a 100-byte stride per thread)
+    __shared__ float wt[256 * 25];
     const int ci = blockIdx.x * 256 + threadIdx.x, co = blockIdx.y;
-    if (ci >= Cin) return;
+    const bool live = ci < Cin;
     const long long xs = (long long)Cout * Cin;
-    const float* src = du + (long long)co * Cin + ci;
+    const float* src = du + (long long)co * Cin + (live ? ci : 0);
     // G^T (5x6) applied to a 6-vector:  out[k] = sum_a G[a][k] v[a]
     auto gt = [](const float v[6], float o[5]) {
         const float p = v[1] + v[2], m = v[1] - v[2], q = v[3] + v[4], n = v[3] - v[4];
@@ -601,14 +604,17 @@ __global__ void __launch_bounds__(256) wino_dw_kernel(const Twin<WinoDwKArgs> tw
 #pragma unroll
         for (int k = 0; k < 5; ++k) t[k][b] = o[k];
     }
-    float* dst = dw + ((long long)co * Cin + ci) * 25;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         float o[5];
         gt(t[k], o);                          // dg[k][l] = sum_b t[k][b] G[b][l]
 #pragma unroll
-        for (int l = 0; l < 5; ++l) dst[k * 5 + l] += o[l];
+        for (int l = 0; l < 5; ++l) wt[threadIdx.x * 25 + k * 5 + l] = o[l];
     }
+    __syncthreads();
+    int nci = Cin - (int)blockIdx.x * 256; if (nci > 256) nci = 256;
+    float* dst = dw + ((long long)co * Cin + (long long)blockIdx.x * 256) * 25;
+    for (int i = threadIdx.x; i < nci * 25; i += 256) dst[i] += wt[i];
 }
 
 // A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,1]]
