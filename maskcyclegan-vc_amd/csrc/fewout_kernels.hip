@@ -809,7 +809,8 @@ namespace {
 //     Z(h, ci, kh)[kw][co] = sum over w of  x[ci][h + kh - 2][w + kw - 7] * dy[co][h][w]            M = 16, N = 16 channels, K = W
 // A workgroup owns 64 output channels (16 per wave) and walks (sample, band of 4 rows) units; a wave keeps Cin * 5 accumulators.  One B
 // read (dy) serves the Cin * 5 MFMAs of a k block, every A read is 16 consecutive columns of a staged x row.
-constexpr int kW2Band = 4, kW2Co = 64, kW2DyP = kW2Band * 64 + 4;       // dy pitch per channel: 4 banks apart (2-way conflicts at most)
+constexpr int kW2Co = 64;
+template <int BAND> constexpr int kW2DyPitch = BAND * 64 + 4;           // dy pitch per channel: 4 banks apart (2-way conflicts at most)
 constexpr int kW2XP = 84;
 struct W2Args {
     const float* x; long long x_sn, x_sc; int x_sh;
@@ -817,9 +818,10 @@ struct W2Args {
     float* dw;
     int N, Cin, Cout, H, W, bands, units, atomic;
 };
-template <int CI>
+template <int CI, int kW2Band>
 __global__ void __launch_bounds__(256, 2) wgrad_cin2_mfma_kernel(const Twin<W2Args> tw)
 {
+    constexpr int kW2DyP = kW2DyPitch<kW2Band>;
     const W2Args a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* dys = sm;                                      // [64 channels][kW2DyP]: dy[co][h0 + r][w] at r * 64 + w
@@ -938,18 +940,23 @@ int mcvc_wgrad_cin2_launch(const ConvProblem& p, int NB, const WgradIO& io, floa
     W2Args w{};
     w.x = io.x; w.x_sn = io.x_sb; w.x_sc = io.x_sc; w.x_sh = io.x_sh;
     w.dy = io.dy; w.dy_sn = io.dy_sb; w.dy_sc = io.dy_sc; w.dy_sh = io.dy_sh; w.dw = dw;
-    w.N = NB; w.Cin = p.Cin; w.Cout = p.Cout; w.H = p.H; w.W = p.W; w.bands = cdiv_i(p.H, kW2Band); w.units = NB * w.bands;
+    // bands of 4 rows; of 2 rows when that is needed to have a workgroup per CU (one or two samples per pass)
     const int blocks = cdiv_i(p.Cout, kW2Co);
+    const int band = ((long long)blocks * NB * cdiv_i(p.H, 4) < 256) ? 2 : 4;
+    w.N = NB; w.Cin = p.Cin; w.Cout = p.Cout; w.H = p.H; w.W = p.W; w.bands = cdiv_i(p.H, band); w.units = NB * w.bands;
     int nch = 1;
     // (every workgroup ends with 64 x Cin x 75 atomic adds into the same dW block: enough workgroups to fill the chip, not more)
     static const int wgs = [] { const char* e = getenv("MCVC_WGRAD_CIN2_WGS"); return e ? atoi(e) : 512; }();
     if (!mcvc_deterministic())
         while (2 * nch <= w.units && blocks * nch < wgs) nch *= 2;
     w.atomic = nch > 1 ? 1 : 0;
-    const size_t lds = (size_t)(kW2Co * kW2DyP + 2 * (kW2Band + 4) * kW2XP) * sizeof(float);
+    size_t lds = (size_t)(kW2Co * (band * 64 + 4) + 2 * (band + 4) * kW2XP) * sizeof(float);
+    const size_t lds_out = (size_t)kW2Co * p.Cin * 75 * sizeof(float);             // the write-out tile reuses the staging area
+    if (lds < lds_out) lds = lds_out;
     TraceScope ts(K_WGRAD_4x1, s, 2.0 * NB * p.H * p.W * p.Cout * p.Cin * p.KH * p.KW, 4.0 * ((double)NB * p.Cout * p.H * p.W + (double)NB * p.Cin * p.H * p.W));
-    if (p.Cin == 1) mcvc_launch(wgrad_cin2_mfma_kernel<1>, dim3((unsigned)blocks, (unsigned)nch), dim3(256), lds, s, w);
-    else mcvc_launch(wgrad_cin2_mfma_kernel<2>, dim3((unsigned)blocks, (unsigned)nch), dim3(256), lds, s, w);
+    const dim3 grid((unsigned)blocks, (unsigned)nch);
+    if (p.Cin == 1) { if (band == 2) mcvc_launch((wgrad_cin2_mfma_kernel<1, 2>), grid, dim3(256), lds, s, w); else mcvc_launch((wgrad_cin2_mfma_kernel<1, 4>), grid, dim3(256), lds, s, w); }
+    else { if (band == 2) mcvc_launch((wgrad_cin2_mfma_kernel<2, 2>), grid, dim3(256), lds, s, w); else mcvc_launch((wgrad_cin2_mfma_kernel<2, 4>), grid, dim3(256), lds, s, w); }
     return (int)hipGetLastError();
 }
 
