@@ -696,7 +696,8 @@ namespace {
 // v_mfma_f32_16x16x4_f32: lane (m = kw, k) of A reads the zero-padded dy row at w' - kw, lane (k, n = ci) of B reads the staged plane of
 // channel ci.  A workgroup owns 16 channels x a band of 8 rows of one sample; its four waves take two rows each and keep five accumulators
 // (one per kernel row), which are summed through LDS and added to dW (atomics when several workgroups share a channel tile).
-constexpr int kW1Band = 8, kW1Ch = 16, kW1PW = 84, kW1Plane = (kW1Band + 4) * kW1PW + 4;      // (+4: planes 20 banks apart, rows stay 16-byte aligned)
+constexpr int kW1Ch = 16, kW1PW = 84;
+template <int BAND> constexpr int kW1PlaneOf = (BAND + 4) * kW1PW + 4;                      // (+4: planes 20 banks apart, rows stay 16-byte aligned)
 constexpr int kW1DyW = 64 + 32;                                                             // a dy row with 16 zeros on either side
 struct W1Args {
     const float* x; long long x_sn, x_sc; int x_sh;
@@ -704,8 +705,10 @@ struct W1Args {
     float* dw;
     int N, Cin, H, W, bands, units, atomic;
 };
+template <int kW1Band>                                 // rows per (sample, band) unit: 8, or 4 when 8 would leave CUs without a workgroup
 __global__ void __launch_bounds__(256, 2) wgrad_cout1_mfma_kernel(const Twin<W1Args> tw)
 {
+    constexpr int kW1Plane = kW1PlaneOf<kW1Band>;
     const W1Args a = tw.v[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* xs = sm;                                   // [16 channels][kW1Plane]: rows h0-2 .. h0+band+1, image column c at LDS column c + 8
@@ -753,8 +756,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_cout1_mfma_kernel(const Twin<W1A
         }
         __syncthreads();
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int r = 2 * wave + rr;                               // output row h0 + r
+        for (int rr = 0; rr < kW1Band / 4; ++rr) {
+            const int r = (kW1Band / 4) * wave + rr;                   // output row h0 + r
             // A[m = ln][k]: dy[h][w' - 7 - m + 7 ... ]: with w' = 4 kb + kq the image column of x is w' - 7, and the tap kw = m pairs it with
             // dy column (w' - 7) - (m - 7) = w' - m: LDS column w' - m + 16
             const float* dr = dys + r * kW1DyW + 16 - ln + kq;
@@ -984,15 +987,17 @@ int mcvc_wgrad_cout1_launch(const ConvProblem& p, int NB, const WgradIO& io, flo
         (io.dy_sh & 3) == 0 && (io.dy_sb & 3) == 0 && ((reinterpret_cast<unsigned long long>(io.x) | reinterpret_cast<unsigned long long>(io.dy)) & 15ull) == 0) {
         W1Args w{};
         w.x = io.x; w.x_sn = io.x_sb; w.x_sc = io.x_sc; w.x_sh = io.x_sh; w.dy = io.dy; w.dy_sn = io.dy_sb; w.dy_sh = io.dy_sh; w.dw = dw;
-        w.N = NB; w.Cin = p.Cin; w.H = p.H; w.W = p.W; w.bands = cdiv_i(p.H, kW1Band); w.units = NB * w.bands;
         const int tiles = cdiv_i(p.Cin, kW1Ch);
+        const int band = ((long long)tiles * NB * cdiv_i(p.H, 8) < 256) ? 4 : 8;
+        w.N = NB; w.Cin = p.Cin; w.H = p.H; w.W = p.W; w.bands = cdiv_i(p.H, band); w.units = NB * w.bands;
         int nch = 1;
         if (!mcvc_deterministic())
             while (2 * nch <= w.units && tiles * nch < 1024) nch *= 2;
         w.atomic = nch > 1 ? 1 : 0;
-        const size_t lds1 = (size_t)(kW1Ch * kW1Plane + kW1Band * kW1DyW) * sizeof(float);
+        const size_t lds1 = (size_t)(kW1Ch * ((band + 4) * kW1PW + 4) + band * kW1DyW) * sizeof(float);        // >= the 4 x 5 x 16 x 16 reduction tile
         TraceScope ts(K_WGRAD_SMALLK, s, 2.0 * NB * p.H * p.W * p.Cin * p.KH * p.KW, 4.0 * ((double)NB * p.Cin * p.H * p.W + (double)NB * p.H * p.W * p.Cin));
-        mcvc_launch(wgrad_cout1_mfma_kernel, dim3((unsigned)tiles, (unsigned)nch), dim3(256), lds1, s, w);
+        if (band == 4) mcvc_launch(wgrad_cout1_mfma_kernel<4>, dim3((unsigned)tiles, (unsigned)nch), dim3(256), lds1, s, w);
+        else mcvc_launch(wgrad_cout1_mfma_kernel<8>, dim3((unsigned)tiles, (unsigned)nch), dim3(256), lds1, s, w);
         return (int)hipGetLastError();
     }
     int nchunk = 1;
