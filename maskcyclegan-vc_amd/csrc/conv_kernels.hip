@@ -831,11 +831,23 @@ __global__ void __launch_bounds__(256) wgrad_smallk_kernel(const Twin<SmallKArgs
         const int cg = co0 + co;
         dys[co * npix + p] = (cg < a.Cout) ? a.dy[(long long)n * a.dy_sb + (long long)cg * a.dy_sc + (long long)oh * a.dy_sh + ow] : 0.f;
     }
-    for (int i = tid; i < nci * npix; i += 256) {
-        const int c = i / npix, p = i - c * npix;
-        const int row = p / a.OW, q = p - row * a.OW;
-        const int n = row / a.OH, oh = row - n * a.OH;
-        xs[c * xp + p] = a.x[(long long)n * a.x_sb + (long long)(ci0 + c) * a.x_sc + (long long)oh * a.x_sh + q];
+    // (eight loads in flight per thread before the first LDS store: a plain load -> store loop is one global round trip per iteration)
+    for (int i0 = tid; i0 < nci * npix; i0 += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            const int c = i / npix, p = i - c * npix;
+            const int row = p / a.OW, q = p - row * a.OW;
+            const int n = row / a.OH, oh = row - n * a.OH;
+            v[u] = (i < nci * npix) ? a.x[(long long)n * a.x_sb + (long long)(ci0 + c) * a.x_sc + (long long)oh * a.x_sh + q] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            const int c = i / npix, p = i - c * npix;
+            if (i < nci * npix) xs[c * xp + p] = v[u];
+        }
     }
     __syncthreads();
     const int e = e0 + tid;
@@ -856,9 +868,14 @@ __global__ void __launch_bounds__(256) wgrad_smallk_kernel(const Twin<SmallKArgs
             for (int c = 0; c < COB; ++c) acc[c] += dr[c * npix + ow] * xv;
         }
     }
+    // read-modify-write of the COB rows: all loads first (written as `*d += acc` the compiler keeps the rows' round trips in sequence:
+    // it cannot prove that the stores do not alias the next row's load)
+    float old[COB];
+#pragma unroll
+    for (int c = 0; c < COB; ++c) old[c] = (co0 + c < a.Cout) ? a.dw[(long long)(co0 + c) * a.Cin * KW + e] : 0.f;
 #pragma unroll
     for (int c = 0; c < COB; ++c)
-        if (co0 + c < a.Cout) { float* d = a.dw + (long long)(co0 + c) * a.Cin * KW + e; *d += acc[c]; }
+        if (co0 + c < a.Cout) a.dw[(long long)(co0 + c) * a.Cin * KW + e] = old[c] + acc[c];
 }
 
 // ---- the same, batched over layers (k = 3, trunk layout [C][B][T4], B*T4 <= 128): block -> (job, 4 output channels, 256 input channels)
@@ -889,9 +906,16 @@ __global__ void __launch_bounds__(256) wgrad_smallk_batch_kernel(const Twin<Smal
         const int co = i / npix, p = i - co * npix;
         dys[co * npix + p] = (co0 + co < jb.Cout) ? jb.dy[(long long)(co0 + co) * npix + p] : 0.f;
     }
-    for (int i = tid; i < nci * npix; i += 256) {       // x rows of the block's channels: consecutive addresses (trunk layout [C][B][T4])
-        const int c = i / npix, p = i - c * npix;
-        xs[c * xp + p] = jb.x[(long long)ci0 * npix + i];
+    for (int i0 = tid; i0 < nci * npix; i0 += 8 * 256) {   // x rows of the block's channels: consecutive addresses (trunk layout [C][B][T4])
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; v[u] = (i < nci * npix) ? jb.x[(long long)ci0 * npix + i] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            const int c = i / npix, p = i - c * npix;
+            if (i < nci * npix) xs[c * xp + p] = v[u];
+        }
     }
     __syncthreads();
     const int e = e0 + tid;
@@ -912,9 +936,12 @@ __global__ void __launch_bounds__(256) wgrad_smallk_batch_kernel(const Twin<Smal
             for (int c = 0; c < COB; ++c) acc[c] += dr[c * npix + ow] * xv;
         }
     }
+    float old[COB];                                   // (all loads of the read-modify-write first: see wgrad_smallk_kernel)
+#pragma unroll
+    for (int c = 0; c < COB; ++c) old[c] = (co0 + c < jb.Cout) ? jb.dw[(long long)(co0 + c) * jb.Cin * KW + e] : 0.f;
 #pragma unroll
     for (int c = 0; c < COB; ++c)
-        if (co0 + c < jb.Cout) { float* d = jb.dw + (long long)(co0 + c) * jb.Cin * KW + e; *d += acc[c]; }
+        if (co0 + c < jb.Cout) jb.dw[(long long)(co0 + c) * jb.Cin * KW + e] = old[c] + acc[c];
 }
 
 bool mcvc_wgrad_smallk_batch_applies(int B, int T4) { return B >= 1 && T4 >= 1 && (long long)B * T4 <= 128; }
