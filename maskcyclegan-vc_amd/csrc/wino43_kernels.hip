@@ -243,18 +243,24 @@ __global__ void __launch_bounds__(256) wino43_dw_kernel(const Twin<W43DwKArgs> t
     const int col = (co < Cout) ? co : co - Cout;
     if (!dw) return;
     float* dst = dw + ((long long)col * Cin + ci) * 25;
+    // (the nine read-modify-writes: all loads before the first store -- written as `dst[..] += o` they run as nine sequential round trips)
+    float r[3][3], old[3][3];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        float o[3];
-        gt(t[u], o);
-        const int kh = 2 * u + p;
-        if (kh > 4) continue;
+    for (int u = 0; u < 3; ++u) gt(t[u], r[u]);
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
-            const int kw = 2 * v + q;
-            if (kw <= 4) dst[kh * 5 + kw] += o[v];
+            const int kh = 2 * u + p, kw = 2 * v + q;
+            old[u][v] = (kh <= 4 && kw <= 4) ? dst[kh * 5 + kw] : 0.f;
         }
-    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int kh = 2 * u + p, kw = 2 * v + q;
+            if (kh <= 4 && kw <= 4) dst[kh * 5 + kw] = old[u][v] + r[u][v];
+        }
 }
 
 }  // namespace

@@ -234,7 +234,11 @@ __global__ void __launch_bounds__(256) wino4_dw_kernel(const Twin<Wino4DwKArgs> 
     __syncthreads();
     int nci = a.Cin - (int)blockIdx.x * 256; if (nci > 256) nci = 256;
     float* dst = a.dw + ((long long)co * a.Cin + (long long)blockIdx.x * 256) * 25;
-    for (int i = threadIdx.x; i < nci * 25; i += 256) dst[i] += wt[i];
+    float old[25];                               // (all loads of the read-modify-write before the first store)
+#pragma unroll
+    for (int u = 0; u < 25; ++u) { const int i = threadIdx.x + u * 256; old[u] = (i < nci * 25) ? dst[i] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 25; ++u) { const int i = threadIdx.x + u * 256; if (i < nci * 25) dst[i] = old[u] + wt[i]; }
 }
 
 }  // namespace

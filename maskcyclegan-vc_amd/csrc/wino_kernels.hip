@@ -273,18 +273,24 @@ __global__ void __launch_bounds__(256) wino3_dw_kernel(const Twin<Wino3DwKArgs> 
     const int col = (co < Cout) ? co : co - Cout;
     if (!dw) return;
     float* dst = dw + ((long long)col * Cin + ci) * 25;
+    // (the nine read-modify-writes: all loads before the first store -- written as `dst[..] += o` they run as nine sequential round trips)
+    float r[3][3], old[3][3];
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        float o[3];
-        gt3(t[u], o);
-        const int kh = 2 * u + p;
-        if (kh > 4) continue;
+    for (int u = 0; u < 3; ++u) gt3(t[u], r[u]);
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
 #pragma unroll
         for (int v = 0; v < 3; ++v) {
-            const int kw = 2 * v + q;
-            if (kw <= 4) dst[kh * 5 + kw] += o[v];
+            const int kh = 2 * u + p, kw = 2 * v + q;
+            old[u][v] = (kh <= 4 && kw <= 4) ? dst[kh * 5 + kw] : 0.f;
         }
-    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const int kh = 2 * u + p, kw = 2 * v + q;
+            if (kh <= 4 && kw <= 4) dst[kh * 5 + kw] = old[u][v] + r[u][v];
+        }
 }
 
 __global__ void __launch_bounds__(256) wino3_output_kernel(const Twin<WinoOutArgs> tw)
@@ -614,7 +620,11 @@ __global__ void __launch_bounds__(256) wino_dw_kernel(const Twin<WinoDwKArgs> tw
     __syncthreads();
     int nci = Cin - (int)blockIdx.x * 256; if (nci > 256) nci = 256;
     float* dst = dw + ((long long)co * Cin + (long long)blockIdx.x * 256) * 25;
-    for (int i = threadIdx.x; i < nci * 25; i += 256) dst[i] += wt[i];
+    float old[25];                               // (all loads of the read-modify-write before the first store)
+#pragma unroll
+    for (int u = 0; u < 25; ++u) { const int i = threadIdx.x + u * 256; old[u] = (i < nci * 25) ? dst[i] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 25; ++u) { const int i = threadIdx.x + u * 256; if (i < nci * 25) dst[i] = old[u] + wt[i]; }
 }
 
 // A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,1]]
