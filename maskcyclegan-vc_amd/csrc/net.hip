@@ -754,10 +754,19 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         SGemmArgs g{};
         g.a = dyt; g.lda = c.cout_tot;                                        // dYt[n][co]
         g.b = xt; g.ldb = KT; g.bseg = KT; g.b_sn = 0;                        // XcolT[n][k]
-        g.c = slabs; g.ldc = KT; g.cseg = KT; g.c_sn = 0; g.c_split = (long long)c.cout_tot * KT; g.c_slab = slabs + g.c_split;
         g.M = c.cout_tot; g.N = KT; g.K = (int)sg_rows; g.nsplit = sg_split;
-        ex.fail(mcvc_sgemm_launch(g, ws));
-        ex.fail(mcvc_dw_accum_launch(slabs, sg_split, g.c_split, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.cout_tot, KT, ws));
+        static const int direct = [] { const char* e = getenv("MCVC_SGEMM_WGRAD_DIRECT"); return e ? atoi(e) : 1; }();
+        if (sg_split == 1 && direct && (c.Cout & 31) == 0) {
+            // no K split: the product is added straight into the OIHW gradients (rows [0, Cout) -> the value tensor, the rest -> the gate
+            // tensor) instead of a slab + dw_accum: a quarter of the dW-sized traffic of the deep layers and one launch less
+            g.c = grads[c.wi[0]]; g.ldc = KT; g.cseg = KT; g.c_sn = 0; g.accumulate = 1;
+            if (c.nbr == 2) { g.c2 = grads[c.wi[1]]; g.m_split = c.Cout; }
+            ex.fail(mcvc_sgemm_launch(g, ws));
+        } else {
+            g.c = slabs; g.ldc = KT; g.cseg = KT; g.c_sn = 0; g.c_split = (long long)c.cout_tot * KT; g.c_slab = slabs + g.c_split;
+            ex.fail(mcvc_sgemm_launch(g, ws));
+            ex.fail(mcvc_dw_accum_launch(slabs, sg_split, g.c_split, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.cout_tot, KT, ws));
+        }
         done = true;
     }
     if (!done && wino_enabled() && ex.wu && c.nbr == 1 && grads[c.wi[0]] && wino4_applies(ex, c, NB, H, W) && (c.Cout % 128) == 0 && (c.Cin % 64) == 0 &&

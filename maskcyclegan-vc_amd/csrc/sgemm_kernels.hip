@@ -112,11 +112,15 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const Twin<SGemmArgs> tw)
             float bv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) bv[r] = bias ? bias[mb + (r & 3) + 8 * (r >> 2)] : 0.f;
+            if (accumulate) {                    // (all 16 loads of the read-modify-write before the first store)
+                float old[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float* dst = row0 + (long long)((r & 3) + 8 * (r >> 2)) * ldc;
-                const float v = acc[r] + bv[r];
-                *dst = accumulate ? *dst + v : v;
+                for (int r = 0; r < 16; ++r) old[r] = row0[(long long)((r & 3) + 8 * (r >> 2)) * ldc];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) row0[(long long)((r & 3) + 8 * (r >> 2)) * ldc] = old[r] + acc[r] + bv[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) row0[(long long)((r & 3) + 8 * (r >> 2)) * ldc] = acc[r] + bv[r];
             }
         }
     }
