@@ -31,6 +31,9 @@ ALG_GFLOP_PER_SAMPLE_ITER = 504.1      # necessary conv 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, exact fp32
 PEAK_BF16_MFMA_TFLOPS = 2500.0         # dense (the 5 PF headline figure includes 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
+# algorithmic bytes of one iteration (weights + conv / norm activation traffic of the necessary passes) + Adam's
+# 2.07 GB (7 words x 73.9 M live parameters), at the tabulated batch sizes
+ALG_BYTES_PER_ITER = {1: 4.9e9 + 2.07e9, 8: 18.4e9 + 2.07e9, 32: 64.7e9 + 2.07e9}
 INFER_GFLOP_PER_SAMPLE_64 = 19.676     # generator forward, conv MAC*2, per sample of 64 frames
 
 
@@ -93,26 +96,35 @@ def pmc_traffic(kernel, B):
     return None, None
 
 
-def trace_one_step(engine, batch):
+def trace_one_step(engine, batches):
+    """Per-launch HIP-event trace of ONE iteration of the schedule that was timed, submitted in order on one stream (kernels do not
+    overlap, so every launch's duration is its own).  With the pipelined step an iteration's worth of work is the discriminator phase of
+    iteration t + the generator phase of iteration t+1: one untraced step leaves a pending discriminator phase, the next step is traced.
+    Returns (rows per kernel family, raw per-launch list of (kernel, ms, flops, bytes))."""
     from mask_cyclegan_vc import _hip
     L = _hip.lib()
-    nk = L.mcvc_trace_kinds()
-    buf = (ctypes.c_double * (4 * nk))()
+    cap = 16384
+    buf = (ctypes.c_double * (4 * cap))()
     torch.cuda.synchronize()
-    was = (engine.concurrent, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs)
-    engine.concurrent = engine.use_graphs = engine.aux_wgrad = engine.pass_graphs = False   # per-kernel durations need non-overlapping eager launches
+    was = (engine._serial, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs)
+    engine._serial, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs = True, False, False, False
+    engine.step(*batches[0])
+    torch.cuda.synchronize()
     L.mcvc_trace_enable(1)
-    engine.step(*batch)
-    L.mcvc_trace_collect(buf)
+    engine.step(*batches[1 % len(batches)])
+    if engine._pending_D is None:              # (schedules without a pending phase: the step above was a whole iteration)
+        pass
+    n = L.mcvc_trace_collect_raw(buf, cap)
     L.mcvc_trace_enable(0)
-    engine.concurrent, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs = was
-    rows = []
-    for k in range(nk):
-        n, ms, fl, by = buf[4 * k:4 * k + 4]
-        if n > 0:
-            rows.append({"kernel": L.mcvc_trace_kind_name(k).decode(), "launches": int(n), "ms": ms, "gflop": fl / 1e9, "mbytes": by / 1e6})
-    rows.sort(key=lambda r: -r["ms"])
-    return rows
+    engine.flush()
+    engine._serial, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs = was
+    raw = [(L.mcvc_trace_kind_name(int(buf[4 * i])).decode(), buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]) for i in range(n)]
+    fam = {}
+    for k, ms, fl, by in raw:
+        r = fam.setdefault(k, {"kernel": k, "launches": 0, "ms": 0.0, "gflop": 0.0, "mbytes": 0.0})
+        r["launches"] += 1; r["ms"] += ms; r["gflop"] += fl / 1e9; r["mbytes"] += by / 1e6
+    rows = sorted(fam.values(), key=lambda r: -r["ms"])
+    return rows, raw
 
 
 def cpu_baseline(B, T, n_timed, first_losses, threads=0, warm=True):
@@ -289,7 +301,8 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
     import contextlib
     run_ctx = torch.cuda.stream(torch.cuda.Stream(device=device)) if os.environ.get("MCVC_BENCH_STREAM") == "1" else contextlib.nullcontext()
     run_ctx.__enter__()                    # (before the engine is built: its lanes are chosen against the stream it will be called on)
-    engine = TrainEngine(nets, B, T, schedule=sched, reducer=FlatGradReducer())
+    reducer = FlatGradReducer()
+    engine = TrainEngine(nets, B, T, schedule=sched, reducer=reducer)
     engine.concurrent = not args.serial
     if args.serial:
         engine.aux_wgrad = False          # truly one stream: per-kernel durations comparable with the traced step's
@@ -312,6 +325,7 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
         dist.barrier()
     torch.cuda.synchronize()
     log("timing %d steps" % steps)
+    reducer.time_waits = world > 1         # exposed (un-hidden) gradient-exchange time: an event pair around every wait for the communication stream
     t0 = time.perf_counter()
     for i in range(steps):
         engine.step(*batches[(warmup + i) % len(batches)])
@@ -330,28 +344,23 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
 
     run_ctx.__exit__(None, None, None)
     log("timed region done: %.2f ms/step" % (1e3 * dt / steps))
+    reducer.time_waits = False
+    exposed_ms, n_waits = reducer.exposed_ms()
+    if world > 1:
+        t = torch.tensor([exposed_ms], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exposed_ms = float(t.item())
     engine.check_faults()
     final = engine.losses()
     finite = all(np.isfinite(v) for v in final.values())
-    rows = [] if args.no_trace else trace_one_step(engine, batches[0])
-    if args.dump_trace and rank == 0 and config_id is None:
-        from mask_cyclegan_vc import _hip
-        L = _hip.lib()
-        buf = (ctypes.c_double * (4 * 8192))()
-        torch.cuda.synchronize()
-        was = (engine.concurrent, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs)
-        engine.concurrent = engine.use_graphs = engine.aux_wgrad = engine.pass_graphs = False
-        L.mcvc_trace_enable(1)
-        engine.step(*batches[0])
-        n = L.mcvc_trace_collect_raw(buf, 8192)
-        L.mcvc_trace_enable(0)
-        engine.concurrent, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs = was
+    rows, raw = ([], []) if args.no_trace else trace_one_step(engine, batches)
+    if args.dump_trace and rank == 0 and config_id is None and raw:
         with open(args.dump_trace, "w") as fh:
-            for i in range(n):
-                k, ms, fl, by = buf[4 * i:4 * i + 4]
+            for i, (k, ms, fl, by) in enumerate(raw):
                 fh.write("%4d %-24s %9.4f ms %10.4f GF %9.3f MB %8.2f TF/s %8.1f GB/s\n" % (
-                    i, L.mcvc_trace_kind_name(int(k)).decode(), ms, fl / 1e9, by / 1e6, fl / 1e9 / max(ms, 1e-6), by / 1e6 / max(ms, 1e-6)))
-    schedule = {"grouped_launches": bool(engine._use_grouped()), "pipelined": bool(engine._use_pipeline()), "queue_probe": getattr(engine, "queue_probe", None),
+                    i, k, ms, fl / 1e9, by / 1e6, fl / 1e9 / max(ms, 1e-6), by / 1e6 / max(ms, 1e-6)))
+    schedule = {"grouped_launches": bool(engine._use_grouped()), "pipelined": bool(engine._use_pipeline()), "merged_forwards": bool(engine._use_merged()),
+                "queue_probe": getattr(engine, "queue_probe", None),
                 "loss_readback": "both losses every iteration; with the pipelined step those of the last complete iteration (one step behind)"}
     del engine, nets
     torch.cuda.empty_cache()
@@ -370,6 +379,7 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
                    "global_batch": world * B, "parallelism": "dp%d" % world},
         "mel_frames_per_s": sample_iters * T,
         "step_mfma_fraction": sample_iters * ALG_GFLOP_PER_SAMPLE_ITER / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world),
+        "exposed_comm_ms_per_step": (exposed_ms / steps) if world > 1 else 0.0, "comm_waits_per_step": n_waits / steps,
         "losses_finite": finite, "last_losses": final, "schedule": schedule, "n_batches": len(batches), "deterministic": bool(args.deterministic),
     }
     if config_id:
@@ -393,6 +403,16 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
         res["executed_gflop_per_sample_iter"] = round(sum(r["gflop"] for r in conv) / B, 1)
         res["algorithmic_gflop_per_sample_iter"] = ALG_GFLOP_PER_SAMPLE_ITER
         res["step_executed_mfma_fraction"] = sum(r["gflop"] for r in conv) / ms / PEAK_FP32_MFMA_TFLOPS
+        # SURVEY 8(d) "conv-roofline time" of the step AS EXECUTED: every launch is bound by the matrix pipe or by HBM, whichever is slower
+        # for the FLOPs it executes (Winograd products count their own multiplies, not the direct convolution's) and the bytes its launcher
+        # counts (operands + results incl. the Winograd-domain U / V / M tensors, slabs, packed copies): sum over launches of
+        # max(FLOPs / 157.3 TF/s, bytes / 8 TB/s).  frac_of_conv_roofline = that floor / the measured step time.
+        roof_ms = sum(max(fl / (PEAK_FP32_MFMA_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)) for _k, _ms, fl, by in raw) * 1e3
+        res["conv_roofline_ms"] = round(roof_ms, 4)
+        res["frac_of_conv_roofline"] = roof_ms / ms
+        res["hbm_bytes_per_step"] = sum(by for _k, _ms, _fl, by in raw)           # launcher-counted
+        res["algorithmic_bytes_per_step"] = ALG_BYTES_PER_ITER.get(B)            # SURVEY 8(d) lower bound incl. Adam (None: not tabulated)
+        res["serial_kernel_ms_per_step"] = round(total_ms, 4)
     log("trace done")
     if world == 1 and cpu_iters > 0:
         cb, parity = cpu_baseline(B, T, cpu_iters, first, args.cpu_threads, warm=cpu_warm)

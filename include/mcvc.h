@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MCVC_ABI_VERSION 1
+#define MCVC_ABI_VERSION 2          /* r4: + mcvc_gen_backward_prefix, mcvc_set_trunk_passes_in_flight, op-level Winograd / staged-GEMM / trunk entries */
 #define MCVC_GEN_NPARAMS 110
 #define MCVC_DISC_NPARAMS 20
 #define MCVC_N_MEL 80
@@ -140,6 +140,27 @@ int mcvc_gen_backward_flags(const float* const* params, const float* packed, flo
                             const float* dout, float* dx, int accumulate_dx, const float* stash,
                             float* scratch, long long scratch_floats, int B, int T, void* stream, void* aux_stream,
                             void* const* milestones, int flags);
+/*      Backward over a PREFIX of a forward pass's samples (r4).  `stash` was written by mcvc_gen_forward with batch stash_B >= B; the pass
+ *      back-propagates through its first B samples only (mask / dout / dx hold B samples; scratch is sized for B).  The trainer batches
+ *      the discriminator phase's generator forwards of iteration t (train.py:259-273: outputs only, their backward is discarded) into the
+ *      generator phase's forwards of iteration t+1 (train.py:203-210: same weights), so those passes run over 3 (2) samples and their
+ *      backward over the first 2 (1).  The 2-D stash tensors are batch-major; the 1-D trunk's are [C][stash_B][T/4] and are read with that
+ *      channel pitch.  stash_B == B is mcvc_gen_backward_flags.                                                                      */
+int mcvc_gen_backward_prefix(const float* const* params, const float* packed, float* const* grads, const float* mask,
+                             const float* dout, float* dx, int accumulate_dx, const float* stash, int stash_B,
+                             float* scratch, long long scratch_floats, int B, int T, void* stream, void* aux_stream,
+                             void* const* milestones, int flags);
+/*      ... over the WINDOW [stash_b0, stash_b0 + B) of the forward pass's samples (stash_b0 * T/4 must be a multiple of 4).  The trainer
+ *      back-propagates the identity sample of a merged pass (train.py:223-224: depends on nothing but its own forward) while the
+ *      discriminators of the cycle chain are still running, and the translation sample -- the window [1, 2) -- at the end of the chain.  */
+int mcvc_gen_backward_window(const float* const* params, const float* packed, float* const* grads, const float* mask,
+                             const float* dout, float* dx, int accumulate_dx, const float* stash, int stash_B, int stash_b0,
+                             float* scratch, long long scratch_floats, int B, int T, void* stream, void* aux_stream,
+                             void* const* milestones, int flags);
+/*      Number of persistent trunk passes the caller keeps in flight at once (a grouped launch counts as two; default 2).  The persistent
+ *      kernels' 64 workgroups per pass wait for each other inside the kernel, so all of them must be resident: they are used only while
+ *      64 x that number <= the device's compute units, otherwise the passes fall back to per-layer launches.  Returns the previous value. */
+int mcvc_set_trunk_passes_in_flight(int n);
 
 /* ---- Generator inference in bf16 (BASELINE configs[4]: generator_A2B, bs=16, 80 x 512 frames).  Replaces the call
  *      `generator(real, ones_like(real))` of the reference's inference driver (mask_cyclegan_vc/test.py:92, 107 ->

@@ -906,10 +906,15 @@ __global__ void __launch_bounds__(256) wgrad_smallk_batch_kernel(const Twin<Smal
         const int co = i / npix, p = i - co * npix;
         dys[co * npix + p] = (co0 + co < jb.Cout) ? jb.dy[(long long)(co0 + co) * npix + p] : 0.f;
     }
+    const int xpitch = (jb.xB > B ? jb.xB : B) * T4;       // (a prefix of a larger forward pass's samples: the channel pitch is that pass's)
     for (int i0 = tid; i0 < nci * npix; i0 += 8 * 256) {   // x rows of the block's channels: consecutive addresses (trunk layout [C][B][T4])
         float v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; v[u] = (i < nci * npix) ? jb.x[(long long)ci0 * npix + i] : 0.f; }
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            const int c = i / npix, p = i - c * npix;
+            v[u] = (i < nci * npix) ? jb.x[(long long)(ci0 + c) * xpitch + p] : 0.f;
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = i0 + u * 256;

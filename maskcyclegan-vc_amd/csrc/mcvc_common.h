@@ -206,7 +206,7 @@ long long mcvc_wgrad_plan_slab_floats(const ConvProblem& p, int NB);
 
 // Batched small-K weight gradients (1-D trunk at small batch): all of a backward pass's trunk layers in ONE launch.
 // Every job is dW[co][ci][kw] += sum_{b,t} dY[co][b][t] * X[ci][b][t + kw - 1]  with dY, X in trunk layout [C][B][T4].
-struct SmallKJob { const float* x; const float* dy; float* dw; int Cin, Cout; };
+struct SmallKJob { const float* x; const float* dy; float* dw; int Cin, Cout; int xB; };   // xB: samples per channel of x (0 = B)
 #define MCVC_SMALLK_MAX_JOBS 24
 int mcvc_wgrad_smallk_batch_launch(const SmallKJob* jobs, int njobs, int B, int T4, hipStream_t s);
 bool mcvc_wgrad_smallk_batch_applies(int B, int T4);

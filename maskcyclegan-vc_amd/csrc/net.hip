@@ -1117,6 +1117,7 @@ struct TrunkPre {              // fused InstanceNorm backward in front of the da
     const float* g0; const float* b0; const float* g1; const float* b1;
     float* out;                // X' = gradient w.r.t. the conv output (the weight gradient reads it)
     float* dg0; float* db0; float* dg1; float* db1;
+    int xB;                    // samples per channel of x (0 = the pass's batch; larger: backward over a prefix of the forward pass's samples)
 };
 
 static bool trunk_dgrad(Exec& ex, const ConvSpec& c, const float* packed, const float* dy, float* dx, int accumulate, int B, int W4,
@@ -1146,7 +1147,7 @@ static bool trunk_dgrad(Exec& ex, const ConvSpec& c, const float* packed, const 
     a.slabs = ex.slabs; a.slab_stride = tot; a.slab_all = slab_all ? 1 : 0;
     if (pre) {
         a.pre = pre->kind; a.pre_C = (pre->kind == 2) ? c.cout_tot / 2 : c.cout_tot;
-        a.pre_x = pre->x; a.pre_stats = pre->stats; a.pre_gamma0 = pre->g0; a.pre_beta0 = pre->b0; a.pre_gamma1 = pre->g1; a.pre_beta1 = pre->b1;
+        a.pre_x = pre->x; a.pre_xB = pre->xB; a.pre_stats = pre->stats; a.pre_gamma0 = pre->g0; a.pre_beta0 = pre->b0; a.pre_gamma1 = pre->g1; a.pre_beta1 = pre->b1;
         a.pre_out = pre->out; a.pre_dgamma0 = pre->dg0; a.pre_dbeta0 = pre->db0; a.pre_dgamma1 = pre->dg1; a.pre_dbeta1 = pre->db1;
         wait_readers(ex, pre->out);
     }
@@ -1472,16 +1473,45 @@ static void record_milestone(Exec& ex, void* ev)
     ex.fail(mcvc_event_record((hipEvent_t)ev, on));
 }
 
+// sample b0 of every stash tensor becomes sample 0: batch-major tensors move by b0 samples, the trunk-layout ones ([C][stash_B][W4]) by b0 rows
+static void shift_stash(GenStash& s, const GenDims& d, int b0)
+{
+    if (b0 <= 0) return;
+    const long long b = b0, T = d.T, W2 = d.W2, W4 = d.W4;
+    s.xin += b * 2 * 80 * T; s.c1 += b * 256 * 80 * T; s.y1 += b * 128 * 80 * T;
+    s.c2 += b * 512 * 40 * W2; s.s2 += b * 512 * 2; s.y2 += b * 256 * 40 * W2;
+    s.c3 += b * 512 * 20 * W4; s.s3 += b * 512 * 2; s.y3 += b * W4;
+    s.c4 += b * W4; s.s4 += b * 256 * 2; s.y4 += b * W4;
+    for (int i = 0; i < 6; ++i) {
+        s.r[i].ca += b * W4; s.r[i].sa += b * 1024 * 2; s.r[i].ya += b * W4;
+        s.r[i].cb += b * W4; s.r[i].sb += b * 256 * 2; s.r[i].y += b * W4;
+    }
+    s.c6 += b * W4; s.s6 += b * 5120 * 2; s.y6 += b * 5120 * W4;
+    s.c7 += b * 256 * 40 * d.Wu1; s.s7 += b * 256 * 2; s.y7 += b * 256 * 40 * d.Wu1;
+    s.c8 += b * 128 * 80 * d.Wu2; s.s8 += b * 128 * 2; s.y8 += b * 128 * 80 * d.Wu2;
+}
+
+// `stash_B` > B: the stash was written by a forward pass over stash_B samples and this pass back-propagates through its samples
+// [stash_b0, stash_b0 + B) only (the trainer's merged forwards: train.py:203-210 of iteration t+1 batched with :259-273 of iteration t, which
+// need no gradient; and the identity sample's backward, which depends on nothing but its own forward, ahead of the others').  The 2-D
+// tensors of the stash are batch-major, so a window is a pointer offset; the 1-D trunk's are [C][stash_B][W4]: their channel pitch is SBT4.
 static void gen_backward_impl(Exec& ex, const float* const* P, const float* packed, float* const* G, const float* mask, const float* dout,
-                              float* dx, int accumulate_dx, const float* stc, float* sc, const GenDims& d, void* const* milestones = nullptr)
+                              float* dx, int accumulate_dx, const float* stc, float* sc, const GenDims& d, void* const* milestones = nullptr,
+                              int stash_B = 0, int stash_b0 = 0)
 {
     ex.params = P;
     const GenNet& g = gen_net();
-    const GenStash o = gen_stash(d);
+    if (stash_B < d.B) stash_B = d.B;
+    GenStash o = gen_stash(gen_dims(stash_B, d.T));
+    shift_stash(o, d, stash_b0);
     const GenScratch q = gen_scratch(d);
     float* st = const_cast<float*>(stc);     // stash is read-only here; kernels take non-const for slab-reduce paths that are not used on it
     const int B = d.B, T = d.T, W2 = d.W2, W4 = d.W4, Wu1 = d.Wu1, Wu2 = d.Wu2;
     const long long BT4 = (long long)B * W4;
+    const long long SBT4 = (long long)stash_B * W4;
+    const int pxB = stash_B > B ? stash_B : 0;
+    // (float4 paths of the trunk kernels need 16-byte aligned rows: a window that starts at an odd multiple of W4 < 4 floats would not be)
+    if (stash_b0 > 0 && (((long long)stash_b0 * W4) & 3)) { ex.fail(MCVC_ERR_INVALID); return; }
     // dY buffers alternate between two copies so an aux-stream weight gradient can still read layer k's dY while the
     // main stream already produces layer k-1's
     float* GA = sc + q.ga;
@@ -1526,12 +1556,12 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
     if (milestones) record_milestone(ex, milestones[0]);          // parameters [100,110) are done
     // ---- conv1dto2d + IN (:266-271): dy arrives NCHW, dx leaves in trunk layout
     GB = nextGB();
-    norm_bwd(ex, st + o.c6, W4, BT4, normp(P, G, 98, 99), st + o.s6, GA, 5120LL * W4, W4, W4, 5120 * BT4, ns,
+    norm_bwd(ex, st + o.c6, W4, SBT4, normp(P, G, 98, 99), st + o.s6, GA, 5120LL * W4, W4, W4, 5120 * BT4, ns,
              GB, W4, BT4, W4, 0, B, 5120, 1, W4, ACT_NONE);
     {
         const float* hin = st + o.r[5].y;
         CView dyv{GB, 0, BT4, W4};
-        conv_wgrad(ex, g.c1d2d, G, 1, B, W4, CView{hin, 0, BT4, W4}, dyv);
+        conv_wgrad(ex, g.c1d2d, G, 1, B, W4, CView{hin, 0, SBT4, W4}, dyv);
         if (trunk_dgrad(ex, g.c1d2d, packed, GB, DH, 0, B, W4, &ns)) {}
         else conv_dgrad(ex, g.c1d2d, packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 0, 1, &ns);
     }
@@ -1561,18 +1591,18 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
             float* dt1 = sc + q.dtx1 + (long long)i * 1024 * BT4;
             TrunkBwdLayerDesc& da = na.L[l++];           // conv1d_out_layer (512 -> 256) + its InstanceNorm: d(h_out) -> d(GLU output)
             da.wt = packed + g.res_out[i].off_tk; da.dy = DH; da.px = st + o.r[i].cb; da.stats = st + o.r[i].sb;
-            da.g0 = P[b + 10]; da.b0 = P[b + 11]; da.xout = dt3; da.dg0 = G[b + 10]; da.db0 = G[b + 11];
+            da.g0 = P[b + 10]; da.b0 = P[b + 11]; da.xout = dt3; da.pxB = pxB; da.dg0 = G[b + 10]; da.db0 = G[b + 11];
             da.out = DT2; da.pre = 1; da.C = 256; da.M = 512; da.rows = 8;
             da.flags = (i < 5 ? TBWD_DY_FRESH : 0) | ((i == 5 && ns > 1) ? TBWD_SLAB_DY : 0);            // (conv1dto2d's K-split slabs)
             TrunkBwdLayerDesc& db = na.L[l++];           // value | gate convs (256 -> 512 each) + norms + GLU: d(GLU output) -> d(h_in), added to the skip path
             db.wt = packed + g.res_vg[i].off_tk; db.dy = DT2; db.px = st + o.r[i].ca; db.stats = st + o.r[i].sa;
-            db.g0 = P[b + 2]; db.b0 = P[b + 3]; db.g1 = P[b + 6]; db.b1 = P[b + 7]; db.xout = dt1;
+            db.g0 = P[b + 2]; db.b0 = P[b + 3]; db.g1 = P[b + 6]; db.b1 = P[b + 7]; db.xout = dt1; db.pxB = pxB;
             db.dg0 = G[b + 2]; db.db0 = G[b + 3]; db.dg1 = G[b + 6]; db.db1 = G[b + 7];
             db.out = DH; db.pre = 2; db.C = 512; db.M = 256; db.rows = 4;
             db.flags = TBWD_ACCUMULATE | TBWD_DY_FRESH | ((i == 5 && ns > 1) ? TBWD_SLAB_OUT : 0);
-            wjobs[nwjobs++] = SmallKJob{st + o.r[i].ya, dt3, G[g.res_out[i].wi[0]], 512, 256};
-            wjobs[nwjobs++] = SmallKJob{hin, dt1, G[g.res_vg[i].wi[0]], 256, 512};
-            wjobs[nwjobs++] = SmallKJob{hin, dt1 + 512LL * BT4, G[g.res_vg[i].wi[1]], 256, 512};
+            wjobs[nwjobs++] = SmallKJob{st + o.r[i].ya, dt3, G[g.res_out[i].wi[0]], 512, 256, pxB};
+            wjobs[nwjobs++] = SmallKJob{hin, dt1, G[g.res_vg[i].wi[0]], 256, 512, pxB};
+            wjobs[nwjobs++] = SmallKJob{hin, dt1 + 512LL * BT4, G[g.res_vg[i].wi[1]], 256, 512, pxB};
         }
         na.nlayers = l; na.B = B; na.T4 = W4; na.slabs = ex.slabs; na.slab_stride = 256 * BT4; na.nslab = ns; na.sync = ex.sync + MCVC_TRUNK_SYNC_WORDS; na.err = ex.sync + MCVC_TRUNK_SYNC_WORDS - 1;
         for (int i = 0; i < 6; ++i) { wait_readers(ex, sc + q.dtx3 + (long long)i * 256 * BT4); wait_readers(ex, sc + q.dtx1 + (long long)i * 1024 * BT4); }
@@ -1588,35 +1618,35 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
                           trunk_pick_ksplit(g.res_vg[i].cout_tot, 3, g.res_vg[i].Cin, B, W4, 0) >= 1;
         if (fuse) {
             if (batch_w) { DT3 = sc + q.dtx3 + (long long)i * 256 * BT4; DT1 = sc + q.dtx1 + (long long)i * 1024 * BT4; }
-            TrunkPre pa{1, st + o.r[i].cb, st + o.r[i].sb, P[b + 10], P[b + 11], nullptr, nullptr, DT3, G[b + 10], G[b + 11], nullptr, nullptr};
+            TrunkPre pa{1, st + o.r[i].cb, st + o.r[i].sb, P[b + 10], P[b + 11], nullptr, nullptr, DT3, G[b + 10], G[b + 11], nullptr, nullptr, pxB};
             trunk_dgrad(ex, g.res_out[i], packed, DH, DT2, 0, B, W4, nullptr, &pa);
-            TrunkPre pb{2, st + o.r[i].ca, st + o.r[i].sa, P[b + 2], P[b + 3], P[b + 6], P[b + 7], DT1, G[b + 2], G[b + 3], G[b + 6], G[b + 7]};
+            TrunkPre pb{2, st + o.r[i].ca, st + o.r[i].sa, P[b + 2], P[b + 3], P[b + 6], P[b + 7], DT1, G[b + 2], G[b + 3], G[b + 6], G[b + 7], pxB};
             ns = 1;
             trunk_dgrad(ex, g.res_vg[i], packed, DT2, DH, 1, B, W4, &ns, &pb);
             if (batch_w) {          // weight gradients of the block: queued for the batched launch behind the chain
-                wjobs[nwjobs++] = SmallKJob{st + o.r[i].ya, DT3, G[g.res_out[i].wi[0]], 512, 256};
-                wjobs[nwjobs++] = SmallKJob{hin, DT1, G[g.res_vg[i].wi[0]], 256, 512};
-                wjobs[nwjobs++] = SmallKJob{hin, DT1 + 512LL * BT4, G[g.res_vg[i].wi[1]], 256, 512};
+                wjobs[nwjobs++] = SmallKJob{st + o.r[i].ya, DT3, G[g.res_out[i].wi[0]], 512, 256, pxB};
+                wjobs[nwjobs++] = SmallKJob{hin, DT1, G[g.res_vg[i].wi[0]], 256, 512, pxB};
+                wjobs[nwjobs++] = SmallKJob{hin, DT1 + 512LL * BT4, G[g.res_vg[i].wi[1]], 256, 512, pxB};
             } else {
-                conv_wgrad(ex, g.res_out[i], G, 1, B, W4, CView{st + o.r[i].ya, 0, BT4, W4}, CView{DT3, 0, BT4, W4});
-                conv_wgrad(ex, g.res_vg[i], G, 1, B, W4, CView{hin, 0, BT4, W4}, CView{DT1, 0, BT4, W4});
+                conv_wgrad(ex, g.res_out[i], G, 1, B, W4, CView{st + o.r[i].ya, 0, SBT4, W4}, CView{DT3, 0, BT4, W4});
+                conv_wgrad(ex, g.res_vg[i], G, 1, B, W4, CView{hin, 0, SBT4, W4}, CView{DT1, 0, BT4, W4});
             }
             continue;
         }
-        norm_bwd(ex, st + o.r[i].cb, W4, BT4, normp(P, G, b + 10, b + 11), st + o.r[i].sb, DH, W4, BT4, W4, 256 * BT4, ns,
+        norm_bwd(ex, st + o.r[i].cb, W4, SBT4, normp(P, G, b + 10, b + 11), st + o.r[i].sb, DH, W4, BT4, W4, 256 * BT4, ns,
                  DT3, W4, BT4, W4, 0, B, 256, 1, W4, ACT_NONE);
         int ns2 = 1;
         {
             CView dyv{DT3, 0, BT4, W4};
-            conv_wgrad(ex, g.res_out[i], G, 1, B, W4, CView{st + o.r[i].ya, 0, BT4, W4}, dyv);
+            conv_wgrad(ex, g.res_out[i], G, 1, B, W4, CView{st + o.r[i].ya, 0, SBT4, W4}, dyv);
             if (!trunk_dgrad(ex, g.res_out[i], packed, DT3, DT2, 0, B, W4))
                 conv_dgrad(ex, g.res_out[i], packed, 1, B, W4, dyv, View{DT2, 0, BT4, W4}, 512 * BT4, 0, 1, &ns2);
         }
-        norm_bwd(ex, st + o.r[i].ca, W4, BT4, normp(P, G, b + 2, b + 3, b + 6, b + 7), st + o.r[i].sa, DT2, W4, BT4, W4, 512 * BT4, ns2,
+        norm_bwd(ex, st + o.r[i].ca, W4, SBT4, normp(P, G, b + 2, b + 3, b + 6, b + 7), st + o.r[i].sa, DT2, W4, BT4, W4, 512 * BT4, ns2,
                  DT1, W4, BT4, W4, 0, B, 512, 1, W4, ACT_GLU);
         {
             CView dyv{DT1, 0, BT4, W4};
-            conv_wgrad(ex, g.res_vg[i], G, 1, B, W4, CView{hin, 0, BT4, W4}, dyv);
+            conv_wgrad(ex, g.res_vg[i], G, 1, B, W4, CView{hin, 0, SBT4, W4}, dyv);
             ns = 1;          // (deterministic mode: DH is left alone and its K-split partials go to slabs the next norm_bwd sums)
             if (!trunk_dgrad(ex, g.res_vg[i], packed, DT1, DH, 1 /*accumulate: skip path*/, B, W4, &ns))
                 conv_dgrad(ex, g.res_vg[i], packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 1, 1, nullptr);
@@ -1635,10 +1665,10 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
     if (milestones) record_milestone(ex, milestones[1]);          // parameters [24,100) are done
     // ---- conv2dto1d + IN (:254-255)
     DT3 = DT3s[1];
-    norm_bwd(ex, st + o.c4, W4, BT4, normp(P, G, 22, 23), st + o.s4, DH, W4, BT4, W4, 256 * BT4, ns, DT3, W4, BT4, W4, 0, B, 256, 1, W4, ACT_NONE);
+    norm_bwd(ex, st + o.c4, W4, SBT4, normp(P, G, 22, 23), st + o.s4, DH, W4, BT4, W4, 256 * BT4, ns, DT3, W4, BT4, W4, 0, B, 256, 1, W4, ACT_NONE);
     {
         CView dyv{DT3, 0, BT4, W4};
-        conv_wgrad(ex, g.c2d1d, G, 1, B, W4, CView{st + o.y3, 0, BT4, W4}, dyv);
+        conv_wgrad(ex, g.c2d1d, G, 1, B, W4, CView{st + o.y3, 0, SBT4, W4}, dyv);
         ns = 1;
         if (!trunk_dgrad(ex, g.c2d1d, packed, DT3, GA, 0, B, W4))
             conv_dgrad(ex, g.c2d1d, packed, 1, B, W4, dyv, View{GA, 0, BT4, W4}, 5120 * BT4, 0, 1, &ns);
@@ -2115,9 +2145,10 @@ int mcvc_gen_trunk_fault(float* scratch, int B, int T, int reset, void* stream)
     if (hipMemcpyAsync(&v, w, sizeof(v), hipMemcpyDeviceToHost, s) != hipSuccess) return -MCVC_ERR_INVALID;
     if (reset && hipMemsetAsync(w, 0, sizeof(v), s) != hipSuccess) return -MCVC_ERR_INVALID;
     if (hipStreamSynchronize(s) != hipSuccess) return -MCVC_ERR_INVALID;
-    return (int)v;
+    return (int)(v & 0x7fffffffu);             // (an un-initialised word -- first read after allocation -- must not look like an error return)
 }
 int mcvc_debug_trunk_fault_inject(int on) { return mcvc_trunk_set_fault_inject(on); }
+int mcvc_set_trunk_passes_in_flight(int n) { return mcvc_trunk_set_passes_in_flight(n); }
 
 int mcvc_gen_backward_overlap(const float* const* params, const float* packed, float* const* grads, const float* mask, const float* dout,
                               float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T,
@@ -2131,7 +2162,23 @@ int mcvc_gen_backward_flags(const float* const* params, const float* packed, flo
                             float* dx, int accumulate_dx, const float* stash, float* scratch, long long scratch_floats, int B, int T,
                             void* stream, void* aux_stream, void* const* milestones, int flags)
 {
-    if (B < 1 || T < 1 || !params || !packed || !dout || !stash || !scratch) return MCVC_ERR_INVALID;
+    return mcvc_gen_backward_window(params, packed, grads, mask, dout, dx, accumulate_dx, stash, B, 0, scratch, scratch_floats, B, T, stream, aux_stream,
+                                    milestones, flags);
+}
+
+int mcvc_gen_backward_prefix(const float* const* params, const float* packed, float* const* grads, const float* mask, const float* dout,
+                             float* dx, int accumulate_dx, const float* stash, int stash_B, float* scratch, long long scratch_floats, int B, int T,
+                             void* stream, void* aux_stream, void* const* milestones, int flags)
+{
+    return mcvc_gen_backward_window(params, packed, grads, mask, dout, dx, accumulate_dx, stash, stash_B, 0, scratch, scratch_floats, B, T, stream,
+                                    aux_stream, milestones, flags);
+}
+
+int mcvc_gen_backward_window(const float* const* params, const float* packed, float* const* grads, const float* mask, const float* dout,
+                             float* dx, int accumulate_dx, const float* stash, int stash_B, int stash_b0, float* scratch, long long scratch_floats,
+                             int B, int T, void* stream, void* aux_stream, void* const* milestones, int flags)
+{
+    if (B < 1 || T < 1 || stash_b0 < 0 || stash_B < stash_b0 + B || !params || !packed || !dout || !stash || !scratch) return MCVC_ERR_INVALID;
     const GenDims d = gen_dims(B, T);
     Exec ex = make_exec(stream, aux_stream, scratch, scratch_floats, gen_scratch(d).slabs, gen_needs(B, T));
     if (ex.wslab_cap < 0) return MCVC_ERR_WORKSPACE;
@@ -2141,7 +2188,7 @@ int mcvc_gen_backward_flags(const float* const* params, const float* packed, flo
     ex.pack_skips = get_pack_skips(packed);
     if (ex.pack_skips & 4) return MCVC_ERR_INVALID;          // forward-only re-pack: the backward sets are stale (mcvc_gen_pack_sets)
     ex.no_join = (flags & 1) && aux_stream;
-    gen_backward_impl(ex, params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, d, milestones);
+    gen_backward_impl(ex, params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, d, milestones, stash_B, stash_b0);
     return ex.err;
 }
 

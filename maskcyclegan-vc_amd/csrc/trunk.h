@@ -27,7 +27,8 @@ struct TrunkArgs {
     //      weight-gradient kernel reads it) and accumulate d(gamma), d(beta).
     int pre;                                // 0 none; 1 plain IN (x = upstream gradient of the norm output); 2 IN + gated GLU
     int pre_C;                              // normalised channels per branch (X' has pre_C or 2*pre_C channels)
-    const float* pre_x;                     // conv output of the forward pass (pre-norm), [Cx][B][T4]
+    const float* pre_x;                     // conv output of the forward pass (pre-norm), [Cx][pre_xB][T4]
+    int pre_xB;                             // samples per channel of pre_x (0 = B; > B: backward over the first B samples of a larger forward pass)
     const float* pre_stats;                 // [B][Cx][2] mean, rstd
     const float* pre_gamma0; const float* pre_beta0; const float* pre_gamma1; const float* pre_beta1;
     float* pre_out;                         // X' [Cx][B][T4]
@@ -65,12 +66,15 @@ struct TrunkFwdNetArgs {
     int fault_inject;                        // test hook: workgroup 0 skips its first arrival (set by the launcher)
 };
 int mcvc_trunk_set_fault_inject(int on);
+// number of persistent trunk passes the caller keeps in flight at once (a grouped launch counts as two): the persistent kernels are used
+// only while 64 x that many workgroups fit the device's compute units; returns the previous value
+int mcvc_trunk_set_passes_in_flight(int n);
 // Co-residency: the kernel's 64 workgroups wait for each other, so all 64 must be resident at once -- each takes a whole CU (up to 160 KB
 // of LDS).  With P persistent passes in flight on different streams the device needs 64 * P <= 256 CUs for every pass to be guaranteed
 // progress; the trainer runs at most two generator passes at a time (one grouped launch = 128 workgroups, or two lanes of 64).  Beyond that
 // a pass can only be delayed, not deadlocked, as long as the over-subscribing passes are not ALL partially resident; the bounded spin in
 // wait_arrivals turns even that case into a reported fault (NaN result + error word) instead of a hang.
-// true when the persistent forward handles (B, T4) -- same regime as the per-layer fused kernels (N = B*T4 <= 32)
+// true when the persistent forward handles (B, T4) -- same regime as the per-layer fused kernels (N = B*T4 <= 64, LDS permitting: 48 at T4 = 16)
 bool mcvc_trunk_net_applies(int B, int T4);
 int mcvc_trunk_fwd_net_launch(TrunkFwdNetArgs& a, hipStream_t s);
 #define MCVC_TRUNK_SYNC_WORDS 32
@@ -84,7 +88,8 @@ int mcvc_trunk_fwd_net_launch(TrunkFwdNetArgs& a, hipStream_t s);
 struct TrunkBwdLayerDesc {
     const float* wt;                         // data-gradient weights [M][Cx*KW] (transposed + flipped copy, pack.h PACK_TRUNK_T)
     const float* dy;                         // gradient w.r.t. the norm (+GLU) output [C][B][T4]
-    const float* px;                         // the forward pass's pre-norm conv output [Cx][B][T4]
+    const float* px;                         // the forward pass's pre-norm conv output [Cx][pxB][T4]
+    int pxB;                                 // samples per channel of px (0 = B; > B: backward over the first B samples of a larger forward pass)
     const float* stats;                      // [B][Cx][2] mean, rstd
     const float* g0; const float* b0; const float* g1; const float* b1;      // affine parameters (value | gate)
     float* xout;                             // X' [Cx][B][T4]

@@ -20,6 +20,16 @@
 //   * K = 5120 (conv2dto1d and the data-gradient of conv1dto2d) does not fit one workgroup's LDS: K-split workgroups write
 //     private slabs (split 0 adds the bias) that the following norm launch sums -- no atomics, no zero-fill launch.
 // The same kernel with mode 0 is the data-gradient of these layers (weights transposed+flipped by pack_trunk_t).
+//
+// r4 -- LDS layout and k mapping (SQ_LDS_BANK_CONFLICT was 31-46 % of the LDS cycles of these kernels):
+//   * a staged row is [4 zeros | T4 values] (k = 3; k = 1: the T4 values alone): the values are 16-byte aligned, so staging is one
+//     ds_write_b128 per float4 instead of four 4-way-conflicting ds_write_b32; the zeros in front of row r+1 are the right halo of row r;
+//   * the four k of one 16x16x4 MFMA are no longer 4 apart in the weight row (mixed (ci, kw) pairs whose LDS addresses differ by
+//     RS+1 or 2*RS-2 -- no pitch separates both) but lane-quarter kq owns WHOLE channels: kq's float4s of a super-group are consecutive
+//     (k = 4*(NQ*kq + q) + j), so in every MFMA step the quarters kq and kq+1 read the same tap of channels 4 (k = 3) or 8 (k = 1)
+//     apart, i.e. 4*RS or 8*RS floats apart; the channel pitch RS is padded to 4 mod 8 (k = 3) / 2 mod 4 (k = 1), which puts the two
+//     16-lane windows of a ds_read_b32 lane group exactly 16 banks apart: conflict-free at T4 = 16;
+//   * up to 64 columns (one to four 16-column accumulators per wave): three samples of 64 frames per pass (the trainer's merged forward).
 #include "mcvc_common.h"
 #include "trace.h"
 #include "launch.h"
@@ -31,6 +41,35 @@ namespace {
 
 constexpr int kTrunkWaves = 8;                 // K is split over the waves of ONE workgroup (2 per SIMD)
 constexpr int kTrunkThreads = 64 * kTrunkWaves;
+
+// staged-row geometry (see the header): data offset inside a row, row pitch, channel pitch
+__host__ __device__ inline int trunk_doff(int KW) { return KW == 3 ? 4 : 0; }
+__host__ __device__ inline int trunk_tp(int T4, int KW) { return T4 + trunk_doff(KW); }
+__host__ __device__ inline int trunk_rs(int B, int T4, int KW)
+{
+    int rs = B * trunk_tp(T4, KW);
+    if (KW == 3) { while ((rs & 7) != 4) ++rs; }      // quarters 4 channels apart -> 16 banks apart
+    else { while ((rs & 3) != 2) ++rs; }              // quarters 8 channels apart -> 16 banks apart
+    return rs;
+}
+__host__ __device__ inline int trunk_na(int N) { return (N + 15) >> 4; }
+// epilogue scratch of one workgroup: red[waves][NA][4][64] | tile[16][16 NA + 1] | sstat[16][8][2] | 16 spare (flag)
+__host__ __device__ inline int trunk_epi_floats(int NA) { return kTrunkWaves * NA * 4 * 64 + 16 * (16 * NA + 1) + 16 * 8 * 2 + 16; }
+
+// zero every staged slot that holds no value: the 4 leading zeros of each row (k = 3), the pad behind the last row of a channel, and
+// 4 floats behind the last channel (right halo of the very last row / the idle lanes' zero slot)
+__device__ __forceinline__ void trunk_zero_gaps(float* Xs, int nch, int B, int TP, int RS, int DOFF, int tid, int nthreads)
+{
+    const int per = B * DOFF + (RS - B * TP);
+    for (int i = tid; i < nch * per + 4; i += nthreads) {
+        const int ci = per > 0 ? i / per : nch, j = i - ci * per;
+        int pos;
+        if (ci >= nch) pos = j;                                        // (the 4 floats behind the last channel)
+        else if (j < B * DOFF) { const int b = j / (DOFF > 0 ? DOFF : 1), o = j - b * DOFF; pos = b * TP + o; }
+        else pos = B * TP + (j - B * DOFF);
+        Xs[ci * RS + pos] = 0.f;
+    }
+}
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
@@ -46,9 +85,10 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
-    constexpr int PW = (KW - 1) / 2;
-    const int TP = a.T4 + 2 * PW;                 // padded row length in LDS
-    const int RS = a.B * TP + 1;                  // per input channel (+1: a guaranteed-zero slot for idle lanes)
+    constexpr int DOFF = (KW == 3) ? 4 : 0;
+    const int TP = a.T4 + DOFF;                   // staged row: [4 zeros | T4 values] (k = 3)
+    const int RS = trunk_rs(a.B, a.T4, KW);       // channel pitch (padded: see the header)
+    constexpr int TLP = 16 * NA + 1;              // pitch of the epilogue tile
     const int glu = (a.mode == TRUNK_IN_GLU);
     const int rows_per_block = glu ? 8 : 16;
     const int r0 = blockIdx.x * rows_per_block;
@@ -67,26 +107,27 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
         else arow = a.a0 + (long long)(r0 + i) * a.K;
     }
     // One super-group = NQ float4 of weights per lane = GK = 16*NQ consecutive k per wave = whole input channels, so the
-    // (ci, kw) pattern repeats and the LDS offsets of its 4*NQ MFMA steps are loop-invariant registers.  Up to CH
-    // super-groups (all of them for the generator's shapes) are requested before anything else happens: at this size the
-    // layer is one DRAM latency, not a bandwidth problem.
+    // (ci, kw) pattern repeats and the LDS offsets of its 4*NQ MFMA steps are loop-invariant registers.  Lane quarter kq owns
+    // the float4s NQ*kq .. NQ*kq + NQ-1 of the super-group (whole channels: see the header).  Up to CH super-groups (all of
+    // them for the generator's shapes) are requested before anything else happens: at this size the layer is one DRAM latency,
+    // not a bandwidth problem.
     constexpr int NQ = (KW == 3) ? 3 : 2;
     constexpr int GK = 16 * NQ;
     constexpr int CH = 4;
     const int sgroups = k_count / GK;
-    const float* ap = arow + k_begin + 4 * kq;
+    const float* ap = arow + k_begin + 4 * NQ * kq;
     float4 wb[CH][NQ];
 #define TRUNK_LOAD_CHUNK(sg0)                                                                                       \
     {                                                                                                              \
         _Pragma("unroll") for (int c = 0; c < CH; ++c) {                                                           \
             const int sg = (sg0) + c;                                                                              \
             const float* pp = ap + (long long)(sg < sgroups ? sg : 0) * GK;                                        \
-            _Pragma("unroll") for (int q = 0; q < NQ; ++q) wb[c][q] = *reinterpret_cast<const float4*>(pp + 16 * q); \
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q) wb[c][q] = *reinterpret_cast<const float4*>(pp + 4 * q); \
         }                                                                                                          \
     }
     TRUNK_LOAD_CHUNK(0);
 
-    // ---- stage X[ci][b][t] (this block's channel slice) with zero halo
+    // ---- stage X[ci][b][t] (this block's channel slice)
     if constexpr (PRE) {
         // fused InstanceNorm backward (see trunk.h).  Work item = a quarter of one (channel, sample) row: four adjacent lanes own a
         // row, each holds ceil(T4/4) <= 8 consecutive elements, the two row sums are width-4 shuffles.  d(gamma), d(beta) of a channel
@@ -94,10 +135,11 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
         const int C = a.pre_C;
         const bool pglu = (a.pre == 2);
         const int Cx = pglu ? 2 * C : C;
+        const int PB = a.pre_xB > 0 ? a.pre_xB : a.B;         // samples per channel of the forward pass's tensor (prefix backward: > B)
         const bool out = (blockIdx.x == 0);
         const float invT = 1.0f / (float)a.T4;
         const int E = (a.T4 + 3) >> 2;                        // elements per lane (<= 8)
-        float* rsum = smem + ci_count * RS;                   // [ci_count][B][2] row sums (s1, s2) -- behind the staged slice
+        float* rsum = smem + ci_count * RS + 4;               // [ci_count][B][2] row sums (s1, s2) -- behind the staged slice
         const int items = ci_count * a.B * 4;
         for (int it0 = 0; it0 < items; it0 += kTrunkThreads) {
             const int item = it0 + tid;
@@ -114,8 +156,8 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
             const float m1 = pglu ? st[2 * (c + C)] : 0.f, r1 = pglu ? st[2 * (c + C) + 1] : 1.f;
             const int t0 = q4 * E;
             const float* dyr = a.x + (long long)c * a.x_sc + (long long)b * a.x_sb + t0;
-            const float* x0r = a.pre_x + ((long long)c * a.B + b) * a.T4 + t0;
-            const float* x1r = a.pre_x + ((long long)(c + C) * a.B + b) * a.T4 + t0;
+            const float* x0r = a.pre_x + ((long long)c * PB + b) * a.T4 + t0;
+            const float* x1r = a.pre_x + ((long long)(c + C) * PB + b) * a.T4 + t0;
             float vd[8], v0[8], v1[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -142,23 +184,20 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
             s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
             if (live) {
                 const float gr = gate ? g1 * r1 : g0 * r0;
-                float* xrow = smem + ci * RS + b * TP;
+                float* xrow = smem + ci * RS + b * TP + DOFF;
                 float* od = out ? (a.pre_out + ((long long)cx * a.B + b) * a.T4 + t0) : nullptr;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (e < E && (t0 + e) < a.T4) {
                         const float dxv = gr * (dzv[e] - s1 * invT - xhv[e] * (s2 * invT));
-                        xrow[PW + t0 + e] = dxv;
+                        xrow[t0 + e] = dxv;
                         if (od) od[e] = dxv;
                     }
                 }
-                if (q4 == 0) {
-                    for (int hcol = 0; hcol < PW; ++hcol) { xrow[hcol] = 0.f; xrow[PW + a.T4 + hcol] = 0.f; }
-                    if (b == 0) smem[ci * RS + a.B * TP] = 0.f;
-                    rsum[(ci * a.B + b) * 2] = s1; rsum[(ci * a.B + b) * 2 + 1] = s2;
-                }
+                if (q4 == 0) { rsum[(ci * a.B + b) * 2] = s1; rsum[(ci * a.B + b) * 2 + 1] = s2; }
             }
         }
+        trunk_zero_gaps(smem, ci_count, a.B, TP, RS, DOFF, tid, kTrunkThreads);
         if (out) {
             __syncthreads();
             for (int ci = tid; ci < ci_count; ci += kTrunkThreads) {
@@ -193,46 +232,33 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
                         const int e = 4 * f;
                         const int r = e / a.T4, t = e - r * a.T4;
                         const int ci = r / a.B, b = r - ci * a.B;
-                        float* d = smem + ci * RS + b * TP + PW + t;
-                        d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                        float* d = smem + ci * RS + b * TP + DOFF + t;
+                        if constexpr (KW == 3) *reinterpret_cast<float4*>(d) = v[u];          // (RS, TP, DOFF, t multiples of 4: 16-byte aligned)
+                        else { *reinterpret_cast<float2*>(d) = make_float2(v[u].x, v[u].y); *reinterpret_cast<float2*>(d + 2) = make_float2(v[u].z, v[u].w); }
                     }
                 }
             }
-            // halo columns + the per-channel zero slot
-            const int per = a.B * 2 * PW + 1;
-            for (int i = tid; i < ci_count * per; i += kTrunkThreads) {
-                const int ci = i / per, j = i - ci * per;
-                int pos;
-                if (j == per - 1) pos = a.B * TP;
-                else { const int b = j / (2 * PW > 0 ? 2 * PW : 1), side = j - b * 2 * PW; pos = b * TP + (side ? TP - 1 : 0); }
-                smem[ci * RS + pos] = 0.f;
-            }
         } else {
-            const int total = ci_count * RS;
-            for (int i = tid; i < total; i += kTrunkThreads) {
-                const int ci = i / RS, rem = i - ci * RS;
-                float v = 0.f;
-                if (rem < a.B * TP) {
-                    const int b = rem / TP, tp = rem - b * TP;
-                    const int t = tp - PW;
-                    if (t >= 0 && t < a.T4) v = xsrc[(long long)ci * a.x_sc + (long long)b * a.x_sb + t];
-                }
-                smem[i] = v;
+            for (int i = tid; i < ci_count * a.B * a.T4; i += kTrunkThreads) {
+                const int r = i / a.T4, t = i - r * a.T4;
+                const int ci = r / a.B, b = r - ci * a.B;
+                smem[ci * RS + b * TP + DOFF + t] = xsrc[(long long)ci * a.x_sc + (long long)b * a.x_sb + t];
             }
         }
+        trunk_zero_gaps(smem, ci_count, a.B, TP, RS, DOFF, tid, kTrunkThreads);
     }
-    // B columns of this lane: n = l15 (+16 for the second accumulator) -> (b, t); idle lanes read the zero slot
+    // B columns of this lane: n = l15 (+16 per further accumulator) -> (b, t); idle lanes read a zero slot
     int off[NA][NQ][4];
 #pragma unroll
     for (int h = 0; h < NA; ++h) {
         const int n = l15 + 16 * h;
         int xcol = a.B * TP, live = 0;
-        if (n < a.N) { const int b = n / a.T4, t = n - b * a.T4; xcol = b * TP + t; live = 1; }
+        if (n < a.N) { const int b = n / a.T4, t = n - b * a.T4; xcol = b * TP + DOFF - (KW - 1) / 2 + t; live = 1; }
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int kr = 16 * q + 4 * kq + j;
+                const int kr = 4 * (NQ * kq + q) + j;
                 off[h][q][j] = (kr / KW) * RS + xcol + (live ? (kr % KW) : 0);
             }
     }
@@ -283,15 +309,15 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[((wave * NA + h) * 4 + r) * 64 + lane] = acc[h][r];
     __syncthreads();
-    float* tile = smem + kTrunkWaves * 2 * 4 * 64;  // [16 rows][33]
-    float* sstat = tile + 16 * 33;                 // [16 rows][B][2]
+    float* tile = smem + kTrunkWaves * NA * 4 * 64;  // [16 rows][TLP]
+    float* sstat = tile + 16 * TLP;                // [16 rows][B][2]
     for (int e = tid; e < NA * 256; e += kTrunkThreads) {
         const int h = e >> 8, r = (e >> 6) & 3, ln = e & 63;
         float v = 0.f;
 #pragma unroll
         for (int w = 0; w < kTrunkWaves; ++w) v += red[((w * NA + h) * 4 + r) * 64 + ln];
         const int row = 4 * (ln >> 4) + r, col = (ln & 15) + 16 * h;
-        tile[row * 33 + col] = v;
+        tile[row * TLP + col] = v;
     }
     __syncthreads();
 
@@ -306,7 +332,7 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
             const int row = e / a.N, nn = e - row * a.N;
             const int b = nn / a.T4, t = nn - b * a.T4;
             float* dst = base + (long long)row_cx(row) * a.c_sc + (long long)b * a.c_sb + t;
-            float v = tile[row * 33 + nn];
+            float v = tile[row * TLP + nn];
             if (a.bias0 && blockIdx.y == 0) v += a.bias0[r0 + row];
             if (a.slab_all) *dst = v;
             else if (a.accumulate) { if (gridDim.y > 1) unsafeAtomicAdd(dst, v); else *dst += v; }
@@ -319,8 +345,8 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
         const int row = e / a.N, nn = e - row * a.N;
         const int cx = row_cx(row);
         const float bias = glu ? ((row < 8) ? a.bias0[r0 + row] : a.bias1[r0 + row - 8]) : a.bias0[r0 + row];
-        const float v = tile[row * 33 + nn] + bias;
-        tile[row * 33 + nn] = v;
+        const float v = tile[row * TLP + nn] + bias;
+        tile[row * TLP + nn] = v;
         const int b = nn / a.T4, t = nn - b * a.T4;
         a.conv_out[(long long)cx * a.c_sc + (long long)b * a.c_sb + t] = v;
     }
@@ -328,7 +354,7 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
     // ---- statistics per (row, b): two-pass over T4 (<= 32) elements, one thread each
     if (tid < 16 * a.B) {
         const int row = tid / a.B, b = tid - row * a.B;
-        const float* p = tile + row * 33 + b * a.T4;
+        const float* p = tile + row * TLP + b * a.T4;
         float s = 0.f;
         for (int t = 0; t < a.T4; ++t) s += p[t];
         const float mean = s / (float)a.T4;
@@ -347,12 +373,12 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
         const int c = r0 + row;
         const int b = nn / a.T4, t = nn - b * a.T4;
         const float m0 = sstat[(row * a.B + b) * 2], s0 = sstat[(row * a.B + b) * 2 + 1];
-        const float z0 = (tile[row * 33 + nn] - m0) * s0 * a.gamma0[c] + a.beta0[c];
+        const float z0 = (tile[row * TLP + nn] - m0) * s0 * a.gamma0[c] + a.beta0[c];
         float y;
         if (glu) {
             const int rg = row + 8;
             const float m1 = sstat[(rg * a.B + b) * 2], s1 = sstat[(rg * a.B + b) * 2 + 1];
-            const float z1 = (tile[rg * 33 + nn] - m1) * s1 * a.gamma1[c] + a.beta1[c];
+            const float z1 = (tile[rg * TLP + nn] - m1) * s1 * a.gamma1[c] + a.beta1[c];
             y = z0 * sigmoidf_(z1);
         } else {
             y = z0;
@@ -373,7 +399,7 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
 constexpr int kNetWaves = 8;
 constexpr int kNetThreads = 64 * kNetWaves;
 constexpr int kNetGrid = 64;
-constexpr int kNetEpiFloats = kNetWaves * 2 * 4 * 64 + 16 * 33 + 16 * 8 * 2 + 16;     // red | tile | sstat | flag
+static_assert(kNetWaves == kTrunkWaves, "the persistent kernels share trunk_epi_floats with the per-layer kernel");
 
 __device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -386,15 +412,15 @@ __device__ __forceinline__ bool wait_arrivals(unsigned* ctr, unsigned target)
     return false;
 }
 
-// stage X[ci][b][t] (all Cin channels) with zero halo + a zero slot per channel (same layout as trunk_layer_kernel)
+// stage X[ci][b][t] (all Cin channels), same layout as trunk_layer_kernel (rows [4 zeros | T4 values] at k = 3, padded channel pitch)
 // `fresh`: the source was written by OTHER workgroups of this launch with write-through (sc1) stores: read it with sc1 loads, which
 // are served by L2 / memory and never by this CU's (possibly stale) L1 -- no acquire fence needed (Guideline 16, R1 with sc1 on both sides)
 typedef int v4i_ __attribute__((ext_vector_type(4)));
 template <int KW>
 __device__ __forceinline__ void net_stage_x(const float* __restrict__ xsrc, float* Xs, int Cin, int B, int T4, int tid, bool fresh)
 {
-    constexpr int PW = (KW - 1) / 2;
-    const int TP = T4 + 2 * PW, RS = B * TP + 1;
+    constexpr int DOFF = (KW == 3) ? 4 : 0;
+    const int TP = T4 + DOFF, RS = trunk_rs(B, T4, KW);
     if (((T4 & 3) == 0) && ((reinterpret_cast<unsigned long long>(xsrc) & 15ull) == 0)) {
         const int nf4 = (Cin * B * T4) >> 2;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc), 0, nf4 * 16, 0x00020000);
@@ -413,40 +439,28 @@ __device__ __forceinline__ void net_stage_x(const float* __restrict__ xsrc, floa
                     const int e = 4 * f;
                     const int r = e / T4, t = e - r * T4;
                     const int ci = r / B, b = r - ci * B;
-                    float* dd = Xs + ci * RS + b * TP + PW + t;
-                    dd[0] = v[u].x; dd[1] = v[u].y; dd[2] = v[u].z; dd[3] = v[u].w;
+                    float* dd = Xs + ci * RS + b * TP + DOFF + t;
+                    if constexpr (KW == 3) *reinterpret_cast<float4*>(dd) = v[u];
+                    else { *reinterpret_cast<float2*>(dd) = make_float2(v[u].x, v[u].y); *reinterpret_cast<float2*>(dd + 2) = make_float2(v[u].z, v[u].w); }
                 }
             }
-        }
-        const int per = B * 2 * PW + 1;
-        for (int i = tid; i < Cin * per; i += kNetThreads) {
-            const int ci = i / per, j = i - ci * per;
-            int pos;
-            if (j == per - 1) pos = B * TP;
-            else { const int b = j / (2 * PW > 0 ? 2 * PW : 1), side = j - b * 2 * PW; pos = b * TP + (side ? TP - 1 : 0); }
-            Xs[ci * RS + pos] = 0.f;
         }
     } else {
-        const int total = Cin * RS;
-        for (int i = tid; i < total; i += kNetThreads) {
-            const int ci = i / RS, rem = i - ci * RS;
-            float v = 0.f;
-            if (rem < B * TP) {
-                const int b = rem / TP, tp = rem - b * TP;
-                const int t = tp - PW;
-                if (t >= 0 && t < T4) {
-                    const float* q = xsrc + (long long)ci * B * T4 + (long long)b * T4 + t;
-                    v = fresh ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
-                }
-            }
-            Xs[i] = v;
+        for (int i = tid; i < Cin * B * T4; i += kNetThreads) {
+            const int r = i / T4, t = i - r * T4;
+            const int ci = r / B, b = r - ci * B;
+            const float* q = xsrc + i;
+            Xs[ci * RS + b * TP + DOFF + t] = fresh ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
         }
     }
+    trunk_zero_gaps(Xs, Cin, B, TP, RS, DOFF, tid, kNetThreads);
 }
 
 // weights of one tile: all of a wave's loads issued at once (the first CH super-groups = everything for the generator's shapes)
+// (one register array for both kernel widths: a layer uses [4][3] at k = 3 and the first two columns at k = 1 -- two separate arrays
+// were both live across the layer loop and pushed the 48-column kernel into scratch)
 template <int KW>
-struct NetW { float4 wb[4][(KW == 3) ? 3 : 2]; };
+struct NetW { float4 wb[4][3]; };
 
 template <int KW>
 __device__ __forceinline__ void net_load_w(const TrunkLayerDesc& d, int tile, NetW<KW>& w)
@@ -465,30 +479,35 @@ __device__ __forceinline__ void net_load_w(const TrunkLayerDesc& d, int tile, Ne
     constexpr int NQ = (KW == 3) ? 3 : 2;
     constexpr int GK = 16 * NQ;
     const int sgroups = k_count / GK;
-    const float* ap = arow + wave * k_count + 4 * kq;
+    const float* ap = arow + wave * k_count + 4 * NQ * kq;       // (lane quarter kq owns whole channels: see the header)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float* pp = ap + (long long)(c < sgroups ? c : 0) * GK;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) w.wb[c][q] = *reinterpret_cast<const float4*>(pp + 16 * q);
+        for (int q = 0; q < NQ; ++q) w.wb[c][q] = *reinterpret_cast<const float4*>(pp + 4 * q);
     }
 }
 
 // one tile of output rows of one layer: conv (K split over the 8 waves) + bias + IN + GLU / residual, stores included
-// Epilogue operands of one tile, one output element per thread: requested together with the weights, BEFORE the wait for the previous
-// layer's activations -- bias / gamma / beta / the residual input are 1-1.5 us of dependent global-load latency otherwise (measured with
-// an in-kernel clock: the epilogue was 5-6 us of a 10 us layer, the arrival wait 0.4 us)
-struct NetE { float bias, g0, b0, g1, b1, res; };
+// Epilogue operands of one tile, requested together with the weights, BEFORE the wait for the previous layer's activations -- bias /
+// gamma / beta / the residual input are 1-1.5 us of dependent global-load latency otherwise (measured with an in-kernel clock: the
+// epilogue was 5-6 us of a 10 us layer, the arrival wait 0.4 us).  A tile has up to 16 x 64 conv outputs = two per thread (bias[2]) and
+// up to 8 x 64 normalised outputs = one per thread.
+struct NetE { float bias[2], g0, b0, g1, b1, res; };
 __device__ __forceinline__ void net_load_e(const TrunkLayerDesc& d, int B, int T4, int tile, NetE& e)
 {
     const int tid = threadIdx.x;
     const int N = B * T4;
     const int glu = (d.mode == TRUNK_IN_GLU);
     const int rows = d.rows, rows_tot = glu ? 2 * rows : rows, r0 = tile * rows;
-    e = NetE{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (tid < rows_tot * N) {
-        const int mrow = tid / N;
-        e.bias = glu ? ((mrow < rows) ? d.bias0[r0 + mrow] : d.bias1[r0 + mrow - rows]) : d.bias0[r0 + mrow];
+    e = NetE{{0.f, 0.f}, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int el = tid + it * kNetThreads;
+        if (el < rows_tot * N) {
+            const int mrow = el / N;
+            e.bias[it] = glu ? ((mrow < rows) ? d.bias0[r0 + mrow] : d.bias1[r0 + mrow - rows]) : d.bias0[r0 + mrow];
+        }
     }
     if (tid < rows * N) {
         const int row = tid / N, col = tid - row * N, c = r0 + row;
@@ -509,8 +528,9 @@ __device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4,
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
-    constexpr int PW = (KW - 1) / 2;
-    const int TP = T4 + 2 * PW, RS = B * TP + 1;
+    constexpr int DOFF = (KW == 3) ? 4 : 0;
+    constexpr int TLP = 16 * NA + 1;
+    const int TP = T4 + DOFF, RS = trunk_rs(B, T4, KW);
     const int N = B * T4, K = d.Cin * KW;
     const int glu = (d.mode == TRUNK_IN_GLU);
     const int rows = d.rows;                       // per branch
@@ -529,19 +549,19 @@ __device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4,
     constexpr int GK = 16 * NQ;
     constexpr int CH = 4;
     const int sgroups = k_count / GK;
-    const float* ap = arow + k_begin + 4 * kq;
-    float4 (&wb)[CH][NQ] = pre.wb;                 // super-groups 0..CH-1 were requested by net_load_w (before the layer's wait)
+    const float* ap = arow + k_begin + 4 * NQ * kq;
+    float4 (&wb)[CH][3] = pre.wb;                  // super-groups 0..CH-1 were requested by net_load_w (before the layer's wait)
     int off[NA][NQ][4];
 #pragma unroll
     for (int h = 0; h < NA; ++h) {
         const int n = l15 + 16 * h;
         int xcol = B * TP, live = 0;
-        if (n < N) { const int b = n / T4, t = n - b * T4; xcol = b * TP + t; live = 1; }
+        if (n < N) { const int b = n / T4, t = n - b * T4; xcol = b * TP + DOFF - (KW - 1) / 2 + t; live = 1; }
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int kr = 16 * q + 4 * kq + j;
+                const int kr = 4 * (NQ * kq + q) + j;
                 off[h][q][j] = (kr / KW) * RS + xcol + (live ? (kr % KW) : 0);
             }
     }
@@ -556,7 +576,7 @@ __device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4,
                 for (int c = 0; c < CH; ++c) {
                     const float* pp = ap + (long long)(sg0 + c < sgroups ? sg0 + c : 0) * GK;
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) wb[c][q] = *reinterpret_cast<const float4*>(pp + 16 * q);
+                    for (int q = 0; q < NQ; ++q) wb[c][q] = *reinterpret_cast<const float4*>(pp + 4 * q);
                 }
             }
 #pragma unroll
@@ -586,24 +606,28 @@ __device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4,
     }
     // ---- cross-wave K reduction: red[wave][h][reg][lane]
     float* red = epi;
-    float* tl = epi + kNetWaves * 2 * 4 * 64;      // [16][33]
-    float* sstat = tl + 16 * 33;                   // [16][B][2]
+    float* tl = epi + kNetWaves * NA * 4 * 64;     // [16][TLP]
 #pragma unroll
     for (int h = 0; h < NA; ++h)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[((wave * NA + h) * 4 + r) * 64 + lane] = acc[h][r];
     __syncthreads();
-    // one thread per MFMA output element (mrow, col), a row's N columns in consecutive threads: sum of the 8 waves' partials + bias
+    // one thread per MFMA output element (mrow, col) (two at more than 32 columns), a row's N columns in consecutive threads: sum of the
+    // 8 waves' partials + bias
     auto row_cx = [&](int row) { return glu ? ((row < rows) ? (r0 + row) : (d.M + r0 + row - rows)) : (r0 + row); };
-    if (tid < rows_tot * N) {
-        const int mrow = tid / N, col = tid - mrow * N;
-        const int h = col >> 4, ln = ((mrow >> 2) << 4) + (col & 15), r = mrow & 3;
-        float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < kNetWaves; ++w) v += red[((w * NA + h) * 4 + r) * 64 + ln];
-        v += pe.bias;
-        tl[mrow * 33 + col] = v;
-        d.conv_out[(long long)row_cx(mrow) * N + col] = v;
+    for (int it = 0; it < (NA > 2 ? 2 : 1); ++it) {
+        const int el = tid + it * kNetThreads;
+        if (el < rows_tot * N) {
+            const int mrow = el / N, col = el - mrow * N;
+            const int h = col >> 4, ln = ((mrow >> 2) << 4) + (col & 15), r = mrow & 3;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < kNetWaves; ++w) v += red[((w * NA + h) * 4 + r) * 64 + ln];
+            v += pe.bias[it];
+            tl[mrow * TLP + col] = v;
+            d.conv_out[(long long)row_cx(mrow) * N + col] = v;
+        }
     }
     __syncthreads();
     // statistics of (row, sample) over its T4 columns, computed by every thread of the segment (LDS broadcast reads) instead of by
@@ -614,7 +638,7 @@ __device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4,
         const int b = col / T4, t = col - b * T4;
         const bool pow2 = (T4 & (T4 - 1)) == 0;            // (uniform) the T4 lanes of a (row, sample) segment are consecutive and aligned
         auto stats_of = [&](int mrow, float& mean, float& rstd) {
-            const float* p = tl + mrow * 33 + b * T4;
+            const float* p = tl + mrow * TLP + b * T4;
             float sum, q;
             if (pow2) {                                   // butterfly over the segment's lanes: 2 log2(T4) shuffles instead of 2 T4 LDS reads
                 sum = p[t];
@@ -638,12 +662,12 @@ __device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4,
         };
         float m0, s0;
         stats_of(row, m0, s0);
-        const float z0 = (tl[row * 33 + col] - m0) * s0 * pe.g0 + pe.b0;
+        const float z0 = (tl[row * TLP + col] - m0) * s0 * pe.g0 + pe.b0;
         float y;
         if (glu) {
             float m1, s1;
             stats_of(row + rows, m1, s1);
-            const float z1 = (tl[(row + rows) * 33 + col] - m1) * s1 * pe.g1 + pe.b1;
+            const float z1 = (tl[(row + rows) * TLP + col] - m1) * s1 * pe.g1 + pe.b1;
             y = z0 * sigmoidf_(z1);
         } else {
             y = z0;
@@ -661,13 +685,14 @@ __global__ void __launch_bounds__(kNetThreads) trunk_fwd_net_kernel(const Twin<T
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;
     float* epi = smem + a.x_floats;
-    float* flag = epi + kNetEpiFloats - 16;
+    float* flag = epi + trunk_epi_floats(NA) - 16;
     const int tid = threadIdx.x;
     for (int l = 0; l < a.nlayers; ++l) {
         const TrunkLayerDesc d = a.L[l];          // (by value: the fields are loaded once per layer, not inside the loops below)
         const int ntiles = d.M / d.rows;
         // this layer's weights do not depend on the previous layer: request them BEFORE waiting for its activations
-        NetW<3> w3; NetW<1> w1; NetE pe;
+        NetW<3> w3; NetE pe;
+        NetW<1>& w1 = reinterpret_cast<NetW<1>&>(w3);
         const bool mine = (int)blockIdx.x < ntiles;
         if (mine) { if (d.KW == 3) net_load_w<3>(d, blockIdx.x, w3); else net_load_w<1>(d, blockIdx.x, w1); net_load_e(d, a.B, a.T4, blockIdx.x, pe); }
         if (l > 0) {
@@ -718,11 +743,12 @@ __global__ void __launch_bounds__(kNetThreads) trunk_fwd_net_kernel(const Twin<T
 // 4-lanes-per-row decomposition as the PRE path of trunk_layer_kernel; owner workgroups store X' and add d(gamma), d(beta)
 __device__ __forceinline__ void bnet_stage_pre(const TrunkBwdNetArgs& a, const TrunkBwdLayerDesc& d, float* Xs, float* rsum, int B, int T4, int tid)
 {
-    constexpr int PW = 1;
-    const int TP = T4 + 2 * PW, RS = B * TP + 1;
+    constexpr int DOFF = 4;
+    const int TP = T4 + DOFF, RS = trunk_rs(B, T4, 3);
     const int C = d.C;
     const bool pglu = (d.pre == 2);
     const int Cx = pglu ? 2 * C : C;
+    const int PB = d.pxB > 0 ? d.pxB : B;                  // samples per channel of the forward pass's tensor (prefix backward: > B)
     const float invT = 1.0f / (float)T4;
     const int E = (T4 + 3) >> 2;
     const int items = Cx * B * 4;
@@ -746,10 +772,11 @@ __device__ __forceinline__ void bnet_stage_pre(const TrunkBwdNetArgs& a, const T
                 const bool gate = pglu && cx >= C;
                 const int c = gate ? cx - C : cx;
                 const long long ro = ((long long)c * B + b) * 16 + q4 * 4;
+                const long long po = ((long long)c * PB + b) * 16 + q4 * 4;
                 vd[u] = fresh ? __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ro * 4), 0, 16))
                               : *reinterpret_cast<const float4*>(d.dy + ro);
-                v0[u] = *reinterpret_cast<const float4*>(d.px + ro);
-                v1[u] = pglu ? *reinterpret_cast<const float4*>(d.px + ro + (long long)C * B * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                v0[u] = *reinterpret_cast<const float4*>(d.px + po);
+                v1[u] = pglu ? *reinterpret_cast<const float4*>(d.px + po + (long long)C * PB * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
                 g0[u] = d.g0[c]; b0[u] = d.b0[c];
                 g1[u] = pglu ? d.g1[c] : 0.f; b1[u] = pglu ? d.b1[c] : 0.f;
                 const float* st = d.stats + (long long)b * Cx * 2;
@@ -789,15 +816,9 @@ __device__ __forceinline__ void bnet_stage_pre(const TrunkBwdNetArgs& a, const T
                     float o[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = gr * (dzv[e] - s1 * invT - xhv[e] * (s2 * invT));
-                    float* xrow = Xs + cx * RS + b * TP + PW + q4 * 4;
-                    xrow[0] = o[0]; xrow[1] = o[1]; xrow[2] = o[2]; xrow[3] = o[3];
+                    *reinterpret_cast<float4*>(Xs + cx * RS + b * TP + DOFF + q4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
                     if (mine) *reinterpret_cast<float4*>(d.xout + ((long long)cx * B + b) * 16 + q4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
-                    if (q4 == 0) {
-                        float* xr = Xs + cx * RS + b * TP;
-                        xr[0] = 0.f; xr[PW + 16] = 0.f;
-                        if (b == 0) Xs[cx * RS + B * TP] = 0.f;
-                        if (mine) { rsum[((cx / nwg) * B + b) * 2] = s1; rsum[((cx / nwg) * B + b) * 2 + 1] = s2; }
-                    }
+                    if (q4 == 0 && mine) { rsum[((cx / nwg) * B + b) * 2] = s1; rsum[((cx / nwg) * B + b) * 2 + 1] = s2; }
                 }
             }
         }
@@ -816,8 +837,8 @@ __device__ __forceinline__ void bnet_stage_pre(const TrunkBwdNetArgs& a, const T
         const float m1 = pglu ? st[2 * (c + C)] : 0.f, r1 = pglu ? st[2 * (c + C) + 1] : 1.f;
         const int t0 = q4 * E;
         const float* dyr = d.dy + ((long long)c * B + b) * T4 + t0;
-        const float* x0r = d.px + ((long long)c * B + b) * T4 + t0;
-        const float* x1r = d.px + ((long long)(c + C) * B + b) * T4 + t0;
+        const float* x0r = d.px + ((long long)c * PB + b) * T4 + t0;
+        const float* x1r = d.px + ((long long)(c + C) * PB + b) * T4 + t0;
         float vd[8], v0[8], v1[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -849,23 +870,20 @@ __device__ __forceinline__ void bnet_stage_pre(const TrunkBwdNetArgs& a, const T
         if (live) {
             const bool mine = (cx % nwg) == me;
             const float gr = gate ? g1 * r1 : g0 * r0;
-            float* xrow = Xs + cx * RS + b * TP;
+            float* xrow = Xs + cx * RS + b * TP + DOFF;
             float* od = mine ? (d.xout + ((long long)cx * B + b) * T4 + t0) : nullptr;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (e < E && (t0 + e) < T4) {
                     const float dxv = gr * (dzv[e] - s1 * invT - xhv[e] * (s2 * invT));
-                    xrow[PW + t0 + e] = dxv;
+                    xrow[t0 + e] = dxv;
                     if (od) od[e] = dxv;
                 }
             }
-            if (q4 == 0) {
-                xrow[0] = 0.f; xrow[PW + T4] = 0.f;
-                if (b == 0) Xs[cx * RS + B * TP] = 0.f;
-                if (mine) { rsum[((cx / nwg) * B + b) * 2] = s1; rsum[((cx / nwg) * B + b) * 2 + 1] = s2; }
-            }
+            if (q4 == 0 && mine) { rsum[((cx / nwg) * B + b) * 2] = s1; rsum[((cx / nwg) * B + b) * 2 + 1] = s2; }
         }
     }
+    trunk_zero_gaps(Xs, Cx, B, TP, RS, DOFF, tid, kNetThreads);
     __syncthreads();
     // d(gamma), d(beta) of the owned channels: sums over the samples in a fixed order
     for (int j = tid; j * nwg + me < Cx; j += kNetThreads) {
@@ -887,12 +905,12 @@ template <int NA>
 __device__ __forceinline__ void bnet_tile(const TrunkBwdLayerDesc& d, int B, int T4, int tile, const float* Xs, float* epi, bool wt,
                                           NetW<3>& pre, float old)
 {
-    constexpr int KW = 3, PW = 1;
+    constexpr int KW = 3, DOFF = 4;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
-    const int TP = T4 + 2 * PW, RS = B * TP + 1;
+    const int TP = T4 + DOFF, RS = trunk_rs(B, T4, 3);
     const int N = B * T4;
     const int Cx = (d.pre == 2) ? 2 * d.C : d.C;
     const int K = Cx * KW;
@@ -902,19 +920,19 @@ __device__ __forceinline__ void bnet_tile(const TrunkBwdLayerDesc& d, int B, int
     const float* arow = d.wt + (long long)(r0 + (l15 < rows ? l15 : rows - 1)) * K;
     constexpr int NQ = 3, GK = 48, CH = 4;
     const int sgroups = k_count / GK;
-    const float* ap = arow + k_begin + 4 * kq;
-    float4 (&wb)[CH][NQ] = pre.wb;
+    const float* ap = arow + k_begin + 4 * NQ * kq;
+    float4 (&wb)[CH][3] = pre.wb;
     int off[NA][NQ][4];
 #pragma unroll
     for (int h = 0; h < NA; ++h) {
         const int n = l15 + 16 * h;
         int xcol = B * TP, live = 0;
-        if (n < N) { const int b = n / T4, t = n - b * T4; xcol = b * TP + t; live = 1; }
+        if (n < N) { const int b = n / T4, t = n - b * T4; xcol = b * TP + DOFF - 1 + t; live = 1; }
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int kr = 16 * q + 4 * kq + j;
+                const int kr = 4 * (NQ * kq + q) + j;
                 off[h][q][j] = (kr / KW) * RS + xcol + (live ? (kr % KW) : 0);
             }
     }
@@ -929,7 +947,7 @@ __device__ __forceinline__ void bnet_tile(const TrunkBwdLayerDesc& d, int B, int
                 for (int c = 0; c < CH; ++c) {
                     const float* pp = ap + (long long)(sg0 + c < sgroups ? sg0 + c : 0) * GK;
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) wb[c][q] = *reinterpret_cast<const float4*>(pp + 16 * q);
+                    for (int q = 0; q < NQ; ++q) wb[c][q] = *reinterpret_cast<const float4*>(pp + 4 * q);
                 }
             }
 #pragma unroll
@@ -984,7 +1002,7 @@ __global__ void __launch_bounds__(kNetThreads) trunk_bwd_net_kernel(const Twin<T
     float* Xs = smem;
     float* rsum = smem + a.x_floats;                       // [ceil(Cx / workgroups)][B][2]
     float* epi = rsum + 16 * 8 * 2 * 2;                    // (Cx <= 1024, 64 workgroups, B <= 8)
-    float* flag = epi + kNetWaves * 2 * 4 * 64;
+    float* flag = epi + kNetWaves * NA * 4 * 64;
     const int tid = threadIdx.x;
     const int N = a.B * a.T4;
     for (int l = 0; l < a.nlayers; ++l) {
@@ -1078,7 +1096,7 @@ int mcvc_fill_rows_launch(float* dst, const float* bias, int C, int per_row, hip
 bool mcvc_trunk_applies(int Cin, int KW, int M, int B, int T4, int mode, int ksplit)
 {
     if (KW != 1 && KW != 3) return false;
-    if (B * T4 > 32 || T4 > 32 || B > 8) return false;
+    if (B * T4 > 64 || T4 > 32 || B > 8) return false;
     const int K = Cin * KW;
     if (ksplit < 1 || (K % ksplit) != 0) return false;
     const int kblk = K / ksplit;
@@ -1092,9 +1110,8 @@ bool mcvc_trunk_applies(int Cin, int KW, int M, int B, int T4, int mode, int ksp
 
 long long mcvc_trunk_lds_floats(int Cin, int KW, int B, int T4, int ksplit)
 {
-    const int TP = T4 + (KW - 1);
-    const long long xs = (long long)(Cin / ksplit) * (B * TP + 1);
-    const long long epi = kTrunkWaves * 2 * 4 * 64 + 16 * 33 + 16 * B * 2 + 16;
+    const long long xs = (long long)(Cin / ksplit) * trunk_rs(B, T4, KW) + 4;
+    const long long epi = trunk_epi_floats(trunk_na(B * T4));
     return xs > epi ? xs : epi;
 }
 
@@ -1117,39 +1134,63 @@ static int trunk_launch_t(const TrunkArgs& a, dim3 grid, size_t lds, hipStream_t
     return a.pre ? trunk_launch_p<KW, NA, true>(a, grid, lds, s) : trunk_launch_p<KW, NA, false>(a, grid, lds, s);
 }
 
+template <int KW>
+static int trunk_launch_k(const TrunkArgs& a, dim3 grid, size_t lds, hipStream_t s)
+{
+    switch (trunk_na(a.N)) {
+    case 1: return trunk_launch_t<KW, 1>(a, grid, lds, s);
+    case 2: return trunk_launch_t<KW, 2>(a, grid, lds, s);
+    case 3: return trunk_launch_t<KW, 3>(a, grid, lds, s);
+    default: return trunk_launch_t<KW, 4>(a, grid, lds, s);
+    }
+}
+
 int mcvc_trunk_launch(const TrunkArgs& a, int ksplit, hipStream_t s)
 {
     if (!mcvc_trunk_applies(a.Cin, a.KW, a.M, a.B, a.T4, a.mode, ksplit)) return MCVC_ERR_INVALID;
     if (ksplit > 1 && !(a.mode == TRUNK_PLAIN && (a.accumulate || a.slabs))) return MCVC_ERR_INVALID;
     if (a.slab_all && !(a.mode == TRUNK_PLAIN && a.slabs)) return MCVC_ERR_INVALID;
-    if (a.pre && (a.mode != TRUNK_PLAIN || a.T4 > 32 || !a.pre_x || !a.pre_stats || !a.pre_out)) return MCVC_ERR_INVALID;
+    if (a.pre && (a.mode != TRUNK_PLAIN || a.T4 > 32 || !a.pre_x || !a.pre_stats || !a.pre_out || (a.pre_xB > 0 && a.pre_xB < a.B))) return MCVC_ERR_INVALID;
     const int rows = (a.mode == TRUNK_IN_GLU) ? 8 : 16;
     dim3 grid((unsigned)(a.M / rows), (unsigned)ksplit);
     size_t lds = (size_t)mcvc_trunk_lds_floats(a.Cin, a.KW, a.B, a.T4, ksplit) * sizeof(float);
     if (a.pre) {          // + [channels of a K slice][B][2] row sums behind the staged slice
-        const long long xs = (long long)(a.Cin / ksplit) * (a.B * (a.T4 + a.KW - 1) + 1) + (long long)(a.Cin / ksplit) * a.B * 2;
+        const long long xs = (long long)(a.Cin / ksplit) * trunk_rs(a.B, a.T4, a.KW) + 4 + (long long)(a.Cin / ksplit) * a.B * 2;
         if ((size_t)xs * sizeof(float) > lds) lds = (size_t)xs * sizeof(float);
         if (lds > 160 * 1024) return MCVC_ERR_INVALID;
     }
     const double mt = (a.mode == TRUNK_IN_GLU) ? 2.0 * a.M : (double)a.M;
     TraceScope ts(K_TRUNK, s, 2.0 * mt * a.K * a.N, 4.0 * (mt * a.K + (double)a.Cin * a.N + 3.0 * mt * a.N));
-    const bool wide = a.N > 16;
-    if (a.KW == 3) return wide ? trunk_launch_t<3, 2>(a, grid, lds, s) : trunk_launch_t<3, 1>(a, grid, lds, s);
-    return wide ? trunk_launch_t<1, 2>(a, grid, lds, s) : trunk_launch_t<1, 1>(a, grid, lds, s);
+    return a.KW == 3 ? trunk_launch_k<3>(a, grid, lds, s) : trunk_launch_k<1>(a, grid, lds, s);
 }
+
+// widest staged input of the persistent forward: 512 channels, k = 3
+static long long net_fwd_lds_floats(int B, int T4) { return (long long)512 * trunk_rs(B, T4, 3) + 4 + trunk_epi_floats(trunk_na(B * T4)); }
+// ... of the persistent backward: 1024 channels (value | gate), k = 3, + the owners' row sums
+static long long net_bwd_lds_floats(int B, int T4) { return (long long)1024 * trunk_rs(B, T4, 3) + 4 + 16 * 8 * 2 * 2 + kNetWaves * trunk_na(B * T4) * 4 * 64 + 16; }
+
+// The persistent kernels' workgroups wait for each other inside the kernel: all kNetGrid of them (x 2 in a grouped launch) must be
+// resident at once, each on a compute unit of its own when its LDS exceeds half a CU's.  The caller states how many such passes it keeps in
+// flight (mcvc_set_trunk_residency); the kernels are used only when the device has the CUs for all of them.
+static int g_trunk_passes_in_flight = 2;          // grouped launches of 2 x 64 workgroups
+static int device_cus()
+{
+    static const int n = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0; return v; }();
+    return n;
+}
+int mcvc_trunk_set_passes_in_flight(int n) { const int was = g_trunk_passes_in_flight; if (n >= 1) g_trunk_passes_in_flight = n; return was; }
+static bool trunk_residency_ok() { const int cus = device_cus(); return cus <= 0 || kNetGrid * g_trunk_passes_in_flight <= cus; }
 
 bool mcvc_trunk_net_applies(int B, int T4)
 {
-    if (B < 1 || B > 8 || T4 < 1 || T4 > 32 || B * T4 > 32) return false;
-    const long long x = (long long)512 * (B * (T4 + 2) + 1);          // widest staged input: 512 channels, k = 3
-    return (x + kNetEpiFloats) * 4 <= 156 * 1024;
+    if (B < 1 || B > 8 || T4 < 1 || T4 > 32 || B * T4 > 48) return false;          // (64 columns never fit the LDS beside 512 staged channels)
+    return trunk_residency_ok() && net_fwd_lds_floats(B, T4) * 4 <= 156 * 1024;
 }
 
 bool mcvc_trunk_bwd_net_applies(int B, int T4)
 {
     if (B < 1 || B > 8 || T4 < 4 || T4 > 32 || B * T4 > 32) return false;
-    const long long x = (long long)1024 * (B * (T4 + 2) + 1);          // widest staged gradient: 1024 channels (value | gate), k = 3
-    return (x + 16 * 8 * 2 * 2 + kNetWaves * 2 * 4 * 64 + 16) * 4 <= 156 * 1024;
+    return trunk_residency_ok() && net_bwd_lds_floats(B, T4) * 4 <= 156 * 1024;
 }
 
 // test hook (mcvc_debug_trunk_fault_inject): the next persistent launches lose one arrival, so that the give-up path can be exercised
@@ -1169,7 +1210,9 @@ int mcvc_trunk_fwd_net_launch(TrunkFwdNetArgs& a, hipStream_t s)
         if (K % (gk * kNetWaves) != 0 || d.rows < 1 || d.rows > 16 || d.M % d.rows != 0) return MCVC_ERR_INVALID;
         if (d.mode == TRUNK_IN_GLU && d.rows > 8) return MCVC_ERR_INVALID;
         if (d.mode != TRUNK_IN_GLU && d.mode != TRUNK_IN) return MCVC_ERR_INVALID;
-        const long long x = (long long)d.Cin * (a.B * (a.T4 + d.KW - 1) + 1);
+        const int rows_tot = d.mode == TRUNK_IN_GLU ? 2 * d.rows : d.rows;
+        if (d.rows * N > kNetThreads || rows_tot * N > 2 * kNetThreads) return MCVC_ERR_INVALID;       // epilogue: one / two elements per thread
+        const long long x = (long long)d.Cin * trunk_rs(a.B, a.T4, d.KW) + 4;
         if (x > xmax) xmax = x;
         const double mt = (d.mode == TRUNK_IN_GLU) ? 2.0 * d.M : (double)d.M;
         flops += 2.0 * mt * K * N;
@@ -1177,22 +1220,22 @@ int mcvc_trunk_fwd_net_launch(TrunkFwdNetArgs& a, hipStream_t s)
     }
     a.x_floats = (int)((xmax + 3) & ~3LL);
     a.fault_inject = g_trunk_fault_inject;
-    const size_t lds = ((size_t)a.x_floats + kNetEpiFloats) * sizeof(float);
+    const int NA = trunk_na(N);
+    const size_t lds = ((size_t)a.x_floats + trunk_epi_floats(NA)) * sizeof(float);
     if (lds > 160 * 1024) return MCVC_ERR_INVALID;
     hipError_t e = hipSuccess;
     // arrival counters back to zero (a kernel, not a memset: it takes part in grouped launches); the error word is sticky (mcvc_gen_trunk_fault)
     mcvc_launch(zero_words_kernel, dim3(1), dim3(64), 0, s, ZeroWordsKArgs{a.sync, MCVC_TRUNK_SYNC_WORDS - 1});
     TraceScope ts(K_TRUNK, s, flops, bytes);
-    const bool wide = N > 16;
-    static bool done[2] = {false, false};
-    if (!done[wide]) {
-        const void* fn = wide ? reinterpret_cast<const void*>(trunk_fwd_net_kernel<2>) : reinterpret_cast<const void*>(trunk_fwd_net_kernel<1>);
-        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static bool done[4] = {false, false, false, false};
+    typedef void (*KernT)(const Twin<TrunkFwdNetArgs>);
+    const KernT fns[4] = {nullptr, trunk_fwd_net_kernel<1>, trunk_fwd_net_kernel<2>, trunk_fwd_net_kernel<3>};
+    if (!done[NA]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[NA]), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        done[wide] = true;
+        done[NA] = true;
     }
-    if (wide) mcvc_launch(trunk_fwd_net_kernel<2>, dim3(kNetGrid), dim3(kNetThreads), lds, s, a);
-    else mcvc_launch(trunk_fwd_net_kernel<1>, dim3(kNetGrid), dim3(kNetThreads), lds, s, a);
+    mcvc_launch(fns[NA], dim3(kNetGrid), dim3(kNetThreads), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -1206,20 +1249,21 @@ int mcvc_trunk_bwd_net_launch(TrunkBwdNetArgs& a, hipStream_t s)
         const TrunkBwdLayerDesc& d = a.L[l];
         const int Cx = (d.pre == 2) ? 2 * d.C : d.C;
         const int K = Cx * 3;
-        if ((d.pre != 1 && d.pre != 2) || Cx > 1024 || K % (48 * kNetWaves) != 0 || d.rows < 1 || d.rows > 16 || d.M % d.rows != 0 || d.rows * N > kNetThreads)
+        if ((d.pre != 1 && d.pre != 2) || Cx > 1024 || K % (48 * kNetWaves) != 0 || d.rows < 1 || d.rows > 16 || d.M % d.rows != 0 || d.rows * N > kNetThreads ||
+            (d.pxB > 0 && d.pxB < a.B))
             return MCVC_ERR_INVALID;
-        const long long x = (long long)Cx * (a.B * (a.T4 + 2) + 1);
+        const long long x = (long long)Cx * trunk_rs(a.B, a.T4, 3) + 4;
         if (x > xmax) xmax = x;
         flops += 2.0 * d.M * K * N;
         bytes += 4.0 * ((double)d.M * K + 3.0 * Cx * N + 2.0 * d.M * N);
     }
     a.x_floats = (int)((xmax + 3) & ~3LL);
     a.fault_inject = g_trunk_fault_inject;
-    const size_t lds = ((size_t)a.x_floats + 16 * 8 * 2 * 2 + kNetWaves * 2 * 4 * 64 + 16) * sizeof(float);
+    const bool wide = N > 16;
+    const size_t lds = ((size_t)a.x_floats + 16 * 8 * 2 * 2 + kNetWaves * (wide ? 2 : 1) * 4 * 64 + 16) * sizeof(float);
     if (lds > 160 * 1024) return MCVC_ERR_INVALID;
     mcvc_launch(zero_words_kernel, dim3(1), dim3(64), 0, s, ZeroWordsKArgs{a.sync, MCVC_TRUNK_SYNC_WORDS - 1});
     TraceScope ts(K_TRUNK, s, flops, bytes);
-    const bool wide = N > 16;
     static bool done[2] = {false, false};
     if (!done[wide]) {
         const void* fn = wide ? reinterpret_cast<const void*>(trunk_bwd_net_kernel<2>) : reinterpret_cast<const void*>(trunk_bwd_net_kernel<1>);

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MCVC_LIB: another build of the same library (same-box A/B of two kernel variants: tools/ab_lib.sh); it must export the same ABI version
 LIB_PATH = os.environ.get("MCVC_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libmcvc_hip.so")
 
+ABI_VERSION = 2                       # include/mcvc.h MCVC_ABI_VERSION
 GEN_NPARAMS = 110
 DISC_NPARAMS = 20
 N_MEL = 80
@@ -54,6 +55,11 @@ _SIGS = {
                                           c_void_p, c_void_p, _PP]),
     "mcvc_gen_backward_flags": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int,
                                         c_void_p, c_void_p, _PP, c_int]),
+    "mcvc_gen_backward_prefix": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_longlong, c_int, c_int,
+                                         c_void_p, c_void_p, _PP, c_int]),
+    "mcvc_gen_backward_window": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong, c_int, c_int,
+                                         c_void_p, c_void_p, _PP, c_int]),
+    "mcvc_set_trunk_passes_in_flight": (c_int, [c_int]),
     "mcvc_gen_trunk_fault": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "mcvc_debug_trunk_fault_inject": (c_int, [c_int]),
     "mcvc_gen_bf16_packed_bytes": (c_longlong, []),
@@ -110,7 +116,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the ABI and the header ever diverge
             fn.restype = res
             fn.argtypes = args
-        if L.mcvc_version() != 1:
+        if L.mcvc_version() != ABI_VERSION:
             raise RuntimeError("libmcvc_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -120,9 +120,7 @@ class TrainEngine:
             self._p_tab[n] = ptr_table(ps)
             it = iter(gv)
             self._g_tab[n] = ptr_table([None if i in _DEAD else next(it) for i in range(len(ps))])
-        self._g_tab2 = {}
-        for n, gv in zip(G_NAMES, self.g_group.second_grad_views()):
-            self._g_tab2[n] = ptr_table(gv)
+        self._g_tab2 = None                    # second generator-gradient buffer (196 MB): created on first use (MCVC_GROUPED_IDENT=1 only)
         # flat-buffer range of each discriminator's live parameters (the discriminator pairs are updated separately when pipelined)
         self._d_ranges = {}
         d_off = [o[0] for o in self.d_group.offsets] + [self.d_group.numel]
@@ -141,6 +139,7 @@ class TrainEngine:
         # kernels are latency-bound and far from filling 256 CUs, so the two chains run as two "lanes" on two HIP
         # streams (lane 0 = the caller's stream) and overlap on the chip; join points are stream-event waits.
         self.concurrent = True
+        self._serial = False                   # bench / tools: submit the task graphs of the CURRENT schedule in order on one stream (per-kernel tracing)
         # two sets of side lanes: the four-lane schedule keeps the streams (and the auxiliary streams created right behind them) it was
         # tuned on -- with probed lanes its auxiliary streams land on the lanes' queues: bs=8 30.5 -> 32.3 ms, bs=32 116.5 -> 118.0 -- the
         # grouped / pipelined schedule uses lanes probed onto distinct hardware queues (_pick_side_streams)
@@ -199,8 +198,25 @@ class TrainEngine:
         # generator phase, as one task graph (_pipelined_step); MCVC_PIPELINE=0 keeps the two phases of an iteration back to back.
         self.pipelined = os.environ.get("MCVC_PIPELINE", "1") != "0"
         self.ranged_update = os.environ.get("MCVC_RANGED_UPDATE", "1") != "0"
+        # Merged forwards (r4): the discriminator phase's generator forwards of iteration t (train.py:259-273) read the same generator
+        # weights as the generator phase's forwards of iteration t+1 (:203-210) and need no gradient: they ride in those passes as one
+        # more sample (_merged_step).  MCVC_MERGED_FWD=0 restores the separate passes of _pipelined_step.
+        # Measured on one MI355X (r4, bs=1, ms per iteration, same box back to back): separate passes 6.00-6.16, merged 6.20-6.26, merged +
+        # the identity sample's backward ahead of the chain (MCVC_EARLY_IDENT=1) 6.49-6.57.  The merged passes do 0.8 ms less kernel work
+        # per iteration, but a three-sample pass takes 1.0 ms against 0.6 for one sample (the Winograd products are MFMA-bound, not
+        # launch-bound) and it runs ALONE where the separate passes overlapped two chains: same critical chain, same wall.  Default: merged
+        # on data-parallel ranks only -- there one grouped persistent trunk pass in flight instead of two leaves half the compute units to
+        # RCCL's kernels (csrc/trunk.h residency rule) -- separate passes on a single GPU.
+        mf = os.environ.get("MCVC_MERGED_FWD")
+        self.merged = (self.reducer.world > 1) if mf is None else (mf != "0")
+        self.early_ident = os.environ.get("MCVC_EARLY_IDENT", "0") != "0"
         self.bwd_no_join = os.environ.get("MCVC_BWD_NO_JOIN", "1") != "0"
         self._pending_D = None                  # (input set, discriminator lr) of the iteration whose discriminator phase is still to run
+        self._skip_dgen = os.environ.get("MCVC_DEBUG_SKIP_DGEN") == "1"
+        if self._skip_dgen:
+            import warnings
+            warnings.warn("MCVC_DEBUG_SKIP_DGEN=1: the discriminator phase's generator forwards are SKIPPED -- the discriminators train on "
+                          "stale buffers; this is a timing ablation, never a training configuration")
         self.slots_done = torch.zeros(2 * _BLOCK, device=dev)          # loss slots of the last COMPLETE iteration
         self._done_host = torch.zeros(2 * _BLOCK).pin_memory()
         self._done_event = torch.cuda.Event()
@@ -318,16 +334,19 @@ class TrainEngine:
             if L.mcvc_gen_out_frames(T) != T:
                 raise ValueError("training needs n_frames to be a multiple of 4 (the cycle must return the input length)")
             T8 = L.mcvc_disc_out_frames(T)
-            B2 = 2 * B
+            B2, B3 = 2 * B, 3 * B
             f = lambda *s: torch.empty(s, device=dev)   # noqa: E731
             mel2 = lambda: f(B2, 80, T)                  # noqa: E731
+            mel3 = lambda: f(B3, 80, T)                  # noqa: E731
+            mg = self._merged_ok(B)
             ws = dict(
                 g_stash2=[f(L.mcvc_gen_stash_floats(B2, T)) for _ in range(2)],      # translation+identity passes
                 g_stash1=[f(L.mcvc_gen_stash_floats(B, T)) for _ in range(2)],       # cycle passes
                 d_stash1=[f(L.mcvc_disc_stash_floats(B, T)) for _ in range(4)],
                 d_stash2=[f(L.mcvc_disc_stash_floats(B2, T)) for _ in range(4)],
                 g_stash3=[f(L.mcvc_gen_stash_floats(B, T)) for _ in range(2)],       # identity passes as their own chain (grouped schedule)
-                g_scratch=[f(max(L.mcvc_gen_scratch_floats(B, T), L.mcvc_gen_scratch_floats(B2, T))) for _ in range(6)],   # one per concurrent pass
+                g_scratch=[f(max(L.mcvc_gen_scratch_floats(B, T), L.mcvc_gen_scratch_floats(B2, T), L.mcvc_gen_scratch_floats(B3, T) if mg else 0))
+                           for _ in range(6)],           # one per concurrent pass
                 d_scratch=[f(max(L.mcvc_disc_scratch_floats(B, T), L.mcvc_disc_scratch_floats(B2, T))) for _ in range(4)],
                 static_sets=[[f(B, 80, T) for _ in range(4)] for _ in range(2)],       # real_A, mask_A, real_B, mask_B (x2: pipelined step)
                 g_stashD=[f(L.mcvc_gen_stash_floats(B, T)) for _ in range(2)],         # the discriminator phase's generator forwards, when pipelined
@@ -340,6 +359,15 @@ class TrainEngine:
                 dout1=[f(B, 1, 10, T8) for _ in range(4)], dlogit1=[f(B, 1, 10, T8) for _ in range(4)],
                 dout2=[f(B2, 1, 10, T8) for _ in range(4)], dlogit2=[f(B2, 1, 10, T8) for _ in range(4)],
             )
+            if mg:
+                # merged forwards (_merged_step): [identity | translation | the previous iteration's D-phase translation] per generator, and
+                # [cycle | the previous iteration's D-phase cycle]
+                ws.update(
+                    g_stash3x=[f(L.mcvc_gen_stash_floats(B3, T)) for _ in range(2)], g_stash2c=[f(L.mcvc_gen_stash_floats(B2, T)) for _ in range(2)],
+                    in3={n: mel3() for n in G_NAMES}, mask3={n: torch.ones(B3, 80, T, device=dev) for n in G_NAMES},
+                    out3={n: mel3() for n in G_NAMES}, gout3={n: mel2() for n in G_NAMES},
+                    cyc2={"A": mel2(), "B": mel2()},
+                )
             self._workspaces[B] = ws
             for sc in ws["g_scratch"]:      # the persistent trunk kernels' error word is sticky and not initialised by the passes
                 for nb in (B, B2):
@@ -347,6 +375,14 @@ class TrainEngine:
         self.B = B
         for k, v in ws.items():
             setattr(self, k, v)
+        # persistent trunk passes this engine keeps in flight at once (the kernels need all their workgroups resident: csrc/trunk.h).  Merged
+        # schedule: one grouped forward (or backward) pass at a time = 2; the earlier pipelined schedule ran the D-phase's generator
+        # forwards beside the G-phase's = 4.  A data-parallel rank leaves room for RCCL's own kernels (one more pass's worth of CUs).
+        if self._use_grouped():
+            inflight = 4 if (not self._use_merged() or (self.early_ident and self.reducer.world == 1)) else 2
+        else:
+            inflight = 2
+        self.L.mcvc_set_trunk_passes_in_flight(inflight + (1 if self.reducer.world > 1 else 0))
         self._cur_set = 0
         self.static_in = self.static_sets[0]
 
@@ -374,7 +410,7 @@ class TrainEngine:
         stream (lane 0 = the caller's stream) after the events named in ``waits``; ``record`` names the event recorded behind it.  Work of
         one lane is ordered by its stream, cross-lane edges are events, everything joins the caller's stream at the end.  Serial mode runs
         the same list in order on one stream."""
-        if not self.concurrent:
+        if not self.concurrent or self._serial:
             for lane, fn, _, _ in tasks:
                 fn(lane)
             return
@@ -394,7 +430,7 @@ class TrainEngine:
                     e0.record(st)
                     fn(lane)
                     e1.record(st)
-                    self._timeline.append((ti, lane, rec, waits, e0, e1))
+                    self._timeline.append((ti, lane, "%s:%s" % (getattr(fn, "__name__", "?"), rec), waits, e0, e1))
                 else:
                     fn(lane)
                 if rec is not None:
@@ -455,18 +491,20 @@ class TrainEngine:
                    lambda: check(self.L.mcvc_gen_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(mask), ptr(out), ptr(stash),
                                                          ptr(sc), sc.numel(), nb, self.T, stream()), "gen_forward"))
 
-    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0, milestones=False, aux_lane=None, ms_of=None, second=False, no_join=False):
+    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0, milestones=False, aux_lane=None, ms_of=None, second=False, no_join=False,
+               stash_nb=None, stash_b0=0):
         """``lane`` picks the scratch buffer; ``aux_lane`` (default: the same) the auxiliary weight-gradient stream -- the two halves of a
-        grouped pass use different scratch buffers but the same streams and milestone events (``ms_of``)."""
+        grouped pass use different scratch buffers but the same streams and milestone events (``ms_of``).  ``stash_nb``: batch of the forward
+        pass that wrote ``stash`` when this pass back-propagates through its samples [stash_b0, stash_b0 + nb) only (mcvc_gen_backward_window)."""
         sc = self.g_scratch[lane]
         ms = self._ms[ms_of or name][1] if milestones else None
         aux = self._aux_ptr(lane if aux_lane is None else aux_lane)
-        gtab = self._g_tab2[name] if second else self._g_tab[name]          # second: weight gradients into the second buffer
+        gtab = self._second_tab(name) if second else self._g_tab[name]      # second: weight gradients into the second buffer
         self._pass(("Gb", name, 0 if mask is None else mask.data_ptr(), dout.data_ptr(), 0 if dx is None else dx.data_ptr(), acc, stash.data_ptr(),
-                    nb, lane, bool(milestones), self.aux_wgrad, second, no_join),
-                   lambda: check(self.L.mcvc_gen_backward_flags(self._p_tab[name], ptr(self.packed[name]), gtab, ptr(mask), ptr(dout),
-                                                                ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(),
-                                                                aux, ms, 1 if no_join else 0), "gen_backward"))
+                    nb, lane, bool(milestones), self.aux_wgrad, second, no_join, stash_nb, stash_b0),
+                   lambda: check(self.L.mcvc_gen_backward_window(self._p_tab[name], ptr(self.packed[name]), gtab, ptr(mask), ptr(dout),
+                                                                 ptr(dx), acc, ptr(stash), stash_nb or nb, stash_b0, ptr(sc), sc.numel(), nb, self.T,
+                                                                 stream(), aux, ms, 1 if no_join else 0), "gen_backward"))
 
     def _D(self, name, x, out, stash, nb, lane=0):
         sc = self.d_scratch[lane]
@@ -482,6 +520,11 @@ class TrainEngine:
                    lambda: check(self.L.mcvc_disc_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name] if with_weight_grads else None,
                                                            ptr(dlogit), 1, ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(), aux),
                                  "disc_backward"))
+
+    def _second_tab(self, name):
+        if self._g_tab2 is None:
+            self._g_tab2 = {n: ptr_table(gv) for n, gv in zip(G_NAMES, self.g_group.second_grad_views())}
+        return self._g_tab2[name]
 
     def _slot(self, i):
         return self.slots[i:i + 1]
@@ -852,13 +895,13 @@ class TrainEngine:
             return lambda ln: self._twin(lambda: fn(a, *args), lambda: fn(b, *args))
 
         def gen_fwd(ln):
-            if os.environ.get("MCVC_DEBUG_SKIP_DGEN") == "1":      # TIMING EXPERIMENT ONLY (wrong losses): what the D-phase generator forwards cost
+            if self._skip_dgen:                    # TIMING EXPERIMENT ONLY (wrong losses): what the D-phase generator forwards cost
                 return
             self._twin(lambda: self._G(A2B, real_A, mask_A, gen_B, gst[0], B, s0),                          # :267 generated_B
                        lambda: self._G(B2A, real_B, mask_B, gen_A, gst[1], B, s1))                          # :259 generated_A
 
         def cycles(ln):
-            if os.environ.get("MCVC_DEBUG_SKIP_DGEN") == "1":
+            if self._skip_dgen:
                 return
             self._twin(lambda: self._G(B2A, gen_B, None, cyc_A, gst[0], B, s0),                             # :271 cycled_A
                        lambda: self._G(A2B, gen_A, None, cyc_B, gst[1], B, s1))                             # :263 cycled_B
@@ -944,7 +987,8 @@ class TrainEngine:
         g = self._g_parts(cur, True, own_d_update=prev is None, ident_second=second, zeroing_update=True, ranged=ranged)
         ident, ov = g["ident"], g["ov"]
         tail = [(2, g["ident_chain"], (), "i")] if (ident and second) else []
-        head = [(2, g["ident_chain"], (), "i")] if (ident and not second) else []
+        # (the chain's backward reads the generators' backward-only weight copies, which lane 3 refreshes first: "rf")
+        head = [(2, g["ident_fwd"], (), None), (2, g["ident_bwd"], ("rf",) if self._pending_D is not None else (), "i")] if (ident and not second) else []
         upd_waits = ("i",) if (ident and second) else ()
         bwd_waits = ("d1", "i") if (ident and not second) else ("d1",)
         if prev is None:                       # first iteration (or the first after a flush): there is no discriminator phase to run beside it
@@ -1028,6 +1072,165 @@ class TrainEngine:
         d["post"]()
         self.slots_done[_BLOCK:].copy_(self.slots[_BLOCK:])           # d_loss and its terms of iteration t: the iteration is complete
         self._publish_done()
+
+
+    # ---- merged forwards (r4) ---------------------------------------------------------------------------------------------------------
+    def _merged_ok(self, B):
+        """Three samples per generator pass must stay inside the fused 1-D trunk kernels (csrc/trunk.h: 48 columns at 64 frames)."""
+        return 3 * B * (self.T // 4) <= 48 and self.T % 4 == 0
+
+    def _use_merged(self):
+        return self.merged and self._use_pipeline() and not self.grouped_ident and self._merged_ok(self.B) and hasattr(self, "in3")
+
+    def _merged_step(self):
+        """``_pipelined_step`` with the discriminator phase's generator forwards INSIDE the generator phase's passes.
+
+        D-phase(t) needs generated = G(real(t), mask(t)) and cycled = G'(generated) with the weights Adam(G)(t) left (train.py:259-273), and
+        discards their backward (reset_grad at :240 of t+1).  G-phase(t+1) runs translation + identity and then cycle forwards with exactly
+        those weights (:203-210).  So one grouped pass per generator carries THREE samples
+            [ identity: real_other(t+1) | ones ;  translation: real(t+1) | mask(t+1) ;  D-phase translation: real(t) | mask(t) ]
+        and the cycle pass TWO: [ fake(t+1) ; generated(t) ] (contiguous rows of the first pass's output).  The backward passes run over the
+        first two / the first sample of those stashes (mcvc_gen_backward_prefix).  Per-sample results are what the separate passes compute
+        (every op of the generator is per sample): parity tests in tests/test_hip_twin.py.  Two of the six grouped generator passes of an
+        iteration disappear; one persistent trunk pass is in flight at a time instead of two.
+            lane 0:  forward x3 -> cycle x2 -> ("d1", "d2") backward cycle -> backward translation + identity -> Adam(G) head + re-pack
+            lane 1:  ("g") D_A | D_B of D-phase(t) -> Adam + re-pack of their slice -> first-step adversarial pair of G-phase(t+1)   "d1"
+            lane 2:  ("c") D_A2 | D_B2 of D-phase(t) -> Adam + re-pack -> second-step adversarial pair                             "d2"
+            lane 3:  backward-only weight copies ("rf"); the backward passes' weight gradients; the ranged generator update"""
+        cur = self.static_in
+        prev, d_lr = self._pending_D if self._pending_D is not None else (None, None)
+        B, B2, B3 = self.B, 2 * self.B, 3 * self.B
+        A2B, B2A = G_NAMES
+        sc = self.sched
+        cl, il = sc.cycle_loss_lambda, sc.identity_loss_lambda
+        ranged = self.ranged_update and self.reducer.world == 1
+        # The identity sample's backward depends on nothing but its own forward (train.py:223-224): it runs as soon as the cycle forwards
+        # have left the chip, beside the discriminators of the cycle chain, into the SECOND gradient buffer (Adam consumes the sum) -- the
+        # last backward pass of the chain is then a one-sample pass.  Data parallel: one gradient buffer is exchanged, the identity sample
+        # stays in the last pass.  MCVC_EARLY_IDENT=0: A/B.
+        early = self.early_ident and self.reducer.world == 1
+        g = self._g_parts(cur, True, own_d_update=False, ident_second=early, zeroing_update=True, ranged=ranged)     # (update / reduce / post closures)
+        ov = g["ov"]
+        ms_on = ov or ranged
+        real_A, mask_A, real_B, mask_B = cur
+        p_real_A, p_mask_A, p_real_B, p_mask_B = prev if prev is not None else cur          # (first iteration: a throw-away third sample)
+        in3, mask3, out3, gout3, cyc2 = self.in3, self.mask3, self.out3, self.gout3, self.cyc2
+        identity_B, fake_B, gen_B = out3[A2B][:B], out3[A2B][B:B2], out3[A2B][B2:]
+        identity_A, fake_A, gen_A = out3[B2A][:B], out3[B2A][B:B2], out3[B2A][B2:]
+        g_identity_B, g_fake_B = gout3[A2B][:B], gout3[A2B][B:]
+        g_identity_A, g_fake_A = gout3[B2A][:B], gout3[B2A][B:]
+        cycle_A, cyc_A = cyc2["A"][:B], cyc2["A"][B:]
+        cycle_B, cyc_B = cyc2["B"][:B], cyc2["B"][B:]
+        m = self.mel
+        di = self.d_in
+        do, dl, ds = self.dout1, self.dlogit1, self.d_stash1
+        d = self._d_parts(prev, gi=2, aux2=None) if prev is not None else None
+        if prev is not None:
+            self.slots_done[:_BLOCK].copy_(self.slots[:_BLOCK])       # g_loss and its terms of iteration t, before the block is reused
+        # ---- on the caller's stream, before the lanes fork
+        self.slots[:_BLOCK].zero_()
+        if not self._g_grad_clean:
+            self.g_group.grad.zero_()
+        torch._foreach_copy_(
+            [in3[A2B][:B], in3[A2B][B:B2], in3[A2B][B2:], mask3[A2B][B:B2], mask3[A2B][B2:],
+             in3[B2A][:B], in3[B2A][B:B2], in3[B2A][B2:], mask3[B2A][B:B2], mask3[B2A][B2:]],
+            [real_B, real_A, p_real_A, mask_A, p_mask_A,
+             real_A, real_B, p_real_B, mask_B, p_mask_B])                # (the identity samples' masks stay all-ones)
+        if d is not None:
+            d["pre"](zero_grads=not self._d_grad_clean)
+        packed = self._g_fwd_packed
+        d_step = self.d_group.step + 1
+
+        def fwd3(ln):                                                                                       # :203, :205, :207-210 | :259, :267
+            if not packed:
+                self._twin(lambda: self._repack1(A2B), lambda: self._repack1(B2A))
+            self._twin(lambda: self._G(A2B, in3[A2B], mask3[A2B], out3[A2B], self.g_stash3x[0], B3, 0),
+                       lambda: self._G(B2A, in3[B2A], mask3[B2A], out3[B2A], self.g_stash3x[1], B3, 1))
+            if d is not None:
+                torch._foreach_copy_([di["discriminator_B"][B:], di["discriminator_A"][B:]], [gen_B, gen_A])
+
+        def cycle2(ln):                                                                                     # :204, :206 | :263, :271
+            self._twin(lambda: self._G(B2A, out3[A2B][B:], None, cyc2["A"], self.g_stash2c[0], B2, 0),
+                       lambda: self._G(A2B, out3[B2A][B:], None, cyc2["B"], self.g_stash2c[1], B2, 1))
+            if d is not None:
+                torch._foreach_copy_([di["discriminator_A2"][B:], di["discriminator_B2"][B:]], [cyc_A, cyc_B])
+            self._twin(lambda: (self._l1(cycle_A, real_A, cl, m["g_cycle_A"], 0), self._l1(identity_B, real_B, il, g_identity_B, 3)),   # :219, :224
+                       lambda: (self._l1(cycle_B, real_B, cl, m["g_cycle_B"], 1), self._l1(identity_A, real_A, il, g_identity_A, 2)))   # :220, :223
+
+        def adv_half(name, i, x, gx, acc):
+            self._D(name, x, do[i], ds[i], B, i)                                                            # :211-216
+            self._lsgan(do[i], 1.0, 1.0, 4 + i, dl[i])                                                      # :227-231
+            self._D_bwd(name, dl[i], gx, acc, ds[i], False, B, i)          # discriminators contribute data-gradients only
+
+        def adv1(ln):
+            self._twin(lambda: adv_half("discriminator_A", 0, fake_A, g_fake_A, 0), lambda: adv_half("discriminator_B", 1, fake_B, g_fake_B, 0))
+
+        def adv2(ln):
+            self._twin(lambda: adv_half("discriminator_A2", 2, cycle_A, m["g_cycle_A"], 1),
+                       lambda: adv_half("discriminator_B2", 3, cycle_B, m["g_cycle_B"], 1))
+
+        nj = self.bwd_no_join
+        fs = (4, 5) if nj else (0, 1)
+
+        def bwd_cycle(ln):      # cycle_A = G_B2A(fake_B) adds to d(fake_B), cycle_B = G_A2B(fake_A) to d(fake_A)
+            self._twin(lambda: self._G_bwd(B2A, None, m["g_cycle_A"], g_fake_B, 1, self.g_stash2c[0], B, 0, aux_lane=0, no_join=nj, stash_nb=B2),
+                       lambda: self._G_bwd(A2B, None, m["g_cycle_B"], g_fake_A, 1, self.g_stash2c[1], B, 1, aux_lane=0, no_join=nj, stash_nb=B2))
+
+        def bwd_final(ln):      # identity + translation samples; the gradient ranges become final one after the other (milestone events)
+            if early:           # ... the translation sample alone: the window [B, 2B) of the three-sample stash
+                self._twin(lambda: self._G_bwd(A2B, mask3[A2B][B:B2], g_fake_B, None, 0, self.g_stash3x[0], B, fs[0], ms_on, aux_lane=0, ms_of=A2B,
+                                               stash_nb=B3, stash_b0=B),
+                           lambda: self._G_bwd(B2A, mask3[B2A][B:B2], g_fake_A, None, 0, self.g_stash3x[1], B, fs[1], ms_on, aux_lane=0, ms_of=A2B,
+                                               stash_nb=B3, stash_b0=B))
+                return
+            self._twin(lambda: self._G_bwd(A2B, mask3[A2B], gout3[A2B], None, 0, self.g_stash3x[0], B2, fs[0], ms_on, aux_lane=0, ms_of=A2B, stash_nb=B3),
+                       lambda: self._G_bwd(B2A, mask3[B2A], gout3[B2A], None, 0, self.g_stash3x[1], B2, fs[1], ms_on, aux_lane=0, ms_of=A2B, stash_nb=B3))
+
+        def ident_bwd(ln):      # the identity samples (window [0, B)): weight gradients inline on this lane, into the second gradient buffer
+            self._twin(lambda: self._G_bwd(A2B, mask3[A2B][:B], g_identity_B, None, 0, self.g_stash3x[0], B, 2, aux_lane=1, second=True, stash_nb=B3),
+                       lambda: self._G_bwd(B2A, mask3[B2A][:B], g_identity_A, None, 0, self.g_stash3x[1], B, 3, aux_lane=1, second=True, stash_nb=B3))
+
+        def side_head(ln):                     # lane 3: the backward-only weight copies (the generator update refreshed the forward ones)
+            if packed:
+                self._twin(lambda: self._repack1(A2B, 2), lambda: self._repack1(B2A, 2))
+
+        def d_update(pair):                    # Adam on one discriminator pair's slice of the flat buffer + its re-pack
+            lo, hi = self._d_ranges[pair[0]][0], self._d_ranges[pair[1]][1]
+
+            def run(ln):
+                if self.reducer.world > 1:
+                    self.reducer.reduce_range_after_(self.d_group.grad, lo, hi, None)
+                    self.reducer.wait(self.device)
+                self._adam_range(self.d_group, lo, hi, d_lr, d_step)
+                for n in pair:
+                    self.nets[n]._packed_version = None
+                self._twin(lambda: self._repack1(pair[0]), lambda: self._repack1(pair[1]))
+            return run
+        tasks = [(3, side_head, (), "rf"), (0, fwd3, (), "g"), (0, cycle2, (), "c")]
+        if d is not None:
+            tasks += [(1, d["full1"], ("g",), None), (1, d_update(("discriminator_A", "discriminator_B")), (), None),
+                      (2, d["full2"], ("c",), None), (2, d_update(("discriminator_A2", "discriminator_B2")), (), None)]
+        if early:               # lane 3 (idle between the weight copies and the backward rounds' weight gradients), behind the cycle forwards
+            tasks += [(3, ident_bwd, ("c",), "i")]
+        uw = ("i",) if early else ()
+        tasks += [(1, adv1, ("g",), "d1"), (2, adv2, ("c",), "d2"),
+                  (0, bwd_cycle, ("d1", "d2", "rf"), None), (0, bwd_final, (), "f")]
+        if ov:
+            tasks += [(3, g["queue_reduce"], (), None)]
+        if ranged:
+            tasks += [(1, g["update_range"](0, False), uw, None), (1, g["update_range"](1, False), (), "u01"), (0, g["update_range"](2, True), uw, None)]
+        else:
+            tasks += [(0, g["update"], uw, None)]
+        self._run_tasks(tasks)
+        self._d_pack_event = None
+        self._g_grad_clean = True              # (cleared by the Adam launches that consumed them)
+        g["post"]()
+        if d is not None:
+            self.d_group.step = d_step
+            self._d_grad_clean = True
+            d["post"]()
+            self.slots_done[_BLOCK:].copy_(self.slots[_BLOCK:])           # d_loss and its terms of iteration t: the iteration is complete
+            self._publish_done()
 
     def _publish_done(self):
         """Losses of the last COMPLETE iteration to pinned host memory (asynchronous copy + event; ``losses(lagged=True)`` waits for it)."""
@@ -1245,7 +1448,10 @@ class TrainEngine:
     def _step_static(self):
         if self._use_pipeline():
             d_lr = self.sched.d_opt_lr           # what torch.optim would use for THIS iteration's discriminator step
-            self._pipelined_step()               # generator phase of this iteration (+ the previous one's discriminator phase)
+            if self._use_merged():
+                self._merged_step()              # ... with the previous discriminator phase's generator forwards inside its own passes
+            else:
+                self._pipelined_step()           # generator phase of this iteration (+ the previous one's discriminator phase)
             self._pending_D = (self.static_in, d_lr)
             self.sched.end_iteration()
             return self.slots

@@ -44,7 +44,7 @@ def init_from_env(backend=None):
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-            if torch.cuda.is_available() and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+            if torch.cuda.is_available() and _ranks_share_a_gpu(local_rank):
                 # Ranks SHARING a GPU (the single-GPU choreography tests only): the persistent trunk kernels wait inside the kernel for
                 # workgroups that must all be resident (csrc/trunk.h) -- that holds for the passes one process keeps in flight, not for
                 # two processes' worth of them on one device.  Run the trunk as per-layer launches there.
@@ -56,6 +56,18 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
+def _ranks_share_a_gpu(local_rank):
+    """True when two ranks of the job run on the same physical device -- from the ACTUAL rank -> (host, device) map (an all-gather), not
+    from LOCAL_WORLD_SIZE, which a launcher other than torchrun may not set (a 16-rank / 2-node job would otherwise be mis-read as 16
+    ranks on 8 GPUs)."""
+    import socket
+    ndev = max(torch.cuda.device_count(), 1)
+    mine = (socket.gethostname(), local_rank % ndev)
+    pairs = [None] * dist.get_world_size()
+    dist.all_gather_object(pairs, mine)
+    return len(set(pairs)) < len(pairs)
+
+
 class FlatGradReducer:
     """Sum-all-reduce a flat gradient buffer in place, in buckets, optionally on a side stream."""
 
@@ -65,6 +77,10 @@ class FlatGradReducer:
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._stream = None
         self._use_side_stream = use_side_stream
+        # bench.py --gpus N: time every wait of a compute stream for the communication stream (an event pair around the wait on the
+        # WAITING stream: what it measures is the time that stream sat blocked, i.e. the communication that was not hidden)
+        self.time_waits = False
+        self._wait_events = []
 
     @property
     def grad_scale(self):
@@ -83,7 +99,7 @@ class FlatGradReducer:
             with torch.cuda.stream(self._stream):
                 for lo in range(0, n, self.bucket_elems):
                     dist.all_reduce(flat[lo:min(n, lo + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group)
-            cur.wait_stream(self._stream)           # Adam (compute stream) consumes the reduced buffer
+            self._wait_on(cur)                      # Adam (compute stream) consumes the reduced buffer
         else:
             for lo in range(0, n, self.bucket_elems):
                 dist.all_reduce(flat[lo:min(n, lo + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group)
@@ -122,10 +138,30 @@ class FlatGradReducer:
             for a in range(lo, hi, self.bucket_elems):
                 dist.all_reduce(flat[a:min(hi, a + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group)
 
+    def _wait_on(self, cur):
+        if self.time_waits:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            cur.wait_stream(self._stream)
+            e1.record(cur)
+            self._wait_events.append((e0, e1))
+        else:
+            cur.wait_stream(self._stream)
+
     def wait(self, device=None):
         """Order the current stream after everything queued on the communication stream."""
         if self._stream is not None:
-            torch.cuda.current_stream(device).wait_stream(self._stream)
+            self._wait_on(torch.cuda.current_stream(device))
+
+    def exposed_ms(self):
+        """(total milliseconds compute streams spent blocked in ``wait``, number of waits) since the last call; synchronises the device."""
+        if not self._wait_events:
+            return 0.0, 0
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        n = len(self._wait_events)
+        self._wait_events = []
+        return ms, n
 
     def broadcast_(self, flat: torch.Tensor, src=0):
         """Make every rank start from rank ``src``'s parameters."""

@@ -163,6 +163,13 @@ class MaskCycleGANVCTraining(object):
             owed = 0                                                       # iterations issued whose losses are not logged yet
 
             def log_one(lo):
+                # A persistent trunk launch that gave up waiting poisons its pass with NaN (csrc/trunk.h): that reaches every loss term of
+                # the iteration, so the (already host-resident) losses are the per-iteration fault probe.  Stop BEFORE another step or a
+                # checkpoint can carry the poisoned gradients into the weights on disk; check_faults() names the cause.
+                if not (np.isfinite(lo["g_loss"]) and np.isfinite(lo["d_loss"])):
+                    self.engine.check_faults()
+                    raise FloatingPointError("non-finite losses (g_loss=%r, d_loss=%r): aborting without saving; resume from the last "
+                                             "checkpoint with --continue_train" % (lo["g_loss"], lo["d_loss"]))
                 self.logger.log_iter(loss_dict={"g_loss": lo["g_loss"], "d_loss": lo["d_loss"]})
                 self.logger.end_iter()
             for run_step in self._epoch_batches():
@@ -184,6 +191,7 @@ class MaskCycleGANVCTraining(object):
                 self.validate()                                            # train.py:317
             if epoch % self.epochs_per_save == 0:
                 self.engine.flush()                                        # a deferred (data-parallel) D update must land first
+                self.engine.check_faults()                                 # (device sync; never checkpoint a poisoned state)
                 self.save_all(epoch)
             self.logger.end_epoch()
             if self.args.max_iters and done >= self.args.max_iters:

@@ -174,7 +174,7 @@ def test_inference_config_bs16_512_frames(nets, meta):
     assert err < 1e-3, err
 
 
-@pytest.mark.parametrize("B,T", [(1, 64), (2, 64), (1, 32), (4, 32), (1, 128)])
+@pytest.mark.parametrize("B,T", [(1, 64), (2, 64), (1, 32), (4, 32), (1, 128), (3, 64), (6, 32), (3, 48)])
 def test_persistent_trunk_forward_matches_the_per_layer_launches(B, T):
     """The 12 dependent residual trunk layers (model.py:258-271) run as ONE persistent launch whose workgroups hand activations to each
     other inside the kernel (write-through stores, arrival counter, sc1 loads).  Same products as the per-layer fused kernels; only
@@ -271,6 +271,60 @@ def test_persistent_trunk_backward_matches_the_per_layer_launches(B, T):
     finally:
         L.mcvc_set_trunk_persistent(was)
         L.mcvc_set_deterministic(was_det)
+
+
+@pytest.mark.parametrize("B,SB,b0,T", [(2, 3, 0, 64), (1, 2, 0, 64), (1, 3, 0, 64), (1, 3, 1, 64), (1, 3, 2, 64), (2, 3, 1, 64), (2, 3, 0, 32), (2, 4, 2, 32),
+                                          (2, 4, 0, 64), (4, 6, 2, 64)])
+def test_backward_over_a_window_of_the_forward_samples(B, SB, b0, T):
+    """mcvc_gen_backward_window: a forward pass over SB samples, a backward pass through its samples [b0, b0 + B) only (the trainer's merged
+    forwards carry the previous iteration's discriminator-phase sample, whose backward the reference discards: train.py:240, 259-273; the
+    identity sample's backward runs ahead of the translation sample's).  Every op of the generator is per sample (model.py:239-280), so the
+    result must equal forward + backward over those B samples alone: input gradient and every parameter gradient to rounding (the two
+    forwards pick different tile shapes / K splits)."""
+    from mask_cyclegan_vc._hip import check, lib, ptr, ptr_table, stream
+    L = lib()
+    g = Generator()
+    g.load_state_dict(orc.filler_params("G", 41), strict=True)
+    g = g.cuda()
+    ps = list(g.parameters())
+    packed = g.packed_weights(ps, force=True)
+    tab = ptr_table(ps)
+    n_scr = max(L.mcvc_gen_scratch_floats(B, T), L.mcvc_gen_scratch_floats(SB, T))
+    scratch = torch.zeros(n_scr, device="cuda")
+    stash_s, stash_b = torch.zeros(L.mcvc_gen_stash_floats(SB, T), device="cuda"), torch.zeros(L.mcvc_gen_stash_floats(B, T), device="cuda")
+    TO = L.mcvc_gen_out_frames(T)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(SB, 80, T, generator=gen).cuda()
+    m = torch.ones_like(x)
+    for b in range(SB):
+        m[b, :, 4 + 3 * b:9 + 5 * b] = 0
+    dout = torch.randn(B, 80, TO, generator=gen).cuda()
+    out_s, out_b = torch.empty(SB, 80, TO, device="cuda"), torch.empty(B, 80, TO, device="cuda")
+    grads = [[torch.zeros_like(p) for p in ps] for _ in range(2)]
+    dxs = [torch.zeros(B, 80, T, device="cuda") for _ in range(2)]
+    for persistent in (1, 2, 0):          # persistent forward + backward trunk, forward only, per-layer launches
+        was = L.mcvc_set_trunk_persistent(persistent)
+        try:
+            for gs in grads:
+                for gt in gs:
+                    gt.zero_()
+            check(L.mcvc_gen_forward(tab, ptr(packed), ptr(x), ptr(m), ptr(out_s), ptr(stash_s), ptr(scratch), n_scr, SB, T, stream()), "fwd SB")
+            xb, mb = x[b0:b0 + B].contiguous(), m[b0:b0 + B].contiguous()
+            check(L.mcvc_gen_backward_window(tab, ptr(packed), ptr_table(grads[0]), ptr(mb), ptr(dout), ptr(dxs[0]), 0, ptr(stash_s), SB, b0, ptr(scratch),
+                                             n_scr, B, T, stream(), None, None, 0), "bwd window")
+            check(L.mcvc_gen_forward(tab, ptr(packed), ptr(xb), ptr(mb), ptr(out_b), ptr(stash_b), ptr(scratch), n_scr, B, T, stream()), "fwd B")
+            check(L.mcvc_gen_backward(tab, ptr(packed), ptr_table(grads[1]), ptr(mb), ptr(dout), ptr(dxs[1]), 0, ptr(stash_b), ptr(scratch), n_scr, B, T,
+                                      stream(), None), "bwd B")
+            torch.cuda.synchronize()
+        finally:
+            L.mcvc_set_trunk_persistent(was)
+        assert float((out_s[b0:b0 + B] - out_b).norm()) <= 5e-5 * float(out_b.norm()), persistent
+        assert float((dxs[0] - dxs[1]).norm()) <= 1e-4 * float(dxs[1].norm()), (persistent, float((dxs[0] - dxs[1]).norm() / dxs[1].norm()))
+        for i, (a_, b_) in enumerate(zip(grads[0], grads[1])):
+            nb_ = float(b_.norm())
+            if nb_ < 1e-4:                                     # conv biases in front of an InstanceNorm: mathematically zero
+                continue
+            assert float((a_ - b_).norm()) <= 1e-4 * nb_ + 1e-9, (persistent, i, float((a_ - b_).norm()) / nb_)
 
 
 def _launches(kind_name, fn):

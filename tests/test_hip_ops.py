@@ -199,7 +199,11 @@ def test_losses_and_adam():
 
 @pytest.mark.parametrize("B,T4,Cin,Cout,KW,kind", [(1, 16, 256, 512, 3, "glu"), (2, 16, 256, 512, 3, "glu"), (2, 16, 512, 256, 3, "res"),
                                                    (1, 16, 512, 256, 3, "res"), (2, 16, 256, 5120, 1, "plain"), (4, 8, 256, 512, 3, "glu"),
-                                                   (1, 32, 512, 256, 3, "res")])
+                                                   (1, 32, 512, 256, 3, "res"),
+                                                   # r4: up to 64 columns (three / four 16-column accumulators per wave) and ragged column counts
+                                                   (3, 16, 256, 512, 3, "glu"), (3, 16, 512, 256, 3, "res"), (3, 16, 256, 5120, 1, "plain"),
+                                                   (4, 16, 256, 512, 3, "glu"), (5, 8, 256, 512, 3, "glu"),
+                                                   (3, 12, 512, 256, 3, "res"), (2, 20, 256, 5120, 1, "plain")])
 def test_fused_trunk_layer_matches_torch(B, T4, Cin, Cout, KW, kind):
     """Isolated parity of trunk_layer_kernel (SURVEY.md section 8b resblock1d / gemm1x1_in): Conv1d + InstanceNorm1d + gated GLU /
     residual in one launch vs the same ops in plain PyTorch fp32 (reference model.py:47-76, 266-267)."""

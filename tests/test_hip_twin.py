@@ -48,6 +48,7 @@ def _steps(grouped, B, n_it=2, ident=False):
     eng = TrainEngine(nets, B, 64, schedule=StepSchedule(batch_size=B, n_samples=4 * B))
     eng.grouped = grouped
     eng.grouped_ident = ident
+    eng.merged = False                     # (the merged forwards have their own test: other tile shapes, agreement to rounding)
     losses = []
     for it in range(n_it):
         eng.step(*_batch(B, 70 + it))
@@ -90,6 +91,7 @@ def test_pipelined_steps_equal_back_to_back_phases(deterministic_mode, B):
         nets = _nets(640)
         eng = TrainEngine(nets, B, 64, schedule=StepSchedule(batch_size=B, n_samples=4 * B, decay_after=2 * B, stop_identity_after=3 * B, num_epochs=3))
         eng.pipelined = pipelined
+        eng.merged = False                 # (separate D-phase generator forwards: the same kernels on the same shapes as the phases back to back)
         seen = []
         for it in range(K):
             eng.step(*_batch(B, 90 + it))
@@ -116,6 +118,47 @@ def test_pipelined_steps_equal_back_to_back_phases(deterministic_mode, B):
     for n in p0:
         for i, (a, b) in enumerate(zip(p0[n], p1[n])):
             assert torch.equal(a, b), (n, i)
+
+
+def test_merged_forwards_equal_the_separate_passes(deterministic_mode):
+    """The default bs=1 step batches iteration t's discriminator-phase generator forwards INTO iteration t+1's generator-phase passes
+    (engine._merged_step: three / two samples per pass, backward over the first two / one).  Every op of the generator is per sample, so all
+    losses of every iteration and all parameters agree with the separate passes of _pipelined_step to rounding (a three-sample pass picks
+    other tile shapes and K splits than a two-sample one: not bit-equal); both are bit-reproducible run to run; Adam step counts, learning
+    rates and the identity cut-off are those of the reference schedule; and the merged step issues fewer launches."""
+    B, K = 1, 5
+
+    def run(merged, early=False):
+        nets = _nets(640)
+        eng = TrainEngine(nets, B, 64, schedule=StepSchedule(batch_size=B, n_samples=4 * B, decay_after=2 * B, stop_identity_after=3 * B, num_epochs=3))
+        eng.merged = merged
+        eng.early_ident = early            # the identity sample's backward as its own one-sample window ahead of the chain (second gradient buffer)
+        eng._use(B)                        # (re-bind: the residency bound of the persistent trunk kernels follows the schedule)
+        assert eng._use_merged() == merged
+        seen = []
+        for it in range(K):
+            eng.step(*_batch(B, 90 + it))
+            lo = eng.losses(lagged=True)
+            assert (lo is None) == (it == 0)
+            if lo is not None:
+                seen.append(lo)
+        seen.append(eng.losses())
+        eng.flush()
+        eng.check_faults()
+        return seen, {n: [p.detach().clone() for p in nets[n].parameters()] for n in G_NAMES + D_NAMES}, (eng.g_group.step, eng.d_group.step), \
+            (eng.sched.g_opt_lr, eng.sched.d_opt_lr, eng.sched.global_step)
+    (l0, p0, s0, h0), (l1, p1, s1, h1), (l2, p2, s2, h2), (l3, p3, s3, h3) = run(False), run(True), run(True), run(True, early=True)
+    assert s0 == s1 == s3 == (K, K) and h0 == h1 == h3
+    assert l1 == l2 and all(torch.equal(a, b) for n in p1 for a, b in zip(p1[n], p2[n]))          # bit-reproducible
+    for lx, px in ((l1, p1), (l3, p3)):
+        for k in l0[0]:                    # first iteration: the same forward arithmetic up to tile shapes
+            assert abs(l0[0][k] - lx[0][k]) <= 2e-6 * abs(l0[0][k]) + 1e-8, (k, l0[0], lx[0])
+        for it, (a, b) in enumerate(zip(l0, lx)):
+            for k in a:
+                assert abs(a[k] - b[k]) < 1e-3 * abs(a[k]) + 1e-7, (it, k, a, b)
+        for n in p0:
+            for a, b in zip(p0[n], px[n]):
+                assert float((a - b).norm()) <= 0.1 * K * 2e-4 * float(a.numel()) ** 0.5 + 1e-7, n      # 10 % of "every element moved by lr" per step
 
 
 def test_grouped_step_default_mode_close_and_halves_the_launches():
