@@ -252,6 +252,38 @@ int mcvc_conv2d_dgrad(const float* dy, const float* w, float* dx, float* wpack, 
 long long mcvc_conv2d_wgrad_slab_floats(int N, int Cin, int H, int W, int Cout, int KH, int KW, int stride, int pad_h, int pad_w);
 int mcvc_conv2d_wgrad(const float* x, const float* dy, float* dw, float* slabs, long long slab_floats, int N, int Cin, int H, int W,
                       int Cout, int KH, int KW, int stride, int pad_h, int pad_w, void* stream);
+/* ---- one convolution LAYER of the path, op by op (r4).  SURVEY.md section 8(b) asks for single-op entries of the kernels that are hot at
+ *      the trainer's shapes: the 5x5 layers run as Winograd products (model.py:86-103 downSample: F(2x2,3x3) / F(4x4,3x3) over the four input
+ *      phases; :226-237 upSample: F(2x2,5x5) / F(4x4,5x5)) and the discriminators' stride-2 3x3 layers (:298-314) as staged GEMMs.  These
+ *      entries run the planner the networks use (conv_fwd / conv_dgrad / conv_wgrad) on ONE layer of `branches` (1, or 2 = value | gate)
+ *      convolutions Cin -> Cout:  x [N][Cin][H][W], y / dy [N][branches*Cout][OH][OW] (value rows first), dx like x, dw like the OIHW
+ *      parameters (ACCUMULATED: pass zeros).  `packed` = mcvc_layer_pack of the parameters (every weight set the planner may read);
+ *      `scratch` >= mcvc_layer_scratch_floats.  `scheme`: 0 the planner's choice at this shape, 1 Winograd with 2x2 output tiles, 2 Winograd
+ *      with 4x4 output tiles (sample / tile thresholds lifted; image sides must be multiples of 4 -- 8 for the stride-2 layers),
+ *      3 no Winograd (staged GEMM where it applies, else direct), 4 direct kernels only.  w0 / w1 = the OIHW tensors themselves (the
+ *      staged-GEMM data gradient multiplies them in place).  pixel_shuffle: the forward store of the up-sampling layers (model.py:232).   */
+long long mcvc_layer_packed_floats(int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w);
+long long mcvc_layer_scratch_floats(int N, int H, int W, int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w);
+int mcvc_layer_pack(const float* w0, const float* b0, const float* w1, const float* b1, float* packed, int Cin, int Cout, int branches,
+                    int KH, int KW, int stride, int pad_h, int pad_w, void* stream);
+int mcvc_layer_forward(const float* x, const float* packed, const float* w0, const float* w1, float* y, float* scratch,
+                       long long scratch_floats, int N, int H, int W, int Cin, int Cout, int branches, int KH, int KW, int stride,
+                       int pad_h, int pad_w, int scheme, int pixel_shuffle, void* stream);
+int mcvc_layer_dgrad(const float* dy, const float* packed, const float* w0, const float* w1, float* dx, float* scratch,
+                     long long scratch_floats, int N, int H, int W, int Cin, int Cout, int branches, int KH, int KW, int stride,
+                     int pad_h, int pad_w, int scheme, void* stream);
+int mcvc_layer_wgrad(const float* x, const float* dy, float* dw0, float* dw1, float* scratch, long long scratch_floats, int N, int H,
+                     int W, int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w, int scheme, void* stream);
+/*      The fused backward of one 1-D trunk layer (SURVEY.md section 8b resblock1d_bwd / gemm1x1_in_bwd; reference model.py:47-76 under
+ *      autograd): InstanceNorm (+ gated GLU when the gate pointers are given) backward of dy [Cout][B][T4] recomputed inside the
+ *      transposed-convolution launch; dconv [Cx][B][T4] = gradient w.r.t. the conv output (Cx = Cout or 2*Cout, value rows first);
+ *      dx [Cin][B][T4] += data gradient; d(gamma), d(beta) += (nullable); x_in != NULL (k = 3): dw / dw_gate += weight gradients.
+ *      wpack: Cin * Cx * KW floats of workspace (the transposed weight copy).                                                          */
+int mcvc_trunk_layer_backward(const float* dy, const float* conv_out, const float* stats, const float* gamma, const float* beta,
+                              const float* gamma_gate, const float* beta_gate, const float* w, const float* w_gate, const float* x_in,
+                              float* dx, float* dconv, float* dgamma, float* dbeta, float* dgamma_gate, float* dbeta_gate, float* dw,
+                              float* dw_gate, float* wpack, int B, int Cin, int T4, int Cout, int KW, void* stream);
+
 /* InstanceNorm(affine) + activation.  act: 0 none, 1 gated GLU (x has 2C channels: value|gate), 2 SiLU.
  * x[N,Cx,H,W] -> y[N,C,H,W]; stats[N,Cx,2] (mean, rstd)                                              */
 int mcvc_instnorm_act_forward(float* x, const float* gamma, const float* beta, const float* gamma_gate,

@@ -24,6 +24,7 @@
 #include "sampler.h"
 #include "../../include/mcvc.h"
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -65,6 +66,8 @@ struct Exec {
     int fuse_next = 0;             // the caller's next step is a norm that can absorb a Winograd output transform (set before conv_fwd)
     int pend_pts = 0;              // 16 / 36 / 43 (= F(4x4,3x3)) / 64: the output transform in `pend` has not run yet -- norm_fwd runs it (fused when it fits)
     WinoOutArgs pend;
+    int force_scheme = 0;          // op-level entries (mcvc_layer_*): 0 planner's choice, 1 Winograd with 2x2 output tiles only, 2 with 4x4 tiles
+                                   // (thresholds on samples / tiles lifted), 3 no Winograd, 4 no Winograd and no staged GEMM (direct kernels)
     int pack_skips;                // what the last re-pack of `packed` left stale: bit 0 = generic trunk copies, bit 1 = direct copies of the Winograd layers
     unsigned* sync;                // arrival counters of the persistent trunk kernels (MCVC_TRUNK_SYNC_WORDS words of the scratch)
     std::vector<std::pair<const void*, hipEvent_t>> readers;
@@ -262,11 +265,13 @@ static void run_conv(Exec& ex, const ConvProblem& p, int NB, ConvIO io, long lon
     ex.fail(mcvc_conv_launch(p, NB, io, w, w_rows, w_cout, bias, ex.s, nullptr));
 }
 
-static bool wino_enabled()
+static bool wino_env_enabled()
 {
     static const int en = [] { const char* e = getenv("MCVC_WINO"); return e ? atoi(e) : 1; }();
     return en != 0;
 }
+static thread_local int t_no_wino = 0;          // (op-level entries that ask for the direct / staged-GEMM kernels)
+static bool wino_enabled() { return wino_env_enabled() && !t_no_wino; }
 
 // tile of the 36 batched products: 128 channels x 64 tiles measured best on all four shapes (128x128 wastes the ragged
 // tile count of upSample1, 256x32 re-reads V too often); knob: MCVC_WINO_CFG = planner index + 1
@@ -319,11 +324,15 @@ static int wino43_min_nb()
 }
 static bool wino4_applies(const Exec& ex, const ConvSpec& c, int NB, int H, int W)
 {
+    if (ex.force_scheme == 1 || ex.force_scheme >= 3) return false;
+    if (ex.force_scheme == 2) return c.wino && c.off_w4f >= 0 && (H & 3) == 0 && (W & 3) == 0;
     return c.wino && c.off_w4f >= 0 && wino4_min_nb() > 0 && NB >= wino4_min_nb() && (H & 3) == 0 && (W & 3) == 0 && !(ex.pack_skips & 16);
 }
 // F(4x4,3x3) for the stride-2 5x5 layers in phase form (wino43_kernels.hip) under the same conditions (OH x OW = the conv's output size)
 static bool wino43_applies(const Exec& ex, const ConvSpec& c, int NB, int OH, int OW)
 {
+    if (ex.force_scheme == 1 || ex.force_scheme >= 3) return false;
+    if (ex.force_scheme == 2) return c.wino3 && c.off_w43 >= 0 && (OH & 3) == 0 && (OW & 3) == 0;
     return c.wino3 && c.off_w43 >= 0 && wino43_min_nb() > 0 && NB >= wino43_min_nb() && (OH & 3) == 0 && (OW & 3) == 0 && !(ex.pack_skips & 32);
 }
 // samples per F(4x4) pass: V / M hold pts * max(K, M) * tiles floats
@@ -343,7 +352,7 @@ static bool conv_wino4(Exec& ex, const ConvSpec& c, const float* packed, int dgr
     const int TH = H / 4, TW = W / 4;
     if ((M % 128) != 0 || (K % 16) != 0) return false;
     const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, K > M ? K : M);
-    if (!nbc || (long long)nbc * TH * TW < wino4_min_tiles()) return false;
+    if (!nbc || ((long long)nbc * TH * TW < wino4_min_tiles() && ex.force_scheme != 2)) return false;
     if (ex.dry) return true;
     for (int b0 = 0; b0 < NB; b0 += nbc) {
         const int nb = NB - b0 < nbc ? NB - b0 : nbc;
@@ -425,11 +434,13 @@ static bool conv_wino(Exec& ex, const ConvSpec& c, const float* packed, int dgra
 //   kind 2: 1 x KW stride 1 (KW = 1, 3) over an image of rows -- the 1-D trunk beyond the fused small-batch kernels (more than 32 columns);
 //           MCVC_SGEMM1D_COLS = smallest column count (0 = never)
 struct SgKind { int kind, taps, OH, OW; };
+static thread_local int t_no_sgemm = 0;
 static SgKind sgemm_kind(const ConvSpec& c, int NB, int H, int W)
 {
     static const int min_nb = [] { const char* e = getenv("MCVC_SGEMM_NB"); return e ? atoi(e) : 1; }();
     static const int min_cols = [] { const char* e = getenv("MCVC_SGEMM1D_COLS"); return e ? atoi(e) : 64; }();
     SgKind k{0, 0, 0, 0};
+    if (t_no_sgemm) return k;
     if (c.nbr > 2 || (c.cout_tot % 64) != 0 || (c.Cout % 32) != 0 || c.cin_pad != c.Cin) return k;
     if (c.KH == 3 && c.KW == 3 && c.stride == 2 && c.ph == 1 && c.pw == 1) {
         k.OH = (H + 1) / 2; k.OW = (W + 1) / 2; k.taps = 9;
@@ -490,7 +501,7 @@ static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, i
         const int OH = H / 2, OW = W / 2, K = 4 * c.Cin, M = c.cout_tot;
         const int TH = OH / 4, TW = OW / 4;
         const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, K > M ? K : M, 36);
-        if (en && nbc && (long long)nbc * TH * TW >= 64) {
+        if (en && nbc && ((long long)nbc * TH * TW >= 64 || ex.force_scheme == 2)) {
             if (nsplit) *nsplit = 1;
             if (ex.dry) return;
             for (int b0 = 0; b0 < NB; b0 += nbc) {
@@ -601,7 +612,7 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
         const int K = c.cout_tot, M = 4 * c.Cin;
         const int TH = OH / 4, TW = OW / 4;
         const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, K > M ? K : M, 36);
-        if (en && nbc && (long long)nbc * TH * TW >= 64 && (M % 128) == 0 && (K % 16) == 0) {
+        if (en && nbc && ((long long)nbc * TH * TW >= 64 || ex.force_scheme == 2) && (M % 128) == 0 && (K % 16) == 0) {
             if (nsplit) *nsplit = 1;
             if (ex.dry) return;
             for (int b0 = 0; b0 < NB; b0 += nbc) {
@@ -774,7 +785,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         // F(4x4,5x5) weight gradient: the same three steps on 8x8 tiles and 64 points
         const int TH = H / 4, TW = W / 4;
         const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, c.Cout > c.Cin ? c.Cout : c.Cin);
-        if (nbc && (long long)nbc * TH * TW >= 32) {
+        if (nbc && ((long long)nbc * TH * TW >= 32 || ex.force_scheme == 2)) {
             for (int b0 = 0; b0 < NB; b0 += nbc) {
                 const int nb = NB - b0 < nbc ? NB - b0 : nbc;
                 const long long NT = (long long)nb * TH * TW, NTp = (NT + 31) & ~31LL;
@@ -834,7 +845,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         const int K4 = 4 * c.Cin, M = c.cout_tot;
         const int TH = OH / 4, TW = OW / 4;
         const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, M > K4 ? M : K4, 36);
-        if (en && nbc && (long long)nbc * TH * TW >= 32 && (M % 128) == 0 && (K4 % 64) == 0 && 36LL * M * K4 <= ex.wu_cap) {
+        if (en && nbc && ((long long)nbc * TH * TW >= 32 || ex.force_scheme == 2) && (M % 128) == 0 && (K4 % 64) == 0 && 36LL * M * K4 <= ex.wu_cap) {
             for (int b0 = 0; b0 < NB; b0 += nbc) {
                 const int nb = NB - b0 < nbc ? NB - b0 : nbc;
                 const long long NT = (long long)nb * TH * TW, NTp = (NT + 31) & ~31LL;
@@ -2358,6 +2369,200 @@ int mcvc_conv2d_wgrad(const float* x, const float* dy, float* dw, float* slabs, 
     if (Cout == 1 && mcvc_wgrad_cout1_applies(p)) return mcvc_wgrad_cout1_launch(p, N, io, dw, (hipStream_t)stream);
     if (mcvc_wgrad_cin2_applies(p, io)) return mcvc_wgrad_cin2_launch(p, N, io, dw, (hipStream_t)stream);
     return mcvc_wgrad_launch(p, N, io, dw, slabs, slab_floats, (hipStream_t)stream);
+}
+
+// ---- one convolution LAYER of the path, op by op, through the planner the networks use (conv_fwd / conv_dgrad / conv_wgrad) ----------
+// SURVEY.md section 8(b) names single-op entries for the kernels that are hot at the trainer's shapes; the Winograd and staged-GEMM forms
+// live inside the planner (their weight sets are job kinds of the whole-network pack), so the op-level ABI is the planner on ONE layer.
+namespace {
+struct LayerCtx { ConvSpec c; long long packed_floats; };
+static LayerCtx layer_ctx(int Cin, int Cout, int nbr, int KH, int KW, int stride, int ph, int pw)
+{
+    LayerCtx l{};
+    l.c = mk(Cin, Cout, nbr, KH, KW, stride, ph, pw, 0, 1, nbr == 2 ? 2 : -1, nbr == 2 ? 3 : -1, 1);
+    long long cur = 0;
+    spec_finalize(l.c, cur);
+    l.packed_floats = cur + 64;
+    return l;
+}
+struct LayerScratch { long long wv, wm, wv2, wm2, wino_floats, wu, wu_floats, tail; };
+static LayerScratch layer_scratch(const ConvSpec& c, int N, int H, int W)
+{
+    LayerScratch q{};
+    long long cur = 0;
+    auto take = [&](long long n) { const long long o = cur; cur += (n + 3) & ~3LL; return o; };
+    const long long tiles2 = (((long long)N * ((H + 1) / 2) * ((W + 1) / 2) + 63) & ~63LL) + 64;
+    const long long chan = std::max<long long>(std::max(4LL * c.Cin, (long long)c.cout_tot), 64);
+    q.wino_floats = 36LL * chan * tiles2;
+    q.wv = take(q.wino_floats); q.wm = take(q.wino_floats); q.wv2 = take(q.wino_floats); q.wm2 = take(q.wino_floats);
+    q.wu_floats = 64LL * c.cout_tot * 4 * c.Cin;
+    q.wu = take(q.wu_floats);
+    q.tail = cur;
+    return q;
+}
+static Needs layer_needs(const ConvSpec& c, int N, int H, int W, int scheme)
+{
+    Exec ex{}; ex.dry = true; ex.force_scheme = scheme;
+    const LayerScratch q = layer_scratch(c, N, H, W);
+    ex.wv = ex.wm = ex.wv2 = ex.wm2 = ex.wu = reinterpret_cast<float*>(16);      // (non-null: the dry run only looks at capacities)
+    ex.wino_cap = q.wino_floats; ex.wu_cap = q.wu_floats;
+    const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
+    int ns = 1;
+    conv_fwd(ex, c, nullptr, N, H, W, CView{nullptr, (long long)c.Cin * H * W, (long long)H * W, W},
+             View{nullptr, (long long)c.cout_tot * OH * OW, (long long)OH * OW, OW}, (long long)N * c.cout_tot * OH * OW, 0, 1, &ns);
+    conv_dgrad(ex, c, nullptr, N, H, W, CView{nullptr, (long long)c.cout_tot * OH * OW, (long long)OH * OW, OW},
+               View{nullptr, (long long)c.Cin * H * W, (long long)H * W, W}, (long long)N * c.Cin * H * W, 0, 1, &ns);
+    conv_wgrad(ex, c, nullptr, N, H, W, CView{nullptr, (long long)c.Cin * H * W, (long long)H * W, W},
+               CView{nullptr, (long long)c.cout_tot * OH * OW, (long long)OH * OW, OW});
+    return Needs{(ex.slab_need + 3) & ~3LL, (ex.wslab_need + 3) & ~3LL, (ex.sg_need + 3) & ~3LL, (ex.sgw_need + 3) & ~3LL};
+}
+struct SchemeGuard {            // scheme 3: no Winograd; 4: neither Winograd nor staged GEMM (thread-local planner switches)
+    int w, g;
+    explicit SchemeGuard(int scheme) : w(t_no_wino), g(t_no_sgemm) { if (scheme >= 3) t_no_wino = 1; if (scheme == 4) t_no_sgemm = 1; }
+    ~SchemeGuard() { t_no_wino = w; t_no_sgemm = g; }
+};
+static Exec layer_exec(const ConvSpec& c, int N, int H, int W, int scheme, float* scratch, long long scratch_floats, void* stream, int* err)
+{
+    const LayerScratch q = layer_scratch(c, N, H, W);
+    const Needs nd = layer_needs(c, N, H, W, scheme);
+    Exec ex = make_exec(stream, nullptr, scratch, scratch_floats, q.tail, nd);
+    if (ex.wslab_cap < 0) { *err = MCVC_ERR_WORKSPACE; return ex; }
+    ex.wv = scratch + q.wv; ex.wm = scratch + q.wm; ex.wv2 = scratch + q.wv2; ex.wm2 = scratch + q.wm2; ex.wino_cap = q.wino_floats;
+    ex.wu = scratch + q.wu; ex.wu_cap = q.wu_floats;
+    ex.force_scheme = scheme;
+    return ex;
+}
+}  // namespace
+
+long long mcvc_layer_packed_floats(int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w)
+{
+    if (branches < 1 || branches > 2 || (stride != 1 && stride != 2)) return -1;
+    return layer_ctx(Cin, Cout, branches, KH, KW, stride, pad_h, pad_w).packed_floats;
+}
+
+long long mcvc_layer_scratch_floats(int N, int H, int W, int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w)
+{
+    if (branches < 1 || branches > 2 || (stride != 1 && stride != 2) || N < 1) return -1;
+    const LayerCtx l = layer_ctx(Cin, Cout, branches, KH, KW, stride, pad_h, pad_w);
+    long long worst = 0;
+    for (int scheme = 0; scheme <= 4; ++scheme) {
+        SchemeGuard sg(scheme);
+        const Needs nd = layer_needs(l.c, N, H, W, scheme);
+        const long long need = nd.slab + nd.wslab + nd.sg + nd.sgw;
+        if (need > worst) worst = need;
+    }
+    ConvProblem p{Cin, H, W, Cout, conv_out(H, KH, stride, pad_h), conv_out(W, KW, stride, pad_w), KH, KW, stride, pad_h, pad_w};
+    return layer_scratch(l.c, N, H, W).tail + worst + mcvc_wgrad_plan_slab_floats(p, N) + 1024;
+}
+
+int mcvc_layer_pack(const float* w0, const float* b0, const float* w1, const float* b1, float* packed, int Cin, int Cout, int branches,
+                    int KH, int KW, int stride, int pad_h, int pad_w, void* stream)
+{
+    if (!w0 || !b0 || !packed || branches < 1 || branches > 2 || (branches == 2 && (!w1 || !b1))) return MCVC_ERR_INVALID;
+    const LayerCtx l = layer_ctx(Cin, Cout, branches, KH, KW, stride, pad_h, pad_w);
+    // the job table of this layer alone (cached per device and layer shape like the networks' tables)
+    const long long h = (((((((long long)Cin * 31 + Cout) * 31 + branches) * 31 + KH) * 31 + KW) * 31 + stride) * 31 + pad_h) * 31 + pad_w;
+    const int key = 1000 + (int)(h % 1000003);
+    int err = 0;
+    const DevPackTable* t = dev_pack_table(key, [&](PackTable& pt) { add_spec_jobs(pt, l.c); }, &err);
+    if (!t) return err ? err : MCVC_ERR_INVALID;
+    const float* params[4] = {w0, b0, w1, b1};
+    return pack_net(t, params, packed, (hipStream_t)stream);
+}
+
+int mcvc_layer_forward(const float* x, const float* packed, const float* w0, const float* w1, float* y, float* scratch, long long scratch_floats,
+                       int N, int H, int W, int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w, int scheme,
+                       int pixel_shuffle, void* stream)
+{
+    if (!x || !packed || !y || !scratch || scheme < 0 || scheme > 4 || branches < 1 || branches > 2 || (stride != 1 && stride != 2)) return MCVC_ERR_INVALID;
+    const LayerCtx l = layer_ctx(Cin, Cout, branches, KH, KW, stride, pad_h, pad_w);
+    if ((scheme == 1 || scheme == 2) && !(l.c.wino || l.c.wino3)) return MCVC_ERR_INVALID;       // no Winograd form of this layer shape
+    SchemeGuard sg(scheme);
+    int err = 0;
+    Exec ex = layer_exec(l.c, N, H, W, scheme, scratch, scratch_floats, stream, &err);
+    if (err) return err;
+    const float* params[4] = {w0, nullptr, w1, nullptr};
+    ex.params = params;
+    const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
+    const long long y_total = (long long)N * l.c.cout_tot * OH * OW;
+    View yv = pixel_shuffle ? View{y, (long long)l.c.cout_tot * OH * OW, 4LL * OH * OW, 2 * OW} : View{y, (long long)l.c.cout_tot * OH * OW, (long long)OH * OW, OW};
+    int ns = 1;
+    conv_fwd(ex, l.c, packed, N, H, W, CView{x, (long long)Cin * H * W, (long long)H * W, W}, yv, y_total, pixel_shuffle, 1, &ns);
+    if (ns > 1) act_fwd(ex, y, y_total, ns, nullptr, 1, 1, (int)y_total, ACT_NONE);
+    return ex.err;
+}
+
+int mcvc_layer_dgrad(const float* dy, const float* packed, const float* w0, const float* w1, float* dx, float* scratch, long long scratch_floats,
+                     int N, int H, int W, int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w, int scheme, void* stream)
+{
+    if (!dy || !packed || !dx || !scratch || scheme < 0 || scheme > 4 || branches < 1 || branches > 2 || (stride != 1 && stride != 2)) return MCVC_ERR_INVALID;
+    const LayerCtx l = layer_ctx(Cin, Cout, branches, KH, KW, stride, pad_h, pad_w);
+    SchemeGuard sg(scheme);
+    int err = 0;
+    Exec ex = layer_exec(l.c, N, H, W, scheme, scratch, scratch_floats, stream, &err);
+    if (err) return err;
+    const float* params[4] = {w0, nullptr, w1, nullptr};
+    ex.params = (w0 && (branches == 1 || w1)) ? params : nullptr;         // (the staged-GEMM data gradient multiplies the OIHW tensors themselves)
+    const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
+    const long long dx_total = (long long)N * Cin * H * W;
+    int ns = 1;
+    conv_dgrad(ex, l.c, packed, N, H, W, CView{dy, (long long)l.c.cout_tot * OH * OW, (long long)OH * OW, OW},
+               View{dx, (long long)Cin * H * W, (long long)H * W, W}, dx_total, 0, 1, &ns);
+    if (ns > 1) act_fwd(ex, dx, dx_total, ns, nullptr, 1, 1, (int)dx_total, ACT_NONE);
+    return ex.err;
+}
+
+int mcvc_layer_wgrad(const float* x, const float* dy, float* dw0, float* dw1, float* scratch, long long scratch_floats, int N, int H, int W,
+                     int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w, int scheme, void* stream)
+{
+    if (!x || !dy || !dw0 || !scratch || scheme < 0 || scheme > 4 || branches < 1 || branches > 2 || (branches == 2 && !dw1)) return MCVC_ERR_INVALID;
+    const LayerCtx l = layer_ctx(Cin, Cout, branches, KH, KW, stride, pad_h, pad_w);
+    SchemeGuard sg(scheme);
+    int err = 0;
+    Exec ex = layer_exec(l.c, N, H, W, scheme, scratch, scratch_floats, stream, &err);
+    if (err) return err;
+    float* grads[4] = {dw0, nullptr, dw1, nullptr};
+    const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
+    conv_wgrad(ex, l.c, grads, N, H, W, CView{x, (long long)Cin * H * W, (long long)H * W, W},
+               CView{dy, (long long)l.c.cout_tot * OH * OW, (long long)OH * OW, OW});
+    return ex.err;
+}
+
+// The fused backward of one 1-D trunk layer (resblock1d_bwd / gemm1x1_in_bwd; reference model.py:47-76 under autograd):
+// InstanceNorm (+ gated GLU) backward of dy recomputed inside the transposed-convolution launch (trunk_layer_kernel<.., PRE>), d(gamma), d(beta)
+// accumulated, dconv = the gradient w.r.t. the conv output stored, dx += the data gradient, and (x_in != NULL) the weight gradients by the
+// batched small-K kernel.  Trunk layout [C][B][T4] for every tensor; gate pointers NULL = plain InstanceNorm (no GLU).
+int mcvc_trunk_layer_backward(const float* dy, const float* conv_out, const float* stats, const float* gamma, const float* beta,
+                              const float* gamma_gate, const float* beta_gate, const float* w, const float* w_gate, const float* x_in,
+                              float* dx, float* dconv, float* dgamma, float* dbeta, float* dgamma_gate, float* dbeta_gate, float* dw, float* dw_gate,
+                              float* wpack, int B, int Cin, int T4, int Cout, int KW, void* stream)
+{
+    if (!dy || !conv_out || !stats || !gamma || !beta || !w || !dx || !dconv || !wpack || (KW != 1 && KW != 3)) return MCVC_ERR_INVALID;
+    const bool glu = w_gate != nullptr;
+    if (glu && (!gamma_gate || !beta_gate)) return MCVC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int Cx = glu ? 2 * Cout : Cout;
+    int rc = mcvc_pack_trunk_t_launch(w, wpack, Cout, Cin, KW, Cx * KW, 0, s);
+    if (!rc && glu) rc = mcvc_pack_trunk_t_launch(w_gate, wpack, Cout, Cin, KW, Cx * KW, Cout, s);
+    if (rc) return rc;
+    const int ks = trunk_pick_ksplit(Cx, KW, Cin, B, T4, 0);
+    if (ks < 1) return MCVC_ERR_INVALID;
+    TrunkArgs a{};
+    a.a0 = wpack;
+    a.x = dy; a.x_sc = (long long)B * T4; a.x_sb = T4;
+    a.Cin = Cx; a.KW = KW; a.K = Cx * KW; a.M = Cin; a.Mtot = Cin; a.B = B; a.T4 = T4; a.N = B * T4;
+    a.conv_out = dx; a.c_sc = (long long)B * T4; a.c_sb = T4; a.accumulate = 1; a.mode = TRUNK_PLAIN;
+    a.pre = glu ? 2 : 1; a.pre_C = Cout; a.pre_x = conv_out; a.pre_stats = stats;
+    a.pre_gamma0 = gamma; a.pre_beta0 = beta; a.pre_gamma1 = gamma_gate; a.pre_beta1 = beta_gate;
+    a.pre_out = dconv; a.pre_dgamma0 = dgamma; a.pre_dbeta0 = dbeta; a.pre_dgamma1 = dgamma_gate; a.pre_dbeta1 = dbeta_gate;
+    rc = mcvc_trunk_launch(a, ks, s);
+    if (rc || !x_in || !dw) return rc;
+    if (KW != 3 || !mcvc_wgrad_smallk_batch_applies(B, T4)) return MCVC_ERR_INVALID;
+    SmallKJob jobs[2];
+    int nj = 0;
+    jobs[nj++] = SmallKJob{x_in, dconv, dw, Cin, Cout, 0};
+    if (glu && dw_gate) jobs[nj++] = SmallKJob{x_in, dconv + (long long)Cout * B * T4, dw_gate, Cin, Cout, 0};
+    return mcvc_wgrad_smallk_batch_launch(jobs, nj, B, T4, s);
 }
 
 int mcvc_instnorm_act_forward(float* x, const float* gamma, const float* beta, const float* gamma_gate, const float* beta_gate,

@@ -84,6 +84,13 @@ _SIGS = {
     "mcvc_conv2d_dgrad": (c_int, [c_void_p] * 5 + [c_int] * 11 + [c_void_p]),
     "mcvc_conv2d_wgrad_slab_floats": (c_longlong, [c_int] * 10),
     "mcvc_conv2d_wgrad": (c_int, [c_void_p] * 4 + [c_longlong] + [c_int] * 10 + [c_void_p]),
+    "mcvc_layer_packed_floats": (c_longlong, [c_int] * 8),
+    "mcvc_layer_scratch_floats": (c_longlong, [c_int] * 11),
+    "mcvc_layer_pack": (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    "mcvc_layer_forward": (c_int, [c_void_p] * 6 + [c_longlong] + [c_int] * 13 + [c_void_p]),
+    "mcvc_layer_dgrad": (c_int, [c_void_p] * 6 + [c_longlong] + [c_int] * 12 + [c_void_p]),
+    "mcvc_layer_wgrad": (c_int, [c_void_p] * 5 + [c_longlong] + [c_int] * 12 + [c_void_p]),
+    "mcvc_trunk_layer_backward": (c_int, [c_void_p] * 19 + [c_int] * 5 + [c_void_p]),
     "mcvc_instnorm_act_forward": (c_int, [c_void_p] * 8 + [c_int] * 5 + [c_void_p]),
     "mcvc_instnorm_act_backward": (c_int, [c_void_p] * 12 + [c_int] * 5 + [c_void_p]),
     "mcvc_trunk_layer_forward": (c_int, [c_void_p] * 13 + [c_int] * 5 + [c_void_p]),

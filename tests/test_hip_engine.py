@@ -114,8 +114,8 @@ def _kink_free_batch(onets, B, T=64):
 @pytest.mark.parametrize("B,T", [(1, 64), (2, 64), (1, 32), (3, 48), (8, 64), (32, 64)])
 def test_step_full_tensor_parity_vs_oracle(golden_dir, B, T):
     """One iteration: every generator / discriminator parameter GRADIENT (full tensors) and the resulting Adam update
-    vs the CPU oracle.  (8, 64) is the per-GPU shape of BASELINE configs[3], (32, 64) is configs[2]: the generic (non-fused)
-    trunk path, the direct-conv fallback of the Winograd layers beyond 16384 tiles, weight gradients over 64 images in the
+    vs the CPU oracle.  (8, 64) is the per-GPU shape of BASELINE configs[3], (32, 64) is configs[2]: the staged-GEMM trunk
+    (more than 64 columns), the F(4x4,5x5) / F(4x4,3x3) Winograd schemes in chunks of samples, weight gradients over 64 images in the
     discriminator phase and Adam -- the full step with the L1 terms on."""
     seeds = [300 + i for i in range(6)]
     nets = _nets(seeds)

@@ -262,3 +262,144 @@ def test_batched_winograd_gemm_matches_torch(nb, M, N, K):
     got = c[:, :, :N].double()
     assert torch.isfinite(got).all()
     assert float((got - ref).norm() / ref.norm()) < 2e-6
+
+
+# ---- op-level parity of the kernels that carry the trainer's shapes (r4): Winograd / staged-GEMM layers and the fused trunk backward ----
+# (name, Cin, Cout, branches, KH, KW, stride, ph, pw, N, H, W, pixel_shuffle, schemes)
+#   schemes: 1 = Winograd, 2x2 output tiles (F(2x2,5x5) / phase F(2x2,3x3)); 2 = 4x4 tiles (F(4x4,5x5) / phase F(4x4,3x3));
+#            3 = no Winograd (the discriminators' layers: staged GEMM); 0 = the planner's choice at this shape
+LAYER_CASES = [
+    ("up2.T64", 256, 512, 1, 5, 5, 1, 2, 2, 1, 40, 32, True, (0, 1, 2)),
+    ("up2.B2", 256, 512, 1, 5, 5, 1, 2, 2, 2, 40, 32, True, (1, 2)),
+    ("up1.T64", 256, 1024, 1, 5, 5, 1, 2, 2, 1, 20, 16, True, (0, 1, 2)),
+    ("up1.B3", 256, 1024, 1, 5, 5, 1, 2, 2, 3, 20, 16, True, (1, 2)),
+    ("up2.ragged", 256, 512, 1, 5, 5, 1, 2, 2, 1, 18, 10, True, (1,)),             # 45 tiles: the column count is no multiple of 32
+    ("up2.T48", 256, 512, 1, 5, 5, 1, 2, 2, 1, 40, 24, True, (1, 2)),
+    ("ds1.T64", 128, 256, 2, 5, 5, 2, 2, 2, 1, 80, 64, False, (0, 1, 2)),
+    ("ds2.T64", 256, 256, 2, 5, 5, 2, 2, 2, 2, 40, 32, False, (1, 2)),
+    ("ds2.B1", 256, 256, 2, 5, 5, 2, 2, 2, 1, 40, 32, False, (1,)),                 # 80 tiles
+    ("ds1.ragged", 128, 256, 2, 5, 5, 2, 2, 2, 2, 24, 20, False, (1,)),             # 12 x 10 outputs: 30 tiles per sample
+    ("d.ds1", 128, 256, 1, 3, 3, 2, 1, 1, 1, 80, 64, False, (3,)),
+    ("d.ds2", 256, 512, 1, 3, 3, 2, 1, 1, 2, 40, 32, False, (3,)),
+    ("d.ds3", 512, 1024, 1, 3, 3, 2, 1, 1, 3, 20, 16, False, (3,)),
+    ("d.ds1.T72", 128, 256, 1, 3, 3, 2, 1, 1, 2, 80, 72, False, (3,)),
+    ("d.ds2.B9", 256, 512, 1, 3, 3, 2, 1, 1, 9, 40, 32, False, (3,)),
+]
+_LAYER_IDS = ["%s-s%d" % (c[0], s) for c in LAYER_CASES for s in c[-1]]
+_LAYER_PARAMS = [(c, s) for c in LAYER_CASES for s in c[-1]]
+
+
+@pytest.mark.parametrize("c,scheme", _LAYER_PARAMS, ids=_LAYER_IDS)
+def test_layer_ops_match_torch(c, scheme):
+    """mcvc_layer_forward / dgrad / wgrad: one convolution layer through the planner the networks use, with the scheme forced -- the
+    Winograd transforms (input, output, G^T dU G), the batched products and the staged-GEMM path are reached op by op instead of only
+    through whole-network gradients (reference model.py:86-103, 226-237, 298-314) -- against F.conv2d / torch.nn.grad in fp32 on the CPU."""
+    from mask_cyclegan_vc._hip import check, lib, ptr, stream
+    L = lib()
+    name, Cin, Cout, nbr, KH, KW, s, ph, pw, N, H, W, shuffle, _ = c
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    ws = [torch.randn(Cout, Cin, KH, KW, generator=g) / np.sqrt(Cin * KH * KW) for _ in range(nbr)]
+    bs = [torch.randn(Cout, generator=g) for _ in range(nbr)]
+    wcat, bcat = torch.cat(ws, 0), torch.cat(bs, 0)
+    ref = F.conv2d(x, wcat, bcat, stride=s, padding=(ph, pw))
+    OH, OW = ref.shape[2], ref.shape[3]
+    dy = torch.randn(N, nbr * Cout, OH, OW, generator=g)
+    spec = (Cin, Cout, nbr, KH, KW, s, ph, pw)
+    packed = torch.zeros(L.mcvc_layer_packed_floats(*spec), device="cuda")
+    scratch = torch.zeros(L.mcvc_layer_scratch_floats(N, H, W, *spec), device="cuda")
+    wd, bd = [w.cuda() for w in ws], [b.cuda() for b in bs]
+    w1, b1 = (wd[1], bd[1]) if nbr == 2 else (None, None)
+    check(L.mcvc_layer_pack(ptr(wd[0]), ptr(bd[0]), ptr(w1), ptr(b1), ptr(packed), *spec, stream()), "layer_pack")
+    xd, dyd = x.cuda(), dy.cuda()
+    # forward (+ the PixelShuffle store of the up-sampling layers)
+    y = torch.full((N, nbr * Cout // 4, 2 * OH, 2 * OW) if shuffle else (N, nbr * Cout, OH, OW), float("nan"), device="cuda")
+    check(L.mcvc_layer_forward(ptr(xd), ptr(packed), ptr(wd[0]), ptr(w1), ptr(y), ptr(scratch), scratch.numel(), N, H, W, *spec, scheme,
+                               1 if shuffle else 0, stream()), "layer_forward")
+    want = F.pixel_shuffle(ref, 2) if shuffle else ref
+    assert rel_l2(y, want) < 5e-5, rel_l2(y, want)
+    # data gradient
+    dx = torch.full((N, Cin, H, W), float("nan"), device="cuda")
+    check(L.mcvc_layer_dgrad(ptr(dyd), ptr(packed), ptr(wd[0]), ptr(w1), ptr(dx), ptr(scratch), scratch.numel(), N, H, W, *spec, scheme, stream()),
+          "layer_dgrad")
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, wcat, dy, stride=s, padding=(ph, pw))
+    assert rel_l2(dx, dx_ref) < 5e-5, rel_l2(dx, dx_ref)
+    # weight gradients (accumulated into zeros; value | gate rows to their own tensors)
+    dws = [torch.zeros_like(w) for w in wd]
+    check(L.mcvc_layer_wgrad(ptr(xd), ptr(dyd), ptr(dws[0]), ptr(dws[1]) if nbr == 2 else None, ptr(scratch), scratch.numel(), N, H, W, *spec,
+                             scheme, stream()), "layer_wgrad")
+    dw_ref = torch.nn.grad.conv2d_weight(x, wcat.shape, dy, stride=s, padding=(ph, pw))
+    for br in range(nbr):
+        e = rel_l2(dws[br], dw_ref[br * Cout:(br + 1) * Cout])
+        assert e < 5e-5, (br, e)
+
+
+def test_layer_ops_refuse_a_winograd_scheme_for_a_layer_without_one():
+    from mask_cyclegan_vc._hip import lib, ptr, stream
+    L = lib()
+    spec = (128, 256, 1, 3, 3, 2, 1, 1)
+    packed = torch.zeros(L.mcvc_layer_packed_floats(*spec), device="cuda")
+    scratch = torch.zeros(L.mcvc_layer_scratch_floats(1, 16, 16, *spec), device="cuda")
+    x, y = torch.zeros(1, 128, 16, 16, device="cuda"), torch.zeros(1, 256, 8, 8, device="cuda")
+    w = torch.zeros(256, 128, 3, 3, device="cuda")
+    assert L.mcvc_layer_forward(ptr(x), ptr(packed), ptr(w), None, ptr(y), ptr(scratch), scratch.numel(), 1, 16, 16, *spec, 2, 0, stream()) != 0
+
+
+@pytest.mark.parametrize("B,T4,Cin,Cout,glu", [(1, 16, 256, 512, True), (2, 16, 256, 512, True), (3, 16, 256, 512, True), (4, 16, 256, 512, True),
+                                               (1, 16, 512, 256, False), (2, 16, 512, 256, False), (3, 16, 512, 256, False), (4, 16, 512, 256, False),
+                                               (3, 12, 256, 512, True), (5, 8, 512, 256, False)])
+def test_fused_trunk_layer_backward_matches_autograd(B, T4, Cin, Cout, glu):
+    """mcvc_trunk_layer_backward (SURVEY.md section 8b resblock1d_bwd): InstanceNorm (+ gated GLU) backward recomputed inside the transposed
+    1x3 convolution launch + the batched small-K weight gradient, against autograd through Conv1d -> InstanceNorm1d -> GLU in fp32
+    (reference model.py:47-76) at 16 ... 64 columns."""
+    from mask_cyclegan_vc._hip import check, lib, ptr, stream
+    L = lib()
+    g = torch.Generator().manual_seed(9)
+    KW = 3
+    x = torch.randn(B, Cin, T4, generator=g, requires_grad=True)
+    mk = lambda: (torch.randn(Cout, Cin, KW, generator=g) / (Cin * KW) ** 0.5).requires_grad_()      # noqa: E731
+    w, wg = mk(), mk()
+    b, bg = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+    ga, be = (1 + 0.1 * torch.randn(Cout, generator=g)).requires_grad_(), (0.1 * torch.randn(Cout, generator=g)).requires_grad_()
+    gg, bgt = (1 + 0.1 * torch.randn(Cout, generator=g)).requires_grad_(), (0.1 * torch.randn(Cout, generator=g)).requires_grad_()
+    c0 = F.conv1d(x, w, b, padding=1)
+    c0.retain_grad()
+    z = F.instance_norm(c0, weight=ga, bias=be, eps=1e-5)
+    if glu:
+        c1 = F.conv1d(x, wg, bg, padding=1)
+        c1.retain_grad()
+        y = z * torch.sigmoid(F.instance_norm(c1, weight=gg, bias=bgt, eps=1e-5))
+        conv = torch.cat((c0, c1), 1)
+    else:
+        y = z
+        conv = c0
+    dy = torch.randn(B, Cout, T4, generator=g)
+    y.backward(dy)
+    Cx = conv.shape[1]
+    tl = lambda t: t.detach().permute(1, 0, 2).contiguous().cuda()          # noqa: E731  trunk layout [C][B][T4]
+    mean = conv.detach().mean(2)
+    rstd = 1.0 / torch.sqrt(conv.detach().var(2, unbiased=False) + 1e-5)
+    stats = torch.stack((mean, rstd), 2).contiguous().cuda()                 # [B][Cx][2]
+    dx = torch.zeros(Cin, B, T4, device="cuda")
+    dconv = torch.full((Cx, B, T4), float("nan"), device="cuda")
+    z_ = lambda n: torch.zeros(n, device="cuda")                            # noqa: E731
+    dga, dbe, dgg, dbg = z_(Cout), z_(Cout), z_(Cout), z_(Cout)
+    dw, dwg = torch.zeros(Cout, Cin, KW, device="cuda"), torch.zeros(Cout, Cin, KW, device="cuda")
+    wpack = torch.zeros(Cin * Cx * KW, device="cuda")
+    wd, wgd = w.detach().cuda(), wg.detach().cuda()
+    dy_d, conv_d, x_d = tl(dy), tl(conv), tl(x)                              # (named: a temporary would be freed before the kernel reads it)
+    ga_d, be_d, gg_d, bgt_d = ga.detach().cuda(), be.detach().cuda(), gg.detach().cuda(), bgt.detach().cuda()
+    check(L.mcvc_trunk_layer_backward(ptr(dy_d), ptr(conv_d), ptr(stats), ptr(ga_d), ptr(be_d),
+                                      ptr(gg_d) if glu else None, ptr(bgt_d) if glu else None,
+                                      ptr(wd), ptr(wgd) if glu else None, ptr(x_d), ptr(dx), ptr(dconv), ptr(dga), ptr(dbe),
+                                      ptr(dgg) if glu else None, ptr(dbg) if glu else None, ptr(dw), ptr(dwg) if glu else None, ptr(wpack),
+                                      B, Cin, T4, Cout, KW, stream()), "trunk_layer_backward")
+    back = lambda t: t.permute(1, 0, 2)                                      # noqa: E731
+    dconv_ref = torch.cat((c0.grad, c1.grad), 1) if glu else c0.grad
+    assert rel_l2(back(dconv), dconv_ref) < 5e-5, rel_l2(back(dconv), dconv_ref)
+    assert rel_l2(back(dx), x.grad) < 5e-5, rel_l2(back(dx), x.grad)
+    assert rel_l2(dga, ga.grad) < 5e-5 and rel_l2(dbe, be.grad) < 5e-5
+    assert rel_l2(dw, w.grad) < 5e-5, rel_l2(dw, w.grad)
+    if glu:
+        assert rel_l2(dgg, gg.grad) < 5e-5 and rel_l2(dbg, bgt.grad) < 5e-5
+        assert rel_l2(dwg, wg.grad) < 5e-5, rel_l2(dwg, wg.grad)
