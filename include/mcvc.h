@@ -161,6 +161,9 @@ int mcvc_gen_backward_window(const float* const* params, const float* packed, fl
  *      kernels' 64 workgroups per pass wait for each other inside the kernel, so all of them must be resident: they are used only while
  *      64 x that number <= the device's compute units, otherwise the passes fall back to per-layer launches.  Returns the previous value. */
 int mcvc_set_trunk_passes_in_flight(int n);
+/*      bit 0 / bit 1: a (B, T) generator pass would run its forward / backward trunk on the persistent kernels under the current
+ *      switches and residency bound (0: per-layer launches).                                                                          */
+int mcvc_gen_trunk_persistent(int B, int T);
 
 /* ---- Generator inference in bf16 (BASELINE configs[4]: generator_A2B, bs=16, 80 x 512 frames).  Replaces the call
  *      `generator(real, ones_like(real))` of the reference's inference driver (mask_cyclegan_vc/test.py:92, 107 ->

@@ -2035,6 +2035,18 @@ int mcvc_gen_trunk_fused(int B, int T)
     return ok ? 1 : 0;
 }
 
+// bit 0: the persistent forward trunk kernel would run a (B, T) pass, bit 1: the persistent backward -- under the current switches
+// (mcvc_set_trunk_persistent) and the residency bound (mcvc_set_trunk_passes_in_flight x 64 workgroups <= compute units)
+int mcvc_gen_trunk_persistent(int B, int T)
+{
+    if (B < 1 || T < 1 || !trunk_enabled()) return 0;
+    const int W4 = gen_dims(B, T).W4;
+    int m = 0;
+    if (trunk_net_enabled() && mcvc_trunk_net_applies(B, W4)) m |= 1;
+    if (trunk_bwd_net_enabled() && mcvc_trunk_bwd_net_applies(B, W4)) m |= 2;
+    return m;
+}
+
 // `sets`: 1 = only what a forward pass reads, 2 = only what a backward pass reads, 3 = both (see add_spec_jobs).  After a forward-only
 // refresh the backward sets are marked stale (bit 2 of the registry) and a backward pass on this buffer fails until sets = 2 has run.
 int mcvc_gen_pack_sets(const float* const* params, float* packed, int max_batch, int T, int sets, void* stream)

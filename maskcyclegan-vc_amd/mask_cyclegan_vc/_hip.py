@@ -60,6 +60,7 @@ _SIGS = {
     "mcvc_gen_backward_window": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong, c_int, c_int,
                                          c_void_p, c_void_p, _PP, c_int]),
     "mcvc_set_trunk_passes_in_flight": (c_int, [c_int]),
+    "mcvc_gen_trunk_persistent": (c_int, [c_int, c_int]),
     "mcvc_gen_trunk_fault": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
     "mcvc_debug_trunk_fault_inject": (c_int, [c_int]),
     "mcvc_gen_bf16_packed_bytes": (c_longlong, []),

@@ -211,6 +211,7 @@ class TrainEngine:
         self.merged = (self.reducer.world > 1) if mf is None else (mf != "0")
         self.early_ident = os.environ.get("MCVC_EARLY_IDENT", "0") != "0"
         self.bwd_no_join = os.environ.get("MCVC_BWD_NO_JOIN", "1") != "0"
+        self.trunk_fallback = False            # a persistent trunk launch faulted in this process: per-layer launches from then on (check_faults)
         self._pending_D = None                  # (input set, discriminator lr) of the iteration whose discriminator phase is still to run
         self._skip_dgen = os.environ.get("MCVC_DEBUG_SKIP_DGEN") == "1"
         if self._skip_dgen:
@@ -383,6 +384,15 @@ class TrainEngine:
         else:
             inflight = 2
         self.L.mcvc_set_trunk_passes_in_flight(inflight + (1 if self.reducer.world > 1 else 0))
+        if self._use_grouped() and not self.trunk_fallback:
+            want = self.L.mcvc_gen_trunk_persistent(B, self.T)
+            self.L.mcvc_set_trunk_passes_in_flight(1)
+            could = self.L.mcvc_gen_trunk_persistent(B, self.T)
+            self.L.mcvc_set_trunk_passes_in_flight(inflight + (1 if self.reducer.world > 1 else 0))
+            if could and not want:
+                import sys
+                print("[mcvc] %d persistent trunk passes in flight do not fit this device's compute units: per-layer trunk launches"
+                      % (inflight + (1 if self.reducer.world > 1 else 0)), file=sys.stderr, flush=True)
         self._cur_set = 0
         self.static_in = self.static_sets[0]
 
@@ -392,7 +402,9 @@ class TrainEngine:
             # every generator pass of this engine has batch <= 2B at T frames: at small batch the trunk layers run on the
             # fused kernels and their generic K-major copies need no refresh (the library falls back to the full pack).
             # sets: 1 = what a forward pass reads, 2 = what only a backward pass reads (mcvc_gen_pack_sets)
-            check(self.L.mcvc_gen_pack_ranges(self._p_tab[n], ptr(self.packed[n]), 2 * self._max_B, self.T, sets, ranges, stream()), "pack " + n)
+            # (largest pass: two samples per input sample -- three with the merged forwards)
+            per = 3 if (self.merged and self._merged_ok(self._max_B)) else 2
+            check(self.L.mcvc_gen_pack_ranges(self._p_tab[n], ptr(self.packed[n]), per * self._max_B, self.T, sets, ranges, stream()), "pack " + n)
         else:
             check(self.L.mcvc_disc_pack_small(self._p_tab[n], ptr(self.packed[n]), self.T, stream()), "pack " + n)
 
@@ -1507,16 +1519,32 @@ class TrainEngine:
             self._graphs[key] = g
         g.replay()
 
-    def check_faults(self):
-        """Raise if a persistent trunk launch of this engine ever gave up waiting for its workgroups (its result was poisoned with NaN, so
-        the losses are non-finite as well).  Synchronises the device: call it per logging interval, not per step."""
+    def check_faults(self, raise_on_fault=True):
+        """Detect a persistent trunk launch of this engine that gave up waiting for its workgroups (its result was poisoned with NaN, so
+        the losses are non-finite as well).  On a fault: the error words are cleared, the library is switched to per-layer trunk launches
+        for the rest of the process (the condition that lost an arrival -- more persistent passes resident than the device holds, or
+        foreign kernels occupying compute units for longer than the bounded spin -- would recur), the switch is logged, and a
+        RuntimeError names the layer (``raise_on_fault=False``: the code is returned instead; the caller restores parameters and optimizer
+        state from before the poisoned step and continues).  Synchronises the device: call it per logging interval, not per step."""
+        first = 0
         for B, ws in self._workspaces.items():
             for lane, sc in enumerate(ws["g_scratch"]):
-                for nb in (B, 2 * B):
-                    code = self.L.mcvc_gen_trunk_fault(ptr(sc), nb, self.T, 0, stream())
-                    if code != 0:
-                        raise RuntimeError("persistent trunk kernel fault %d (layer %d) in lane %d at batch %d: more concurrent generator "
-                                           "passes than the device can keep resident" % (code, code - 1, lane, nb))
+                code = self.L.mcvc_gen_trunk_fault(ptr(sc), B, self.T, 1, stream())          # (the word sits at the same place for every batch)
+                if code != 0 and not first:
+                    first = (code, lane, B)
+        if not first:
+            return 0
+        code, lane, B = first
+        self.trunk_fallback = True
+        self.L.mcvc_set_trunk_persistent(0)
+        import sys
+        print("[mcvc] persistent trunk kernel fault %d (layer %d) in lane %d: switching to per-layer trunk launches" % (code, (code & 0xff) - 1, lane),
+              file=sys.stderr, flush=True)
+        if raise_on_fault:
+            raise RuntimeError("persistent trunk kernel fault %d (layer %d) in lane %d at batch %d: more concurrent generator passes than the "
+                               "device can keep resident; the step's result is poisoned -- restore the last good state (per-layer launches "
+                               "are now in effect)" % (code, (code & 0xff) - 1, lane, B))
+        return code
 
     def losses(self, lagged=False):
         """Host read of the loss slots, like the reference's ``.item()`` calls (train.py:303).  Default: the losses of the iteration

@@ -321,3 +321,82 @@ def test_module_forward_after_engine_step_uses_the_updated_weights():
     assert float((y_after - y_before).abs().max()) > 1e-5          # the step did change the weights
     assert float((y_after - y_ref).norm() / y_ref.norm()) < 1e-5, "module forward used stale packed weights"
     assert float((p_after - p_ref).norm() / p_ref.norm()) < 1e-5
+
+
+def test_trunk_fault_falls_back_to_per_layer_launches_and_training_continues(deterministic_mode):
+    """A persistent trunk launch that loses an arrival (test hook mcvc_debug_trunk_fault_inject) poisons its pass with NaN.  The engine's
+    fault check must (i) see it, (ii) switch the process to per-layer trunk launches and say so, (iii) leave the engine usable: with the
+    parameters and optimizer state of before the poisoned step restored, the following iterations are finite and agree (to the rounding of
+    the one iteration that ran on the persistent kernels) with a run that used per-layer launches from the start."""
+    from mask_cyclegan_vc._hip import lib
+    L = lib()
+    B = 1
+
+    def batch(seed):
+        rs = np.random.RandomState(seed)
+        out = []
+        for _ in range(2):
+            out.append(torch.from_numpy(rs.randn(B, 80, 64).astype(np.float32)).cuda())
+            out.append(torch.from_numpy(orc.fif_mask(rs, B, 80, 64, 25)).cuda())
+        return out
+
+    def snapshot(eng):
+        eng.flush()
+        return [t.clone() for g in (eng.g_group, eng.d_group) for t in (g.flat, g.exp_avg, g.exp_avg_sq)], (eng.g_group.step, eng.d_group.step), \
+            (eng.sched.g_opt_lr, eng.sched.d_opt_lr, eng.sched.global_step)
+
+    def restore(eng, snap):
+        tensors, steps, sch = snap
+        it = iter(tensors)
+        for g in (eng.g_group, eng.d_group):
+            for t in (g.flat, g.exp_avg, g.exp_avg_sq):
+                t.copy_(next(it))
+            g.grad.zero_()
+        eng.g_group.step, eng.d_group.step = steps
+        eng.sched.g_opt_lr, eng.sched.d_opt_lr, eng.sched.global_step = sch
+        eng._g_grad_clean = eng._d_grad_clean = True
+        eng.repack(G_NAMES + D_NAMES)
+
+    was = L.mcvc_set_trunk_persistent(1)
+    try:
+        # reference run: per-layer launches from the start
+        L.mcvc_set_trunk_persistent(0)
+        ref = TrainEngine(_nets([800 + i for i in range(6)]), B, 64, schedule=StepSchedule(batch_size=B, n_samples=4))
+        want = []
+        for it in range(3):
+            ref.step(*batch(40 + it))
+            want.append(ref.losses())
+        ref.flush()
+        # faulting run
+        L.mcvc_set_trunk_persistent(1)
+        eng = TrainEngine(_nets([800 + i for i in range(6)]), B, 64, schedule=StepSchedule(batch_size=B, n_samples=4))
+        assert L.mcvc_gen_trunk_persistent(B, 64) & 1
+        eng.step(*batch(40))
+        got = [eng.losses()]
+        assert eng.check_faults() == 0
+        snap = snapshot(eng)
+        inj = L.mcvc_debug_trunk_fault_inject(1)
+        try:
+            eng.step(*batch(41))
+            bad = eng.losses()
+        finally:
+            L.mcvc_debug_trunk_fault_inject(inj)
+        assert not np.isfinite(bad["g_loss"]), bad
+        with pytest.raises(RuntimeError, match="persistent trunk kernel fault"):
+            eng.check_faults()
+        assert eng.trunk_fallback and L.mcvc_gen_trunk_persistent(B, 64) == 0          # per-layer launches from here on
+        assert eng.check_faults() == 0                                                   # (the error words were cleared)
+        restore(eng, snap)
+        for it in (1, 2):
+            eng.step(*batch(40 + it))
+            got.append(eng.losses())
+        eng.flush()
+        assert all(np.isfinite(v) for lo in got for v in lo.values())
+        # iteration 0 ran on the persistent kernels (bit-identical per layer to the per-layer launches up to the statistics' summation order)
+        for k in want[0]:
+            assert abs(got[0][k] - want[0][k]) <= 1e-5 * abs(want[0][k]) + 1e-8, (k, got[0], want[0])
+        for it in (1, 2):
+            for k in want[it]:
+                assert abs(got[it][k] - want[it][k]) <= 1e-3 * abs(want[it][k]) + 1e-7, (it, k, got[it], want[it])
+    finally:
+        L.mcvc_set_trunk_persistent(was)
