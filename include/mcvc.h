@@ -99,6 +99,9 @@ int mcvc_disc_pack(const float* const* params, float* packed, void* stream);
  *      size): their K-major forward copies + biases only -- 4x fewer bytes than the full re-pack; falls back to it otherwise.  A pass that
  *      would need one of the stale copies returns MCVC_ERR_INVALID instead of reading it.                         */
 int mcvc_disc_pack_small(const float* const* params, float* packed, int T, void* stream);
+/*      ... for passes of up to max_batch samples (r4): the discriminators' stride-2 layers run as implicit GEMMs (forward: a tap-major K-major
+ *      copy; data gradient from MCVC_IGEMM_DGRAD_NB samples per pass: four per-parity-class copies) -- only the copies some pass reads.  */
+int mcvc_disc_pack_batch(const float* const* params, float* packed, int max_batch, int T, void* stream);
 
 /* ---- Generator: replaces Generator.forward (mask_cyclegan_vc/model.py:239-280) and its autograd
  *      x, mask: [B,80,T] (mask NULL = all ones, test.py:92); out: [B,80,T']                        */

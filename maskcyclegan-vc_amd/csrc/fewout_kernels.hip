@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(256) disc_out_dgrad_kernel(const Twin<DiscOutD
 // pixel in registers and walks COB output channels (weights: wave-uniform scalar loads); it stores the pre-activation (backward) and the
 // activation, both coalesced along the pixels.  w = the OIHW parameter ([Cout][1][3][3]).
 constexpr int kDiscC1Cob = 16;
-struct DiscConv1FwdKArgs { const float* x; const float* w; const float* bias; float* c0; float* y0; int Cout; int H; int W; };
+struct DiscConv1FwdKArgs { const float* x; const float* w; const float* bias; float* c0; float* y0; int Cout; int H; int W; int xs; };
 __global__ void __launch_bounds__(256) disc_conv1_fwd_kernel(const Twin<DiscConv1FwdKArgs> tw)
 {
     const DiscConv1FwdKArgs ka_ = tw.v[blockIdx.z];
@@ -427,6 +427,13 @@ __global__ void __launch_bounds__(256) disc_conv1_fwd_kernel(const Twin<DiscConv
             xv[kh * 3 + kw] = (ih >= 0 && ih < H && iw >= 0 && iw < W) ? xp[ih * W + iw] : 0.f;
         }
     const long long o0 = ((long long)n * Cout + co0) * HW + p;
+    // xs: the activation goes out in the phase-split padded layout the implicit-GEMM forward of downSample1 gathers from (sgemm.h);
+    // the thread of pixel (h, wc) also writes the zero borders next to it (row 0 of its sub-plane for h < 2, columns 0..3 for wc < 2)
+    const int xs = ka_.xs;
+    const int pw = W / 2 + 4;
+    const long long plane = (long long)(H / 2 + 1) * pw;
+    const long long x0 = ((long long)n * Cout + co0) * 4 * plane + (long long)((h & 1) * 2 + (wc & 1)) * plane;
+    const long long xo = x0 + (long long)((h >> 1) + 1) * pw + (wc >> 1) + 4;
 #pragma unroll 4
     for (int j = 0; j < kDiscC1Cob; ++j) {
         if (co0 + j >= Cout) break;
@@ -435,7 +442,16 @@ __global__ void __launch_bounds__(256) disc_conv1_fwd_kernel(const Twin<DiscConv
 #pragma unroll
         for (int t = 0; t < 9; ++t) v = fmaf(wr[t], xv[t], v);
         c0[o0 + (long long)j * HW] = v;
-        y0[o0 + (long long)j * HW] = v / (1.0f + __expf(-v));
+        const float yv = v / (1.0f + __expf(-v));
+        if (!xs) { y0[o0 + (long long)j * HW] = yv; continue; }
+        float* yp = y0 + (long long)j * 4 * plane;
+        yp[xo] = yv;
+        if (h < 2) yp[x0 + (wc >> 1) + 4] = 0.f;
+        if (wc < 2) {
+            float* r = yp + x0 + (long long)((h >> 1) + 1) * pw;
+            r[0] = 0.f; r[1] = 0.f; r[2] = 0.f; r[3] = 0.f;
+            if (h < 2) { float* r0 = yp + x0; r0[0] = 0.f; r0[1] = 0.f; r0[2] = 0.f; r0[3] = 0.f; }
+        }
     }
 }
 
@@ -484,11 +500,11 @@ int mcvc_disc_out_dgrad_launch(const float* dlogit, const float* w, float* dx, i
     return (int)hipGetLastError();
 }
 
-int mcvc_disc_conv1_fwd_launch(const float* x, const float* w, const float* bias, float* c0, float* y0, int NB, int Cout, int H, int W, hipStream_t s)
+int mcvc_disc_conv1_fwd_launch(const float* x, const float* w, const float* bias, float* c0, float* y0, int NB, int Cout, int H, int W, hipStream_t s, int xs)
 {
     const double outs = (double)NB * Cout * H * W;
     TraceScope ts(K_CONV_FEW, s, 2.0 * 9 * outs, 4.0 * (2.0 * outs + (double)NB * H * W));
-    mcvc_launch(disc_conv1_fwd_kernel, dim3((unsigned)cdiv_i(H * W, 256), (unsigned)(cdiv_i(Cout, kDiscC1Cob) * NB)), dim3(256), 0, s, DiscConv1FwdKArgs{x, w, bias, c0, y0, Cout, H, W});
+    mcvc_launch(disc_conv1_fwd_kernel, dim3((unsigned)cdiv_i(H * W, 256), (unsigned)(cdiv_i(Cout, kDiscC1Cob) * NB)), dim3(256), 0, s, DiscConv1FwdKArgs{x, w, bias, c0, y0, Cout, H, W, xs});
     return (int)hipGetLastError();
 }
 

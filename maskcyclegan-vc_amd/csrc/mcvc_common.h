@@ -112,6 +112,9 @@ struct NormArgs {
     int N, C, H, W;
     int act;
     float eps;
+    // y in the phase-split padded layout of sgemm.h ("xs": the next layer is a 3x3 stride-2 convolution run as an implicit GEMM): plane (n, c)
+    // at y + n*y_sn + c*y_sc holds four sub-planes of xs_plane floats, rows of xs_pw floats; the kernel also writes the zero borders
+    int y_xs, xs_pw; long long xs_plane;
 };
 
 struct NormBwdArgs {
@@ -129,6 +132,8 @@ struct NormBwdArgs {
     long long dx_sn, dx_sc;
     int dx_sh;
     int unshuffle;            // 1: plane (n,c) element (h,w) -> conv channel 4c+2(h&1)+(w&1), pixel (h>>1, w>>1), row pitch dx_sh
+    int dx_pitch;             // > W (dense mode only): rows of dx_pitch floats, H + 1 rows per plane; the kernel writes zeros beyond column W - 1 and
+                              // in row H (the implicit-GEMM data gradient reads one column / row past the image: sgemm.h)
     float* dgamma[2];         // accumulated (+=); may be null
     float* dbeta[2];
     int N, C, H, W;
@@ -184,7 +189,8 @@ int mcvc_fewout_launch(const ConvProblem& p, int NB, const ConvIO& io, const flo
 // the discriminators' output layer (1x3, C -> 1, + sigmoid) and its data-gradient; w / bias = the parameters themselves
 int mcvc_disc_out_fwd_launch(const float* x, const float* w, const float* bias, float* logit, float* out, int NB, int C, int H, int W, hipStream_t s);
 // the discriminators' first layer (3x3 from one channel) + x*sigmoid(x): c0 = pre-activation, y0 = activation, dense [NB][Cout][H][W]
-int mcvc_disc_conv1_fwd_launch(const float* x, const float* w, const float* bias, float* c0, float* y0, int NB, int Cout, int H, int W, hipStream_t s);
+// xs != 0: y0 in the phase-split padded layout of sgemm.h (borders zeroed)
+int mcvc_disc_conv1_fwd_launch(const float* x, const float* w, const float* bias, float* c0, float* y0, int NB, int Cout, int H, int W, hipStream_t s, int xs = 0);
 int mcvc_disc_out_dgrad_launch(const float* dlogit, const float* w, float* dx, int NB, int C, int H, int W, hipStream_t s);
 
 struct WgradIO {

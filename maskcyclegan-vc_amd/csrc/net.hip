@@ -66,6 +66,9 @@ struct Exec {
     int fuse_next = 0;             // the caller's next step is a norm that can absorb a Winograd output transform (set before conv_fwd)
     int pend_pts = 0;              // 16 / 36 / 43 (= F(4x4,3x3)) / 64: the output transform in `pend` has not run yet -- norm_fwd runs it (fused when it fits)
     WinoOutArgs pend;
+    int y_xs_pw = 0; long long y_xs_plane = 0;   // the next norm_fwd writes y in the phase-split padded layout (sgemm.h); consumed by norm_fwd
+    int dx_pitch = 0;              // the next norm_bwd writes dx in the padded dY layout (rows of dx_pitch floats + a zero row); consumed by norm_bwd
+    int wgrad_x_xs = 0;            // conv_wgrad: x is in the phase-split padded layout
     int force_scheme = 0;          // op-level entries (mcvc_layer_*): 0 planner's choice, 1 Winograd with 2x2 output tiles only, 2 with 4x4 tiles
                                    // (thresholds on samples / tiles lifted), 3 no Winograd, 4 no Winograd and no staged GEMM (direct kernels)
     int pack_skips;                // what the last re-pack of `packed` left stale: bit 0 = generic trunk copies, bit 1 = direct copies of the Winograd layers
@@ -147,6 +150,9 @@ struct ConvSpec {
     // enough pixels to fill the chip per launch the four parity classes run as four exact stride-1 convs instead (1.78x fewer MACs)
     long long off_dcls;            // -1: no per-class copies
     DgradClass ucls[4];
+    // 3x3 stride-2 padding-1 layers (the discriminators'): implicit-GEMM operands (sgemm.h) -- the forward copy with tap-major rows and the
+    // four parity classes' data-gradient matrices with rows (tap, co)
+    int igemm; long long off_ifwd, off_idg; DgradClass icls[4];
 };
 
 static void spec_finalize(ConvSpec& c, long long& cur)
@@ -205,6 +211,18 @@ static void spec_finalize(ConvSpec& c, long long& cur)
             c.ucls[k] = c.cls[k];
             c.ucls[k].offset = cur - c.off_dcls;
             cur += ((long long)c.dg_rows_co * c.cls[k].nth * c.cls[k].ntw + 1) * c.cin_pk;   // + zero pad row
+        }
+    }
+    c.igemm = 0; c.off_ifwd = c.off_idg = -1;
+    if (st == 2 && c.KH == 3 && c.KW == 3 && c.ph == 1 && c.pw == 1 && (c.Cin % 64) == 0 && (c.cout_tot % 64) == 0 && c.ncls == 4) {
+        c.igemm = 1;
+        cur = (cur + 3) & ~3LL;
+        c.off_ifwd = cur; cur += (long long)9 * c.Cin * c.cout_pk;
+        c.off_idg = cur;
+        for (int k = 0; k < c.ncls; ++k) {
+            c.icls[k] = c.cls[k];
+            c.icls[k].offset = cur - c.off_idg;
+            cur += (long long)c.cout_tot * c.cls[k].nth * c.cls[k].ntw * c.cin_pk;
         }
     }
     cur = (cur + 3) & ~3LL;
@@ -461,6 +479,90 @@ static int sgemm_split(int M, long long N, int K)
     int sp = 1;
     while (sp < maxsp && tiles * sp < wgs && (K % (64 * sp)) == 0 && K / (2 * sp) >= 64) sp *= 2;
     return sp;
+}
+
+// ---- implicit GEMM for the 3x3 stride-2 padding-1 layers (sgemm.h): no tap planes, no gather kernel -------------------------------------
+static bool igemm_enabled()
+{
+    static const int en = [] { const char* e = getenv("MCVC_IGEMM"); return e ? atoi(e) : 1; }();
+    return en != 0;
+}
+static bool igemm_applies(const ConvSpec& c, int H, int W)
+{
+    return igemm_enabled() && c.igemm && (H & 1) == 0 && (W & 1) == 0 && ((W / 2) & 3) == 0 && H >= 2 && W >= 8;
+}
+// K split: enough 64 x 64 tiles x classes x splits to occupy the chip, at least two 32-deep stages per split of the shortest class
+static int igemm_split(long long tiles, int Kmin)
+{
+    static const int wgs = [] { const char* e = getenv("MCVC_SGEMM_WGS"); return e ? atoi(e) : 256; }();
+    static const int maxsp = [] { const char* e = getenv("MCVC_SGEMM_MAXSPLIT"); return e ? atoi(e) : 8; }();
+    int sp = 1;
+    while (sp < maxsp && tiles * sp < wgs && (Kmin % (64 * sp)) == 0 && Kmin / (2 * sp) >= 64) sp *= 2;
+    return sp;
+}
+// forward: xs = the input in the phase-split padded layout, y = the conv output (dense planes); K-split slabs 1.. are summed by the consumer
+static void conv_fwd_igemm(Exec& ex, const ConvSpec& c, const float* packed, int NB, int H, int W, const float* xs, View y, long long y_total,
+                           int allow_split, int* nsplit)
+{
+    const int OH = H / 2, OW = W / 2, P = OH * OW, KT = 9 * c.Cin;
+    const long long NT = (long long)NB * P;
+    const int sp = (allow_split && nsplit) ? igemm_split((long long)(c.cout_tot / 64) * ((NT + 63) / 64), KT) : 1;
+    const long long slab_need = (long long)(sp - 1) * y_total;
+    if (slab_need > ex.slab_need) ex.slab_need = slab_need;
+    if (nsplit) *nsplit = sp;
+    if (ex.dry) return;
+    if (slab_need > ex.slab_cap) { ex.fail(MCVC_ERR_WORKSPACE); return; }
+    const int pw = mcvc_xs_pw(W);
+    const long long plane = mcvc_xs_plane(H, W);
+    IGemmArgs g{};
+    g.ncls = 1;
+    g.cls[0].a = packed + c.off_ifwd; g.cls[0].ntaps = 9; g.cls[0].coff = 0;
+    for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) {          // tap (kh, kw) of output (oh, ow) reads x[2 oh + kh - 1][2 ow + kw - 1]
+            const int ph = (kh == 1) ? 0 : 1, di = (kh == 0) ? -1 : 0, pq = (kw == 1) ? 0 : 1, dj = (kw == 0) ? -1 : 0;
+            g.cls[0].boff[3 * kh + kw] = (long long)(2 * ph + pq) * plane + (long long)(1 + di) * pw + 4 + dj;
+        }
+    g.lda = c.cout_pk;
+    g.b = xs; g.b_cs = 4 * plane; g.b_sn = (long long)c.Cin * 4 * plane; g.b_pitch = pw; g.Cb = c.Cin; g.OW = OW; g.P = P;
+    g.c = y.p; g.ldc = y.sc; g.c_sn = y.sb; g.c_sh = y.sh; g.c_sw = 1;
+    g.bias = packed + c.off_bias;
+    g.M = c.cout_tot; g.N = (int)NT; g.nsplit = sp; g.c_slab = ex.slabs; g.c_split = y_total;
+    ex.fail(mcvc_igemm_launch(g, ex.s));
+}
+// data gradient: dyp = dY in the padded layout (planes of (OH + 1) x (OW + 4), zero borders), dx dense; the four output-parity classes in
+// one launch, every input pixel written by exactly one of them; K-split slabs (dx-shaped) are summed by the consumer
+static void conv_dgrad_igemm(Exec& ex, const ConvSpec& c, const float* packed, int NB, int H, int W, const float* dyp, View dx, long long dx_total,
+                             int accumulate, int allow_split, int* nsplit)
+{
+    const int OH = H / 2, OW = W / 2, P = OH * OW;
+    const long long NT = (long long)NB * P;
+    int sp = (allow_split && nsplit && !accumulate) ? igemm_split(4LL * (c.Cin / 64) * ((NT + 63) / 64), c.cout_tot) : 1;
+    const long long slab_need = (long long)(sp - 1) * dx_total;
+    if (slab_need > ex.slab_need) ex.slab_need = slab_need;
+    if (nsplit) *nsplit = sp;
+    if (ex.dry) return;
+    if (slab_need > ex.slab_cap) { ex.fail(MCVC_ERR_WORKSPACE); return; }
+    if (ex.pack_skips & 64) { ex.fail(MCVC_ERR_INVALID); return; }          // (re-packed for smaller passes only: mcvc_disc_pack_batch)
+    const int pitch = mcvc_dyp_pitch(OW);
+    const long long plane = mcvc_dyp_plane(OH, OW);
+    IGemmArgs g{};
+    g.ncls = c.ncls;
+    for (int k = 0; k < c.ncls; ++k) {
+        const DgradClass& d = c.icls[k];
+        IGemmClass& q = g.cls[k];
+        q.a = packed + c.off_idg + d.offset; q.ntaps = d.nth * d.ntw;
+        q.coff = (long long)d.qh * dx.sh + d.qw;
+        for (int u = 0; u < d.nth; ++u)
+            for (int v = 0; v < d.ntw; ++v) {     // input row 2a + qh receives tap kh from output row a + (qh + 1 - kh) / 2
+                const int kh = d.khmax - 2 * u, kw = d.kwmax - 2 * v;
+                q.boff[u * d.ntw + v] = (long long)((d.qh + 1 - kh) / 2) * pitch + (d.qw + 1 - kw) / 2;
+            }
+    }
+    g.lda = c.cin_pk;
+    g.b = dyp; g.b_cs = plane; g.b_sn = (long long)c.cout_tot * plane; g.b_pitch = pitch; g.Cb = c.cout_tot; g.OW = OW; g.P = P;
+    g.c = dx.p; g.ldc = dx.sc; g.c_sn = dx.sb; g.c_sh = 2 * dx.sh; g.c_sw = 2; g.accumulate = accumulate;
+    g.M = c.Cin; g.N = (int)NT; g.nsplit = sp; g.c_slab = ex.slabs; g.c_split = dx_total;
+    ex.fail(mcvc_igemm_launch(g, ex.s));
 }
 
 static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, int H, int W, CView x, View y, long long y_total,
@@ -758,7 +860,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
     bool done = false;
     if (sk.kind && ex.sgw && sg_floats <= ex.sgw_cap && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]])) {
         float* xt = ex.sgw; float* dyt = xt + sg_rows * KT; float* slabs = dyt + sg_rows * c.cout_tot;
-        StageArgs sx{x.p, x.sb, x.sc, x.sh, NB, c.Cin, H, W, sk.OH, sk.OW, xt, KT, (int)sg_rows};
+        StageArgs sx{x.p, x.sb, x.sc, x.sh, NB, c.Cin, H, W, sk.OH, sk.OW, xt, KT, (int)sg_rows, (sk.kind == 1 && ex.wgrad_x_xs) ? 1 : 0};
         ex.fail(sk.kind == 1 ? mcvc_im2col_s2_t_launch(sx, ws) : mcvc_im2col_1d_t_launch(sx, c.KW, ws));
         StageArgs sy{dy.p, dy.sb, dy.sc, dy.sh, NB, c.cout_tot, sk.OH, sk.OW, sk.OH, sk.OW, dyt, c.cout_tot, (int)sg_rows};
         ex.fail(mcvc_planes_t_launch(sy, ws));
@@ -963,12 +1065,15 @@ static void add_job(PackTable& t, PackJob j, int gx, int gy)
 // wino_only: the layer runs on the Winograd kernels in every pass (forward, data-gradient); its direct K-major copies are skipped
 // sets: 1 = the copies a FORWARD pass reads (K-major forward copies, biases, forward Winograd sets), 2 = the copies only a BACKWARD pass
 // reads (data-gradient copies, transposed trunk copies, data-gradient Winograd sets), 3 = both
-static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = false, bool wino_only = false, int sets = 3, bool w4 = true, bool w43 = true)
+// igemm_only: the layer runs on the implicit-GEMM kernels in every pass (the discriminators' stride-2 layers): only the bias, the tap-major
+// forward copy and the per-class data-gradient copies are refreshed
+static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = false, bool wino_only = false, int sets = 3, bool w4 = true, bool w43 = true,
+                          bool igemm_only = false)
 {
     const int K = c.Cin * c.KH * c.KW;
     const bool fw = (sets & 1) != 0, bw = (sets & 2) != 0;
     for (int br = 0; br < c.nbr; ++br) {
-        const bool skip_direct = wino_only && (c.wino || c.wino3);
+        const bool skip_direct = (wino_only && (c.wino || c.wino3)) || (igemm_only && c.igemm);
         if (trunk_only && c.off_tk >= 0) {
             if (!bw) continue;
             PackJob q{}; q.kind = PACK_TRUNK_T; q.param = c.wi[br]; q.dst = c.off_tk; q.Cout = c.Cout; q.Cin = c.Cin; q.KW = c.KW;
@@ -990,7 +1095,7 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             t.dga.push_back(a);
             add_job(t, d, cdiv_i(c.Cin, 32), c.Cout);
         }
-        if (c.off_dcls >= 0 && bw) {          // exact per-class copies (large-batch data-gradient of the 3x3 stride-2 layers)
+        if (c.off_dcls >= 0 && bw && !(igemm_only && c.igemm)) {          // exact per-class copies (large-batch data-gradient of the 3x3 stride-2 layers)
             PackDgradArgs u = a;
             u.merged = 0; u.ld = c.cin_pk;
             for (int k = 0; k < c.ncls; ++k) u.cls[k] = c.ucls[k];
@@ -1003,6 +1108,17 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             PackJob q{}; q.kind = PACK_TRUNK_T; q.param = c.wi[br]; q.dst = c.off_tk; q.Cout = c.Cout; q.Cin = c.Cin; q.KW = c.KW;
             q.ld = c.cout_tot * c.KW; q.co_off = br * c.Cout;
             add_job(t, q, cdiv_i(c.Cin, 32), cdiv_i(c.Cout, 32));
+        }
+        if (c.igemm && (sets & 4) == 0) {                   // (sets bit 2: skip the implicit-GEMM copies)
+            PackJob fi{}; fi.kind = PACK_FWD_TAP; fi.param = c.wi[br]; fi.dst = c.off_ifwd; fi.Cout = c.Cout; fi.K = K; fi.ld = c.cout_pk;
+            fi.co_off = br * c.Cout; fi.KW = c.KH * c.KW;
+            if (fw) add_job(t, fi, cdiv_i(K, 32), cdiv_i(c.Cout, 32));
+            PackDgradArgs u = a;
+            u.merged = 0; u.ld = c.cin_pk; u.tapmajor = 1; u.cout_rows = c.cout_tot;
+            for (int k = 0; k < c.ncls; ++k) u.cls[k] = c.icls[k];
+            PackJob di{}; di.kind = PACK_DGRAD; di.param = c.wi[br]; di.dst = c.off_idg; di.dg = (int)t.dga.size();
+            if (bw) { t.dga.push_back(u); add_job(t, di, cdiv_i(c.Cin, 32), c.Cout); }
+            t.bytes += 4.0 * (fw + bw) * 2.0 * c.Cout * K;
         }
         if (c.wino3) {
             PackJob w3{}; w3.kind = PACK_WINO3_D; w3.param = c.wi[br]; w3.dst = c.off_w3; w3.Cout = c.Cout; w3.Cin = c.Cin; w3.ld = c.mg_ld;
@@ -1040,7 +1156,7 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             if (bw) add_job(t, wd, cdiv_i(c.Cin, 256), c.Cout);
             t.bytes += 4.0 * (fw + bw) * (25.0 + 36.0) * c.Cout * c.Cin;
         }
-        t.bytes += 4.0 * ((c.off_tk >= 0 ? 6.0 : 4.0) * c.Cout * K + 2.0 * c.Cout);
+        t.bytes += skip_direct ? 8.0 * c.Cout : 4.0 * ((c.off_tk >= 0 ? 6.0 : 4.0) * c.Cout * K + 2.0 * c.Cout);
     }
 }
 
@@ -1214,12 +1330,13 @@ static int fuse_wino_norm()
 static void norm_fwd(Exec& ex, float* x, long long x_sn, long long x_sc, long long x_total, int nslab, const NormP& np, float* stats,
                      float* y, long long y_sn, long long y_sc, int y_sh, const float* res, int N, int C, int H, int W, int act)
 {
-    if (ex.dry) return;
+    if (ex.dry) { ex.y_xs_pw = 0; return; }
     NormArgs a{};
     a.x = x; a.x_slabs = ex.slabs; a.x_sn = x_sn; a.x_sc = x_sc; a.slab_stride = x_total; a.nslab = nslab;
     a.gamma[0] = np.g[0]; a.gamma[1] = np.g[1]; a.beta[0] = np.b[0]; a.beta[1] = np.b[1];
     a.stats = stats; a.y = y; a.res = res; a.y_sn = y_sn; a.y_sc = y_sc; a.y_sh = y_sh;
     a.N = N; a.C = C; a.H = H; a.W = W; a.act = act; a.eps = kInEps;
+    if (ex.y_xs_pw) { a.y_xs = 1; a.xs_pw = ex.y_xs_pw; a.xs_plane = ex.y_xs_plane; ex.y_xs_pw = 0; }
     if (ex.pend_pts) {
         const int pts = ex.pend_pts;
         ex.pend_pts = 0;
@@ -1234,7 +1351,7 @@ static void norm_bwd(Exec& ex, const float* x, long long x_sn, long long x_sc, c
                      float* dy, long long y_sn, long long y_sc, int y_sh, long long dy_total, int nslab,
                      float* dx, long long dx_sn, long long dx_sc, int dx_sh, int unshuffle, int N, int C, int H, int W, int act)
 {
-    if (ex.dry) return;
+    if (ex.dry) { ex.dx_pitch = 0; return; }
     wait_readers(ex, dx);
     NormBwdArgs a{};
     a.x = x; a.x_sn = x_sn; a.x_sc = x_sc;
@@ -1243,6 +1360,7 @@ static void norm_bwd(Exec& ex, const float* x, long long x_sn, long long x_sc, c
     a.dx = dx; a.dx_sn = dx_sn; a.dx_sc = dx_sc; a.dx_sh = dx_sh; a.unshuffle = unshuffle;
     a.dgamma[0] = np.dg[0]; a.dgamma[1] = np.dg[1]; a.dbeta[0] = np.db[0]; a.dbeta[1] = np.db[1];
     a.N = N; a.C = C; a.H = H; a.W = W; a.act = act;
+    a.dx_pitch = ex.dx_pitch; ex.dx_pitch = 0;
     ex.fail(mcvc_norm_bwd_launch(a, ex.s));
 }
 
@@ -1747,6 +1865,8 @@ static DiscDims disc_dims(int B, int T)
     d.B = B; d.T = T; d.H[0] = 80; d.W[0] = T;
     for (int i = 1; i < 4; ++i) { d.H[i] = conv_out(d.H[i - 1], 3, 2, 1); d.W[i] = conv_out(d.W[i - 1], 3, 2, 1); }
     d.big = (long long)B * 128 * 80 * T;
+    // (gradient ping-pong buffers also hold dY in the padded layout of the implicit data gradient: (OH + 1) x (OW + 4) per plane)
+    for (int i = 1; i < 4; ++i) { const long long p = (long long)B * (128 << i) * mcvc_dyp_plane(d.H[i], d.W[i]); if (p > d.big) d.big = p; }
     return d;
 }
 static const int kDC[4] = {128, 256, 512, 1024};
@@ -1758,10 +1878,12 @@ static DiscStash disc_stash(const DiscDims& d)
     long long cur = 0;
     auto take = [&](long long n) { const long long o = cur; cur += (n + 3) & ~3LL; return o; };
     const long long B = d.B;
-    s.c0 = take(B * 128 * 80 * d.T); s.y0 = take(B * 128 * 80 * d.T);
+    // (the inputs of the three stride-2 layers -- y0, y[0], y[1] -- may be stored in the phase-split padded layout of sgemm.h: the larger size)
+    auto xs_or_dense = [&](int C, int H, int W) { const long long xs = (H & 1) || (W & 1) ? 0 : mcvc_xs_floats(C, H, W); const long long dn = (long long)C * H * W; return B * (xs > dn ? xs : dn); };
+    s.c0 = take(B * 128 * 80 * d.T); s.y0 = take(xs_or_dense(128, 80, d.T));
     for (int i = 0; i < 3; ++i) {
         const long long n = B * kDC[i + 1] * d.H[i + 1] * d.W[i + 1];
-        s.c[i] = take(n); s.s[i] = take(B * kDC[i + 1] * 2); s.y[i] = take(n);
+        s.c[i] = take(n); s.s[i] = take(B * kDC[i + 1] * 2); s.y[i] = take(i < 2 ? xs_or_dense(kDC[i + 1], d.H[i + 1], d.W[i + 1]) : n);
     }
     s.logit = take(B * d.H[3] * d.W[3]);
     s.total = cur;
@@ -1783,6 +1905,26 @@ static int disc_out_direct()
     return en;
 }
 
+// every stride-2 layer of a (B, T) pass takes the implicit-GEMM kernels (and the first layer its own kernel, which stores the phase-split layout)
+static bool disc_igemm(const DiscDims& d)
+{
+    const DiscNet& n = disc_net();
+    bool ok = disc_out_direct() != 0;
+    for (int i = 0; i < 3 && ok; ++i) ok = igemm_applies(n.ds[i], d.H[i], d.W[i]) && sgemm_kind(n.ds[i], d.B, d.H[i], d.W[i]).kind == 1;
+    return ok;
+}
+
+// ... and their data gradients too: from MCVC_IGEMM_DGRAD_NB samples per pass.  Measured (r4, one MI355X): at one or two samples per pass the
+// four parity classes of one launch are unbalanced (1 / 2 / 2 / 4 taps: the longest class is the launch) and the per-class weight copies cost
+// a re-pack of their own -- 59-63 us against 52-61 us for product + gather, + 74 us of re-pack per discriminator pair; from 8 samples per
+// pass the gather kernel and the 2.25x larger product output are what counts (bs=32: -4.5 ms of staging per iteration).
+static int igemm_dgrad_min_nb()
+{
+    static const int nb = [] { const char* e = getenv("MCVC_IGEMM_DGRAD_NB"); return e ? atoi(e) : 4; }();
+    return nb;
+}
+static bool disc_igemm_dgrad(const DiscDims& d) { return disc_igemm(d) && igemm_dgrad_min_nb() > 0 && d.B >= igemm_dgrad_min_nb(); }
+
 static void disc_forward_impl(Exec& ex, const float* const* P, const float* packed, const float* x, float* out, float* st, const DiscDims& d)
 {
     ex.params = P;
@@ -1790,9 +1932,10 @@ static void disc_forward_impl(Exec& ex, const float* const* P, const float* pack
     const DiscStash o = disc_stash(d);
     const int B = d.B, T = d.T;
     int ns = 1;
+    const bool ig = disc_igemm(d);           // the three stride-2 layers as implicit GEMMs: their inputs are stored phase-split (sgemm.h)
     // model.py:343-344  unsqueeze(1) -> conv 3x3 -> x*sigmoid(x)
     if (disc_out_direct() && !ex.dry) {
-        ex.fail(mcvc_disc_conv1_fwd_launch(x, P[n.conv1.wi[0]], P[n.conv1.bi[0]], st + o.c0, st + o.y0, B, 128, 80, T, ex.s));
+        ex.fail(mcvc_disc_conv1_fwd_launch(x, P[n.conv1.wi[0]], P[n.conv1.bi[0]], st + o.c0, st + o.y0, B, 128, 80, T, ex.s, ig ? 1 : 0));
     } else {
         conv_fwd(ex, n.conv1, packed, B, 80, T, CView{x, 80LL * T, 80LL * T, T}, View{st + o.c0, 128LL * 80 * T, 80LL * T, T},
                  (long long)B * 128 * 80 * T, 0, 1, &ns);
@@ -1801,8 +1944,16 @@ static void disc_forward_impl(Exec& ex, const float* const* P, const float* pack
     const float* h = st + o.y0;
     for (int i = 0; i < 3; ++i) {                       // :345-347
         const int Ci = kDC[i], Co = kDC[i + 1], Hi = d.H[i], Wi = d.W[i], Ho = d.H[i + 1], Wo = d.W[i + 1];
-        conv_fwd(ex, n.ds[i], packed, B, Hi, Wi, CView{h, (long long)Ci * Hi * Wi, (long long)Hi * Wi, Wi},
-                 View{st + o.c[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo}, (long long)B * Co * Ho * Wo, 0, 1, &ns);
+        if (ig) conv_fwd_igemm(ex, n.ds[i], packed, B, Hi, Wi, h, View{st + o.c[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo},
+                               (long long)B * Co * Ho * Wo, 1, &ns);
+        else conv_fwd(ex, n.ds[i], packed, B, Hi, Wi, CView{h, (long long)Ci * Hi * Wi, (long long)Hi * Wi, Wi},
+                      View{st + o.c[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo}, (long long)B * Co * Ho * Wo, 0, 1, &ns);
+        if (ig && i < 2) {                              // this layer's output feeds the next stride-2 layer: phase-split padded store
+            const long long pl = mcvc_xs_plane(Ho, Wo);
+            ex.y_xs_pw = mcvc_xs_pw(Wo); ex.y_xs_plane = pl;
+            norm_fwd(ex, st + o.c[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, (long long)B * Co * Ho * Wo, ns, normp(P, nullptr, 4 + 4 * i, 5 + 4 * i),
+                     st + o.s[i], st + o.y[i], (long long)Co * 4 * pl, 4 * pl, Wo, nullptr, B, Co, Ho, Wo, ACT_SILU);
+        } else
         norm_fwd(ex, st + o.c[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, (long long)B * Co * Ho * Wo, ns, normp(P, nullptr, 4 + 4 * i, 5 + 4 * i),
                  st + o.s[i], st + o.y[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo, nullptr, B, Co, Ho, Wo, ACT_SILU);
         h = st + o.y[i];
@@ -1850,13 +2001,43 @@ static void disc_backward_impl(Exec& ex, const float* const* P, const float* pac
         if (disc_out_direct() && !ex.dry) ex.fail(mcvc_disc_out_dgrad_launch(dlogit, P[n.outc.wi[0]], GA, B, 1024, H3, W3, ex.s));
         else conv_dgrad(ex, n.outc, packed, B, H3, W3, dyv, View{GA, 1024LL * H3 * W3, (long long)H3 * W3, W3}, (long long)B * 1024 * H3 * W3, 0, 1, &ns);
     }
+    const bool ig = disc_igemm(d), ig_dg = disc_igemm_dgrad(d);
     for (int i = 2; i >= 0; --i) {
         const int Ci = kDC[i], Co = kDC[i + 1], Hi = d.H[i], Wi = d.W[i], Ho = d.H[i + 1], Wo = d.W[i + 1];
         GB = nextGB();
+        const float* hin = (i == 0) ? (st + o.y0) : (st + o.y[i - 1]);
+        if (ig && !ig_dg) {
+            // implicit forward only (small batch): the input is stored phase-split -- the weight gradient's staging reads it as it is; the data
+            // gradient multiplies the OIHW tensors and gathers (it never reads the input)
+            const long long xpl = mcvc_xs_plane(Hi, Wi);
+            norm_bwd(ex, st + o.c[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, normp(P, G, 4 + 4 * i, 5 + 4 * i), st + o.s[i],
+                     GA, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo, (long long)B * Co * Ho * Wo, ns,
+                     GB, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo, 0, B, Co, Ho, Wo, ACT_SILU);
+            CView dyv{GB, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo};
+            ex.wgrad_x_xs = 1;
+            conv_wgrad(ex, n.ds[i], G, B, Hi, Wi, CView{hin, (long long)Ci * 4 * xpl, 4 * xpl, Wi}, dyv);
+            ex.wgrad_x_xs = 0;
+            conv_dgrad(ex, n.ds[i], packed, B, Hi, Wi, dyv, View{GA, (long long)Ci * Hi * Wi, (long long)Hi * Wi, Wi}, (long long)B * Ci * Hi * Wi, 0, 1, &ns);
+            continue;
+        }
+        if (ig) {
+            // dY leaves the InstanceNorm backward in the padded layout the implicit data gradient gathers from (zero column / row written there);
+            // the layer's input is stored phase-split (forward): the weight gradient's staging reads both as they are
+            const int pitch = mcvc_dyp_pitch(Wo);
+            const long long pl = mcvc_dyp_plane(Ho, Wo), xpl = mcvc_xs_plane(Hi, Wi);
+            ex.dx_pitch = pitch;
+            norm_bwd(ex, st + o.c[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, normp(P, G, 4 + 4 * i, 5 + 4 * i), st + o.s[i],
+                     GA, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo, (long long)B * Co * Ho * Wo, ns,
+                     GB, (long long)Co * pl, pl, pitch, 0, B, Co, Ho, Wo, ACT_SILU);
+            ex.wgrad_x_xs = 1;
+            conv_wgrad(ex, n.ds[i], G, B, Hi, Wi, CView{hin, (long long)Ci * 4 * xpl, 4 * xpl, Wi}, CView{GB, (long long)Co * pl, pl, pitch});
+            ex.wgrad_x_xs = 0;
+            conv_dgrad_igemm(ex, n.ds[i], packed, B, Hi, Wi, GB, View{GA, (long long)Ci * Hi * Wi, (long long)Hi * Wi, Wi}, (long long)B * Ci * Hi * Wi, 0, 1, &ns);
+            continue;
+        }
         norm_bwd(ex, st + o.c[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, normp(P, G, 4 + 4 * i, 5 + 4 * i), st + o.s[i],
                  GA, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo, (long long)B * Co * Ho * Wo, ns,
                  GB, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo, 0, B, Co, Ho, Wo, ACT_SILU);
-        const float* hin = (i == 0) ? (st + o.y0) : (st + o.y[i - 1]);
         CView dyv{GB, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo};
         conv_wgrad(ex, n.ds[i], G, B, Hi, Wi, CView{hin, (long long)Ci * Hi * Wi, (long long)Hi * Wi, Wi}, dyv);
         conv_dgrad(ex, n.ds[i], packed, B, Hi, Wi, dyv, View{GA, (long long)Ci * Hi * Wi, (long long)Hi * Wi, Wi}, (long long)B * Ci * Hi * Wi, 0, 1, &ns);
@@ -2124,18 +2305,34 @@ int mcvc_disc_pack(const float* const* params, float* packed, void* stream)
 // K-major FORWARD copy + bias -- their data gradient multiplies the OIHW parameters themselves and their weight gradient reads no weights
 // at all; the first / output layers (tiny) are refreshed in full.  Falls back to the full pack when a layer would not take that path at
 // (B = 1, T).  The direct kernels' data-gradient copies are then marked stale (bit 8) and refuse to run.
-int mcvc_disc_pack_small(const float* const* params, float* packed, int T, void* stream)
+int mcvc_disc_pack_small(const float* const* params, float* packed, int T, void* stream) { return mcvc_disc_pack_batch(params, packed, 1, T, stream); }
+
+// ... for passes of up to max_batch samples: the per-class data-gradient copies of the implicit GEMMs are refreshed only when some pass is large
+// enough to use them (MCVC_IGEMM_DGRAD_NB)
+int mcvc_disc_pack_batch(const float* const* params, float* packed, int max_batch, int T, void* stream)
 {
     const DiscNet& n = disc_net();
-    const DiscDims d = disc_dims(1, T);
+    const DiscDims d = disc_dims(max_batch < 1 ? 1 : max_batch, T);
     bool staged = true;
     for (int i = 0; i < 3; ++i) staged = staged && sgemm_kind(n.ds[i], 1, d.H[i], d.W[i]).kind == 1;
     if (!staged) { set_pack_skips(packed, 0); return mcvc_disc_pack(params, packed, stream); }
     int err = 0;
+    if (disc_igemm(d)) {          // implicit GEMMs: the tap-major forward copy (+ the per-class data-gradient copies) of the stride-2 layers
+        const bool dg = disc_igemm_dgrad(d);
+        const DevPackTable* t = dev_pack_table(dg ? 3 : 4, [dg](PackTable& pt) {
+            const DiscNet& n = disc_net();
+            add_spec_jobs(pt, n.conv1);
+            for (int i = 0; i < 3; ++i) add_spec_jobs(pt, n.ds[i], false, false, dg ? 3 : 1, true, true, true);
+            add_spec_jobs(pt, n.outc);
+        }, &err);
+        if (!t) return err;
+        set_pack_skips(packed, dg ? 8 : (8 | 64));          // (bit 64: the per-class data-gradient copies of the implicit GEMMs are stale)
+        return pack_net(t, params, packed, (hipStream_t)stream);
+    }
     const DevPackTable* t = dev_pack_table(2, [](PackTable& pt) {
         const DiscNet& n = disc_net();
         add_spec_jobs(pt, n.conv1);
-        for (int i = 0; i < 3; ++i) add_spec_jobs(pt, n.ds[i], false, false, 1);
+        for (int i = 0; i < 3; ++i) add_spec_jobs(pt, n.ds[i], false, false, 1 | 4);
         add_spec_jobs(pt, n.outc);
     }, &err);
     if (!t) return err;

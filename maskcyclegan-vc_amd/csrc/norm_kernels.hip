@@ -36,6 +36,33 @@ __device__ __forceinline__ float gsum(float v, float* red)
     }
 }
 
+// zero borders of one (n, c) plane group in the phase-split padded layout (row 0 and columns 0..3 of the four sub-planes), by a group of G lanes
+template <int G>
+__device__ __forceinline__ void xs_zero_borders(float* y0, int H, int pw, long long plane, int l)
+{
+    const int per = pw + 4 * (H >> 1);
+    for (int i = l; i < 4 * per; i += G) {
+        const int pq = i / per, j = i - pq * per;
+        float* p = y0 + pq * plane;
+        if (j < pw) p[j] = 0.f;
+        else { const int r = (j - pw) >> 2, cc = (j - pw) & 3; p[(long long)(r + 1) * pw + cc] = 0.f; }
+    }
+}
+__device__ __forceinline__ long long xs_off(int h, int w, int pw, long long plane)
+{
+    return (long long)((h & 1) * 2 + (w & 1)) * plane + (long long)((h >> 1) + 1) * pw + (w >> 1) + 4;
+}
+// zero borders of one padded dY plane (columns W .. pitch-1 of rows 0 .. H-1, and row H)
+template <int G>
+__device__ __forceinline__ void dyp_zero_borders(float* d0, int H, int W, int pitch, int l)
+{
+    const int pc = pitch - W, per = H * pc + pitch;
+    for (int i = l; i < per; i += G) {
+        if (i < H * pc) { const int r = i / pc, cc = i - r * pc; d0[(long long)r * pitch + W + cc] = 0.f; }
+        else d0[(long long)H * pitch + (i - H * pc)] = 0.f;
+    }
+}
+
 template <int G>
 __global__ void __launch_bounds__(256) norm_fwd_kernel(const Twin<NormArgs> tw)
 {
@@ -94,10 +121,11 @@ __global__ void __launch_bounds__(256) norm_fwd_kernel(const Twin<NormArgs> tw)
         } else {
             y = z0;
         }
-        const long long yo = yoff0 + (long long)h * a.y_sh + w;
+        const long long yo = a.y_xs ? yoff0 + xs_off(h, w, a.xs_pw, a.xs_plane) : yoff0 + (long long)h * a.y_sh + w;
         if (a.res) y += a.res[yo];
         a.y[yo] = y;
     }
+    if (a.y_xs) xs_zero_borders<G>(a.y + yoff0, a.H, a.xs_pw, a.xs_plane, l);
 }
 
 // one group per channel c, looping over n: d(gamma), d(beta) are owned by the group -> no atomics,
@@ -185,13 +213,16 @@ __global__ void __launch_bounds__(256) norm_bwd_kernel(const Twin<NormBwdArgs> t
                 const int co = 4 * c + 2 * (h & 1) + (w & 1);
                 a.dx[(long long)n * a.dx_sn + (long long)co * a.dx_sc + (long long)(h >> 1) * a.dx_sh + (w >> 1)] = dx0;
             } else {
-                a.dx[(long long)n * a.dx_sn + (long long)c * a.dx_sc + i] = dx0;
+                const long long di = a.dx_pitch ? (long long)h * a.dx_pitch + w : i;
+                a.dx[(long long)n * a.dx_sn + (long long)c * a.dx_sc + di] = dx0;
                 if (nbr == 2) {
                     const float dx1 = gam[1] * rstd[1] * (dz1 - s1[1] * invP - xh1 * (s2[1] * invP));
-                    a.dx[(long long)n * a.dx_sn + (long long)(c + a.C) * a.dx_sc + i] = dx1;
+                    a.dx[(long long)n * a.dx_sn + (long long)(c + a.C) * a.dx_sc + di] = dx1;
                 }
             }
         }
+        if (a.dx_pitch && !a.unshuffle)
+            for (int br = 0; br < nbr; ++br) dyp_zero_borders<G>(a.dx + (long long)n * a.dx_sn + (long long)(c + br * a.C) * a.dx_sc, a.H, a.W, a.dx_pitch, l);
     }
     if (l == 0) {
         for (int br = 0; br < nbr; ++br) {
@@ -245,7 +276,7 @@ __global__ void __launch_bounds__(256) norm_fwd_reg_kernel(const Twin<NormArgs> 
     for (int e = 0; e < E; ++e) {
         const int i = l + e * G;
         const int h = i / a.W, w = i - h * a.W;
-        yo[e] = yoff0 + (long long)h * a.y_sh + w;
+        yo[e] = a.y_xs ? yoff0 + xs_off(h, w, a.xs_pw, a.xs_plane) : yoff0 + (long long)h * a.y_sh + w;
         rv[e] = (a.res != nullptr && i < P) ? a.res[yo[e]] : 0.f;
     }
     const float g0 = a.gamma[0][c], b0 = a.beta[0][c];
@@ -289,6 +320,7 @@ __global__ void __launch_bounds__(256) norm_fwd_reg_kernel(const Twin<NormArgs> 
             a.y[yo[e]] = y + rv[e];
         }
     }
+    if (a.y_xs) xs_zero_borders<G>(a.y + yoff0, a.H, a.xs_pw, a.xs_plane, l);
 }
 
 template <int G, int E>
@@ -385,14 +417,17 @@ __global__ void __launch_bounds__(256) norm_bwd_reg_kernel(const Twin<NormBwdArg
                     const int co = 4 * c + 2 * (h & 1) + (w & 1);
                     a.dx[(long long)n * a.dx_sn + (long long)co * a.dx_sc + (long long)(h >> 1) * a.dx_sh + (w >> 1)] = dx0;
                 } else {
-                    a.dx[(long long)n * a.dx_sn + (long long)c * a.dx_sc + i] = dx0;
+                    const long long di = a.dx_pitch ? (long long)hh[e] * a.dx_pitch + ww[e] : i;
+                    a.dx[(long long)n * a.dx_sn + (long long)c * a.dx_sc + di] = dx0;
                     if (nbr == 2) {
                         const float dx1 = gam[1] * rstd[1] * (dz[1][e] - s1[1] * invP - xh[1][e] * (s2[1] * invP));
-                        a.dx[(long long)n * a.dx_sn + (long long)(c + a.C) * a.dx_sc + i] = dx1;
+                        a.dx[(long long)n * a.dx_sn + (long long)(c + a.C) * a.dx_sc + di] = dx1;
                     }
                 }
             }
         }
+        if (a.dx_pitch && !a.unshuffle)
+            for (int br = 0; br < nbr; ++br) dyp_zero_borders<G>(a.dx + (long long)n * a.dx_sn + (long long)(c + br * a.C) * a.dx_sc, a.H, a.W, a.dx_pitch, l);
     }
     if (l == 0 && n_begin < n_end) {
         for (int br = 0; br < nbr; ++br) {

@@ -20,6 +20,8 @@ struct PackDgradArgs {
     int mg_kh, mg_kw;      // common tap window of the merged layout
     int ncls;
     DgradClass cls[4];
+    int tapmajor;          // 1: rows (t, co) instead of (co, t): row = t * cout_rows + co_off + co (the implicit GEMM's per-class A operand)
+    int cout_rows;         // rows per tap (= concatenated output channels)
 };
 
 int mcvc_pack_fwd_launch(const float* w, float* dst, int Cout, int K, int ld, int co_off, hipStream_t s);
@@ -27,7 +29,8 @@ int mcvc_pack_dgrad_launch(const float* w, float* dst, const PackDgradArgs& a, i
 int mcvc_copy_launch(const float* src, float* dst, int n, hipStream_t s);
 
 // ---- whole-network re-pack (one launch): device-resident job table
-enum PackKind { PACK_FWD = 0, PACK_DGRAD = 1, PACK_COPY = 2, PACK_TRUNK_T = 3, PACK_WINO_F = 4, PACK_WINO_D = 5, PACK_WINO3_D = 6, PACK_WINO3_F = 7, PACK_WINO4_F = 8, PACK_WINO4_D = 9, PACK_WINO43_D = 10, PACK_WINO43_F = 11 };
+enum PackKind { PACK_FWD = 0, PACK_DGRAD = 1, PACK_COPY = 2, PACK_TRUNK_T = 3, PACK_WINO_F = 4, PACK_WINO_D = 5, PACK_WINO3_D = 6, PACK_WINO3_F = 7, PACK_WINO4_F = 8, PACK_WINO4_D = 9, PACK_WINO43_D = 10, PACK_WINO43_F = 11,
+                PACK_FWD_TAP = 12 };      // forward K-major copy with TAP-major rows: dst[(tap * Cin + ci) * ld + co]   (implicit GEMM, sgemm.h)
 struct PackJob {
     int kind, param;       // param = index into the parameter-pointer table
     int block0, gx;        // first workgroup of this job in the flat grid; tile (bx, by) = (rel % gx, rel / gx)

@@ -18,8 +18,9 @@
 #include "wino4.h"
 
 // [R=Cout][K] -> dst[k*ld + co_off + co], 32x32 LDS tiles, both sides coalesced
+// taps > 0: the rows are re-ordered tap-major (k = ci * taps + tap  ->  row tap * Cin + ci)
 __device__ __forceinline__ void pack_fwd_tile(const float* __restrict__ w, float* __restrict__ dst, int Cout, int K, int ld, int co_off,
-                                              int bx, int by, float* smem)
+                                              int bx, int by, float* smem, int taps = 0)
 {
     float (*tile)[33] = reinterpret_cast<float (*)[33]>(smem);
     const int k0 = bx * 32, c0 = by * 32;
@@ -31,7 +32,10 @@ __device__ __forceinline__ void pack_fwd_tile(const float* __restrict__ w, float
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int k = k0 + r, co = c0 + tx;
-        if (k < K && co < Cout) dst[(long long)k * ld + co_off + co] = tile[tx][r];
+        if (k < K && co < Cout) {
+            const int row = taps > 0 ? (k % taps) * (K / taps) + k / taps : k;
+            dst[(long long)row * ld + co_off + co] = tile[tx][r];
+        }
     }
 }
 
@@ -53,7 +57,9 @@ __device__ __forceinline__ void pack_dgrad_tile(const float* __restrict__ w, flo
             const int kh = a.cls[c].khmax - a.step * u, kw = a.cls[c].kwmax - a.step * v;
             if (lane < nci) {
                 const float wv = lds[lane * khkw + kh * a.KW + kw];
-                if (a.merged) {
+                if (a.tapmajor) {
+                    dst[a.cls[c].offset + ((long long)t * a.cout_rows + a.co_off + co) * a.ld + ci0 + lane] = wv;
+                } else if (a.merged) {
                     const long long row = ((long long)(a.co_off + co) * a.mg_kh + (u + a.cls[c].su)) * a.mg_kw + (v + a.cls[c].sv);
                     dst[row * a.ld + 4 * (ci0 + lane) + 2 * a.cls[c].qh + a.cls[c].qw] = wv;
                 } else {
@@ -137,6 +143,7 @@ __global__ void __launch_bounds__(256) pack_net_kernel(const Twin<PackNetKArgs> 
     float* dst = packed + j.dst;
     switch (j.kind) {
     case PACK_FWD: pack_fwd_tile(w, dst, j.Cout, j.K, j.ld, j.co_off, bx, by, lds); break;
+    case PACK_FWD_TAP: pack_fwd_tile(w, dst, j.Cout, j.K, j.ld, j.co_off, bx, by, lds, j.KW); break;          // (KW field = taps per channel)
     case PACK_DGRAD: pack_dgrad_tile(w, dst, dga[j.dg], bx, by, lds); break;
     case PACK_TRUNK_T: pack_trunk_t_tile(w, dst, j.Cout, j.Cin, j.KW, j.ld, j.co_off, bx, by, lds); break;
     case PACK_WINO_F: wino_weight_tile(w, dst, j.Cout, j.Cin, j.ld, j.xi_stride, j.co_off, 0, bx, by); break;

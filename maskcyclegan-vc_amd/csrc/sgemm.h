@@ -30,11 +30,47 @@ struct SGemmArgs {
 };
 int mcvc_sgemm_launch(const SGemmArgs& a, hipStream_t s);
 
+// ---- implicit GEMM (r4): the B operand is gathered from the activation itself, no tap planes in HBM --------------------------------------
+// One launch = up to 4 products ("classes": blockIdx.y) that share B, C and the geometry.  A class is  C_c[m][n] = sum_{t, c} A_c[t*Cb + c][m] *
+// B(t, c, n)  with a per-tap shift of the gathered window:
+//     B(t, c, n = (bb, i, j)) = b[boff_c[t] + c*b_cs + bb*b_sn + i*b_pitch + j]        (i, j = row / column of n inside its image: n % P = i*OW + j)
+//     C_c(m, n)               = c[coff_c + m*ldc + bb*c_sn + i*c_sh + j*c_sw]
+// A stage of 32 k lies inside one tap (Cb % 32 == 0), so its B rows are 32 consecutive channels at one uniform offset: the same 16-byte
+// LDS-DMA pieces as the plain GEMM, at addresses that are only 4-byte aligned where a tap shifts the window by one column (measured: fine).
+//   forward of a 3x3 stride-2 convolution: one class, 9 taps over the PHASE-SPLIT padded input (xs layout below), C = y in place;
+//   data gradient: the four output-parity classes (1 + 2 + 2 + 4 taps) over dY with one zero column / row of padding, C scattered to
+//   dx[2a + qh][2b + qw] -- every input pixel is written by exactly one class: no tap planes, no gather kernel, no atomics.
+struct IGemmClass { const float* a; int ntaps; long long coff; long long boff[9]; };
+struct IGemmArgs {
+    IGemmClass cls[4]; int ncls;
+    long long lda;
+    const float* b; long long b_cs, b_sn; int b_pitch;
+    int Cb;                             // channels per tap; K of class c = cls[c].ntaps * Cb
+    int OW, P;                          // n -> (bb = n / P, i = (n % P) / OW, j = n % OW);  OW % 4 == 0
+    float* c; long long ldc, c_sn; int c_sh, c_sw;
+    const float* bias; int accumulate;
+    int M, N;                           // M % 64 == 0, N % 4 == 0
+    int nsplit; float* c_slab; long long c_split;      // K split of every class: split s > 0 writes the C layout at c_slab + (s - 1) * c_split
+    int nt, mt;                         // (filled by the launcher)
+};
+int mcvc_igemm_launch(const IGemmArgs& a, hipStream_t s);
+
+// Phase-split padded activation layout ("xs") read by the implicit forward GEMM of a 3x3 stride-2 padding-1 convolution over an H x W image
+// (H, W even): per (sample, channel) four planes pq = 2*(h & 1) + (w & 1), each (H/2 + 1) rows of PW = W/2 + 4 floats; element (h, w) sits at
+// row (h >> 1) + 1, column (w >> 1) + 4; row 0 and columns 0..3 are zero (the taps kh = 0 / kw = 0 of the first output row / column read them).
+static inline int mcvc_xs_pw(int W) { return W / 2 + 4; }
+static inline long long mcvc_xs_plane(int H, int W) { return (long long)(H / 2 + 1) * (W / 2 + 4); }
+static inline long long mcvc_xs_floats(int C, int H, int W) { return 4LL * C * mcvc_xs_plane(H, W); }       // per sample
+// dY layout read by the implicit data gradient: planes of (OH + 1) rows x (OW + 4) floats, zero beyond row OH - 1 / column OW - 1
+static inline int mcvc_dyp_pitch(int OW) { return OW + 4; }
+static inline long long mcvc_dyp_plane(int OH, int OW) { return (long long)(OH + 1) * (OW + 4); }
+
 struct StageArgs {
     const float* x; long long x_sb, x_sc; int x_sh;      // image view [NB][C][H][W] (W contiguous)
     int NB, C, H, W, OH, OW;                               // 3x3, stride 2, padding 1: OH = (H + 1) / 2 ...
     float* out; long long ld;                              // see the launchers
     int rows_pad;                                          // transposed forms: rows [NB*OH*OW, rows_pad) are written as zeros
+    int xs;                                                // im2col_s2_t: x is in the phase-split padded layout (x_sb / x_sc = its sample / channel strides)
 };
 // Xcol[k = 9*ci + tap][n], ld >= NB*OH*OW
 int mcvc_im2col_s2_launch(const StageArgs& a, hipStream_t s);

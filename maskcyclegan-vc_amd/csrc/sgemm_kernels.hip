@@ -126,6 +126,119 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const Twin<SGemmArgs> tw)
     }
 }
 
+
+// ---- implicit GEMM: sgemm_kernel with a gathered B operand, per-class A / C and a strided (scatter) C store -- see sgemm.h ----------------
+__global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
+{
+    const IGemmArgs& a = tw.v[blockIdx.z];
+    const IGemmClass& cl = a.cls[blockIdx.y];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    int lid;
+    {   // consecutive tiles (same A panel) on the same XCD: they share its L2
+        const int total = (int)gridDim.x, linear = (int)blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = linear & 7, k = linear >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int nt = a.nt, mt = a.mt, nsplit = a.nsplit, Cb = a.Cb, OW = a.OW, P = a.P, N = a.N;
+    const long long lda = a.lda, b_cs = a.b_cs, b_sn = a.b_sn;
+    const int b_pitch = a.b_pitch;
+    const int n0 = (lid % nt) * BN; lid /= nt;
+    const int m0 = (lid % mt) * BM;
+    const int ks = lid / mt;
+    const int Kc = cl.ntaps * Cb / nsplit;
+    const int kbase = ks * Kc;
+    const float* const A = cl.a;
+    const float* const Bp = a.b;
+    long long aoff[NA], boff[NBI]; int adst[NA], bdst[NBI];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int f = tid + i * 256;
+        aoff[i] = (long long)(f / (BM / 4)) * lda + m0 + 4 * (f % (BM / 4));
+        adst[i] = (wave * 64 + i * 256) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) {
+        const int f = tid + i * 256;
+        int n = n0 + 4 * (f % (BN / 4));
+        if (n > N - 4) n = N - 4;                                  // columns past N: any valid address (masked at the store)
+        const int bb = n / P, rem = n - bb * P;
+        const int ii = rem / OW, jj = rem - ii * OW;
+        boff[i] = (long long)(f / (BN / 4)) * b_cs + (long long)bb * b_sn + (long long)ii * b_pitch + jj;
+        bdst[i] = SA + (wave * 64 + i * 256) * 4;
+    }
+    auto issue = [&](int stage_k, int buf) {
+        float* base = smem + buf * STAGE;
+        const int k0 = kbase + stage_k * GK;
+        const int t = k0 / Cb, c0 = k0 - t * Cb;                  // (a stage lies inside one tap: Cb % 32 == 0)
+        const float* ab = A + (long long)k0 * lda;
+        const float* bb = Bp + cl.boff[t] + (long long)c0 * b_cs;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) glds16(ab + aoff[i], base + adst[i]);
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) glds16(bb + boff[i], base + bdst[i]);
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nst = Kc / GK;
+#pragma unroll
+    for (int s = 0; s < ST - 1; ++s)
+        if (s < nst) issue(s, s);
+    const int a_lane = half * BM + wm * 32 + l31;                  // A[k = 2p + half][m]
+    const int b_lane = SA + half * BN + wn * 32 + l31;             // B[k = 2p + half][n]
+    for (int st = 0; st < nst; ++st) {
+        const int newer = (nst - 1 - st) < (ST - 2) ? (nst - 1 - st) : (ST - 2);
+        if (newer >= 2) wait_vm<2 * ND>(); else if (newer == 1) wait_vm<ND>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        if (st + ST - 1 < nst) issue(st + ST - 1, (st + ST - 1) % ST);
+        const float* sb = smem + (st % ST) * STAGE;
+        float a0 = sb[a_lane], b0 = sb[b_lane];
+#pragma unroll
+        for (int p = 0; p < GK / 2; ++p) {
+            const int q = (p + 1 < GK / 2) ? p + 1 : p;
+            const float na0 = sb[a_lane + q * 2 * BM], nb0 = sb[b_lane + q * 2 * BN];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            a0 = na0; b0 = nb0;
+        }
+    }
+    const int n = n0 + wn * 32 + l31;
+    const long long ldc = a.ldc;
+    const int accumulate = a.accumulate;
+    const float* bias = a.bias;
+    if (n < N) {
+        const int bb = n / P, rem = n - bb * P;
+        const int ii = rem / OW, jj = rem - ii * OW;
+        const int mb = m0 + wm * 32 + 4 * half;
+        const long long coff = cl.coff + (long long)bb * a.c_sn + (long long)ii * a.c_sh + (long long)jj * a.c_sw + (long long)mb * ldc;
+        if (ks) {
+            float* slab = a.c_slab + (long long)(ks - 1) * a.c_split + coff;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(long long)((r & 3) + 8 * (r >> 2)) * ldc] = acc[r];
+        } else {
+            float* row0 = a.c + coff;
+            float bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = bias ? bias[mb + (r & 3) + 8 * (r >> 2)] : 0.f;
+            if (accumulate) {                    // (all 16 loads of the read-modify-write before the first store)
+                float old[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[r] = row0[(long long)((r & 3) + 8 * (r >> 2)) * ldc];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) row0[(long long)((r & 3) + 8 * (r >> 2)) * ldc] = old[r] + acc[r] + bv[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) row0[(long long)((r & 3) + 8 * (r >> 2)) * ldc] = acc[r] + bv[r];
+            }
+        }
+    }
+}
+
 // ---- staging ----------------------------------------------------------------------------------------------------------------
 // tap (kh, kw) of output pixel (oh, ow) reads x[2*oh + kh - 1][2*ow + kw - 1]
 __global__ void __launch_bounds__(256) im2col_s2_kernel(const Twin<StageArgs> tw)
@@ -161,6 +274,8 @@ __global__ void __launch_bounds__(256) im2col_s2_t_kernel(const Twin<StageArgs> 
     const long long n0 = (long long)blockIdx.x * 32;
     const int c0 = blockIdx.y * 32;
     const int nl = threadIdx.x & 31, cw = threadIdx.x >> 5;        // 8 channel rows per sweep
+    const int xs_pw = a.W / 2 + 4;
+    const long long xs_plane = (long long)(a.H / 2 + 1) * xs_pw;
     const long long n = n0 + nl;
     const bool live = n < NT;
     int b = 0, oh = 0, ow = 0;
@@ -175,7 +290,9 @@ __global__ void __launch_bounds__(256) im2col_s2_t_kernel(const Twin<StageArgs> 
             for (int kw = 0; kw < 3; ++kw) {
                 const int iw = 2 * ow + kw - 1;
                 const bool ok = live && ci < a.C && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-                tile[nl][cl * 9 + 3 * kh + kw] = ok ? xp[(long long)ih * a.x_sh + iw] : 0.f;
+                const long long xo = a.xs ? (long long)((ih & 1) * 2 + (iw & 1)) * xs_plane + (long long)((ih >> 1) + 1) * xs_pw + (iw >> 1) + 4
+                                          : (long long)ih * a.x_sh + iw;
+                tile[nl][cl * 9 + 3 * kh + kw] = ok ? xp[xo] : 0.f;
             }
         }
     }
@@ -382,6 +499,35 @@ int mcvc_sgemm_launch(const SGemmArgs& a0, hipStream_t s)
     }
     TraceScope ts(K_SGEMM, s, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.K * a.M + (double)a.K * a.N + (double)a.M * a.N * a.nsplit));
     mcvc_launch(sgemm_kernel, dim3((unsigned)(a.nt * a.mt * a.nsplit)), dim3(256), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+int mcvc_igemm_launch(const IGemmArgs& a0, hipStream_t s)
+{
+    IGemmArgs a = a0;
+    if (a.nsplit < 1) a.nsplit = 1;
+    if (a.ncls < 1 || a.ncls > 4 || (a.M % BM) != 0 || (a.N & 3) || a.N < 4 || (a.lda & 3) || (a.Cb % GK) != 0 || (a.OW & 3) || a.P < a.OW || (a.P % a.OW) != 0 ||
+        (a.nsplit > 1 && !a.c_slab))
+        return MCVC_ERR_INVALID;
+    double flops = 0.0, bytes = 0.0;
+    for (int c = 0; c < a.ncls; ++c) {
+        const IGemmClass& k = a.cls[c];
+        if (!k.a || k.ntaps < 1 || k.ntaps > 9 || ((long long)k.ntaps * a.Cb) % (GK * a.nsplit) != 0) return MCVC_ERR_INVALID;
+        const double K = (double)k.ntaps * a.Cb;
+        flops += 2.0 * a.M * a.N * K;
+        bytes += 4.0 * (K * a.M + (double)a.M * a.N * a.nsplit);
+    }
+    bytes += 4.0 * (double)a.Cb * a.N * 2.25;            // (the gathered activation: read once from HBM, the taps' overlap hits in L2)
+    a.nt = cdiv_i(a.N, BN); a.mt = a.M / BM;
+    constexpr size_t lds = (size_t)ST * STAGE * sizeof(float);
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    TraceScope ts(K_SGEMM, s, flops, bytes);
+    mcvc_launch(igemm_kernel, dim3((unsigned)(a.nt * a.mt * a.nsplit), (unsigned)a.ncls), dim3(256), lds, s, a);
     return (int)hipGetLastError();
 }
 

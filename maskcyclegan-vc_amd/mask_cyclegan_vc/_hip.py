@@ -49,6 +49,7 @@ _SIGS = {
     "mcvc_gen_pack_ranges": (c_int, [_PP, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mcvc_disc_pack": (c_int, [_PP, c_void_p, c_void_p]),
     "mcvc_disc_pack_small": (c_int, [_PP, c_void_p, c_int, c_void_p]),
+    "mcvc_disc_pack_batch": (c_int, [_PP, c_void_p, c_int, c_int, c_void_p]),
     "mcvc_gen_forward": (c_int, [_PP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "mcvc_gen_backward": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p]),
     "mcvc_gen_backward_overlap": (c_int, [_PP, c_void_p, _PP, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int,

@@ -328,7 +328,7 @@ class TrainEngine:
         if B > self._max_B:                 # a larger batch than any so far may leave the fused-trunk regime: full re-pack
             self._max_B = B
             if hasattr(self, "packed"):
-                self.repack(G_NAMES)
+                self.repack(G_NAMES + D_NAMES)         # (the discriminators' copies depend on the largest pass as well: mcvc_disc_pack_batch)
         ws = self._workspaces.get(B)
         if ws is None:
             L, T, dev = self.L, self.T, self.device
@@ -406,7 +406,8 @@ class TrainEngine:
             per = 3 if (self.merged and self._merged_ok(self._max_B)) else 2
             check(self.L.mcvc_gen_pack_ranges(self._p_tab[n], ptr(self.packed[n]), per * self._max_B, self.T, sets, ranges, stream()), "pack " + n)
         else:
-            check(self.L.mcvc_disc_pack_small(self._p_tab[n], ptr(self.packed[n]), self.T, stream()), "pack " + n)
+            # (every discriminator pass of this engine has at most 2 * max_B samples)
+            check(self.L.mcvc_disc_pack_batch(self._p_tab[n], ptr(self.packed[n]), 2 * self._max_B, self.T, stream()), "pack " + n)
 
     def repack(self, names):
         """Refresh the K-major weight copies (one lane per network when running concurrently)."""
