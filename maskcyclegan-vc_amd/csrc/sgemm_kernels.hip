@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const Twin<SGemmArgs> tw)
 __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
 {
     const IGemmArgs& a = tw.v[blockIdx.z];
-    const IGemmClass& cl = a.cls[blockIdx.y];
+    const IGemmClass& cl = a.cls[gridDim.y - 1 - blockIdx.y];        // (classes are listed by ascending tap count: the longest first)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -609,16 +609,22 @@ class TrainEngine:
         # adversarial gradients that the cycle backward accumulates onto (dA, dB), and the two backward passes of one generator, which
         # accumulate into the same weight gradients (c0, c1).
         cl, il = sc.cycle_loss_lambda, sc.identity_loss_lambda
+        # After the identity cut-off (train.py:314-315: lambda = 0 for the rest of training, 98 % of a default run) the identity passes are
+        # dead code -- their loss term weighs 0 and so does every gradient behind it; like the discriminators' weight gradients of this
+        # phase they are not computed: the translation passes run over B samples instead of 2B.
+        nbt = B2 if il != 0 else B
 
         def cycle_a(ln):
             self._G("generator_B2A", fake_B, None, m["cycle_A"], self.g_stash1[0], B, ln)                  # :204 (mask of ones)
             self._l1(m["cycle_A"], real_A, cl, m["g_cycle_A"], 0)                                          # :219
-            self._l1(identity_B, real_B, il, g_identity_B, 3)                                              # :224
+            if il != 0:
+                self._l1(identity_B, real_B, il, g_identity_B, 3)                                          # :224
 
         def cycle_b(ln):
             self._G("generator_A2B", fake_A, None, m["cycle_B"], self.g_stash1[1], B, ln)                  # :206
             self._l1(m["cycle_B"], real_B, cl, m["g_cycle_B"], 1)                                          # :220
-            self._l1(identity_A, real_A, il, g_identity_A, 2)                                              # :223
+            if il != 0:
+                self._l1(identity_A, real_A, il, g_identity_A, 2)                                          # :223
 
         def adv(name, i, x, gx, acc):
             def run(ln):
@@ -661,8 +667,8 @@ class TrainEngine:
             return run
         assert G_NAMES[0] == "generator_A2B"
         self._run_tasks([
-            (0, lambda ln: self._G("generator_A2B", self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], B2, ln), (), "g0"),   # :203, :209-210
-            (1, lambda ln: self._G("generator_B2A", self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], B2, ln), (), "g1"),   # :205, :207-208
+            (0, lambda ln: self._G("generator_A2B", self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], nbt, ln), (), "g0"),   # :203, :209-210
+            (1, lambda ln: self._G("generator_B2A", self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], nbt, ln), (), "g1"),   # :205, :207-208
             (0, cycle_a, (), None),
             (1, cycle_b, (), None),
             (2, finish_d, (), None),
@@ -674,8 +680,8 @@ class TrainEngine:
             (0, lambda ln: self._G_bwd("generator_B2A", None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B, ln), ("dB",), "c0"),
             (1, lambda ln: self._G_bwd("generator_A2B", None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, ln), ("dA",), "c1"),
             # the last pass over each generator: its gradient ranges become final one after the other (milestone events)
-            (0, lambda ln: self._G_bwd("generator_A2B", self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], B2, ln, ov), ("c1",), "fA2B"),
-            (1, lambda ln: self._G_bwd("generator_B2A", self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], B2, ln, ov), ("c0",), "fB2A"),
+            (0, lambda ln: self._G_bwd("generator_A2B", self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], nbt, ln, ov), ("c1",), "fA2B"),
+            (1, lambda ln: self._G_bwd("generator_B2A", self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], nbt, ln, ov), ("c0",), "fB2A"),
         ] + ([(2, queue_reduce, (), None)] if (fuse_update and ov) else [])
           + ([(0, update("generator_A2B"), (), None), (1, update("generator_B2A"), (), None)] if fuse_update else []))
         self._g_fwd_packed = bool(fuse_update)
@@ -703,7 +709,8 @@ class TrainEngine:
         A2B, B2A = G_NAMES
         ov = self.overlap_g_reduce
         ms_on = ov or ranged                   # milestone events of the last backward pass: gradient exchange and / or ranged update
-        ident = self.grouped_ident
+        ident = self.grouped_ident and il != 0
+        ident_dead = il == 0                   # (after the identity cut-off the identity passes are dead code: see generator_phase)
         g_lr = sc.g_opt_lr
         P = {}
 
@@ -718,7 +725,7 @@ class TrainEngine:
                                  [real_A, real_B, real_B, real_A, mask_A, mask_B])     # one launch; the masks' second halves stay all-ones
 
         def fwd2(ln):                                                                                       # :203, :205, :207-210
-            nb = B if ident else B2                    # (the halves of the batched buffers are contiguous: translation first, identity second)
+            nb = B if (ident or ident_dead) else B2    # (the halves of the batched buffers are contiguous: translation first, identity second)
             self._twin(lambda: self._G(A2B, self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], nb, 0),
                        lambda: self._G(B2A, self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], nb, 1))
 
@@ -739,12 +746,12 @@ class TrainEngine:
             if k == 0:
                 self._G(B2A, fake_B, None, m["cycle_A"], self.g_stash1[0], B, 0)                           # :204 (mask of ones)
                 self._l1(m["cycle_A"], real_A, cl, m["g_cycle_A"], 0)                                       # :219
-                if not ident:
+                if not ident and not ident_dead:
                     self._l1(identity_B, real_B, il, g_identity_B, 3)                                       # :224
             else:
                 self._G(A2B, fake_A, None, m["cycle_B"], self.g_stash1[1], B, 1)                           # :206
                 self._l1(m["cycle_B"], real_B, cl, m["g_cycle_B"], 1)                                       # :220
-                if not ident:
+                if not ident and not ident_dead:
                     self._l1(identity_A, real_A, il, g_identity_A, 2)                                       # :223
 
         def cycle(ln):
@@ -782,7 +789,7 @@ class TrainEngine:
                        lambda: self._G_bwd(A2B, None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, 1, aux_lane=0, no_join=nj))
 
         def bwd_final(ln):      # the last pass over each generator; its gradient ranges become final one after the other (milestone events)
-            nb = B if ident else B2
+            nb = B if (ident or ident_dead) else B2
             self._twin(lambda: self._G_bwd(A2B, self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], nb, fs[0], ms_on, aux_lane=0, ms_of=A2B),
                        lambda: self._G_bwd(B2A, self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], nb, fs[1], ms_on, aux_lane=0, ms_of=A2B))
 
@@ -1093,7 +1100,9 @@ class TrainEngine:
         return 3 * B * (self.T // 4) <= 48 and self.T % 4 == 0
 
     def _use_merged(self):
-        return self.merged and self._use_pipeline() and not self.grouped_ident and self._merged_ok(self.B) and hasattr(self, "in3")
+        # (after the identity cut-off the merged passes would carry a dead sample: the separate passes skip it)
+        return self.merged and self._use_pipeline() and not self.grouped_ident and self._merged_ok(self.B) and hasattr(self, "in3") and \
+            self.sched.identity_loss_lambda != 0
 
     def _merged_step(self):
         """``_pipelined_step`` with the discriminator phase's generator forwards INSIDE the generator phase's passes.
