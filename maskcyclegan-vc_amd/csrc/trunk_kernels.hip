@@ -54,7 +54,10 @@ __host__ __device__ inline int trunk_rs(int B, int T4, int KW)
 }
 __host__ __device__ inline int trunk_na(int N) { return (N + 15) >> 4; }
 // epilogue scratch of one workgroup: red[waves][NA][4][64] | tile[16][16 NA + 1] | sstat[16][8][2] | 16 spare (flag)
-__host__ __device__ inline int trunk_epi_floats(int NA) { return kTrunkWaves * NA * 4 * 64 + 16 * (16 * NA + 1) + 16 * 8 * 2 + 16; }
+// (red rows are kRedPitch = 80 floats apart, not 64: the reducing threads of a 32-lane group read two accumulator registers r, r + 1 of 16
+//  lanes each -- 64 apart they would share their 16 banks, 80 apart they sit 16 banks apart)
+constexpr int kRedPitch = 80;
+__host__ __device__ inline int trunk_epi_floats(int NA) { return kTrunkWaves * NA * 4 * kRedPitch + 16 * (16 * NA + 1) + 16 * 8 * 2 + 16; }
 
 // zero every staged slot that holds no value: the 4 leading zeros of each row (k = 3), the pad behind the last row of a channel, and
 // 4 floats behind the last channel (right halo of the very last row / the idle lanes' zero slot)
@@ -186,6 +189,13 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
                 const float gr = gate ? g1 * r1 : g0 * r0;
                 float* xrow = smem + ci * RS + b * TP + DOFF;
                 float* od = out ? (a.pre_out + ((long long)cx * a.B + b) * a.T4 + t0) : nullptr;
+                if (a.T4 == 16 && KW == 3) {          // (the trainer's shape: four elements per lane = one 16-byte store, LDS and global)
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = gr * (dzv[e] - s1 * invT - xhv[e] * (s2 * invT));
+                    *reinterpret_cast<float4*>(xrow + t0) = make_float4(o[0], o[1], o[2], o[3]);
+                    if (od) *reinterpret_cast<float4*>(od) = make_float4(o[0], o[1], o[2], o[3]);
+                } else
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (e < E && (t0 + e) < a.T4) {
@@ -307,15 +317,15 @@ __global__ void __launch_bounds__(kTrunkThreads) trunk_layer_kernel(const Twin<T
 #pragma unroll
     for (int h = 0; h < NA; ++h)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[((wave * NA + h) * 4 + r) * 64 + lane] = acc[h][r];
+        for (int r = 0; r < 4; ++r) red[((wave * NA + h) * 4 + r) * kRedPitch + lane] = acc[h][r];
     __syncthreads();
-    float* tile = smem + kTrunkWaves * NA * 4 * 64;  // [16 rows][TLP]
+    float* tile = smem + kTrunkWaves * NA * 4 * kRedPitch;  // [16 rows][TLP]
     float* sstat = tile + 16 * TLP;                // [16 rows][B][2]
     for (int e = tid; e < NA * 256; e += kTrunkThreads) {
         const int h = e >> 8, r = (e >> 6) & 3, ln = e & 63;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < kTrunkWaves; ++w) v += red[((w * NA + h) * 4 + r) * 64 + ln];
+        for (int w = 0; w < kTrunkWaves; ++w) v += red[((w * NA + h) * 4 + r) * kRedPitch + ln];
         const int row = 4 * (ln >> 4) + r, col = (ln & 15) + 16 * h;
         tile[row * TLP + col] = v;
     }
@@ -529,9 +539,9 @@ __device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
     constexpr int DOFF = (KW == 3) ? 4 : 0;
-    constexpr int TLP = 16 * NA + 1;
     const int TP = T4 + DOFF, RS = trunk_rs(B, T4, KW);
     const int N = B * T4, K = d.Cin * KW;
+    const int TLP = N;                             // (tile rows N apart: thread el reads / writes word el -- no bank conflicts; the statistics are shuffles)
     const int glu = (d.mode == TRUNK_IN_GLU);
     const int rows = d.rows;                       // per branch
     const int rows_tot = glu ? 2 * rows : rows;    // MFMA rows in use (<= 16)
@@ -606,11 +616,11 @@ __device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4,
     }
     // ---- cross-wave K reduction: red[wave][h][reg][lane]
     float* red = epi;
-    float* tl = epi + kNetWaves * NA * 4 * 64;     // [16][TLP]
+    float* tl = epi + kNetWaves * NA * 4 * kRedPitch;     // [16][TLP]
 #pragma unroll
     for (int h = 0; h < NA; ++h)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[((wave * NA + h) * 4 + r) * 64 + lane] = acc[h][r];
+        for (int r = 0; r < 4; ++r) red[((wave * NA + h) * 4 + r) * kRedPitch + lane] = acc[h][r];
     __syncthreads();
     // one thread per MFMA output element (mrow, col) (two at more than 32 columns), a row's N columns in consecutive threads: sum of the
     // 8 waves' partials + bias
@@ -623,7 +633,7 @@ __device__ __forceinline__ void net_tile(const TrunkLayerDesc& d, int B, int T4,
             const int h = col >> 4, ln = ((mrow >> 2) << 4) + (col & 15), r = mrow & 3;
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < kNetWaves; ++w) v += red[((w * NA + h) * 4 + r) * 64 + ln];
+            for (int w = 0; w < kNetWaves; ++w) v += red[((w * NA + h) * 4 + r) * kRedPitch + ln];
             v += pe.bias[it];
             tl[mrow * TLP + col] = v;
             d.conv_out[(long long)row_cx(mrow) * N + col] = v;
@@ -979,14 +989,14 @@ __device__ __forceinline__ void bnet_tile(const TrunkBwdLayerDesc& d, int B, int
 #pragma unroll
     for (int h = 0; h < NA; ++h)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[((wave * NA + h) * 4 + r) * 64 + lane] = acc[h][r];
+        for (int r = 0; r < 4; ++r) red[((wave * NA + h) * 4 + r) * kRedPitch + lane] = acc[h][r];
     __syncthreads();
     if (tid < rows * N) {
         const int mrow = tid / N, col = tid - mrow * N;
         const int h = col >> 4, ln = ((mrow >> 2) << 4) + (col & 15), r = mrow & 3;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < kNetWaves; ++w) v += red[((w * NA + h) * 4 + r) * 64 + ln];
+        for (int w = 0; w < kNetWaves; ++w) v += red[((w * NA + h) * 4 + r) * kRedPitch + ln];
         if (d.flags & TBWD_ACCUMULATE) v += old;
         float* dst = d.out + (long long)(r0 + mrow) * N + col;
         if (wt) st_wt(dst, v); else *dst = v;
@@ -1002,7 +1012,7 @@ __global__ void __launch_bounds__(kNetThreads) trunk_bwd_net_kernel(const Twin<T
     float* Xs = smem;
     float* rsum = smem + a.x_floats;                       // [ceil(Cx / workgroups)][B][2]
     float* epi = rsum + 16 * 8 * 2 * 2;                    // (Cx <= 1024, 64 workgroups, B <= 8)
-    float* flag = epi + kNetWaves * NA * 4 * 64;
+    float* flag = epi + kNetWaves * NA * 4 * kRedPitch;
     const int tid = threadIdx.x;
     const int N = a.B * a.T4;
     for (int l = 0; l < a.nlayers; ++l) {
@@ -1167,7 +1177,7 @@ int mcvc_trunk_launch(const TrunkArgs& a, int ksplit, hipStream_t s)
 // widest staged input of the persistent forward: 512 channels, k = 3
 static long long net_fwd_lds_floats(int B, int T4) { return (long long)512 * trunk_rs(B, T4, 3) + 4 + trunk_epi_floats(trunk_na(B * T4)); }
 // ... of the persistent backward: 1024 channels (value | gate), k = 3, + the owners' row sums
-static long long net_bwd_lds_floats(int B, int T4) { return (long long)1024 * trunk_rs(B, T4, 3) + 4 + 16 * 8 * 2 * 2 + kNetWaves * trunk_na(B * T4) * 4 * 64 + 16; }
+static long long net_bwd_lds_floats(int B, int T4) { return (long long)1024 * trunk_rs(B, T4, 3) + 4 + 16 * 8 * 2 * 2 + kNetWaves * trunk_na(B * T4) * 4 * kRedPitch + 16; }
 
 // The persistent kernels' workgroups wait for each other inside the kernel: all kNetGrid of them (x 2 in a grouped launch) must be
 // resident at once, each on a compute unit of its own when its LDS exceeds half a CU's.  The caller states how many such passes it keeps in
@@ -1184,13 +1194,13 @@ static bool trunk_residency_ok() { const int cus = device_cus(); return cus <= 0
 bool mcvc_trunk_net_applies(int B, int T4)
 {
     if (B < 1 || B > 8 || T4 < 1 || T4 > 32 || B * T4 > 48) return false;          // (64 columns never fit the LDS beside 512 staged channels)
-    return trunk_residency_ok() && net_fwd_lds_floats(B, T4) * 4 <= 156 * 1024;
+    return trunk_residency_ok() && net_fwd_lds_floats(B, T4) * 4 <= 160 * 1024;
 }
 
 bool mcvc_trunk_bwd_net_applies(int B, int T4)
 {
     if (B < 1 || B > 8 || T4 < 4 || T4 > 32 || B * T4 > 32) return false;
-    return trunk_residency_ok() && net_bwd_lds_floats(B, T4) * 4 <= 156 * 1024;
+    return trunk_residency_ok() && net_bwd_lds_floats(B, T4) * 4 <= 160 * 1024;
 }
 
 // test hook (mcvc_debug_trunk_fault_inject): the next persistent launches lose one arrival, so that the give-up path can be exercised
@@ -1260,7 +1270,7 @@ int mcvc_trunk_bwd_net_launch(TrunkBwdNetArgs& a, hipStream_t s)
     a.x_floats = (int)((xmax + 3) & ~3LL);
     a.fault_inject = g_trunk_fault_inject;
     const bool wide = N > 16;
-    const size_t lds = ((size_t)a.x_floats + 16 * 8 * 2 * 2 + kNetWaves * (wide ? 2 : 1) * 4 * 64 + 16) * sizeof(float);
+    const size_t lds = ((size_t)a.x_floats + 16 * 8 * 2 * 2 + kNetWaves * (wide ? 2 : 1) * 4 * kRedPitch + 16) * sizeof(float);
     if (lds > 160 * 1024) return MCVC_ERR_INVALID;
     mcvc_launch(zero_words_kernel, dim3(1), dim3(64), 0, s, ZeroWordsKArgs{a.sync, MCVC_TRUNK_SYNC_WORDS - 1});
     TraceScope ts(K_TRUNK, s, flops, bytes);

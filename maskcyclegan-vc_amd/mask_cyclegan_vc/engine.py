@@ -210,6 +210,9 @@ class TrainEngine:
         mf = os.environ.get("MCVC_MERGED_FWD")
         self.merged = (self.reducer.world > 1) if mf is None else (mf != "0")
         self.early_ident = os.environ.get("MCVC_EARLY_IDENT", "0") != "0"
+        # Experiment (r4): the identity sample rides in the translation FORWARD pass (cheap) but its BACKWARD runs as its own one-sample
+        # window on lane 2, beside the cycle backward, into the second gradient buffer; the last pass of the chain is then one sample.
+        self.split_ident_bwd = os.environ.get("MCVC_SPLIT_IDENT_BWD", "0") != "0"
         self.bwd_no_join = os.environ.get("MCVC_BWD_NO_JOIN", "1") != "0"
         self.trunk_fallback = False            # a persistent trunk launch faulted in this process: per-layer launches from then on (check_faults)
         self._pending_D = None                  # (input set, discriminator lr) of the iteration whose discriminator phase is still to run
@@ -788,10 +791,17 @@ class TrainEngine:
             self._twin(lambda: self._G_bwd(B2A, None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B, 0, aux_lane=0, no_join=nj),
                        lambda: self._G_bwd(A2B, None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, 1, aux_lane=0, no_join=nj))
 
+        split_ib = bool(ident_second) and not ident and not ident_dead and self.split_ident_bwd
+
         def bwd_final(ln):      # the last pass over each generator; its gradient ranges become final one after the other (milestone events)
-            nb = B if (ident or ident_dead) else B2
-            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], nb, fs[0], ms_on, aux_lane=0, ms_of=A2B),
-                       lambda: self._G_bwd(B2A, self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], nb, fs[1], ms_on, aux_lane=0, ms_of=A2B))
+            nb = B if (ident or ident_dead or split_ib) else B2
+            snb = B2 if split_ib else None          # (split: the translation sample = the first half of the two-sample stash)
+            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], nb, fs[0], ms_on, aux_lane=0, ms_of=A2B, stash_nb=snb),
+                       lambda: self._G_bwd(B2A, self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], nb, fs[1], ms_on, aux_lane=0, ms_of=A2B, stash_nb=snb))
+
+        def ident_bwd_win(ln):  # the identity sample = the window [B, 2B) of the same stash; weight gradients inline, second gradient buffer
+            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B[B:], g_identity_B, None, 0, self.g_stash2[0], B, 2, aux_lane=1, second=True, stash_nb=B2, stash_b0=B),
+                       lambda: self._G_bwd(B2A, self.mask_B2A[B:], g_identity_A, None, 0, self.g_stash2[1], B, 3, aux_lane=1, second=True, stash_nb=B2, stash_b0=B))
 
         def queue_reduce(ln):
             # data parallel: range k of BOTH generators is final at milestone k of the grouped pass; same collective order on every rank
@@ -838,7 +848,7 @@ class TrainEngine:
         def post():
             self._g_fwd_packed = bool(fuse_update)
             self._combine(0, self._comb_g)
-        P.update(update_range=update_range, pre=pre, fwd2=fwd2, ident_chain=ident_chain, ident_fwd=ident_fwd, ident_bwd=ident_bwd, cycle=cycle, adv1=adv1, adv2=adv2, bwd_cycle=bwd_cycle, bwd_final=bwd_final,
+        P.update(split_ib=split_ib, ident_bwd_win=ident_bwd_win, update_range=update_range, pre=pre, fwd2=fwd2, ident_chain=ident_chain, ident_fwd=ident_fwd, ident_bwd=ident_bwd, cycle=cycle, adv1=adv1, adv2=adv2, bwd_cycle=bwd_cycle, bwd_final=bwd_final,
                  queue_reduce=queue_reduce, update=update, post=post, ident=ident, ov=ov)
         return P
 
@@ -1002,19 +1012,22 @@ class TrainEngine:
         available one ``step()`` later (``losses(lagged=True)``); ``flush()`` / ``losses()`` complete a pending phase."""
         cur = self.static_in
         prev, d_lr = self._pending_D if self._pending_D is not None else (None, None)
-        second = self.reducer.world == 1 and self.grouped_ident          # (data parallel: one gradient buffer is exchanged)
+        second = self.reducer.world == 1 and (self.grouped_ident or self.split_ident_bwd)          # (data parallel: one gradient buffer is exchanged)
         ranged = self.ranged_update and self.reducer.world == 1
         g = self._g_parts(cur, True, own_d_update=prev is None, ident_second=second, zeroing_update=True, ranged=ranged)
         ident, ov = g["ident"], g["ov"]
+        split_ib = g["split_ib"]
         tail = [(2, g["ident_chain"], (), "i")] if (ident and second) else []
         # (the chain's backward reads the generators' backward-only weight copies, which lane 3 refreshes first: "rf")
         head = [(2, g["ident_fwd"], (), None), (2, g["ident_bwd"], ("rf",) if self._pending_D is not None else (), "i")] if (ident and not second) else []
-        upd_waits = ("i",) if (ident and second) else ()
+        upd_waits = ("i",) if ((ident and second) or split_ib) else ()
         bwd_waits = ("d1", "i") if (ident and not second) else ("d1",)
+        # (split: the identity sample's backward starts with the cycle backward -- behind both adversarial pairs -- on lane 2)
+        ib = [(2, g["ident_bwd_win"], ("a2",), "i")] if split_ib else []
         if prev is None:                       # first iteration (or the first after a flush): there is no discriminator phase to run beside it
             g["pre"](zero_grads=True)
             tasks = [(0, g["fwd2"], (), "g")] + head + [
-                (0, g["cycle"], (), None), (2, g["adv1"], ("g",), "d1")] + tail + [(0, g["adv2"], (), None),
+                (0, g["cycle"], (), None), (2, g["adv1"], ("g",), "d1")] + tail + [(0, g["adv2"], (), "a2")] + ib + [
                 (0, g["bwd_cycle"], bwd_waits, None), (0, g["bwd_final"], (), "f")]
             tasks += ([(3, g["queue_reduce"], (), None)] if ov else []) + [(0, g["update"], upd_waits, None)]
             self._run_tasks(tasks)
@@ -1071,7 +1084,8 @@ class TrainEngine:
             (1, d_update(("discriminator_A2", "discriminator_B2")), (), "dupd2"),
             (adv1_lane, g["adv1"], ("g", "dupd1"), "d1"),
         ] + tail + [
-            (0, g["adv2"], ("dupd2",), None),
+            (0, g["adv2"], ("dupd2",), "a2"),
+        ] + ([(2, g["ident_bwd_win"], ("a2", "rf"), "i")] if split_ib else []) + [
             (0, g["bwd_cycle"], bwd_waits + ("rf",), None),
             (0, g["bwd_final"], (), "f"),
         ] + ([(3, g["queue_reduce"], (), None)] if ov else [])
