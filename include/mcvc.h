@@ -266,7 +266,8 @@ int mcvc_conv2d_wgrad(const float* x, const float* dy, float* dw, float* slabs, 
  *      parameters (ACCUMULATED: pass zeros).  `packed` = mcvc_layer_pack of the parameters (every weight set the planner may read);
  *      `scratch` >= mcvc_layer_scratch_floats.  `scheme`: 0 the planner's choice at this shape, 1 Winograd with 2x2 output tiles, 2 Winograd
  *      with 4x4 output tiles (sample / tile thresholds lifted; image sides must be multiples of 4 -- 8 for the stride-2 layers),
- *      3 no Winograd (staged GEMM where it applies, else direct), 4 direct kernels only.  w0 / w1 = the OIHW tensors themselves (the
+ *      3 no Winograd (staged GEMM where it applies, else direct), 4 direct kernels only, 5 implicit GEMM (forward / dgrad of the 3x3
+ *      stride-2 layers: the kernels the discriminator passes run, sgemm.h; the dense operand is converted to their layout first).  w0 / w1 = the OIHW tensors themselves (the
  *      staged-GEMM data gradient multiplies them in place).  pixel_shuffle: the forward store of the up-sampling layers (model.py:232).   */
 long long mcvc_layer_packed_floats(int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w);
 long long mcvc_layer_scratch_floats(int N, int H, int W, int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w);

@@ -2623,6 +2623,10 @@ static Needs layer_needs(const ConvSpec& c, int N, int H, int W, int scheme)
                View{nullptr, (long long)c.Cin * H * W, (long long)H * W, W}, (long long)N * c.Cin * H * W, 0, 1, &ns);
     conv_wgrad(ex, c, nullptr, N, H, W, CView{nullptr, (long long)c.Cin * H * W, (long long)H * W, W},
                CView{nullptr, (long long)c.cout_tot * OH * OW, (long long)OH * OW, OW});
+    if (igemm_applies(c, H, W)) {
+        conv_fwd_igemm(ex, c, nullptr, N, H, W, nullptr, View{nullptr, (long long)c.cout_tot * OH * OW, (long long)OH * OW, OW}, (long long)N * c.cout_tot * OH * OW, 1, &ns);
+        conv_dgrad_igemm(ex, c, nullptr, N, H, W, nullptr, View{nullptr, (long long)c.Cin * H * W, (long long)H * W, W}, (long long)N * c.Cin * H * W, 0, 1, &ns);
+    }
     return Needs{(ex.slab_need + 3) & ~3LL, (ex.wslab_need + 3) & ~3LL, (ex.sg_need + 3) & ~3LL, (ex.sgw_need + 3) & ~3LL};
 }
 struct SchemeGuard {            // scheme 3: no Winograd; 4: neither Winograd nor staged GEMM (thread-local planner switches)
@@ -2683,9 +2687,23 @@ int mcvc_layer_forward(const float* x, const float* packed, const float* w0, con
                        int N, int H, int W, int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w, int scheme,
                        int pixel_shuffle, void* stream)
 {
-    if (!x || !packed || !y || !scratch || scheme < 0 || scheme > 4 || branches < 1 || branches > 2 || (stride != 1 && stride != 2)) return MCVC_ERR_INVALID;
+    if (!x || !packed || !y || !scratch || scheme < 0 || scheme > 5 || branches < 1 || branches > 2 || (stride != 1 && stride != 2)) return MCVC_ERR_INVALID;
     const LayerCtx l = layer_ctx(Cin, Cout, branches, KH, KW, stride, pad_h, pad_w);
     if ((scheme == 1 || scheme == 2) && !(l.c.wino || l.c.wino3)) return MCVC_ERR_INVALID;       // no Winograd form of this layer shape
+    if (scheme == 5) {          // implicit GEMM (sgemm.h): the dense input is converted to the phase-split padded layout the networks' producers write
+        if (!igemm_applies(l.c, H, W) || pixel_shuffle) return MCVC_ERR_INVALID;
+        int err5 = 0;
+        Exec ex5 = layer_exec(l.c, N, H, W, 0, scratch, scratch_floats, stream, &err5);
+        if (err5) return err5;
+        if ((long long)N * mcvc_xs_floats(Cin, H, W) > ex5.wino_cap) return MCVC_ERR_WORKSPACE;
+        ex5.fail(mcvc_xs_from_dense_launch(x, ex5.wv, N, Cin, H, W, ex5.s));
+        const int OH5 = H / 2, OW5 = W / 2;
+        const long long yt = (long long)N * l.c.cout_tot * OH5 * OW5;
+        int ns5 = 1;
+        conv_fwd_igemm(ex5, l.c, packed, N, H, W, ex5.wv, View{y, (long long)l.c.cout_tot * OH5 * OW5, (long long)OH5 * OW5, OW5}, yt, 1, &ns5);
+        if (ns5 > 1) act_fwd(ex5, y, yt, ns5, nullptr, 1, 1, (int)yt, ACT_NONE);
+        return ex5.err;
+    }
     SchemeGuard sg(scheme);
     int err = 0;
     Exec ex = layer_exec(l.c, N, H, W, scheme, scratch, scratch_floats, stream, &err);
@@ -2704,8 +2722,22 @@ int mcvc_layer_forward(const float* x, const float* packed, const float* w0, con
 int mcvc_layer_dgrad(const float* dy, const float* packed, const float* w0, const float* w1, float* dx, float* scratch, long long scratch_floats,
                      int N, int H, int W, int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w, int scheme, void* stream)
 {
-    if (!dy || !packed || !dx || !scratch || scheme < 0 || scheme > 4 || branches < 1 || branches > 2 || (stride != 1 && stride != 2)) return MCVC_ERR_INVALID;
+    if (!dy || !packed || !dx || !scratch || scheme < 0 || scheme > 5 || branches < 1 || branches > 2 || (stride != 1 && stride != 2)) return MCVC_ERR_INVALID;
     const LayerCtx l = layer_ctx(Cin, Cout, branches, KH, KW, stride, pad_h, pad_w);
+    if (scheme == 5) {          // implicit GEMM: the four parity classes scattered straight into dx; the dense dY is padded first (the networks' norm_bwd writes it padded)
+        if (!igemm_applies(l.c, H, W)) return MCVC_ERR_INVALID;
+        int err5 = 0;
+        Exec ex5 = layer_exec(l.c, N, H, W, 0, scratch, scratch_floats, stream, &err5);
+        if (err5) return err5;
+        const int OH5 = H / 2, OW5 = W / 2;
+        if ((long long)N * l.c.cout_tot * mcvc_dyp_plane(OH5, OW5) > ex5.wino_cap) return MCVC_ERR_WORKSPACE;
+        ex5.fail(mcvc_dyp_from_dense_launch(dy, ex5.wm, N, l.c.cout_tot, OH5, OW5, ex5.s));
+        const long long dxt = (long long)N * Cin * H * W;
+        int ns5 = 1;
+        conv_dgrad_igemm(ex5, l.c, packed, N, H, W, ex5.wm, View{dx, (long long)Cin * H * W, (long long)H * W, W}, dxt, 0, 1, &ns5);
+        if (ns5 > 1) act_fwd(ex5, dx, dxt, ns5, nullptr, 1, 1, (int)dxt, ACT_NONE);
+        return ex5.err;
+    }
     SchemeGuard sg(scheme);
     int err = 0;
     Exec ex = layer_exec(l.c, N, H, W, scheme, scratch, scratch_floats, stream, &err);

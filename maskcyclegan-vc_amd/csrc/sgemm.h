@@ -65,6 +65,12 @@ static inline long long mcvc_xs_floats(int C, int H, int W) { return 4LL * C * m
 static inline int mcvc_dyp_pitch(int OW) { return OW + 4; }
 static inline long long mcvc_dyp_plane(int OH, int OW) { return (long long)(OH + 1) * (OW + 4); }
 
+// dense [NB][C][H][W] -> the phase-split padded layout (zero borders included) / dense dY [NB][C][OH][OW] -> the padded dY layout: the
+// networks' producers write these layouts themselves; these two kernels serve the op-level entries (mcvc_layer_*, scheme 5), whose
+// operands arrive dense
+int mcvc_xs_from_dense_launch(const float* x, float* xs, int NB, int C, int H, int W, hipStream_t s);
+int mcvc_dyp_from_dense_launch(const float* dy, float* dyp, int NB, int C, int OH, int OW, hipStream_t s);
+
 struct StageArgs {
     const float* x; long long x_sb, x_sc; int x_sh;      // image view [NB][C][H][W] (W contiguous)
     int NB, C, H, W, OH, OW;                               // 3x3, stride 2, padding 1: OH = (H + 1) / 2 ...

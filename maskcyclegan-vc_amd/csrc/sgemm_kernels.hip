@@ -476,7 +476,52 @@ __global__ void __launch_bounds__(256) dw_accum_kernel(const Twin<DwAccumKArgs> 
     *d = o;
 }
 
+
+// ---- layout converters for the op-level entries (the networks' producers write these layouts directly) -------------------------------------
+struct XsConvKArgs { const float* src; float* dst; int C, H, W, pw; long long plane; int mode; };       // mode 0: xs, 1: padded dY
+__global__ void __launch_bounds__(256) layout_conv_kernel(const Twin<XsConvKArgs> tw)
+{
+    const XsConvKArgs a = tw.v[blockIdx.z];
+    const long long nc = blockIdx.y;                                   // (sample, channel)
+    if (a.mode == 0) {
+        const long long tot = 4 * a.plane;
+        float* d = a.dst + nc * tot;
+        const float* sp = a.src + nc * a.H * a.W;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long long)gridDim.x * 256) {
+            const int pq = (int)(i / a.plane); const int rem = (int)(i - (long long)pq * a.plane);
+            const int r = rem / a.pw, c = rem - r * a.pw;
+            float v = 0.f;
+            if (r >= 1 && c >= 4) { const int h = 2 * (r - 1) + (pq >> 1), w = 2 * (c - 4) + (pq & 1); if (h < a.H && w < a.W) v = sp[(long long)h * a.W + w]; }
+            d[i] = v;
+        }
+    } else {
+        float* d = a.dst + nc * a.plane;
+        const float* sp = a.src + nc * a.H * a.W;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.plane; i += (long long)gridDim.x * 256) {
+            const int r = (int)(i / a.pw), c = (int)(i - (long long)r * a.pw);
+            d[i] = (r < a.H && c < a.W) ? sp[(long long)r * a.W + c] : 0.f;
+        }
+    }
+}
+
 }  // namespace
+
+int mcvc_xs_from_dense_launch(const float* x, float* xs, int NB, int C, int H, int W, hipStream_t s)
+{
+    if ((H & 1) || (W & 1)) return MCVC_ERR_INVALID;
+    const long long plane = mcvc_xs_plane(H, W);
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * NB * C * ((double)H * W + 4.0 * plane));
+    mcvc_launch(layout_conv_kernel, dim3((unsigned)((4 * plane + 255) / 256), (unsigned)(NB * C)), dim3(256), 0, s, XsConvKArgs{x, xs, C, H, W, mcvc_xs_pw(W), plane, 0});
+    return (int)hipGetLastError();
+}
+
+int mcvc_dyp_from_dense_launch(const float* dy, float* dyp, int NB, int C, int OH, int OW, hipStream_t s)
+{
+    const long long plane = mcvc_dyp_plane(OH, OW);
+    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * NB * C * ((double)OH * OW + plane));
+    mcvc_launch(layout_conv_kernel, dim3((unsigned)((plane + 255) / 256), (unsigned)(NB * C)), dim3(256), 0, s, XsConvKArgs{dy, dyp, C, OH, OW, mcvc_dyp_pitch(OW), plane, 1});
+    return (int)hipGetLastError();
+}
 
 int mcvc_sgemm_launch(const SGemmArgs& a0, hipStream_t s)
 {

@@ -379,25 +379,34 @@ class TrainEngine:
         self.B = B
         for k, v in ws.items():
             setattr(self, k, v)
-        # persistent trunk passes this engine keeps in flight at once (the kernels need all their workgroups resident: csrc/trunk.h).  Merged
-        # schedule: one grouped forward (or backward) pass at a time = 2; the earlier pipelined schedule ran the D-phase's generator
-        # forwards beside the G-phase's = 4.  A data-parallel rank leaves room for RCCL's own kernels (one more pass's worth of CUs).
+        self._resid = None
+        self._set_residency()
+        self._cur_set = 0
+        self.static_in = self.static_sets[0]
+
+    def _set_residency(self):
+        """Tell the library how many persistent trunk passes this engine keeps in flight (the kernels need all their workgroups resident:
+        csrc/trunk.h) -- per schedule: merged forwards = one grouped pass at a time = 2; the separate-pass pipelined schedule runs the
+        D-phase's generator forwards beside the G-phase's = 4; a data-parallel rank leaves one pass's worth of compute units to RCCL's kernels.
+        Re-evaluated whenever the schedule changes (the identity cut-off ends the merged schedule)."""
         if self._use_grouped():
             inflight = 4 if (not self._use_merged() or (self.early_ident and self.reducer.world == 1)) else 2
         else:
             inflight = 2
-        self.L.mcvc_set_trunk_passes_in_flight(inflight + (1 if self.reducer.world > 1 else 0))
+        inflight += 1 if self.reducer.world > 1 else 0
+        self.L.mcvc_set_trunk_passes_in_flight(inflight)          # (process-wide in the library: re-stated every step, another engine may have changed it)
+        if self._resid == (inflight, self.B):
+            return
+        self._resid = (inflight, self.B)
         if self._use_grouped() and not self.trunk_fallback:
-            want = self.L.mcvc_gen_trunk_persistent(B, self.T)
+            want = self.L.mcvc_gen_trunk_persistent(self.B, self.T)
             self.L.mcvc_set_trunk_passes_in_flight(1)
-            could = self.L.mcvc_gen_trunk_persistent(B, self.T)
-            self.L.mcvc_set_trunk_passes_in_flight(inflight + (1 if self.reducer.world > 1 else 0))
+            could = self.L.mcvc_gen_trunk_persistent(self.B, self.T)
+            self.L.mcvc_set_trunk_passes_in_flight(inflight)
             if could and not want:
                 import sys
-                print("[mcvc] %d persistent trunk passes in flight do not fit this device's compute units: per-layer trunk launches"
-                      % (inflight + (1 if self.reducer.world > 1 else 0)), file=sys.stderr, flush=True)
-        self._cur_set = 0
-        self.static_in = self.static_sets[0]
+                print("[mcvc] %d persistent trunk passes in flight do not fit this device's compute units: per-layer trunk launches" % inflight,
+                      file=sys.stderr, flush=True)
 
     # ---- thin call helpers ------------------------------------------------------------------------
     def _repack1(self, n, sets=3, ranges=7):
@@ -1482,6 +1491,7 @@ class TrainEngine:
         return self._step_static()
 
     def _step_static(self):
+        self._set_residency()
         if self._use_pipeline():
             d_lr = self.sched.d_opt_lr           # what torch.optim would use for THIS iteration's discriminator step
             if self._use_merged():

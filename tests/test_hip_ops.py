@@ -279,11 +279,13 @@ LAYER_CASES = [
     ("ds2.T64", 256, 256, 2, 5, 5, 2, 2, 2, 2, 40, 32, False, (1, 2)),
     ("ds2.B1", 256, 256, 2, 5, 5, 2, 2, 2, 1, 40, 32, False, (1,)),                 # 80 tiles
     ("ds1.ragged", 128, 256, 2, 5, 5, 2, 2, 2, 2, 24, 20, False, (1,)),             # 12 x 10 outputs: 30 tiles per sample
-    ("d.ds1", 128, 256, 1, 3, 3, 2, 1, 1, 1, 80, 64, False, (3,)),
-    ("d.ds2", 256, 512, 1, 3, 3, 2, 1, 1, 2, 40, 32, False, (3,)),
-    ("d.ds3", 512, 1024, 1, 3, 3, 2, 1, 1, 3, 20, 16, False, (3,)),
-    ("d.ds1.T72", 128, 256, 1, 3, 3, 2, 1, 1, 2, 80, 72, False, (3,)),
-    ("d.ds2.B9", 256, 512, 1, 3, 3, 2, 1, 1, 9, 40, 32, False, (3,)),
+    ("d.ds1", 128, 256, 1, 3, 3, 2, 1, 1, 1, 80, 64, False, (3, 5)),               # 5 = implicit GEMM (forward, data gradient)
+    ("d.ds2", 256, 512, 1, 3, 3, 2, 1, 1, 2, 40, 32, False, (3, 5)),
+    ("d.ds3", 512, 1024, 1, 3, 3, 2, 1, 1, 3, 20, 16, False, (3, 5)),
+    ("d.ds1.T72", 128, 256, 1, 3, 3, 2, 1, 1, 2, 80, 72, False, (3, 5)),
+    ("d.ds2.B9", 256, 512, 1, 3, 3, 2, 1, 1, 9, 40, 32, False, (3, 5)),
+    ("d.ds3.T128", 512, 1024, 1, 3, 3, 2, 1, 1, 1, 20, 32, False, (5,)),
+    ("d.ds1.small", 128, 256, 1, 3, 3, 2, 1, 1, 1, 12, 16, False, (5,)),
 ]
 _LAYER_IDS = ["%s-s%d" % (c[0], s) for c in LAYER_CASES for s in c[-1]]
 _LAYER_PARAMS = [(c, s) for c in LAYER_CASES for s in c[-1]]
@@ -327,7 +329,7 @@ def test_layer_ops_match_torch(c, scheme):
     # weight gradients (accumulated into zeros; value | gate rows to their own tensors)
     dws = [torch.zeros_like(w) for w in wd]
     check(L.mcvc_layer_wgrad(ptr(xd), ptr(dyd), ptr(dws[0]), ptr(dws[1]) if nbr == 2 else None, ptr(scratch), scratch.numel(), N, H, W, *spec,
-                             scheme, stream()), "layer_wgrad")
+                             3 if scheme == 5 else scheme, stream()), "layer_wgrad")          # (the weight gradient of these layers is a staged GEMM)
     dw_ref = torch.nn.grad.conv2d_weight(x, wcat.shape, dy, stride=s, padding=(ph, pw))
     for br in range(nbr):
         e = rel_l2(dws[br], dw_ref[br * Cout:(br + 1) * Cout])
