@@ -471,14 +471,33 @@ static SgKind sgemm_kind(const ConvSpec& c, int NB, int H, int W)
 }
 static void sgemm_want(Exec& ex, long long floats) { if (floats > ex.sg_need) ex.sg_need = floats; }
 // K-split of a product with M x N outputs: enough 64 x 64 tiles x splits to occupy the chip, at least two 32-deep stages per split
-static int sgemm_split(int M, long long N, int K)
+// K split of a product of `tiles` 64 x 64 output tiles whose shortest K range is Kmin: with fewer tiles than the chip has workgroup slots,
+// split until it is occupied (r2).  Experiment (r4, MCVC_SGEMM_WAVES=1, OFF): also split a tile count that is a small non-integer multiple of
+// the 512 slots (640 tiles = 1.25 rounds cost 2 rounds alone on the chip; split s makes the rounds 1/s as long:
+// cost(s) = ceil(tiles * s / slots) * (1 / s + c) + p * (s - 1)).  Measured SLOWER: bs=8 22.2-22.6 -> 23.0-23.2 ms, bs=32 76.0 -> 77.3 -- the
+// other lanes' kernels already fill a product's last round, and the extra slabs are traffic the lanes compete for.
+static int split_by_cost(long long tiles, int Kmin)
 {
-    const long long tiles = (long long)(M / 64) * ((N + 63) / 64);
     static const int wgs = [] { const char* e = getenv("MCVC_SGEMM_WGS"); return e ? atoi(e) : 256; }();
     static const int maxsp = [] { const char* e = getenv("MCVC_SGEMM_MAXSPLIT"); return e ? atoi(e) : 8; }();
+    static const int waves = [] { const char* e = getenv("MCVC_SGEMM_WAVES"); return e ? atoi(e) : 0; }();
     int sp = 1;
-    while (sp < maxsp && tiles * sp < wgs && (K % (64 * sp)) == 0 && K / (2 * sp) >= 64) sp *= 2;
-    return sp;
+    while (sp < maxsp && tiles * sp < wgs && (Kmin % (64 * sp)) == 0 && Kmin / (2 * sp) >= 64) sp *= 2;
+    if (!waves || tiles > 4096) return sp;
+    const double slots = 512.0, c = 0.06, p = 0.04;
+    double best = 1e30; int best_sp = sp;
+    for (int s = sp; s <= maxsp; s *= 2) {
+        if ((Kmin % (64 * s)) != 0 || Kmin / (2 * s) < 64) break;
+        const double rounds = (double)((tiles * s + 511) / 512);
+        (void)slots;
+        const double cost = rounds * (1.0 / s + c) + p * (s - 1);
+        if (cost < best - 1e-9) { best = cost; best_sp = s; }
+    }
+    return best_sp;
+}
+static int sgemm_split(int M, long long N, int K)
+{
+    return split_by_cost((long long)(M / 64) * ((N + 63) / 64), K);
 }
 
 // ---- implicit GEMM for the 3x3 stride-2 padding-1 layers (sgemm.h): no tap planes, no gather kernel -------------------------------------
@@ -492,14 +511,7 @@ static bool igemm_applies(const ConvSpec& c, int H, int W)
     return igemm_enabled() && c.igemm && (H & 1) == 0 && (W & 1) == 0 && ((W / 2) & 3) == 0 && H >= 2 && W >= 8;
 }
 // K split: enough 64 x 64 tiles x classes x splits to occupy the chip, at least two 32-deep stages per split of the shortest class
-static int igemm_split(long long tiles, int Kmin)
-{
-    static const int wgs = [] { const char* e = getenv("MCVC_SGEMM_WGS"); return e ? atoi(e) : 256; }();
-    static const int maxsp = [] { const char* e = getenv("MCVC_SGEMM_MAXSPLIT"); return e ? atoi(e) : 8; }();
-    int sp = 1;
-    while (sp < maxsp && tiles * sp < wgs && (Kmin % (64 * sp)) == 0 && Kmin / (2 * sp) >= 64) sp *= 2;
-    return sp;
-}
+static int igemm_split(long long tiles, int Kmin) { return split_by_cost(tiles, Kmin); }
 // forward: xs = the input in the phase-split padded layout, y = the conv output (dense planes); K-split slabs 1.. are summed by the consumer
 static void conv_fwd_igemm(Exec& ex, const ConvSpec& c, const float* packed, int NB, int H, int W, const float* xs, View y, long long y_total,
                            int allow_split, int* nsplit)
