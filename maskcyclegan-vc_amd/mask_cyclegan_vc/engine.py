@@ -49,6 +49,8 @@ def _align4(n):
     return (n + 3) & ~3
 
 
+_LANES = {}      # (device, caller stream, probe switches) -> (legacy sides, aux streams, probed sides, probe report)
+
 class _FlatGroup:
     """Parameters of several modules re-homed into one flat buffer (+ gradient and Adam buffers)."""
 
@@ -143,16 +145,25 @@ class TrainEngine:
         # two sets of side lanes: the four-lane schedule keeps the streams (and the auxiliary streams created right behind them) it was
         # tuned on -- with probed lanes its auxiliary streams land on the lanes' queues: bs=8 30.5 -> 32.3 ms, bs=32 116.5 -> 118.0 -- the
         # grouped / pipelined schedule uses lanes probed onto distinct hardware queues (_pick_side_streams)
-        self._sides_legacy = [torch.cuda.Stream(device=dev) for _ in range(3)]
-        # inside a backward pass the weight-gradient kernels are off the critical path: one auxiliary stream per lane
-        self._aux = [torch.cuda.Stream(device=dev) for _ in range(4)]
-        # (a stream gets its hardware queue at first USE: touch these in creation order before the probe puts work on its candidates)
-        _t = torch.zeros(64, device=dev)
-        for st in self._sides_legacy + self._aux:
-            with torch.cuda.stream(st):
-                _t.add_(1.0)
-        torch.cuda.synchronize(dev)
-        self._sides_probed = self._pick_side_streams(dev)
+        # One set of lanes per (device, caller stream) and process: a second engine in the same process (bench.py's extra batch sizes, an
+        # evaluation engine beside the training one) reuses them -- every new HIP stream lands on one of the 4 hardware queues in pool
+        # order, and a later engine's fresh streams landed on worse combinations (nested bs=8 24.1 ms against 22.6 in a process of its own)
+        key = (torch.device(dev).index or 0, torch.cuda.current_stream(dev).cuda_stream, os.environ.get("MCVC_STREAM_PROBE", "1"),
+               os.environ.get("MCVC_LANE_PRIO"))
+        lanes = _LANES.get(key)
+        if lanes is None:
+            legacy = [torch.cuda.Stream(device=dev) for _ in range(3)]
+            # inside a backward pass the weight-gradient kernels are off the critical path: one auxiliary stream per lane
+            aux = [torch.cuda.Stream(device=dev) for _ in range(4)]
+            # (a stream gets its hardware queue at first USE: touch these in creation order before the probe puts work on its candidates)
+            _t = torch.zeros(64, device=dev)
+            for st in legacy + aux:
+                with torch.cuda.stream(st):
+                    _t.add_(1.0)
+            torch.cuda.synchronize(dev)
+            probed = self._pick_side_streams(dev)
+            lanes = _LANES[key] = (legacy, aux, probed, self.queue_probe)
+        self._sides_legacy, self._aux, self._sides_probed, self.queue_probe = lanes
         self.aux_wgrad = os.environ.get("MCVC_AUX_WGRAD", "1") != "0"
         # ... for the generators only: the four discriminator lanes already occupy the four hardware queues, and giving each a
         # second stream for its weight gradients measured 1.2 % slower (101.5 vs 102.8 it/s)
@@ -274,6 +285,7 @@ class TrainEngine:
         the tiny kernel finishing only with the spin = same queue) and kept when independent.  MCVC_STREAM_PROBE=0: take the first
         three pool streams as before."""
         cands = [torch.cuda.Stream(device=dev) for _ in range(16)]
+        self.queue_probe = None
         if os.environ.get("MCVC_STREAM_PROBE", "1") == "0":
             return cands[:want]
         main = torch.cuda.current_stream(dev)
