@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define MCVC_ABI_VERSION 2          /* r4: + mcvc_gen_backward_prefix, mcvc_set_trunk_passes_in_flight, op-level Winograd / staged-GEMM / trunk entries */
+#define MCVC_ABI_VERSION 3          /* r4: + mcvc_gen_backward_prefix, mcvc_set_trunk_passes_in_flight, op-level Winograd / staged-GEMM / trunk entries;
+                                       3: + mcvc_gen_update_ranges / mcvc_disc_update_batch (optimizer step fused with the re-pack) */
 #define MCVC_GEN_NPARAMS 110
 #define MCVC_DISC_NPARAMS 20
 #define MCVC_N_MEL 80
@@ -227,6 +228,20 @@ int mcvc_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, 
  *      reset_grad / zero_grad, train.py:157-161, does before the next accumulation -- here without a separate pass over the buffers).   */
 int mcvc_adam_step2(float* p, float* g, float* g2, int zero_grads, float* exp_avg, float* exp_avg_sq, long long n, float lr,
                     float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/*      optimizer.step() fused with the weight re-pack (reference train.py:242 / :299 are just `optimizer.step()`: the packed copies are this
+ *      library's own, so their refresh belongs to the step): ONE launch in which a workgroup owns a tile of filters of one parameter tensor --
+ *      it applies the Adam update above to the tile (bit-identical to mcvc_adam_step2), keeps the new weights in LDS and writes every packed
+ *      copy derived from them (K-major / tap-major / per-class data-gradient / transposed trunk / Winograd U sets) from there.  No second
+ *      pass over the OIHW tensors: the per-step `pack` kernel family is gone (it remains for load_state_dict: mcvc_*_pack*).
+ *      numel[i]: elements of parameter tensor i (0: a parameter that is neither updated nor packed -- the unused downSample4 block);
+ *      flat / grad / grad2 (nullable) / exp_avg / exp_avg_sq: flat buffers in which params[i], its gradient(s) and moments sit at EQUAL
+ *      offsets (gradient of params[i] = grad + (params[i] - flat)); range_mask / max_batch / T as mcvc_gen_pack_ranges / mcvc_disc_pack_batch. */
+int mcvc_gen_update_ranges(const float* const* params, const long long* numel, float* packed, int max_batch, int T, int range_mask,
+                           const float* flat, float* grad, float* grad2, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                           float beta2, float eps, int step, float grad_scale, int zero_grads, void* stream);
+int mcvc_disc_update_batch(const float* const* params, const long long* numel, float* packed, int max_batch, int T,
+                           const float* flat, float* grad, float* grad2, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                           float beta2, float eps, int step, float grad_scale, int zero_grads, void* stream);
 int mcvc_axpy(float* y, const float* x, float alpha, long long n, void* stream);
 
 /* ---- on-device input pipeline: replaces VCDataset.__getitem__ + DataLoader collate + 4 H2D copies per iteration

@@ -192,7 +192,7 @@ __global__ void loss_combine_kernel(const Twin<LossCombineKArgs> tw)
 
 // torch.optim.Adam single-tensor math on a flat buffer (weight_decay 0, amsgrad off):
 //   m = lerp(m, g, 1-b1); v = b2*v + (1-b2) g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
-struct AdamKArgs { float* p; float* g; float* m; float* v; long long n; float lr; float b1; float b2; float eps; float bc1; float sqrt_bc2; float grad_scale;
+struct AdamKArgs { float* p; float* g; float* m; float* v; long long n; AdamCoef c;
                    float* g2; int zero; };      // g2 (nullable): a second gradient buffer, added to g; zero: clear the gradient buffer(s) behind the read
 __global__ void __launch_bounds__(256) adam_kernel(const Twin<AdamKArgs> tw)
 {
@@ -204,14 +204,7 @@ __global__ void __launch_bounds__(256) adam_kernel(const Twin<AdamKArgs> tw)
     float* __restrict__ m = ka_.m;
     float* __restrict__ v = ka_.v;
     long long n = ka_.n;
-    float lr = ka_.lr;
-    float b1 = ka_.b1;
-    float b2 = ka_.b2;
-    float eps = ka_.eps;
-    float bc1 = ka_.bc1;
-    float sqrt_bc2 = ka_.sqrt_bc2;
-    float grad_scale = ka_.grad_scale;
-    const float step_size = lr / bc1;
+    const AdamCoef c = ka_.c;
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -228,13 +221,7 @@ __global__ void __launch_bounds__(256) adam_kernel(const Twin<AdamKArgs> tw)
         float* mf = reinterpret_cast<float*>(&mm);
         float* vf = reinterpret_cast<float*>(&vv);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float gr = gf[k] * grad_scale;
-            mf[k] = mf[k] + (gr - mf[k]) * (1.0f - b1);
-            vf[k] = vf[k] * b2 + (1.0f - b2) * gr * gr;
-            const float denom = sqrtf(vf[k]) / sqrt_bc2 + eps;
-            pf[k] = pf[k] - step_size * (mf[k] / denom);
-        }
+        for (int k = 0; k < 4; ++k) adam_elem(pf[k], gf[k], mf[k], vf[k], c);
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
         reinterpret_cast<float4*>(v)[i] = vv;
@@ -243,12 +230,11 @@ __global__ void __launch_bounds__(256) adam_kernel(const Twin<AdamKArgs> tw)
     const long long base = n4 << 2;
     const long long t = base + (long long)blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x == 0 && t < n) {
-        const float gr = (g[t] + (g2 ? g2[t] : 0.f)) * grad_scale;
+        const float gr = g[t] + (g2 ? g2[t] : 0.f);
         if (zero) { g[t] = 0.f; if (g2) g2[t] = 0.f; }
-        const float mn = m[t] + (gr - m[t]) * (1.0f - b1);
-        const float vn = v[t] * b2 + (1.0f - b2) * gr * gr;
-        m[t] = mn; v[t] = vn;
-        p[t] = p[t] - step_size * (mn / (sqrtf(vn) / sqrt_bc2 + eps));
+        float pn = p[t], mn = m[t], vn = v[t];
+        adam_elem(pn, gr, mn, vn, c);
+        m[t] = mn; v[t] = vn; p[t] = pn;
     }
 }
 
@@ -322,16 +308,21 @@ int mcvc_loss_combine_launch(const float* pairs, int n, const int* loss_dst, con
     return (int)hipGetLastError();
 }
 
+AdamCoef mcvc_adam_coef(float lr, float b1, float b2, float eps, int step, float grad_scale)
+{
+    // bias corrections in double like torch.optim.Adam's python scalars, then rounded once
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2 = 1.0 - pow((double)b2, (double)step);
+    return AdamCoef{(float)((double)lr / bc1), b1, b2, eps, (float)sqrt(bc2), grad_scale};
+}
+
 int mcvc_adam_launch(float* p, float* g, float* g2, int zero_grads, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
                      int step, float grad_scale, hipStream_t s)
 {
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)g2 | (uintptr_t)m | (uintptr_t)v) & 15) != 0) return MCVC_ERR_INVALID;
-    // bias corrections in double like torch.optim.Adam's python scalars, then rounded once
-    const double bc1 = 1.0 - pow((double)b1, (double)step);
-    const double bc2 = 1.0 - pow((double)b2, (double)step);
     TraceScope ts(K_ADAM, s, 0.0, (28.0 + (g2 ? 4.0 : 0.0) + (zero_grads ? (g2 ? 8.0 : 4.0) : 0.0)) * n);
     mcvc_launch(adam_kernel, dim3(ew_blocks(n >> 2, 256)), dim3(256), 0, s,
-                AdamKArgs{p, g, m, v, n, (float)((double)lr / bc1), b1, b2, eps, 1.0f, (float)sqrt(bc2), grad_scale, g2, zero_grads});
+                AdamKArgs{p, g, m, v, n, mcvc_adam_coef(lr, b1, b2, eps, step, grad_scale), g2, zero_grads});
     return (int)hipGetLastError();
 }
 

@@ -1064,7 +1064,7 @@ static void pack_spec(Exec& ex, const ConvSpec& c, const float* const* params, f
 }
 
 // ---- whole-network pack: job table built once per network kind, resident on the device ---------------------
-struct PackTable { std::vector<PackJob> jobs; std::vector<PackDgradArgs> dga; int nblocks = 0; double bytes = 0.0; };
+struct PackTable { std::vector<PackJob> jobs; std::vector<PackDgradArgs> dga; int nblocks = 0; double bytes = 0.0, wbytes = 0.0; };     // wbytes: the written share
 
 static void add_job(PackTable& t, PackJob j, int gx, int gy)
 {
@@ -1085,13 +1085,17 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
     const int K = c.Cin * c.KH * c.KW;
     const bool fw = (sets & 1) != 0, bw = (sets & 2) != 0;
     for (int br = 0; br < c.nbr; ++br) {
+        // (on leaving this iteration: every weight job it added carries its tensor's geometry -- the fused update's tiles, build_upd_table)
+        struct Geo { PackTable& t; const ConvSpec& c; size_t first;
+                     ~Geo() { for (size_t q = first; q < t.jobs.size(); ++q) if (t.jobs[q].kind != PACK_COPY) {
+                                  PackJob& j = t.jobs[q]; j.Cout = c.Cout; j.Cin = c.Cin; j.taps = c.KH * c.KW; } } } geo{t, c, t.jobs.size()};
         const bool skip_direct = (wino_only && (c.wino || c.wino3)) || (igemm_only && c.igemm);
         if (trunk_only && c.off_tk >= 0) {
             if (!bw) continue;
             PackJob q{}; q.kind = PACK_TRUNK_T; q.param = c.wi[br]; q.dst = c.off_tk; q.Cout = c.Cout; q.Cin = c.Cin; q.KW = c.KW;
             q.ld = c.cout_tot * c.KW; q.co_off = br * c.Cout;
             add_job(t, q, cdiv_i(c.Cin, 32), cdiv_i(c.Cout, 32));
-            t.bytes += 8.0 * c.Cout * K;
+            t.bytes += 8.0 * c.Cout * K; t.wbytes += 4.0 * c.Cout * K;
             continue;
         }
         PackJob f{}; f.kind = PACK_FWD; f.param = c.wi[br]; f.dst = c.off_fwd; f.Cout = c.Cout; f.K = K; f.ld = c.cout_pk; f.co_off = br * c.Cout;
@@ -1114,7 +1118,7 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             PackJob du{}; du.kind = PACK_DGRAD; du.param = c.wi[br]; du.dst = c.off_dcls; du.dg = (int)t.dga.size();
             t.dga.push_back(u);
             add_job(t, du, cdiv_i(c.Cin, 32), c.Cout);
-            t.bytes += 4.0 * 2.0 * c.Cout * K;
+            t.bytes += 4.0 * 2.0 * c.Cout * K; t.wbytes += 4.0 * c.Cout * K;
         }
         if (c.off_tk >= 0 && bw) {
             PackJob q{}; q.kind = PACK_TRUNK_T; q.param = c.wi[br]; q.dst = c.off_tk; q.Cout = c.Cout; q.Cin = c.Cin; q.KW = c.KW;
@@ -1130,7 +1134,7 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             for (int k = 0; k < c.ncls; ++k) u.cls[k] = c.icls[k];
             PackJob di{}; di.kind = PACK_DGRAD; di.param = c.wi[br]; di.dst = c.off_idg; di.dg = (int)t.dga.size();
             if (bw) { t.dga.push_back(u); add_job(t, di, cdiv_i(c.Cin, 32), c.Cout); }
-            t.bytes += 4.0 * (fw + bw) * 2.0 * c.Cout * K;
+            t.bytes += 4.0 * (fw + bw) * 2.0 * c.Cout * K; t.wbytes += 4.0 * (fw + bw) * c.Cout * K;
         }
         if (c.wino3) {
             PackJob w3{}; w3.kind = PACK_WINO3_D; w3.param = c.wi[br]; w3.dst = c.off_w3; w3.Cout = c.Cout; w3.Cin = c.Cin; w3.ld = c.mg_ld;
@@ -1139,7 +1143,7 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             PackJob w3f{}; w3f.kind = PACK_WINO3_F; w3f.param = c.wi[br]; w3f.dst = c.off_w3f; w3f.Cout = c.Cout; w3f.Cin = c.Cin; w3f.ld = c.cout_pk;
             w3f.xi_stride = c.w3f_xi; w3f.co_off = br * c.Cout;
             if (fw) add_job(t, w3f, cdiv_i(c.Cout, 256), c.Cin);
-            t.bytes += 4.0 * (fw + bw) * (25.0 + 64.0) * c.Cout * c.Cin;
+            t.bytes += 4.0 * (fw + bw) * (25.0 + 64.0) * c.Cout * c.Cin; t.wbytes += 4.0 * (fw + bw) * 64.0 * c.Cout * c.Cin;
         }
         if (c.wino3 && w43) {
             PackJob w3{}; w3.kind = PACK_WINO43_D; w3.param = c.wi[br]; w3.dst = c.off_w43; w3.Cout = c.Cout; w3.Cin = c.Cin; w3.ld = c.mg_ld;
@@ -1148,7 +1152,7 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             PackJob w3f{}; w3f.kind = PACK_WINO43_F; w3f.param = c.wi[br]; w3f.dst = c.off_w43f; w3f.Cout = c.Cout; w3f.Cin = c.Cin; w3f.ld = c.cout_pk;
             w3f.xi_stride = c.w3f_xi; w3f.co_off = br * c.Cout;
             if (fw) add_job(t, w3f, cdiv_i(c.Cout, 256), c.Cin);
-            t.bytes += 4.0 * (fw + bw) * (25.0 + 144.0) * c.Cout * c.Cin;
+            t.bytes += 4.0 * (fw + bw) * (25.0 + 144.0) * c.Cout * c.Cin; t.wbytes += 4.0 * (fw + bw) * 144.0 * c.Cout * c.Cin;
         }
         if (c.wino && w4) {
             PackJob wf{}; wf.kind = PACK_WINO4_F; wf.param = c.wi[br]; wf.dst = c.off_w4f; wf.Cout = c.Cout; wf.Cin = c.Cin; wf.ld = c.cout_pk;
@@ -1157,7 +1161,7 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             PackJob wd{}; wd.kind = PACK_WINO4_D; wd.param = c.wi[br]; wd.dst = c.off_w4d; wd.Cout = c.Cout; wd.Cin = c.Cin; wd.ld = c.cin_pk;
             wd.xi_stride = c.wd_xi; wd.co_off = br * c.Cout;
             if (bw) add_job(t, wd, cdiv_i(c.Cin, 256), c.Cout);
-            t.bytes += 4.0 * (fw + bw) * (25.0 + 64.0) * c.Cout * c.Cin;
+            t.bytes += 4.0 * (fw + bw) * (25.0 + 64.0) * c.Cout * c.Cin; t.wbytes += 4.0 * (fw + bw) * 64.0 * c.Cout * c.Cin;
         }
         if (c.wino) {
             PackJob wf{}; wf.kind = PACK_WINO_F; wf.param = c.wi[br]; wf.dst = c.off_wf; wf.Cout = c.Cout; wf.Cin = c.Cin; wf.ld = c.cout_pk;
@@ -1166,9 +1170,10 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             PackJob wd{}; wd.kind = PACK_WINO_D; wd.param = c.wi[br]; wd.dst = c.off_wd; wd.Cout = c.Cout; wd.Cin = c.Cin; wd.ld = c.cin_pk;
             wd.xi_stride = c.wd_xi; wd.co_off = br * c.Cout;
             if (bw) add_job(t, wd, cdiv_i(c.Cin, 256), c.Cout);
-            t.bytes += 4.0 * (fw + bw) * (25.0 + 36.0) * c.Cout * c.Cin;
+            t.bytes += 4.0 * (fw + bw) * (25.0 + 36.0) * c.Cout * c.Cin; t.wbytes += 4.0 * (fw + bw) * 36.0 * c.Cout * c.Cin;
         }
         t.bytes += skip_direct ? 8.0 * c.Cout : 4.0 * ((c.off_tk >= 0 ? 6.0 : 4.0) * c.Cout * K + 2.0 * c.Cout);
+        t.wbytes += skip_direct ? 4.0 * c.Cout : 4.0 * ((c.off_tk >= 0 ? 3.0 : 2.0) * c.Cout * K + c.Cout);
     }
 }
 
@@ -1203,6 +1208,102 @@ static int pack_net(const DevPackTable* t, const float* const* params, float* pa
     PackPtrs ptrs{};
     for (int i : t->used) { if (i < 0 || i >= 128) return MCVC_ERR_INVALID; ptrs.p[i] = params[i]; }
     return mcvc_pack_net_launch(t->jobs, t->njobs, t->nblocks, t->dga, ptrs, packed, t->bytes, s);
+}
+
+// ---- optimizer step fused with the re-pack (pack.h: UpdOwner) -----------------------------------------------------------------------
+// The job table of a re-pack (same `build` as dev_pack_table) is re-grouped by parameter: every tensor of the parameter range gets ONE owner
+// -- a tiled owner whose workgroups update a (CB x IB x taps) block of filters and emit all packed forms of that block, or a flat owner
+// (biases, norm affine parameters, tensors nothing is packed from) -- so that one launch is optimizer.step() AND the refresh of every
+// copy the kernels read (reference train.py:242,299).
+struct DevUpdTable { UpdOwner* owners; PackJob* jobs; PackDgradArgs* dga; int nown, nblocks; double adam_floats, pack_bytes; std::vector<int> used;
+                     std::vector<long long> sizes; };      // sizes[k]: element count of parameter used[k] the tiles were built for
+
+template <class Build, class InRange>
+static const DevUpdTable* dev_upd_table(int kind, Build&& build, const long long* numel, int nparams, InRange&& in_range, int* err)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, DevUpdTable> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { *err = MCVC_ERR_INVALID; return nullptr; }
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({dev, kind});
+    if (it != cache.end()) return &it->second;
+    PackTable t;
+    build(t);
+    std::vector<PackJob> jobs;                  // re-ordered: the emits of one parameter are consecutive
+    std::vector<UpdOwner> owners;
+    DevUpdTable d{};
+    int nblocks = 0;
+    for (int prm = 0; prm < nparams && prm < 128; ++prm) {
+        std::vector<PackJob> mine;
+        for (const PackJob& j : t.jobs) if (j.param == prm) mine.push_back(j);
+        if (!in_range(prm)) { if (!mine.empty()) { *err = MCVC_ERR_INVALID; return nullptr; } continue; }
+        if (numel[prm] <= 0) { if (!mine.empty()) { *err = MCVC_ERR_INVALID; return nullptr; } continue; }       // (dead parameter)
+        UpdOwner o{};
+        o.param = prm; o.block0 = nblocks; o.e0 = (int)jobs.size(); o.ne = (int)mine.size();
+        bool weight = false;
+        for (const PackJob& j : mine) weight = weight || j.kind != PACK_COPY;
+        if (!weight) {
+            o.flat = 1; o.Cout = (int)numel[prm]; o.Cin = o.taps = 1; o.gx = 1;
+            for (const PackJob& j : mine) if (j.Cout != o.Cout) { *err = MCVC_ERR_INVALID; return nullptr; }
+            nblocks += cdiv_i(o.Cout, 256);
+        } else {
+            const PackJob& j0 = mine[0];
+            o.Cout = j0.Cout; o.Cin = j0.Cin; o.taps = j0.taps;
+            for (const PackJob& j : mine) if (j.kind == PACK_COPY || j.Cout != o.Cout || j.Cin != o.Cin || j.taps != o.taps) { *err = MCVC_ERR_INVALID; return nullptr; }
+            if ((long long)o.Cout * o.Cin * o.taps != numel[prm]) { *err = MCVC_ERR_INVALID; return nullptr; }
+            // tile: 16 x 16 filters of 25 taps (the Winograd layers: one filter per thread), 32 x 32 of 9, 32 x 64 of 3, 32 x 128 of 1;
+            // the 5 x 15 edge layers (2 input channels / 1 output channel) as they come
+            int cb = 32, ib = 32;
+            if (o.taps == 25) { cb = 16; ib = 16; }
+            else if (o.taps == 3) ib = 64;
+            else if (o.taps == 1) ib = 128;
+            else if (o.taps > 25) ib = 16;
+            o.CB = cb < o.Cout ? cb : o.Cout; o.IB = ib < o.Cin ? ib : o.Cin;
+            if ((size_t)o.CB * (((o.IB * o.taps + 3) & ~3) + kUpdPitchPad) * sizeof(float) > kUpdLds) { *err = MCVC_ERR_INVALID; return nullptr; }
+            o.vec4 = ((o.IB * o.taps) % 4 == 0 && (o.Cin % o.IB) == 0 && ((long long)o.Cin * o.taps) % 4 == 0) ? 1 : 0;
+            o.gx = cdiv_i(o.Cin, o.IB);
+            nblocks += o.gx * cdiv_i(o.Cout, o.CB);
+        }
+        d.adam_floats += (double)numel[prm];
+        for (const PackJob& j : mine) jobs.push_back(j);
+        owners.push_back(o);
+        d.used.push_back(prm); d.sizes.push_back(numel[prm]);
+    }
+    if (jobs.size() != t.jobs.size() || owners.empty()) { *err = MCVC_ERR_INVALID; return nullptr; }
+    d.nown = (int)owners.size(); d.nblocks = nblocks;
+    d.pack_bytes = t.wbytes;
+    if (jobs.empty()) jobs.push_back(PackJob{});
+    if (t.dga.empty()) t.dga.push_back(PackDgradArgs{});
+    hipError_t e = hipMalloc((void**)&d.owners, owners.size() * sizeof(UpdOwner));
+    if (e == hipSuccess) e = hipMalloc((void**)&d.jobs, jobs.size() * sizeof(PackJob));
+    if (e == hipSuccess) e = hipMalloc((void**)&d.dga, t.dga.size() * sizeof(PackDgradArgs));
+    if (e == hipSuccess) e = hipMemcpy(d.owners, owners.data(), owners.size() * sizeof(UpdOwner), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d.jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d.dga, t.dga.data(), t.dga.size() * sizeof(PackDgradArgs), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { *err = (int)e; return nullptr; }
+    return &cache.emplace(std::make_pair(dev, kind), std::move(d)).first->second;
+}
+
+// the optimizer arguments of the fused update: the gradient(s) and the moments live at the same offsets of their flat buffers as the
+// parameters do in theirs (engine.py _FlatGroup), so one float offset per buffer locates them from a parameter pointer
+struct UpdOpt { const float* flat; const float* grad; const float* grad2; const float* exp_avg; const float* exp_avg_sq;
+                float lr, beta1, beta2, eps; int step; float grad_scale; int zero_grads; };
+
+static int update_net(const DevUpdTable* t, const float* const* params, const long long* numel, float* packed, const UpdOpt& o, hipStream_t s)
+{
+    for (size_t k = 0; k < t->used.size(); ++k) if (numel[t->used[k]] != t->sizes[k]) return MCVC_ERR_INVALID;      // (the table is cached per configuration)
+    if (!o.flat || !o.grad || !o.exp_avg || !o.exp_avg_sq || o.step < 1) return MCVC_ERR_INVALID;
+    if ((((uintptr_t)o.flat | (uintptr_t)o.grad | (uintptr_t)o.grad2 | (uintptr_t)o.exp_avg | (uintptr_t)o.exp_avg_sq) & 15) != 0) return MCVC_ERR_INVALID;
+    PackPtrs ptrs{};
+    for (int i : t->used) { if (i < 0 || i >= 128 || !params[i] || (((uintptr_t)params[i]) & 15) != 0) return MCVC_ERR_INVALID; ptrs.p[i] = params[i]; }
+    UpdAdam ad{};
+    ad.d_g = o.grad - o.flat; ad.d_m = o.exp_avg - o.flat; ad.d_v = o.exp_avg_sq - o.flat;
+    ad.has_g2 = o.grad2 ? 1 : 0; ad.d_g2 = o.grad2 ? o.grad2 - o.flat : 0;
+    ad.zero = o.zero_grads;
+    ad.c = mcvc_adam_coef(o.lr, o.beta1, o.beta2, o.eps, o.step, o.grad_scale);
+    const double bytes = (28.0 + (o.grad2 ? 4.0 : 0.0) + (o.zero_grads ? (o.grad2 ? 8.0 : 4.0) : 0.0)) * t->adam_floats + t->pack_bytes;
+    return mcvc_update_net_launch(t->owners, t->nown, t->nblocks, t->jobs, t->dga, ptrs, packed, ad, bytes, s);
 }
 
 // ---- fused small-batch trunk layer (trunk_kernels.hip) ------------------------------------------------
@@ -2250,48 +2351,81 @@ int mcvc_gen_pack_sets(const float* const* params, float* packed, int max_batch,
 // ... restricted to the layers of some parameter ranges (bit 0: upSample1/2 + lastConvLayer = parameters [100,110); bit 1: the residual
 // blocks + conv1dto2d = [24,100); bit 2: conv1, downSample1/2, conv2dto1d = [0,24) -- the ranges whose gradients become final one after the
 // other during a backward pass, mcvc_gen_backward_overlap): the optimizer step + re-pack of a range can then run beside the rest of the pass
-int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batch, int T, int sets, int range_mask, void* stream)
+struct GenPackCfg { bool fused, wino_only, w4, w43, up1_w4; int skipped; };
+static GenPackCfg gen_pack_cfg(int max_batch, int T)
 {
-    if (sets < 1 || sets > 3 || range_mask < 1 || range_mask > 7) return MCVC_ERR_INVALID;
-    bool fused = true;
+    GenPackCfg q{};
+    q.fused = true;
     for (int b = 1; b <= max_batch; ++b)
-        if (!mcvc_gen_trunk_fused(b, T)) fused = false;
+        if (!mcvc_gen_trunk_fused(b, T)) q.fused = false;
     // every 5x5 layer of every such pass runs on the Winograd kernels (conv_wino / the wino3 branches take no fallback) when
     // the frame count keeps all image sizes even, the tile counts are inside the kernels' range and nothing was switched
     // off through the MCVC_WINO* knobs: then their direct K-major copies are not refreshed either
     static const bool knobs_default = !getenv("MCVC_WINO") && !getenv("MCVC_WINO3") && !getenv("MCVC_WINO3_FWD") && !getenv("MCVC_WINO_GEMM");
     const GenDims dm = gen_dims(max_batch, T);
-    const bool wino_only = fused && knobs_default && (T % 4) == 0 && T >= 32 && (long long)max_batch * 20 * dm.W4 <= 16384;
-    int err = 0;
+    q.wino_only = q.fused && knobs_default && (T % 4) == 0 && T >= 32 && (long long)max_batch * 20 * dm.W4 <= 16384;
     // the 64-point weight sets of upSample1/2 only when some pass can take the F(4x4,5x5) path (wino4_applies); otherwise marked absent (bit 16)
-    const bool w4 = knobs_default && wino4_min_nb() > 0 && max_batch >= wino4_min_nb() && (T % 16) == 0;
-    const bool w43 = knobs_default && wino43_min_nb() > 0 && max_batch >= wino43_min_nb() && (T % 16) == 0;      // (bit 32)
-    const bool up1_w4 = (long long)max_batch * 5 * (T / 16) >= wino4_min_tiles();             // upSample1 runs on 20 x T/4 images: 5 x T/16 tiles per sample
-    auto build = [wino_only, fused, sets, range_mask, w4, w43, up1_w4](PackTable& pt) {
-        const GenNet& g = gen_net();
-        if (range_mask & 4) {
-            const ConvSpec* head[] = {&g.conv1, &g.ds1, &g.ds2};
-            for (const ConvSpec* c : head) add_spec_jobs(pt, *c, false, wino_only, sets, w4, w43);
-            add_spec_jobs(pt, g.c2d1d, fused, false, sets);
-        }
-        if (range_mask & 1) {
-            const ConvSpec* up[] = {&g.up1, &g.up2, &g.last};
-            // (a layer whose largest pass has fewer than 64 F(4x4) tiles never takes that path, conv_wino4: its 64-point sets are not written)
-            for (const ConvSpec* c : up) add_spec_jobs(pt, *c, false, wino_only, sets, w4 && (c != &g.up1 || up1_w4), w43);
-        }
-        if (range_mask & 2) {
-            add_spec_jobs(pt, g.c1d2d, fused, false, sets);
-            for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i], fused, false, sets); add_spec_jobs(pt, g.res_out[i], fused, false, sets); }
-        }
-    };
-    const DevPackTable* t = dev_pack_table(16 + 4 * sets + (fused ? (wino_only ? 3 : 2) : 0) + 64 * range_mask + (w4 ? 1024 : 0) + (w43 ? 2048 : 0) + (up1_w4 ? 4096 : 0), build, &err);
+    q.w4 = knobs_default && wino4_min_nb() > 0 && max_batch >= wino4_min_nb() && (T % 16) == 0;
+    q.w43 = knobs_default && wino43_min_nb() > 0 && max_batch >= wino43_min_nb() && (T % 16) == 0;      // (bit 32)
+    q.up1_w4 = (long long)max_batch * 5 * (T / 16) >= wino4_min_tiles();             // upSample1 runs on 20 x T/4 images: 5 x T/16 tiles per sample
+    q.skipped = (q.fused ? (q.wino_only ? 3 : 1) : 0) | (q.w4 ? 0 : 16) | (q.w43 ? 0 : 32);
+    return q;
+}
+static void gen_pack_build(PackTable& pt, const GenPackCfg& q, int sets, int range_mask)
+{
+    const GenNet& g = gen_net();
+    if (range_mask & 4) {
+        const ConvSpec* head[] = {&g.conv1, &g.ds1, &g.ds2};
+        for (const ConvSpec* c : head) add_spec_jobs(pt, *c, false, q.wino_only, sets, q.w4, q.w43);
+        add_spec_jobs(pt, g.c2d1d, q.fused, false, sets);
+    }
+    if (range_mask & 1) {
+        const ConvSpec* up[] = {&g.up1, &g.up2, &g.last};
+        // (a layer whose largest pass has fewer than 64 F(4x4) tiles never takes that path, conv_wino4: its 64-point sets are not written)
+        for (const ConvSpec* c : up) add_spec_jobs(pt, *c, false, q.wino_only, sets, q.w4 && (c != &g.up1 || q.up1_w4), q.w43);
+    }
+    if (range_mask & 2) {
+        add_spec_jobs(pt, g.c1d2d, q.fused, false, sets);
+        for (int i = 0; i < 6; ++i) { add_spec_jobs(pt, g.res_vg[i], q.fused, false, sets); add_spec_jobs(pt, g.res_out[i], q.fused, false, sets); }
+    }
+}
+static int gen_pack_key(const GenPackCfg& q, int sets, int range_mask)
+{
+    return 16 + 4 * sets + (q.fused ? (q.wino_only ? 3 : 2) : 0) + 64 * range_mask + (q.w4 ? 1024 : 0) + (q.w43 ? 2048 : 0) + (q.up1_w4 ? 4096 : 0);
+}
+
+int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batch, int T, int sets, int range_mask, void* stream)
+{
+    if (sets < 1 || sets > 3 || range_mask < 1 || range_mask > 7) return MCVC_ERR_INVALID;
+    const GenPackCfg q = gen_pack_cfg(max_batch, T);
+    int err = 0;
+    const DevPackTable* t = dev_pack_table(gen_pack_key(q, sets, range_mask), [&](PackTable& pt) { gen_pack_build(pt, q, sets, range_mask); }, &err);
     if (!t) return err;
-    const int skipped = (fused ? (wino_only ? 3 : 1) : 0) | (w4 ? 0 : 16) | (w43 ? 0 : 32);
-    if (sets == 1) set_pack_skips(packed, skipped | 4);
+    if (sets == 1) set_pack_skips(packed, q.skipped | 4);
     else if (sets == 2) set_pack_skips(packed, get_pack_skips(packed) & ~4);
-    else set_pack_skips(packed, skipped);
+    else set_pack_skips(packed, q.skipped);
     if (t->njobs == 0) return 0;
     return pack_net(t, params, packed, (hipStream_t)stream);
+}
+
+// optimizer.step() of a generator's parameter ranges (train.py:242) fused with the refresh of every packed copy derived from them: ONE
+// launch, one reader and one writer per weight (update_net_kernel).  `numel`: element count of each of the 110 parameter tensors;
+// flat / grad / grad2 (nullable) / exp_avg / exp_avg_sq: the flat buffers the parameters, their gradients and moments live in at EQUAL
+// offsets (the engine's layout): the gradient of params[i] is grad + (params[i] - flat).  zero_grads: clear the gradient(s) behind the read.
+int mcvc_gen_update_ranges(const float* const* params, const long long* numel, float* packed, int max_batch, int T, int range_mask,
+                           const float* flat, float* grad, float* grad2, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                           float eps, int step, float grad_scale, int zero_grads, void* stream)
+{
+    if (!params || !numel || !packed || range_mask < 1 || range_mask > 7) return MCVC_ERR_INVALID;
+    const GenPackCfg q = gen_pack_cfg(max_batch, T);
+    int err = MCVC_ERR_INVALID;
+    auto in_range = [range_mask](int p) { return ((range_mask & 1) && p >= 100 && p < 110) || ((range_mask & 2) && p >= 24 && p < 100) || ((range_mask & 4) && p < 24); };
+    const DevUpdTable* t = dev_upd_table(gen_pack_key(q, 3, range_mask), [&](PackTable& pt) { gen_pack_build(pt, q, 3, range_mask); }, numel, MCVC_GEN_NPARAMS,
+                                         in_range, &err);
+    if (!t) return err;
+    // (a range's update leaves ITS copies fresh; the registry word describes which KINDS of copies exist, as after a full re-pack)
+    set_pack_skips(packed, q.skipped);
+    return update_net(t, params, numel, packed, UpdOpt{flat, grad, grad2, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale, zero_grads}, (hipStream_t)stream);
 }
 
 int mcvc_gen_pack_small_batch(const float* const* params, float* packed, int max_batch, int T, void* stream)
@@ -2321,35 +2455,59 @@ int mcvc_disc_pack_small(const float* const* params, float* packed, int T, void*
 
 // ... for passes of up to max_batch samples: the per-class data-gradient copies of the implicit GEMMs are refreshed only when some pass is large
 // enough to use them (MCVC_IGEMM_DGRAD_NB)
-int mcvc_disc_pack_batch(const float* const* params, float* packed, int max_batch, int T, void* stream)
+// which job table a discriminator re-pack for passes of up to max_batch samples uses: 1 = full, 2 = staged GEMMs, 3 / 4 = implicit GEMMs
+// with / without the per-class data-gradient copies; `skips` = the registry word it leaves
+static int disc_pack_kind(int max_batch, int T, int* skips)
 {
     const DiscNet& n = disc_net();
     const DiscDims d = disc_dims(max_batch < 1 ? 1 : max_batch, T);
     bool staged = true;
     for (int i = 0; i < 3; ++i) staged = staged && sgemm_kind(n.ds[i], 1, d.H[i], d.W[i]).kind == 1;
-    if (!staged) { set_pack_skips(packed, 0); return mcvc_disc_pack(params, packed, stream); }
-    int err = 0;
+    if (!staged) { *skips = 0; return 1; }
     if (disc_igemm(d)) {          // implicit GEMMs: the tap-major forward copy (+ the per-class data-gradient copies) of the stride-2 layers
         const bool dg = disc_igemm_dgrad(d);
-        const DevPackTable* t = dev_pack_table(dg ? 3 : 4, [dg](PackTable& pt) {
-            const DiscNet& n = disc_net();
-            add_spec_jobs(pt, n.conv1);
-            for (int i = 0; i < 3; ++i) add_spec_jobs(pt, n.ds[i], false, false, dg ? 3 : 1, true, true, true);
-            add_spec_jobs(pt, n.outc);
-        }, &err);
-        if (!t) return err;
-        set_pack_skips(packed, dg ? 8 : (8 | 64));          // (bit 64: the per-class data-gradient copies of the implicit GEMMs are stale)
-        return pack_net(t, params, packed, (hipStream_t)stream);
+        *skips = dg ? 8 : (8 | 64);          // (bit 64: the per-class data-gradient copies of the implicit GEMMs are stale)
+        return dg ? 3 : 4;
     }
-    const DevPackTable* t = dev_pack_table(2, [](PackTable& pt) {
-        const DiscNet& n = disc_net();
-        add_spec_jobs(pt, n.conv1);
-        for (int i = 0; i < 3; ++i) add_spec_jobs(pt, n.ds[i], false, false, 1 | 4);
-        add_spec_jobs(pt, n.outc);
-    }, &err);
+    *skips = 8;
+    return 2;
+}
+static void disc_pack_build(PackTable& pt, int kind)
+{
+    const DiscNet& n = disc_net();
+    add_spec_jobs(pt, n.conv1);
+    for (int i = 0; i < 3; ++i) {
+        if (kind == 1) add_spec_jobs(pt, n.ds[i]);
+        else if (kind == 2) add_spec_jobs(pt, n.ds[i], false, false, 1 | 4);
+        else add_spec_jobs(pt, n.ds[i], false, false, kind == 3 ? 3 : 1, true, true, true);
+    }
+    add_spec_jobs(pt, n.outc);
+}
+
+int mcvc_disc_pack_batch(const float* const* params, float* packed, int max_batch, int T, void* stream)
+{
+    int skips = 0, err = 0;
+    const int kind = disc_pack_kind(max_batch, T, &skips);
+    if (kind == 1) { set_pack_skips(packed, 0); return mcvc_disc_pack(params, packed, stream); }
+    const DevPackTable* t = dev_pack_table(kind, [kind](PackTable& pt) { disc_pack_build(pt, kind); }, &err);
     if (!t) return err;
-    set_pack_skips(packed, 8);
+    set_pack_skips(packed, skips);
     return pack_net(t, params, packed, (hipStream_t)stream);
+}
+
+// optimizer.step() of one discriminator (train.py:299) fused with the refresh of its packed copies; arguments as mcvc_gen_update_ranges
+// (`numel`: 20 entries, 0 for the parameters of the unused downSample4 block, which are neither updated nor packed).
+int mcvc_disc_update_batch(const float* const* params, const long long* numel, float* packed, int max_batch, int T,
+                           const float* flat, float* grad, float* grad2, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
+                           float eps, int step, float grad_scale, int zero_grads, void* stream)
+{
+    if (!params || !numel || !packed) return MCVC_ERR_INVALID;
+    int skips = 0, err = MCVC_ERR_INVALID;
+    const int kind = disc_pack_kind(max_batch, T, &skips);
+    const DevUpdTable* t = dev_upd_table(kind, [kind](PackTable& pt) { disc_pack_build(pt, kind); }, numel, MCVC_DISC_NPARAMS, [](int) { return true; }, &err);
+    if (!t) return err;
+    set_pack_skips(packed, skips);
+    return update_net(t, params, numel, packed, UpdOpt{flat, grad, grad2, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale, zero_grads}, (hipStream_t)stream);
 }
 
 int mcvc_gen_forward(const float* const* params, const float* packed, const float* x, const float* mask, float* out, float* stash,

@@ -37,7 +37,7 @@ struct PackJob {
     long long dst;         // float offset inside the packed buffer
     int Cout, K, ld, co_off, KW, Cin;
     int dg;                // PACK_DGRAD: index into the PackDgradArgs table
-    int pad_;
+    int taps;              // KH * KW of the tensor this job reads (weight jobs; the fused update's tile geometry)
     long long xi_stride;   // PACK_WINO_*: floats between the 36 transformed matrices
 };
 struct PackPtrs { const float* p[128]; };
@@ -45,3 +45,23 @@ constexpr size_t kPackNetLds = 32 * 75 * sizeof(float);      // largest tap coun
 int mcvc_pack_net_launch(const PackJob* d_jobs, int njobs, int nblocks, const PackDgradArgs* d_dga, const PackPtrs& ptrs, float* packed,
                          double bytes, hipStream_t s);
 int mcvc_pack_trunk_t_launch(const float* w, float* dst, int Cout, int Cin, int KW, int ld, int co_off, hipStream_t s);
+
+// ---- optimizer step fused with the re-pack (update_net_kernel): ONE workgroup owns a tile of filters of one parameter tensor -- it applies
+// Adam to the tile (p, m, v in place, gradient cleared behind the read), keeps the updated weights in LDS and writes EVERY packed form the
+// planner derives from that tensor (the "emits": the PackJob entries of this parameter) out of LDS.  One reader and one writer per weight:
+// no second pass over the OIHW tensors, no ordering problem between the in-place update and the re-pack (train.py:242,299 is optimizer.step()).
+#include "misc.h"
+struct UpdOwner {
+    int param;             // parameter-table index
+    int block0, gx;        // first workgroup of this owner in the flat grid; tiles along ci
+    int Cout, Cin, taps;   // tensor [Cout][Cin][taps]; flat owners (biases, norm affine parameters): Cout = numel, Cin = taps = 1
+    int CB, IB;            // tile: CB output channels x IB input channels x all taps
+    int e0, ne;            // emits: jobs [e0, e0 + ne) of the job table
+    int flat;              // 1: plain elementwise owner, 256 elements per workgroup
+    int vec4;              // 1: every tile row is a 16-byte-aligned run of a multiple of four floats
+};
+struct UpdAdam { long long d_g, d_g2, d_m, d_v; int has_g2, zero; AdamCoef c; };     // d_*: float offsets from a parameter to its gradient(s) / moments
+constexpr int kUpdPitchPad = 4;
+constexpr size_t kUpdLds = 40 * 1024;
+int mcvc_update_net_launch(const UpdOwner* d_owners, int nown, int nblocks, const PackJob* d_jobs, const PackDgradArgs* d_dga, const PackPtrs& ptrs,
+                           float* packed, const UpdAdam& ad, double bytes, hipStream_t s);

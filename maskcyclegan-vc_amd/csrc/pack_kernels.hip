@@ -158,6 +158,188 @@ __global__ void __launch_bounds__(256) pack_net_kernel(const Twin<PackNetKArgs> 
     }
 }
 
+// ---- optimizer step fused with the re-pack (pack.h: UpdOwner) -----------------------------------------------------------------
+// LDS tile of updated weights: T[c][i * taps + t] at c * pitch, c < nc output channels, i < ni input channels of the tile at (co0, ci0)
+struct UpdTile { const float* lds; int pitch, taps, co0, ci0, nc, ni, CB, IB, Cin; };
+
+// K-major forward copy (rows k = ci * taps + t, or tap-major t * Cin + ci): runs of CB consecutive output channels
+__device__ __forceinline__ void upd_emit_fwd(const PackJob& j, float* __restrict__ dst, const UpdTile& t, bool tapmajor)
+{
+    const int nk = t.ni * t.taps;
+    for (int idx = threadIdx.x; idx < nk * t.CB; idx += 256) {
+        const int c = idx % t.CB, kl = idx / t.CB;
+        if (c >= t.nc) continue;
+        const int i = kl / t.taps, tp = kl - i * t.taps;
+        const int ci = t.ci0 + i;
+        const long long row = tapmajor ? (long long)tp * t.Cin + ci : (long long)ci * t.taps + tp;
+        dst[row * j.ld + j.co_off + t.co0 + c] = t.lds[c * t.pitch + kl];
+    }
+}
+
+// data-gradient copies (pack_dgrad_tile's three layouts): runs of IB consecutive input channels
+__device__ __forceinline__ void upd_emit_dgrad(float* __restrict__ dst, const PackDgradArgs& a, const UpdTile& t)
+{
+    for (int cl = 0; cl < a.ncls; ++cl) {
+        const DgradClass& k = a.cls[cl];
+        const int nt = k.nth * k.ntw;
+        const int total = nt * t.nc * t.IB;
+        for (int idx = threadIdx.x; idx < total; idx += 256) {
+            const int i = idx % t.IB, r = idx / t.IB;
+            if (i >= t.ni) continue;
+            const int c = r % t.nc, tp = r / t.nc;
+            const int u = tp / k.ntw, v = tp - u * k.ntw;
+            const int kh = k.khmax - a.step * u, kw = k.kwmax - a.step * v;
+            const float wv = t.lds[c * t.pitch + i * t.taps + kh * a.KW + kw];
+            const int co = t.co0 + c, ci = t.ci0 + i;
+            if (a.tapmajor) {
+                dst[k.offset + ((long long)tp * a.cout_rows + a.co_off + co) * a.ld + ci] = wv;
+            } else if (a.merged) {
+                const long long row = ((long long)(a.co_off + co) * a.mg_kh + (u + k.su)) * a.mg_kw + (v + k.sv);
+                dst[row * a.ld + 4 * ci + 2 * k.qh + k.qw] = wv;
+            } else {
+                dst[k.offset + ((long long)(a.co_off + co) * nt + tp) * a.ld + ci] = wv;
+            }
+        }
+    }
+}
+
+// Wt[ci][(co_off + co) * KW + kwp] = W[co][ci][KW-1-kwp]: runs of CB * KW consecutive floats per input channel
+__device__ __forceinline__ void upd_emit_trunk_t(const PackJob& j, float* __restrict__ dst, const UpdTile& t)
+{
+    const int KW = t.taps, span = t.nc * KW;
+    for (int idx = threadIdx.x; idx < span * t.ni; idx += 256) {
+        const int q = idx % span, i = idx / span;
+        const int c = q / KW, kwp = q - c * KW;
+        dst[(long long)(t.ci0 + i) * j.ld + (long long)(j.co_off + t.co0) * KW + q] = t.lds[c * t.pitch + i * KW + (KW - 1 - kwp)];
+    }
+}
+
+// Winograd weight sets: one filter per thread; threads along co for the forward sets (columns = output channels), along ci for the
+// data-gradient sets (columns = input channels)
+template <class F>
+__device__ __forceinline__ void upd_emit_filters(const UpdTile& t, bool along_co, F&& f)
+{
+    const int nf = t.nc * t.ni;
+    for (int q = threadIdx.x; q < nf; q += 256) {
+        const int c = along_co ? q % t.nc : q / t.ni, i = along_co ? q / t.nc : q % t.ni;
+        f(t.lds + c * t.pitch + i * 25, t.co0 + c, t.ci0 + i);
+    }
+}
+
+struct UpdNetKArgs { const UpdOwner* owners; int nown; const PackJob* jobs; const PackDgradArgs* dga; PackPtrs ptrs; float* packed; UpdAdam ad; };
+__global__ void __launch_bounds__(256) update_net_kernel(const Twin<UpdNetKArgs> tw)
+{
+    const UpdNetKArgs& ka_ = tw.v[blockIdx.z];
+    const UpdOwner* __restrict__ owners = ka_.owners;
+    const PackJob* __restrict__ jobs = ka_.jobs;
+    const PackDgradArgs* __restrict__ dga = ka_.dga;
+    float* __restrict__ packed = ka_.packed;
+    const UpdAdam ad = ka_.ad;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int blk = blockIdx.x;
+    int lo = 0, hi = ka_.nown - 1;                    // last owner with block0 <= blk
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (owners[mid].block0 <= blk) lo = mid; else hi = mid - 1; }
+    const UpdOwner o = owners[lo];
+    const int rel = blk - o.block0;
+    float* __restrict__ p = const_cast<float*>(ka_.ptrs.p[o.param]);
+    float* __restrict__ g = p + ad.d_g;
+    float* __restrict__ g2 = ad.has_g2 ? p + ad.d_g2 : nullptr;
+    float* __restrict__ m = p + ad.d_m;
+    float* __restrict__ v = p + ad.d_v;
+    const AdamCoef c = ad.c;
+    if (o.flat) {                                     // biases, norm affine parameters: 256 elements per workgroup, at most a copy to emit
+        const int i = rel * 256 + threadIdx.x;
+        if (i >= o.Cout) return;
+        float gr = g[i];
+        if (g2) gr += g2[i];
+        if (ad.zero) { g[i] = 0.f; if (g2) g2[i] = 0.f; }
+        float pn = p[i], mn = m[i], vn = v[i];
+        adam_elem(pn, gr, mn, vn, c);
+        p[i] = pn; m[i] = mn; v[i] = vn;
+        for (int e = 0; e < o.ne; ++e) packed[jobs[o.e0 + e].dst + i] = pn;      // (PACK_COPY)
+        return;
+    }
+    const int bx = rel % o.gx, by = rel / o.gx;
+    UpdTile t;
+    t.lds = lds; t.taps = o.taps; t.CB = o.CB; t.IB = o.IB; t.Cin = o.Cin;
+    t.co0 = by * o.CB; t.ci0 = bx * o.IB;
+    t.nc = min(o.CB, o.Cout - t.co0); t.ni = min(o.IB, o.Cin - t.ci0);
+    const int run = t.ni * o.taps;                    // floats per tile row (contiguous in the OIHW tensor)
+    t.pitch = ((o.IB * o.taps + 3) & ~3) + kUpdPitchPad;
+    const long long row_stride = (long long)o.Cin * o.taps;
+    const long long base = (long long)t.co0 * row_stride + (long long)t.ci0 * o.taps;
+    // ---- Adam on the tile; the new weights stay in LDS
+    if (o.vec4) {
+        const int run4 = run >> 2, total4 = t.nc * run4;
+        for (int q = threadIdx.x; q < total4; q += 256) {
+            const int cc = q / run4, r4 = q - cc * run4;
+            const long long off = base + cc * row_stride + 4 * r4;
+            float4 pp = *reinterpret_cast<const float4*>(p + off);
+            float4 gg = *reinterpret_cast<const float4*>(g + off);
+            if (g2) { const float4 h = *reinterpret_cast<const float4*>(g2 + off); gg.x += h.x; gg.y += h.y; gg.z += h.z; gg.w += h.w; }
+            if (ad.zero) {
+                *reinterpret_cast<float4*>(g + off) = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g2) *reinterpret_cast<float4*>(g2 + off) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float4 mm = *reinterpret_cast<const float4*>(m + off);
+            float4 vv = *reinterpret_cast<const float4*>(v + off);
+            float* pf = reinterpret_cast<float*>(&pp);
+            float* gf = reinterpret_cast<float*>(&gg);
+            float* mf = reinterpret_cast<float*>(&mm);
+            float* vf = reinterpret_cast<float*>(&vv);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) adam_elem(pf[k], gf[k], mf[k], vf[k], c);
+            *reinterpret_cast<float4*>(p + off) = pp;
+            *reinterpret_cast<float4*>(m + off) = mm;
+            *reinterpret_cast<float4*>(v + off) = vv;
+            *reinterpret_cast<float4*>(lds + cc * t.pitch + 4 * r4) = pp;
+        }
+    } else {
+        const int total = t.nc * run;
+        for (int q = threadIdx.x; q < total; q += 256) {
+            const int cc = q / run, r = q - cc * run;
+            const long long off = base + cc * row_stride + r;
+            float gr = g[off];
+            if (g2) gr += g2[off];
+            if (ad.zero) { g[off] = 0.f; if (g2) g2[off] = 0.f; }
+            float pn = p[off], mn = m[off], vn = v[off];
+            adam_elem(pn, gr, mn, vn, c);
+            p[off] = pn; m[off] = mn; v[off] = vn;
+            lds[cc * t.pitch + r] = pn;
+        }
+    }
+    if (o.ne == 0) return;
+    __syncthreads();
+    // ---- every packed form of this tile, out of LDS
+    for (int e = 0; e < o.ne; ++e) {
+        const PackJob j = jobs[o.e0 + e];
+        float* dst = packed + j.dst;
+        switch (j.kind) {
+        case PACK_FWD: upd_emit_fwd(j, dst, t, false); break;
+        case PACK_FWD_TAP: upd_emit_fwd(j, dst, t, true); break;
+        case PACK_DGRAD: upd_emit_dgrad(dst, dga[j.dg], t); break;
+        case PACK_TRUNK_T: upd_emit_trunk_t(j, dst, t); break;
+        case PACK_WINO_F: upd_emit_filters(t, true, [&](const float* f, int co, int ci) { wino_weight_core(f, dst, co, ci, j.ld, j.xi_stride, j.co_off, 0); }); break;
+        case PACK_WINO_D: upd_emit_filters(t, false, [&](const float* f, int co, int ci) { wino_weight_core(f, dst, co, ci, j.ld, j.xi_stride, j.co_off, 1); }); break;
+        case PACK_WINO3_D: upd_emit_filters(t, false, [&](const float* f, int co, int ci) { wino3_weight_core_p<4>(f, dst, co, ci, j.ld, j.xi_stride, j.co_off); }); break;
+        case PACK_WINO3_F: upd_emit_filters(t, true, [&](const float* f, int co, int ci) { wino3_weight_fwd_core_p<4>(f, dst, co, ci, j.ld, j.xi_stride, j.co_off); }); break;
+        case PACK_WINO4_F: upd_emit_filters(t, true, [&](const float* f, int co, int ci) { wino4_weight_core(f, dst, co, ci, j.ld, j.xi_stride, j.co_off, 0); }); break;
+        case PACK_WINO4_D: upd_emit_filters(t, false, [&](const float* f, int co, int ci) { wino4_weight_core(f, dst, co, ci, j.ld, j.xi_stride, j.co_off, 1); }); break;
+        case PACK_WINO43_D: upd_emit_filters(t, false, [&](const float* f, int co, int ci) { wino3_weight_core_p<6>(f, dst, co, ci, j.ld, j.xi_stride, j.co_off); }); break;
+        case PACK_WINO43_F: upd_emit_filters(t, true, [&](const float* f, int co, int ci) { wino3_weight_fwd_core_p<6>(f, dst, co, ci, j.ld, j.xi_stride, j.co_off); }); break;
+        default: break;
+        }
+    }
+}
+
+int mcvc_update_net_launch(const UpdOwner* d_owners, int nown, int nblocks, const PackJob* d_jobs, const PackDgradArgs* d_dga, const PackPtrs& ptrs,
+                           float* packed, const UpdAdam& ad, double bytes, hipStream_t s)
+{
+    TraceScope ts(K_ADAM, s, 0.0, bytes);
+    mcvc_launch(update_net_kernel, dim3((unsigned)nblocks), dim3(256), kUpdLds, s, UpdNetKArgs{d_owners, nown, d_jobs, d_dga, ptrs, packed, ad});
+    return (int)hipGetLastError();
+}
+
 int mcvc_pack_net_launch(const PackJob* d_jobs, int njobs, int nblocks, const PackDgradArgs* d_dga, const PackPtrs& ptrs, float* packed,
                          double bytes, hipStream_t s)
 {

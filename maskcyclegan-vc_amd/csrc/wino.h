@@ -51,14 +51,10 @@ int mcvc_wino_output_launch(const WinoOutArgs& a, hipStream_t s);
 //   dgrad == 0: k = ci, col = co_off + co             (forward)
 //   dgrad == 1: k = co_off + co, col = ci, taps flipped (data-gradient)
 // G (6x5) for points {0, 1, -1, 2, -2, inf}
-static __device__ __forceinline__ void wino_weight_tile(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int dgrad, int bx, int by)
+// (..._core: the transform of ONE filter whose 25 taps are at g -- global memory for the re-pack kernel, an LDS tile of freshly updated
+//  weights for the fused optimizer step, pack_kernels.hip)
+static __device__ __forceinline__ void wino_weight_core(const float* g, float* dst, int co, int ci, int ld, long long xi_stride, int co_off, int dgrad)
 {
-    // forward: threads along co (columns of the K-major matrix); data-gradient: threads along ci
-    const int a_idx = bx * 256 + threadIdx.x;       // fastest index: co (forward) / ci (dgrad)
-    const int b_idx = by;                           //                ci (forward) / co (dgrad)
-    const int co = dgrad ? b_idx : a_idx, ci = dgrad ? a_idx : b_idx;
-    if (co >= Cout || ci >= Cin) return;
-    const float* g = w + ((long long)co * Cin + ci) * 25;
     float gg[5][5];
 #pragma unroll
     for (int k = 0; k < 5; ++k)
@@ -91,6 +87,15 @@ static __device__ __forceinline__ void wino_weight_tile(const float* w, float* d
         for (int aa = 0; aa < 6; ++aa) d0[(long long)(aa * 6 + b) * xi_stride] = o[aa];
     }
 }
+static __device__ __forceinline__ void wino_weight_tile(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int dgrad, int bx, int by)
+{
+    // forward: threads along co (columns of the K-major matrix); data-gradient: threads along ci
+    const int a_idx = bx * 256 + threadIdx.x;       // fastest index: co (forward) / ci (dgrad)
+    const int b_idx = by;                           //                ci (forward) / co (dgrad)
+    const int co = dgrad ? b_idx : a_idx, ci = dgrad ? a_idx : b_idx;
+    if (co >= Cout || ci >= Cin) return;
+    wino_weight_core(w + ((long long)co * Cin + ci) * 25, dst, co, ci, ld, xi_stride, co_off, dgrad);
+}
 
 
 // Batched product of the 36 Winograd points:  C[xi][m][n] = sum_k A[xi][k][m] * B[xi][k][n]   (all operands K-major)
@@ -122,11 +127,8 @@ static __device__ __forceinline__ void wino_g3(float v0, float v1, float v2, flo
 // (pack_dgrad_tile builds the same matrix for the direct kernel).  U = G g' G^T with G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
 // One thread per (co, ci), ci fastest: stores 4 consecutive columns x 16 points.
 template <int P>
-static __device__ __forceinline__ void wino3_weight_tile_p(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int bx, int by)
+static __device__ __forceinline__ void wino3_weight_core_p(const float* g, float* dst, int co, int ci, int ld, long long xi_stride, int co_off)
 {
-    const int ci = bx * 256 + threadIdx.x, co = by;
-    if (co >= Cout || ci >= Cin) return;
-    const float* g = w + ((long long)co * Cin + ci) * 25;
     float gg[5][5];
 #pragma unroll
     for (int k = 0; k < 25; ++k) gg[k / 5][k % 5] = g[k];
@@ -156,15 +158,20 @@ static __device__ __forceinline__ void wino3_weight_tile_p(const float* w, float
         }
 }
 
+template <int P>
+static __device__ __forceinline__ void wino3_weight_tile_p(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int bx, int by)
+{
+    const int ci = bx * 256 + threadIdx.x, co = by;
+    if (co >= Cout || ci >= Cin) return;
+    wino3_weight_core_p<P>(w + ((long long)co * Cin + ci) * 25, dst, co, ci, ld, xi_stride, co_off);
+}
+
 // Forward twin: y[oh][ow] = sum w[kh][kw] x[2oh+kh-2][2ow+kw-2] = 3x3 stride-1 pad-1 correlation over the phase planes
 // X[4ci+2p+q][i][j] = x[ci][2i+p][2j+q] with taps g'[u'][v'] = w[co][ci][2u'+p][2v'+q] (absent when the index exceeds 4).
 // U[xi][k = 4ci+2p+q][col = co_off + co].  One thread per (co, ci), co fastest.
 template <int P>
-static __device__ __forceinline__ void wino3_weight_fwd_tile_p(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int bx, int by)
+static __device__ __forceinline__ void wino3_weight_fwd_core_p(const float* g, float* dst, int co, int ci, int ld, long long xi_stride, int co_off)
 {
-    const int co = bx * 256 + threadIdx.x, ci = by;
-    if (co >= Cout || ci >= Cin) return;
-    const float* g = w + ((long long)co * Cin + ci) * 25;
     float gg[5][5];
 #pragma unroll
     for (int k = 0; k < 25; ++k) gg[k / 5][k % 5] = g[k];
@@ -189,6 +196,14 @@ static __device__ __forceinline__ void wino3_weight_fwd_tile_p(const float* w, f
                 for (int aa = 0; aa < P; ++aa) d0[(long long)(aa * P + b) * xi_stride] = o[aa];
             }
         }
+}
+
+template <int P>
+static __device__ __forceinline__ void wino3_weight_fwd_tile_p(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int bx, int by)
+{
+    const int co = bx * 256 + threadIdx.x, ci = by;
+    if (co >= Cout || ci >= Cin) return;
+    wino3_weight_fwd_core_p<P>(w + ((long long)co * Cin + ci) * 25, dst, co, ci, ld, xi_stride, co_off);
 }
 
 static __device__ __forceinline__ void wino3_weight_tile(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int bx, int by)

@@ -41,12 +41,8 @@ int mcvc_wino4_dw_launch(const float* du, float* dw, int Cout, int Cin, hipStrea
 
 // Weight transform U = G g G^T (8x8 from 5x5), one thread per (co, ci), called from the whole-network re-pack kernel; same conventions as
 // wino_weight_tile (dgrad: taps flipped, rows = output channels).
-static __device__ __forceinline__ void wino4_weight_tile(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int dgrad, int bx, int by)
+static __device__ __forceinline__ void wino4_weight_core(const float* g, float* dst, int co, int ci, int ld, long long xi_stride, int co_off, int dgrad)
 {
-    const int a_idx = bx * 256 + threadIdx.x, b_idx = by;
-    const int co = dgrad ? b_idx : a_idx, ci = dgrad ? a_idx : b_idx;
-    if (co >= Cout || ci >= Cin) return;
-    const float* g = w + ((long long)co * Cin + ci) * 25;
     float t[5][8];                                  // t[k][b] = sum_l g[k][l] G[b][l]
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -73,4 +69,11 @@ static __device__ __forceinline__ void wino4_weight_tile(const float* w, float* 
             for (int k = 0; k < 5; ++k) acc += kW4G[aa][k] * t[k][b];
             d0[(long long)(aa * 8 + b) * xi_stride] = acc;
         }
+}
+static __device__ __forceinline__ void wino4_weight_tile(const float* w, float* dst, int Cout, int Cin, int ld, long long xi_stride, int co_off, int dgrad, int bx, int by)
+{
+    const int a_idx = bx * 256 + threadIdx.x, b_idx = by;
+    const int co = dgrad ? b_idx : a_idx, ci = dgrad ? a_idx : b_idx;
+    if (co >= Cout || ci >= Cin) return;
+    wino4_weight_core(w + ((long long)co * Cin + ci) * 25, dst, co, ci, ld, xi_stride, co_off, dgrad);
 }

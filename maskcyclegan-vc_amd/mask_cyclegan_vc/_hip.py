@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MCVC_LIB: another build of the same library (same-box A/B of two kernel variants: tools/ab_lib.sh); it must export the same ABI version
 LIB_PATH = os.environ.get("MCVC_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libmcvc_hip.so")
 
-ABI_VERSION = 2                       # include/mcvc.h MCVC_ABI_VERSION
+ABI_VERSION = 3                       # include/mcvc.h MCVC_ABI_VERSION
 GEN_NPARAMS = 110
 DISC_NPARAMS = 20
 N_MEL = 80
@@ -78,6 +78,10 @@ _SIGS = {
     "mcvc_loss_combine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcvc_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
     "mcvc_adam_step2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
+    "mcvc_gen_update_ranges": (c_int, [_PP, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_float, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
+    "mcvc_disc_update_batch": (c_int, [_PP, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_float, c_float, c_float, c_float, c_int, c_float, c_int, c_void_p]),
     "mcvc_draw_batch": (c_int, [c_void_p, c_void_p, c_int, c_longlong, c_void_p, c_void_p, c_int, c_longlong, c_int, c_int, c_int,
                                 ctypes.c_ulonglong, ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mcvc_axpy": (c_int, [c_void_p, c_void_p, c_float, c_longlong, c_void_p]),

@@ -123,6 +123,15 @@ class TrainEngine:
             it = iter(gv)
             self._g_tab[n] = ptr_table([None if i in _DEAD else next(it) for i in range(len(ps))])
         self._g_tab2 = None                    # second generator-gradient buffer (196 MB): created on first use (MCVC_GROUPED_IDENT=1 only)
+        # optimizer.step() fused with the weight re-pack (mcvc_gen_update_ranges / mcvc_disc_update_batch, r4): ONE launch per network (pair)
+        # updates a tile of filters, keeps it in LDS and writes every packed copy from there -- no per-step `pack` launches, no second read
+        # of the OIHW tensors, forward AND backward copies fresh when the step returns (the separate refresh of the backward-only copies
+        # beside the next discriminator phase disappears).  Bit-identical to Adam + re-pack (tests/test_hip_update.py).
+        # MCVC_FUSED_UPDATE=0: the two-launch form.
+        self.fused_update = os.environ.get("MCVC_FUSED_UPDATE", "1") != "0"
+        ll = lambda v: (ctypes.c_longlong * len(v))(*v)     # noqa: E731
+        self._numel = {n: ll([p.numel() for p in ps]) for n, ps in zip(G_NAMES, g_lists)}
+        self._numel.update({n: ll([0 if i in _DEAD else p.numel() for i, p in enumerate(ps)]) for n, ps in zip(D_NAMES, d_all)})
         # flat-buffer range of each discriminator's live parameters (the discriminator pairs are updated separately when pipelined)
         self._d_ranges = {}
         d_off = [o[0] for o in self.d_group.offsets] + [self.d_group.numel]
@@ -422,13 +431,14 @@ class TrainEngine:
 
     # ---- thin call helpers ------------------------------------------------------------------------
     def _repack1(self, n, sets=3, ranges=7):
+        if sets == 2 and self.fused_update:
+            return                              # (the fused update wrote the backward-only copies together with the forward ones)
         if n in G_NAMES:
             # every generator pass of this engine has batch <= 2B at T frames: at small batch the trunk layers run on the
             # fused kernels and their generic K-major copies need no refresh (the library falls back to the full pack).
             # sets: 1 = what a forward pass reads, 2 = what only a backward pass reads (mcvc_gen_pack_sets)
             # (largest pass: two samples per input sample -- three with the merged forwards)
-            per = 3 if (self.merged and self._merged_ok(self._max_B)) else 2
-            check(self.L.mcvc_gen_pack_ranges(self._p_tab[n], ptr(self.packed[n]), per * self._max_B, self.T, sets, ranges, stream()), "pack " + n)
+            check(self.L.mcvc_gen_pack_ranges(self._p_tab[n], ptr(self.packed[n]), self._per_pass() * self._max_B, self.T, sets, ranges, stream()), "pack " + n)
         else:
             # (every discriminator pass of this engine has at most 2 * max_B samples)
             check(self.L.mcvc_disc_pack_batch(self._p_tab[n], ptr(self.packed[n]), 2 * self._max_B, self.T, stream()), "pack " + n)
@@ -605,6 +615,39 @@ class TrainEngine:
         self.nets[name]._packed_version = None
         self.nets[name]._bf16_version = None
 
+    def _per_pass(self):
+        """Samples per generator pass and input sample (the library sizes the packed copies for the largest pass)."""
+        return 3 if (self.merged and self._merged_ok(self._max_B)) else 2
+
+    def _update_gen(self, name, range_mask, lr, step, second=False, zero=True):
+        """optimizer.step() on the parameter ranges ``range_mask`` of ONE generator fused with the refresh of every packed copy derived
+        from them (train.py:242; mcvc_gen_update_ranges).  ``second``: the gradient is grad + grad2; ``zero``: clear it behind the read."""
+        grp = self.g_group
+        g2 = grp.grad2 if (second and grp.grad2 is not None) else None
+        check(self.L.mcvc_gen_update_ranges(self._p_tab[name], self._numel[name], ptr(self.packed[name]), self._per_pass() * self._max_B, self.T,
+                                            range_mask, ptr(grp.flat), ptr(grp.grad), ptr(g2), ptr(grp.exp_avg), ptr(grp.exp_avg_sq), float(lr),
+                                            self.betas[0], self.betas[1], self.eps, step, self.reducer.grad_scale, 1 if zero else 0, stream()),
+              "gen_update " + name)
+        self.nets[name]._packed_version = None
+        self.nets[name]._bf16_version = None
+
+    def _update_disc(self, name, lr, step, zero=True):
+        """optimizer.step() of ONE discriminator fused with the refresh of its packed copies (train.py:299; mcvc_disc_update_batch)."""
+        grp = self.d_group
+        check(self.L.mcvc_disc_update_batch(self._p_tab[name], self._numel[name], ptr(self.packed[name]), 2 * self._max_B, self.T,
+                                            ptr(grp.flat), ptr(grp.grad), None, ptr(grp.exp_avg), ptr(grp.exp_avg_sq), float(lr),
+                                            self.betas[0], self.betas[1], self.eps, step, self.reducer.grad_scale, 1 if zero else 0, stream()),
+              "disc_update " + name)
+        self.nets[name]._packed_version = None
+
+    def _update_discs(self, lr, zero=False):
+        """All four discriminators (the plain schedules' discriminator_update): two grouped launches."""
+        self.d_group.step += 1
+        st = self.d_group.step
+        for a, b in (D_NAMES[:2], D_NAMES[2:]):
+            self._twin(lambda a=a: self._update_disc(a, lr, st, zero), lambda b=b: self._update_disc(b, lr, st, zero))
+        self._d_pack_event = None
+
     # ---- the two phases -------------------------------------------------------------------------------
     def generator_phase(self, real_A, mask_A, real_B, mask_B, fuse_update=False):
         """train.py:195-242.  ``fuse_update`` (what ``step()`` uses on one rank): each lane also applies Adam to the generator whose last
@@ -686,6 +729,9 @@ class TrainEngine:
         def update(name):
             def run(ln):
                 self.reducer.wait(self.device)             # (no-op on one GPU)
+                if self.fused_update:
+                    self._update_gen(name, 7, g_lr, g_step, zero=False)
+                    return
                 self._adam_generator(name, g_step, g_lr)
                 self._repack1(name, 1)
             return run
@@ -836,6 +882,12 @@ class TrainEngine:
 
         def update(ln):
             self.reducer.wait(self.device)             # (no-op on one GPU)
+            if self.fused_update:
+                self.g_group.step += 1
+                st = self.g_group.step
+                self._twin(lambda: self._update_gen(A2B, 7, g_lr, st, second=ident_second and zeroing_update, zero=zeroing_update),
+                           lambda: self._update_gen(B2A, 7, g_lr, st, second=ident_second and zeroing_update, zero=zeroing_update))
+                return
             if zeroing_update:                         # (pipelined step: the gradients are cleared as they are consumed)
                 self.g_group.step += 1
                 self._adam_range(self.g_group, 0, self.g_group.numel, g_lr, self.g_group.step, second=ident_second)
@@ -857,9 +909,13 @@ class TrainEngine:
                     self.g_group.step += 1
                 step = self.g_group.step
                 (a0, a1), (b0, b1) = self._g_ranges[A2B][k], self._g_ranges[B2A][k]
-                self._twin(lambda: self._adam_range(self.g_group, a0, a1, g_lr, step, second=ident_second),
-                           lambda: self._adam_range(self.g_group, b0, b1, g_lr, step, second=ident_second))
-                self._twin(lambda: self._repack1(A2B, 1, 1 << k), lambda: self._repack1(B2A, 1, 1 << k))
+                if self.fused_update:
+                    self._twin(lambda: self._update_gen(A2B, 1 << k, g_lr, step, second=ident_second),
+                               lambda: self._update_gen(B2A, 1 << k, g_lr, step, second=ident_second))
+                else:
+                    self._twin(lambda: self._adam_range(self.g_group, a0, a1, g_lr, step, second=ident_second),
+                               lambda: self._adam_range(self.g_group, b0, b1, g_lr, step, second=ident_second))
+                    self._twin(lambda: self._repack1(A2B, 1, 1 << k), lambda: self._repack1(B2A, 1, 1 << k))
                 if last:
                     for n in G_NAMES:
                         self.nets[n]._packed_version = None
@@ -1074,6 +1130,9 @@ class TrainEngine:
                 if self.reducer.world > 1:
                     self.reducer.reduce_range_after_(self.d_group.grad, lo, hi, None)
                     self.reducer.wait(self.device)
+                if self.fused_update:
+                    self._twin(lambda: self._update_disc(pair[0], d_lr, d_step), lambda: self._update_disc(pair[1], d_lr, d_step))
+                    return
                 self._adam_range(self.d_group, lo, hi, d_lr, d_step)
                 for n in pair:
                     self.nets[n]._packed_version = None
@@ -1258,6 +1317,9 @@ class TrainEngine:
                 if self.reducer.world > 1:
                     self.reducer.reduce_range_after_(self.d_group.grad, lo, hi, None)
                     self.reducer.wait(self.device)
+                if self.fused_update:
+                    self._twin(lambda: self._update_disc(pair[0], d_lr, d_step), lambda: self._update_disc(pair[1], d_lr, d_step))
+                    return
                 self._adam_range(self.d_group, lo, hi, d_lr, d_step)
                 for n in pair:
                     self.nets[n]._packed_version = None
@@ -1420,6 +1482,9 @@ class TrainEngine:
             self._pending_d_lr = self.sched.d_opt_lr          # the value torch.optim would have used now
             return
         self.reducer.reduce_(self.d_group.grad)
+        if self.fused_update:
+            self._update_discs(self.sched.d_opt_lr)
+            return
         self._adam(self.d_group, self.sched.d_opt_lr)
         self._repack_d_async()
 
@@ -1427,8 +1492,11 @@ class TrainEngine:
         if self._pending_d_lr is None:
             return
         self.reducer.wait(self.device)
-        self._adam(self.d_group, self._pending_d_lr)
-        self._pending_d_lr = None
+        lr, self._pending_d_lr = self._pending_d_lr, None
+        if self.fused_update:
+            self._update_discs(lr)
+            return
+        self._adam(self.d_group, lr)
         self._repack_d_async()
 
     def _repack_d_async(self):
@@ -1467,10 +1535,13 @@ class TrainEngine:
             self.slots_done[:_BLOCK].copy_(self.slots[:_BLOCK])
             self.discriminator_phase_grouped(*inp)
             self.reducer.reduce_(self.d_group.grad)
-            self._adam(self.d_group, d_lr)
-            self.d_group.grad.zero_()
+            if self.fused_update:
+                self._update_discs(d_lr, zero=True)
+            else:
+                self._adam(self.d_group, d_lr)
+                self.d_group.grad.zero_()
+                self._repack_d_async()
             self._d_grad_clean = True
-            self._repack_d_async()
             self.slots_done[_BLOCK:].copy_(self.slots[_BLOCK:])
             self._publish_done()
         self._finish_d_update()

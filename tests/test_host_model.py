@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     assert declared, "no declarations parsed"
     assert declared == set(_hip.EXPORTED_SYMBOLS), declared ^ set(_hip.EXPORTED_SYMBOLS)
     L = _hip.lib()                      # raises if a symbol is missing from the .so
-    assert L.mcvc_version() == 2
+    assert L.mcvc_version() == _hip.ABI_VERSION == 3
     assert L.mcvc_gen_out_frames(64) == 64 and L.mcvc_gen_out_frames(65) == 68   # reference: T=65 -> 68
     assert L.mcvc_disc_out_frames(64) == 8
     assert L.mcvc_gen_packed_floats() > 2 * 24_000_000
