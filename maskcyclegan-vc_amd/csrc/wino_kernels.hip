@@ -966,6 +966,8 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
     b.mt = a.M / 128;
     TraceScope ts(K_WINO_GEMM, s, 2.0 * nxi * a.M * a.N * a.K, 4.0 * nxi * ((double)a.K * a.M + (double)a.K * a.N + (double)a.M * a.N));
     static const int cfg2 = [] { const char* e = getenv("MCVC_GEMM_CFG"); return e ? atoi(e) : 0; }();     // tuning: force a gemm2 shape
+    static const bool verbose = getenv("MCVC_GEMM_VERBOSE") != nullptr;        // one line per product: shapes for tools/gemm_bs1_shapes.py
+    if (verbose && mcvc_twin_phase() != 1) fprintf(stderr, "[gemm] nxi=%d M=%d N=%d K=%d lda=%d ldb=%d twin=%d\n", nxi, a.M, a.N, a.K, a.lda, a.ldb, mcvc_twin_phase() == 2);
     switch (cfg2) {
         case 1: return gemm2_launch<128, 64, 16, 4>(b, nxi, s);
         case 2: return gemm2_launch<128, 32, 16, 4>(b, nxi, s);
@@ -988,7 +990,16 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
     }
     // long-K products (the F(2x2,3x3) layers: K = 4*Cin or Cout >= 512): 64x64 tiles with 32-deep stages measured 10-20 % faster than
     // 128x64 / 128x32 with 16-deep stages (profiles/r02_gemm_tune.log) -- twice the workgroups and half the barriers per k
-    if (cfg2 == 0 && a.K >= 512 && (a.K % 32) == 0 && (a.M % 64) == 0) return gemm2_launch<64, 64, 32, 4>(b, nxi, s);
+    // ... unless the narrow tiles leave the busiest compute unit clearly less to do (r4, profiles/r04b_gemm_bs1_shapes.log): every product of
+    // these sizes follows  time ~ ceil(workgroups / 256) x BM x BN x K  -- the tile-rounds of the fullest CU.  The one- and two-sample
+    // data-gradient products (N = 96 / 160 columns, M = 256 / 1024) take 4 rounds of 64x64 tiles (N padded to 128 / 192) against 3 of 128x32:
+    // 44 -> 36, 61 -> 45, 44 -> 36 us at one sample, 58 -> 52, 73 -> 59, 58 -> 52 us at two.
+    auto rounds_cost = [&](int bm, int bn) { return (double)cdiv_i(cdiv_i(a.N, bn) * (a.M / bm) * nxi, 256) * bm * bn; };
+    static const int costsel = [] { const char* e = getenv("MCVC_GEMM_COST"); return e ? atoi(e) : 1; }();
+    if (cfg2 == 0 && a.K >= 512 && (a.K % 32) == 0 && (a.M % 64) == 0) {
+        if (!(costsel && a.ldb >= 32 && rounds_cost(128, 32) < 0.94 * rounds_cost(64, 64))) return gemm2_launch<64, 64, 32, 4>(b, nxi, s);
+        return gemm2_launch<128, 32, 16, 4>(b, nxi, s);
+    }
     // short-K products (the Winograd weight gradients at one or two samples per pass: K = tiles = 96 ... 128): every stage of the tile in
     // flight at once (six 16-deep stages) instead of a four-stage ring that is mostly fill and drain
     static const int shortk = [] { const char* e = getenv("MCVC_GEMM_SHORTK"); return e ? atoi(e) : 0; }();
