@@ -56,7 +56,11 @@ constexpr int kMaxWP = 10;          // 16-byte weight pieces per thread and stag
 
 // KWT > 0: the kernel width is a compile-time constant (taps fully unrolled: the compiler hoists the next operands' LDS reads above
 // the current MFMAs); KWT == 0: run-time width.
-template <int WM, int WN, int MT, int NT, int KWT, int PPT>
+// WREG: the weight stages go global -> registers -> LDS (plain loads, ds_write_b128 at the head of the next stage) instead of by LDS-DMA.
+// One workgroup per CU streams 40 KB of weights per stage; as 40 `global_load_lds` instructions per stage that is ~19 GB/s per CU through a
+// path that delivers ~25 (MI355X_MICROARCH.md: ldsdma-fill), and each of those instructions holds its wave's issue slot for 100-185 cycles
+// in the middle of the MFMA stream (r4 ablation: 19 % of the stride-1 layers' time).
+template <int WM, int WN, int MT, int NT, int KWT, int PPT, bool WREG = false>
 __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvArgs a)
 {
     constexpr int kMaxPP = PPT;
@@ -128,6 +132,20 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + woff[i]),
                                                  (__attribute__((address_space(3))) void*)(dst + (size_t)(wave * 64 + i * kConvThreads) * 16), 16, 0, 0);
     };
+    uint4 wreg[WREG ? NWP : 1];
+    auto load_w = [&](int stage) __attribute__((always_inline)) {
+        const int cc = stage / a.KH, kh = stage - cc * a.KH;
+        const bf16_t* base = a.w + (long long)(kh * ncc + cc) * KW * 32;
+#pragma unroll
+        for (int i = 0; i < (WREG ? NWP : 0); ++i)
+            wreg[i] = (woff[i] >= 0) ? *reinterpret_cast<const uint4*>(base + woff[i]) : make_uint4(0u, 0u, 0u, 0u);
+    };
+    auto store_w = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* dst = Ws + buf * wbuf_bytes;
+#pragma unroll
+        for (int i = 0; i < (WREG ? NWP : 0); ++i)
+            if (woff[i] >= 0) *reinterpret_cast<uint4*>(dst + (size_t)(tid + i * kConvThreads) * 16) = wreg[i];
+    };
     // ---- input patch: small patches (<= kMaxPP pieces per thread) are prefetched through registers one chunk ahead; large ones
     //      (stride-2 layers) are staged synchronously, four loads in flight per thread
     // stride 2: patch columns are stored de-interleaved (even columns, then odd columns) so that the 16 lanes of an operand read --
@@ -136,7 +154,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     const int PWe = (a.PW + 1) >> 1;
     auto patch_col = [&](int j) { return s2 ? (j < PWe ? 2 * j : 2 * (j - PWe) + 1) : j; };
     const bool p_pref = patch_pieces <= kMaxPP * kConvThreads;
-    long long poff[kMaxPP];                   // element offset of the piece inside the image (without the chunk offset); -1 = zero fill
+    int poff[kMaxPP];                         // element offset of the piece inside the image (without the chunk offset; an image is < 2^31 elements: host check); -1 = zero fill
 #pragma unroll
     for (int i = 0; i < kMaxPP; ++i) {
         const int q = tid + i * kConvThreads;
@@ -144,7 +162,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
         const int pr = pp / a.PW, pc = pp - pr * a.PW;
         const int ih = ih0 + pr, iw = iw0 + patch_col(pc);
         const bool ok = p_pref && q < patch_pieces && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        poff[i] = ok ? ((long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 2) & 3)) * 8) : -1;
+        poff[i] = ok ? (int)((long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 2) & 3)) * 8) : -1;
     }
     const bf16_t* ximg = a.x + (long long)n_img * a.x_sn;
     uint4 preg[kMaxPP];
@@ -200,7 +218,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    issue_w(0, 0);
+    if constexpr (WREG) load_w(0); else issue_w(0, 0);
     if (p_pref) load_patch(0);
     for (int stage = 0; stage < nstage; ++stage) {
         const int cc = stage / a.KH, kh = stage - cc * a.KH;
@@ -208,21 +226,31 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
         // everything requested during the previous stage (this stage's weights, the next chunk's patch registers) has had that stage's
         // MFMAs to land; the barrier also says every wave is done reading the buffer the next copy overwrites
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (WREG: buffer `buf` was last read two stages ago and every wave has passed the barrier since: the stores need none in front)
+        if constexpr (WREG) store_w(buf);
         __syncthreads();
         if (kh == 0) {
             if (p_pref) store_patch(); else stage_patch_sync(cc);
             __syncthreads();
         }
-        if (stage + 1 < nstage) issue_w(stage + 1, buf ^ 1);          // in flight during the MFMAs below
+        if constexpr (WREG) { if (stage + 1 < nstage) load_w(stage + 1); }
+        else if (stage + 1 < nstage) issue_w(stage + 1, buf ^ 1);          // in flight during the MFMAs below
         if (p_pref && kh == a.KH - 1 && cc + 1 < ncc) load_patch(cc + 1);
         const unsigned char* Wb = Ws + buf * wbuf_bytes;
         const int pk = kh * a.PW;
         // one step = (tap, 16-channel half) = MT + NT operand reads (ds_read_b128) and MT * NT MFMAs
+        // weight operand address = (per-lane base of (mt, 16-channel half)) + tap * 64: the tap offset is an instruction immediate once the
+        // steps are unrolled, so 2 * MT base registers serve all 2 * KW steps (the compiler otherwise keeps one per (mt, tap, half): 40)
+        const unsigned char* abase[MT][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) abase[mt][h2] = Wb + (size_t)(((rowA[mt] * KW) << 2) + ((h2 * 2 + half) ^ gA[mt])) * 16;
         auto load_step = [&](int step, bf16x8 (&av)[MT], bf16x8 (&bv)[NT]) {
             const int tap = step >> 1, lc = (step & 1) * 2 + half;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                av[mt] = *reinterpret_cast<const bf16x8*>(Wb + (size_t)(((rowA[mt] * KW + tap) << 2) + (lc ^ gA[mt])) * 16);
+                av[mt] = *reinterpret_cast<const bf16x8*>(abase[mt][step & 1] + tap * 64);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int pp = ppB[nt] + pk + (s2 ? (tap >> 1) + (tap & 1) * PWe : tap);
@@ -315,11 +343,11 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     }
 }
 
-template <int WM, int WN, int MT, int NT, int KWT, int PPT>
+template <int WM, int WN, int MT, int NT, int KWT, int PPT, bool WREG = false>
 int conv_launch_t(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
 {
     constexpr int BM = WM * MT * 32;
-    auto kern = bf16_conv_kernel<WM, WN, MT, NT, KWT, PPT>;
+    auto kern = bf16_conv_kernel<WM, WN, MT, NT, KWT, PPT, WREG>;
     static bool done = false;
     if (!done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -335,6 +363,19 @@ template <int WM, int WN, int MT, int NT>
 int conv_launch_kw(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
 {
     const bool big_patch = a.PH * a.PW * 4 > 4 * kConvThreads;
+    // (the 512-pixel tiles of the large stride-1 layers stage 816 / 1056 patch pixels = 13 / 17 pieces per thread: with 12 they fell off the
+    //  register prefetch onto the synchronous staging loop -- four dependent rounds of global loads per channel chunk in front of 50 MFMA-bound
+    //  steps; r4, 16 x 512 frames: upSample2 1090 -> 938 us.  MCVC_BF16_WREG=1: weights through registers instead of LDS-DMA, measured
+    //  SLOWER (938 -> 1004 us: 20-47 spilled registers, the ds_write_b128 of a stage exposed in front of its barrier))
+    static const int ppt_knob = [] { const char* e = getenv("MCVC_BF16_PPT"); return e ? atoi(e) : 1; }();
+    if constexpr (WM == 1 && WN == 4 && MT == 4 && NT == 4) {
+        const int pieces = a.PH * a.PW * 4;
+        static const int wreg_knob = [] { const char* e = getenv("MCVC_BF16_WREG"); return e ? atoi(e) : 0; }();
+        if (a.KW == 5 && wreg_knob && ppt_knob && pieces > 12 * kConvThreads && pieces <= 13 * kConvThreads) return conv_launch_t<WM, WN, MT, NT, 5, 13, true>(a, lds, s);
+        if (a.KW == 5 && wreg_knob && ppt_knob && pieces > 13 * kConvThreads && pieces <= 17 * kConvThreads) return conv_launch_t<WM, WN, MT, NT, 5, 17, true>(a, lds, s);
+        if (a.KW == 5 && ppt_knob && pieces > 12 * kConvThreads && pieces <= 13 * kConvThreads) return conv_launch_t<WM, WN, MT, NT, 5, 13>(a, lds, s);
+        if (a.KW == 5 && ppt_knob && pieces > 13 * kConvThreads && pieces <= 17 * kConvThreads) return conv_launch_t<WM, WN, MT, NT, 5, 17>(a, lds, s);
+    }
     if (a.KW == 5) return big_patch ? conv_launch_t<WM, WN, MT, NT, 5, 12>(a, lds, s) : conv_launch_t<WM, WN, MT, NT, 5, 4>(a, lds, s);
     if (a.KW == 3) return big_patch ? conv_launch_t<WM, WN, MT, NT, 3, 12>(a, lds, s) : conv_launch_t<WM, WN, MT, NT, 3, 4>(a, lds, s);
     if (a.KW == 1) return conv_launch_t<WM, WN, MT, NT, 1, 4>(a, lds, s);
