@@ -994,6 +994,13 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
     // these sizes follows  time ~ ceil(workgroups / 256) x BM x BN x K  -- the tile-rounds of the fullest CU.  The one- and two-sample
     // data-gradient products (N = 96 / 160 columns, M = 256 / 1024) take 4 rounds of 64x64 tiles (N padded to 128 / 192) against 3 of 128x32:
     // 44 -> 36, 61 -> 45, 44 -> 36 us at one sample, 58 -> 52, 73 -> 59, 58 -> 52 us at two.
+    // large grids (from ~16 samples per pass): 128 x 128 tiles, 2 x 2 accumulators per wave -- half the L2 -> LDS bytes per FLOP of the 64 x 64 /
+    // 128 x 64 tiles and one operand read per MFMA instead of 1.5-2.  r4, cold operands, alone on the chip: 36 x 512 x 2560 x 512 558 -> 502 us,
+    // 36 x 512 x 5120 x 512 878 -> 803, 64 x 256 x 2560 x 512 388 -> 356; bs=32 iteration 73.5-74.2 -> 72.0-72.1 ms.  Not for small grids: tile
+    // rounds (bs=8: 21.7-22.0 -> 22.4 ms when forced) and few-column weight-gradient products (N = 256 ... 512) lose.
+    static const int big = [] { const char* e = getenv("MCVC_GEMM_BIG"); return e ? atoi(e) : 1; }();
+    if (cfg2 == 0 && big && a.N >= 1280 && (a.K % 16) == 0 && (long long)cdiv_i(a.N, 128) * (a.M / 128) * nxi >= 1280)
+        return gemm2_launch<128, 128, 16, 4>(b, nxi, s);
     auto rounds_cost = [&](int bm, int bn) { return (double)cdiv_i(cdiv_i(a.N, bn) * (a.M / bm) * nxi, 256) * bm * bn; };
     static const int costsel = [] { const char* e = getenv("MCVC_GEMM_COST"); return e ? atoi(e) : 1; }();
     if (cfg2 == 0 && a.K >= 512 && (a.K % 32) == 0 && (a.M % 64) == 0) {
