@@ -1252,10 +1252,13 @@ static const DevUpdTable* dev_upd_table(int kind, Build&& build, const long long
             o.Cout = j0.Cout; o.Cin = j0.Cin; o.taps = j0.taps;
             for (const PackJob& j : mine) if (j.kind == PACK_COPY || j.Cout != o.Cout || j.Cin != o.Cin || j.taps != o.taps) { *err = MCVC_ERR_INVALID; return nullptr; }
             if ((long long)o.Cout * o.Cin * o.taps != numel[prm]) { *err = MCVC_ERR_INVALID; return nullptr; }
-            // tile: 16 x 16 filters of 25 taps (the Winograd layers: one filter per thread), 32 x 32 of 9, 32 x 64 of 3, 32 x 128 of 1;
+            // tile: 32 x 16 filters of 25 taps (the Winograd layers: two filters per thread), 32 x 32 of 9, 32 x 64 of 3, 32 x 128 of 1;
             // the 5 x 15 edge layers (2 input channels / 1 output channel) as they come
             int cb = 32, ib = 32;
-            if (o.taps == 25) { cb = 16; ib = 16; }
+            // (25 taps: 32 x 16 filters = two per thread, 52 KB of LDS -- full 128-byte runs in the forward-type copies; measured against
+            //  16 x 16: the family 0.733 -> 0.716 ms per bs=1 iteration, 1.26 -> 1.19 at bs=8.  MCVC_UPD_CB25=16 for the A/B)
+            static const int cb25 = [] { const char* e = getenv("MCVC_UPD_CB25"); return e ? atoi(e) : 32; }();
+            if (o.taps == 25) { cb = cb25 == 16 ? 16 : 32; ib = 16; }
             else if (o.taps == 3) ib = 64;
             else if (o.taps == 1) ib = 128;
             else if (o.taps > 25) ib = 16;

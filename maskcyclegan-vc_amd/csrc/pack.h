@@ -62,6 +62,6 @@ struct UpdOwner {
 };
 struct UpdAdam { long long d_g, d_g2, d_m, d_v; int has_g2, zero; AdamCoef c; };     // d_*: float offsets from a parameter to its gradient(s) / moments
 constexpr int kUpdPitchPad = 4;
-constexpr size_t kUpdLds = 40 * 1024;
+constexpr size_t kUpdLds = 52 * 1024;
 int mcvc_update_net_launch(const UpdOwner* d_owners, int nown, int nblocks, const PackJob* d_jobs, const PackDgradArgs* d_dga, const PackPtrs& ptrs,
                            float* packed, const UpdAdam& ad, double bytes, hipStream_t s);
