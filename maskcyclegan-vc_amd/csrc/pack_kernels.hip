@@ -271,28 +271,45 @@ __global__ void __launch_bounds__(256) update_net_kernel(const Twin<UpdNetKArgs>
     // ---- Adam on the tile; the new weights stay in LDS
     if (o.vec4) {
         const int run4 = run >> 2, total4 = t.nc * run4;
-        for (int q = threadIdx.x; q < total4; q += 256) {
-            const int cc = q / run4, r4 = q - cc * run4;
-            const long long off = base + cc * row_stride + 4 * r4;
-            float4 pp = *reinterpret_cast<const float4*>(p + off);
-            float4 gg = *reinterpret_cast<const float4*>(g + off);
-            if (g2) { const float4 h = *reinterpret_cast<const float4*>(g2 + off); gg.x += h.x; gg.y += h.y; gg.z += h.z; gg.w += h.w; }
-            if (ad.zero) {
-                *reinterpret_cast<float4*>(g + off) = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (g2) *reinterpret_cast<float4*>(g2 + off) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            float4 mm = *reinterpret_cast<const float4*>(m + off);
-            float4 vv = *reinterpret_cast<const float4*>(v + off);
-            float* pf = reinterpret_cast<float*>(&pp);
-            float* gf = reinterpret_cast<float*>(&gg);
-            float* mf = reinterpret_cast<float*>(&mm);
-            float* vf = reinterpret_cast<float*>(&vv);
+        // two float4 per thread and round: all ten loads of a round are in flight before the first is used (the tile is one DRAM latency
+        // deep otherwise: a thread of a 32 x 16 x 25 tile walks 12 dependent load -> compute -> store rounds)
+        constexpr int U = 2;
+        for (int q0 = threadIdx.x; q0 < total4; q0 += U * 256) {
+            float4 pp[U], gg[U], hh[U], mm[U], vv[U];
+            long long off[U]; int ldo[U]; bool ok[U];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) adam_elem(pf[k], gf[k], mf[k], vf[k], c);
-            *reinterpret_cast<float4*>(p + off) = pp;
-            *reinterpret_cast<float4*>(m + off) = mm;
-            *reinterpret_cast<float4*>(v + off) = vv;
-            *reinterpret_cast<float4*>(lds + cc * t.pitch + 4 * r4) = pp;
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + u * 256;
+                ok[u] = q < total4;
+                const int qq = ok[u] ? q : 0;
+                const int cc = qq / run4, r4 = qq - cc * run4;
+                off[u] = base + cc * row_stride + 4 * r4;
+                ldo[u] = cc * t.pitch + 4 * r4;
+                pp[u] = *reinterpret_cast<const float4*>(p + off[u]);
+                gg[u] = *reinterpret_cast<const float4*>(g + off[u]);
+                hh[u] = g2 ? *reinterpret_cast<const float4*>(g2 + off[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+                mm[u] = *reinterpret_cast<const float4*>(m + off[u]);
+                vv[u] = *reinterpret_cast<const float4*>(v + off[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+                if (g2) { gg[u].x += hh[u].x; gg[u].y += hh[u].y; gg[u].z += hh[u].z; gg[u].w += hh[u].w; }
+                if (ad.zero) {
+                    *reinterpret_cast<float4*>(g + off[u]) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g2) *reinterpret_cast<float4*>(g2 + off[u]) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                float* pf = reinterpret_cast<float*>(&pp[u]);
+                float* gf = reinterpret_cast<float*>(&gg[u]);
+                float* mf = reinterpret_cast<float*>(&mm[u]);
+                float* vf = reinterpret_cast<float*>(&vv[u]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) adam_elem(pf[k], gf[k], mf[k], vf[k], c);
+                *reinterpret_cast<float4*>(p + off[u]) = pp[u];
+                *reinterpret_cast<float4*>(m + off[u]) = mm[u];
+                *reinterpret_cast<float4*>(v + off[u]) = vv[u];
+                *reinterpret_cast<float4*>(lds + ldo[u]) = pp[u];
+            }
         }
     } else {
         const int total = t.nc * run;
