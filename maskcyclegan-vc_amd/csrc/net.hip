@@ -915,7 +915,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
                 ga.a = ex.wm2; ga.a_xi = NTp * c.Cout; ga.lda = c.Cout;
                 ga.b = ex.wv2; ga.b_xi = NTp * c.Cin; ga.ldb = c.Cin;
                 ga.c = ex.wu; ga.c_xi = (long long)c.Cout * c.Cin; ga.ldc = c.Cin;
-                ga.M = c.Cout; ga.N = c.Cin; ga.K = (int)NTp; ga.nxi = 64;
+                ga.M = c.Cout; ga.N = c.Cin; ga.K = (int)((NT + 15) & ~15LL);      /* (rows [NT, NTp) of the tile-major operands are zeros: contract over the 16-row stages that hold tiles -- 80 instead of 96 at one sample) */ ga.nxi = 64;
                 ex.fail(mcvc_wino_gemm_launch(ga, ws));
                 ex.fail(mcvc_wino4_dw_launch(ex.wu, grads[c.wi[0]], c.Cout, c.Cin, ws));
             }
@@ -945,7 +945,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
                 ga.a = ex.wm2; ga.a_xi = NTp * c.Cout; ga.lda = c.Cout;          // dMt[xi][tile][co]
                 ga.b = ex.wv2; ga.b_xi = NTp * c.Cin; ga.ldb = c.Cin;            // Vt[xi][tile][ci]
                 ga.c = ex.wu; ga.c_xi = (long long)c.Cout * c.Cin; ga.ldc = c.Cin;
-                ga.M = c.Cout; ga.N = c.Cin; ga.K = (int)NTp;
+                ga.M = c.Cout; ga.N = c.Cin; ga.K = (int)((NT + 15) & ~15LL);      /* (rows [NT, NTp) of the tile-major operands are zeros: contract over the 16-row stages that hold tiles -- 80 instead of 96 at one sample) */
                 ex.fail(mcvc_wino_gemm_launch(ga, ws));
                 ex.fail(mcvc_wino_dw_launch(ex.wu, grads[c.wi[0]], c.Cout, c.Cin, ws));      // dW += G^T dU G: the chunks add up
             }
@@ -975,7 +975,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
                 ga.a = ex.wm2; ga.a_xi = NTp * M; ga.lda = M;
                 ga.b = ex.wv2; ga.b_xi = NTp * K4; ga.ldb = K4;
                 ga.c = ex.wu; ga.c_xi = (long long)M * K4; ga.ldc = K4;
-                ga.M = M; ga.N = K4; ga.K = (int)NTp; ga.nxi = 36;
+                ga.M = M; ga.N = K4; ga.K = (int)((NT + 15) & ~15LL);      /* (rows [NT, NTp) of the tile-major operands are zeros: contract over the 16-row stages that hold tiles -- 80 instead of 96 at one sample) */ ga.nxi = 36;
                 ex.fail(mcvc_wino_gemm_launch(ga, ws));
                 ex.fail(mcvc_wino43_dw_launch(ex.wu, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.nbr, c.Cin, ws));
             }
@@ -1007,7 +1007,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
                 ga.a = ex.wm2; ga.a_xi = NTp * M; ga.lda = M;
                 ga.b = ex.wv2; ga.b_xi = NTp * K4; ga.ldb = K4;
                 ga.c = ex.wu; ga.c_xi = (long long)M * K4; ga.ldc = K4;
-                ga.M = M; ga.N = K4; ga.K = (int)NTp; ga.nxi = 16;
+                ga.M = M; ga.N = K4; ga.K = (int)((NT + 15) & ~15LL);      /* (rows [NT, NTp) of the tile-major operands are zeros: contract over the 16-row stages that hold tiles -- 80 instead of 96 at one sample) */ ga.nxi = 16;
                 ex.fail(mcvc_wino_gemm_launch(ga, ws));
                 ex.fail(mcvc_wino3_dw_launch(ex.wu, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.nbr, c.Cin, ws));
             }
