@@ -91,7 +91,8 @@ int mcvc_gen_pack_small_batch(const float* const* params, float* packed, int max
  * backward pass on this buffer returns MCVC_ERR_INVALID until sets = 2 has run (the trainer's discriminator phase needs the updated
  * generators forward-only; the rest of the refresh runs beside it).                                    */
 int mcvc_gen_pack_sets(const float* const* params, float* packed, int max_batch, int T, int sets, void* stream);
-/* ... and restricted to parameter ranges (range_mask bit 0: parameters [100,110), bit 1: [24,100), bit 2: [0,24); 7 = all): the ranges
+/* ... and restricted to parameter ranges (range_mask bit 0: parameters [100,110), bit 1: [24,100), bit 2: [0,24); 7 = all; r4: bits 3 / 4 / 5
+ * = [12,24) / [4,12) / [0,4), the head in three parts -- see MCVC_BWD_FINE_MILESTONES): the ranges
  * whose gradients mcvc_gen_backward_overlap reports final one after the other, so that a range's optimizer step + re-pack can run beside the
  * rest of the backward pass.                                                                              */
 int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batch, int T, int sets, int range_mask, void* stream);
@@ -140,6 +141,11 @@ int mcvc_debug_trunk_fault_inject(int on);
  *      has drained (the next pass uses other buffers), (iii) a later pass on that aux_stream joins (flags = 0) before the gradients are read.
  *      The trainer runs the cycle pass's backward this way: the translation pass's data-gradient chain starts ~0.2 ms earlier.       */
 #define MCVC_BWD_NO_JOIN 1
+/*      flags & MCVC_BWD_FINE_MILESTONES (r4): `milestones` holds FOUR events; [2] is recorded when the gradients of parameters [12,24)
+ *      (downSample2, conv2dto1d) are final, [3] when those of [4,12) (downSample1) are: the head of the network in the order a backward pass
+ *      finishes it, so that the optimizer step of all but conv1 (mcvc_gen_update_ranges, range_mask bits 8 / 16 / 32 = [12,24) / [4,12) /
+ *      [0,4); bit 4 = their union, not to be combined with them) runs beside the rest of the pass instead of behind it.                */
+#define MCVC_BWD_FINE_MILESTONES 2
 int mcvc_gen_backward_flags(const float* const* params, const float* packed, float* const* grads, const float* mask,
                             const float* dout, float* dx, int accumulate_dx, const float* stash,
                             float* scratch, long long scratch_floats, int B, int T, void* stream, void* aux_stream,

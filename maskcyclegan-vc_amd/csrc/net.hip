@@ -44,6 +44,7 @@ struct Exec {
     hipStream_t s;
     bool dry;
     int err;
+    bool fine_ms = false;          // generator backward: four milestones (flags & MCVC_BWD_FINE_MILESTONES), see gen_backward_impl
     float* slabs;
     long long slab_cap;
     long long slab_need;
@@ -1927,6 +1928,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         conv_wgrad(ex, g.ds2, G, B, 40, W2, CView{st + o.y2, 256LL * 40 * W2, 40LL * W2, W2}, dyv);
         conv_dgrad(ex, g.ds2, packed, B, 40, W2, dyv, View{GA, 256LL * 40 * W2, 40LL * W2, W2}, (long long)B * 256 * 40 * W2, 0, 1, &ns);
     }
+    if (milestones && ex.fine_ms) record_milestone(ex, milestones[2]);          // parameters [12,24) (downSample2, conv2dto1d) are done
     // ---- downSample1 (:245)
     GB = nextGB();
     norm_bwd(ex, st + o.c2, 512LL * 40 * W2, 40LL * W2, normp(P, G, 6, 7, 10, 11), st + o.s2, GA, 256LL * 40 * W2, 40LL * W2, W2,
@@ -1936,6 +1938,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
         conv_wgrad(ex, g.ds1, G, B, 80, T, CView{st + o.y1, 128LL * 80 * T, 80LL * T, T}, dyv);
         conv_dgrad(ex, g.ds1, packed, B, 80, T, dyv, View{GA, 128LL * 80 * T, 80LL * T, T}, (long long)B * 128 * 80 * T, 0, 1, &ns);
     }
+    if (milestones && ex.fine_ms) record_milestone(ex, milestones[3]);          // parameters [4,12) (downSample1) are done
     // ---- conv1 gated GLU (:242)
     GB = nextGB();
     act_bwd(ex, st + o.c1, GA, (long long)B * 128 * 80 * T, ns, GB, B, 128, 80 * T, ACT_GLU);
@@ -2374,12 +2377,21 @@ static GenPackCfg gen_pack_cfg(int max_batch, int T)
     q.skipped = (q.fused ? (q.wino_only ? 3 : 1) : 0) | (q.w4 ? 0 : 16) | (q.w43 ? 0 : 32);
     return q;
 }
+// range_mask bits: 1 = parameters [100,110), 2 = [24,100), 4 = [0,24); r4: the head in three parts, in the order their gradients become final
+// during a backward pass (MCVC_BWD_FINE_MILESTONES): 8 = [12,24) (downSample2, conv2dto1d), 16 = [4,12) (downSample1), 32 = [0,4) (conv1)
+static bool gen_range_mask_ok(int m) { return m >= 1 && m <= 63 && !((m & 4) && (m & 56)); }
+static bool gen_in_range(int m, int p)
+{
+    return ((m & 1) && p >= 100 && p < 110) || ((m & 2) && p >= 24 && p < 100) || ((m & 4) && p < 24) ||
+           ((m & 8) && p >= 12 && p < 24) || ((m & 16) && p >= 4 && p < 12) || ((m & 32) && p < 4);
+}
 static void gen_pack_build(PackTable& pt, const GenPackCfg& q, int sets, int range_mask)
 {
     const GenNet& g = gen_net();
-    if (range_mask & 4) {
-        const ConvSpec* head[] = {&g.conv1, &g.ds1, &g.ds2};
-        for (const ConvSpec* c : head) add_spec_jobs(pt, *c, false, q.wino_only, sets, q.w4, q.w43);
+    if (range_mask & (4 | 32)) add_spec_jobs(pt, g.conv1, false, q.wino_only, sets, q.w4, q.w43);
+    if (range_mask & (4 | 16)) add_spec_jobs(pt, g.ds1, false, q.wino_only, sets, q.w4, q.w43);
+    if (range_mask & (4 | 8)) {
+        add_spec_jobs(pt, g.ds2, false, q.wino_only, sets, q.w4, q.w43);
         add_spec_jobs(pt, g.c2d1d, q.fused, false, sets);
     }
     if (range_mask & 1) {
@@ -2394,12 +2406,12 @@ static void gen_pack_build(PackTable& pt, const GenPackCfg& q, int sets, int ran
 }
 static int gen_pack_key(const GenPackCfg& q, int sets, int range_mask)
 {
-    return 16 + 4 * sets + (q.fused ? (q.wino_only ? 3 : 2) : 0) + 64 * range_mask + (q.w4 ? 1024 : 0) + (q.w43 ? 2048 : 0) + (q.up1_w4 ? 4096 : 0);
+    return 16 + 4 * sets + (q.fused ? (q.wino_only ? 3 : 2) : 0) + 64 * range_mask /* <= 63 */ + (q.w4 ? 4096 : 0) + (q.w43 ? 8192 : 0) + (q.up1_w4 ? 16384 : 0);
 }
 
 int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batch, int T, int sets, int range_mask, void* stream)
 {
-    if (sets < 1 || sets > 3 || range_mask < 1 || range_mask > 7) return MCVC_ERR_INVALID;
+    if (sets < 1 || sets > 3 || !gen_range_mask_ok(range_mask)) return MCVC_ERR_INVALID;
     const GenPackCfg q = gen_pack_cfg(max_batch, T);
     int err = 0;
     const DevPackTable* t = dev_pack_table(gen_pack_key(q, sets, range_mask), [&](PackTable& pt) { gen_pack_build(pt, q, sets, range_mask); }, &err);
@@ -2419,10 +2431,10 @@ int mcvc_gen_update_ranges(const float* const* params, const long long* numel, f
                            const float* flat, float* grad, float* grad2, float* exp_avg, float* exp_avg_sq, float lr, float beta1, float beta2,
                            float eps, int step, float grad_scale, int zero_grads, void* stream)
 {
-    if (!params || !numel || !packed || range_mask < 1 || range_mask > 7) return MCVC_ERR_INVALID;
+    if (!params || !numel || !packed || !gen_range_mask_ok(range_mask)) return MCVC_ERR_INVALID;
     const GenPackCfg q = gen_pack_cfg(max_batch, T);
     int err = MCVC_ERR_INVALID;
-    auto in_range = [range_mask](int p) { return ((range_mask & 1) && p >= 100 && p < 110) || ((range_mask & 2) && p >= 24 && p < 100) || ((range_mask & 4) && p < 24); };
+    auto in_range = [range_mask](int p) { return gen_in_range(range_mask, p); };
     const DevUpdTable* t = dev_upd_table(gen_pack_key(q, 3, range_mask), [&](PackTable& pt) { gen_pack_build(pt, q, 3, range_mask); }, numel, MCVC_GEN_NPARAMS,
                                          in_range, &err);
     if (!t) return err;
@@ -2581,6 +2593,7 @@ int mcvc_gen_backward_window(const float* const* params, const float* packed, fl
     ex.pack_skips = get_pack_skips(packed);
     if (ex.pack_skips & 4) return MCVC_ERR_INVALID;          // forward-only re-pack: the backward sets are stale (mcvc_gen_pack_sets)
     ex.no_join = (flags & 1) && aux_stream;
+    ex.fine_ms = (flags & 2) != 0;
     gen_backward_impl(ex, params, packed, grads, mask, dout, dx, accumulate_dx, stash, scratch, d, milestones, stash_B, stash_b0);
     return ex.err;
 }

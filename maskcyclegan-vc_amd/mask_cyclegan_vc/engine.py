@@ -262,16 +262,19 @@ class TrainEngine:
         self.overlap_g_reduce = self.reducer.world > 1 and dev.type == "cuda"
         self._ms = {}
         for n in G_NAMES:
-            evs = [torch.cuda.Event() for _ in range(2)]
+            evs = [torch.cuda.Event() for _ in range(4)]        # ([2], [3]: the head's finer milestones, MCVC_BWD_FINE_MILESTONES)
             for e in evs:
                 e.record()                                  # forces creation of the underlying hipEvent_t
-            self._ms[n] = (evs, (ctypes.c_void_p * 2)(*[e.cuda_event for e in evs]))
+            self._ms[n] = (evs, (ctypes.c_void_p * 4)(*[e.cuda_event for e in evs]))
         # flat-buffer ranges [lo, hi) of parameters [100,110), [24,100), [0,24) of each generator
         self._g_ranges = {}
+        self._g_ranges5 = {}
         base = self.g_group.grad.data_ptr()
         for n, gv in zip(G_NAMES, self.g_group.grad_views):
             off = [(g.data_ptr() - base) // 4 for g in gv] + [(gv[-1].data_ptr() - base) // 4 + _align4(gv[-1].numel())]
             self._g_ranges[n] = [(off[100], off[110]), (off[24], off[100]), (off[0], off[24])]
+            # the ranged update's five parts (library range_mask bits 1, 2, 8, 16, 32), in the order a backward pass finishes them
+            self._g_ranges5[n] = [(off[100], off[110]), (off[24], off[100]), (off[12], off[24]), (off[4], off[12]), (off[0], off[4])]
         self._workspaces = {}
         self._max_B = batch_size
         self._use(batch_size)
@@ -551,7 +554,7 @@ class TrainEngine:
                     nb, lane, bool(milestones), self.aux_wgrad, second, no_join, stash_nb, stash_b0),
                    lambda: check(self.L.mcvc_gen_backward_window(self._p_tab[name], ptr(self.packed[name]), gtab, ptr(mask), ptr(dout),
                                                                  ptr(dx), acc, ptr(stash), stash_nb or nb, stash_b0, ptr(sc), sc.numel(), nb, self.T,
-                                                                 stream(), aux, ms, 1 if no_join else 0), "gen_backward"))
+                                                                 stream(), aux, ms, (1 if no_join else 0) | (2 if milestones else 0)), "gen_backward"))
 
     def _D(self, name, x, out, stash, nb, lane=0):
         sc = self.d_scratch[lane]
@@ -899,23 +902,26 @@ class TrainEngine:
             self._twin(lambda: self._repack1(A2B, 1), lambda: self._repack1(B2A, 1))
 
         def update_range(k, last):
-            """Adam + forward re-pack of parameter range k of both generators (0: up-sampling blocks + last conv, 1: residual trunk,
-            2: the head) as grouped launches.  Ranges 0 / 1 wait for the backward pass's milestone event: their gradients are final while
-            the pass is still running (mcvc_gen_backward_overlap)."""
+            """Optimizer step (+ re-pack) of part k of both generators as grouped launches: 0 = up-sampling blocks + last conv, 1 = residual
+            trunk, 2 = downSample2 + conv2dto1d, 3 = downSample1, 4 = conv1 -- the order in which a backward pass finishes them.  Parts 0-3
+            wait for the pass's milestone events: their gradients are final while the pass is still running, so only conv1's (0.01 % of the
+            parameters) is left behind the pass (r4: the head used to be ONE part of 150 us at the end of the critical chain)."""
+            mask = (1, 2, 8, 16, 32)[k]        # library range_mask of part k: [100,110), [24,100), [12,24), [4,12), [0,4)
+
             def run(ln):
-                if k < 2:
+                if k < 4:
                     torch.cuda.current_stream(self.device).wait_event(self._ms[A2B][0][k])
                 if k == 0:
                     self.g_group.step += 1
                 step = self.g_group.step
-                (a0, a1), (b0, b1) = self._g_ranges[A2B][k], self._g_ranges[B2A][k]
+                (a0, a1), (b0, b1) = self._g_ranges5[A2B][k], self._g_ranges5[B2A][k]
                 if self.fused_update:
-                    self._twin(lambda: self._update_gen(A2B, 1 << k, g_lr, step, second=ident_second),
-                               lambda: self._update_gen(B2A, 1 << k, g_lr, step, second=ident_second))
+                    self._twin(lambda: self._update_gen(A2B, mask, g_lr, step, second=ident_second),
+                               lambda: self._update_gen(B2A, mask, g_lr, step, second=ident_second))
                 else:
                     self._twin(lambda: self._adam_range(self.g_group, a0, a1, g_lr, step, second=ident_second),
                                lambda: self._adam_range(self.g_group, b0, b1, g_lr, step, second=ident_second))
-                    self._twin(lambda: self._repack1(A2B, 1, 1 << k), lambda: self._repack1(B2A, 1, 1 << k))
+                    self._twin(lambda: self._repack1(A2B, 1, mask), lambda: self._repack1(B2A, 1, mask))
                 if last:
                     for n in G_NAMES:
                         self.nets[n]._packed_version = None
@@ -1175,7 +1181,8 @@ class TrainEngine:
             # identity chain "i" and D-phase(t)'s generator forwards "cyc"); only the head's is left for the end of the chain
             # (lane 1, idle since "dupd2" -- lane 3's stream carries the backward rounds' weight gradients)
             tasks += [(1, g["update_range"](0, False), upd_waits + ("cyc",), None), (1, g["update_range"](1, False), (), "u01"),
-                      (0, g["update_range"](2, True), upd_waits + ("cyc",), None)]
+                      (1, g["update_range"](2, False), (), None), (1, g["update_range"](3, False), (), None),
+                      (0, g["update_range"](4, True), upd_waits + ("cyc",), None)]
         else:
             tasks += [(0, g["update"], upd_waits + ("cyc",), None)]
         self._run_tasks(tasks)
@@ -1337,7 +1344,8 @@ class TrainEngine:
         if ov:
             tasks += [(3, g["queue_reduce"], (), None)]
         if ranged:
-            tasks += [(1, g["update_range"](0, False), uw, None), (1, g["update_range"](1, False), (), "u01"), (0, g["update_range"](2, True), uw, None)]
+            tasks += [(1, g["update_range"](0, False), uw, None), (1, g["update_range"](1, False), (), "u01"),
+                      (1, g["update_range"](2, False), (), None), (1, g["update_range"](3, False), (), None), (0, g["update_range"](4, True), uw, None)]
         else:
             tasks += [(0, g["update"], uw, None)]
         self._run_tasks(tasks)
