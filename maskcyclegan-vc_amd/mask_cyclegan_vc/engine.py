@@ -269,6 +269,7 @@ class TrainEngine:
         # flat-buffer ranges [lo, hi) of parameters [100,110), [24,100), [0,24) of each generator
         self._g_ranges = {}
         self._g_ranges5 = {}
+        self.fine_update = os.environ.get("MCVC_FINE_UPDATE", "1") != "0"
         base = self.g_group.grad.data_ptr()
         for n, gv in zip(G_NAMES, self.g_group.grad_views):
             off = [(g.data_ptr() - base) // 4 for g in gv] + [(gv[-1].data_ptr() - base) // 4 + _align4(gv[-1].numel())]
@@ -907,14 +908,19 @@ class TrainEngine:
             wait for the pass's milestone events: their gradients are final while the pass is still running, so only conv1's (0.01 % of the
             parameters) is left behind the pass (r4: the head used to be ONE part of 150 us at the end of the critical chain)."""
             mask = (1, 2, 8, 16, 32)[k]        # library range_mask of part k: [100,110), [24,100), [12,24), [4,12), [0,4)
+            fine = self.fine_update            # (MCVC_FINE_UPDATE=0: the head as ONE part behind the pass -- the A/B of the finer milestones)
+            if not fine and k == 4:
+                mask = 4
 
             def run(ln):
+                if not fine and k in (2, 3):
+                    return
                 if k < 4:
                     torch.cuda.current_stream(self.device).wait_event(self._ms[A2B][0][k])
                 if k == 0:
                     self.g_group.step += 1
                 step = self.g_group.step
-                (a0, a1), (b0, b1) = self._g_ranges5[A2B][k], self._g_ranges5[B2A][k]
+                (a0, a1), (b0, b1) = (self._g_ranges5[A2B][k], self._g_ranges5[B2A][k]) if fine or k < 2 else (self._g_ranges[A2B][2], self._g_ranges[B2A][2])
                 if self.fused_update:
                     self._twin(lambda: self._update_gen(A2B, mask, g_lr, step, second=ident_second),
                                lambda: self._update_gen(B2A, mask, g_lr, step, second=ident_second))
