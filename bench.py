@@ -96,6 +96,22 @@ def pmc_traffic(kernel, B):
     return None, None
 
 
+def pmc_bytes_per_step(B):
+    """(HBM bytes per training step from the PMC passes, bytes per kernel family, source): the sum over kernel INSTANCES of the bytes of
+    their dispatches in the profiled iterations (tools/pmc_traffic.py `hbm_bytes_per_step_pmc`; FETCH_SIZE x 2 + WRITE_SIZE, two separate
+    passes).  Like `roofline.traffic` a labelled constant of the named revision -- the counters cannot be read inside the bench."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic_bs%d.json" % B)), reverse=True):
+        try:
+            with open(path) as fh:
+                js = json.load(fh)
+            if "hbm_bytes_per_step_pmc" in js:
+                return js["hbm_bytes_per_step_pmc"], js.get("family_hbm_bytes_per_step"), "profiles/%s@%s" % (os.path.basename(path), js.get("git_rev", "?"))
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None, None
+
+
 def trace_one_step(engine, batches):
     """Per-launch HIP-event trace of ONE iteration of the schedule that was timed, submitted in order on one stream (kernels do not
     overlap, so every launch's duration is its own).  With the pipelined step an iteration's worth of work is the discriminator phase of
@@ -267,6 +283,10 @@ def parse_args():
     ap.add_argument("--cpu-iters", type=int, default=-1, help="timed CPU-baseline iterations (0 = skip; default: about 10-30 s of CPU work)")
     ap.add_argument("--no-trace", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="default single-GPU run: skip the nested records of BASELINE configs[2..4]")
+    ap.add_argument("--sync-losses", action="store_true", help="read the CURRENT iteration's g_loss and d_loss on the host every step, as the "
+                    "reference's .item() calls do (train.py:302-304): completes the iteration before the next one is issued (no pipelining)")
+    ap.add_argument("--allow-degraded", action="store_true", help="--gpus N: do not fail when the ranks did not all take part in the collective or the "
+                    "persistent trunk kernels fell back to per-layer launches (single-GPU choreography tests over gloo)")
     ap.add_argument("--serial", action="store_true", help="one stream: no lanes, no auxiliary weight-gradient stream (A/B comparison, per-kernel profiling)")
     ap.add_argument("--graphs", action="store_true", help="replay HIP graphs of the two phases (experimental; not faster on ROCm 7.2)")
     ap.add_argument("--no-pass-graphs", action="store_true", help="launch every network pass eagerly instead of replaying its HIP graph (A/B)")
@@ -327,11 +347,13 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
     log("timing %d steps" % steps)
     reducer.time_waits = world > 1         # exposed (un-hidden) gradient-exchange time: an event pair around every wait for the communication stream
     t0 = time.perf_counter()
+    sync_losses = bool(getattr(args, "sync_losses", False))
     for i in range(steps):
         engine.step(*batches[(warmup + i) % len(batches)])
         # the reference reads both losses every iteration (train.py:303).  So do we; with the pipelined step they are the losses of the
-        # last COMPLETE iteration (the previous one: its discriminator phase runs beside this iteration's generator phase)
-        engine.losses(lagged=True)
+        # last COMPLETE iteration (the previous one: its discriminator phase runs beside this iteration's generator phase).
+        # --sync-losses: the reference-exact readback -- THIS iteration's pair, which completes the iteration first
+        engine.losses(lagged=not sync_losses)
     engine.flush()                         # ... and the last one to the timed region: exactly K complete iterations
     if world > 1:
         dist.barrier()
@@ -361,7 +383,17 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
                     i, k, ms, fl / 1e9, by / 1e6, fl / 1e9 / max(ms, 1e-6), by / 1e6 / max(ms, 1e-6)))
     schedule = {"grouped_launches": bool(engine._use_grouped()), "pipelined": bool(engine._use_pipeline()), "merged_forwards": bool(engine._use_merged()),
                 "queue_probe": getattr(engine, "queue_probe", None),
-                "loss_readback": "both losses every iteration; with the pipelined step those of the last complete iteration (one step behind)"}
+                "loss_readback": ("both losses of the CURRENT iteration every step (reference-exact, train.py:302-304): the pipelined overlap of "
+                                  "iteration t's discriminator phase with iteration t+1's generator phase is given up") if sync_losses else
+                                 "both losses every iteration; with the pipelined step those of the last complete iteration (one step behind)",
+                "trunk_persistent": engine.L.mcvc_gen_trunk_persistent(B, T) if engine._use_grouped() else None,
+                "trunk_fallback": bool(engine.trunk_fallback)}
+    # what the persistent trunk kernels would do with ONE pass in flight: tells "this shape has no persistent kernel" from "the residency
+    # bound of this schedule switched them off" (the silent degradation a multi-GPU line must not hide)
+    engine.L.mcvc_set_trunk_passes_in_flight(1)
+    schedule["trunk_persistent_possible"] = engine.L.mcvc_gen_trunk_persistent(B, T) if engine._use_grouped() else None
+    engine._resid = None
+    engine._set_residency()
     del engine, nets
     torch.cuda.empty_cache()
     if rank != 0:
@@ -410,8 +442,20 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
         roof_ms = sum(max(fl / (PEAK_FP32_MFMA_TFLOPS * 1e12), by / (PEAK_HBM_GBS * 1e9)) for _k, _ms, fl, by in raw) * 1e3
         res["conv_roofline_ms"] = round(roof_ms, 4)
         res["frac_of_conv_roofline"] = roof_ms / ms
-        res["hbm_bytes_per_step"] = sum(by for _k, _ms, _fl, by in raw)           # launcher-counted
-        res["algorithmic_bytes_per_step"] = ALG_BYTES_PER_ITER.get(B)            # SURVEY 8(d) lower bound incl. Adam (None: not tabulated)
+        # two byte counts, named for what they are: what the LAUNCHERS count for the kernels of the traced step (operands + results as the
+        # host code knows them: live), and what the HBM counters saw (PMC passes of the named revision, per kernel instance: a constant)
+        res["hbm_bytes_per_step_launcher"] = sum(by for _k, _ms, _fl, by in raw)
+        pmc_b, pmc_fam, pmc_src = pmc_bytes_per_step(B)
+        res["hbm_bytes_per_step_pmc"] = pmc_b
+        res["hbm_bytes_per_step_pmc_source"] = pmc_src
+        alg_b = ALG_BYTES_PER_ITER.get(B)
+        res["algorithmic_bytes_per_step"] = alg_b                                # SURVEY 8(d) lower bound incl. Adam (None: not tabulated)
+        if alg_b:
+            res["hbm_bytes_ratio_to_algorithmic"] = {"launcher": res["hbm_bytes_per_step_launcher"] / alg_b,
+                                                     "pmc": (pmc_b / alg_b) if pmc_b else None}
+        if pmc_fam:
+            launcher_fam = {r["kernel"]: r["mbytes"] * 1e6 for r in rows}
+            res["hbm_bytes_per_step_by_family"] = {k: {"pmc": round(v), "launcher": round(launcher_fam.get(k, 0.0))} for k, v in list(pmc_fam.items())[:12]}
         res["serial_kernel_ms_per_step"] = round(total_ms, 4)
     log("trace done")
     if world == 1 and cpu_iters > 0:
@@ -462,13 +506,36 @@ def main():
             extra.append(rec)
             if res is not None:
                 res["configs"] = [r for r in extra if r is not None]
+        # the price of the reference-exact loss readback, driver-observed: the same config once more, short, with
+        # the CURRENT iteration's losses read every step
+        if world == 1 and B == 1 and T == 64 and not args.no_extra_configs and not (args.serial or args.graphs or args.sync_losses):
+            sub = argparse.Namespace(**dict(vars(args), dump_trace=None, no_trace=True, sync_losses=True))
+            rec = train_record(sub, rank, world, device, 1, 64, 30, 5, 0, 16, config_id="sync-losses")
+            if res is not None and rec is not None:
+                res["schedule"]["sync_losses_ms_per_step"] = rec["ms_per_step"]
+                res["schedule"]["sync_losses_cost"] = rec["ms_per_step"] / res["ms_per_step"] - 1.0
     info = dist_info(world, device)
+    degraded = []
+    if world > 1 and args.mode == "train":
+        if info["rccl_ranks_seen"] != world:
+            degraded.append("collective saw %d of %d ranks" % (info["rccl_ranks_seen"], world))
+        sc = (res or {}).get("schedule", {}) if rank == 0 else {}
+        if sc.get("trunk_fallback") or (sc.get("trunk_persistent_possible") and not sc.get("trunk_persistent")):
+            degraded.append("persistent trunk kernels fell back to per-layer launches on the ranks (residency bound or fault)")
     if rank == 0 and res is not None:
         res["dist"] = info
+        if degraded:
+            res["degraded"] = degraded
         print(json.dumps(res))
     if world > 1:
+        flag = torch.tensor([1.0 if degraded else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         dist.barrier()
         dist.destroy_process_group()
+        if float(flag.item()) > 0 and not args.allow_degraded:
+            # a SCALE line must not be quietly degraded: the line above says what happened, the exit code makes the run fail
+            log("DEGRADED multi-GPU run: %s" % "; ".join(degraded))
+            sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -26,7 +26,8 @@ static inline int round_up_i(int a, int b) { return cdiv_i(a, b) * b; }
 // convolution of dY with re-packed weights).  Implicit GEMM on v_mfma_f32_32x32x2_f32:
 //   M = output channel (co), N = output pixel, K = (input channel, kh, kw).
 // The input patch of a pixel tile is staged ONCE in LDS per channel chunk and every tap reads a
-// shifted window of it -- no im2col buffer exists anywhere.
+// shifted window of it -- this kernel reads no im2col buffer (the staged GEMMs of sgemm_kernels.hip are the one
+// place in the library where tap planes / transposed operands are materialised: DESIGN.md section 4).
 // ------------------------------------------------------------------------------------------------
 enum ConvOutMode { CONV_OUT_SLAB = 0, CONV_OUT_ACCUM = 1 };
 

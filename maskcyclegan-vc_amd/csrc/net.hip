@@ -1252,6 +1252,8 @@ static const DevUpdTable* dev_upd_table(int kind, Build&& build, const long long
             const PackJob& j0 = mine[0];
             o.Cout = j0.Cout; o.Cin = j0.Cin; o.taps = j0.taps;
             for (const PackJob& j : mine) if (j.kind == PACK_COPY || j.Cout != o.Cout || j.Cin != o.Cin || j.taps != o.taps) { *err = MCVC_ERR_INVALID; return nullptr; }
+            // (the Winograd weight transforms read ONE 5 x 5 filter = 25 consecutive LDS words: upd_emit_filters)
+            for (const PackJob& j : mine) if (j.kind >= PACK_WINO_F && j.kind <= PACK_WINO43_F && j.taps != 25) { *err = MCVC_ERR_INVALID; return nullptr; }
             if ((long long)o.Cout * o.Cin * o.taps != numel[prm]) { *err = MCVC_ERR_INVALID; return nullptr; }
             // tile: 32 x 16 filters of 25 taps (the Winograd layers: two filters per thread), 32 x 32 of 9, 32 x 64 of 3, 32 x 128 of 1;
             // the 5 x 15 edge layers (2 input channels / 1 output channel) as they come

@@ -415,10 +415,11 @@ class TrainEngine:
         D-phase's generator forwards beside the G-phase's = 4; a data-parallel rank leaves one pass's worth of compute units to RCCL's kernels.
         Re-evaluated whenever the schedule changes (the identity cut-off ends the merged schedule)."""
         if self._use_grouped():
-            inflight = 4 if (not self._use_merged() or (self.early_ident and self.reducer.world == 1)) else 2
+            inflight = 4 if ((not self._use_merged() and not self._serial_fwd()) or (self.early_ident and self.reducer.world == 1)) else 2
         else:
             inflight = 2
         inflight += 1 if self.reducer.world > 1 else 0
+        inflight = int(os.environ.get("MCVC_TEST_FORCE_RESIDENCY", inflight))     # (tests: force the residency bound to fail)
         self.L.mcvc_set_trunk_passes_in_flight(inflight)          # (process-wide in the library: re-stated every step, another engine may have changed it)
         if self._resid == (inflight, self.B):
             return
@@ -1154,10 +1155,12 @@ class TrainEngine:
         # experiment (MCVC_STAGGER): bit 0 = the translation forwards wait for the D-phase's generator forwards, bit 1 = the cycle forwards
         # for the D-phase's cycle forwards -- the D-phase chain is the critical one, the G-phase forwards have 0.7 ms of slack
         stagger = int(os.environ.get("MCVC_STAGGER", "0"))
+        serial = self._serial_fwd()            # (data-parallel ranks: one grouped persistent trunk pass in flight at a time)
         tasks = [
             (3, side_head, (), "rf"),          # (first: a backward pass refuses to run on a buffer whose backward copies are marked stale)
             (1, (lambda ln: (None if packed else d["repack_full"](ln), d["gen_fwd"](ln))), (), "gen"),
-            (0, g["fwd2"], ("gen",) if stagger & 1 else (), "g"),
+        ] + ([(1, d["cycles"], (), "cyc")] if serial else []) + [
+            (0, g["fwd2"], ("cyc",) if serial else (("gen",) if stagger & 1 else ()), "g"),
         ] + head
         if split:
             tasks += [(3, d["real1"], (), None), (3, d["real2"], (), "r2")]
@@ -1167,8 +1170,7 @@ class TrainEngine:
             tail = []
             tasks += [(2, g["ident_fwd"], (), None), (2, g["ident_bwd"], ("rf",), "i")]
             adv1_lane = 3 if ident_pos == "head3" else 2
-        tasks += [
-            (1, d["cycles"], (), "cyc"),
+        tasks += ([] if serial else [(1, d["cycles"], (), "cyc")]) + [
             (0, g["cycle"], ("cyc",) if stagger & 2 else (), None),
             (3, d["fake1"] if split else d["full1"], ("gen",), None),
             (3, d_update(("discriminator_A", "discriminator_B")), (), "dupd1"),
@@ -1205,6 +1207,14 @@ class TrainEngine:
     def _merged_ok(self, B):
         """Three samples per generator pass must stay inside the fused 1-D trunk kernels (csrc/trunk.h: 48 columns at 64 frames)."""
         return 3 * B * (self.T // 4) <= 48 and self.T % 4 == 0
+
+    def _serial_fwd(self):
+        """Data-parallel ranks on the separate-pass pipelined schedule (the merged schedule ends with the identity cut-off: 98 % of a default
+        run) order the G-phase's grouped forwards BEHIND the D-phase's generator forwards, so that ONE grouped persistent trunk pass is in
+        flight at a time, like on the merged schedule: 2 + 1 (RCCL's share) x 64 workgroups fit the 256 compute units, where the free-running
+        4 + 1 do not and every pass would fall back to per-layer trunk launches.  The D-phase chain is the critical one; the
+        G-phase forwards have ~0.7 ms of slack behind it (MCVC_STAGGER measurements)."""
+        return self.reducer.world > 1 and self._use_pipeline() and not self._use_merged()
 
     def _use_merged(self):
         # (after the identity cut-off the merged passes would carry a dead sample: the separate passes skip it)

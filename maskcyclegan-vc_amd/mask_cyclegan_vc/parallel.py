@@ -44,7 +44,7 @@ def init_from_env(backend=None):
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-            if torch.cuda.is_available() and _ranks_share_a_gpu(local_rank):
+            if torch.cuda.is_available() and _ranks_share_a_gpu(local_rank) and os.environ.get("MCVC_TEST_DISTINCT_GPUS") != "1":
                 # Ranks SHARING a GPU (the single-GPU choreography tests only): the persistent trunk kernels wait inside the kernel for
                 # workgroups that must all be resident (csrc/trunk.h) -- that holds for the passes one process keeps in flight, not for
                 # two processes' worth of them on one device.  Run the trunk as per-layer launches there.
@@ -56,15 +56,34 @@ def init_from_env(backend=None):
     return rank, world, local_rank
 
 
-def _ranks_share_a_gpu(local_rank):
-    """True when two ranks of the job run on the same physical device -- from the ACTUAL rank -> (host, device) map (an all-gather), not
-    from LOCAL_WORLD_SIZE, which a launcher other than torchrun may not set (a 16-rank / 2-node job would otherwise be mis-read as 16
-    ranks on 8 GPUs)."""
+def _device_identity(local_rank):
+    """(host, physical device) of this rank.  The LOGICAL index is not an identity: a launcher that hands every rank one GPU through
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES makes it 0 on all of them.  The device's UUID (or its PCI address) is."""
     import socket
     ndev = max(torch.cuda.device_count(), 1)
-    mine = (socket.gethostname(), local_rank % ndev)
+    idx = local_rank % ndev
+    ident = None
+    try:
+        props = torch.cuda.get_device_properties(idx)
+        uuid = getattr(props, "uuid", None)
+        if uuid is not None and str(uuid).strip("0-") != "":
+            ident = "uuid:%s" % uuid
+        elif hasattr(props, "pci_bus_id"):
+            ident = "pci:%s:%s:%s" % (getattr(props, "pci_domain_id", 0), props.pci_bus_id, getattr(props, "pci_device_id", 0))
+    except Exception:        # noqa: BLE001 -- an identity probe must never take the job down; fall back to the logical index
+        ident = None
+    if ident is None:
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES") or ""
+        ident = "idx:%s:%d" % (vis, idx)
+    return (socket.gethostname(), ident)
+
+
+def _ranks_share_a_gpu(local_rank):
+    """True when two ranks of the job run on the same physical device -- from the ACTUAL rank -> (host, device identity) map (an
+    all-gather), not from LOCAL_WORLD_SIZE, which a launcher other than torchrun may not set (a 16-rank / 2-node job would otherwise be
+    mis-read as 16 ranks on 8 GPUs), and not from the logical device index (see _device_identity)."""
     pairs = [None] * dist.get_world_size()
-    dist.all_gather_object(pairs, mine)
+    dist.all_gather_object(pairs, _device_identity(local_rank))
     return len(set(pairs)) < len(pairs)
 
 

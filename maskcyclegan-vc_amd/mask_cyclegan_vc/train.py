@@ -45,6 +45,12 @@ class MaskCycleGANVCTraining(object):
     def __init__(self, args):
         self.args = args
         self.rank, self.world, self.local_rank = init_from_env()
+        # control-plane collectives (the collective abort of train()'s fault probe) run over gloo on host tensors: they must not queue
+        # behind -- or synchronise with -- the device work of the step in flight
+        self._ctl_group = None
+        if self.world > 1:
+            import torch.distributed as dist
+            self._ctl_group = dist.new_group(backend="gloo")
         if not torch.cuda.is_available():
             raise RuntimeError("mask_cyclegan_vc.train (MI355X build) needs a HIP device; there is no CPU path")
         torch.cuda.set_device(self.local_rank)
@@ -164,12 +170,24 @@ class MaskCycleGANVCTraining(object):
 
             def log_one(lo):
                 # A persistent trunk launch that gave up waiting poisons its pass with NaN (csrc/trunk.h): that reaches every loss term of
-                # the iteration, so the (already host-resident) losses are the per-iteration fault probe.  Stop BEFORE another step or a
-                # checkpoint can carry the poisoned gradients into the weights on disk; check_faults() names the cause.
-                if not (np.isfinite(lo["g_loss"]) and np.isfinite(lo["d_loss"])):
-                    self.engine.check_faults()
-                    raise FloatingPointError("non-finite losses (g_loss=%r, d_loss=%r): aborting without saving; resume from the last "
-                                             "checkpoint with --continue_train" % (lo["g_loss"], lo["d_loss"]))
+                # the iteration, so the (already host-resident) losses are the per-iteration fault probe.  The losses are one step() behind
+                # (iteration t is checked after t + 1 has been issued), so the poisoned update may already be in the weights: what the
+                # abort guarantees is that no CHECKPOINT is written from them.  Data parallel: the losses are rank-local -- only the
+                # poisoned rank sees the NaN at once, the others one iteration later through the all-reduced gradients -- so the verdict is
+                # taken collectively (one integer over the gloo control group: no device work, no stream sync) and every rank leaves the
+                # loop in the same iteration instead of blocking in the next collective until a watchdog kills it.
+                bad = not (np.isfinite(lo["g_loss"]) and np.isfinite(lo["d_loss"]))
+                if self._ctl_group is not None:
+                    import torch.distributed as dist
+                    flag = torch.tensor([1 if bad else 0], dtype=torch.int32)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self._ctl_group)
+                    bad_any = bool(flag.item())
+                else:
+                    bad_any = bad
+                if bad_any:
+                    self.engine.check_faults(raise_on_fault=bad)          # (names the cause on the rank that faulted)
+                    raise FloatingPointError("non-finite losses on %s (g_loss=%r, d_loss=%r here): aborting without saving; resume from the "
+                                             "last checkpoint with --continue_train" % ("this rank" if bad else "another rank", lo["g_loss"], lo["d_loss"]))
                 self.logger.log_iter(loss_dict={"g_loss": lo["g_loss"], "d_loss": lo["d_loss"]})
                 self.logger.end_iter()
             for run_step in self._epoch_batches():

@@ -384,6 +384,14 @@ class StepOracle:
         return float(g_loss), float(d_loss)
 
 
+def sample_index(numel: int, k: int = 256) -> np.ndarray:
+    """Positions of the parameter samples committed with the multi-step train() fixtures (tests/golden/make_golden.py): up to ``k``
+    seeded positions per tensor, every element of a smaller tensor."""
+    if numel <= k:
+        return np.arange(numel)
+    return np.unique(np.random.RandomState(numel % 100003).randint(0, numel, k))
+
+
 def default_init_nets(seed: int = 0) -> Dict[str, Params]:
     """Six nets with torch's default init law drawn from ``torch.manual_seed(seed)`` in the reference's
     construction order (train.py:103-110).  Uses nn.Conv*/InstanceNorm reset laws via plain tensors:

@@ -67,6 +67,11 @@ def kink_free_seeds(eng, n, seed0, margin=3e-5):
     return keep
 
 
+N_IT = int(os.environ.get("MCVC_TEST_DDP_ITERS", "3"))
+# identity cut-off of part (2)'s schedule (train.py:314-315; global_step advances by world x batch per iteration): with a small value the
+# later iterations run the regime after the cut-off -- on data-parallel ranks the separate-pass pipelined schedule with its forwards ordered
+# one behind the other (engine._serial_fwd)
+STOP_ID = float(os.environ.get("MCVC_TEST_DDP_STOP_ID", "1e9"))
 PER_RANK = int(os.environ.get("MCVC_TEST_DDP_PER_RANK", "8"))          # BASELINE configs[3]: bs=8 per GPU (2: the grouped + pipelined schedule)
 
 
@@ -112,10 +117,11 @@ def main():
         del ref
     # ---- (2) ranks stay identical through full iterations (deferred D update, async all-reduce)
     del eng
-    eng2 = TrainEngine(nets_for(800), PER_RANK, 64, schedule=StepSchedule(batch_size=PER_RANK, n_samples=64, world_size=world),
+    eng2 = TrainEngine(nets_for(800), PER_RANK, 64, schedule=StepSchedule(batch_size=PER_RANK, n_samples=64, world_size=world, stop_identity_after=STOP_ID),
                        reducer=FlatGradReducer())
-    mean_losses, mine_losses = [], []
-    for it in range(3):
+    mean_losses, mine_losses, sched_seen = [], [], []
+    for it in range(N_IT):
+        sched_seen.append((bool(eng2._use_merged()), bool(eng2._serial_fwd()), float(eng2.sched.identity_loss_lambda)))
         eng2.step(*batch_of(range(100 + 2 * PER_RANK * it + PER_RANK * rank, 100 + 2 * PER_RANK * it + PER_RANK * rank + PER_RANK)))
         # pipelined schedule (small batch): the losses of the last COMPLETE iteration, one step behind -- reading the current ones every
         # iteration would complete the pending discriminator phase and never exercise the pipelined graph
@@ -125,9 +131,10 @@ def main():
     if eng2._pending_D is not None:
         mine_losses.append(eng2.losses())
     eng2.flush()
-    assert len(mine_losses) == 3
+    assert len(mine_losses) == N_IT
     if rank == 0:
         print("pipelined schedule: %s" % bool(eng2._use_pipeline()), flush=True)
+        print("per iteration (merged forwards, serialised forwards, identity lambda): %s" % sched_seen, flush=True)
     for lo in mine_losses:
         assert np.isfinite(lo["g_loss"]) and np.isfinite(lo["d_loss"])
         t = torch.tensor([lo["g_loss"], lo["d_loss"]], dtype=torch.float64, device=cdev)
@@ -138,8 +145,9 @@ def main():
     if rank == 0:
         solo = FlatGradReducer()
         solo.world = 1
-        ref = TrainEngine(nets_for(800), 2 * PER_RANK, 64, schedule=StepSchedule(batch_size=2 * PER_RANK, n_samples=64), reducer=solo)
-        for it in range(3):
+        ref = TrainEngine(nets_for(800), 2 * PER_RANK, 64, schedule=StepSchedule(batch_size=2 * PER_RANK, n_samples=64, stop_identity_after=STOP_ID),
+                          reducer=solo)
+        for it in range(N_IT):
             ref.step(*batch_of(range(100 + 2 * PER_RANK * it, 100 + 2 * PER_RANK * it + 2 * PER_RANK)))
             lo = ref.losses()
             for a, b in zip(mean_losses[it], (lo["g_loss"], lo["d_loss"])):
@@ -156,7 +164,7 @@ def main():
         if rank == 0:
             print("parameter spread across ranks %.3e" % spread, flush=True)
         ok = ok and spread == 0.0
-    assert eng2.d_group.step == 3 and eng2.g_group.step == 3
+    assert eng2.d_group.step == N_IT and eng2.g_group.step == N_IT
     flag = torch.tensor([1.0 if ok else 0.0], device=cdev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     torch.cuda.synchronize()

@@ -64,7 +64,134 @@ def seeded_inputs(seed, B, T, max_mask_len=25):
     return torch.from_numpy(x), torch.from_numpy(m)
 
 
-def main():
+# ---- 6. unmodified train() ---------------------------------------------------------------
+def run_train(refs, decay_after, stop_identity_after, n_utt, bs, tag, sample_final=False):
+    Generator, Discriminator, MaskCycleGANVCTraining, VCDataset, TrainLogger = refs
+    seed = 0
+    random.seed(seed)
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "gold"), exist_ok=True)
+    rs = np.random.RandomState(1234)
+    data_A = [rs.randn(80, 64 + rs.randint(0, 40)).astype(np.float32) for _ in range(n_utt)]
+    data_B = [rs.randn(80, 64 + rs.randint(0, 40)).astype(np.float32) for _ in range(n_utt)]
+    t = object.__new__(MaskCycleGANVCTraining)
+    t.num_epochs = 1
+    t.start_epoch = 1
+    t.generator_lr = 2e-4
+    t.discriminator_lr = 1e-4
+    t.decay_after = decay_after
+    t.stop_identity_after = stop_identity_after
+    t.mini_batch_size = bs
+    t.cycle_loss_lambda = 10
+    t.identity_loss_lambda = 5
+    t.device = "cpu"
+    t.epochs_per_save = 10 ** 9
+    t.epochs_per_plot = 10 ** 9
+    t.n_samples = n_utt
+    t.generator_lr_decay = t.generator_lr / float(t.num_epochs * (t.n_samples // t.mini_batch_size))
+    t.discriminator_lr_decay = t.discriminator_lr / float(t.num_epochs * (t.n_samples // t.mini_batch_size))
+    t.dataset = VCDataset(datasetA=data_A, datasetB=data_B, n_frames=64, max_mask_len=25)
+
+    class RecordingLoader:
+        """Wraps the DataLoader the harness hands to the unmodified train(); records batches."""
+
+        def __init__(self, inner):
+            self.inner = inner
+            self.dataset = inner.dataset
+            self.batches = []
+
+        def __iter__(self):
+            for b in self.inner:
+                self.batches.append([np.asarray(v).copy() for v in b])
+                yield b
+
+        def __len__(self):
+            return len(self.inner)
+
+    t.train_dataloader = RecordingLoader(torch.utils.data.DataLoader(
+        dataset=t.dataset, batch_size=bs, shuffle=True, drop_last=False))
+    largs = Namespace(batch_size=bs, save_dir=tmp, name="gold", start_epoch=1, steps_per_print=1, num_epochs=1)
+    t.logger = TrainLogger(largs, len(t.dataset))
+    t.saver = None
+    names = list(orc.NET_ORDER)
+    nets = [Generator(), Generator(), Discriminator(), Discriminator(), Discriminator(), Discriminator()]
+    for i, (n, net) in enumerate(zip(names, nets)):
+        net.load_state_dict(orc.filler_params("G" if i < 2 else "D", 300 + i), strict=True)
+        setattr(t, n, net)
+    g_params = list(t.generator_A2B.parameters()) + list(t.generator_B2A.parameters())
+    d_params = (list(t.discriminator_A.parameters()) + list(t.discriminator_B.parameters())
+                + list(t.discriminator_A2.parameters()) + list(t.discriminator_B2.parameters()))
+    t.generator_optimizer = torch.optim.Adam(g_params, lr=t.generator_lr, betas=(0.5, 0.999))
+    t.discriminator_optimizer = torch.optim.Adam(d_params, lr=t.discriminator_lr, betas=(0.5, 0.999))
+
+    # observe (not modify) per-iteration state through the logger's end_iter, which train() calls
+    trace = []
+    orig_end_iter = t.logger.end_iter
+
+    def end_iter():
+        orig_end_iter()
+        trace.append({
+            "global_step": t.logger.global_step,
+            "g_opt_lr": t.generator_optimizer.param_groups[0]["lr"],
+            "d_opt_lr": t.discriminator_optimizer.param_groups[0]["lr"],
+            "identity_lambda_before_check": t.identity_loss_lambda,
+            "norms": {n: [float(p.detach().double().norm()) for p in getattr(t, n).parameters()] for n in names},
+        })
+    t.logger.end_iter = end_iter
+    losses = []
+    orig_log_iter = t.logger.log_iter
+
+    def log_iter(loss_dict):
+        losses.append(dict(loss_dict))
+        orig_log_iter(loss_dict)
+    t.logger.log_iter = log_iter
+
+    t.train()
+    out = {"losses": losses,
+           "trace": trace,
+           "final": {"generator_lr_attr": t.generator_lr, "discriminator_lr_attr": t.discriminator_lr,
+                     "identity_loss_lambda": t.identity_loss_lambda,
+                     "g_opt_lr": t.generator_optimizer.param_groups[0]["lr"],
+                     "d_opt_lr": t.discriminator_optimizer.param_groups[0]["lr"]},
+           "adam_state_keys_G": sorted(t.generator_optimizer.state_dict()["state"].keys()),
+           "adam_state_keys_D": sorted(t.discriminator_optimizer.state_dict()["state"].keys()),
+           "adam_group_keys": sorted(t.generator_optimizer.state_dict()["param_groups"][0].keys()),
+           "config": {"decay_after": decay_after, "stop_identity_after": stop_identity_after,
+                      "n_utt": n_utt, "batch_size": bs, "filler_seeds": [300 + i for i in range(6)],
+                      "g_lr": 2e-4, "d_lr": 1e-4, "num_epochs": 1}}
+    batches = {}
+    if sample_final:
+        # a fixed sample of every parameter tensor after the last iteration (full tensors would be 590 MB): pins the
+        # multi-step UPDATE element by element, not only its norm
+        for n in names:
+            for j, p in enumerate(getattr(t, n).parameters()):
+                flat = p.detach().flatten()
+                batches["final_%s_%d" % (n, j)] = flat[torch.from_numpy(orc.sample_index(flat.numel()))].numpy().copy()
+    for i, b in enumerate(t.train_dataloader.batches):
+        for nm, arr in zip(("real_A", "mask_A", "real_B", "mask_B"), b):
+            batches["it%d_%s" % (i, nm)] = arr.astype(np.float32)
+    np.savez_compressed(os.path.join(HERE, "step_%s_batches.npz" % tag), **batches)
+    json.dump(out, open(os.path.join(HERE, "step_%s.json" % tag), "w"), indent=0)
+    print(tag, losses)
+
+
+TRAIN_CASES = {
+    "plain": dict(decay_after=1e9, stop_identity_after=1e9, n_utt=3, bs=1),
+    # trip the LR-decay call-site bug (train.py:307-311) and the identity cut-off (train.py:314-315) early
+    "decay": dict(decay_after=1, stop_identity_after=2, n_utt=4, bs=2),
+    # iterations 2 and 3 RUN with identity_loss_lambda == 0 (train.py:314-315 trips after iteration 1; :207-210 keeps computing the
+    # identity forwards): the regime a canonical run spends > 97 % of its life in
+    "cutoff": dict(decay_after=1e9, stop_identity_after=2, n_utt=8, bs=2, sample_final=True),
+}
+
+
+def run_train_case(tag, *refs):
+    run_train(refs, tag=tag, **TRAIN_CASES[tag])
+
+
+def main(only=None):
     torch.set_num_threads(8)
     _stub_modules()
     sys.path.insert(0, REF)
@@ -74,6 +201,9 @@ def main():
     from logger.train_logger import TrainLogger                  # reference, unmodified
 
     meta = {"torch": torch.__version__, "numpy": np.__version__}
+
+    if only is not None:           # regenerate ONE train() fixture without touching the others
+        return run_train_case(only, Generator, Discriminator, MaskCycleGANVCTraining, VCDataset, TrainLogger)
 
     # ---- 1. key layout --------------------------------------------------------------------
     g, d = Generator(), Discriminator()
@@ -156,113 +286,9 @@ def main():
     meta["grad_case"] = {"B": 2, "T": 64, "seed": 2000, "loss": "mean((1-D(G(x,m)))^2)+10*mean|x-G(x,m)|"}
     json.dump(gnorm, open(os.path.join(HERE, "grad_norms.json"), "w"), indent=0)
 
-    # ---- 6. unmodified train() ---------------------------------------------------------------
-    def run_train(decay_after, stop_identity_after, n_utt, bs, tag):
-        seed = 0
-        random.seed(seed)
-        torch.manual_seed(seed)
-        np.random.seed(seed)
-        tmp = tempfile.mkdtemp()
-        os.makedirs(os.path.join(tmp, "gold"), exist_ok=True)
-        rs = np.random.RandomState(1234)
-        data_A = [rs.randn(80, 64 + rs.randint(0, 40)).astype(np.float32) for _ in range(n_utt)]
-        data_B = [rs.randn(80, 64 + rs.randint(0, 40)).astype(np.float32) for _ in range(n_utt)]
-        t = object.__new__(MaskCycleGANVCTraining)
-        t.num_epochs = 1
-        t.start_epoch = 1
-        t.generator_lr = 2e-4
-        t.discriminator_lr = 1e-4
-        t.decay_after = decay_after
-        t.stop_identity_after = stop_identity_after
-        t.mini_batch_size = bs
-        t.cycle_loss_lambda = 10
-        t.identity_loss_lambda = 5
-        t.device = "cpu"
-        t.epochs_per_save = 10 ** 9
-        t.epochs_per_plot = 10 ** 9
-        t.n_samples = n_utt
-        t.generator_lr_decay = t.generator_lr / float(t.num_epochs * (t.n_samples // t.mini_batch_size))
-        t.discriminator_lr_decay = t.discriminator_lr / float(t.num_epochs * (t.n_samples // t.mini_batch_size))
-        t.dataset = VCDataset(datasetA=data_A, datasetB=data_B, n_frames=64, max_mask_len=25)
-
-        class RecordingLoader:
-            """Wraps the DataLoader the harness hands to the unmodified train(); records batches."""
-
-            def __init__(self, inner):
-                self.inner = inner
-                self.dataset = inner.dataset
-                self.batches = []
-
-            def __iter__(self):
-                for b in self.inner:
-                    self.batches.append([np.asarray(v).copy() for v in b])
-                    yield b
-
-            def __len__(self):
-                return len(self.inner)
-
-        t.train_dataloader = RecordingLoader(torch.utils.data.DataLoader(
-            dataset=t.dataset, batch_size=bs, shuffle=True, drop_last=False))
-        largs = Namespace(batch_size=bs, save_dir=tmp, name="gold", start_epoch=1, steps_per_print=1, num_epochs=1)
-        t.logger = TrainLogger(largs, len(t.dataset))
-        t.saver = None
-        names = list(orc.NET_ORDER)
-        nets = [Generator(), Generator(), Discriminator(), Discriminator(), Discriminator(), Discriminator()]
-        for i, (n, net) in enumerate(zip(names, nets)):
-            net.load_state_dict(orc.filler_params("G" if i < 2 else "D", 300 + i), strict=True)
-            setattr(t, n, net)
-        g_params = list(t.generator_A2B.parameters()) + list(t.generator_B2A.parameters())
-        d_params = (list(t.discriminator_A.parameters()) + list(t.discriminator_B.parameters())
-                    + list(t.discriminator_A2.parameters()) + list(t.discriminator_B2.parameters()))
-        t.generator_optimizer = torch.optim.Adam(g_params, lr=t.generator_lr, betas=(0.5, 0.999))
-        t.discriminator_optimizer = torch.optim.Adam(d_params, lr=t.discriminator_lr, betas=(0.5, 0.999))
-
-        # observe (not modify) per-iteration state through the logger's end_iter, which train() calls
-        trace = []
-        orig_end_iter = t.logger.end_iter
-
-        def end_iter():
-            orig_end_iter()
-            trace.append({
-                "global_step": t.logger.global_step,
-                "g_opt_lr": t.generator_optimizer.param_groups[0]["lr"],
-                "d_opt_lr": t.discriminator_optimizer.param_groups[0]["lr"],
-                "identity_lambda_before_check": t.identity_loss_lambda,
-                "norms": {n: [float(p.detach().double().norm()) for p in getattr(t, n).parameters()] for n in names},
-            })
-        t.logger.end_iter = end_iter
-        losses = []
-        orig_log_iter = t.logger.log_iter
-
-        def log_iter(loss_dict):
-            losses.append(dict(loss_dict))
-            orig_log_iter(loss_dict)
-        t.logger.log_iter = log_iter
-
-        t.train()
-        out = {"losses": losses,
-               "trace": trace,
-               "final": {"generator_lr_attr": t.generator_lr, "discriminator_lr_attr": t.discriminator_lr,
-                         "identity_loss_lambda": t.identity_loss_lambda,
-                         "g_opt_lr": t.generator_optimizer.param_groups[0]["lr"],
-                         "d_opt_lr": t.discriminator_optimizer.param_groups[0]["lr"]},
-               "adam_state_keys_G": sorted(t.generator_optimizer.state_dict()["state"].keys()),
-               "adam_state_keys_D": sorted(t.discriminator_optimizer.state_dict()["state"].keys()),
-               "adam_group_keys": sorted(t.generator_optimizer.state_dict()["param_groups"][0].keys()),
-               "config": {"decay_after": decay_after, "stop_identity_after": stop_identity_after,
-                          "n_utt": n_utt, "batch_size": bs, "filler_seeds": [300 + i for i in range(6)],
-                          "g_lr": 2e-4, "d_lr": 1e-4, "num_epochs": 1}}
-        batches = {}
-        for i, b in enumerate(t.train_dataloader.batches):
-            for nm, arr in zip(("real_A", "mask_A", "real_B", "mask_B"), b):
-                batches["it%d_%s" % (i, nm)] = arr.astype(np.float32)
-        np.savez_compressed(os.path.join(HERE, "step_%s_batches.npz" % tag), **batches)
-        json.dump(out, open(os.path.join(HERE, "step_%s.json" % tag), "w"), indent=0)
-        print(tag, losses)
-
-    run_train(decay_after=1e9, stop_identity_after=1e9, n_utt=3, bs=1, tag="plain")
-    # trip the LR-decay call-site bug (train.py:307-311) and the identity cut-off (train.py:314-315) early
-    run_train(decay_after=1, stop_identity_after=2, n_utt=4, bs=2, tag="decay")
+    refs = (Generator, Discriminator, MaskCycleGANVCTraining, VCDataset, TrainLogger)
+    for tag in TRAIN_CASES:
+        run_train_case(tag, *refs)
 
     # ---- 7. dataset draws ---------------------------------------------------------------------
     np.random.seed(0)
@@ -283,4 +309,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None)

@@ -29,6 +29,25 @@ def test_bench_under_torchrun_two_ranks():
     assert abs(res["value"] - 2 * 1e3 / res["ms_per_step"]) < 1e-6 * res["value"]        # whole-job rate = ranks x per-rank rate
     assert "cpu_baseline" not in res and "configs" not in res   # N=1 only
     assert res["dist"]["backend"] == "gloo" and res["dist"]["world"] == 2 and res["dist"]["rccl_ranks_seen"] == 2
+    assert "degraded" not in res                   # (ranks sharing a GPU switch the persistent trunk off on purpose: not a degradation)
+
+
+def test_multi_gpu_bench_fails_when_the_ranks_are_silently_degraded():
+    """a SCALE line must not be quietly degraded.  Here the persistent trunk kernels are forced off their residency
+    bound on both ranks (MCVC_TEST_FORCE_RESIDENCY: the engine claims 9 passes in flight = 576 workgroups > 256 compute units, what five
+    free-running grouped passes did on data-parallel ranks after the identity cut-off before r5) while the ranks do NOT share a GPU as
+    far as the job can tell (MCVC_TEST_DISTINCT_GPUS=1 skips the shared-device switch): bench.py must print its line, say why, and exit
+    non-zero; --allow-degraded turns that into a zero exit."""
+    env = dict(os.environ, MCVC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MCVC_TEST_FORCE_RESIDENCY="9", MCVC_TEST_DISTINCT_GPUS="1")
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-trace"]
+    r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode != 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.loads(lines[0])
+    assert res["degraded"] and "per-layer" in res["degraded"][0] and res["schedule"]["trunk_persistent_possible"] and not res["schedule"]["trunk_persistent"]
+    r = subprocess.run(base + ["--allow-degraded"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_default_single_gpu_bench_carries_every_baseline_config():
@@ -48,6 +67,10 @@ def test_default_single_gpu_bench_carries_every_baseline_config():
     for c in res["configs"]:
         assert c["value"] > 0 and c["ms_per_step"] > 0 and 0 < c["roofline"]["frac"] < 1 and c["roofline"]["kernel"]
     assert res["configs"][2]["dtype"] == "bf16" and res["configs"][2]["outputs_finite"]
+    # the two byte counts are named for what they are, and the reference-exact loss readback is priced in the same run
+    assert res["hbm_bytes_per_step_launcher"] > 0 and "hbm_bytes_per_step_pmc" in res and "hbm_bytes_per_step" not in res
+    sc = res["schedule"]
+    assert sc["sync_losses_ms_per_step"] > 0 and -0.2 < sc["sync_losses_cost"] < 1.0 and "one step behind" in sc["loss_readback"]
 
 
 def test_nccl_backend_refuses_fewer_gpus_than_ranks():

@@ -86,6 +86,66 @@ def test_lr_decay_bug_and_identity_cutoff_match_reference(golden_dir):
     assert abs(eng.sched.generator_lr - fin["generator_lr_attr"]) < 1e-12
 
 
+def test_four_iterations_past_the_identity_cutoff_pipelined_and_unflushed(golden_dir):
+    """The regime a canonical run spends > 97 % of its life in (train.py:314-315: identity_loss_lambda = 0 from then on; :207-210 keeps
+    computing the identity forwards, which the engine drops as dead work -- ``ident_dead`` in engine._g_parts), pinned to the REFERENCE:
+    the ``cutoff`` fixture is four iterations of the unmodified train() at bs=2 whose iterations 2 and 3 run with lambda_id == 0.
+    Replayed through the DEFAULT schedule -- grouped launches, iteration t's discriminator phase pipelined beside iteration t+1's
+    generator phase -- with NO flush() between the steps: losses are read the way the training loop reads them (``lagged=True``), the
+    parameters after the single flush at the end.  Gates: losses 1e-3; per parameter tensor the norm (fixture trace), the fixture's
+    element samples and the full tensor against the oracle (itself pinned to the same fixture in test_oracle_golden.py), rel-L2 <= 1e-3."""
+    skip = _zero_grad_bias_names(golden_dir)
+    js = json.load(open(os.path.join(golden_dir, "step_cutoff.json")))
+    bt = np.load(os.path.join(golden_dir, "step_cutoff_batches.npz"))
+    cfg = js["config"]
+    bs, n_it = cfg["batch_size"], 4
+    nets = _nets(cfg["filler_seeds"])
+    sched = StepSchedule(generator_lr=cfg["g_lr"], discriminator_lr=cfg["d_lr"], num_epochs=cfg["num_epochs"], n_samples=cfg["n_utt"],
+                         batch_size=bs, decay_after=cfg["decay_after"], stop_identity_after=cfg["stop_identity_after"])
+    eng = TrainEngine(nets, bs, 64, schedule=sched)
+    assert eng._use_pipeline(), "the default schedule at this batch size is the pipelined one"
+    onets = {n: orc.filler_params("G" if i < 2 else "D", s) for i, (n, s) in enumerate(zip(orc.NET_ORDER, cfg["filler_seeds"]))}
+    so = orc.StepOracle(onets, skip_wasted=True)
+    got, lam = [], []
+    for it in range(n_it):
+        batch = [torch.from_numpy(bt["it%d_%s" % (it, k)]) for k in ("real_A", "mask_A", "real_B", "mask_B")]
+        lam.append(sched.identity_loss_lambda)
+        eng.step(*[b.cuda() for b in batch])
+        assert eng._pending_D is not None                       # (iteration `it`'s discriminator phase has NOT run yet)
+        lo = eng.losses(lagged=True)                            # iteration it - 1, complete; never waits for work in flight
+        assert (lo is None) == (it == 0)
+        if lo is not None:
+            got.append(lo)
+        so.identity_lambda = float(lam[-1])
+        so.step(*batch)                                         # the oracle, same bookkeeping (no lr decay in this fixture)
+    assert lam == [t["identity_lambda_before_check"] for t in js["trace"]] == [5, 5, 0, 0]
+    eng.flush()
+    got.append(eng.losses())
+    assert sched.identity_loss_lambda == js["final"]["identity_loss_lambda"] == 0 and sched.global_step == js["trace"][-1]["global_step"]
+    for it, (lo, ref) in enumerate(zip(got, js["losses"])):
+        assert abs(lo["g_loss"] - ref["g_loss"]) < 1e-3 * abs(ref["g_loss"]), (it, lo, ref)
+        assert abs(lo["d_loss"] - ref["d_loss"]) < 1e-3 * abs(ref["d_loss"]), (it, lo, ref)
+    assert got[2]["identity_loss"] == 0.0 and got[3]["identity_loss"] == 0.0 and got[1]["identity_loss"] > 0.0
+    worst = 0.0
+    for name in orc.NET_ORDER:
+        for j, ((pn, p), rn) in enumerate(zip(nets[name].named_parameters(), js["trace"][-1]["norms"][name])):
+            if pn in skip:
+                continue
+            mine = p.detach().cpu()
+            tol = 1e-2 if p.numel() == 1 else 1e-3              # (the one-element output bias: see _run_against_golden)
+            assert abs(float(mine.double().norm()) - rn) <= tol * max(rn, 1e-3), (name, pn)
+            if p.numel() == 1:
+                continue
+            flat = mine.flatten()
+            ref = bt["final_%s_%d" % (name, j)]
+            e_s = float(np.linalg.norm(flat[torch.from_numpy(orc.sample_index(flat.numel()))].numpy().astype(np.float64) - ref)
+                        / max(np.linalg.norm(ref.astype(np.float64)), 1e-30))
+            e_f = float((mine.double() - onets[name][pn].double()).norm() / onets[name][pn].double().norm())
+            worst = max(worst, e_s, e_f)
+            assert e_s < 1e-3 and e_f < 1e-3, (name, pn, e_s, e_f)
+    print("cutoff fixture, 4 un-flushed pipelined iterations: worst per-tensor rel-L2 %.3e" % worst)
+
+
 def _kink_free_batch(onets, B, T=64):
     """|a-b| terms have a discontinuous gradient at a == b: an element that lands within rounding of the kink
     gets sign(+/-) from either side legitimately (observed: exactly one flipped element of 5120 => 2/sqrt(5120)
@@ -111,20 +171,21 @@ def _kink_free_batch(onets, B, T=64):
     raise AssertionError("no kink-free batch found")
 
 
-@pytest.mark.parametrize("B,T", [(1, 64), (2, 64), (1, 32), (3, 48), (8, 64), (32, 64)])
-def test_step_full_tensor_parity_vs_oracle(golden_dir, B, T):
+@pytest.mark.parametrize("B,T,lam_id", [(1, 64, 5.0), (2, 64, 5.0), (1, 32, 5.0), (3, 48, 5.0), (8, 64, 5.0), (32, 64, 5.0), (1, 64, 0.0), (8, 64, 0.0)])
+def test_step_full_tensor_parity_vs_oracle(golden_dir, B, T, lam_id):
     """One iteration: every generator / discriminator parameter GRADIENT (full tensors) and the resulting Adam update
     vs the CPU oracle.  (8, 64) is the per-GPU shape of BASELINE configs[3], (32, 64) is configs[2]: the staged-GEMM trunk
     (more than 64 columns), the F(4x4,5x5) / F(4x4,3x3) Winograd schemes in chunks of samples, weight gradients over 64 images in the
-    discriminator phase and Adam -- the full step with the L1 terms on."""
+    discriminator phase and Adam -- the full step with the L1 terms on.  ``lam_id`` = 0: the schedule after the identity cut-off
+    (train.py:314-315), where the engine does not compute the identity passes at all."""
     seeds = [300 + i for i in range(6)]
     nets = _nets(seeds)
     onets = {n: orc.filler_params("G" if i < 2 else "D", s) for i, (n, s) in enumerate(zip(orc.NET_ORDER, seeds))}
     batch = _kink_free_batch(onets, B, T)
-    so = orc.StepOracle(onets, skip_wasted=True)
+    so = orc.StepOracle(onets, skip_wasted=True, identity_lambda=lam_id)
     before = {n: {k: v.clone() for k, v in onets[n].items()} for n in onets}
     g_ref, d_ref, g_grads, d_grads = so.step(*batch, return_grads=True)
-    eng = TrainEngine(nets, B, T, schedule=StepSchedule(batch_size=B, n_samples=4 * B))
+    eng = TrainEngine(nets, B, T, schedule=StepSchedule(batch_size=B, n_samples=4 * B, identity_loss_lambda=lam_id))
     # the iteration, phase by phase (what eng.step() does), so that the discriminator phase can start from the ORACLE's
     # updated generators: Adam's first step is lr*sign(g), i.e. rounding-level differences in near-zero generator gradients
     # become +-2e-4 parameter differences, and comparing discriminator gradients downstream of two such generator sets

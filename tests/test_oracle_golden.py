@@ -173,6 +173,59 @@ def test_full_step_matches_unmodified_reference_train(golden_dir, skip_wasted):
     assert sorted(so.g_opt.state.keys()) == js["adam_state_keys_G"] == list(range(220))
 
 
+def _replay(golden_dir, tag, n_it, tol):
+    """StepOracle over a fixture of the unmodified train(), with the reference's end-of-iteration bookkeeping (train.py:307-315) applied
+    to the oracle's learning rates and identity weight between iterations."""
+    js, bt = _load_step(golden_dir, tag)
+    cfg = js["config"]
+    nets = _nets_from_filler(cfg["filler_seeds"])
+    so = orc.StepOracle(nets, skip_wasted=True)
+    g_lr, d_lr, gs = cfg["g_lr"], cfg["d_lr"], 0
+    denom = float(cfg["num_epochs"] * (cfg["n_utt"] // cfg["batch_size"]))
+    for it in range(n_it):
+        batch = [torch.from_numpy(bt["it%d_%s" % (it, k)]) for k in ("real_A", "mask_A", "real_B", "mask_B")]
+        assert js["trace"][it]["identity_lambda_before_check"] == so.identity_lambda
+        g_loss, d_loss = so.step(*batch)
+        assert abs(g_loss - js["losses"][it]["g_loss"]) < tol * abs(js["losses"][it]["g_loss"]), (it, g_loss)
+        assert abs(d_loss - js["losses"][it]["d_loss"]) < tol * abs(js["losses"][it]["d_loss"]), (it, d_loss)
+        for name in orc.NET_ORDER:
+            names = orc.generator_param_names() if name.startswith("generator") else orc.discriminator_param_names()
+            for k, rn in zip(names, js["trace"][it]["norms"][name]):
+                assert abs(float(nets[name][k].double().norm()) - rn) <= tol * max(rn, 1e-3), (it, name, k)
+        gs += cfg["batch_size"]
+        if gs > cfg["decay_after"]:                                   # train.py:307-311, call-site bug included
+            g_lr = max(0.0, g_lr - cfg["g_lr"] / denom)
+            d_lr = max(0.0, d_lr - cfg["d_lr"] / denom)
+            so.g_opt.lr = d_lr
+        if gs > cfg["stop_identity_after"]:                           # train.py:314-315
+            so.identity_lambda = 0
+    return js, bt, nets
+
+
+def test_oracle_across_the_lr_decay_bug(golden_dir):
+    _replay(golden_dir, "decay", 2, 2e-4)
+
+
+def test_oracle_past_the_identity_cutoff(golden_dir):
+    """Iterations 2 and 3 of the ``cutoff`` fixture run with identity_loss_lambda == 0 in the reference's unmodified train()
+    (train.py:207-210 still computes the identity forwards, :223-224 weighs them 0).  Also pins the fixture's parameter SAMPLES:
+    element-wise values after four iterations, not only norms."""
+    js, bt, nets = _replay(golden_dir, "cutoff", 4, 3e-4)
+    assert [t["identity_lambda_before_check"] for t in js["trace"]] == [5, 5, 0, 0] and js["final"]["identity_loss_lambda"] == 0
+    zero_bias = {k.split(":", 1)[1] for k, v in json.load(open(os.path.join(golden_dir, "grad_norms.json"))).items() if v is not None and v < 1e-6}
+    for name in orc.NET_ORDER:
+        names = orc.generator_param_names() if name.startswith("generator") else orc.discriminator_param_names()
+        for j, k in enumerate(names):
+            if k in zero_bias:
+                continue
+            flat = nets[name][k].flatten()
+            mine = flat[torch.from_numpy(orc.sample_index(flat.numel()))].numpy()
+            ref = bt["final_%s_%d" % (name, j)]
+            if ref.size == 1:            # the discriminators' one-element output bias: cancellation + Adam's normalisation (see test_hip_engine)
+                continue
+            assert rel_l2(mine, ref) < 1e-3, (name, k, rel_l2(mine, ref))
+
+
 def test_dataset_mask_law(golden_dir):
     """FIF masks drawn by the reference VCDataset: ones with one zeroed span shared by all 80 bins."""
     dr = np.load(os.path.join(golden_dir, "dataset_draws.npz"))

@@ -24,18 +24,40 @@ def family(name):
     return re.sub(r"_kernel.*$", "", re.sub(r"\(.*$", "", n))
 
 
-def per_family(dbfile, counter):
+def dispatches(dbfile, counter):
+    """[(dispatch_id, kernel name, counter value summed over its instances)] in dispatch order."""
     db = sqlite3.connect(dbfile)
-    q = "select kernel_name, dispatch_id, sum(value) from counters_collection where counter_name = ? group by kernel_name, dispatch_id"
+    q = "select dispatch_id, kernel_name, sum(value) from counters_collection where counter_name = ? group by dispatch_id, kernel_name order by dispatch_id"
+    return [(d, k, v) for d, k, v in db.execute(q, (counter,))]
+
+
+def per_family(rows):
     agg = {}
-    for k, _, v in db.execute(q, (counter,)):
+    for _, k, v in rows:
         a = agg.setdefault(family(k), [0, 0.0])
         a[0] += 1; a[1] += v
     return agg
 
 
-fetch = per_family(sys.argv[1], "FETCH_SIZE")
-write = per_family(sys.argv[2], "WRITE_SIZE")
+def short(name):
+    return re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", "").replace("void ", "")).strip()
+
+
+def per_step(rows, nsteps, scale):
+    """Bytes per training step by KERNEL INSTANCE (the full template instantiation, not the family average): every dispatch behind the
+    last `pack_net_kernel` (the one-off re-pack of the six networks when the engine is built) belongs to one of the `nsteps` identical
+    iterations the profiled command ran (warm-up + timed), so per instance  bytes per step = sum over its dispatches / nsteps."""
+    last_pack = max([i for i, (_, k, _v) in enumerate(rows) if "pack_net_kernel" in k] or [-1])
+    inst = {}
+    for _, k, v in rows[last_pack + 1:]:
+        a = inst.setdefault(short(k), [0, 0.0])
+        a[0] += 1; a[1] += scale * v
+    return {k: {"launches_per_step": n / nsteps, "bytes_per_launch": b / max(n, 1), "bytes_per_step": b / nsteps} for k, (n, b) in inst.items()}
+
+
+frows, wrows = dispatches(sys.argv[1], "FETCH_SIZE"), dispatches(sys.argv[2], "WRITE_SIZE")
+nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+fetch, write = per_family(frows), per_family(wrows)
 out = {}
 for fam in sorted(set(fetch) | set(write)):
     nf, f = fetch.get(fam, (0, 0.0))
@@ -44,5 +66,21 @@ for fam in sorted(set(fetch) | set(write)):
     wr = 1024.0 * w / max(nw, 1)
     out[fam] = {"launches_sampled": int(max(nf, nw)), "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                 "hbm_bytes_per_launch": rd + wr}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE on bench.py --serial (2 x FETCH_SIZE correction for gfx950)",
-           "families": out}, sys.stdout, indent=1)
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE on bench.py --serial (2 x FETCH_SIZE correction for gfx950)",
+       "families": out}
+if nsteps > 0:
+    rd, wr = per_step(frows, nsteps, 2.0 * 1024.0), per_step(wrows, nsteps, 1024.0)
+    inst = {}
+    for k in sorted(set(rd) | set(wr)):
+        r, w = rd.get(k), wr.get(k)
+        inst[k] = {"launches_per_step": (r or w)["launches_per_step"], "family": family(k),
+                   "hbm_read_bytes_per_step": r["bytes_per_step"] if r else 0.0, "hbm_write_bytes_per_step": w["bytes_per_step"] if w else 0.0}
+        inst[k]["hbm_bytes_per_step"] = inst[k]["hbm_read_bytes_per_step"] + inst[k]["hbm_write_bytes_per_step"]
+    fam_step = {}
+    for k, v in inst.items():
+        fam_step[v["family"]] = fam_step.get(v["family"], 0.0) + v["hbm_bytes_per_step"]
+    res["steps_profiled"] = nsteps
+    res["instances"] = inst
+    res["family_hbm_bytes_per_step"] = dict(sorted(fam_step.items(), key=lambda kv: -kv[1]))
+    res["hbm_bytes_per_step_pmc"] = sum(v["hbm_bytes_per_step"] for v in inst.values())
+json.dump(res, sys.stdout, indent=1)

@@ -22,9 +22,10 @@ pmc() { # name, counters..., then -- command
 for B in $BATCHES; do
   ST=30; if [ $B -ge 8 ]; then ST=12; fi; if [ $B -ge 32 ]; then ST=6; fi
   CI=""; if [ $B -ge 32 ]; then CI="--cpu-iters 1"; fi
+  # (3 + 2 = 5 identical iterations: tools/pmc_traffic.py divides the dispatches behind the initial re-pack by that)
   CMD="python bench.py --no-extra-configs --batch-size $B --cpu-iters 0 --steps 3 --warmup 2 --no-trace --serial"
   DBF=$(pmc f FETCH_SIZE -- $CMD); DBW=$(pmc w WRITE_SIZE -- $CMD)
-  python tools/pmc_traffic.py $DBF $DBW > $OUT/pmc_traffic_bs$B.json.tmp 2> $OUT/pmc_bs$B.err \
+  python tools/pmc_traffic.py $DBF $DBW 5 > $OUT/pmc_traffic_bs$B.json.tmp 2> $OUT/pmc_bs$B.err \
     && python -c "
 import json
 j=json.load(open('$OUT/pmc_traffic_bs$B.json.tmp')); j['git_rev']='$REV'; j['batch_size']=$B
