@@ -122,8 +122,8 @@ def trace_one_step(engine, batches):
     cap = 16384
     buf = (ctypes.c_double * (4 * cap))()
     torch.cuda.synchronize()
-    was = (engine._serial, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs)
-    engine._serial, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs = True, False, False, False
+    was = (engine._serial, engine.aux_wgrad)
+    engine._serial, engine.aux_wgrad = True, False
     engine.step(*batches[0])
     torch.cuda.synchronize()
     L.mcvc_trace_enable(1)
@@ -133,7 +133,7 @@ def trace_one_step(engine, batches):
     n = L.mcvc_trace_collect_raw(buf, cap)
     L.mcvc_trace_enable(0)
     engine.flush()
-    engine._serial, engine.use_graphs, engine.aux_wgrad, engine.pass_graphs = was
+    engine._serial, engine.aux_wgrad = was
     raw = [(L.mcvc_trace_kind_name(int(buf[4 * i])).decode(), buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]) for i in range(n)]
     fam = {}
     for k, ms, fl, by in raw:
@@ -288,9 +288,6 @@ def parse_args():
     ap.add_argument("--allow-degraded", action="store_true", help="--gpus N: do not fail when the ranks did not all take part in the collective or the "
                     "persistent trunk kernels fell back to per-layer launches (single-GPU choreography tests over gloo)")
     ap.add_argument("--serial", action="store_true", help="one stream: no lanes, no auxiliary weight-gradient stream (A/B comparison, per-kernel profiling)")
-    ap.add_argument("--graphs", action="store_true", help="replay HIP graphs of the two phases (experimental; not faster on ROCm 7.2)")
-    ap.add_argument("--no-pass-graphs", action="store_true", help="launch every network pass eagerly instead of replaying its HIP graph (A/B)")
-    ap.add_argument("--graphs-aux", action="store_true", help="with --graphs: keep the auxiliary weight-gradient streams inside the capture")
     ap.add_argument("--dump-trace", default=None, help="write one traced step's per-launch records (launch order) to this file")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")
     return ap.parse_args()
@@ -318,19 +315,11 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
     nets = build_nets(device)
     sched = StepSchedule(generator_lr=2e-4, discriminator_lr=1e-4, num_epochs=6172, n_samples=81, batch_size=B,
                          decay_after=2e5, stop_identity_after=1e4, world_size=world)     # bash_scripts/mask_cyclegan_train.sh
-    import contextlib
-    run_ctx = torch.cuda.stream(torch.cuda.Stream(device=device)) if os.environ.get("MCVC_BENCH_STREAM") == "1" else contextlib.nullcontext()
-    run_ctx.__enter__()                    # (before the engine is built: its lanes are chosen against the stream it will be called on)
     reducer = FlatGradReducer()
     engine = TrainEngine(nets, B, T, schedule=sched, reducer=reducer)
     engine.concurrent = not args.serial
     if args.serial:
         engine.aux_wgrad = False          # truly one stream: per-kernel durations comparable with the traced step's
-    engine.use_graphs = args.graphs
-    if args.graphs or args.no_pass_graphs:
-        engine.pass_graphs = False          # (phase-level capture and per-pass capture do not nest)
-    if args.graphs and not args.graphs_aux:
-        engine.aux_wgrad = False            # lanes + auxiliary streams in one capture crash hipStreamEndCapture (ROCm 7.2)
     batches = synthetic_batches(n_batches, B, T, rank, device)
     log("engine ready; warm-up")
 
@@ -364,7 +353,6 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    run_ctx.__exit__(None, None, None)
     log("timed region done: %.2f ms/step" % (1e3 * dt / steps))
     reducer.time_waits = False
     exposed_ms, n_waits = reducer.exposed_ms()
@@ -491,7 +479,7 @@ def main():
         # The default single-GPU invocation (the one the driver runs) also measures the other BASELINE configs, each as a nested record
         # with its own roofline and CPU sample: configs[2] = the bs=32 step, the per-GPU shape of configs[3] = the bs=8 step, configs[4] =
         # generator_A2B bf16 inference at 16 x 512 frames.  The headline line above them is unchanged (configs[1], bs=1).
-        if world == 1 and B == 1 and T == 64 and not args.no_extra_configs and not (args.serial or args.graphs):
+        if world == 1 and B == 1 and T == 64 and not args.no_extra_configs and not args.serial:
             extra = []
             sub = argparse.Namespace(**dict(vars(args), dump_trace=None))
             skip_cpu = args.cpu_iters == 0
@@ -508,7 +496,7 @@ def main():
                 res["configs"] = [r for r in extra if r is not None]
         # the price of the reference-exact loss readback, driver-observed: the same config once more, short, with
         # the CURRENT iteration's losses read every step
-        if world == 1 and B == 1 and T == 64 and not args.no_extra_configs and not (args.serial or args.graphs or args.sync_losses):
+        if world == 1 and B == 1 and T == 64 and not args.no_extra_configs and not (args.serial or args.sync_losses):
             sub = argparse.Namespace(**dict(vars(args), dump_trace=None, no_trace=True, sync_losses=True))
             rec = train_record(sub, rank, world, device, 1, 64, 30, 5, 0, 16, config_id="sync-losses")
             if res is not None and rec is not None:

@@ -58,11 +58,9 @@ constexpr int kMaxWP = 10;          // 16-byte weight pieces per thread and stag
 
 // KWT > 0: the kernel width is a compile-time constant (taps fully unrolled: the compiler hoists the next operands' LDS reads above
 // the current MFMAs); KWT == 0: run-time width.
-// WREG: the weight stages go global -> registers -> LDS (plain loads, ds_write_b128 at the head of the next stage) instead of by LDS-DMA.
-// One workgroup per CU streams 40 KB of weights per stage; as 40 `global_load_lds` instructions per stage that is ~19 GB/s per CU through a
-// path that delivers ~25 (MI355X_MICROARCH.md: ldsdma-fill), and each of those instructions holds its wave's issue slot for 100-185 cycles
-// in the middle of the MFMA stream (r4 ablation: 19 % of the stride-1 layers' time).
-template <int WM, int WN, int MT, int NT, int KWT, int PPT, bool WREG = false>
+// (Weights through registers instead of LDS-DMA -- global -> registers -> ds_write_b128 -- was built in r4 and measured slower: 938 -> 1004 us on
+// upSample2, 20-47 spilled registers and the stores exposed in front of the stage barrier; removed)
+template <int WM, int WN, int MT, int NT, int KWT, int PPT>
 __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvArgs a)
 {
     constexpr int kMaxPP = PPT;
@@ -133,20 +131,6 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
             if (woff[i] >= 0)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + woff[i]),
                                                  (__attribute__((address_space(3))) void*)(dst + (size_t)(wave * 64 + i * kConvThreads) * 16), 16, 0, 0);
-    };
-    uint4 wreg[WREG ? NWP : 1];
-    auto load_w = [&](int stage) __attribute__((always_inline)) {
-        const int cc = stage / a.KH, kh = stage - cc * a.KH;
-        const bf16_t* base = a.w + (long long)(kh * ncc + cc) * KW * 32;
-#pragma unroll
-        for (int i = 0; i < (WREG ? NWP : 0); ++i)
-            wreg[i] = (woff[i] >= 0) ? *reinterpret_cast<const uint4*>(base + woff[i]) : make_uint4(0u, 0u, 0u, 0u);
-    };
-    auto store_w = [&](int buf) __attribute__((always_inline)) {
-        unsigned char* dst = Ws + buf * wbuf_bytes;
-#pragma unroll
-        for (int i = 0; i < (WREG ? NWP : 0); ++i)
-            if (woff[i] >= 0) *reinterpret_cast<uint4*>(dst + (size_t)(tid + i * kConvThreads) * 16) = wreg[i];
     };
     // ---- input patch: small patches (<= kMaxPP pieces per thread) are prefetched through registers one chunk ahead; large ones
     //      (stride-2 layers) are staged synchronously, four loads in flight per thread
@@ -220,7 +204,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    if constexpr (WREG) load_w(0); else issue_w(0, 0);
+    issue_w(0, 0);
     if (p_pref) load_patch(0);
     for (int stage = 0; stage < nstage; ++stage) {
         const int cc = stage / a.KH, kh = stage - cc * a.KH;
@@ -228,15 +212,12 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
         // everything requested during the previous stage (this stage's weights, the next chunk's patch registers) has had that stage's
         // MFMAs to land; the barrier also says every wave is done reading the buffer the next copy overwrites
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // (WREG: buffer `buf` was last read two stages ago and every wave has passed the barrier since: the stores need none in front)
-        if constexpr (WREG) store_w(buf);
         __syncthreads();
         if (kh == 0) {
             if (p_pref) store_patch(); else stage_patch_sync(cc);
             __syncthreads();
         }
-        if constexpr (WREG) { if (stage + 1 < nstage) load_w(stage + 1); }
-        else if (stage + 1 < nstage) issue_w(stage + 1, buf ^ 1);          // in flight during the MFMAs below
+        if (stage + 1 < nstage) issue_w(stage + 1, buf ^ 1);          // in flight during the MFMAs below
         if (p_pref && kh == a.KH - 1 && cc + 1 < ncc) load_patch(cc + 1);
         const unsigned char* Wb = Ws + buf * wbuf_bytes;
         const int pk = kh * a.PW;
@@ -345,11 +326,11 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     }
 }
 
-template <int WM, int WN, int MT, int NT, int KWT, int PPT, bool WREG = false>
+template <int WM, int WN, int MT, int NT, int KWT, int PPT>
 int conv_launch_t(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
 {
     constexpr int BM = WM * MT * 32;
-    auto kern = bf16_conv_kernel<WM, WN, MT, NT, KWT, PPT, WREG>;
+    auto kern = bf16_conv_kernel<WM, WN, MT, NT, KWT, PPT>;
     static bool done = false;
     if (!done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -367,14 +348,10 @@ int conv_launch_kw(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
     const bool big_patch = a.PH * a.PW * 4 > 4 * kConvThreads;
     // (the 512-pixel tiles of the large stride-1 layers stage 816 / 1056 patch pixels = 13 / 17 pieces per thread: with 12 they fell off the
     //  register prefetch onto the synchronous staging loop -- four dependent rounds of global loads per channel chunk in front of 50 MFMA-bound
-    //  steps; r4, 16 x 512 frames: upSample2 1090 -> 938 us.  MCVC_BF16_WREG=1: weights through registers instead of LDS-DMA, measured
-    //  SLOWER (938 -> 1004 us: 20-47 spilled registers, the ds_write_b128 of a stage exposed in front of its barrier))
-    static const int ppt_knob = [] { const char* e = getenv("MCVC_BF16_PPT"); return e ? atoi(e) : 1; }();
+    //  steps; r4, 16 x 512 frames: upSample2 1090 -> 938 us)
+    static const int ppt_knob = mcvc_knob("MCVC_BF16_PPT", 1);
     if constexpr (WM == 1 && WN == 4 && MT == 4 && NT == 4) {
         const int pieces = a.PH * a.PW * 4;
-        static const int wreg_knob = [] { const char* e = getenv("MCVC_BF16_WREG"); return e ? atoi(e) : 0; }();
-        if (a.KW == 5 && wreg_knob && ppt_knob && pieces > 12 * kConvThreads && pieces <= 13 * kConvThreads) return conv_launch_t<WM, WN, MT, NT, 5, 13, true>(a, lds, s);
-        if (a.KW == 5 && wreg_knob && ppt_knob && pieces > 13 * kConvThreads && pieces <= 17 * kConvThreads) return conv_launch_t<WM, WN, MT, NT, 5, 17, true>(a, lds, s);
         if (a.KW == 5 && ppt_knob && pieces > 12 * kConvThreads && pieces <= 13 * kConvThreads) return conv_launch_t<WM, WN, MT, NT, 5, 13>(a, lds, s);
         if (a.KW == 5 && ppt_knob && pieces > 13 * kConvThreads && pieces <= 17 * kConvThreads) return conv_launch_t<WM, WN, MT, NT, 5, 17>(a, lds, s);
     }
@@ -391,7 +368,7 @@ int conv_launch_kw(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
 // only reachable through MCVC_BF16_CFG=3 for experiments)
 static int conv_config(const Bf16ConvArgs& a)
 {
-    static const int knob = [] { const char* e = getenv("MCVC_BF16_CFG"); return e ? atoi(e) : -1; }();
+    static const int knob = mcvc_knob("MCVC_BF16_CFG", -1);
     if (a.Cout_pad % 64 != 0) return 2;
     if (knob == 3 && a.stride == 2 && a.Cout_pad % 128 == 0 && !a.glu) return 3;
     const long long px = (long long)a.N * a.OH * a.OW;
@@ -472,7 +449,7 @@ int mcvc_bf16_conv_launch(const Bf16ConvArgs& a0, hipStream_t s)
     a.PH = (a.TH - 1) * a.stride + a.KH; a.PW = (TW - 1) * a.stride + a.KW;
     {   // widen the staged patch to the nearest row pitch whose operand reads are free of LDS bank conflicts (the extra columns are
         // real image columns or zero fill; nothing reads them)
-        static const int knob = [] { const char* e = getenv("MCVC_BF16_PITCH"); return e ? atoi(e) : 1; }();
+        static const int knob = mcvc_knob("MCVC_BF16_PITCH", 1);
         if (knob && a.tw_log2 < 5) {
             int best = a.PW; double bc = bf16_patch_conflicts(a.tw_log2, a.PW, a.stride, a.KH, a.KW);
             for (int pw = a.PW + 1; pw <= a.PW + 12 && bc > 0.0; ++pw) {
@@ -787,7 +764,7 @@ int mcvc_bf16_norm_launch(const Bf16NormArgs& a, hipStream_t s)
     const int C = a.shuffle ? a.Cx / 4 : (a.act == BF16_ACT_GLU ? a.Cx / 2 : a.Cx);
     if (C & 7) return MCVC_ERR_INVALID;
     const double el = (double)a.N * a.H * a.W * a.Cx;
-    static const int small_knob = [] { const char* e = getenv("MCVC_BF16_NORM_SMALL"); return e ? atoi(e) : 1; }();
+    static const int small_knob = mcvc_knob("MCVC_BF16_NORM_SMALL", 1);
     if (small_knob && a.has_norm && !a.shuffle && a.H * a.W <= 256 && (C % 8) == 0) {
         TraceScope ts(K_NORM_FWD, s, 0.0, 2.0 * (el + (double)a.N * a.H * a.W * C));
         const dim3 grid((unsigned)cdiv_i(C, 64), (unsigned)a.N);

@@ -218,8 +218,8 @@ __global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const 
         const int cur = (ch - ch_begin) & 1;
         const bool more = (ch + 1 < ch_end);
         if (more) {
-            if (!(a.dbg & 1)) dma_weights(ch + 1, wbase + (cur ^ 1) * ws_floats);
-            if (!(a.dbg & 2)) { if (a.gemm) dma_patch(ch + 1, (cur ^ 1) * a.xs_floats); else fetch_patch(ch + 1); }
+            dma_weights(ch + 1, wbase + (cur ^ 1) * ws_floats);
+            if (a.gemm) dma_patch(ch + 1, (cur ^ 1) * a.xs_floats); else fetch_patch(ch + 1);
         }
         // ---- MFMA main loop: (channel pair, kh) rows at run time, the KW taps of a row unrolled with immediate
         // offsets.  Operand reads are software-pipelined one tap ahead (the reads of tap t+1 -- or of the next row's
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const 
         if (KW == 1 && a.KH == 1) {
             // 1x1 (GEMM-shaped: the Winograd products, the generic trunk): one tap per channel pair -- a plain K loop with
             // fixed operand strides, unrolled so that several pairs' operand reads are in flight
-            if (!(a.dbg & 4)) {
+            {
                 const int a0 = wbase + cur * ws_floats + a_lane;
                 const int x0 = cur * a.xs_floats;
 #pragma unroll 4
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const 
                         for (int j = 0; j < WN; ++j) acc[i][j] = MFMA32(av[i], bv[j], acc[i][j]);
                 }
             }
-        } else if (!(a.dbg & 4)) {
+        } else {
             int a_off = wbase + cur * ws_floats + a_lane;
             int x_row = cur * a.xs_floats;
             const int nrows = npairs * a.KH;
@@ -290,15 +290,14 @@ __global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const 
                 a_off = a_next; x_row = x_next;
             }
         }
-        if (more && !(a.dbg & 2) && !a.gemm) commit_patch((cur ^ 1) * a.xs_floats);
-        if (!(a.dbg & 16)) __syncthreads();
+        if (more && !a.gemm) commit_patch((cur ^ 1) * a.xs_floats);
+        __syncthreads();
     }
 
     // ---- epilogue: bias, (shuffled) store / slab store / accumulate
     float* ybase = (split == 0 || a.out_mode == CONV_OUT_ACCUM) ? a.y : (a.y_slabs + (long long)(split - 1) * a.slab_stride);
     ybase += (long long)n * a.y_sb;
     const bool add_bias = (a.bias != nullptr) && (split == 0);
-    if (a.dbg & 8) return;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int sub = wn_id * WN + j;
@@ -336,12 +335,8 @@ __global__ void __launch_bounds__(256, MCVC_CONV_MINW) conv_direct_kernel(const 
 // ---- host planner --------------------------------------------------------------------------------
 namespace {
 
-// tuning knobs (read once from the environment; defaults are the shipped configuration)
-static int env_int(const char* name, int dflt)
-{
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+// tuning knobs (mcvc_common.h mcvc_knob: constants in the product, MCVC_<NAME> in an experiments build)
+static int env_int(const char* name, int dflt) { return mcvc_knob(name, dflt); }
 // planner knobs (tools/conv_tune.py): read once, or on every call when MCVC_CONV_TUNE=1 was set at load time
 static int conv_knob(const char* name, int dflt)
 {
@@ -350,7 +345,6 @@ static int conv_knob(const char* name, int dflt)
     return dflt;
 }
 static int conv_lds_budget_floats() { static const int v = env_int("MCVC_CONV_LDS_KB", 78) * 256; return conv_knob("MCVC_CONV_LDS_KB", v / 256) * 256; }
-static int conv_debug_bits() { static const int v = env_int("MCVC_CONV_DEBUG", 0); return v; }   // timing ablations only (wrong results)
 
 enum ConvCfg { CFG_L = 0, CFG_M, CFG_N, CFG_T, CFG_S, CFG_S2, CFG_COUNT };
 struct CfgDesc { int cot, npix, kind; };
@@ -572,7 +566,6 @@ int mcvc_conv_launch(const ConvProblem& p, int NB, const ConvIO& io, const float
     a.y_slabs = io.slabs; a.slab_stride = io.slab_stride;
     a.w = wpk; a.w_rows = w_rows; a.w_cout = w_cout; a.bias = bias; a.w_nstride = io.w_nstride;
     a.out_mode = io.accumulate ? CONV_OUT_ACCUM : CONV_OUT_SLAB;
-    a.dbg = conv_debug_bits();
     a.shuffle = io.shuffle;
     a.YH = io.YH > 0 ? io.YH : 2 * p.OH; a.YW = io.YW > 0 ? io.YW : 2 * p.OW;
     if (nsplit_out) *nsplit_out = a.nsplit;

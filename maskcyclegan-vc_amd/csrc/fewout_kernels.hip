@@ -40,7 +40,6 @@ struct FewArgs {
     int nsplit, ch_per_split, NB;
     int PH, PWp;                 // LDS patch rows / pitch (multiple of 4)
     int accumulate;
-    int dbg;                     // timing experiments (MCVC_FEW_DBG): 1 = staging only, 2 = arithmetic only
 };
 
 template <int CO, int KW>
@@ -255,13 +254,11 @@ __global__ void __launch_bounds__(256, (CO == 1 ? 2 : 1)) conv_fewout_mfma_kerne
 #pragma unroll
             for (int j = 0; j < NTI; ++j) acc[co][r][j] = f32x4_{0.f, 0.f, 0.f, 0.f};
     const int nrounds = (c_end > c_begin) ? (c_end - c_begin + kFewCC - 1) / kFewCC : 0;
-    const int dbg = a.dbg;
-    if (nrounds > 0 && !(dbg & 2)) stage(c_begin, xs);
+    if (nrounds > 0) stage(c_begin, xs);
     for (int rd = 0; rd < nrounds; ++rd) {
         float* cur = xs + (rd & 1) * bufsz;
         __syncthreads();
-        if (rd + 1 < nrounds && !(dbg & 2)) stage(c_begin + (rd + 1) * kFewCC, xs + ((rd + 1) & 1) * bufsz);
-        if (dbg & 1) continue;
+        if (rd + 1 < nrounds) stage(c_begin + (rd + 1) * kFewCC, xs + ((rd + 1) & 1) * bufsz);
         const float* wcur = cur + kFewCC * plane;
         // software pipeline over the five k blocks of the round: the 20 B values (+ A) of block b+1 are read while block b multiplies; the
         // order is pinned (left alone the scheduler pairs every ds_read with its MFMAs: an LDS round trip per two MFMAs)
@@ -457,7 +454,7 @@ __global__ void __launch_bounds__(256) disc_conv1_fwd_kernel(const Twin<DiscConv
 
 static int few_enabled()
 {
-    static const int v = [] { const char* e = getenv("MCVC_FEWOUT"); return e ? atoi(e) : 1; }();
+    static const int v = mcvc_knob("MCVC_FEWOUT", 1);
     return v;
 }
 
@@ -534,8 +531,6 @@ int mcvc_fewout_launch(const ConvProblem& p, int NB, const ConvIO& io, const flo
     a.PH = kFewTH + p.KH - 1;
     a.PWp = round_up_i(kFewTW + p.KW - 1 + 3, 4);           // (+3: the last float4 of a row window may read past PW)
     a.accumulate = io.accumulate;
-    static const int dbg = [] { const char* e = getenv("MCVC_FEW_DBG"); return e ? atoi(e) : 0; }();
-    a.dbg = dbg;
     dim3 grid((unsigned)(a.tiles_w * a.tiles_h), (unsigned)(NB * io.nsplit));
     const int co_t = p.Cout <= 1 ? 1 : (p.Cout <= 2 ? 2 : 4);
     const size_t lds = (size_t)2 * (kFewCC * a.PH * a.PWp + kFewCC * p.KH * co_t * ((p.KW + 3) & ~3) + 4) * sizeof(float);
@@ -544,7 +539,7 @@ int mcvc_fewout_launch(const ConvProblem& p, int NB, const ConvIO& io, const flo
                   4.0 * ((double)NB * p.Cin * p.H * p.W + (double)p.Cin * p.KH * p.KW * p.Cout + px * p.Cout * io.nsplit));
     const int co = co_t;
     // 5 x 15 kernels with one or two output channels: the matrix-core form (MCVC_FEWOUT_MFMA=0: the VALU kernel)
-    static const int mfma = [] { const char* e = getenv("MCVC_FEWOUT_MFMA"); return e ? atoi(e) : 1; }();
+    static const int mfma = mcvc_knob("MCVC_FEWOUT_MFMA", 1);
     const bool dma16 = ((a.x_sh & 3) == 0) && ((p.W & 3) == 0) && ((a.x_sc & 3) == 0) && ((a.x_sb & 3) == 0) &&
                        ((reinterpret_cast<unsigned long long>(a.x) & 15ull) == 0) && (long long)p.H * a.x_sh < (1LL << 30);
     if (mfma && p.KW == 15 && p.KH == 5 && co <= 2 && dma16 && a.PWp == kFewMfmaPW && a.PH == kFewMfmaPH) {
@@ -947,7 +942,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_cin2_mfma_kernel(const Twin<W2Ar
 
 bool mcvc_wgrad_cin2_applies(const ConvProblem& p, const WgradIO& io)
 {
-    static const int en = [] { const char* e = getenv("MCVC_WGRAD_CIN2_MFMA"); return e ? atoi(e) : 1; }();
+    static const int en = mcvc_knob("MCVC_WGRAD_CIN2_MFMA", 1);
     return en && p.Cin >= 1 && p.Cin <= 2 && p.KH == 5 && p.KW == 15 && p.stride == 1 && p.pad_h == 2 && p.pad_w == 7 && p.W == 64 && p.OH == p.H &&
            p.OW == p.W && (io.x_sh & 3) == 0 && (io.x_sc & 3) == 0 && (io.x_sb & 3) == 0 && (io.dy_sh & 3) == 0 && (io.dy_sc & 3) == 0 &&
            (io.dy_sb & 3) == 0 && ((reinterpret_cast<unsigned long long>(io.x) | reinterpret_cast<unsigned long long>(io.dy)) & 15ull) == 0;
@@ -965,7 +960,7 @@ int mcvc_wgrad_cin2_launch(const ConvProblem& p, int NB, const WgradIO& io, floa
     w.N = NB; w.Cin = p.Cin; w.Cout = p.Cout; w.H = p.H; w.W = p.W; w.bands = cdiv_i(p.H, band); w.units = NB * w.bands;
     int nch = 1;
     // (every workgroup ends with 64 x Cin x 75 atomic adds into the same dW block: enough workgroups to fill the chip, not more)
-    static const int wgs = [] { const char* e = getenv("MCVC_WGRAD_CIN2_WGS"); return e ? atoi(e) : 512; }();
+    static const int wgs = mcvc_knob("MCVC_WGRAD_CIN2_WGS", 512);
     if (!mcvc_deterministic())
         while (2 * nch <= w.units && blocks * nch < wgs) nch *= 2;
     w.atomic = nch > 1 ? 1 : 0;
@@ -998,7 +993,7 @@ int mcvc_wgrad_cout1_launch(const ConvProblem& p, int NB, const WgradIO& io, flo
     // (sample, band of rows) units over gridDim.y workgroups that add their partial sums atomically; deterministic mode: one workgroup per
     // input channel walks whole planes in a fixed order
     // 5 x 15 kernels on 16-byte aligned images: the matrix-core form (MCVC_WGRAD1_MFMA=0: the VALU kernel)
-    static const int mfma = [] { const char* e = getenv("MCVC_WGRAD1_MFMA"); return e ? atoi(e) : 1; }();
+    static const int mfma = mcvc_knob("MCVC_WGRAD1_MFMA", 1);
     if (mfma && p.KH == 5 && p.KW == 15 && p.pad_h == 2 && p.pad_w == 7 && p.W == 64 && (io.x_sh & 3) == 0 && (io.x_sc & 3) == 0 && (io.x_sb & 3) == 0 &&
         (io.dy_sh & 3) == 0 && (io.dy_sb & 3) == 0 && ((reinterpret_cast<unsigned long long>(io.x) | reinterpret_cast<unsigned long long>(io.dy)) & 15ull) == 0) {
         W1Args w{};

@@ -17,6 +17,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // The reference's CPU path is bit-reproducible run to run; this mode restores that property.
 int mcvc_deterministic();
 
+// ------------------------------------------------------------------------------------------------
+// Planner knobs.  In the product every knob IS its default: the call below is a constant, nothing reads the environment (the one
+// environment switch of the library is MCVC_DETERMINISTIC, net.hip).  The tuning tools (tools/conv_tune.py, wgrad_tune.py, gemm_*.py,
+// ab_*.sh) run against an EXPERIMENTS build of the same sources -- `MCVC_EXPERIMENTS=1 python __graft_entry__.py` compiles them with
+// -DMCVC_EXPERIMENTS into lib/libmcvc_hip_exp.so, selected with MCVC_LIB -- in which MCVC_<NAME> overrides the default, so every choice
+// recorded in DESIGN.md can be re-measured without shipping its switch.
+// ------------------------------------------------------------------------------------------------
+#ifdef MCVC_EXPERIMENTS
+#include <cstdlib>
+static inline int mcvc_knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline bool mcvc_knob_set(const char* name) { return getenv(name) != nullptr; }
+#else
+static inline int mcvc_knob(const char*, int dflt) { return dflt; }
+static inline bool mcvc_knob_set(const char*) { return false; }
+#endif
+
 static inline int cdiv_i(int a, int b) { return (a + b - 1) / b; }
 static inline long long cdiv_ll(long long a, long long b) { return (a + b - 1) / b; }
 static inline int round_up_i(int a, int b) { return cdiv_i(a, b) * b; }
@@ -56,7 +72,6 @@ struct ConvArgs {
     int out_mode;          // ConvOutMode
     int shuffle;           // 1: PixelShuffle(2) store  y[c=co>>2][2oh+((co>>1)&1)][2ow+(co&1)]
     int YH, YW;            // shuffle mode: bounds of the shuffled image (rows/cols beyond are not stored)
-    int dbg;               // timing-ablation bits (MCVC_CONV_DEBUG); 0 in production
     long long w_nstride;   // image n uses the packed weights at w + n*w_nstride (0: shared; Winograd: one matrix per transform point)
     int gemm;              // 1: GEMM mode (1x1 conv whose pixel tiles are contiguous): the input patch is streamed by LDS-DMA too
 };

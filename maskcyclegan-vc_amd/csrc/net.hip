@@ -286,7 +286,7 @@ static void run_conv(Exec& ex, const ConvProblem& p, int NB, ConvIO io, long lon
 
 static bool wino_env_enabled()
 {
-    static const int en = [] { const char* e = getenv("MCVC_WINO"); return e ? atoi(e) : 1; }();
+    static const int en = mcvc_knob("MCVC_WINO", 1);
     return en != 0;
 }
 static thread_local int t_no_wino = 0;          // (op-level entries that ask for the direct / staged-GEMM kernels)
@@ -296,7 +296,7 @@ static bool wino_enabled() { return wino_env_enabled() && !t_no_wino; }
 // tile count of upSample1, 256x32 re-reads V too often); knob: MCVC_WINO_CFG = planner index + 1
 static int wino_tile_cfg(int M, long long NT)
 {
-    static const int knob = [] { const char* e = getenv("MCVC_WINO_CFG"); return e ? atoi(e) : -1; }();
+    static const int knob = mcvc_knob("MCVC_WINO_CFG", -1);
     (void)M; (void)NT;
     return knob >= 0 ? knob : 2;
 }
@@ -327,18 +327,18 @@ static long long wino_chunk_tiles(int NB, long long tiles_per_sample)          /
 // (the last three with F(4x4,3x3) on downSample1/2 as well, MCVC_WINO43_NB: at one sample per pass that one costs 0.3 ms)
 static int wino4_min_nb()
 {
-    static const int nb = [] { const char* e = getenv("MCVC_WINO4_NB"); return e ? atoi(e) : 1; }();
+    static const int nb = mcvc_knob("MCVC_WINO4_NB", 1);
     return nb;
 }
 // fewest F(4x4,5x5) tiles in a pass (the GEMM's column count; 32-column granularity)
 static int wino4_min_tiles()
 {
-    static const int n = [] { const char* e = getenv("MCVC_WINO4_MIN_TILES"); return e ? atoi(e) : 64; }();
+    static const int n = mcvc_knob("MCVC_WINO4_MIN_TILES", 64);
     return n < 32 ? 32 : n;
 }
 static int wino43_min_nb()
 {
-    static const int nb = [] { const char* e = getenv("MCVC_WINO43_NB"); return e ? atoi(e) : 4; }();
+    static const int nb = mcvc_knob("MCVC_WINO43_NB", 4);
     return nb;
 }
 static bool wino4_applies(const Exec& ex, const ConvSpec& c, int NB, int H, int W)
@@ -407,7 +407,7 @@ static bool conv_wino(Exec& ex, const ConvSpec& c, const float* packed, int dgra
     const int nbc = wino_chunk(NB, (long long)TH * TW);
     if (!nbc || 36LL * (K > M ? K : M) * wino_chunk_tiles(NB, (long long)TH * TW) > ex.wino_cap) return false;
     if (ex.dry) return true;
-    static const int own_gemm = [] { const char* e = getenv("MCVC_WINO_GEMM"); return e ? atoi(e) : 1; }();
+    static const int own_gemm = mcvc_knob("MCVC_WINO_GEMM", 1);
     for (int b0 = 0; b0 < NB; b0 += nbc) {
         const int nb = NB - b0 < nbc ? NB - b0 : nbc;
         const long long NT = (long long)nb * TH * TW;
@@ -456,8 +456,8 @@ struct SgKind { int kind, taps, OH, OW; };
 static thread_local int t_no_sgemm = 0;
 static SgKind sgemm_kind(const ConvSpec& c, int NB, int H, int W)
 {
-    static const int min_nb = [] { const char* e = getenv("MCVC_SGEMM_NB"); return e ? atoi(e) : 1; }();
-    static const int min_cols = [] { const char* e = getenv("MCVC_SGEMM1D_COLS"); return e ? atoi(e) : 64; }();
+    static const int min_nb = mcvc_knob("MCVC_SGEMM_NB", 1);
+    static const int min_cols = mcvc_knob("MCVC_SGEMM1D_COLS", 64);
     SgKind k{0, 0, 0, 0};
     if (t_no_sgemm) return k;
     if (c.nbr > 2 || (c.cout_tot % 64) != 0 || (c.Cout % 32) != 0 || c.cin_pad != c.Cin) return k;
@@ -471,30 +471,16 @@ static SgKind sgemm_kind(const ConvSpec& c, int NB, int H, int W)
     return k;
 }
 static void sgemm_want(Exec& ex, long long floats) { if (floats > ex.sg_need) ex.sg_need = floats; }
-// K-split of a product with M x N outputs: enough 64 x 64 tiles x splits to occupy the chip, at least two 32-deep stages per split
-// K split of a product of `tiles` 64 x 64 output tiles whose shortest K range is Kmin: with fewer tiles than the chip has workgroup slots,
-// split until it is occupied (r2).  Experiment (r4, MCVC_SGEMM_WAVES=1, OFF): also split a tile count that is a small non-integer multiple of
-// the 512 slots (640 tiles = 1.25 rounds cost 2 rounds alone on the chip; split s makes the rounds 1/s as long:
-// cost(s) = ceil(tiles * s / slots) * (1 / s + c) + p * (s - 1)).  Measured SLOWER: bs=8 22.2-22.6 -> 23.0-23.2 ms, bs=32 76.0 -> 77.3 -- the
-// other lanes' kernels already fill a product's last round, and the extra slabs are traffic the lanes compete for.
+// K-split: the smallest power-of-two split (<= 8) that yields >= 256 workgroups while a slab keeps >= 64 k per half.  (A cost-model split
+// against round quantisation -- stream-K's effect with uniform splits -- was built in r4 and measured SLOWER inside the concurrent lanes: bs=8
+// 22.2-22.6 -> 23.0-23.2 ms, the other lanes' kernels already fill a product's last round; removed)
 static int split_by_cost(long long tiles, int Kmin)
 {
-    static const int wgs = [] { const char* e = getenv("MCVC_SGEMM_WGS"); return e ? atoi(e) : 256; }();
-    static const int maxsp = [] { const char* e = getenv("MCVC_SGEMM_MAXSPLIT"); return e ? atoi(e) : 8; }();
-    static const int waves = [] { const char* e = getenv("MCVC_SGEMM_WAVES"); return e ? atoi(e) : 0; }();
+    static const int wgs = mcvc_knob("MCVC_SGEMM_WGS", 256);
+    static const int maxsp = mcvc_knob("MCVC_SGEMM_MAXSPLIT", 8);
     int sp = 1;
     while (sp < maxsp && tiles * sp < wgs && (Kmin % (64 * sp)) == 0 && Kmin / (2 * sp) >= 64) sp *= 2;
-    if (!waves || tiles > 4096) return sp;
-    const double slots = 512.0, c = 0.06, p = 0.04;
-    double best = 1e30; int best_sp = sp;
-    for (int s = sp; s <= maxsp; s *= 2) {
-        if ((Kmin % (64 * s)) != 0 || Kmin / (2 * s) < 64) break;
-        const double rounds = (double)((tiles * s + 511) / 512);
-        (void)slots;
-        const double cost = rounds * (1.0 / s + c) + p * (s - 1);
-        if (cost < best - 1e-9) { best = cost; best_sp = s; }
-    }
-    return best_sp;
+    return sp;
 }
 static int sgemm_split(int M, long long N, int K)
 {
@@ -504,7 +490,7 @@ static int sgemm_split(int M, long long N, int K)
 // ---- implicit GEMM for the 3x3 stride-2 padding-1 layers (sgemm.h): no tap planes, no gather kernel -------------------------------------
 static bool igemm_enabled()
 {
-    static const int en = [] { const char* e = getenv("MCVC_IGEMM"); return e ? atoi(e) : 1; }();
+    static const int en = mcvc_knob("MCVC_IGEMM", 1);
     return en != 0;
 }
 static bool igemm_applies(const ConvSpec& c, int H, int W)
@@ -612,7 +598,7 @@ static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, i
     if (conv_wino(ex, c, packed, 0, NB, H, W, x, y, shuffle, 0)) { if (nsplit) *nsplit = 1; return; }
     if (c.wino3 && wino_enabled() && ex.wv && !shuffle && (H & 1) == 0 && (W & 1) == 0 && (c.cout_tot % 128) == 0 && wino43_applies(ex, c, NB, H / 2, W / 2)) {
         // ... as F(4x4,3x3): 36 points per 16 outputs
-        static const int en = [] { const char* e = getenv("MCVC_WINO3_FWD"); return e ? atoi(e) : 1; }();
+        static const int en = mcvc_knob("MCVC_WINO3_FWD", 1);
         const int OH = H / 2, OW = W / 2, K = 4 * c.Cin, M = c.cout_tot;
         const int TH = OH / 4, TW = OW / 4;
         const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, K > M ? K : M, 36);
@@ -645,7 +631,7 @@ static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, i
     }
     if (c.wino3 && wino_enabled() && ex.wv && !shuffle && (H & 1) == 0 && (W & 1) == 0 && (c.cout_tot % 128) == 0) {
         // stride-2 5x5 forward = 3x3 stride-1 conv over the four input phases: Winograd F(2x2,3x3), K = 4*Cin
-        static const int en = [] { const char* e = getenv("MCVC_WINO3_FWD"); return e ? atoi(e) : 1; }();
+        static const int en = mcvc_knob("MCVC_WINO3_FWD", 1);
         const int OH = H / 2, OW = W / 2, K = 4 * c.Cin, M = c.cout_tot;
         const int TH = (OH + 1) / 2, TW = (OW + 1) / 2;
         const int nbc = wino_chunk(NB, (long long)TH * TW);
@@ -723,7 +709,7 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
     }
     if (c.wino3 && wino_enabled() && ex.wv && wino43_applies(ex, c, NB, OH, OW) && 2 * OH == H && 2 * OW == W) {
         // ... as F(4x4,3x3)
-        static const int en = [] { const char* e = getenv("MCVC_WINO3"); return e ? atoi(e) : 1; }();
+        static const int en = mcvc_knob("MCVC_WINO3", 1);
         const int K = c.cout_tot, M = 4 * c.Cin;
         const int TH = OH / 4, TW = OW / 4;
         const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, K > M ? K : M, 36);
@@ -755,7 +741,7 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
     }
     if (c.wino3 && wino_enabled() && ex.wv) {
         // merged stride-2 data-gradient = a 3x3 stride-1 conv over dY with 4*Cin output channels: Winograd F(2x2,3x3)
-        static const int en = [] { const char* e = getenv("MCVC_WINO3"); return e ? atoi(e) : 1; }();
+        static const int en = mcvc_knob("MCVC_WINO3", 1);
         const int K = c.cout_tot, M = 4 * c.Cin;
         const int TH = (OH + 1) / 2, TW = (OW + 1) / 2;
         const int nbc = wino_chunk(NB, (long long)TH * TW);
@@ -788,7 +774,7 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
     }
     if (!ex.dry && (((ex.pack_skips & 1) && c.off_tk >= 0) || ((ex.pack_skips & 2) && (c.wino || c.wino3)))) { ex.fail(MCVC_ERR_INVALID); return; }
     if (!ex.dry && (ex.pack_skips & 8) && c.stride == 2) { ex.fail(MCVC_ERR_INVALID); return; }      // (mcvc_disc_pack_small: these copies are stale)
-    static const int ucls_nb = [] { const char* e = getenv("MCVC_DGRAD_CLASSES_NB"); return e ? atoi(e) : 8; }();
+    static const int ucls_nb = mcvc_knob("MCVC_DGRAD_CLASSES_NB", 8);
     const bool per_class = c.merged && c.off_dcls >= 0 && NB >= ucls_nb;
     if (c.merged && !per_class) {
         ConvProblem p{c.cout_tot, OH, OW, 4 * c.Cin, (H + 1) / 2, (W + 1) / 2, c.mg_kh, c.mg_kw, 1, c.mg_pad_h, c.mg_pad_w};
@@ -836,7 +822,7 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
 
 static int wgrad_cin1_enabled()
 {
-    static const int en = [] { const char* e = getenv("MCVC_WGRAD_CIN1"); return e ? atoi(e) : 1; }();
+    static const int en = mcvc_knob("MCVC_WGRAD_CIN1", 1);
     return en;
 }
 
@@ -881,7 +867,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         g.a = dyt; g.lda = c.cout_tot;                                        // dYt[n][co]
         g.b = xt; g.ldb = KT; g.bseg = KT; g.b_sn = 0;                        // XcolT[n][k]
         g.M = c.cout_tot; g.N = KT; g.K = (int)sg_rows; g.nsplit = sg_split;
-        static const int direct = [] { const char* e = getenv("MCVC_SGEMM_WGRAD_DIRECT"); return e ? atoi(e) : 1; }();
+        static const int direct = mcvc_knob("MCVC_SGEMM_WGRAD_DIRECT", 1);
         if (sg_split == 1 && direct && (c.Cout & 31) == 0) {
             // no K split: the product is added straight into the OIHW gradients (rows [0, Cout) -> the value tensor, the rest -> the gate
             // tensor) instead of a slab + dw_accum: a quarter of the dW-sized traffic of the deep layers and one launch less
@@ -925,7 +911,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
     }
     if (!done && c.wino && wino_enabled() && ex.wu && c.nbr == 1 && grads[c.wi[0]]) {
         // Winograd weight gradient: dU[xi] = dM[xi] V[xi]^T over the tiles, then dW += G^T dU G.  Operands tile-major.
-        static const int en = [] { const char* e = getenv("MCVC_WINO_WGRAD"); return e ? atoi(e) : 1; }();
+        static const int en = mcvc_knob("MCVC_WINO_WGRAD", 1);
         const int TH = (H + 1) / 2, TW = (W + 1) / 2;
         const int nbc = wino_chunk(NB, (long long)TH * TW);
         const long long NTc = wino_chunk_tiles(NB, (long long)TH * TW);
@@ -956,7 +942,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
     if (!done && c.wino3 && wino_enabled() && ex.wu && (H & 1) == 0 && (W & 1) == 0 && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]]) &&
         wino43_applies(ex, c, NB, OH, OW)) {
         // ... as F(4x4,3x3)
-        static const int en = [] { const char* e = getenv("MCVC_WINO3_WGRAD"); return e ? atoi(e) : 1; }();
+        static const int en = mcvc_knob("MCVC_WINO3_WGRAD", 1);
         const int K4 = 4 * c.Cin, M = c.cout_tot;
         const int TH = OH / 4, TW = OW / 4;
         const int nbc = wino4_chunk(ex, NB, (long long)TH * TW, M > K4 ? M : K4, 36);
@@ -986,7 +972,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
     if (!done && c.wino3 && wino_enabled() && ex.wu && (H & 1) == 0 && (W & 1) == 0 && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]])) {
         // stride-2 5x5 weight gradient in the phase formulation (see conv_fwd): dU[xi][co][4ci+2p+q] over the tiles, both
         // branches (value | gate) in one product, then the 3x3 blocks are scattered back into the two 5x5 gradients
-        static const int en = [] { const char* e = getenv("MCVC_WINO3_WGRAD"); return e ? atoi(e) : 1; }();
+        static const int en = mcvc_knob("MCVC_WINO3_WGRAD", 1);
         const int K4 = 4 * c.Cin, M = c.cout_tot;
         const int TH = (OH + 1) / 2, TW = (OW + 1) / 2;
         const int nbc = wino_chunk(NB, (long long)TH * TW);
@@ -1260,7 +1246,7 @@ static const DevUpdTable* dev_upd_table(int kind, Build&& build, const long long
             int cb = 32, ib = 32;
             // (25 taps: 32 x 16 filters = two per thread, 52 KB of LDS -- full 128-byte runs in the forward-type copies; measured against
             //  16 x 16: the family 0.733 -> 0.716 ms per bs=1 iteration, 1.26 -> 1.19 at bs=8.  MCVC_UPD_CB25=16 for the A/B)
-            static const int cb25 = [] { const char* e = getenv("MCVC_UPD_CB25"); return e ? atoi(e) : 32; }();
+            static const int cb25 = mcvc_knob("MCVC_UPD_CB25", 32);
             if (o.taps == 25) { cb = cb25 == 16 ? 16 : 32; ib = 16; }
             else if (o.taps == 3) ib = 64;
             else if (o.taps == 1) ib = 128;
@@ -1315,12 +1301,12 @@ static int update_net(const DevUpdTable* t, const float* const* params, const lo
 // ---- fused small-batch trunk layer (trunk_kernels.hip) ------------------------------------------------
 static bool trunk_enabled()
 {
-    static const int en = [] { const char* e = getenv("MCVC_TRUNK"); return e ? atoi(e) : 1; }();
+    static const int en = mcvc_knob("MCVC_TRUNK", 1);
     return en != 0;
 }
 
 // persistent 13-layer forward (trunk_fwd_net_kernel) instead of one fused launch per layer; knob MCVC_TRUNK_NET=0 for A/B runs
-static int g_trunk_net = [] { const char* e = getenv("MCVC_TRUNK_NET"); return e ? (atoi(e) != 0) : 1; }();
+static int g_trunk_net = mcvc_knob("MCVC_TRUNK_NET", 1) != 0;
 static bool trunk_net_enabled() { return g_trunk_net != 0; }
 static bool trunk_bwd_net_enabled() { return g_trunk_net == 1; }          // (2 = forward only)
 
@@ -1442,7 +1428,7 @@ static NormP normp(const float* const* params, float* const* grads, int g0, int 
 
 static int fuse_wino_norm()
 {
-    static const int en = [] { const char* e = getenv("MCVC_FUSE_WINO_NORM"); return e ? atoi(e) : 1; }();
+    static const int en = mcvc_knob("MCVC_FUSE_WINO_NORM", 1);
     return en;
 }
 
@@ -1817,14 +1803,14 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
     // small batch: the InstanceNorm backward of each layer is recomputed inside the data-gradient launch that consumes it (one thread
     // per channel of the workgroup's K slice) -- 2 dependent launches per residual block instead of 4.  Needs an un-split upstream
     // gradient (the fused staging does not sum slabs) and the fused data-gradient kernels for both convs of the block.
-    static const int fuse_knob = [] { const char* e = getenv("MCVC_TRUNK_BWD_FUSE"); return e ? atoi(e) : 1; }();
-    static const int batch_knob = [] { const char* e = getenv("MCVC_TRUNK_WGRAD_BATCH"); return e ? atoi(e) : 1; }();
+    static const int fuse_knob = mcvc_knob("MCVC_TRUNK_BWD_FUSE", 1);
+    static const int batch_knob = mcvc_knob("MCVC_TRUNK_WGRAD_BATCH", 1);
     SmallKJob wjobs[MCVC_SMALLK_MAX_JOBS];
     int nwjobs = 0;
     const bool batch_w = batch_knob && mcvc_wgrad_smallk_batch_applies(B, W4) && (W4 <= 128);
     // Persistent backward (trunk.h): the 12 dependent data-gradient layers of the six blocks in ONE launch, when every layer would take the
     // fused path anyway, the gradient arriving from conv1dto2d is not split into slabs and the staged gradients fit the LDS
-    static const int bwd_net_knob = [] { const char* e = getenv("MCVC_TRUNK_BWD_NET"); return e ? atoi(e) : 1; }();
+    static const int bwd_net_knob = mcvc_knob("MCVC_TRUNK_BWD_NET", 1);
     bool bwd_net = bwd_net_knob && trunk_bwd_net_enabled() && fuse_knob && trunk_enabled() && batch_w && !ex.dry && G && ex.sync &&
                    mcvc_trunk_bwd_net_applies(B, W4);
     for (int i = 0; i < 6 && bwd_net; ++i)
@@ -2022,7 +2008,7 @@ static DiscScratch disc_scratch(const DiscDims& d)
 // conv + activation pairs
 static int disc_out_direct()
 {
-    static const int en = [] { const char* e = getenv("MCVC_DISC_OUT"); return e ? atoi(e) : 1; }();
+    static const int en = mcvc_knob("MCVC_DISC_OUT", 1);
     return en;
 }
 
@@ -2041,7 +2027,7 @@ static bool disc_igemm(const DiscDims& d)
 // pass the gather kernel and the 2.25x larger product output are what counts (bs=32: -4.5 ms of staging per iteration).
 static int igemm_dgrad_min_nb()
 {
-    static const int nb = [] { const char* e = getenv("MCVC_IGEMM_DGRAD_NB"); return e ? atoi(e) : 4; }();
+    static const int nb = mcvc_knob("MCVC_IGEMM_DGRAD_NB", 4);
     return nb;
 }
 static bool disc_igemm_dgrad(const DiscDims& d) { return disc_igemm(d) && igemm_dgrad_min_nb() > 0 && d.B >= igemm_dgrad_min_nb(); }
@@ -2369,7 +2355,7 @@ static GenPackCfg gen_pack_cfg(int max_batch, int T)
     // every 5x5 layer of every such pass runs on the Winograd kernels (conv_wino / the wino3 branches take no fallback) when
     // the frame count keeps all image sizes even, the tile counts are inside the kernels' range and nothing was switched
     // off through the MCVC_WINO* knobs: then their direct K-major copies are not refreshed either
-    static const bool knobs_default = !getenv("MCVC_WINO") && !getenv("MCVC_WINO3") && !getenv("MCVC_WINO3_FWD") && !getenv("MCVC_WINO_GEMM");
+    static const bool knobs_default = !mcvc_knob_set("MCVC_WINO") && !mcvc_knob_set("MCVC_WINO3") && !mcvc_knob_set("MCVC_WINO3_FWD") && !mcvc_knob_set("MCVC_WINO_GEMM");
     const GenDims dm = gen_dims(max_batch, T);
     q.wino_only = q.fused && knobs_default && (T % 4) == 0 && T >= 32 && (long long)max_batch * 20 * dm.W4 <= 16384;
     // the 64-point weight sets of upSample1/2 only when some pass can take the F(4x4,5x5) path (wino4_applies); otherwise marked absent (bit 16)

@@ -152,92 +152,10 @@ __global__ void __launch_bounds__(256) wino3_input_phase_kernel(const Twin<Wino3
 }
 
 // tile-major twins for the weight gradient (16 tiles x 16 channels per workgroup, channel fastest)
-struct Wino3InputPhaseTKArgs { WinoXformArgs a; int XH; int XW; };
-__global__ void __launch_bounds__(256) wino3_input_phase_t_kernel(const Twin<Wino3InputPhaseTKArgs> tw)
-{
-    const Wino3InputPhaseTKArgs ka_ = tw.v[blockIdx.z];
-    const WinoXformArgs& a = ka_.a;
-    int XH = ka_.XH;
-    int XW = ka_.XW;
-    const int k = blockIdx.y * 16 + (threadIdx.x & 15);
-    const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (tile >= a.NTp || k >= a.C) return;
-    float* dst = a.v + (long long)tile * a.C + k;
-    const long long xs = (long long)a.NTp * a.C;
-    if (tile >= a.NT) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) dst[q * xs] = 0.f;
-        return;
-    }
-    const int ci = k >> 2, p = (k >> 1) & 1, q = k & 1;
-    const int per = a.TH * a.TW;
-    const int n = tile / per, r = tile - n * per;
-    const int ty = r / a.TW, tx = r - ty * a.TW;
-    const int i0 = 2 * ty - 1, j0 = 2 * tx - 1;
-    const float* src = a.x + (long long)n * a.x_sb + (long long)ci * a.x_sc;
-    float t[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float d[4];
-        const int ih = 2 * (i0 + i) + p;
-        const bool rok = (i0 + i >= 0) && (ih < XH);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int iw = 2 * (j0 + j) + q;
-            d[j] = (rok && j0 + j >= 0 && iw < XW) ? src[(long long)ih * a.x_sh + iw] : 0.f;
-        }
-        bt4(d, t[i]);
-    }
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        float col[4], o[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) col[i] = t[i][b];
-        bt4(col, o);
-#pragma unroll
-        for (int aa = 0; aa < 4; ++aa) dst[(long long)(aa * 4 + b) * xs] = o[aa];
-    }
-}
 
 // A3 (4x2) = [[1,0],[1,1],[1,-1],[0,-1]]:  dM = A3 dy A3^T
 __device__ __forceinline__ void a42(float d0, float d1, float o[4]) { o[0] = d0; o[1] = d0 + d1; o[2] = d0 - d1; o[3] = -d1; }
 
-__global__ void __launch_bounds__(256) wino3_dy_t_kernel(const Twin<WinoXformArgs> tw)
-{
-    const WinoXformArgs a = tw.v[blockIdx.z];
-    const int c = blockIdx.y * 16 + (threadIdx.x & 15);
-    const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (tile >= a.NTp || c >= a.C) return;
-    float* dst = a.v + (long long)tile * a.C + c;
-    const long long xs = (long long)a.NTp * a.C;
-    if (tile >= a.NT) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) dst[q * xs] = 0.f;
-        return;
-    }
-    const int per = a.TH * a.TW;
-    const int n = tile / per, r = tile - n * per;
-    const int ty = r / a.TW, tx = r - ty * a.TW;
-    const float* src = a.x + (long long)n * a.x_sb + (long long)c * a.x_sc;
-    float dy[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int oh = 2 * ty + i, ow = 2 * tx + j;
-            dy[i][j] = (oh < a.H && ow < a.W) ? src[(long long)oh * a.x_sh + ow] : 0.f;
-        }
-    float t0[4], t1[4];
-    a42(dy[0][0], dy[1][0], t0);
-    a42(dy[0][1], dy[1][1], t1);
-#pragma unroll
-    for (int aa = 0; aa < 4; ++aa) {
-        float o[4];
-        a42(t0[aa], t1[aa], o);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) dst[(long long)(aa * 4 + b) * xs] = o[b];
-    }
-}
 
 // dg' = G3^T dU G3 (3x3 per (co, k = 4ci+2p+q)), scattered into the OIHW gradient: dw[co][ci][2u'+p][2v'+q] += dg'[u'][v']
 struct Wino3DwKArgs { const float* du; float* dw0; float* dw1; int Cout; int nbr; int Cin; };
@@ -340,47 +258,6 @@ __global__ void __launch_bounds__(256) wino3_output_kernel(const Twin<WinoOutArg
 // dU[xi][co][ci] = sum_tile dM[xi][co][tile] * V[xi][ci][tile]: the tile index is the contraction dimension, so both
 // operands are stored tile-major ([xi][tile][channel]) -- the K-major layout the batched GEMM streams.  A workgroup
 // covers 16 tiles x 16 channels with the channel fastest, so every store is a 64-byte run.
-__global__ void __launch_bounds__(256) wino_input_t_kernel(const Twin<WinoXformArgs> tw)
-{
-    const WinoXformArgs a = tw.v[blockIdx.z];
-    const int c = blockIdx.y * 16 + (threadIdx.x & 15);
-    const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (tile >= a.NTp || c >= a.C) return;
-    float* dst = a.v + (long long)tile * a.C + c;
-    const long long xs = (long long)a.NTp * a.C;
-    if (tile >= a.NT) {
-#pragma unroll
-        for (int q = 0; q < 36; ++q) dst[q * xs] = 0.f;
-        return;
-    }
-    const int per = a.TH * a.TW;
-    const int n = tile / per, r = tile - n * per;
-    const int ty = r / a.TW, tx = r - ty * a.TW;
-    const int ih0 = 2 * ty - a.pad, iw0 = 2 * tx - a.pad;
-    const float* src = a.x + (long long)n * a.x_sb + (long long)c * a.x_sc;
-    float t[6][6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        float d[6];
-        const int ih = ih0 + i;
-        const bool rok = (ih >= 0) && (ih < a.H);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int iw = iw0 + j;
-            d[j] = (rok && iw >= 0 && iw < a.W) ? src[(long long)ih * a.x_sh + iw] : 0.f;
-        }
-        bt6(d, t[i]);
-    }
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-        float col[6], o[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) col[i] = t[i][b];
-        bt6(col, o);
-#pragma unroll
-        for (int aa = 0; aa < 6; ++aa) dst[(long long)(aa * 6 + b) * xs] = o[aa];
-    }
-}
 
 // A (6x2) = [[1,0],[1,1],[1,-1],[1,2],[1,-2],[0,1]]:  dM = A dy A^T
 __device__ __forceinline__ void a62(float d0, float d1, float o[6])
@@ -388,42 +265,6 @@ __device__ __forceinline__ void a62(float d0, float d1, float o[6])
     o[0] = d0; o[1] = d0 + d1; o[2] = d0 - d1; o[3] = d0 + 2.f * d1; o[4] = d0 - 2.f * d1; o[5] = d1;
 }
 
-__global__ void __launch_bounds__(256) wino_dy_t_kernel(const Twin<WinoXformArgs> tw)      // x = dY [N][C][H][W], H x W = conv output
-{
-    const WinoXformArgs a = tw.v[blockIdx.z];
-    const int c = blockIdx.y * 16 + (threadIdx.x & 15);
-    const int tile = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (tile >= a.NTp || c >= a.C) return;
-    float* dst = a.v + (long long)tile * a.C + c;
-    const long long xs = (long long)a.NTp * a.C;
-    if (tile >= a.NT) {
-#pragma unroll
-        for (int q = 0; q < 36; ++q) dst[q * xs] = 0.f;
-        return;
-    }
-    const int per = a.TH * a.TW;
-    const int n = tile / per, r = tile - n * per;
-    const int ty = r / a.TW, tx = r - ty * a.TW;
-    const float* src = a.x + (long long)n * a.x_sb + (long long)c * a.x_sc;
-    float dy[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int oh = 2 * ty + i, ow = 2 * tx + j;
-            dy[i][j] = (oh < a.H && ow < a.W) ? src[(long long)oh * a.x_sh + ow] : 0.f;
-        }
-    float t0[6], t1[6];                       // t[a][j] = A[a][0] dy[0][j] + A[a][1] dy[1][j]
-    a62(dy[0][0], dy[1][0], t0);
-    a62(dy[0][1], dy[1][1], t1);
-#pragma unroll
-    for (int aa = 0; aa < 6; ++aa) {
-        float o[6];
-        a62(t0[aa], t1[aa], o);               // dM[a][b] = t[a][0] A[b][0] + t[a][1] A[b][1]
-#pragma unroll
-        for (int b = 0; b < 6; ++b) dst[(long long)(aa * 6 + b) * xs] = o[b];
-    }
-}
 
 // ---- tile-major operands through an LDS transpose (r3) ---------------------------------------------------------------------------
 // The kernels above give a lane one (tile, channel) and let 16 lanes walk the channels: 64-byte stores and reads scattered over 16
@@ -568,11 +409,6 @@ static int xform_t_launch(const WinoXformArgs& a, int XH, int XW, double bytes, 
     TraceScope ts(K_ELEMENTWISE, s, 0.0, bytes);
     mcvc_launch(xform_t_kernel<KIND>, grid, dim3(256), lds, s, XformTKArgs{a, XH, XW});
     return (int)hipGetLastError();
-}
-static bool xform_t_on()
-{
-    static const int en = [] { const char* e = getenv("MCVC_XFORM_T_LDS"); return e ? atoi(e) : 1; }();
-    return en != 0;
 }
 
 // dg = G^T dU G, accumulated into the OIHW gradient.  One thread per (co, ci), ci fastest (coalesced reads of dU).
@@ -959,14 +795,15 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
     const int nxi = a.nxi > 0 ? a.nxi : 36;
     WinoGemmArgs b = a;
     // 32-column tiles when 64-column tiles would pad the N range by more than 10 % on a short range (ragged tile counts at B <= 2)
-    static const int knob = [] { const char* e = getenv("MCVC_WINO_BN"); return e ? atoi(e) : 0; }();
+    static const int knob = mcvc_knob("MCVC_WINO_BN", 0);
     const int pad64 = cdiv_i(a.N, 64) * 64, pad32 = cdiv_i(a.N, 32) * 32;
     bool narrow = (pad64 * 10 > pad32 * 11) && a.N <= 512 && a.ldb >= 32;
     if (knob == 32) narrow = a.ldb >= 32; else if (knob == 64) narrow = false;
     b.mt = a.M / 128;
     TraceScope ts(K_WINO_GEMM, s, 2.0 * nxi * a.M * a.N * a.K, 4.0 * nxi * ((double)a.K * a.M + (double)a.K * a.N + (double)a.M * a.N));
-    static const int cfg2 = [] { const char* e = getenv("MCVC_GEMM_CFG"); return e ? atoi(e) : 0; }();     // tuning: force a gemm2 shape
-    static const bool verbose = getenv("MCVC_GEMM_VERBOSE") != nullptr;        // one line per product: shapes for tools/gemm_bs1_shapes.py
+#ifdef MCVC_EXPERIMENTS                      // tile sweeps of tools/gemm_*.py: force one gemm2 shape (1-11: r2 sweep; 12-15: 128 x 128 tiles)
+    static const int cfg2 = mcvc_knob("MCVC_GEMM_CFG", 0);
+    static const bool verbose = mcvc_knob_set("MCVC_GEMM_VERBOSE");        // one line per product: shapes for tools/gemm_bs1_shapes.py
     if (verbose && mcvc_twin_phase() != 1) fprintf(stderr, "[gemm] nxi=%d M=%d N=%d K=%d lda=%d ldb=%d twin=%d\n", nxi, a.M, a.N, a.K, a.lda, a.ldb, mcvc_twin_phase() == 2);
     switch (cfg2) {
         case 1: return gemm2_launch<128, 64, 16, 4>(b, nxi, s);
@@ -984,10 +821,11 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
         case 13: return gemm2_launch<128, 128, 32, 3>(b, nxi, s);
         case 14: return gemm2_launch<128, 128, 16, 6>(b, nxi, s);
         case 15: return gemm2_launch<128, 128, 32, 2>(b, nxi, s);
-        case 16: return gemm2_launch<128, 96, 16, 4>(b, nxi, s);
-        case 17: return gemm2_launch<128, 160, 16, 4>(b, nxi, s);
         default: break;
     }
+#else
+    constexpr int cfg2 = 0;
+#endif
     // long-K products (the F(2x2,3x3) layers: K = 4*Cin or Cout >= 512): 64x64 tiles with 32-deep stages measured 10-20 % faster than
     // 128x64 / 128x32 with 16-deep stages (profiles/r02_gemm_tune.log) -- twice the workgroups and half the barriers per k
     // ... unless the narrow tiles leave the busiest compute unit clearly less to do (r4, profiles/r04b_gemm_bs1_shapes.log): every product of
@@ -998,29 +836,14 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
     // 128 x 64 tiles and one operand read per MFMA instead of 1.5-2.  r4, cold operands, alone on the chip: 36 x 512 x 2560 x 512 558 -> 502 us,
     // 36 x 512 x 5120 x 512 878 -> 803, 64 x 256 x 2560 x 512 388 -> 356; bs=32 iteration 73.5-74.2 -> 72.0-72.1 ms.  Not for small grids: tile
     // rounds (bs=8: 21.7-22.0 -> 22.4 ms when forced) and few-column weight-gradient products (N = 256 ... 512) lose.
-    static const int big = [] { const char* e = getenv("MCVC_GEMM_BIG"); return e ? atoi(e) : 1; }();
+    static const int big = mcvc_knob("MCVC_GEMM_BIG", 1);
     if (cfg2 == 0 && big && a.N >= 1280 && (a.K % 16) == 0 && (long long)cdiv_i(a.N, 128) * (a.M / 128) * nxi >= 1280)
         return gemm2_launch<128, 128, 16, 4>(b, nxi, s);
     auto rounds_cost = [&](int bm, int bn) { return (double)cdiv_i(cdiv_i(a.N, bn) * (a.M / bm) * nxi, 256) * bm * bn; };
-    static const int costsel = [] { const char* e = getenv("MCVC_GEMM_COST"); return e ? atoi(e) : 1; }();
+    static const int costsel = mcvc_knob("MCVC_GEMM_COST", 1);
     if (cfg2 == 0 && a.K >= 512 && (a.K % 32) == 0 && (a.M % 64) == 0) {
         if (!(costsel && a.ldb >= 32 && rounds_cost(128, 32) < 0.94 * rounds_cost(64, 64))) return gemm2_launch<64, 64, 32, 4>(b, nxi, s);
         return gemm2_launch<128, 32, 16, 4>(b, nxi, s);
-    }
-    // short-K products (the Winograd weight gradients at one or two samples per pass: K = tiles = 96 ... 128): every stage of the tile in
-    // flight at once (six 16-deep stages) instead of a four-stage ring that is mostly fill and drain
-    static const int shortk = [] { const char* e = getenv("MCVC_GEMM_SHORTK"); return e ? atoi(e) : 0; }();
-    if (cfg2 == 0 && shortk && a.K <= 16 * 6) {
-        if (shortk == 1) return gemm2_launch<128, 64, 16, 6>(b, nxi, s);
-        if (shortk == 2) return gemm2_launch<64, 64, 16, 6>(b, nxi, s);
-        if (shortk == 3) return gemm2_launch<128, 32, 16, 6>(b, nxi, s);
-    }
-    // one-tile-wide shapes: N in (64, 96] / (128, 160] columns (the one- and two-sample passes): a 128 x N tile reads U once instead of once
-    // per 32-column tile and a third / a fifth of the workgroups carry the prologue + epilogue (MCVC_GEMM_WIDE=0: the narrow tiles)
-    static const int wide = [] { const char* e = getenv("MCVC_GEMM_WIDE"); return e ? atoi(e) : 0; }();
-    if (cfg2 == 0 && wide && (a.K % 16) == 0) {
-        if (a.N > 64 && a.N <= 96 && a.ldb >= 96) return gemm2_launch<128, 96, 16, 4>(b, nxi, s);
-        if (a.N > 128 && a.N <= 160 && a.ldb >= 160) return gemm2_launch<128, 160, 16, 4>(b, nxi, s);
     }
     if (narrow) {
         b.nt = cdiv_i(a.N, 32);
@@ -1040,20 +863,12 @@ int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s)
 
 int mcvc_wino_input_t_launch(const WinoXformArgs& a, hipStream_t s)
 {
-    if (xform_t_on()) return xform_t_launch<0>(a, 0, 0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp), s);
-    dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
-    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp));
-    mcvc_launch(wino_input_t_kernel, grid, dim3(256), 0, s, a);
-    return (int)hipGetLastError();
+    return xform_t_launch<0>(a, 0, 0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp), s);
 }
 
 int mcvc_wino_dy_t_launch(const WinoXformArgs& a, hipStream_t s)
 {
-    if (xform_t_on()) return xform_t_launch<1>(a, 0, 0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp), s);
-    dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
-    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp));
-    mcvc_launch(wino_dy_t_kernel, grid, dim3(256), 0, s, a);
-    return (int)hipGetLastError();
+    return xform_t_launch<1>(a, 0, 0, 4.0 * ((double)a.N * a.C * a.H * a.W + 36.0 * a.C * a.NTp), s);
 }
 
 int mcvc_wino_dw_launch(const float* du, float* dw, int Cout, int Cin, hipStream_t s)
@@ -1090,20 +905,12 @@ int mcvc_wino3_input_phase_launch(const WinoXformArgs& a, int XH, int XW, hipStr
 
 int mcvc_wino3_input_phase_t_launch(const WinoXformArgs& a, int XH, int XW, hipStream_t s)
 {
-    if (xform_t_on()) return xform_t_launch<2>(a, XH, XW, 4.0 * ((double)a.N * (a.C / 4) * XH * XW + 16.0 * a.C * a.NTp), s);
-    dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
-    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * (a.C / 4) * XH * XW + 16.0 * a.C * a.NTp));
-    mcvc_launch(wino3_input_phase_t_kernel, grid, dim3(256), 0, s, Wino3InputPhaseTKArgs{a, XH, XW});
-    return (int)hipGetLastError();
+    return xform_t_launch<2>(a, XH, XW, 4.0 * ((double)a.N * (a.C / 4) * XH * XW + 16.0 * a.C * a.NTp), s);
 }
 
 int mcvc_wino3_dy_t_launch(const WinoXformArgs& a, hipStream_t s)
 {
-    if (xform_t_on()) return xform_t_launch<3>(a, 0, 0, 4.0 * ((double)a.N * a.C * a.H * a.W + 16.0 * a.C * a.NTp), s);
-    dim3 grid((unsigned)cdiv_i(a.NTp, 16), (unsigned)cdiv_i(a.C, 16));
-    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.N * a.C * a.H * a.W + 16.0 * a.C * a.NTp));
-    mcvc_launch(wino3_dy_t_kernel, grid, dim3(256), 0, s, a);
-    return (int)hipGetLastError();
+    return xform_t_launch<3>(a, 0, 0, 4.0 * ((double)a.N * a.C * a.H * a.W + 16.0 * a.C * a.NTp), s);
 }
 
 int mcvc_wino3_dw_launch(const float* du, float* dw0, float* dw1, int Cout, int nbr, int Cin, hipStream_t s)

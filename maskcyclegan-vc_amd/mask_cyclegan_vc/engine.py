@@ -25,6 +25,8 @@ import torch
 
 from . import _hip
 from ._hip import check, lib, ptr, ptr_table, stream
+from .lanes import get_lanes
+from .optim_state import load_optimizer_state_dict, optimizer_state_dict
 from .parallel import FlatGradReducer
 from .schedule import StepSchedule
 
@@ -48,8 +50,6 @@ def _pair(k):
 def _align4(n):
     return (n + 3) & ~3
 
-
-_LANES = {}      # (device, caller stream, probe switches) -> (legacy sides, aux streams, probed sides, probe report)
 
 class _FlatGroup:
     """Parameters of several modules re-homed into one flat buffer (+ gradient and Adam buffers)."""
@@ -77,7 +77,6 @@ class _FlatGroup:
                 off += _align4(n)
             self.views.append(vs); self.grad_views.append(gs)
         self.numel = total
-        self.grad2 = None
         self.offsets = []                 # flat-buffer offset of every tensor, per module
         off = 0
         for ps in param_lists:
@@ -86,12 +85,6 @@ class _FlatGroup:
                 o.append(off)
                 off += _align4(p.numel())
             self.offsets.append(o)
-
-    def second_grad_views(self):
-        """A second gradient buffer with the same layout (backward passes that must not race with the writers of ``grad``)."""
-        if self.grad2 is None:
-            self.grad2 = torch.zeros_like(self.grad)
-        return [[self.grad2[o:o + g.numel()].view(g.shape) for o, g in zip(os_, gs)] for os_, gs in zip(self.offsets, self.grad_views)]
 
 
 class TrainEngine:
@@ -122,13 +115,9 @@ class TrainEngine:
             self._p_tab[n] = ptr_table(ps)
             it = iter(gv)
             self._g_tab[n] = ptr_table([None if i in _DEAD else next(it) for i in range(len(ps))])
-        self._g_tab2 = None                    # second generator-gradient buffer (196 MB): created on first use (MCVC_GROUPED_IDENT=1 only)
-        # optimizer.step() fused with the weight re-pack (mcvc_gen_update_ranges / mcvc_disc_update_batch, r4): ONE launch per network (pair)
+        # optimizer.step() is fused with the weight re-pack (mcvc_gen_update_ranges / mcvc_disc_update_batch, r4): ONE launch per network (pair)
         # updates a tile of filters, keeps it in LDS and writes every packed copy from there -- no per-step `pack` launches, no second read
-        # of the OIHW tensors, forward AND backward copies fresh when the step returns (the separate refresh of the backward-only copies
-        # beside the next discriminator phase disappears).  Bit-identical to Adam + re-pack (tests/test_hip_update.py).
-        # MCVC_FUSED_UPDATE=0: the two-launch form.
-        self.fused_update = os.environ.get("MCVC_FUSED_UPDATE", "1") != "0"
+        # of the OIHW tensors, forward AND backward copies fresh when the step returns.  Bit-identical to Adam + re-pack (tests/test_hip_update.py).
         ll = lambda v: (ctypes.c_longlong * len(v))(*v)     # noqa: E731
         self._numel = {n: ll([p.numel() for p in ps]) for n, ps in zip(G_NAMES, g_lists)}
         self._numel.update({n: ll([0 if i in _DEAD else p.numel() for i, p in enumerate(ps)]) for n, ps in zip(D_NAMES, d_all)})
@@ -151,111 +140,41 @@ class TrainEngine:
         # streams (lane 0 = the caller's stream) and overlap on the chip; join points are stream-event waits.
         self.concurrent = True
         self._serial = False                   # bench / tools: submit the task graphs of the CURRENT schedule in order on one stream (per-kernel tracing)
-        # two sets of side lanes: the four-lane schedule keeps the streams (and the auxiliary streams created right behind them) it was
-        # tuned on -- with probed lanes its auxiliary streams land on the lanes' queues: bs=8 30.5 -> 32.3 ms, bs=32 116.5 -> 118.0 -- the
-        # grouped / pipelined schedule uses lanes probed onto distinct hardware queues (_pick_side_streams)
-        # One set of lanes per (device, caller stream) and process: a second engine in the same process (bench.py's extra batch sizes, an
-        # evaluation engine beside the training one) reuses them -- every new HIP stream lands on one of the 4 hardware queues in pool
-        # order, and a later engine's fresh streams landed on worse combinations (nested bs=8 24.1 ms against 22.6 in a process of its own)
-        key = (torch.device(dev).index or 0, torch.cuda.current_stream(dev).cuda_stream, os.environ.get("MCVC_STREAM_PROBE", "1"),
-               os.environ.get("MCVC_LANE_PRIO"))
-        lanes = _LANES.get(key)
-        if lanes is None:
-            legacy = [torch.cuda.Stream(device=dev) for _ in range(3)]
-            # inside a backward pass the weight-gradient kernels are off the critical path: one auxiliary stream per lane
-            aux = [torch.cuda.Stream(device=dev) for _ in range(4)]
-            # (a stream gets its hardware queue at first USE: touch these in creation order before the probe puts work on its candidates)
-            _t = torch.zeros(64, device=dev)
-            for st in legacy + aux:
-                with torch.cuda.stream(st):
-                    _t.add_(1.0)
-            torch.cuda.synchronize(dev)
-            probed = self._pick_side_streams(dev)
-            lanes = _LANES[key] = (legacy, aux, probed, self.queue_probe)
-        self._sides_legacy, self._aux, self._sides_probed, self.queue_probe = lanes
-        self.aux_wgrad = os.environ.get("MCVC_AUX_WGRAD", "1") != "0"
-        # ... for the generators only: the four discriminator lanes already occupy the four hardware queues, and giving each a
-        # second stream for its weight gradients measured 1.2 % slower (101.5 vs 102.8 it/s)
-        self.aux_wgrad_d = False
-        # HIP-graph replay of the two phases is available but OFF by default: measured on MI355X / ROCm 7.2 it does not
-        # shorten the step (the host is not the limiter: 19.7 ms replayed vs 19.5 ms eager) and capturing lanes together
-        # with the auxiliary streams crashes inside hipStreamEndCapture.  Also tried and dropped at 13.8 ms/step: one graph
-        # per network pass (forward passes: 13.9 ms, no gain; with backward passes: 16.7 ms, slower) and one host thread per
-        # lane (no change -- the ~4 ms of real host work per step is not on the critical path; tools/host_overhead.py).
-        self.use_graphs = False
-        self._graphs, self._eager_runs = {}, {}
-        # Round 2: the per-queue timeline (profiles/r02_lanes_bs1_eager.txt) shows the two generator lanes running one AFTER the other in
-        # the backward rounds: a backward pass is ~70 launches of ~10 us plus ~60 event record / wait calls, the host needs about as long
-        # to submit it as the GPU needs to run it, and lane 1 is only submitted when lane 0's submission is finished.  So every
-        # network PASS (one library call) is captured once into its own HIP graph -- its auxiliary stream is a first-level fork of the
-        # capture stream, the form that survives hipStreamEndCapture -- and a round is two (four) graph launches on two (four) streams.
-        # MCVC_PASS_GRAPHS: "0" off, "1" all passes, or a comma list of pass kinds (G, Gb, D, Db)
-        pg = os.environ.get("MCVC_PASS_GRAPHS", "0")       # measured: neutral for forward / discriminator passes, +1.2 ms for the forked backward
-        self.pass_graphs = pg != "0"
-        self._pass_kinds = None if pg in ("0", "1") else set(pg.split(","))
-        self._pgraphs = {}
-        self._capture_stream = torch.cuda.Stream(device=dev)
-        # the discriminators' weight re-pack after their Adam step is needed only ~1.5 ms later (after the next iteration's
-        # four generator forwards): it runs on its own stream and the discriminator forwards wait for its event
+        # lanes: the caller's stream + side streams on distinct hardware queues (lanes.py)
+        self._sides_legacy, self._aux, self._sides_probed, self.queue_probe = get_lanes(dev)
+        self.aux_wgrad = True                  # generators' weight gradients on auxiliary streams ...
+        self.aux_wgrad_d = False               # ... not the discriminators': their four lanes occupy the four hardware queues (1.2 % slower)
+        # (HIP-graph replay of a phase / of a network pass: built in rounds 1-2, measured slower or equal on ROCm 7.2, removed in r5 -- DESIGN 5.)
         self._task_events = {}
         self._g_fwd_packed = False
         self._g_grad_clean = self._d_grad_clean = False
-        self.fuse_g_update = os.environ.get("MCVC_FUSE_G_UPDATE", "1") != "0"
         # Grouped launches (csrc/twin.h): G_A2B / G_B2A -- and the discriminator pairs -- run the same layer schedule on different weights,
         # so every kernel of a pair of passes goes out ONCE with gridDim.z = 2 instead of twice on two lanes: half the launches, twice the
-        # workgroups per launch, the two chains in lock-step.  Lane 0 then carries the generator chain (both generators), lane 1 the
-        # first-step discriminator pair.  MCVC_GROUPED=0 restores the four-lane schedule; MCVC_GROUPED_MAX_B: largest per-pass batch B for
-        # which the grouped schedule is used (large batches fill the chip per network anyway).
-        self.grouped = os.environ.get("MCVC_GROUPED", "1") != "0"
-        # measured (r03, ms per iteration, four-lane / grouped + pipelined): bs=1 6.99 / 6.74, bs=2 10.95 / 10.98, bs=4 17.81 / 17.73,
-        # bs=8 31.2 / 32.0, bs=32 117.8 / 118.0 -- from 8 samples per pass the kernels fill the chip per network and the four-lane schedule stays
-        self.grouped_max_b = int(os.environ.get("MCVC_GROUPED_MAX_B", "4"))
-        # ... with the identity passes G(real, ones) as their own chain (forward, loss, backward on lane 2, beside the translation ->
-        # cycle chain) instead of inside batched 2B passes: they depend on nothing else, and their weight gradients are ordered in front
-        # of the cycle backward by one event
-        self.grouped_ident = os.environ.get("MCVC_GROUPED_IDENT", "0") != "0"
+        # workgroups per launch, the two chains in lock-step.  ``grouped_max_b``: largest per-pass batch for which the grouped schedule is
+        # used (from 8 samples per pass the kernels fill the chip per network and the four-lane schedule is as fast: DESIGN section 5).
+        self.grouped = True
+        self.grouped_max_b = 4
         # Pipelined step (needs the grouped schedule): iteration t's discriminator phase is issued together with iteration t+1's
-        # generator phase, as one task graph (_pipelined_step); MCVC_PIPELINE=0 keeps the two phases of an iteration back to back.
-        self.pipelined = os.environ.get("MCVC_PIPELINE", "1") != "0"
-        self.ranged_update = os.environ.get("MCVC_RANGED_UPDATE", "1") != "0"
+        # generator phase, as one task graph (_pipelined_step); False keeps the two phases of an iteration back to back (tests).
+        self.pipelined = True
         # Merged forwards (r4): the discriminator phase's generator forwards of iteration t (train.py:259-273) read the same generator
         # weights as the generator phase's forwards of iteration t+1 (:203-210) and need no gradient: they ride in those passes as one
-        # more sample (_merged_step).  MCVC_MERGED_FWD=0 restores the separate passes of _pipelined_step.
-        # Measured on one MI355X (r4, bs=1, ms per iteration, same box back to back): separate passes 6.00-6.16, merged 6.20-6.26, merged +
-        # the identity sample's backward ahead of the chain (MCVC_EARLY_IDENT=1) 6.49-6.57.  The merged passes do 0.8 ms less kernel work
-        # per iteration, but a three-sample pass takes 1.0 ms against 0.6 for one sample (the Winograd products are MFMA-bound, not
-        # launch-bound) and it runs ALONE where the separate passes overlapped two chains: same critical chain, same wall.  Default: merged
-        # on data-parallel ranks only -- there one grouped persistent trunk pass in flight instead of two leaves half the compute units to
-        # RCCL's kernels (csrc/trunk.h residency rule) -- separate passes on a single GPU.
-        mf = os.environ.get("MCVC_MERGED_FWD")
-        self.merged = (self.reducer.world > 1) if mf is None else (mf != "0")
-        self.early_ident = os.environ.get("MCVC_EARLY_IDENT", "0") != "0"
-        # Experiment (r4): the identity sample rides in the translation FORWARD pass (cheap) but its BACKWARD runs as its own one-sample
-        # window on lane 2, beside the cycle backward, into the second gradient buffer; the last pass of the chain is then one sample.
-        self.split_ident_bwd = os.environ.get("MCVC_SPLIT_IDENT_BWD", "0") != "0"
-        self.bwd_no_join = os.environ.get("MCVC_BWD_NO_JOIN", "1") != "0"
+        # more sample (_merged_step).  Slower than the separate passes on one GPU (6.20-6.26 vs 6.00-6.16 ms at bs=1: DESIGN section 5);
+        # default on data-parallel ranks only -- there one grouped persistent trunk pass in flight instead of two leaves half the compute
+        # units to RCCL's kernels (csrc/trunk.h residency rule).
+        self.merged = self.reducer.world > 1
         self.trunk_fallback = False            # a persistent trunk launch faulted in this process: per-layer launches from then on (check_faults)
         self._pending_D = None                  # (input set, discriminator lr) of the iteration whose discriminator phase is still to run
-        self._skip_dgen = os.environ.get("MCVC_DEBUG_SKIP_DGEN") == "1"
-        if self._skip_dgen:
-            import warnings
-            warnings.warn("MCVC_DEBUG_SKIP_DGEN=1: the discriminator phase's generator forwards are SKIPPED -- the discriminators train on "
-                          "stale buffers; this is a timing ablation, never a training configuration")
         self.slots_done = torch.zeros(2 * _BLOCK, device=dev)          # loss slots of the last COMPLETE iteration
         self._done_host = torch.zeros(2 * _BLOCK).pin_memory()
         self._done_event = torch.cuda.Event()
         self._done_valid = False
-        self.split_d_min_batch = int(os.environ.get("MCVC_SPLIT_D_MIN_BATCH", "4"))
+        self.split_d_min_batch = 4
         self._timeline = None
-        self._pack_stream = torch.cuda.Stream(device=dev)
-        self._d_pack_event = None
-        # data parallel: start the discriminator gradient all-reduce at the end of an iteration and finish the update
-        # (wait + Adam + re-pack) where the discriminators are next used, i.e. after the next generator forwards
-        # With more than one rank the discriminators' Adam step (+ re-pack) is queued where they are next needed (lane 2 of the next generator
-        # phase) so that the gradient exchange hides behind the generator forwards.  On one GPU the same deferral is SLOWER (MCVC_DEFER_D=1:
-        # 6.91 -> 7.26 ms at bs=1, 30.4 -> 31.3 at bs=8): Adam's 0.7 GB of traffic beside the two generator forwards costs them more than
-        # the 0.11 ms it takes alone between two iterations.
-        self.defer_d_update = self.reducer.world > 1 or os.environ.get("MCVC_DEFER_D", "0") != "0"
+        # data parallel (plain schedules): start the discriminator gradient all-reduce at the end of an iteration and finish the update
+        # where the discriminators are next used, i.e. after the next generator forwards -- the exchange hides behind them.  On one GPU
+        # the same deferral measured slower (6.91 -> 7.26 ms at bs=1: the update's 0.7 GB of traffic beside the generator forwards).
+        self.defer_d_update = self.reducer.world > 1
         self._pending_d_lr = None
         # ... and the generator gradient all-reduce starts per parameter range while the last backward passes are still
         # running: the library records an event when a range's gradients are complete (mcvc_gen_backward_overlap)
@@ -268,14 +187,10 @@ class TrainEngine:
             self._ms[n] = (evs, (ctypes.c_void_p * 4)(*[e.cuda_event for e in evs]))
         # flat-buffer ranges [lo, hi) of parameters [100,110), [24,100), [0,24) of each generator
         self._g_ranges = {}
-        self._g_ranges5 = {}
-        self.fine_update = os.environ.get("MCVC_FINE_UPDATE", "1") != "0"
         base = self.g_group.grad.data_ptr()
         for n, gv in zip(G_NAMES, self.g_group.grad_views):
             off = [(g.data_ptr() - base) // 4 for g in gv] + [(gv[-1].data_ptr() - base) // 4 + _align4(gv[-1].numel())]
             self._g_ranges[n] = [(off[100], off[110]), (off[24], off[100]), (off[0], off[24])]
-            # the ranged update's five parts (library range_mask bits 1, 2, 8, 16, 32), in the order a backward pass finishes them
-            self._g_ranges5[n] = [(off[100], off[110]), (off[24], off[100]), (off[12], off[24]), (off[4], off[12]), (off[0], off[4])]
         self._workspaces = {}
         self._max_B = batch_size
         self._use(batch_size)
@@ -286,61 +201,6 @@ class TrainEngine:
     @property
     def _sides(self):
         return self._sides_probed if self._use_grouped() else self._sides_legacy
-
-    # ---- lanes on distinct hardware queues -----------------------------------------------------------------------------
-    def _pick_side_streams(self, dev, want=3):
-        """Three side streams that share a hardware queue neither with each other nor with the caller's stream.
-
-        ROCm multiplexes HIP streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and two streams on one queue serialise: a
-        kernel on one waits for everything queued earlier on the other -- a false dependency between lanes that the task graph does
-        not contain (tools/queue_probe.py prints the classes; PyTorch's pooled streams land on the queues in no simple order).  So the
-        lanes are CHOSEN: candidates are probed against the streams already picked (a ~0.25 ms spin on one, a tiny kernel on the other;
-        the tiny kernel finishing only with the spin = same queue) and kept when independent.  MCVC_STREAM_PROBE=0: take the first
-        three pool streams as before."""
-        cands = [torch.cuda.Stream(device=dev) for _ in range(16)]
-        self.queue_probe = None
-        if os.environ.get("MCVC_STREAM_PROBE", "1") == "0":
-            return cands[:want]
-        main = torch.cuda.current_stream(dev)
-        x = torch.zeros(256, device=dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        spin = 2_000_000
-        torch.cuda.synchronize(dev)
-        e0.record(); torch.cuda._sleep(spin); e1.record(); torch.cuda.synchronize(dev)
-        spin = max(1000, int(spin * 0.25 / max(e0.elapsed_time(e1), 1e-3)))
-        e0.record(); torch.cuda._sleep(spin); e1.record(); torch.cuda.synchronize(dev)
-        spin_ms = e0.elapsed_time(e1)
-
-        def delays(a, b):          # does a spin on stream a hold back a kernel queued afterwards on stream b?
-            torch.cuda.synchronize(dev)
-            start, done = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            with torch.cuda.stream(a):
-                start.record(a)
-                torch.cuda._sleep(spin)
-            with torch.cuda.stream(b):
-                x.add_(1.0)
-                done.record(b)
-            torch.cuda.synchronize(dev)
-            return start.elapsed_time(done) > 0.6 * spin_ms
-        picked = []
-        for c in cands:
-            # (work queued on ANY stream after null-stream work waits for it -- the legacy default-stream rule -- so against a null main
-            # stream only the other direction identifies a shared queue)
-            indep = delays(c, main) is False and (main.cuda_stream == 0 or not delays(main, c))
-            indep = indep and all(not delays(c, p) and not delays(p, c) for p in picked)
-            if indep:
-                picked.append(c)
-                if len(picked) == want:
-                    break
-        self.queue_probe = {"independent_lanes": len(picked), "spin_ms": spin_ms, "main_is_null_stream": main.cuda_stream == 0}
-        for c in cands:                # fewer than `want` independent queues (GPU_MAX_HW_QUEUES < 4): fill up with what there is
-            if len(picked) < want and c not in picked:
-                picked.append(c)
-        prio = os.environ.get("MCVC_LANE_PRIO")      # experiment: comma list of side lanes (1..3) that get a high-priority stream
-        if prio:
-            for ln in prio.split(","):
-                picked[int(ln) - 1] = torch.cuda.Stream(device=dev, priority=-1)
-        return picked
 
     # ---- activations / workspaces: static shapes per batch size (graph-capturable), created on first use -----------
     def _use(self, B):
@@ -373,7 +233,6 @@ class TrainEngine:
                 g_stash1=[f(L.mcvc_gen_stash_floats(B, T)) for _ in range(2)],       # cycle passes
                 d_stash1=[f(L.mcvc_disc_stash_floats(B, T)) for _ in range(4)],
                 d_stash2=[f(L.mcvc_disc_stash_floats(B2, T)) for _ in range(4)],
-                g_stash3=[f(L.mcvc_gen_stash_floats(B, T)) for _ in range(2)],       # identity passes as their own chain (grouped schedule)
                 g_scratch=[f(max(L.mcvc_gen_scratch_floats(B, T), L.mcvc_gen_scratch_floats(B2, T), L.mcvc_gen_scratch_floats(B3, T) if mg else 0))
                            for _ in range(6)],           # one per concurrent pass
                 d_scratch=[f(max(L.mcvc_disc_scratch_floats(B, T), L.mcvc_disc_scratch_floats(B2, T))) for _ in range(4)],
@@ -415,7 +274,7 @@ class TrainEngine:
         D-phase's generator forwards beside the G-phase's = 4; a data-parallel rank leaves one pass's worth of compute units to RCCL's kernels.
         Re-evaluated whenever the schedule changes (the identity cut-off ends the merged schedule)."""
         if self._use_grouped():
-            inflight = 4 if ((not self._use_merged() and not self._serial_fwd()) or (self.early_ident and self.reducer.world == 1)) else 2
+            inflight = 4 if (not self._use_merged() and not self._serial_fwd()) else 2
         else:
             inflight = 2
         inflight += 1 if self.reducer.world > 1 else 0
@@ -435,15 +294,12 @@ class TrainEngine:
                       file=sys.stderr, flush=True)
 
     # ---- thin call helpers ------------------------------------------------------------------------
-    def _repack1(self, n, sets=3, ranges=7):
-        if sets == 2 and self.fused_update:
-            return                              # (the fused update wrote the backward-only copies together with the forward ones)
+    def _repack1(self, n):
+        """Full refresh of one network's packed copies from its parameters: where weights arrive from outside the optimizer step
+        (construction, load_state_dict, a larger batch than any so far, a phase called on its own after the caller wrote parameters)."""
         if n in G_NAMES:
-            # every generator pass of this engine has batch <= 2B at T frames: at small batch the trunk layers run on the
-            # fused kernels and their generic K-major copies need no refresh (the library falls back to the full pack).
-            # sets: 1 = what a forward pass reads, 2 = what only a backward pass reads (mcvc_gen_pack_sets)
-            # (largest pass: two samples per input sample -- three with the merged forwards)
-            check(self.L.mcvc_gen_pack_ranges(self._p_tab[n], ptr(self.packed[n]), self._per_pass() * self._max_B, self.T, sets, ranges, stream()), "pack " + n)
+            # (largest pass: two samples per input sample -- three with the merged forwards; the library sizes the copies for it)
+            check(self.L.mcvc_gen_pack_ranges(self._p_tab[n], ptr(self.packed[n]), self._per_pass() * self._max_B, self.T, 3, 7, stream()), "pack " + n)
         else:
             # (every discriminator pass of this engine has at most 2 * max_B samples)
             check(self.L.mcvc_disc_pack_batch(self._p_tab[n], ptr(self.packed[n]), 2 * self._max_B, self.T, stream()), "pack " + n)
@@ -495,40 +351,13 @@ class TrainEngine:
             main.wait_stream(streams[ln])
 
     def _aux_ptr(self, lane):
-        import ctypes
-        import os
-        only = os.environ.get("MCVC_AUX_LANES")            # experiment knob: comma list of lanes that get an auxiliary stream
-        if only is not None and str(lane) not in only.split(","):
-            return None
         if not self.aux_wgrad:
             return None
         if self._use_grouped():
             # grouped schedules: the generator chain's weight gradients (lane 0, the two backward rounds) run on lane 3's stream, idle by
-            # then and on a hardware queue of its own; the identity chain (aux lane 1) keeps its weight gradients on its own stream
+            # then and on a hardware queue of its own
             return ctypes.c_void_p(self._sides[2].cuda_stream) if lane == 0 else None
         return ctypes.c_void_p(self._aux[lane].cuda_stream)
-
-    def _pass(self, key, fn):
-        """Run one network pass (a library call with static arguments): eagerly the first two times (lazy kernel attributes, event pool),
-        then captured once into a HIP graph and replayed on the current stream."""
-        if not self.pass_graphs or (self._pass_kinds is not None and key[0] not in self._pass_kinds):
-            return fn()
-        key = key + (self.L.mcvc_get_deterministic(),)          # the accumulation mode is baked into a captured pass
-        ent = self._pgraphs.get(key)
-        if ent is None:
-            ent = self._pgraphs[key] = [0, None]
-        if ent[1] is None:
-            if ent[0] < 2:
-                ent[0] += 1
-                return fn()
-            cur = torch.cuda.current_stream(self.device)
-            cur.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self._capture_stream):
-                fn()
-            ent[1] = g
-            torch.cuda.current_stream(self.device).wait_stream(self._capture_stream)
-        ent[1].replay()
 
     def _twin(self, f0, f1):
         """Two identical call sequences on different networks as ONE set of grouped launches (gridDim.z = 2; _hip.twin)."""
@@ -539,44 +368,31 @@ class TrainEngine:
 
     def _G(self, name, x, mask, out, stash, nb, lane=0):
         sc = self.g_scratch[lane]
-        self._pass(("G", name, x.data_ptr(), 0 if mask is None else mask.data_ptr(), out.data_ptr(), stash.data_ptr(), nb, lane),
-                   lambda: check(self.L.mcvc_gen_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(mask), ptr(out), ptr(stash),
-                                                         ptr(sc), sc.numel(), nb, self.T, stream()), "gen_forward"))
+        check(self.L.mcvc_gen_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(mask), ptr(out), ptr(stash), ptr(sc), sc.numel(), nb, self.T,
+                                      stream()), "gen_forward")
 
-    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0, milestones=False, aux_lane=None, ms_of=None, second=False, no_join=False,
-               stash_nb=None, stash_b0=0):
+    def _G_bwd(self, name, mask, dout, dx, acc, stash, nb, lane=0, milestones=False, aux_lane=None, ms_of=None, no_join=False, stash_nb=None, stash_b0=0):
         """``lane`` picks the scratch buffer; ``aux_lane`` (default: the same) the auxiliary weight-gradient stream -- the two halves of a
         grouped pass use different scratch buffers but the same streams and milestone events (``ms_of``).  ``stash_nb``: batch of the forward
         pass that wrote ``stash`` when this pass back-propagates through its samples [stash_b0, stash_b0 + nb) only (mcvc_gen_backward_window)."""
         sc = self.g_scratch[lane]
         ms = self._ms[ms_of or name][1] if milestones else None
         aux = self._aux_ptr(lane if aux_lane is None else aux_lane)
-        gtab = self._second_tab(name) if second else self._g_tab[name]      # second: weight gradients into the second buffer
-        self._pass(("Gb", name, 0 if mask is None else mask.data_ptr(), dout.data_ptr(), 0 if dx is None else dx.data_ptr(), acc, stash.data_ptr(),
-                    nb, lane, bool(milestones), self.aux_wgrad, second, no_join, stash_nb, stash_b0),
-                   lambda: check(self.L.mcvc_gen_backward_window(self._p_tab[name], ptr(self.packed[name]), gtab, ptr(mask), ptr(dout),
-                                                                 ptr(dx), acc, ptr(stash), stash_nb or nb, stash_b0, ptr(sc), sc.numel(), nb, self.T,
-                                                                 stream(), aux, ms, (1 if no_join else 0) | (2 if milestones else 0)), "gen_backward"))
+        check(self.L.mcvc_gen_backward_window(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name], ptr(mask), ptr(dout), ptr(dx), acc, ptr(stash),
+                                              stash_nb or nb, stash_b0, ptr(sc), sc.numel(), nb, self.T, stream(), aux, ms,
+                                              (1 if no_join else 0) | (2 if milestones else 0)), "gen_backward")
 
     def _D(self, name, x, out, stash, nb, lane=0):
         sc = self.d_scratch[lane]
-        self._pass(("D", name, x.data_ptr(), out.data_ptr(), stash.data_ptr(), nb, lane),
-                   lambda: check(self.L.mcvc_disc_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(out), ptr(stash), ptr(sc),
-                                                          sc.numel(), nb, self.T, stream()), "disc_forward"))
+        check(self.L.mcvc_disc_forward(self._p_tab[name], ptr(self.packed[name]), ptr(x), ptr(out), ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream()),
+              "disc_forward")
 
     def _D_bwd(self, name, dlogit, dx, acc, stash, with_weight_grads, nb, lane=0, aux_stream=None):
         sc = self.d_scratch[lane]
         aux = ctypes.c_void_p(aux_stream.cuda_stream) if (aux_stream is not None and with_weight_grads and self.aux_wgrad) else \
             (self._aux_ptr(lane) if (with_weight_grads and self.aux_wgrad_d) else None)
-        self._pass(("Db", name, dlogit.data_ptr(), 0 if dx is None else dx.data_ptr(), acc, stash.data_ptr(), bool(with_weight_grads), nb, lane),
-                   lambda: check(self.L.mcvc_disc_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name] if with_weight_grads else None,
-                                                           ptr(dlogit), 1, ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(), aux),
-                                 "disc_backward"))
-
-    def _second_tab(self, name):
-        if self._g_tab2 is None:
-            self._g_tab2 = {n: ptr_table(gv) for n, gv in zip(G_NAMES, self.g_group.second_grad_views())}
-        return self._g_tab2[name]
+        check(self.L.mcvc_disc_backward(self._p_tab[name], ptr(self.packed[name]), self._g_tab[name] if with_weight_grads else None, ptr(dlogit), 1,
+                                        ptr(dx), acc, ptr(stash), ptr(sc), sc.numel(), nb, self.T, stream(), aux), "disc_backward")
 
     def _slot(self, i):
         return self.slots[i:i + 1]
@@ -594,43 +410,18 @@ class TrainEngine:
         n, loss_dst, term_dst = comb
         check(self.L.mcvc_loss_combine(ptr(self._slot(_pair(first))), n, loss_dst, term_dst, ptr(self.slots), stream()), "loss_combine")
 
-    def _adam(self, grp, lr):
-        grp.step += 1
-        check(self.L.mcvc_adam_step(ptr(grp.flat), ptr(grp.grad), ptr(grp.exp_avg), ptr(grp.exp_avg_sq), grp.numel, float(lr),
-                                    self.betas[0], self.betas[1], self.eps, grp.step, self.reducer.grad_scale, stream()), "adam_step")
-        # the raw-pointer update does not bump the parameters' autograd version counters: drop the modules' own packed-weight
-        # caches so that a later module-API forward (validation, in-process inference) re-packs from the new values
-        for n in (G_NAMES if grp is self.g_group else D_NAMES):
-            self.nets[n]._packed_version = None
-            self.nets[n]._bf16_version = None
-
-    def _adam_range(self, grp, lo, hi, lr, step, second=False):
-        """Adam on ``[lo, hi)`` of a flat group with step count ``step``, clearing the gradients it has consumed (the next iteration
-        accumulates into clean buffers without a separate memset); ``second``: the gradient is grad + grad2."""
-        g2 = grp.grad2[lo:hi] if (second and grp.grad2 is not None) else None
-        check(self.L.mcvc_adam_step2(ptr(grp.flat[lo:hi]), ptr(grp.grad[lo:hi]), ptr(g2), 1, ptr(grp.exp_avg[lo:hi]), ptr(grp.exp_avg_sq[lo:hi]),
-                                     hi - lo, float(lr), self.betas[0], self.betas[1], self.eps, step, self.reducer.grad_scale, stream()), "adam_step2")
-
-    def _adam_generator(self, name, step, lr):
-        """Adam on ONE generator's slice of the flat buffer (both slices of an iteration share the step count)."""
-        grp = self.g_group
-        lo, hi = self._g_ranges[name][2][0], self._g_ranges[name][0][1]
-        check(self.L.mcvc_adam_step(ptr(grp.flat[lo:hi]), ptr(grp.grad[lo:hi]), ptr(grp.exp_avg[lo:hi]), ptr(grp.exp_avg_sq[lo:hi]), hi - lo,
-                                    float(lr), self.betas[0], self.betas[1], self.eps, step, self.reducer.grad_scale, stream()), "adam_step")
-        self.nets[name]._packed_version = None
-        self.nets[name]._bf16_version = None
-
     def _per_pass(self):
         """Samples per generator pass and input sample (the library sizes the packed copies for the largest pass)."""
         return 3 if (self.merged and self._merged_ok(self._max_B)) else 2
 
-    def _update_gen(self, name, range_mask, lr, step, second=False, zero=True):
+    def _update_gen(self, name, range_mask, lr, step, zero=True):
         """optimizer.step() on the parameter ranges ``range_mask`` of ONE generator fused with the refresh of every packed copy derived
-        from them (train.py:242; mcvc_gen_update_ranges).  ``second``: the gradient is grad + grad2; ``zero``: clear it behind the read."""
+        from them (train.py:242; mcvc_gen_update_ranges).  ``zero``: clear the gradient behind the read.  The raw-pointer update does not
+        bump the parameters' autograd version counters: the module's own packed-weight caches are dropped so that a later module-API
+        forward (validation, in-process inference) re-packs from the new values."""
         grp = self.g_group
-        g2 = grp.grad2 if (second and grp.grad2 is not None) else None
         check(self.L.mcvc_gen_update_ranges(self._p_tab[name], self._numel[name], ptr(self.packed[name]), self._per_pass() * self._max_B, self.T,
-                                            range_mask, ptr(grp.flat), ptr(grp.grad), ptr(g2), ptr(grp.exp_avg), ptr(grp.exp_avg_sq), float(lr),
+                                            range_mask, ptr(grp.flat), ptr(grp.grad), None, ptr(grp.exp_avg), ptr(grp.exp_avg_sq), float(lr),
                                             self.betas[0], self.betas[1], self.eps, step, self.reducer.grad_scale, 1 if zero else 0, stream()),
               "gen_update " + name)
         self.nets[name]._packed_version = None
@@ -651,13 +442,18 @@ class TrainEngine:
         st = self.d_group.step
         for a, b in (D_NAMES[:2], D_NAMES[2:]):
             self._twin(lambda a=a: self._update_disc(a, lr, st, zero), lambda b=b: self._update_disc(b, lr, st, zero))
-        self._d_pack_event = None
+
+    def _update_gens(self, lr, zero=False):
+        """Both generators, all ranges (the plain schedules' generator update): one grouped launch."""
+        self.g_group.step += 1
+        st = self.g_group.step
+        self._twin(lambda: self._update_gen(G_NAMES[0], 7, lr, st, zero), lambda: self._update_gen(G_NAMES[1], 7, lr, st, zero))
 
     # ---- the two phases -------------------------------------------------------------------------------
     def generator_phase(self, real_A, mask_A, real_B, mask_B, fuse_update=False):
-        """train.py:195-242.  ``fuse_update`` (what ``step()`` uses on one rank): each lane also applies Adam to the generator whose last
-        backward pass it ran and refreshes that generator's FORWARD weight copies (train.py:242 + re-pack) -- no join, one optimizer
-        launch per generator, and the backward-only copies are refreshed later, beside the discriminator phase."""
+        """train.py:195-242 on four lanes (more than ``grouped_max_b`` samples per pass).  ``fuse_update`` (what ``step()`` uses): each lane
+        also runs the optimizer step of the generator whose last backward pass it ran, fused with the refresh of its packed copies
+        (train.py:242) -- no join of the lanes, one launch per generator."""
         B, B2 = self.B, 2 * self.B
         m = self.mel
         sc = self.sched
@@ -677,9 +473,8 @@ class TrainEngine:
         # The phase as a dependency graph over four lanes.  Lane 0 follows real_A -> fake_B -> cycle_A -> D_A2 and back, lane 1 follows
         # real_B -> fake_A -> cycle_B -> D_B2 and back: these two are the critical path.  The first-step adversarial terms D_A(fake_A),
         # D_B(fake_B) need only the translated batches: lanes 2 and 3 run their forward, loss and data-gradient WHILE lanes 0/1 are in the
-        # cycle forwards (round 2 ran them after, four discriminators abreast).  Cross-lane edges: the translated batches (g0, g1), the
-        # adversarial gradients that the cycle backward accumulates onto (dA, dB), and the two backward passes of one generator, which
-        # accumulate into the same weight gradients (c0, c1).
+        # cycle forwards.  Cross-lane edges: the translated batches (g0, g1), the adversarial gradients that the cycle backward accumulates
+        # onto (dA, dB), and the two backward passes of one generator, which accumulate into the same weight gradients (c0, c1).
         cl, il = sc.cycle_loss_lambda, sc.identity_loss_lambda
         # After the identity cut-off (train.py:314-315: lambda = 0 for the rest of training, 98 % of a default run) the identity passes are
         # dead code -- their loss term weighs 0 and so does every gradient behind it; like the discriminators' weight gradients of this
@@ -700,7 +495,6 @@ class TrainEngine:
 
         def adv(name, i, x, gx, acc):
             def run(ln):
-                self._wait_d_pack()            # discriminator weights changed at the end of the previous iteration
                 self._D(name, x, do[i], ds[i], B, ln)                                                      # :211-216
                 self._lsgan(do[i], 1.0, 1.0, 4 + i, dl[i])                                                 # :227-231
                 self._D_bwd(name, dl[i], gx, acc, ds[i], False, B, ln)         # discriminators contribute data-gradients only
@@ -734,11 +528,7 @@ class TrainEngine:
         def update(name):
             def run(ln):
                 self.reducer.wait(self.device)             # (no-op on one GPU)
-                if self.fused_update:
-                    self._update_gen(name, 7, g_lr, g_step, zero=False)
-                    return
-                self._adam_generator(name, g_step, g_lr)
-                self._repack1(name, 1)
+                self._update_gen(name, 7, g_lr, g_step, zero=False)
             return run
         assert G_NAMES[0] == "generator_A2B"
         self._run_tasks([
@@ -760,17 +550,16 @@ class TrainEngine:
         ] + ([(2, queue_reduce, (), None)] if (fuse_update and ov) else [])
           + ([(0, update("generator_A2B"), (), None), (1, update("generator_B2A"), (), None)] if fuse_update else []))
         self._g_fwd_packed = bool(fuse_update)
-        self._d_pack_event = None
         self._combine(0, self._comb_g)          # g_loss and its terms, summed in the reference's order (:233-237)
 
     def _use_grouped(self):
-        return self.grouped and self.B <= self.grouped_max_b and not self.use_graphs and not self.pass_graphs
+        return self.grouped and self.B <= self.grouped_max_b
 
     # ---- grouped schedule: the two phases as parts that the plain and the pipelined step assemble into task graphs ----------------
-    def _g_parts(self, inp, fuse_update, own_d_update=True, ident_second=False, zeroing_update=False, ranged=False):
+    def _g_parts(self, inp, fuse_update, own_d_update=True, zeroing_update=False, ranged=False):
         """Closures of the generator phase (train.py:195-242) in grouped launches.  ``own_d_update``: the first-step adversarial pair
-        completes a deferred discriminator update / waits for the asynchronous re-pack itself (plain step); the pipelined step orders
-        the discriminators' update in front of the adversarial pairs through the task graph instead."""
+        completes a deferred discriminator update itself (plain step); the pipelined step orders the discriminators' update in front of
+        the adversarial pairs through the task graph instead."""
         real_A, mask_A, real_B, mask_B = inp
         B, B2 = self.B, 2 * self.B
         m = self.mel
@@ -784,8 +573,8 @@ class TrainEngine:
         A2B, B2A = G_NAMES
         ov = self.overlap_g_reduce
         ms_on = ov or ranged                   # milestone events of the last backward pass: gradient exchange and / or ranged update
-        ident = self.grouped_ident and il != 0
         ident_dead = il == 0                   # (after the identity cut-off the identity passes are dead code: see generator_phase)
+        nbt = B if ident_dead else B2          # (the halves of the batched buffers are contiguous: translation first, identity second)
         g_lr = sc.g_opt_lr
         P = {}
 
@@ -800,33 +589,19 @@ class TrainEngine:
                                  [real_A, real_B, real_B, real_A, mask_A, mask_B])     # one launch; the masks' second halves stay all-ones
 
         def fwd2(ln):                                                                                       # :203, :205, :207-210
-            nb = B if (ident or ident_dead) else B2    # (the halves of the batched buffers are contiguous: translation first, identity second)
-            self._twin(lambda: self._G(A2B, self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], nb, 0),
-                       lambda: self._G(B2A, self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], nb, 1))
-
-        def ident_fwd(ln):                             # identity_B = G_A2B(real_B, ones), identity_A = G_B2A(real_A, ones): forward, loss
-            self._twin(lambda: self._G(A2B, self.in_A2B[B:], self.mask_A2B[B:], identity_B, self.g_stash3[0], B, 2),
-                       lambda: self._G(B2A, self.in_B2A[B:], self.mask_B2A[B:], identity_A, self.g_stash3[1], B, 3))
-            self._twin(lambda: self._l1(identity_B, real_B, il, g_identity_B, 3), lambda: self._l1(identity_A, real_A, il, g_identity_A, 2))   # :223-224
-
-        def ident_bwd(ln):
-            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B[B:], g_identity_B, None, 0, self.g_stash3[0], B, 2, aux_lane=1, second=ident_second),
-                       lambda: self._G_bwd(B2A, self.mask_B2A[B:], g_identity_A, None, 0, self.g_stash3[1], B, 3, aux_lane=1, second=ident_second))
-
-        def ident_chain(ln):
-            ident_fwd(ln)
-            ident_bwd(ln)
+            self._twin(lambda: self._G(A2B, self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], nbt, 0),
+                       lambda: self._G(B2A, self.in_B2A, self.mask_B2A, self.out_B2A, self.g_stash2[1], nbt, 1))
 
         def cycle_half(k):
             if k == 0:
                 self._G(B2A, fake_B, None, m["cycle_A"], self.g_stash1[0], B, 0)                           # :204 (mask of ones)
                 self._l1(m["cycle_A"], real_A, cl, m["g_cycle_A"], 0)                                       # :219
-                if not ident and not ident_dead:
+                if not ident_dead:
                     self._l1(identity_B, real_B, il, g_identity_B, 3)                                       # :224
             else:
                 self._G(A2B, fake_A, None, m["cycle_B"], self.g_stash1[1], B, 1)                           # :206
                 self._l1(m["cycle_B"], real_B, cl, m["g_cycle_B"], 1)                                       # :220
-                if not ident and not ident_dead:
+                if not ident_dead:
                     self._l1(identity_A, real_A, il, g_identity_A, 2)                                       # :223
 
         def cycle(ln):
@@ -840,40 +615,22 @@ class TrainEngine:
         def adv1(ln):
             if own_d_update:
                 self._finish_d_update()        # data parallel: the D all-reduce of the previous iteration hides behind the generator forwards
-                self._wait_d_pack()            # discriminator weights changed at the end of the previous iteration
             self._twin(lambda: adv_half("discriminator_A", 0, fake_A, g_fake_A, 0), lambda: adv_half("discriminator_B", 1, fake_B, g_fake_B, 0))
             if own_d_update and fuse_update and not self._d_grad_clean:
                 self.d_group.grad.zero_()      # free once their Adam step is queued: cleared here, on the side lane (99 MB memset)
                 self._d_grad_clean = True
 
         def adv2(ln):
-            if own_d_update:
-                self._wait_d_pack()
             self._twin(lambda: adv_half("discriminator_A2", 2, m["cycle_A"], m["g_cycle_A"], 1),
                        lambda: adv_half("discriminator_B2", 3, m["cycle_B"], m["g_cycle_B"], 1))
 
-        # The cycle pass's weight gradients (auxiliary stream) outlast its data-gradient chain by ~0.2 ms; the translation pass needs only
-        # the data gradient, so it starts without that join: its own weight gradients queue behind them on the same auxiliary stream
-        # (same tensors, in order), it works in other scratch buffers (4, 5: free since D-phase(t)'s generator forwards), and its final
-        # join covers both passes.  (MCVC_BWD_NO_JOIN=0: join after every pass.)
-        nj = self.bwd_no_join and ident
-        fs = (4, 5) if nj else (0, 1)
-
         def bwd_cycle(ln):      # cycle_A = G_B2A(fake_B) adds to d(fake_B), cycle_B = G_A2B(fake_A) to d(fake_A)
-            self._twin(lambda: self._G_bwd(B2A, None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B, 0, aux_lane=0, no_join=nj),
-                       lambda: self._G_bwd(A2B, None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, 1, aux_lane=0, no_join=nj))
-
-        split_ib = bool(ident_second) and not ident and not ident_dead and self.split_ident_bwd
+            self._twin(lambda: self._G_bwd(B2A, None, m["g_cycle_A"], g_fake_B, 1, self.g_stash1[0], B, 0, aux_lane=0),
+                       lambda: self._G_bwd(A2B, None, m["g_cycle_B"], g_fake_A, 1, self.g_stash1[1], B, 1, aux_lane=0))
 
         def bwd_final(ln):      # the last pass over each generator; its gradient ranges become final one after the other (milestone events)
-            nb = B if (ident or ident_dead or split_ib) else B2
-            snb = B2 if split_ib else None          # (split: the translation sample = the first half of the two-sample stash)
-            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], nb, fs[0], ms_on, aux_lane=0, ms_of=A2B, stash_nb=snb),
-                       lambda: self._G_bwd(B2A, self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], nb, fs[1], ms_on, aux_lane=0, ms_of=A2B, stash_nb=snb))
-
-        def ident_bwd_win(ln):  # the identity sample = the window [B, 2B) of the same stash; weight gradients inline, second gradient buffer
-            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B[B:], g_identity_B, None, 0, self.g_stash2[0], B, 2, aux_lane=1, second=True, stash_nb=B2, stash_b0=B),
-                       lambda: self._G_bwd(B2A, self.mask_B2A[B:], g_identity_A, None, 0, self.g_stash2[1], B, 3, aux_lane=1, second=True, stash_nb=B2, stash_b0=B))
+            self._twin(lambda: self._G_bwd(A2B, self.mask_A2B, self.gout_A2B, None, 0, self.g_stash2[0], nbt, 0, ms_on, aux_lane=0, ms_of=A2B),
+                       lambda: self._G_bwd(B2A, self.mask_B2A, self.gout_B2A, None, 0, self.g_stash2[1], nbt, 1, ms_on, aux_lane=0, ms_of=A2B))
 
         def queue_reduce(ln):
             # data parallel: range k of BOTH generators is final at milestone k of the grouped pass; same collective order on every rank
@@ -885,88 +642,52 @@ class TrainEngine:
                 lo, hi = self._g_ranges[n][2]
                 self.reducer.reduce_range_after_(self.g_group.grad, lo, hi, self._task_events.get("f") if self.concurrent else None)
 
-        def update(ln):
+        def update(ln):         # optimizer step of both generators + every packed copy, one grouped launch (train.py:242)
             self.reducer.wait(self.device)             # (no-op on one GPU)
-            if self.fused_update:
-                self.g_group.step += 1
-                st = self.g_group.step
-                self._twin(lambda: self._update_gen(A2B, 7, g_lr, st, second=ident_second and zeroing_update, zero=zeroing_update),
-                           lambda: self._update_gen(B2A, 7, g_lr, st, second=ident_second and zeroing_update, zero=zeroing_update))
-                return
-            if zeroing_update:                         # (pipelined step: the gradients are cleared as they are consumed)
-                self.g_group.step += 1
-                self._adam_range(self.g_group, 0, self.g_group.numel, g_lr, self.g_group.step, second=ident_second)
-                for n in G_NAMES:
-                    self.nets[n]._packed_version = None
-                    self.nets[n]._bf16_version = None
-            else:
-                self._adam(self.g_group, g_lr)         # one launch over both generators
-            self._twin(lambda: self._repack1(A2B, 1), lambda: self._repack1(B2A, 1))
+            self._update_gens(g_lr, zero=zeroing_update)
 
         def update_range(k, last):
             """Optimizer step (+ re-pack) of part k of both generators as grouped launches: 0 = up-sampling blocks + last conv, 1 = residual
             trunk, 2 = downSample2 + conv2dto1d, 3 = downSample1, 4 = conv1 -- the order in which a backward pass finishes them.  Parts 0-3
             wait for the pass's milestone events: their gradients are final while the pass is still running, so only conv1's (0.01 % of the
-            parameters) is left behind the pass (r4: the head used to be ONE part of 150 us at the end of the critical chain)."""
+            parameters) is left behind the pass."""
             mask = (1, 2, 8, 16, 32)[k]        # library range_mask of part k: [100,110), [24,100), [12,24), [4,12), [0,4)
-            fine = self.fine_update            # (MCVC_FINE_UPDATE=0: the head as ONE part behind the pass -- the A/B of the finer milestones)
-            if not fine and k == 4:
-                mask = 4
 
             def run(ln):
-                if not fine and k in (2, 3):
-                    return
                 if k < 4:
                     torch.cuda.current_stream(self.device).wait_event(self._ms[A2B][0][k])
                 if k == 0:
                     self.g_group.step += 1
                 step = self.g_group.step
-                (a0, a1), (b0, b1) = (self._g_ranges5[A2B][k], self._g_ranges5[B2A][k]) if fine or k < 2 else (self._g_ranges[A2B][2], self._g_ranges[B2A][2])
-                if self.fused_update:
-                    self._twin(lambda: self._update_gen(A2B, mask, g_lr, step, second=ident_second),
-                               lambda: self._update_gen(B2A, mask, g_lr, step, second=ident_second))
-                else:
-                    self._twin(lambda: self._adam_range(self.g_group, a0, a1, g_lr, step, second=ident_second),
-                               lambda: self._adam_range(self.g_group, b0, b1, g_lr, step, second=ident_second))
-                    self._twin(lambda: self._repack1(A2B, 1, mask), lambda: self._repack1(B2A, 1, mask))
-                if last:
-                    for n in G_NAMES:
-                        self.nets[n]._packed_version = None
-                        self.nets[n]._bf16_version = None
+                self._twin(lambda: self._update_gen(A2B, mask, g_lr, step), lambda: self._update_gen(B2A, mask, g_lr, step))
             return run
 
         def post():
             self._g_fwd_packed = bool(fuse_update)
             self._combine(0, self._comb_g)
-        P.update(split_ib=split_ib, ident_bwd_win=ident_bwd_win, update_range=update_range, pre=pre, fwd2=fwd2, ident_chain=ident_chain, ident_fwd=ident_fwd, ident_bwd=ident_bwd, cycle=cycle, adv1=adv1, adv2=adv2, bwd_cycle=bwd_cycle, bwd_final=bwd_final,
-                 queue_reduce=queue_reduce, update=update, post=post, ident=ident, ov=ov)
+        P.update(update_range=update_range, pre=pre, fwd2=fwd2, cycle=cycle, adv1=adv1, adv2=adv2, bwd_cycle=bwd_cycle, bwd_final=bwd_final,
+                 queue_reduce=queue_reduce, update=update, post=post, ov=ov)
         return P
 
     def generator_phase_grouped(self, real_A, mask_A, real_B, mask_B, fuse_update=False):
         """train.py:195-242 with the two generators (and each discriminator pair) in grouped launches: the same dataflow as
-        ``generator_phase`` on three lanes.  Lane 0: both translation passes, both cycle passes, the second-step discriminators, both
-        backward rounds, the update.  Lane 1: the first-step adversarial pair D_A(fake_A) | D_B(fake_B), which needs only the translated
-        batches and runs beside the cycle forwards.  Lane 2: the identity chain (forward, loss, backward), which needs nothing; its
-        weight gradients add into the same tensors as the other backward passes', so it is complete ("i") before the first of them."""
-        # with the update inside the phase, the identity chain's weight gradients go to the second gradient buffer and Adam consumes the
-        # sum, clearing both (same arithmetic as the pipelined step, which runs that chain beside the backward rounds)
-        second = bool(fuse_update) and self.reducer.world == 1 and self.grouped_ident
-        p = self._g_parts((real_A, mask_A, real_B, mask_B), fuse_update, ident_second=second, zeroing_update=bool(fuse_update))
+        ``generator_phase`` on two lanes.  Lane 0: both translation (+ identity) passes, both cycle passes, the second-step discriminators,
+        both backward rounds, the update.  Lane 1: the first-step adversarial pair D_A(fake_A) | D_B(fake_B), which needs only the
+        translated batches and runs beside the cycle forwards."""
+        p = self._g_parts((real_A, mask_A, real_B, mask_B), fuse_update, zeroing_update=bool(fuse_update))
         p["pre"]()
-        ident, ov = p["ident"], p["ov"]
+        ov = p["ov"]
         self._run_tasks([
             (0, p["fwd2"], (), "g"),
-        ] + ([(2, p["ident_chain"], (), "i")] if ident else []) + [
             (0, p["cycle"], (), None),
             (1, p["adv1"], ("g",), "d1"),
             (0, p["adv2"], (), None),
-            (0, p["bwd_cycle"], ("d1", "i") if ident else ("d1",), None),
+            (0, p["bwd_cycle"], ("d1",), None),
             (0, p["bwd_final"], (), "f"),
         ] + ([(1, p["queue_reduce"], (), None)] if (fuse_update and ov) else [])
           + ([(0, p["update"], (), None)] if fuse_update else []))
-        self._d_pack_event = None
         if fuse_update:
-            self._g_grad_clean = True          # (cleared by the Adam launch that consumed them)
+            self._g_grad_clean = True          # (cleared by the update launch that consumed them)
         p["post"]()
 
     def _d_parts(self, inp, gi=0, aux2=None):
@@ -1015,26 +736,19 @@ class TrainEngine:
             return lambda ln: self._twin(lambda: fn(a, *args), lambda: fn(b, *args))
 
         def gen_fwd(ln):
-            if self._skip_dgen:                    # TIMING EXPERIMENT ONLY (wrong losses): what the D-phase generator forwards cost
-                return
             self._twin(lambda: self._G(A2B, real_A, mask_A, gen_B, gst[0], B, s0),                          # :267 generated_B
                        lambda: self._G(B2A, real_B, mask_B, gen_A, gst[1], B, s1))                          # :259 generated_A
 
         def cycles(ln):
-            if self._skip_dgen:
-                return
             self._twin(lambda: self._G(B2A, gen_B, None, cyc_A, gst[0], B, s0),                             # :271 cycled_A
                        lambda: self._G(A2B, gen_A, None, cyc_B, gst[1], B, s1))                             # :263 cycled_B
 
         def repack_full(ln):
             self._twin(lambda: self._repack1(A2B), lambda: self._repack1(B2A))
 
-        def repack_bwd(ln):                    # the backward-only copies (the generator update refreshed the forward ones only)
-            self._twin(lambda: self._repack1(A2B, 2), lambda: self._repack1(B2A, 2))
-
         def post():
             self._combine(8, self._comb_d)
-        P.update(pre=pre, gen_fwd=gen_fwd, cycles=cycles, repack_full=repack_full, repack_bwd=repack_bwd, post=post,
+        P.update(pre=pre, gen_fwd=gen_fwd, cycles=cycles, repack_full=repack_full, post=post,
                  full1=pair(disc_full, "discriminator_A", "discriminator_B"), full2=pair(disc_full, "discriminator_A2", "discriminator_B2"),
                  real1=pair(disc_half, "discriminator_A", "discriminator_B", False), real2=pair(disc_half, "discriminator_A2", "discriminator_B2", False),
                  fake1=pair(disc_half, "discriminator_A", "discriminator_B", True), fake2=pair(disc_half, "discriminator_A2", "discriminator_B2", True))
@@ -1042,23 +756,21 @@ class TrainEngine:
 
     def discriminator_phase_grouped(self, real_A, mask_A, real_B, mask_B):
         """train.py:247-299, grouped like ``generator_phase_grouped``: lane 0 runs both generators' forwards (translation, then cycle) and
-        the second-step discriminator pair, lane 1 refreshes the backward-only weight copies and runs D_A | D_B."""
+        the second-step discriminator pair, lane 1 runs D_A | D_B."""
         p = self._d_parts((real_A, mask_A, real_B, mask_B))
         p["pre"]()
         packed = self._g_fwd_packed
         self._g_fwd_packed = False
 
         def gen_fwd(ln):
-            if not packed:                     # phase called on its own: full refresh first
+            if not packed:                     # phase called on its own (the caller may have written parameters): full refresh first
                 p["repack_full"](ln)
             p["gen_fwd"](ln)
 
         def refresh(ln):                       # beside the generator forwards; the generator gradients are free by now
-            if packed:
-                p["repack_bwd"](ln)
-                if not self._g_grad_clean:
-                    self.g_group.grad.zero_()  # (196 MB memset on the side lane instead of at the top of the next iteration)
-                    self._g_grad_clean = True
+            if packed and not self._g_grad_clean:
+                self.g_group.grad.zero_()      # (196 MB memset on the side lane instead of at the top of the next iteration)
+                self._g_grad_clean = True
         if self.B >= self.split_d_min_batch:
             # the real halves need nothing from the generators: lane 1 runs them while lane 0 is in the generator forwards
             tasks = [
@@ -1081,6 +793,18 @@ class TrainEngine:
         self._run_tasks(tasks)
         p["post"]()
 
+    def _d_pair_update(self, pair, d_lr, d_step):
+        """Task: optimizer step of one discriminator pair (its slice of the flat buffer; data parallel: behind its all-reduce) fused with the
+        refresh of its packed copies -- one grouped launch (train.py:299)."""
+        lo, hi = self._d_ranges[pair[0]][0], self._d_ranges[pair[1]][1]
+
+        def run(ln):
+            if self.reducer.world > 1:
+                self.reducer.reduce_range_after_(self.d_group.grad, lo, hi, None)
+                self.reducer.wait(self.device)
+            self._twin(lambda: self._update_disc(pair[0], d_lr, d_step), lambda: self._update_disc(pair[1], d_lr, d_step))
+        return run
+
     # ---- pipelined step ------------------------------------------------------------------------------------------------------------
     def _pipelined_step(self):
         """Iteration t+1's generator phase beside iteration t's discriminator phase.
@@ -1089,119 +813,73 @@ class TrainEngine:
         and writes the discriminators; the NEXT iteration's generator forwards (translation, identity, cycle: train.py:203-210) read the
         same generator weights and no discriminator at all -- only its adversarial passes (:211-216) need the updated discriminators,
         and each pair only its own two networks.  So a step issues, as ONE task graph:
-            lane 1:  D-phase(t): generator forwards -> cycle forwards -> D_A2 | D_B2 -> [all-reduce] Adam on their slice, re-pack -> "dupd2"
-            lane 3:  backward-only weight copies; D_A | D_B of D-phase(t) -> Adam on their slice, re-pack                          -> "dupd1"
-            lane 0:  G-phase(t+1): translation -> cycle -> (dupd2) D_A2 | D_B2 adversarial -> backward x 2 -> Adam(G) + re-pack
-            lane 2:  (dupd1) the first-step adversarial pair of G-phase(t+1); then its identity chain (forward, loss, backward)
-        The identity chain depends on nothing but the generator weights, so it fills the tail of the step, where the two backward rounds
-        are alone on the chip; its weight gradients go to a SECOND gradient buffer (they would race with the backward rounds' otherwise)
-        and Adam consumes the sum -- clearing both buffers as it reads them, which also removes the per-iteration gradient memsets.
+            lane 1:  D-phase(t): generator forwards -> cycle forwards -> D_A2 | D_B2 -> [all-reduce] update of their slice -> "dupd2";
+                     then the ranged generator update of G-phase(t+1) behind the last backward pass's milestone events
+            lane 3:  D_A | D_B of D-phase(t) -> update of their slice -> "dupd1"; the backward rounds' weight gradients
+            lane 0:  G-phase(t+1): translation (+ identity) -> cycle -> (dupd2) D_A2 | D_B2 adversarial -> backward x 2 -> conv1's update
+            lane 2:  (dupd1) the first-step adversarial pair of G-phase(t+1)
         Every quantity is computed from exactly the weights and inputs the reference uses (the order of the optimizers' steps is kept:
         a discriminator's Adam step (t) is complete before it is read by iteration t+1; Adam(G)(t+1) waits for D-phase(t)'s generator
-        forwards); two generator-forward latencies leave the critical path of every iteration.  ``d_loss`` of an iteration becomes
-        available one ``step()`` later (``losses(lagged=True)``); ``flush()`` / ``losses()`` complete a pending phase."""
+        forwards); two generator-forward latencies leave the critical path of every iteration.  The update launches clear the gradients
+        they consume: no per-iteration gradient memsets.  ``d_loss`` of an iteration becomes available one ``step()`` later
+        (``losses(lagged=True)``); ``flush()`` / ``losses()`` complete a pending phase."""
         cur = self.static_in
         prev, d_lr = self._pending_D if self._pending_D is not None else (None, None)
-        second = self.reducer.world == 1 and (self.grouped_ident or self.split_ident_bwd)          # (data parallel: one gradient buffer is exchanged)
-        ranged = self.ranged_update and self.reducer.world == 1
-        g = self._g_parts(cur, True, own_d_update=prev is None, ident_second=second, zeroing_update=True, ranged=ranged)
-        ident, ov = g["ident"], g["ov"]
-        split_ib = g["split_ib"]
-        tail = [(2, g["ident_chain"], (), "i")] if (ident and second) else []
-        # (the chain's backward reads the generators' backward-only weight copies, which lane 3 refreshes first: "rf")
-        head = [(2, g["ident_fwd"], (), None), (2, g["ident_bwd"], ("rf",) if self._pending_D is not None else (), "i")] if (ident and not second) else []
-        upd_waits = ("i",) if ((ident and second) or split_ib) else ()
-        bwd_waits = ("d1", "i") if (ident and not second) else ("d1",)
-        # (split: the identity sample's backward starts with the cycle backward -- behind both adversarial pairs -- on lane 2)
-        ib = [(2, g["ident_bwd_win"], ("a2",), "i")] if split_ib else []
+        ranged = self.reducer.world == 1
+        g = self._g_parts(cur, True, own_d_update=prev is None, zeroing_update=True, ranged=ranged)
+        ov = g["ov"]
         if prev is None:                       # first iteration (or the first after a flush): there is no discriminator phase to run beside it
             g["pre"](zero_grads=True)
-            tasks = [(0, g["fwd2"], (), "g")] + head + [
-                (0, g["cycle"], (), None), (2, g["adv1"], ("g",), "d1")] + tail + [(0, g["adv2"], (), "a2")] + ib + [
-                (0, g["bwd_cycle"], bwd_waits, None), (0, g["bwd_final"], (), "f")]
-            tasks += ([(3, g["queue_reduce"], (), None)] if ov else []) + [(0, g["update"], upd_waits, None)]
+            tasks = [(0, g["fwd2"], (), "g"), (0, g["cycle"], (), None), (2, g["adv1"], ("g",), "d1"), (0, g["adv2"], (), None),
+                     (0, g["bwd_cycle"], ("d1",), None), (0, g["bwd_final"], (), "f")]
+            tasks += ([(3, g["queue_reduce"], (), None)] if ov else []) + [(0, g["update"], (), None)]
             self._run_tasks(tasks)
-            self._d_pack_event = None
-            self._g_grad_clean = True          # (cleared by the Adam launch that consumed them)
+            self._g_grad_clean = True          # (cleared by the update launch that consumed them)
             g["post"]()
             return
         self.slots_done[:_BLOCK].copy_(self.slots[:_BLOCK])           # g_loss and its terms of iteration t, before the block is reused
-        d = self._d_parts(prev, gi=2, aux2=self._sides[1] if os.environ.get("MCVC_D2_AUX", "1") != "0" else None)   # (lane 2: idle until "dupd1")
-        g["pre"](zero_grads=False)             # (all gradient buffers were cleared by the Adam steps that consumed them)
+        d = self._d_parts(prev, gi=2, aux2=self._sides[1])            # (lane 2's stream: idle until "dupd1")
+        g["pre"](zero_grads=False)             # (all gradient buffers were cleared by the update launches that consumed them)
         d["pre"](zero_grads=False)
         packed = self._g_fwd_packed
         d_step = self.d_group.step + 1
-
-        def side_head(ln):                     # lane 3
-            if packed:
-                d["repack_bwd"](ln)
-
-        def d_update(pair):                    # Adam on one discriminator pair's slice of the flat buffer + its re-pack
-            lo, hi = self._d_ranges[pair[0]][0], self._d_ranges[pair[1]][1]
-
-            def run(ln):
-                if self.reducer.world > 1:
-                    self.reducer.reduce_range_after_(self.d_group.grad, lo, hi, None)
-                    self.reducer.wait(self.device)
-                if self.fused_update:
-                    self._twin(lambda: self._update_disc(pair[0], d_lr, d_step), lambda: self._update_disc(pair[1], d_lr, d_step))
-                    return
-                self._adam_range(self.d_group, lo, hi, d_lr, d_step)
-                for n in pair:
-                    self.nets[n]._packed_version = None
-                self._twin(lambda: self._repack1(pair[0]), lambda: self._repack1(pair[1]))
-            return run
         split = self.B >= self.split_d_min_batch
-        # experiment (MCVC_STAGGER): bit 0 = the translation forwards wait for the D-phase's generator forwards, bit 1 = the cycle forwards
-        # for the D-phase's cycle forwards -- the D-phase chain is the critical one, the G-phase forwards have 0.7 ms of slack
-        stagger = int(os.environ.get("MCVC_STAGGER", "0"))
         serial = self._serial_fwd()            # (data-parallel ranks: one grouped persistent trunk pass in flight at a time)
         tasks = [
-            (3, side_head, (), "rf"),          # (first: a backward pass refuses to run on a buffer whose backward copies are marked stale)
             (1, (lambda ln: (None if packed else d["repack_full"](ln), d["gen_fwd"](ln))), (), "gen"),
         ] + ([(1, d["cycles"], (), "cyc")] if serial else []) + [
-            (0, g["fwd2"], ("cyc",) if serial else (("gen",) if stagger & 1 else ()), "g"),
-        ] + head
+            (0, g["fwd2"], ("cyc",) if serial else (), "g"),
+        ]
         if split:
             tasks += [(3, d["real1"], (), None), (3, d["real2"], (), "r2")]
-        ident_pos = os.environ.get("MCVC_IDENT_POS", "tail") if (ident and second) else "tail"
-        adv1_lane = 2
-        if ident_pos in ("head", "head3"):     # experiment: the identity chain at the START of lane 2 (beside the forwards) instead of the tail
-            tail = []
-            tasks += [(2, g["ident_fwd"], (), None), (2, g["ident_bwd"], ("rf",), "i")]
-            adv1_lane = 3 if ident_pos == "head3" else 2
         tasks += ([] if serial else [(1, d["cycles"], (), "cyc")]) + [
-            (0, g["cycle"], ("cyc",) if stagger & 2 else (), None),
+            (0, g["cycle"], (), None),
             (3, d["fake1"] if split else d["full1"], ("gen",), None),
-            (3, d_update(("discriminator_A", "discriminator_B")), (), "dupd1"),
+            (3, self._d_pair_update(("discriminator_A", "discriminator_B"), d_lr, d_step), (), "dupd1"),
             (1, d["fake2"] if split else d["full2"], ("r2",) if split else (), None),
-            (1, d_update(("discriminator_A2", "discriminator_B2")), (), "dupd2"),
-            (adv1_lane, g["adv1"], ("g", "dupd1"), "d1"),
-        ] + tail + [
-            (0, g["adv2"], ("dupd2",), "a2"),
-        ] + ([(2, g["ident_bwd_win"], ("a2", "rf"), "i")] if split_ib else []) + [
-            (0, g["bwd_cycle"], bwd_waits + ("rf",), None),
+            (1, self._d_pair_update(("discriminator_A2", "discriminator_B2"), d_lr, d_step), (), "dupd2"),
+            (2, g["adv1"], ("g", "dupd1"), "d1"),
+            (0, g["adv2"], ("dupd2",), None),
+            (0, g["bwd_cycle"], ("d1",), None),
             (0, g["bwd_final"], (), "f"),
         ] + ([(3, g["queue_reduce"], (), None)] if ov else [])
         if ranged:
-            # the generator update range by range: the up-sampling blocks' and the trunk's Adam step + forward re-pack run on lane 1 beside
-            # the rest of the last backward pass (behind its milestone events; after everything that still reads the old weights: the
-            # identity chain "i" and D-phase(t)'s generator forwards "cyc"); only the head's is left for the end of the chain
-            # (lane 1, idle since "dupd2" -- lane 3's stream carries the backward rounds' weight gradients)
-            tasks += [(1, g["update_range"](0, False), upd_waits + ("cyc",), None), (1, g["update_range"](1, False), (), "u01"),
+            # the generator update range by range: the up-sampling blocks', the trunk's and most of the head's optimizer step + re-pack run
+            # on lane 1 (idle since "dupd2" -- lane 3's stream carries the backward rounds' weight gradients) beside the rest of the last
+            # backward pass, behind its milestone events and after everything that still reads the old weights (D-phase(t)'s generator
+            # forwards: "cyc"); only conv1's is left for the end of the chain
+            tasks += [(1, g["update_range"](0, False), ("cyc",), None), (1, g["update_range"](1, False), (), None),
                       (1, g["update_range"](2, False), (), None), (1, g["update_range"](3, False), (), None),
-                      (0, g["update_range"](4, True), upd_waits + ("cyc",), None)]
+                      (0, g["update_range"](4, True), ("cyc",), None)]
         else:
-            tasks += [(0, g["update"], upd_waits + ("cyc",), None)]
+            tasks += [(0, g["update"], ("cyc",), None)]
         self._run_tasks(tasks)
         self.d_group.step = d_step
-        self._d_pack_event = None
         self._g_grad_clean = self._d_grad_clean = True
         g["post"]()
         d["post"]()
         self.slots_done[_BLOCK:].copy_(self.slots[_BLOCK:])           # d_loss and its terms of iteration t: the iteration is complete
         self._publish_done()
-
 
     # ---- merged forwards (r4) ---------------------------------------------------------------------------------------------------------
     def _merged_ok(self, B):
@@ -1213,13 +891,12 @@ class TrainEngine:
         run) order the G-phase's grouped forwards BEHIND the D-phase's generator forwards, so that ONE grouped persistent trunk pass is in
         flight at a time, like on the merged schedule: 2 + 1 (RCCL's share) x 64 workgroups fit the 256 compute units, where the free-running
         4 + 1 do not and every pass would fall back to per-layer trunk launches.  The D-phase chain is the critical one; the
-        G-phase forwards have ~0.7 ms of slack behind it (MCVC_STAGGER measurements)."""
+        G-phase forwards have ~0.7 ms of slack behind it."""
         return self.reducer.world > 1 and self._use_pipeline() and not self._use_merged()
 
     def _use_merged(self):
         # (after the identity cut-off the merged passes would carry a dead sample: the separate passes skip it)
-        return self.merged and self._use_pipeline() and not self.grouped_ident and self._merged_ok(self.B) and hasattr(self, "in3") and \
-            self.sched.identity_loss_lambda != 0
+        return self.merged and self._use_pipeline() and self._merged_ok(self.B) and hasattr(self, "in3") and self.sched.identity_loss_lambda != 0
 
     def _merged_step(self):
         """``_pipelined_step`` with the discriminator phase's generator forwards INSIDE the generator phase's passes.
@@ -1229,26 +906,22 @@ class TrainEngine:
         those weights (:203-210).  So one grouped pass per generator carries THREE samples
             [ identity: real_other(t+1) | ones ;  translation: real(t+1) | mask(t+1) ;  D-phase translation: real(t) | mask(t) ]
         and the cycle pass TWO: [ fake(t+1) ; generated(t) ] (contiguous rows of the first pass's output).  The backward passes run over the
-        first two / the first sample of those stashes (mcvc_gen_backward_prefix).  Per-sample results are what the separate passes compute
+        first two / the first sample of those stashes (mcvc_gen_backward_window).  Per-sample results are what the separate passes compute
         (every op of the generator is per sample): parity tests in tests/test_hip_twin.py.  Two of the six grouped generator passes of an
         iteration disappear; one persistent trunk pass is in flight at a time instead of two.
-            lane 0:  forward x3 -> cycle x2 -> ("d1", "d2") backward cycle -> backward translation + identity -> Adam(G) head + re-pack
-            lane 1:  ("g") D_A | D_B of D-phase(t) -> Adam + re-pack of their slice -> first-step adversarial pair of G-phase(t+1)   "d1"
-            lane 2:  ("c") D_A2 | D_B2 of D-phase(t) -> Adam + re-pack -> second-step adversarial pair                             "d2"
-            lane 3:  backward-only weight copies ("rf"); the backward passes' weight gradients; the ranged generator update"""
+            lane 0:  forward x3 -> cycle x2 -> ("d1", "d2") backward cycle -> backward translation + identity -> conv1's update
+            lane 1:  ("g") D_A | D_B of D-phase(t) -> update of their slice -> first-step adversarial pair of G-phase(t+1)   "d1";
+                     then the ranged generator update
+            lane 2:  ("c") D_A2 | D_B2 of D-phase(t) -> update -> second-step adversarial pair                             "d2"
+            lane 3:  the backward passes' weight gradients"""
         cur = self.static_in
         prev, d_lr = self._pending_D if self._pending_D is not None else (None, None)
         B, B2, B3 = self.B, 2 * self.B, 3 * self.B
         A2B, B2A = G_NAMES
         sc = self.sched
         cl, il = sc.cycle_loss_lambda, sc.identity_loss_lambda
-        ranged = self.ranged_update and self.reducer.world == 1
-        # The identity sample's backward depends on nothing but its own forward (train.py:223-224): it runs as soon as the cycle forwards
-        # have left the chip, beside the discriminators of the cycle chain, into the SECOND gradient buffer (Adam consumes the sum) -- the
-        # last backward pass of the chain is then a one-sample pass.  Data parallel: one gradient buffer is exchanged, the identity sample
-        # stays in the last pass.  MCVC_EARLY_IDENT=0: A/B.
-        early = self.early_ident and self.reducer.world == 1
-        g = self._g_parts(cur, True, own_d_update=False, ident_second=early, zeroing_update=True, ranged=ranged)     # (update / reduce / post closures)
+        ranged = self.reducer.world == 1
+        g = self._g_parts(cur, True, own_d_update=False, zeroing_update=True, ranged=ranged)     # (update / reduce / post closures)
         ov = g["ov"]
         ms_on = ov or ranged
         real_A, mask_A, real_B, mask_B = cur
@@ -1308,65 +981,32 @@ class TrainEngine:
             self._twin(lambda: adv_half("discriminator_A2", 2, cycle_A, m["g_cycle_A"], 1),
                        lambda: adv_half("discriminator_B2", 3, cycle_B, m["g_cycle_B"], 1))
 
-        nj = self.bwd_no_join
-        fs = (4, 5) if nj else (0, 1)
-
+        # The cycle pass's weight gradients (auxiliary stream) outlast its data-gradient chain by ~0.2 ms; the translation pass needs only the
+        # data gradient, so it starts without that join (MCVC_BWD_NO_JOIN, include/mcvc.h): its own weight gradients queue behind them on the
+        # same auxiliary stream (same tensors, in order), it works in other scratch buffers (4, 5), and its final join covers both passes.
         def bwd_cycle(ln):      # cycle_A = G_B2A(fake_B) adds to d(fake_B), cycle_B = G_A2B(fake_A) to d(fake_A)
-            self._twin(lambda: self._G_bwd(B2A, None, m["g_cycle_A"], g_fake_B, 1, self.g_stash2c[0], B, 0, aux_lane=0, no_join=nj, stash_nb=B2),
-                       lambda: self._G_bwd(A2B, None, m["g_cycle_B"], g_fake_A, 1, self.g_stash2c[1], B, 1, aux_lane=0, no_join=nj, stash_nb=B2))
+            self._twin(lambda: self._G_bwd(B2A, None, m["g_cycle_A"], g_fake_B, 1, self.g_stash2c[0], B, 0, aux_lane=0, no_join=True, stash_nb=B2),
+                       lambda: self._G_bwd(A2B, None, m["g_cycle_B"], g_fake_A, 1, self.g_stash2c[1], B, 1, aux_lane=0, no_join=True, stash_nb=B2))
 
         def bwd_final(ln):      # identity + translation samples; the gradient ranges become final one after the other (milestone events)
-            if early:           # ... the translation sample alone: the window [B, 2B) of the three-sample stash
-                self._twin(lambda: self._G_bwd(A2B, mask3[A2B][B:B2], g_fake_B, None, 0, self.g_stash3x[0], B, fs[0], ms_on, aux_lane=0, ms_of=A2B,
-                                               stash_nb=B3, stash_b0=B),
-                           lambda: self._G_bwd(B2A, mask3[B2A][B:B2], g_fake_A, None, 0, self.g_stash3x[1], B, fs[1], ms_on, aux_lane=0, ms_of=A2B,
-                                               stash_nb=B3, stash_b0=B))
-                return
-            self._twin(lambda: self._G_bwd(A2B, mask3[A2B], gout3[A2B], None, 0, self.g_stash3x[0], B2, fs[0], ms_on, aux_lane=0, ms_of=A2B, stash_nb=B3),
-                       lambda: self._G_bwd(B2A, mask3[B2A], gout3[B2A], None, 0, self.g_stash3x[1], B2, fs[1], ms_on, aux_lane=0, ms_of=A2B, stash_nb=B3))
+            self._twin(lambda: self._G_bwd(A2B, mask3[A2B], gout3[A2B], None, 0, self.g_stash3x[0], B2, 4, ms_on, aux_lane=0, ms_of=A2B, stash_nb=B3),
+                       lambda: self._G_bwd(B2A, mask3[B2A], gout3[B2A], None, 0, self.g_stash3x[1], B2, 5, ms_on, aux_lane=0, ms_of=A2B, stash_nb=B3))
 
-        def ident_bwd(ln):      # the identity samples (window [0, B)): weight gradients inline on this lane, into the second gradient buffer
-            self._twin(lambda: self._G_bwd(A2B, mask3[A2B][:B], g_identity_B, None, 0, self.g_stash3x[0], B, 2, aux_lane=1, second=True, stash_nb=B3),
-                       lambda: self._G_bwd(B2A, mask3[B2A][:B], g_identity_A, None, 0, self.g_stash3x[1], B, 3, aux_lane=1, second=True, stash_nb=B3))
-
-        def side_head(ln):                     # lane 3: the backward-only weight copies (the generator update refreshed the forward ones)
-            if packed:
-                self._twin(lambda: self._repack1(A2B, 2), lambda: self._repack1(B2A, 2))
-
-        def d_update(pair):                    # Adam on one discriminator pair's slice of the flat buffer + its re-pack
-            lo, hi = self._d_ranges[pair[0]][0], self._d_ranges[pair[1]][1]
-
-            def run(ln):
-                if self.reducer.world > 1:
-                    self.reducer.reduce_range_after_(self.d_group.grad, lo, hi, None)
-                    self.reducer.wait(self.device)
-                if self.fused_update:
-                    self._twin(lambda: self._update_disc(pair[0], d_lr, d_step), lambda: self._update_disc(pair[1], d_lr, d_step))
-                    return
-                self._adam_range(self.d_group, lo, hi, d_lr, d_step)
-                for n in pair:
-                    self.nets[n]._packed_version = None
-                self._twin(lambda: self._repack1(pair[0]), lambda: self._repack1(pair[1]))
-            return run
-        tasks = [(3, side_head, (), "rf"), (0, fwd3, (), "g"), (0, cycle2, (), "c")]
+        tasks = [(0, fwd3, (), "g"), (0, cycle2, (), "c")]
         if d is not None:
-            tasks += [(1, d["full1"], ("g",), None), (1, d_update(("discriminator_A", "discriminator_B")), (), None),
-                      (2, d["full2"], ("c",), None), (2, d_update(("discriminator_A2", "discriminator_B2")), (), None)]
-        if early:               # lane 3 (idle between the weight copies and the backward rounds' weight gradients), behind the cycle forwards
-            tasks += [(3, ident_bwd, ("c",), "i")]
-        uw = ("i",) if early else ()
+            tasks += [(1, d["full1"], ("g",), None), (1, self._d_pair_update(("discriminator_A", "discriminator_B"), d_lr, d_step), (), None),
+                      (2, d["full2"], ("c",), None), (2, self._d_pair_update(("discriminator_A2", "discriminator_B2"), d_lr, d_step), (), None)]
         tasks += [(1, adv1, ("g",), "d1"), (2, adv2, ("c",), "d2"),
-                  (0, bwd_cycle, ("d1", "d2", "rf"), None), (0, bwd_final, (), "f")]
+                  (0, bwd_cycle, ("d1", "d2"), None), (0, bwd_final, (), "f")]
         if ov:
             tasks += [(3, g["queue_reduce"], (), None)]
         if ranged:
-            tasks += [(1, g["update_range"](0, False), uw, None), (1, g["update_range"](1, False), (), "u01"),
-                      (1, g["update_range"](2, False), (), None), (1, g["update_range"](3, False), (), None), (0, g["update_range"](4, True), uw, None)]
+            tasks += [(1, g["update_range"](0, False), (), None), (1, g["update_range"](1, False), (), None),
+                      (1, g["update_range"](2, False), (), None), (1, g["update_range"](3, False), (), None), (0, g["update_range"](4, True), (), None)]
         else:
-            tasks += [(0, g["update"], uw, None)]
+            tasks += [(0, g["update"], (), None)]
         self._run_tasks(tasks)
-        self._d_pack_event = None
-        self._g_grad_clean = True              # (cleared by the Adam launches that consumed them)
+        self._g_grad_clean = True              # (cleared by the update launches that consumed them)
         g["post"]()
         if d is not None:
             self.d_group.step = d_step
@@ -1382,7 +1022,7 @@ class TrainEngine:
         self._done_valid = True
 
     def generator_update(self):
-        """All-reduce (data parallel) + Adam on the flat generator buffer (train.py:242); eager: its scalars change per step."""
+        """All-reduce (data parallel) + optimizer step of both generators (train.py:242) behind a generator phase that ran without its own."""
         if self.overlap_g_reduce:
             # same collective order on every rank: range k of A2B, range k of B2A, k = 0, 1, then the two tails
             for k in range(2):
@@ -1395,13 +1035,11 @@ class TrainEngine:
             self.reducer.wait(self.device)
         else:
             self.reducer.reduce_(self.g_group.grad)
-        self._adam(self.g_group, self.sched.g_opt_lr)
+        self._update_gens(self.sched.g_opt_lr)
 
     def discriminator_phase(self, real_A, mask_A, real_B, mask_B):
-        """train.py:247-299."""
+        """train.py:247-299 on four lanes."""
         B, B2 = self.B, 2 * self.B
-        m = self.mel
-        sc = self.sched
         self.slots[_BLOCK:].zero_()
         if self._d_grad_clean:
             self._d_grad_clean = False
@@ -1430,19 +1068,17 @@ class TrainEngine:
         # Same shape as the generator phase: lanes 0/1 carry the two generator chains, D_A / D_B need only the generated batches and run
         # on lanes 2/3 while lanes 0/1 are in the cycle forwards; the second-step discriminators follow the cycle forwards on lanes 0/1.
         if self._g_fwd_packed:
-            # the generator phase left lane 0 with generator_A2B updated + its forward copies fresh, lane 1 with generator_B2A: each lane
-            # starts with its own generator; the backward-only copies are refreshed on lanes 2/3 while those wait for the generated batches
+            # the generator phase left lane 0 with generator_A2B updated and its copies fresh, lane 1 with generator_B2A: each lane starts
+            # with its own generator
             self._g_fwd_packed = False
 
-            def refresh_b2a(ln):
-                self._repack1("generator_B2A", 2)
-                self.g_group.grad.zero_()      # the generator gradients are free (their Adam step ended the generator phase): 196 MB
+            def clear_g(ln):
+                self.g_group.grad.zero_()      # the generator gradients are free (their update ended the generator phase): 196 MB
                 self._g_grad_clean = True      # memset on an idle lane instead of at the top of the next iteration
             head = [
                 (0, lambda ln: self._G("generator_A2B", real_A, mask_A, gen_B, self.g_stash1[0], B, ln), (), "gB"),      # :267 generated_B
                 (1, lambda ln: self._G("generator_B2A", real_B, mask_B, gen_A, self.g_stash1[1], B, ln), (), "gA"),      # :259 generated_A
-                (2, refresh_b2a, (), None),
-                (3, lambda ln: self._repack1("generator_A2B", 2), (), None),
+                (2, clear_g, (), None),
             ]
             cycles = [
                 (0, lambda ln: self._G("generator_B2A", gen_B, None, cyc_A, self.g_stash1[0], B, ln), (), None),         # :271 cycled_A
@@ -1451,8 +1087,7 @@ class TrainEngine:
             if B >= self.split_d_min_batch:
                 # The real halves need nothing from the generators: lanes 2/3 run them while lanes 0/1 are in the generator forwards, so the
                 # tail of the phase (second-step discriminators behind the cycle forwards) is a pass over the generated half only.  A
-                # discriminator's two passes add into the same gradients: same lane, or ordered by an event.  At one sample per pass the
-                # extra two chains slow the generator forwards by more than the tail gains (7.18 -> 7.57 ms; bs=8: 31.7 -> 31.2).
+                # discriminator's two passes add into the same gradients: same lane, or ordered by an event.
                 def half(name, fake):
                     i = idx[name]
                     sl = slice(B, B2) if fake else slice(0, B)
@@ -1499,49 +1134,24 @@ class TrainEngine:
         self._combine(8, self._comb_d)
 
     def discriminator_update(self):
-        """train.py:299.  With more than one rank the all-reduce is only *started* here; Adam runs when the discriminators
+        """train.py:299.  With more than one rank the all-reduce is only *started* here; the optimizer step runs when the discriminators
         are next needed (``_finish_d_update``), so the exchange overlaps the next iteration's generator forwards."""
-        if self.defer_d_update and (self.reducer.world > 1 or not self.use_graphs):
+        if self.defer_d_update:
             self.reducer.reduce_async_(self.d_group.grad)
             self._pending_d_lr = self.sched.d_opt_lr          # the value torch.optim would have used now
             return
         self.reducer.reduce_(self.d_group.grad)
-        if self.fused_update:
-            self._update_discs(self.sched.d_opt_lr)
-            return
-        self._adam(self.d_group, self.sched.d_opt_lr)
-        self._repack_d_async()
+        self._update_discs(self.sched.d_opt_lr)
 
     def _finish_d_update(self):
         if self._pending_d_lr is None:
             return
         self.reducer.wait(self.device)
         lr, self._pending_d_lr = self._pending_d_lr, None
-        if self.fused_update:
-            self._update_discs(lr)
-            return
-        self._adam(self.d_group, lr)
-        self._repack_d_async()
-
-    def _repack_d_async(self):
-        """Refresh the discriminators' packed weights on the pack stream (ordered after the Adam step just queued)."""
-        cur = torch.cuda.current_stream(self.device)
-        self._pack_stream.wait_stream(cur)
-        with torch.cuda.stream(self._pack_stream):
-            for n in D_NAMES:
-                self._repack1(n)
-            ev = torch.cuda.Event()
-            ev.record()
-        self._d_pack_event = ev
-
-    def _wait_d_pack(self):
-        """Make the CURRENT stream wait for the discriminators' re-pack (every lane that runs a discriminator calls this; the generator
-        phase drops the event once all lanes have joined)."""
-        if self._d_pack_event is not None:
-            torch.cuda.current_stream(self.device).wait_event(self._d_pack_event)
+        self._update_discs(lr)
 
     def _use_pipeline(self):
-        return self.pipelined and self._use_grouped() and self.fuse_g_update and self.concurrent and (self.reducer.world == 1 or self.overlap_g_reduce)
+        return self.pipelined and self._use_grouped() and self.concurrent and (self.reducer.world == 1 or self.overlap_g_reduce)
 
     def _next_input_set(self):
         """The static input buffers the coming iteration writes its minibatch into: the other set while the previous iteration's
@@ -1559,18 +1169,11 @@ class TrainEngine:
             self.slots_done[:_BLOCK].copy_(self.slots[:_BLOCK])
             self.discriminator_phase_grouped(*inp)
             self.reducer.reduce_(self.d_group.grad)
-            if self.fused_update:
-                self._update_discs(d_lr, zero=True)
-            else:
-                self._adam(self.d_group, d_lr)
-                self.d_group.grad.zero_()
-                self._repack_d_async()
+            self._update_discs(d_lr, zero=True)
             self._d_grad_clean = True
             self.slots_done[_BLOCK:].copy_(self.slots[_BLOCK:])
             self._publish_done()
         self._finish_d_update()
-        self._wait_d_pack()
-        self._d_pack_event = None
 
     def step(self, real_A, mask_A, real_B, mask_B):
         """One full iteration.  Inputs: float32 [B,80,T] on the engine's device.  Returns the loss-slot
@@ -1582,7 +1185,6 @@ class TrainEngine:
             raise ValueError("batch shape %s does not match the engine (B, 80, %d)" % (tuple(real_A.shape), self.T))
         if real_A.shape[0] != self.B:
             self._use(int(real_A.shape[0]))
-        # static input buffers (graph replays read fixed addresses)
         self._next_input_set()
         torch._foreach_copy_(list(self.static_in), [real_A, mask_A, real_B, mask_B])
         return self._step_static()
@@ -1610,7 +1212,7 @@ class TrainEngine:
             return self.slots
         if self._pending_D is not None:
             self.flush()
-        if (self.reducer.world == 1 or self.overlap_g_reduce) and not self.use_graphs and self.fuse_g_update:
+        if self.reducer.world == 1 or self.overlap_g_reduce:
             phase = self.generator_phase_grouped if self._use_grouped() else self.generator_phase
             phase(*self.static_in, fuse_update=True)                      # includes the generator update (no join of the lanes)
         else:
@@ -1621,44 +1223,12 @@ class TrainEngine:
         self.sched.end_iteration()
         return self.slots
 
-    # ---- HIP graphs: each phase's ~500 launches (two lanes + auxiliary streams included) are captured once and replayed
     def _run_phase(self, which):
         if self._use_grouped():
             fn = self.generator_phase_grouped if which == "G" else self.discriminator_phase_grouped
         else:
             fn = self.generator_phase if which == "G" else self.discriminator_phase
-        if not self.use_graphs:
-            fn(*self.static_in)
-            return
-        key = (which, self.B, float(self.sched.cycle_loss_lambda), float(self.sched.identity_loss_lambda), self.concurrent, self.aux_wgrad)
-        g = self._graphs.get(key)
-        if g is None:
-            if self._eager_runs.get(key, 0) < 2:          # warm-up: first runs are eager (lazy kernel attributes, event pool)
-                self._eager_runs[key] = self._eager_runs.get(key, 0) + 1
-                fn(*self.static_in)
-                return
-            torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            try:
-                with torch.cuda.graph(g, stream=self._capture_stream):
-                    # the auxiliary weight-gradient streams join the capture as FIRST-LEVEL forks of the capture stream: forking
-                    # them from an already forked lane stream (a nested fork) segfaults inside hipStreamEndCapture on ROCm 7.2
-                    cur = torch.cuda.current_stream(self.device)
-                    if self.aux_wgrad:
-                        for ax in self._aux:
-                            ax.wait_stream(cur)
-                    fn(*self.static_in)
-                    if self.aux_wgrad:
-                        for ax in self._aux:
-                            cur.wait_stream(ax)
-            except Exception as exc:                        # stay correct if capture is not possible on this runtime
-                print("mask_cyclegan_vc.engine: HIP graph capture failed (%s); continuing eagerly" % exc)
-                self.use_graphs = False
-                torch.cuda.synchronize(self.device)
-                fn(*self.static_in)
-                return
-            self._graphs[key] = g
-        g.replay()
+        fn(*self.static_in)
 
     def check_faults(self, raise_on_fault=True):
         """Detect a persistent trunk launch of this engine that gave up waiting for its workgroups (its result was poisoned with NaN, so
@@ -1721,54 +1291,9 @@ class TrainEngine:
                 eng.load_optimizer_state_dict(which, sd)
         return _Adapter()
 
-    # ---- torch.optim.Adam-compatible optimizer state (checkpoint layout of the reference) -----------------
+    # ---- torch.optim.Adam-compatible optimizer state (checkpoint layout of the reference): optim_state.py
     def optimizer_state_dict(self, which):
-        """``torch.optim.Adam.state_dict()``-shaped dict: per-parameter ``step/exp_avg/exp_avg_sq`` keyed by the
-        position in the concatenated parameter list (G: 0..219; D: 0..79 with the dead 14-17,34-37,... absent)."""
-        self.flush()
-        grp = self.g_group if which == "G" else self.d_group
-        names = G_NAMES if which == "G" else D_NAMES
-        lr = self.sched.g_opt_lr if which == "G" else self.sched.d_opt_lr
-        state, idx, off = {}, 0, 0
-        for n in names:
-            ps = list(self.nets[n].parameters())
-            for i, p in enumerate(ps):
-                if which == "D" and i in _DEAD:
-                    idx += 1
-                    continue
-                k = p.numel()
-                if grp.step > 0:
-                    state[idx] = {"step": torch.tensor(float(grp.step)),
-                                  "exp_avg": grp.exp_avg[off:off + k].view(p.shape).detach().cpu().clone(),
-                                  "exp_avg_sq": grp.exp_avg_sq[off:off + k].view(p.shape).detach().cpu().clone()}
-                off += _align4(k)
-                idx += 1
-        group = {"lr": lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
-                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
-                 "params": list(range(idx))}
-        return {"state": state, "param_groups": [group]}
+        return optimizer_state_dict(self, which)
 
     def load_optimizer_state_dict(self, which, sd):
-        self.flush()
-        grp = self.g_group if which == "G" else self.d_group
-        names = G_NAMES if which == "G" else D_NAMES
-        idx, off, step = 0, 0, 0
-        for n in names:
-            for i, p in enumerate(self.nets[n].parameters()):
-                if which == "D" and i in _DEAD:
-                    idx += 1
-                    continue
-                k = p.numel()
-                st = sd["state"].get(idx)
-                if st is not None:
-                    grp.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
-                    grp.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
-                    step = max(step, int(float(st["step"])))
-                off += _align4(k)
-                idx += 1
-        grp.step = step
-        lr = sd["param_groups"][0]["lr"]
-        if which == "G":
-            self.sched.g_opt_lr = lr
-        else:
-            self.sched.d_opt_lr = lr
+        load_optimizer_state_dict(self, which, sd)

@@ -226,6 +226,40 @@ def test_oracle_past_the_identity_cutoff(golden_dir):
             assert rel_l2(mine, ref) < 1e-3, (name, k, rel_l2(mine, ref))
 
 
+def test_reference_arithmetic_spread_after_four_adam_steps(golden_dir):
+    """How far the REFERENCE's own arithmetic is from itself after the four iterations of the ``cutoff`` fixture when only the summation
+    order changes (3 threads and the full autograd graph against the fixture's 8 threads): Adam's first steps move an element by
+    ~lr * sign(g) whatever |g| is, so rounding-level gradients turn into +-lr parameter differences.  This spread -- not 1e-3 -- is what
+    bounds per-tensor parity of ANY implementation after several optimizer steps; tests/test_hip_engine.py gates the HIP engine at 1.5 x
+    the upper bound asserted here, and at 1e-3 on everything that is well-posed (losses, norms, single-iteration gradients)."""
+    js, bt = _load_step(golden_dir, "cutoff")
+    was = torch.get_num_threads()
+    torch.set_num_threads(3)
+    try:
+        nets = _nets_from_filler(js["config"]["filler_seeds"])
+        so = orc.StepOracle(nets, skip_wasted=False)
+        for it, lam in enumerate((5, 5, 0, 0)):
+            so.identity_lambda = float(lam)
+            g_loss, d_loss = so.step(*[torch.from_numpy(bt["it%d_%s" % (it, k)]) for k in ("real_A", "mask_A", "real_B", "mask_B")])
+            assert abs(g_loss - js["losses"][it]["g_loss"]) < 1e-3 * abs(js["losses"][it]["g_loss"])     # (observed 4e-4 at the fourth iteration)
+    finally:
+        torch.set_num_threads(was)
+    zero_bias = {k.split(":", 1)[1] for k, v in json.load(open(os.path.join(golden_dir, "grad_norms.json"))).items() if v is not None and v < 1e-6}
+    errs = []
+    for name in orc.NET_ORDER:
+        names = orc.generator_param_names() if name.startswith("generator") else orc.discriminator_param_names()
+        for j, k in enumerate(names):
+            ref = bt["final_%s_%d" % (name, j)]
+            if k in zero_bias or ref.size == 1:
+                continue
+            flat = nets[name][k].flatten()
+            errs.append(rel_l2(flat[torch.from_numpy(orc.sample_index(flat.numel()))].numpy(), ref))
+    errs = np.asarray(errs)
+    print("reference self-spread after 4 steps: worst %.2e, %d of %d sampled tensors beyond 1e-3" % (errs.max(), int((errs > 1e-3).sum()), errs.size))
+    assert errs.max() < 5e-3 / 1.5                 # the bound the GPU test scales
+    assert errs.max() > 1e-3                       # ... and the reason a 1e-3 per-tensor gate after several steps is not a property of the path
+
+
 def test_dataset_mask_law(golden_dir):
     """FIF masks drawn by the reference VCDataset: ones with one zeroed span shared by all 80 bins."""
     dr = np.load(os.path.join(golden_dir, "dataset_draws.npz"))
