@@ -219,12 +219,8 @@ static void spec_finalize(ConvSpec& c, long long& cur)
         c.igemm = 1;
         cur = (cur + 3) & ~3LL;
         c.off_ifwd = cur; cur += (long long)9 * c.Cin * c.cout_pk;
-        c.off_idg = cur;
-        for (int k = 0; k < c.ncls; ++k) {
-            c.icls[k] = c.cls[k];
-            c.icls[k].offset = cur - c.off_idg;
-            cur += (long long)c.cout_tot * c.cls[k].nth * c.cls[k].ntw * c.cin_pk;
-        }
+        // (the implicit data gradient reads this tap-major forward copy row-major -- sgemm.h arow -- its per-class copies of r4 are gone)
+        for (int k = 0; k < c.ncls; ++k) { c.icls[k] = c.cls[k]; c.icls[k].offset = 0; }
     }
     cur = (cur + 3) & ~3LL;
     c.wino = (c.KH == 5 && c.KW == 5 && st == 1 && c.nbr == 1 && c.Cin >= 64 && c.Cout >= 64) ? 1 : 0;
@@ -447,24 +443,19 @@ static bool conv_wino(Exec& ex, const ConvSpec& c, const float* packed, int dgra
     return true;
 }
 
-// Convolutions that run as staged GEMMs on the LDS-DMA GEMM pipeline (sgemm.h):
-//   kind 1: 3x3 stride 2 padding 1 (the discriminators' downSample1-3) -- MCVC_SGEMM_NB = smallest batch per pass (0 = never): measured
-//           at bs = 1 / 2 / 4 / 8 / 32 the GEMM form wins everywhere (7.64 vs 8.79, 12.3 vs 14.6, 20.8 vs 22.0, 35.3 vs 43.6, 132.5 vs 161.5 ms/step)
-//   kind 2: 1 x KW stride 1 (KW = 1, 3) over an image of rows -- the 1-D trunk beyond the fused small-batch kernels (more than 32 columns);
-//           MCVC_SGEMM1D_COLS = smallest column count (0 = never)
+// Convolutions that run as staged GEMMs on the LDS-DMA GEMM pipeline (sgemm.h): 1 x KW stride 1 (KW = 1, 3) over an image of rows -- the 1-D
+// trunk beyond the fused small-batch kernels (more than 64 columns; MCVC_SGEMM1D_COLS = smallest column count, 0 = never).  (kind 1 of r2-r4,
+// the discriminators' 3 x 3 stride-2 layers as staged products -- tap planes, transposed operands, gather -- is gone: those layers run as
+// IMPLICIT GEMMs in every pass whose shapes allow it (igemm_applies) and on the direct kernels otherwise.)
 struct SgKind { int kind, taps, OH, OW; };
 static thread_local int t_no_sgemm = 0;
 static SgKind sgemm_kind(const ConvSpec& c, int NB, int H, int W)
 {
-    static const int min_nb = mcvc_knob("MCVC_SGEMM_NB", 1);
     static const int min_cols = mcvc_knob("MCVC_SGEMM1D_COLS", 64);
     SgKind k{0, 0, 0, 0};
     if (t_no_sgemm) return k;
     if (c.nbr > 2 || (c.cout_tot % 64) != 0 || (c.Cout % 32) != 0 || c.cin_pad != c.Cin) return k;
-    if (c.KH == 3 && c.KW == 3 && c.stride == 2 && c.ph == 1 && c.pw == 1) {
-        k.OH = (H + 1) / 2; k.OW = (W + 1) / 2; k.taps = 9;
-        if (min_nb > 0 && NB >= min_nb && ((c.Cin * 9) % 64) == 0 && ((k.OH * k.OW) % 4) == 0) k.kind = 1;
-    } else if (c.KH == 1 && (c.KW == 1 || c.KW == 3) && c.stride == 1 && c.ph == 0 && c.pw == (c.KW - 1) / 2) {
+    if (c.KH == 1 && (c.KW == 1 || c.KW == 3) && c.stride == 1 && c.ph == 0 && c.pw == (c.KW - 1) / 2) {
         k.OH = H; k.OW = W; k.taps = c.KW;
         if (min_cols > 0 && (long long)NB * H * W >= min_cols && ((c.Cin * c.KW) % 64) == 0 && ((H * W) % 4) == 0) k.kind = 2;
     }
@@ -536,12 +527,14 @@ static void conv_dgrad_igemm(Exec& ex, const ConvSpec& c, const float* packed, i
     const int OH = H / 2, OW = W / 2, P = OH * OW;
     const long long NT = (long long)NB * P;
     int sp = (allow_split && nsplit && !accumulate) ? igemm_split(4LL * (c.Cin / 64) * ((NT + 63) / 64), c.cout_tot) : 1;
+    // (Tried on top, r5: deeper uniform splits -- 4-tap class at most 512 deep -- and tap-wise splits with zero-filled slabs for the classes with
+    //  fewer taps, so that every workgroup is one tap deep: bs=1 6.01 -> 6.03-6.12 and -> 6.3 ms.  The consumer reading 4-8 slabs costs more
+    //  than the imbalance of the classes; the uniform split of r4 stays.)
     const long long slab_need = (long long)(sp - 1) * dx_total;
     if (slab_need > ex.slab_need) ex.slab_need = slab_need;
     if (nsplit) *nsplit = sp;
     if (ex.dry) return;
     if (slab_need > ex.slab_cap) { ex.fail(MCVC_ERR_WORKSPACE); return; }
-    if (ex.pack_skips & 64) { ex.fail(MCVC_ERR_INVALID); return; }          // (re-packed for smaller passes only: mcvc_disc_pack_batch)
     const int pitch = mcvc_dyp_pitch(OW);
     const long long plane = mcvc_dyp_plane(OH, OW);
     IGemmArgs g{};
@@ -549,15 +542,16 @@ static void conv_dgrad_igemm(Exec& ex, const ConvSpec& c, const float* packed, i
     for (int k = 0; k < c.ncls; ++k) {
         const DgradClass& d = c.icls[k];
         IGemmClass& q = g.cls[k];
-        q.a = packed + c.off_idg + d.offset; q.ntaps = d.nth * d.ntw;
+        q.a = packed + c.off_ifwd; q.ntaps = d.nth * d.ntw;          // the tap-major FORWARD copy, read row-major (sgemm.h arow)
         q.coff = (long long)d.qh * dx.sh + d.qw;
         for (int u = 0; u < d.nth; ++u)
             for (int v = 0; v < d.ntw; ++v) {     // input row 2a + qh receives tap kh from output row a + (qh + 1 - kh) / 2
                 const int kh = d.khmax - 2 * u, kw = d.kwmax - 2 * v;
                 q.boff[u * d.ntw + v] = (long long)((d.qh + 1 - kh) / 2) * pitch + (d.qw + 1 - kw) / 2;
+                q.atap[u * d.ntw + v] = 3 * kh + kw;
             }
     }
-    g.lda = c.cin_pk;
+    g.lda = c.cout_pk; g.arow = 1;
     g.b = dyp; g.b_cs = plane; g.b_sn = (long long)c.cout_tot * plane; g.b_pitch = pitch; g.Cb = c.cout_tot; g.OW = OW; g.P = P;
     g.c = dx.p; g.ldc = dx.sc; g.c_sn = dx.sb; g.c_sh = 2 * dx.sh; g.c_sw = 2; g.accumulate = accumulate;
     g.M = c.Cin; g.N = (int)NT; g.nsplit = sp; g.c_slab = ex.slabs; g.c_split = dx_total;
@@ -581,7 +575,7 @@ static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, i
             (NB == 1 || y.sb == (long long)c.cout_tot * P)) {
             if (!b_in_place) {
                 StageArgs sa{x.p, x.sb, x.sc, x.sh, NB, c.Cin, H, W, sk.OH, sk.OW, ex.sg, NT, 0};
-                ex.fail(sk.kind == 1 ? mcvc_im2col_s2_launch(sa, ex.s) : mcvc_im2col_1d_launch(sa, c.KW, ex.s));
+                ex.fail(mcvc_im2col_1d_launch(sa, c.KW, ex.s));
             }
             SGemmArgs g{};
             g.a = packed + c.off_fwd; g.lda = c.cout_pk;                       // Wt[k = taps*ci + tap][co] (value | gate columns)
@@ -700,8 +694,7 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
             ex.fail(mcvc_sgemm_launch(g, ex.s));
             if (!c_in_place) {
                 StageArgs sa{dx.p, dx.sb, dx.sc, dx.sh, NB, c.Cin, H, W, sk.OH, sk.OW, ex.sg, NT, 0};
-                ex.fail(sk.kind == 1 ? mcvc_col2im_s2_launch(sa, sp, KT * NT, accumulate, ex.s)
-                                     : mcvc_col2im_1d_launch(sa, c.KW, sp, KT * NT, accumulate, ex.s));
+                ex.fail(mcvc_col2im_1d_launch(sa, c.KW, sp, KT * NT, accumulate, ex.s));
             }
             if (nsplit) *nsplit = 1;
             return;
@@ -832,7 +825,8 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
     ConvProblem p{c.Cin, H, W, c.Cout, OH, OW, c.KH, c.KW, c.stride, c.ph, c.pw};
     // GEMM form (sgemm.h): pixel-major operands in the weight gradients' own staging region, K-split slabs, then dw += slabs
     const SgKind sk = sgemm_kind(c, NB, H, W);
-    const int KT = sk.taps * c.Cin;
+    const bool ig3 = ex.wgrad_x_xs && igemm_applies(c, H, W);             // a 3 x 3 stride-2 layer whose input arrives phase-split
+    const int KT = (ig3 ? 9 : sk.taps) * c.Cin;
     int sg_split = 1; long long sg_rows = 0;
     if (sk.kind) {
         const int tiles = (c.cout_tot / 64) * (KT / 64);
@@ -841,7 +835,21 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         sg_rows = (NT + unit - 1) / unit * unit;
         while (sg_split > 1 && sg_rows / sg_split < 64) { sg_split /= 2; sg_rows = (NT + 32LL * sg_split - 1) / (32LL * sg_split) * (32LL * sg_split); }
     }
-    const long long sg_floats = sk.kind ? sg_rows * ((long long)KT + c.cout_tot) + (long long)sg_split * c.cout_tot * KT : 0;
+    long long sg_floats = sk.kind ? sg_rows * ((long long)KT + c.cout_tot) + (long long)sg_split * c.cout_tot * KT : 0;
+    // implicit form (r5, wgemm_kernels.hip): x arrives phase-split (the layer's forward ran as an implicit GEMM) -- both operands are read where
+    // they lie; K split over the pixels when 128 x 32-filter tiles alone cannot fill the chip (slabs in the same staging region, dw_accum sums)
+    static const int wgemm_on = mcvc_knob("MCVC_WGEMM", 1);
+    const bool implicit = wgemm_on && ig3 && (c.cout_tot % 128) == 0 && (c.Cin % mcvc_wgemm_cib(9)) == 0 &&
+                          (c.nbr == 1 || (c.Cout % 32) == 0);
+    int wg_split = 1;
+    if (implicit) {
+        const int tiles = (c.cout_tot / 128) * (c.Cin / mcvc_wgemm_cib(9));
+        const long long nst = ((long long)NB * OH * OW + 31) / 32;
+        static const int wg_target = mcvc_knob("MCVC_WGEMM_WGS", 256), wg_max = mcvc_knob("MCVC_WGEMM_MAXSPLIT", 64);
+        // (a workgroup per compute unit -- a tile holds 156 KB of LDS -- and at least two pixel stages per split)
+        while (wg_split < wg_max && tiles * wg_split < wg_target && nst / (2 * wg_split) >= 2) wg_split *= 2;
+        sg_floats = wg_split > 1 ? (long long)wg_split * c.cout_tot * KT : 0;
+    }
     if (ex.dry) {          // K-split slabs: their own region, so they never alias the data-gradient slabs of the main stream
         if (sk.kind && sg_floats > ex.sgw_need) ex.sgw_need = sg_floats;          // (the direct kernel's slabs stay reserved as the fallback)
         const long long need = mcvc_wgrad_plan_slab_floats(p, NB);
@@ -857,10 +865,35 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         ws = ex.s2;
     }
     bool done = false;
-    if (sk.kind && ex.sgw && sg_floats <= ex.sgw_cap && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]])) {
+    if (implicit && (wg_split == 1 || (ex.sgw && sg_floats <= ex.sgw_cap)) && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]])) {
+        const int pw = mcvc_xs_pw(W);
+        const long long plane = mcvc_xs_plane(H, W);
+        WGemmArgs g{};
+        g.a = dy.p; g.a_cs = dy.sc; g.a_sn = dy.sb; g.a_pitch = dy.sh;
+        g.b = x.p; g.b_cs = x.sc; g.b_sn = x.sb; g.b_pitch = pw; g.ntaps = 9;
+        for (int kh = 0; kh < 3; ++kh)
+            for (int kw = 0; kw < 3; ++kw) {          // tap (kh, kw) of output (oh, ow) multiplies x[2 oh + kh - 1][2 ow + kw - 1]  (conv_fwd_igemm)
+                const int ph = (kh == 1) ? 0 : 1, di = (kh == 0) ? -1 : 0, pq = (kw == 1) ? 0 : 1, dj = (kw == 0) ? -1 : 0;
+                g.boff[3 * kh + kw] = (long long)(2 * ph + pq) * plane + (long long)(1 + di) * pw + 4 + dj;
+            }
+        g.zero = x.p;                                 // (row 0 of the first phase plane: zeros by construction of the layout)
+        g.OW = OW; g.P = OH * OW; g.NPIX = NB * g.P;
+        g.M = c.cout_tot; g.Cin = c.Cin; g.nsplit = wg_split;
+        if (wg_split == 1) {
+            g.c = grads[c.wi[0]]; g.accumulate = 1;
+            if (c.nbr == 2) { g.c2 = grads[c.wi[1]]; g.m_split = c.Cout; }
+            ex.fail(mcvc_wgemm_launch(g, ws));
+        } else {
+            g.c = ex.sgw; g.c_split = (long long)c.cout_tot * KT; g.c_slab = ex.sgw + g.c_split;
+            ex.fail(mcvc_wgemm_launch(g, ws));
+            ex.fail(mcvc_dw_accum_launch(ex.sgw, wg_split, g.c_split, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.cout_tot, KT, ws));
+        }
+        done = true;
+    }
+    if (!done && sk.kind && ex.sgw && sg_floats <= ex.sgw_cap && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]])) {
         float* xt = ex.sgw; float* dyt = xt + sg_rows * KT; float* slabs = dyt + sg_rows * c.cout_tot;
-        StageArgs sx{x.p, x.sb, x.sc, x.sh, NB, c.Cin, H, W, sk.OH, sk.OW, xt, KT, (int)sg_rows, (sk.kind == 1 && ex.wgrad_x_xs) ? 1 : 0};
-        ex.fail(sk.kind == 1 ? mcvc_im2col_s2_t_launch(sx, ws) : mcvc_im2col_1d_t_launch(sx, c.KW, ws));
+        StageArgs sx{x.p, x.sb, x.sc, x.sh, NB, c.Cin, H, W, sk.OH, sk.OW, xt, KT, (int)sg_rows, 0};
+        ex.fail(mcvc_im2col_1d_t_launch(sx, c.KW, ws));
         StageArgs sy{dy.p, dy.sb, dy.sc, dy.sh, NB, c.cout_tot, sk.OH, sk.OW, sk.OH, sk.OW, dyt, c.cout_tot, (int)sg_rows};
         ex.fail(mcvc_planes_t_launch(sy, ws));
         SGemmArgs g{};
@@ -1116,12 +1149,7 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             PackJob fi{}; fi.kind = PACK_FWD_TAP; fi.param = c.wi[br]; fi.dst = c.off_ifwd; fi.Cout = c.Cout; fi.K = K; fi.ld = c.cout_pk;
             fi.co_off = br * c.Cout; fi.KW = c.KH * c.KW;
             if (fw) add_job(t, fi, cdiv_i(K, 32), cdiv_i(c.Cout, 32));
-            PackDgradArgs u = a;
-            u.merged = 0; u.ld = c.cin_pk; u.tapmajor = 1; u.cout_rows = c.cout_tot;
-            for (int k = 0; k < c.ncls; ++k) u.cls[k] = c.icls[k];
-            PackJob di{}; di.kind = PACK_DGRAD; di.param = c.wi[br]; di.dst = c.off_idg; di.dg = (int)t.dga.size();
-            if (bw) { t.dga.push_back(u); add_job(t, di, cdiv_i(c.Cin, 32), c.Cout); }
-            t.bytes += 4.0 * (fw + bw) * 2.0 * c.Cout * K; t.wbytes += 4.0 * (fw + bw) * c.Cout * K;
+            t.bytes += 4.0 * fw * 2.0 * c.Cout * K; t.wbytes += 4.0 * fw * c.Cout * K;
         }
         if (c.wino3) {
             PackJob w3{}; w3.kind = PACK_WINO3_D; w3.param = c.wi[br]; w3.dst = c.off_w3; w3.Cout = c.Cout; w3.Cin = c.Cin; w3.ld = c.mg_ld;
@@ -2017,20 +2045,9 @@ static bool disc_igemm(const DiscDims& d)
 {
     const DiscNet& n = disc_net();
     bool ok = disc_out_direct() != 0;
-    for (int i = 0; i < 3 && ok; ++i) ok = igemm_applies(n.ds[i], d.H[i], d.W[i]) && sgemm_kind(n.ds[i], d.B, d.H[i], d.W[i]).kind == 1;
+    for (int i = 0; i < 3 && ok; ++i) ok = igemm_applies(n.ds[i], d.H[i], d.W[i]);
     return ok;
 }
-
-// ... and their data gradients too: from MCVC_IGEMM_DGRAD_NB samples per pass.  Measured (r4, one MI355X): at one or two samples per pass the
-// four parity classes of one launch are unbalanced (1 / 2 / 2 / 4 taps: the longest class is the launch) and the per-class weight copies cost
-// a re-pack of their own -- 59-63 us against 52-61 us for product + gather, + 74 us of re-pack per discriminator pair; from 8 samples per
-// pass the gather kernel and the 2.25x larger product output are what counts (bs=32: -4.5 ms of staging per iteration).
-static int igemm_dgrad_min_nb()
-{
-    static const int nb = mcvc_knob("MCVC_IGEMM_DGRAD_NB", 4);
-    return nb;
-}
-static bool disc_igemm_dgrad(const DiscDims& d) { return disc_igemm(d) && igemm_dgrad_min_nb() > 0 && d.B >= igemm_dgrad_min_nb(); }
 
 static void disc_forward_impl(Exec& ex, const float* const* P, const float* packed, const float* x, float* out, float* st, const DiscDims& d)
 {
@@ -2108,25 +2125,11 @@ static void disc_backward_impl(Exec& ex, const float* const* P, const float* pac
         if (disc_out_direct() && !ex.dry) ex.fail(mcvc_disc_out_dgrad_launch(dlogit, P[n.outc.wi[0]], GA, B, 1024, H3, W3, ex.s));
         else conv_dgrad(ex, n.outc, packed, B, H3, W3, dyv, View{GA, 1024LL * H3 * W3, (long long)H3 * W3, W3}, (long long)B * 1024 * H3 * W3, 0, 1, &ns);
     }
-    const bool ig = disc_igemm(d), ig_dg = disc_igemm_dgrad(d);
+    const bool ig = disc_igemm(d);
     for (int i = 2; i >= 0; --i) {
         const int Ci = kDC[i], Co = kDC[i + 1], Hi = d.H[i], Wi = d.W[i], Ho = d.H[i + 1], Wo = d.W[i + 1];
         GB = nextGB();
         const float* hin = (i == 0) ? (st + o.y0) : (st + o.y[i - 1]);
-        if (ig && !ig_dg) {
-            // implicit forward only (small batch): the input is stored phase-split -- the weight gradient's staging reads it as it is; the data
-            // gradient multiplies the OIHW tensors and gathers (it never reads the input)
-            const long long xpl = mcvc_xs_plane(Hi, Wi);
-            norm_bwd(ex, st + o.c[i], (long long)Co * Ho * Wo, (long long)Ho * Wo, normp(P, G, 4 + 4 * i, 5 + 4 * i), st + o.s[i],
-                     GA, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo, (long long)B * Co * Ho * Wo, ns,
-                     GB, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo, 0, B, Co, Ho, Wo, ACT_SILU);
-            CView dyv{GB, (long long)Co * Ho * Wo, (long long)Ho * Wo, Wo};
-            ex.wgrad_x_xs = 1;
-            conv_wgrad(ex, n.ds[i], G, B, Hi, Wi, CView{hin, (long long)Ci * 4 * xpl, 4 * xpl, Wi}, dyv);
-            ex.wgrad_x_xs = 0;
-            conv_dgrad(ex, n.ds[i], packed, B, Hi, Wi, dyv, View{GA, (long long)Ci * Hi * Wi, (long long)Hi * Wi, Wi}, (long long)B * Ci * Hi * Wi, 0, 1, &ns);
-            continue;
-        }
         if (ig) {
             // dY leaves the InstanceNorm backward in the padded layout the implicit data gradient gathers from (zero column / row written there);
             // the layer's input is stored phase-split (forward): the weight gradient's staging reads both as they are
@@ -2450,30 +2453,20 @@ int mcvc_disc_pack(const float* const* params, float* packed, void* stream)
     return pack_net(t, params, packed, (hipStream_t)stream);
 }
 
-// Discriminator re-pack restricted to what the staged-GEMM schedule reads: of the three stride-2 layers (99.9 % of the weights) only the
-// K-major FORWARD copy + bias -- their data gradient multiplies the OIHW parameters themselves and their weight gradient reads no weights
-// at all; the first / output layers (tiny) are refreshed in full.  Falls back to the full pack when a layer would not take that path at
-// (B = 1, T).  The direct kernels' data-gradient copies are then marked stale (bit 8) and refuse to run.
+// Discriminator re-pack restricted to what the implicit-GEMM schedule reads: of the three stride-2 layers (99.9 % of the weights) only the
+// tap-major FORWARD copy + bias -- it serves the forward pass and, read row-major, the data gradient (sgemm.h arow); the weight gradient reads
+// no weights at all; the first / output layers (tiny) are refreshed in full.  Falls back to the full pack when a layer would not take that
+// path at T frames.  The direct kernels' data-gradient copies are then marked stale (bit 8) and refuse to run.
 int mcvc_disc_pack_small(const float* const* params, float* packed, int T, void* stream) { return mcvc_disc_pack_batch(params, packed, 1, T, stream); }
 
-// ... for passes of up to max_batch samples: the per-class data-gradient copies of the implicit GEMMs are refreshed only when some pass is large
-// enough to use them (MCVC_IGEMM_DGRAD_NB)
-// which job table a discriminator re-pack for passes of up to max_batch samples uses: 1 = full, 2 = staged GEMMs, 3 / 4 = implicit GEMMs
-// with / without the per-class data-gradient copies; `skips` = the registry word it leaves
+// which job table a discriminator re-pack for passes of up to max_batch samples uses: 1 = full, 4 = implicit GEMMs; `skips` = the registry
+// word it leaves
 static int disc_pack_kind(int max_batch, int T, int* skips)
 {
-    const DiscNet& n = disc_net();
     const DiscDims d = disc_dims(max_batch < 1 ? 1 : max_batch, T);
-    bool staged = true;
-    for (int i = 0; i < 3; ++i) staged = staged && sgemm_kind(n.ds[i], 1, d.H[i], d.W[i]).kind == 1;
-    if (!staged) { *skips = 0; return 1; }
-    if (disc_igemm(d)) {          // implicit GEMMs: the tap-major forward copy (+ the per-class data-gradient copies) of the stride-2 layers
-        const bool dg = disc_igemm_dgrad(d);
-        *skips = dg ? 8 : (8 | 64);          // (bit 64: the per-class data-gradient copies of the implicit GEMMs are stale)
-        return dg ? 3 : 4;
-    }
-    *skips = 8;
-    return 2;
+    if (disc_igemm(d)) { *skips = 8; return 4; }
+    *skips = 0;
+    return 1;
 }
 static void disc_pack_build(PackTable& pt, int kind)
 {
@@ -2481,8 +2474,7 @@ static void disc_pack_build(PackTable& pt, int kind)
     add_spec_jobs(pt, n.conv1);
     for (int i = 0; i < 3; ++i) {
         if (kind == 1) add_spec_jobs(pt, n.ds[i]);
-        else if (kind == 2) add_spec_jobs(pt, n.ds[i], false, false, 1 | 4);
-        else add_spec_jobs(pt, n.ds[i], false, false, kind == 3 ? 3 : 1, true, true, true);
+        else add_spec_jobs(pt, n.ds[i], false, false, 1, true, true, true);
     }
     add_spec_jobs(pt, n.outc);
 }
@@ -2800,6 +2792,10 @@ static Needs layer_needs(const ConvSpec& c, int N, int H, int W, int scheme)
     if (igemm_applies(c, H, W)) {
         conv_fwd_igemm(ex, c, nullptr, N, H, W, nullptr, View{nullptr, (long long)c.cout_tot * OH * OW, (long long)OH * OW, OW}, (long long)N * c.cout_tot * OH * OW, 1, &ns);
         conv_dgrad_igemm(ex, c, nullptr, N, H, W, nullptr, View{nullptr, (long long)c.Cin * H * W, (long long)H * W, W}, (long long)N * c.Cin * H * W, 0, 1, &ns);
+        ex.wgrad_x_xs = 1;             // (the implicit weight gradient's K-split slabs)
+        conv_wgrad(ex, c, nullptr, N, H, W, CView{nullptr, (long long)c.Cin * 4 * mcvc_xs_plane(H, W), 4 * mcvc_xs_plane(H, W), W},
+                   CView{nullptr, (long long)c.cout_tot * OH * OW, (long long)OH * OW, OW});
+        ex.wgrad_x_xs = 0;
     }
     return Needs{(ex.slab_need + 3) & ~3LL, (ex.wslab_need + 3) & ~3LL, (ex.sg_need + 3) & ~3LL, (ex.sgw_need + 3) & ~3LL};
 }
@@ -2930,14 +2926,28 @@ int mcvc_layer_dgrad(const float* dy, const float* packed, const float* w0, cons
 int mcvc_layer_wgrad(const float* x, const float* dy, float* dw0, float* dw1, float* scratch, long long scratch_floats, int N, int H, int W,
                      int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w, int scheme, void* stream)
 {
-    if (!x || !dy || !dw0 || !scratch || scheme < 0 || scheme > 4 || branches < 1 || branches > 2 || (branches == 2 && !dw1)) return MCVC_ERR_INVALID;
+    if (!x || !dy || !dw0 || !scratch || scheme < 0 || scheme > 5 || branches < 1 || branches > 2 || (branches == 2 && !dw1)) return MCVC_ERR_INVALID;
     const LayerCtx l = layer_ctx(Cin, Cout, branches, KH, KW, stride, pad_h, pad_w);
+    const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
+    if (scheme == 5) {          // implicit weight gradient (wgemm_kernels.hip): the dense input is converted to the phase-split padded layout first
+        if (!igemm_applies(l.c, H, W)) return MCVC_ERR_INVALID;
+        int err5 = 0;
+        Exec ex5 = layer_exec(l.c, N, H, W, 0, scratch, scratch_floats, stream, &err5);
+        if (err5) return err5;
+        if ((long long)N * mcvc_xs_floats(Cin, H, W) > ex5.wino_cap) return MCVC_ERR_WORKSPACE;
+        ex5.fail(mcvc_xs_from_dense_launch(x, ex5.wv, N, Cin, H, W, ex5.s));
+        float* grads5[4] = {dw0, nullptr, dw1, nullptr};
+        const long long xpl = mcvc_xs_plane(H, W);
+        ex5.wgrad_x_xs = 1;
+        conv_wgrad(ex5, l.c, grads5, N, H, W, CView{ex5.wv, (long long)Cin * 4 * xpl, 4 * xpl, W},
+                   CView{dy, (long long)l.c.cout_tot * OH * OW, (long long)OH * OW, OW});
+        return ex5.err;
+    }
     SchemeGuard sg(scheme);
     int err = 0;
     Exec ex = layer_exec(l.c, N, H, W, scheme, scratch, scratch_floats, stream, &err);
     if (err) return err;
     float* grads[4] = {dw0, nullptr, dw1, nullptr};
-    const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
     conv_wgrad(ex, l.c, grads, N, H, W, CView{x, (long long)Cin * H * W, (long long)H * W, W},
                CView{dy, (long long)l.c.cout_tot * OH * OW, (long long)OH * OW, OW});
     return ex.err;

@@ -1,14 +1,13 @@
-// Strided 3x3 convolutions of the discriminators (downSample1-3, model.py:298-314) as staged GEMMs.
+// GEMM forms of the convolutions that are plain matrix products, on the 64x64 / k32 LDS-DMA GEMM pipeline (wino_kernels.hip):
 //
-// The three stride-2 layers are plain matrix products, and the 64x64 / k32 LDS-DMA GEMM pipeline (wino_kernels.hip) runs them at
-// 105-120 TF/s at 32+ samples per pass where the direct stride-2 kernels reach 40-60 (forward), 40 (data gradient) and 35-39 TF/s
-// (weight gradient): profiles/r02_gemm_probe.log; with a K-split it also wins at one sample per pass (13 % of the bs=1 iteration).
-// The operands that are not already matrices are staged once per pass (tap planes of x, 2.25x its size; all of it stays in HBM / MALL):
-//
-//   forward        Y[co][n]     = sum_k  Wt[k][co]  * Xcol[k][n]        k = 9*ci + 3*kh + kw, n = (b, oh, ow); + bias, stored as y[b][co][p]
-//   data gradient  dXcol[k][n]  = sum_co W[co][k]   * dY[co][n]         W = the OIHW parameter tensors themselves (value | gate rows),
-//                                                                      dY read in place ([b][co][p]); then dx[b][ci][ih][iw] gathers its <= 4 taps
-//   weight grad.   dW[co][k]    = sum_n  dYt[n][co] * XcolT[n][k]       both operands pixel-major; K-split slabs, then dw += sum of slabs
+//   * the discriminators' 3 x 3 stride-2 layers (downSample1-3, model.py:298-314) as IMPLICIT GEMMs -- forward and data gradient gather
+//     their B operand from the activation where it lies (igemm_kernel: phase-split padded input / padded dY), the data gradient reads the
+//     forward weight copy row-major, the weight gradient reads both operands in place (wgemm_kernels.hip): no tap planes, no transposed
+//     copies, no gather kernel (the staged forms of r2-r4 -- im2col_s2 / im2col_s2_t / col2im_s2 -- are gone);
+//   * the 1 x KW convolutions of the 1-D trunk beyond the fused small-batch kernels (more than 64 columns) as STAGED GEMMs (sgemm_kernel):
+//       forward        Y[co][n]     = sum_k  Wt[k][co]  * Xcol[k][n]        k = KW*ci + kw, n = (b, w); + bias
+//       data gradient  dXcol[k][n]  = sum_co W[co][k]   * dY[co][n]         W = the OIHW parameter tensors themselves (value | gate rows), then a gather
+//       weight grad.   dW[co][k]    = sum_n  dYt[n][co] * XcolT[n][k]       both operands pixel-major; K-split slabs, then dw += sum of slabs
 //
 #pragma once
 #include <hip/hip_runtime.h>
@@ -40,7 +39,9 @@ int mcvc_sgemm_launch(const SGemmArgs& a, hipStream_t s);
 //   forward of a 3x3 stride-2 convolution: one class, 9 taps over the PHASE-SPLIT padded input (xs layout below), C = y in place;
 //   data gradient: the four output-parity classes (1 + 2 + 2 + 4 taps) over dY with one zero column / row of padding, C scattered to
 //   dx[2a + qh][2b + qw] -- every input pixel is written by exactly one class: no tap planes, no gather kernel, no atomics.
-struct IGemmClass { const float* a; int ntaps; long long coff; long long boff[9]; };
+struct IGemmClass { const float* a; int ntaps; long long coff; long long boff[9]; int atap[9]; };
+// arow = 1: A is read from a row-major source shared by all classes -- element (k = (t, c), m) at a[(atap[t] * M + m) * lda + c] -- the
+// tap-major forward copy of a convolution's weights serving its data gradient (m = input channel, c = output channel)
 struct IGemmArgs {
     IGemmClass cls[4]; int ncls;
     long long lda;
@@ -48,12 +49,32 @@ struct IGemmArgs {
     int Cb;                             // channels per tap; K of class c = cls[c].ntaps * Cb
     int OW, P;                          // n -> (bb = n / P, i = (n % P) / OW, j = n % OW);  OW % 4 == 0
     float* c; long long ldc, c_sn; int c_sh, c_sw;
-    const float* bias; int accumulate;
+    const float* bias; int accumulate; int arow;
     int M, N;                           // M % 64 == 0, N % 4 == 0
     int nsplit; float* c_slab; long long c_split;      // K split of every class: split s > 0 writes the C layout at c_slab + (s - 1) * c_split
     int nt, mt;                         // (filled by the launcher)
 };
 int mcvc_igemm_launch(const IGemmArgs& a, hipStream_t s);
+
+// ---- implicit weight gradient (r5, wgemm_kernels.hip): both operands read where they lie, pixel-contiguous rows, no transposed copies ----------
+//     dW[co][ci][t] (+)= sum_{n = (bb, i, j)} dY(co, n) * X_t(ci, n)
+//     dY(co, n)  = a[co*a_cs + bb*a_sn + i*a_pitch + j]                   (dense planes or the padded dY layout)
+//     X_t(ci, n) = b[boff[t] + ci*b_cs + bb*b_sn + i*b_pitch + j]         (tap t's window: of the phase-split padded input for the 3 x 3 stride-2 layers)
+// dW = the OIHW gradient tensor(s): rows [0, m_split) -> c, the rest -> c2 (value | gate), row pitch Cin * ntaps.  K split over the pixels:
+// split s > 0 writes the same layout at c_slab + (s - 1) * c_split (split 0 then writes c plain; mcvc_dw_accum_launch sums), nsplit == 1 adds
+// straight into the gradient when `accumulate`.
+struct WGemmArgs {
+    const float* a; long long a_cs, a_sn; int a_pitch;
+    const float* b; long long b_cs, b_sn; int b_pitch; long long boff[9]; int ntaps;      // ntaps = 9 (3 x 3), 3 or 1 (1-D)
+    const float* zero;                   // 16 bytes of zeros, 16-byte aligned (the pieces beyond the last pixel)
+    int OW, P, NPIX;                     // n -> (bb = n / P, i = (n % P) / OW, j = n % OW); OW % 4 == 0; NPIX = samples * P
+    int M, Cin;                          // M % 128 == 0; Cin % 32 == 0 (ntaps = 9) / % 64 == 0
+    float* c; float* c2; int m_split; int accumulate;
+    int nsplit; float* c_slab; long long c_split;
+    long long ldc; int nstages, nt, mt;  // (filled by the launcher)
+};
+int mcvc_wgemm_launch(const WGemmArgs& a, hipStream_t s);
+int mcvc_wgemm_cib(int taps);            // input channels per workgroup tile
 
 // Phase-split padded activation layout ("xs") read by the implicit forward GEMM of a 3x3 stride-2 padding-1 convolution over an H x W image
 // (H, W even): per (sample, channel) four planes pq = 2*(h & 1) + (w & 1), each (H/2 + 1) rows of PW = W/2 + 4 floats; element (h, w) sits at
@@ -76,18 +97,11 @@ struct StageArgs {
     int NB, C, H, W, OH, OW;                               // 3x3, stride 2, padding 1: OH = (H + 1) / 2 ...
     float* out; long long ld;                              // see the launchers
     int rows_pad;                                          // transposed forms: rows [NB*OH*OW, rows_pad) are written as zeros
-    int xs;                                                // im2col_s2_t: x is in the phase-split padded layout (x_sb / x_sc = its sample / channel strides)
+    int xs;                                                // (unused since r5)
 };
-// Xcol[k = 9*ci + tap][n], ld >= NB*OH*OW
-int mcvc_im2col_s2_launch(const StageArgs& a, hipStream_t s);
-// XcolT[n][k], ld = 9*C
-int mcvc_im2col_s2_t_launch(const StageArgs& a, hipStream_t s);
 // Yt[n][c] from y[b][c][p] (H x W = the plane of y; OH/OW unused), ld = C
 int mcvc_planes_t_launch(const StageArgs& a, hipStream_t s);
-// dx[b][ci][ih][iw] (=|+=) sum over the taps that reach it of dXcol[9*ci + tap][n], summed over nslab K-split slabs of dXcol
-// (x / x_* = the dx view; out = dXcol, read)
-int mcvc_col2im_s2_launch(const StageArgs& a, int nslab, long long slab_stride, int accumulate, hipStream_t s);
-// The same for 1 x KW convolutions along w (KW = 1, 3; stride 1, padding (KW-1)/2) over an image of NB*H rows -- the 1-D trunk at more
+// Staged forms of the 1 x KW convolutions along w (KW = 1, 3; stride 1, padding (KW-1)/2) over an image of NB*H rows -- the 1-D trunk at more
 // than 32 columns (model.py:47-76, 142-189): k = KW*ci + tap, n = (b*H + h)*W + w
 int mcvc_im2col_1d_launch(const StageArgs& a, int KW, hipStream_t s);
 int mcvc_im2col_1d_t_launch(const StageArgs& a, int KW, hipStream_t s);

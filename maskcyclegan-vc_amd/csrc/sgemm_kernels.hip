@@ -128,6 +128,13 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const Twin<SGemmArgs> tw)
 
 
 // ---- implicit GEMM: sgemm_kernel with a gathered B operand, per-class A / C and a strided (scatter) C store -- see sgemm.h ----------------
+// AROW (r5, the data gradient): the A operand is read from a ROW-major source -- rows = m, the 32 k of a stage contiguous -- which is what the
+// tap-major FORWARD copy of the weights is to the data gradient (row (tap, ci), output channels contiguous: m = ci, k = co).  The tile is
+// staged as [64 rows][8 pieces of 16 bytes] (piece p of row r at slot p ^ ((r >> 1) & 7): the lane that fills LDS slot s fetches the piece
+// that belongs there) and the transposition happens in the operand read: the k slots of the 16 MFMAs of a stage are pixel... channel
+// 16 * half + j (an MFMA's k index is only a label -- B is read at the same rows), so a lane needs 16 consecutive floats of its row = four
+// conflict-free ds_read_b128 (wgemm_kernels.hip has the bank argument).  The per-class data-gradient copies of r4 are gone.
+template <bool AROW>
 __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
 {
     const IGemmArgs& a = tw.v[blockIdx.z];
@@ -157,6 +164,10 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int f = tid + i * 256;
+        if (AROW) {                                                // slot f of the [64 rows][8 pieces] tile: row f / 8, swizzled piece
+            const int row = f >> 3, pc = (f & 7) ^ ((row >> 1) & 7);
+            aoff[i] = (long long)(m0 + row) * lda + 4 * pc;
+        } else
         aoff[i] = (long long)(f / (BM / 4)) * lda + m0 + 4 * (f % (BM / 4));
         adst[i] = (wave * 64 + i * 256) * 4;
     }
@@ -174,7 +185,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
         float* base = smem + buf * STAGE;
         const int k0 = kbase + stage_k * GK;
         const int t = k0 / Cb, c0 = k0 - t * Cb;                  // (a stage lies inside one tap: Cb % 32 == 0)
-        const float* ab = A + (long long)k0 * lda;
+        const float* ab = AROW ? A + (long long)cl.atap[t] * a.M * lda + c0 : A + (long long)k0 * lda;
         const float* bb = Bp + cl.boff[t] + (long long)c0 * b_cs;
 #pragma unroll
         for (int i = 0; i < NA; ++i) glds16(ab + aoff[i], base + adst[i]);
@@ -196,6 +207,25 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
         __builtin_amdgcn_s_barrier();
         if (st + ST - 1 < nst) issue(st + ST - 1, (st + ST - 1) % ST);
         const float* sb = smem + (st % ST) * STAGE;
+        if (AROW) {
+            const float* ar = sb + (wm * 32 + l31) * GK;
+            const int sw = (l31 >> 1) & 7;
+            float4 av[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const float4*>(ar + (((4 * half + q) ^ sw) << 2));
+            const float* br = sb + SA + (16 * half) * BN + wn * 32 + l31;
+            float bv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) bv[j] = br[j * BN];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[4 * q + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bv[4 * q + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bv[4 * q + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[4 * q + 3], acc, 0, 0, 0);
+            }
+            continue;
+        }
         float a0 = sb[a_lane], b0 = sb[b_lane];
 #pragma unroll
         for (int p = 0; p < GK / 2; ++p) {
@@ -239,71 +269,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
     }
 }
 
-// ---- staging ----------------------------------------------------------------------------------------------------------------
-// tap (kh, kw) of output pixel (oh, ow) reads x[2*oh + kh - 1][2*ow + kw - 1]
-__global__ void __launch_bounds__(256) im2col_s2_kernel(const Twin<StageArgs> tw)
-{
-    const StageArgs a = tw.v[blockIdx.z];
-    const int P = a.OH * a.OW;
-    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int ci = blockIdx.y;
-    if (n >= (long long)a.NB * P) return;
-    const int b = (int)(n / P), p = (int)(n - (long long)b * P);
-    const int oh = p / a.OW, ow = p - oh * a.OW;
-    const float* xp = a.x + (long long)b * a.x_sb + (long long)ci * a.x_sc;
-    float* o = a.out + (long long)ci * 9 * a.ld + n;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int ih = 2 * oh + kh - 1;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int iw = 2 * ow + kw - 1;
-            const bool ok = ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-            o[(long long)(3 * kh + kw) * a.ld] = ok ? xp[(long long)ih * a.x_sh + iw] : 0.f;
-        }
-    }
-}
-
-// XcolT[n][9*ci + tap]: 32 pixels x 32 channels per workgroup through LDS (reads along pixels, writes along k)
-__global__ void __launch_bounds__(256) im2col_s2_t_kernel(const Twin<StageArgs> tw)
-{
-    const StageArgs a = tw.v[blockIdx.z];
-    __shared__ float tile[32][32 * 9 + 1];
-    const int P = a.OH * a.OW;
-    const long long NT = (long long)a.NB * P;
-    const long long n0 = (long long)blockIdx.x * 32;
-    const int c0 = blockIdx.y * 32;
-    const int nl = threadIdx.x & 31, cw = threadIdx.x >> 5;        // 8 channel rows per sweep
-    const int xs_pw = a.W / 2 + 4;
-    const long long xs_plane = (long long)(a.H / 2 + 1) * xs_pw;
-    const long long n = n0 + nl;
-    const bool live = n < NT;
-    int b = 0, oh = 0, ow = 0;
-    if (live) { b = (int)(n / P); const int p = (int)(n - (long long)b * P); oh = p / a.OW; ow = p - oh * a.OW; }
-    for (int cl = cw; cl < 32; cl += 8) {
-        const int ci = c0 + cl;
-        const float* xp = a.x + (long long)b * a.x_sb + (long long)ci * a.x_sc;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int ih = 2 * oh + kh - 1;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int iw = 2 * ow + kw - 1;
-                const bool ok = live && ci < a.C && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-                const long long xo = a.xs ? (long long)((ih & 1) * 2 + (iw & 1)) * xs_plane + (long long)((ih >> 1) + 1) * xs_pw + (iw >> 1) + 4
-                                          : (long long)ih * a.x_sh + iw;
-                tile[nl][cl * 9 + 3 * kh + kw] = ok ? xp[xo] : 0.f;
-            }
-        }
-    }
-    __syncthreads();
-    const int kmax = (a.C - c0 < 32 ? a.C - c0 : 32) * 9;
-    for (int e = threadIdx.x; e < 32 * 288; e += 256) {
-        const int r = e / 288, k = e - r * 288;
-        if (n0 + r < a.rows_pad && k < kmax) a.out[(n0 + r) * a.ld + (long long)c0 * 9 + k] = tile[r][k];
-    }
-}
-
+// ---- staging of the 1-D trunk's GEMM forms ----------------------------------------------------------------------------------------
 // Yt[n][c] from y[b][c][p]
 __global__ void __launch_bounds__(256) planes_t_kernel(const Twin<StageArgs> tw)
 {
@@ -326,44 +292,6 @@ __global__ void __launch_bounds__(256) planes_t_kernel(const Twin<StageArgs> tw)
     for (int r = ty; r < 32; r += 8)
         if (n0 + r < a.rows_pad && c0 + tx < a.C) a.out[(n0 + r) * a.ld + c0 + tx] = tile[tx][r];
 }
-
-// dx[b][ci][ih][iw] (=|+=) the taps that reach it: kh = ih + 1 - 2*oh in [0, 3)
-struct Col2imS2KArgs { StageArgs a; int nslab; long long slab_stride; int accumulate; };
-__global__ void __launch_bounds__(256) col2im_s2_kernel(const Twin<Col2imS2KArgs> tw)
-{
-    const Col2imS2KArgs ka_ = tw.v[blockIdx.z];
-    const StageArgs& a = ka_.a;
-    int nslab = ka_.nslab;
-    long long slab_stride = ka_.slab_stride;
-    int accumulate = ka_.accumulate;
-    const int HW = a.H * a.W, P = a.OH * a.OW;
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int ci = blockIdx.y;
-    if (e >= (long long)a.NB * HW) return;
-    const int b = (int)(e / HW), q = (int)(e - (long long)b * HW);
-    const int ih = q / a.W, iw = q - ih * a.W;
-    const float* col = a.out + (long long)ci * 9 * a.ld + (long long)b * P;
-    float s = 0.f;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int t = ih + 1 - kh;
-        if (t < 0 || (t & 1)) continue;
-        const int oh = t >> 1;
-        if (oh >= a.OH) continue;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int u = iw + 1 - kw;
-            if (u < 0 || (u & 1)) continue;
-            const int ow = u >> 1;
-            if (ow >= a.OW) continue;
-            const float* cp = col + (long long)(3 * kh + kw) * a.ld + oh * a.OW + ow;
-            for (int k = 0; k < nslab; ++k) s += cp[(long long)k * slab_stride];
-        }
-    }
-    float* d = const_cast<float*>(a.x) + (long long)b * a.x_sb + (long long)ci * a.x_sc + (long long)ih * a.x_sh + iw;
-    *d = accumulate ? *d + s : s;
-}
-
 
 // ---- 1 x KW convolutions along w (stride 1, padding (KW-1)/2) over rows (b, h): the 1-D trunk run as an image of B rows -------------
 // Xcol[KW*ci + tap][n] = x[b][ci][h][w + tap - pw],  n = (b*H + h)*W + w
@@ -567,27 +495,14 @@ int mcvc_igemm_launch(const IGemmArgs& a0, hipStream_t s)
     constexpr size_t lds = (size_t)ST * STAGE * sizeof(float);
     static bool done = false;
     if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         done = true;
     }
     TraceScope ts(K_SGEMM, s, flops, bytes);
-    mcvc_launch(igemm_kernel, dim3((unsigned)(a.nt * a.mt * a.nsplit), (unsigned)a.ncls), dim3(256), lds, s, a);
-    return (int)hipGetLastError();
-}
-
-int mcvc_im2col_s2_launch(const StageArgs& a, hipStream_t s)
-{
-    const long long NT = (long long)a.NB * a.OH * a.OW;
-    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.NB * a.C * a.H * a.W + 9.0 * a.C * NT));
-    mcvc_launch(im2col_s2_kernel, dim3((unsigned)((NT + 255) / 256), (unsigned)a.C), dim3(256), 0, s, a);
-    return (int)hipGetLastError();
-}
-
-int mcvc_im2col_s2_t_launch(const StageArgs& a, hipStream_t s)
-{
-    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.NB * a.C * a.H * a.W + 9.0 * a.C * a.rows_pad));
-    mcvc_launch(im2col_s2_t_kernel, dim3((unsigned)((a.rows_pad + 31) / 32), (unsigned)cdiv_i(a.C, 32)), dim3(256), 0, s, a);
+    if (a.arow) mcvc_launch(igemm_kernel<true>, dim3((unsigned)(a.nt * a.mt * a.nsplit), (unsigned)a.ncls), dim3(256), lds, s, a);
+    else mcvc_launch(igemm_kernel<false>, dim3((unsigned)(a.nt * a.mt * a.nsplit), (unsigned)a.ncls), dim3(256), lds, s, a);
     return (int)hipGetLastError();
 }
 
@@ -597,15 +512,6 @@ int mcvc_planes_t_launch(const StageArgs& a, hipStream_t s)
     mcvc_launch(planes_t_kernel, dim3((unsigned)((a.rows_pad + 31) / 32), (unsigned)cdiv_i(a.C, 32)), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
-
-int mcvc_col2im_s2_launch(const StageArgs& a, int nslab, long long slab_stride, int accumulate, hipStream_t s)
-{
-    const long long NE = (long long)a.NB * a.H * a.W;
-    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((accumulate ? 2.0 : 1.0) * a.NB * a.C * a.H * a.W + 9.0 * nslab * a.C * a.NB * a.OH * a.OW));
-    mcvc_launch(col2im_s2_kernel, dim3((unsigned)((NE + 255) / 256), (unsigned)a.C), dim3(256), 0, s, Col2imS2KArgs{a, nslab, slab_stride, accumulate});
-    return (int)hipGetLastError();
-}
-
 
 int mcvc_im2col_1d_launch(const StageArgs& a, int KW, hipStream_t s)
 {

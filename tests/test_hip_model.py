@@ -346,12 +346,15 @@ def _launches(kind_name, fn):
     return int(buf[4 * names.index(kind_name)])
 
 
-@pytest.mark.parametrize("B,T", [(1, 64), (2, 64), (8, 64), (9, 64), (8, 72)])
+@pytest.mark.parametrize("B,T", [(1, 64), (2, 64), (3, 64), (4, 64), (8, 64), (9, 64), (16, 64), (2, 128), (8, 72)])
 def test_discriminator_gemm_path_vs_oracle(B, T, nets, meta):
-    """The discriminators' stride-2 3x3 layers run as staged GEMMs (csrc/sgemm.h: tap planes -> batched-GEMM pipeline -> gather),
-    forward, data gradient and weight gradient: whole discriminator, every gradient, vs the CPU oracle (model.py:298-349).
-    B = 1, 2: K-split products whose slabs the consumers sum; B = 9: a pixel count that is not a multiple of the K-split unit (zero
-    rows); T = 72: the last strided layer's plane is not a multiple of 4 and stays on the direct kernels."""
+    """The discriminators' stride-2 3x3 layers run as IMPLICIT GEMMs (csrc/sgemm.h): forward and data gradient gather their B operand from
+    the phase-split padded input / the padded dY, the data gradient reads the forward weight copy row-major, the weight gradient reads dY and
+    the phase-split input in place (wgemm_kernels.hip) -- no tap planes, transposed operands or gather kernel at ANY batch size (r5; r2-r4
+    staged them below 4 samples per pass and for every weight gradient).  Whole discriminator, every gradient, vs the CPU oracle
+    (model.py:298-349).  B = 1, 2, 3: K-split products whose slabs the consumers sum, K-split weight gradients (slabs + dw_accum); B = 9: pixel
+    counts that are no multiple of a tile; B = 16: the large-pass splits; T = 128: other plane shapes; T = 72: planes the implicit kernels do
+    not take (36 / 18 / 9 columns) -- the direct kernels."""
     _, d = nets
     dp = orc.filler_params("D", meta["filler_seeds"]["D"])
     dn = orc.discriminator_param_names()
@@ -372,7 +375,7 @@ def test_discriminator_gemm_path_vs_oracle(B, T, nets, meta):
         (dd * w.cuda()).sum().backward()
         out["d"] = dd
     n_gemm = _launches("sgemm", run)
-    assert n_gemm == (9 if T == 64 else 6), n_gemm            # 3 layers (2 at T = 72) x {forward, data gradient, weight gradient}
+    assert n_gemm == (0 if T == 72 else 9), n_gemm            # 3 layers x {forward, data gradient, weight gradient}; none at T = 72
     assert rel_l2(out["d"], dr) < TOL
     assert rel_l2(xd.grad, ref[0]) < TOL
     ddict = dict(d.named_parameters())
@@ -383,7 +386,7 @@ def test_discriminator_gemm_path_vs_oracle(B, T, nets, meta):
             continue
         e = rel_l2(ddict[k].grad, r); worst = max(worst, e)
         assert e < TOL, (k, e)
-    print("B=%d T=%d staged-GEMM discriminator: worst parameter-gradient rel-L2 vs oracle %.3e" % (B, T, worst))
+    print("B=%d T=%d implicit-GEMM discriminator: worst parameter-gradient rel-L2 vs oracle %.3e" % (B, T, worst))
 
 
 def test_generator_repack_in_two_parts_and_its_guard():

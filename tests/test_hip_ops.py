@@ -267,7 +267,8 @@ def test_batched_winograd_gemm_matches_torch(nb, M, N, K):
 # ---- op-level parity of the kernels that carry the trainer's shapes (r4): Winograd / staged-GEMM layers and the fused trunk backward ----
 # (name, Cin, Cout, branches, KH, KW, stride, ph, pw, N, H, W, pixel_shuffle, schemes)
 #   schemes: 1 = Winograd, 2x2 output tiles (F(2x2,5x5) / phase F(2x2,3x3)); 2 = 4x4 tiles (F(4x4,5x5) / phase F(4x4,3x3));
-#            3 = no Winograd (the discriminators' layers: staged GEMM); 0 = the planner's choice at this shape
+#            3 = no Winograd (the discriminators' layers: the direct kernels); 0 = the planner's choice at this shape;
+#            5 = implicit GEMMs (forward, data gradient by parity classes, weight gradient with both operands in place)
 LAYER_CASES = [
     ("up2.T64", 256, 512, 1, 5, 5, 1, 2, 2, 1, 40, 32, True, (0, 1, 2)),
     ("up2.B2", 256, 512, 1, 5, 5, 1, 2, 2, 2, 40, 32, True, (1, 2)),
@@ -286,6 +287,8 @@ LAYER_CASES = [
     ("d.ds2.B9", 256, 512, 1, 3, 3, 2, 1, 1, 9, 40, 32, False, (3, 5)),
     ("d.ds3.T128", 512, 1024, 1, 3, 3, 2, 1, 1, 1, 20, 32, False, (5,)),
     ("d.ds1.small", 128, 256, 1, 3, 3, 2, 1, 1, 1, 12, 16, False, (5,)),
+    ("d.ds1.B4", 128, 256, 1, 3, 3, 2, 1, 1, 4, 80, 64, False, (5,)),              # K split of the implicit weight gradient over 160 pixel stages
+    ("d.ds3.B8", 512, 1024, 1, 3, 3, 2, 1, 1, 8, 20, 16, False, (5,)),             # 128 tiles, no split: straight into the gradient
 ]
 _LAYER_IDS = ["%s-s%d" % (c[0], s) for c in LAYER_CASES for s in c[-1]]
 _LAYER_PARAMS = [(c, s) for c in LAYER_CASES for s in c[-1]]
@@ -329,7 +332,7 @@ def test_layer_ops_match_torch(c, scheme):
     # weight gradients (accumulated into zeros; value | gate rows to their own tensors)
     dws = [torch.zeros_like(w) for w in wd]
     check(L.mcvc_layer_wgrad(ptr(xd), ptr(dyd), ptr(dws[0]), ptr(dws[1]) if nbr == 2 else None, ptr(scratch), scratch.numel(), N, H, W, *spec,
-                             3 if scheme == 5 else scheme, stream()), "layer_wgrad")          # (the weight gradient of these layers is a staged GEMM)
+                             scheme, stream()), "layer_wgrad")          # (5: the implicit weight gradient, both operands read where they lie)
     dw_ref = torch.nn.grad.conv2d_weight(x, wcat.shape, dy, stride=s, padding=(ph, pw))
     for br in range(nbr):
         e = rel_l2(dws[br], dw_ref[br * Cout:(br + 1) * Cout])
