@@ -42,8 +42,8 @@ static inline int round_up_i(int a, int b) { return cdiv_i(a, b) * b; }
 // convolution of dY with re-packed weights).  Implicit GEMM on v_mfma_f32_32x32x2_f32:
 //   M = output channel (co), N = output pixel, K = (input channel, kh, kw).
 // The input patch of a pixel tile is staged ONCE in LDS per channel chunk and every tap reads a
-// shifted window of it -- this kernel reads no im2col buffer (the staged GEMMs of sgemm_kernels.hip are the one
-// place in the library where tap planes / transposed operands are materialised: DESIGN.md section 4).
+// shifted window of it -- no im2col buffer exists anywhere in the library (r5: the GEMM-shaped layers -- the discriminators'
+// 3 x 3 stride-2 convolutions, the 1-D trunk beyond the fused kernels -- gather their operands in place too: sgemm.h).
 // ------------------------------------------------------------------------------------------------
 enum ConvOutMode { CONV_OUT_SLAB = 0, CONV_OUT_ACCUM = 1 };
 

@@ -449,19 +449,22 @@ static bool conv_wino(Exec& ex, const ConvSpec& c, const float* packed, int dgra
 // IMPLICIT GEMMs in every pass whose shapes allow it (igemm_applies) and on the direct kernels otherwise.)
 struct SgKind { int kind, taps, OH, OW; };
 static thread_local int t_no_sgemm = 0;
+// (op-level entries: operands are the CALLER's tensors.  The 1 x 3 implicit forms read one float in front of / behind a tensor -- the shifted
+//  windows' first / last piece, whose out-of-row element is then dropped -- which is inside the library's own stash / scratch layouts but not
+//  guaranteed to be mapped for a foreign allocation: those entries keep the direct kernels for 1-D layers)
+static thread_local int t_user_operands = 0;
 static SgKind sgemm_kind(const ConvSpec& c, int NB, int H, int W)
 {
     static const int min_cols = mcvc_knob("MCVC_SGEMM1D_COLS", 64);
     SgKind k{0, 0, 0, 0};
-    if (t_no_sgemm) return k;
+    if (t_no_sgemm || t_user_operands) return k;
     if (c.nbr > 2 || (c.cout_tot % 64) != 0 || (c.Cout % 32) != 0 || c.cin_pad != c.Cin) return k;
     if (c.KH == 1 && (c.KW == 1 || c.KW == 3) && c.stride == 1 && c.ph == 0 && c.pw == (c.KW - 1) / 2) {
         k.OH = H; k.OW = W; k.taps = c.KW;
-        if (min_cols > 0 && (long long)NB * H * W >= min_cols && ((c.Cin * c.KW) % 64) == 0 && ((H * W) % 4) == 0) k.kind = 2;
+        if (min_cols > 0 && (long long)NB * H * W >= min_cols && (c.Cin % 64) == 0 && (W & 3) == 0) k.kind = 2;
     }
     return k;
 }
-static void sgemm_want(Exec& ex, long long floats) { if (floats > ex.sg_need) ex.sg_need = floats; }
 // K-split: the smallest power-of-two split (<= 8) that yields >= 256 workgroups while a slab keeps >= 64 k per half.  (A cost-model split
 // against round quantisation -- stream-K's effect with uniform splits -- was built in r4 and measured SLOWER inside the concurrent lanes: bs=8
 // 22.2-22.6 -> 23.0-23.2 ms, the other lanes' kernels already fill a product's last round; removed)
@@ -511,8 +514,9 @@ static void conv_fwd_igemm(Exec& ex, const ConvSpec& c, const float* packed, int
         for (int kw = 0; kw < 3; ++kw) {          // tap (kh, kw) of output (oh, ow) reads x[2 oh + kh - 1][2 ow + kw - 1]
             const int ph = (kh == 1) ? 0 : 1, di = (kh == 0) ? -1 : 0, pq = (kw == 1) ? 0 : 1, dj = (kw == 0) ? -1 : 0;
             g.cls[0].boff[3 * kh + kw] = (long long)(2 * ph + pq) * plane + (long long)(1 + di) * pw + 4 + dj;
+            g.cls[0].aoff[3 * kh + kw] = (long long)(3 * kh + kw) * c.Cin * c.cout_pk;      // tap-major copy: rows (tap, ci)
         }
-    g.lda = c.cout_pk;
+    g.a_ks = c.cout_pk;
     g.b = xs; g.b_cs = 4 * plane; g.b_sn = (long long)c.Cin * 4 * plane; g.b_pitch = pw; g.Cb = c.Cin; g.OW = OW; g.P = P;
     g.c = y.p; g.ldc = y.sc; g.c_sn = y.sb; g.c_sh = y.sh; g.c_sw = 1;
     g.bias = packed + c.off_bias;
@@ -548,10 +552,10 @@ static void conv_dgrad_igemm(Exec& ex, const ConvSpec& c, const float* packed, i
             for (int v = 0; v < d.ntw; ++v) {     // input row 2a + qh receives tap kh from output row a + (qh + 1 - kh) / 2
                 const int kh = d.khmax - 2 * u, kw = d.kwmax - 2 * v;
                 q.boff[u * d.ntw + v] = (long long)((d.qh + 1 - kh) / 2) * pitch + (d.qw + 1 - kw) / 2;
-                q.atap[u * d.ntw + v] = 3 * kh + kw;
+                q.aoff[u * d.ntw + v] = (long long)(3 * kh + kw) * c.Cin * c.cout_pk;
             }
     }
-    g.lda = c.cout_pk; g.arow = 1;
+    g.a_ks = c.cout_pk; g.arow = 1;
     g.b = dyp; g.b_cs = plane; g.b_sn = (long long)c.cout_tot * plane; g.b_pitch = pitch; g.Cb = c.cout_tot; g.OW = OW; g.P = P;
     g.c = dx.p; g.ldc = dx.sc; g.c_sn = dx.sb; g.c_sh = 2 * dx.sh; g.c_sw = 2; g.accumulate = accumulate;
     g.M = c.Cin; g.N = (int)NT; g.nsplit = sp; g.c_slab = ex.slabs; g.c_split = dx_total;
@@ -565,22 +569,33 @@ static void conv_fwd(Exec& ex, const ConvSpec& c, const float* packed, int NB, i
     if (sk.kind) {
         const int P = sk.OH * sk.OW, KT = sk.taps * c.Cin;
         const long long NT = (long long)NB * P;
-        const bool b_in_place = sk.kind == 2 && c.KW == 1;                                   // a 1x1 conv multiplies x itself
-        const long long stage = b_in_place ? 0 : KT * NT;
+        const bool b_in_place = c.KW == 1;                                                    // a 1x1 conv multiplies x itself
         const int sp = (allow_split && nsplit) ? sgemm_split(c.cout_tot, NT, KT) : 1;       // slabs 1.. are summed by the consumer (norm / act)
         const long long slab_need = (long long)(sp - 1) * y_total;
-        if (ex.dry) { sgemm_want(ex, stage); if (slab_need > ex.slab_need) ex.slab_need = slab_need; if (nsplit) *nsplit = sp; return; }
-        if (sk.kind == 2 && (ex.pack_skips & 1) && c.off_tk >= 0) { ex.fail(MCVC_ERR_INVALID); return; }     // stale K-major copy
-        if ((b_in_place ? (x.sh == W && x.sc == P) : (ex.sg && stage <= ex.sg_cap)) && slab_need <= ex.slab_cap && y.sh == sk.OW && y.sc == P &&
+        if (ex.dry) { if (slab_need > ex.slab_need) ex.slab_need = slab_need; if (nsplit) *nsplit = sp; return; }
+        if ((ex.pack_skips & 1) && c.off_tk >= 0) { ex.fail(MCVC_ERR_INVALID); return; }     // stale K-major copy
+        if (!b_in_place && slab_need <= ex.slab_cap && y.sh == sk.OW && y.sc == P && (NB == 1 || y.sb == (long long)c.cout_tot * P)) {
+            // 1 x 3 over dense rows: an implicit GEMM (sgemm.h) -- the three windows of x are gathered where they lie, shifted by -1 / 0 / +1
+            // column; the K-major forward copy's rows are (ci, kw), so a tap's rows are KW apart
+            IGemmArgs g{};
+            g.ncls = 1;
+            IGemmClass& q = g.cls[0];
+            q.a = packed + c.off_fwd; q.ntaps = c.KW; q.coff = 0;
+            for (int kw = 0; kw < c.KW; ++kw) { q.boff[kw] = kw - c.pw; q.aoff[kw] = (long long)kw * c.cout_pk; q.zs[kw] = kw < c.pw ? 1 : (kw > c.pw ? 2 : 0); }
+            g.a_ks = (long long)c.KW * c.cout_pk; g.zw = W;
+            g.b = x.p; g.b_cs = x.sc; g.b_sn = x.sb; g.b_pitch = x.sh; g.Cb = c.Cin; g.OW = W; g.P = P;
+            g.c = y.p; g.ldc = y.sc; g.c_sn = y.sb; g.c_sh = y.sh; g.c_sw = 1;
+            g.bias = packed + c.off_bias;
+            g.M = c.cout_tot; g.N = (int)NT; g.nsplit = sp; g.c_slab = ex.slabs; g.c_split = y_total;
+            ex.fail(mcvc_igemm_launch(g, ex.s));
+            if (nsplit) *nsplit = sp;
+            return;
+        }
+        if (b_in_place && x.sh == W && x.sc == P && slab_need <= ex.slab_cap && y.sh == sk.OW && y.sc == P &&
             (NB == 1 || y.sb == (long long)c.cout_tot * P)) {
-            if (!b_in_place) {
-                StageArgs sa{x.p, x.sb, x.sc, x.sh, NB, c.Cin, H, W, sk.OH, sk.OW, ex.sg, NT, 0};
-                ex.fail(mcvc_im2col_1d_launch(sa, c.KW, ex.s));
-            }
             SGemmArgs g{};
-            g.a = packed + c.off_fwd; g.lda = c.cout_pk;                       // Wt[k = taps*ci + tap][co] (value | gate columns)
-            if (b_in_place) { g.b = x.p; g.ldb = x.sc; g.bseg = P; g.b_sn = x.sb; }
-            else { g.b = ex.sg; g.ldb = NT; g.bseg = (int)NT; g.b_sn = 0; }
+            g.a = packed + c.off_fwd; g.lda = c.cout_pk;                       // Wt[k = ci][co] (value | gate columns)
+            g.b = x.p; g.ldb = x.sc; g.bseg = P; g.b_sn = x.sb;
             g.c = y.p; g.ldc = y.sc; g.cseg = P; g.c_sn = y.sb;
             g.bias = packed + c.off_bias;
             g.M = c.cout_tot; g.N = (int)NT; g.K = KT; g.nsplit = sp; g.c_slab = ex.slabs; g.c_split = y_total;
@@ -675,30 +690,37 @@ static void conv_dgrad(Exec& ex, const ConvSpec& c, const float* packed, int NB,
     const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
     const int st = c.stride;
     const SgKind sk = sgemm_kind(c, NB, H, W);
-    if (sk.kind && (ex.dry || ex.params)) {
-        const int P = sk.OH * sk.OW, KT = sk.taps * c.Cin;
+    if (sk.kind) {
+        // 1 x KW over dense rows as an implicit GEMM (sgemm.h): M = input channels, K = (kw, output channel); A = the K-major FORWARD copy read
+        // row-major (rows (ci, kw), output channels contiguous: arow), B = the windows of dY shifted by pw - kw columns.  An accumulating
+        // destination with a K split leaves dx alone: all splits go to slabs and the consumer sums dx + slabs (*nsplit = splits + 1).
+        const int P = sk.OH * sk.OW;
         const long long NT = (long long)NB * P;
-        const int sp = sgemm_split(KT, NT, c.cout_tot);
-        const bool c_in_place = sk.kind == 2 && c.KW == 1 && sp == 1;                      // a 1x1 conv's product IS dx
-        const long long stage = c_in_place ? 0 : sp * KT * NT;
-        if (ex.dry) { sgemm_want(ex, stage); if (nsplit) *nsplit = 1; return; }
-        if ((c_in_place ? (dx.sh == W && dx.sc == P) : (ex.sg && stage <= ex.sg_cap)) && dy.sh == sk.OW && dy.sc == P && ex.params[c.wi[0]] &&
-            (c.nbr == 1 || ex.params[c.wi[1]])) {
-            SGemmArgs g{};
-            g.a = ex.params[c.wi[0]]; g.lda = KT;                                                      // W[co][k]: the OIHW tensors themselves
-            if (c.nbr == 2) { g.a2 = ex.params[c.wi[1]]; g.k_split = c.Cout; }                         // (value | gate rows)
-            g.b = dy.p; g.ldb = dy.sc; g.bseg = P; g.b_sn = dy.sb;                                      // dY[co][n] read in place
-            g.M = KT; g.N = (int)NT; g.K = c.cout_tot; g.nsplit = sp;
-            if (c_in_place) { g.c = dx.p; g.ldc = dx.sc; g.cseg = P; g.c_sn = dx.sb; g.accumulate = accumulate; }
-            else { g.c = ex.sg; g.ldc = NT; g.cseg = (int)NT; g.c_sn = 0; g.c_slab = ex.sg + KT * NT; g.c_split = KT * NT; }     // dXcol[k][n]
-            ex.fail(mcvc_sgemm_launch(g, ex.s));
-            if (!c_in_place) {
-                StageArgs sa{dx.p, dx.sb, dx.sc, dx.sh, NB, c.Cin, H, W, sk.OH, sk.OW, ex.sg, NT, 0};
-                ex.fail(mcvc_col2im_1d_launch(sa, c.KW, sp, KT * NT, accumulate, ex.s));
-            }
-            if (nsplit) *nsplit = 1;
-            return;
+        int sp = (allow_split && nsplit) ? igemm_split((long long)(c.Cin / 64) * ((NT + 63) / 64), sk.taps * c.cout_tot) : 1;
+        while (sp > 1 && ((long long)sk.taps * c.cout_tot) % (32LL * sp) != 0) sp /= 2;
+        const bool slab_all = accumulate && sp > 1;
+        const long long slab_need = (long long)(slab_all ? sp : sp - 1) * dx_total;
+        if (slab_need > ex.slab_need) ex.slab_need = slab_need;
+        if (nsplit) *nsplit = slab_all ? sp + 1 : sp;
+        if (ex.dry) return;
+        if ((ex.pack_skips & 1) && c.off_tk >= 0) { ex.fail(MCVC_ERR_INVALID); return; }     // stale K-major copy
+        if (slab_need > ex.slab_cap) { ex.fail(MCVC_ERR_WORKSPACE); return; }
+        IGemmArgs g{};
+        g.ncls = 1;
+        IGemmClass& q = g.cls[0];
+        q.a = packed + c.off_fwd; q.ntaps = c.KW; q.coff = 0;
+        for (int kw = 0; kw < c.KW; ++kw) {
+            const int sh = c.pw - kw;                 // dX[n] += W[:, :, kw]^T dY[n + pw - kw]
+            q.boff[kw] = sh; q.aoff[kw] = (long long)kw * c.cout_pk; q.zs[kw] = sh < 0 ? 1 : (sh > 0 ? 2 : 0);
         }
+        g.a_ks = (long long)c.KW * c.cout_pk; g.arow = 1; g.zw = W;
+        g.b = dy.p; g.b_cs = dy.sc; g.b_sn = dy.sb; g.b_pitch = dy.sh; g.Cb = c.cout_tot; g.OW = W; g.P = P;
+        g.ldc = dx.sc; g.c_sn = dx.sb; g.c_sh = dx.sh; g.c_sw = 1;
+        g.M = c.Cin; g.N = (int)NT; g.nsplit = sp; g.c_split = dx_total;
+        if (slab_all) { g.c = ex.slabs; g.c_slab = ex.slabs + dx_total; }
+        else { g.c = dx.p; g.c_slab = ex.slabs; g.accumulate = accumulate; }
+        ex.fail(mcvc_igemm_launch(g, ex.s));
+        return;
     }
     if (c.wino3 && wino_enabled() && ex.wv && wino43_applies(ex, c, NB, OH, OW) && 2 * OH == H && 2 * OW == W) {
         // ... as F(4x4,3x3)
@@ -824,26 +846,19 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
     const int OH = conv_out(H, c.KH, c.stride, c.ph), OW = conv_out(W, c.KW, c.stride, c.pw);
     ConvProblem p{c.Cin, H, W, c.Cout, OH, OW, c.KH, c.KW, c.stride, c.ph, c.pw};
     // GEMM form (sgemm.h): pixel-major operands in the weight gradients' own staging region, K-split slabs, then dw += slabs
-    const SgKind sk = sgemm_kind(c, NB, H, W);
+    const SgKind sk = sgemm_kind(c, NB, H, W);                            // (the 1 x KW layers of the wide trunk)
     const bool ig3 = ex.wgrad_x_xs && igemm_applies(c, H, W);             // a 3 x 3 stride-2 layer whose input arrives phase-split
-    const int KT = (ig3 ? 9 : sk.taps) * c.Cin;
-    int sg_split = 1; long long sg_rows = 0;
-    if (sk.kind) {
-        const int tiles = (c.cout_tot / 64) * (KT / 64);
-        while (sg_split < 8 && tiles * sg_split < 512) sg_split *= 2;
-        const long long unit = 32LL * sg_split, NT = (long long)NB * sk.OH * sk.OW;
-        sg_rows = (NT + unit - 1) / unit * unit;
-        while (sg_split > 1 && sg_rows / sg_split < 64) { sg_split /= 2; sg_rows = (NT + 32LL * sg_split - 1) / (32LL * sg_split) * (32LL * sg_split); }
-    }
-    long long sg_floats = sk.kind ? sg_rows * ((long long)KT + c.cout_tot) + (long long)sg_split * c.cout_tot * KT : 0;
+    const int wtaps = ig3 ? 9 : sk.taps;
+    const int KT = wtaps * c.Cin;
+    long long sg_floats = 0;
     // implicit form (r5, wgemm_kernels.hip): x arrives phase-split (the layer's forward ran as an implicit GEMM) -- both operands are read where
     // they lie; K split over the pixels when 128 x 32-filter tiles alone cannot fill the chip (slabs in the same staging region, dw_accum sums)
     static const int wgemm_on = mcvc_knob("MCVC_WGEMM", 1);
-    const bool implicit = wgemm_on && ig3 && (c.cout_tot % 128) == 0 && (c.Cin % mcvc_wgemm_cib(9)) == 0 &&
+    const bool implicit = wgemm_on && (ig3 || sk.kind == 2) && (c.cout_tot % 128) == 0 && (c.Cin % mcvc_wgemm_cib(wtaps)) == 0 &&
                           (c.nbr == 1 || (c.Cout % 32) == 0);
     int wg_split = 1;
     if (implicit) {
-        const int tiles = (c.cout_tot / 128) * (c.Cin / mcvc_wgemm_cib(9));
+        const int tiles = (c.cout_tot / 128) * (c.Cin / mcvc_wgemm_cib(wtaps));
         const long long nst = ((long long)NB * OH * OW + 31) / 32;
         static const int wg_target = mcvc_knob("MCVC_WGEMM_WGS", 256), wg_max = mcvc_knob("MCVC_WGEMM_MAXSPLIT", 64);
         // (a workgroup per compute unit -- a tile holds 156 KB of LDS -- and at least two pixel stages per split)
@@ -851,7 +866,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         sg_floats = wg_split > 1 ? (long long)wg_split * c.cout_tot * KT : 0;
     }
     if (ex.dry) {          // K-split slabs: their own region, so they never alias the data-gradient slabs of the main stream
-        if (sk.kind && sg_floats > ex.sgw_need) ex.sgw_need = sg_floats;          // (the direct kernel's slabs stay reserved as the fallback)
+        if (implicit && sg_floats > ex.sgw_need) ex.sgw_need = sg_floats;          // (the direct kernel's slabs stay reserved as the fallback)
         const long long need = mcvc_wgrad_plan_slab_floats(p, NB);
         if (need > ex.wslab_need) ex.wslab_need = need;
         return;
@@ -866,17 +881,22 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
     }
     bool done = false;
     if (implicit && (wg_split == 1 || (ex.sgw && sg_floats <= ex.sgw_cap)) && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]])) {
-        const int pw = mcvc_xs_pw(W);
-        const long long plane = mcvc_xs_plane(H, W);
         WGemmArgs g{};
         g.a = dy.p; g.a_cs = dy.sc; g.a_sn = dy.sb; g.a_pitch = dy.sh;
-        g.b = x.p; g.b_cs = x.sc; g.b_sn = x.sb; g.b_pitch = pw; g.ntaps = 9;
-        for (int kh = 0; kh < 3; ++kh)
-            for (int kw = 0; kw < 3; ++kw) {          // tap (kh, kw) of output (oh, ow) multiplies x[2 oh + kh - 1][2 ow + kw - 1]  (conv_fwd_igemm)
-                const int ph = (kh == 1) ? 0 : 1, di = (kh == 0) ? -1 : 0, pq = (kw == 1) ? 0 : 1, dj = (kw == 0) ? -1 : 0;
-                g.boff[3 * kh + kw] = (long long)(2 * ph + pq) * plane + (long long)(1 + di) * pw + 4 + dj;
-            }
-        g.zero = x.p;                                 // (row 0 of the first phase plane: zeros by construction of the layout)
+        g.b = x.p; g.b_cs = x.sc; g.b_sn = x.sb; g.ntaps = wtaps;
+        if (ig3) {
+            const int pw = mcvc_xs_pw(W);
+            const long long plane = mcvc_xs_plane(H, W);
+            g.b_pitch = pw;
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw) {          // tap (kh, kw) of output (oh, ow) multiplies x[2 oh + kh - 1][2 ow + kw - 1]  (conv_fwd_igemm)
+                    const int ph = (kh == 1) ? 0 : 1, di = (kh == 0) ? -1 : 0, pq = (kw == 1) ? 0 : 1, dj = (kw == 0) ? -1 : 0;
+                    g.boff[3 * kh + kw] = (long long)(2 * ph + pq) * plane + (long long)(1 + di) * pw + 4 + dj;
+                }
+        } else {                                          // 1 x KW over dense rows: tap kw multiplies x[w + kw - pw]; the rows' ends count as padding
+            g.b_pitch = x.sh; g.zw = (c.KW == 3) ? W : 0;
+            for (int kw = 0; kw < c.KW; ++kw) g.boff[kw] = kw - c.pw;
+        }
         g.OW = OW; g.P = OH * OW; g.NPIX = NB * g.P;
         g.M = c.cout_tot; g.Cin = c.Cin; g.nsplit = wg_split;
         if (wg_split == 1) {
@@ -890,30 +910,7 @@ static void conv_wgrad(Exec& ex, const ConvSpec& c, float* const* grads, int NB,
         }
         done = true;
     }
-    if (!done && sk.kind && ex.sgw && sg_floats <= ex.sgw_cap && grads[c.wi[0]] && (c.nbr == 1 || grads[c.wi[1]])) {
-        float* xt = ex.sgw; float* dyt = xt + sg_rows * KT; float* slabs = dyt + sg_rows * c.cout_tot;
-        StageArgs sx{x.p, x.sb, x.sc, x.sh, NB, c.Cin, H, W, sk.OH, sk.OW, xt, KT, (int)sg_rows, 0};
-        ex.fail(mcvc_im2col_1d_t_launch(sx, c.KW, ws));
-        StageArgs sy{dy.p, dy.sb, dy.sc, dy.sh, NB, c.cout_tot, sk.OH, sk.OW, sk.OH, sk.OW, dyt, c.cout_tot, (int)sg_rows};
-        ex.fail(mcvc_planes_t_launch(sy, ws));
-        SGemmArgs g{};
-        g.a = dyt; g.lda = c.cout_tot;                                        // dYt[n][co]
-        g.b = xt; g.ldb = KT; g.bseg = KT; g.b_sn = 0;                        // XcolT[n][k]
-        g.M = c.cout_tot; g.N = KT; g.K = (int)sg_rows; g.nsplit = sg_split;
-        static const int direct = mcvc_knob("MCVC_SGEMM_WGRAD_DIRECT", 1);
-        if (sg_split == 1 && direct && (c.Cout & 31) == 0) {
-            // no K split: the product is added straight into the OIHW gradients (rows [0, Cout) -> the value tensor, the rest -> the gate
-            // tensor) instead of a slab + dw_accum: a quarter of the dW-sized traffic of the deep layers and one launch less
-            g.c = grads[c.wi[0]]; g.ldc = KT; g.cseg = KT; g.c_sn = 0; g.accumulate = 1;
-            if (c.nbr == 2) { g.c2 = grads[c.wi[1]]; g.m_split = c.Cout; }
-            ex.fail(mcvc_sgemm_launch(g, ws));
-        } else {
-            g.c = slabs; g.ldc = KT; g.cseg = KT; g.c_sn = 0; g.c_split = (long long)c.cout_tot * KT; g.c_slab = slabs + g.c_split;
-            ex.fail(mcvc_sgemm_launch(g, ws));
-            ex.fail(mcvc_dw_accum_launch(slabs, sg_split, g.c_split, grads[c.wi[0]], c.nbr == 2 ? grads[c.wi[1]] : nullptr, c.Cout, c.cout_tot, KT, ws));
-        }
-        done = true;
-    }
+    if (!done && ex.wgrad_x_xs) { ex.fail(MCVC_ERR_WORKSPACE); return; }     // (nothing else reads a phase-split input: never fall through to a dense reader)
     if (!done && wino_enabled() && ex.wu && c.nbr == 1 && grads[c.wi[0]] && wino4_applies(ex, c, NB, H, W) && (c.Cout % 128) == 0 && (c.Cin % 64) == 0 &&
         64LL * c.Cout * c.Cin <= ex.wu_cap) {
         // F(4x4,5x5) weight gradient: the same three steps on 8x8 tiles and 64 points
@@ -1911,7 +1908,7 @@ static void gen_backward_impl(Exec& ex, const float* const* P, const float* pack
             conv_wgrad(ex, g.res_vg[i], G, 1, B, W4, CView{hin, 0, SBT4, W4}, dyv);
             ns = 1;          // (deterministic mode: DH is left alone and its K-split partials go to slabs the next norm_bwd sums)
             if (!trunk_dgrad(ex, g.res_vg[i], packed, DT1, DH, 1 /*accumulate: skip path*/, B, W4, &ns))
-                conv_dgrad(ex, g.res_vg[i], packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 1, 1, nullptr);
+                conv_dgrad(ex, g.res_vg[i], packed, 1, B, W4, dyv, View{DH, 0, BT4, W4}, 256 * BT4, 1, 1, &ns);      // (a K split leaves its partials in slabs the next norm_bwd sums)
         }
     }
     if (nwjobs > 0) {              // ONE launch for the residual layers' weight gradients, beside the rest of the backward chain
@@ -2800,9 +2797,9 @@ static Needs layer_needs(const ConvSpec& c, int N, int H, int W, int scheme)
     return Needs{(ex.slab_need + 3) & ~3LL, (ex.wslab_need + 3) & ~3LL, (ex.sg_need + 3) & ~3LL, (ex.sgw_need + 3) & ~3LL};
 }
 struct SchemeGuard {            // scheme 3: no Winograd; 4: neither Winograd nor staged GEMM (thread-local planner switches)
-    int w, g;
-    explicit SchemeGuard(int scheme) : w(t_no_wino), g(t_no_sgemm) { if (scheme >= 3) t_no_wino = 1; if (scheme == 4) t_no_sgemm = 1; }
-    ~SchemeGuard() { t_no_wino = w; t_no_sgemm = g; }
+    int w, g, u;
+    explicit SchemeGuard(int scheme) : w(t_no_wino), g(t_no_sgemm), u(t_user_operands) { if (scheme >= 3) t_no_wino = 1; if (scheme == 4) t_no_sgemm = 1; t_user_operands = 1; }
+    ~SchemeGuard() { t_no_wino = w; t_no_sgemm = g; t_user_operands = u; }
 };
 static Exec layer_exec(const ConvSpec& c, int N, int H, int W, int scheme, float* scratch, long long scratch_floats, void* stream, int* err)
 {

@@ -1,13 +1,14 @@
-// GEMM forms of the convolutions that are plain matrix products, on the 64x64 / k32 LDS-DMA GEMM pipeline (wino_kernels.hip):
+// GEMM forms of the convolutions that are plain matrix products, on the 64x64 / k32 LDS-DMA GEMM pipeline (wino_kernels.hip) -- all of them
+// IMPLICIT since r5: every operand is read where its producer left it, no tap planes, no transposed copies, no gather kernels (the staged
+// forms of r2-r4 -- im2col_s2 / im2col_s2_t / col2im_s2 / im2col_1d / im2col_1d_t / col2im_1d / planes_t -- are gone):
 //
-//   * the discriminators' 3 x 3 stride-2 layers (downSample1-3, model.py:298-314) as IMPLICIT GEMMs -- forward and data gradient gather
-//     their B operand from the activation where it lies (igemm_kernel: phase-split padded input / padded dY), the data gradient reads the
-//     forward weight copy row-major, the weight gradient reads both operands in place (wgemm_kernels.hip): no tap planes, no transposed
-//     copies, no gather kernel (the staged forms of r2-r4 -- im2col_s2 / im2col_s2_t / col2im_s2 -- are gone);
-//   * the 1 x KW convolutions of the 1-D trunk beyond the fused small-batch kernels (more than 64 columns) as STAGED GEMMs (sgemm_kernel):
-//       forward        Y[co][n]     = sum_k  Wt[k][co]  * Xcol[k][n]        k = KW*ci + kw, n = (b, w); + bias
-//       data gradient  dXcol[k][n]  = sum_co W[co][k]   * dY[co][n]         W = the OIHW parameter tensors themselves (value | gate rows), then a gather
-//       weight grad.   dW[co][k]    = sum_n  dYt[n][co] * XcolT[n][k]       both operands pixel-major; K-split slabs, then dw += sum of slabs
+//   * the discriminators' 3 x 3 stride-2 layers (downSample1-3, model.py:298-314): forward and data gradient gather their B operand from
+//     the phase-split padded input / the padded dY (igemm_kernel), the data gradient reads the forward weight copy row-major (arow), the
+//     weight gradient reads both operands in place (wgemm_kernels.hip);
+//   * the 1 x KW convolutions of the 1-D trunk beyond the fused small-batch kernels (more than 64 columns, model.py:47-76, 142-189): the
+//     same two kernels over DENSE rows -- a tap's window is the row shifted by -1 / 0 / +1 column, and the value a shifted window picks up
+//     from the neighbouring row at a row's end is dropped at the operand read (zw / zs below); a 1 x 1 convolution multiplies the activation
+//     itself (sgemm_kernel).
 //
 #pragma once
 #include <hip/hip_runtime.h>
@@ -39,12 +40,14 @@ int mcvc_sgemm_launch(const SGemmArgs& a, hipStream_t s);
 //   forward of a 3x3 stride-2 convolution: one class, 9 taps over the PHASE-SPLIT padded input (xs layout below), C = y in place;
 //   data gradient: the four output-parity classes (1 + 2 + 2 + 4 taps) over dY with one zero column / row of padding, C scattered to
 //   dx[2a + qh][2b + qw] -- every input pixel is written by exactly one class: no tap planes, no gather kernel, no atomics.
-struct IGemmClass { const float* a; int ntaps; long long coff; long long boff[9]; int atap[9]; };
-// arow = 1: A is read from a row-major source shared by all classes -- element (k = (t, c), m) at a[(atap[t] * M + m) * lda + c] -- the
-// tap-major forward copy of a convolution's weights serving its data gradient (m = input channel, c = output channel)
+// A of tap t: element (c, m) at a[aoff[t] + c*a_ks + m]  (K-major rows, m contiguous; a_ks = floats between consecutive k rows), or with
+// arow = 1 at a[aoff[t] + m*a_ks + c] -- a ROW-major source, the 32 k of a stage contiguous: the forward weight copy of a convolution serving
+// its data gradient (m = input channel, c = output channel).  zs[t] (with IGemmArgs.zw): 1 / 2 = tap t's window is shifted by -1 / +1 column
+// over dense rows of zw columns -- B values at a row's first / last column are taken as the zero the padding holds.
+struct IGemmClass { const float* a; int ntaps; long long coff; long long boff[9]; long long aoff[9]; int zs[9]; };
 struct IGemmArgs {
     IGemmClass cls[4]; int ncls;
-    long long lda;
+    long long a_ks; int zw;
     const float* b; long long b_cs, b_sn; int b_pitch;
     int Cb;                             // channels per tap; K of class c = cls[c].ntaps * Cb
     int OW, P;                          // n -> (bb = n / P, i = (n % P) / OW, j = n % OW);  OW % 4 == 0
@@ -66,7 +69,8 @@ int mcvc_igemm_launch(const IGemmArgs& a, hipStream_t s);
 struct WGemmArgs {
     const float* a; long long a_cs, a_sn; int a_pitch;
     const float* b; long long b_cs, b_sn; int b_pitch; long long boff[9]; int ntaps;      // ntaps = 9 (3 x 3), 3 or 1 (1-D)
-    const float* zero;                   // 16 bytes of zeros, 16-byte aligned (the pieces beyond the last pixel)
+    int zw;                              // ntaps = 3 over DENSE rows of zw columns (the 1-D trunk): taps 0 / 2 are shifted by -1 / +1 column
+                                         // (boff = -1 / +1) and their x values at a row's first / last column count as the padding's zero
     int OW, P, NPIX;                     // n -> (bb = n / P, i = (n % P) / OW, j = n % OW); OW % 4 == 0; NPIX = samples * P
     int M, Cin;                          // M % 128 == 0; Cin % 32 == 0 (ntaps = 9) / % 64 == 0
     float* c; float* c2; int m_split; int accumulate;
@@ -92,19 +96,5 @@ static inline long long mcvc_dyp_plane(int OH, int OW) { return (long long)(OH +
 int mcvc_xs_from_dense_launch(const float* x, float* xs, int NB, int C, int H, int W, hipStream_t s);
 int mcvc_dyp_from_dense_launch(const float* dy, float* dyp, int NB, int C, int OH, int OW, hipStream_t s);
 
-struct StageArgs {
-    const float* x; long long x_sb, x_sc; int x_sh;      // image view [NB][C][H][W] (W contiguous)
-    int NB, C, H, W, OH, OW;                               // 3x3, stride 2, padding 1: OH = (H + 1) / 2 ...
-    float* out; long long ld;                              // see the launchers
-    int rows_pad;                                          // transposed forms: rows [NB*OH*OW, rows_pad) are written as zeros
-    int xs;                                                // (unused since r5)
-};
-// Yt[n][c] from y[b][c][p] (H x W = the plane of y; OH/OW unused), ld = C
-int mcvc_planes_t_launch(const StageArgs& a, hipStream_t s);
-// Staged forms of the 1 x KW convolutions along w (KW = 1, 3; stride 1, padding (KW-1)/2) over an image of NB*H rows -- the 1-D trunk at more
-// than 32 columns (model.py:47-76, 142-189): k = KW*ci + tap, n = (b*H + h)*W + w
-int mcvc_im2col_1d_launch(const StageArgs& a, int KW, hipStream_t s);
-int mcvc_im2col_1d_t_launch(const StageArgs& a, int KW, hipStream_t s);
-int mcvc_col2im_1d_launch(const StageArgs& a, int KW, int nslab, long long slab_stride, int accumulate, hipStream_t s);
 // g0[co][k] += sum_s slabs[s][co][k] (co < Cout), g1[co - Cout][k] += ... (co >= Cout; g1 may be null when rows == Cout)
 int mcvc_dw_accum_launch(const float* slabs, int nslab, long long slab_stride, float* g0, float* g1, int Cout, int rows, int K9, hipStream_t s);

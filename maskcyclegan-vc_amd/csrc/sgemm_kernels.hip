@@ -13,6 +13,11 @@ __device__ __forceinline__ void glds16(const float* g, float* l)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
+// A 16-byte LDS read the compiler does not see as a memory access: hipcc puts `s_waitcnt vmcnt(0)` in front of a ds_read_b128 that follows
+// global_load_lds instructions (it cannot tell the ring's stages apart) -- which would drain the whole LDS-DMA pipeline every stage; the
+// stage's data IS complete here (explicit vmcnt wait + barrier above).  Such reads are issued as inline assembly on this LDS byte address.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p; }
 
 // C = A^T B on 64 x 64 tiles, 32-deep stages, 4-stage LDS-DMA pipeline (global_load_lds, explicit vmcnt), v_mfma_f32_32x32x2_f32:
 // the pipeline of gemm2_kernel<64,64,32,4> (wino_kernels.hip) with generalised operand addressing -- two A sources along K (the value
@@ -134,7 +139,8 @@ __global__ void __launch_bounds__(256) sgemm_kernel(const Twin<SGemmArgs> tw)
 // that belongs there) and the transposition happens in the operand read: the k slots of the 16 MFMAs of a stage are pixel... channel
 // 16 * half + j (an MFMA's k index is only a label -- B is read at the same rows), so a lane needs 16 consecutive floats of its row = four
 // conflict-free ds_read_b128 (wgemm_kernels.hip has the bank argument).  The per-class data-gradient copies of r4 are gone.
-template <bool AROW>
+// ZFIX: the 1-D trunk's shifted windows over dense rows (see zpos below) -- its own instantiation, so that the discriminators' loops carry no select.
+template <bool AROW, bool ZFIX>
 __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
 {
     const IGemmArgs& a = tw.v[blockIdx.z];
@@ -151,7 +157,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
     const int nt = a.nt, mt = a.mt, nsplit = a.nsplit, Cb = a.Cb, OW = a.OW, P = a.P, N = a.N;
-    const long long lda = a.lda, b_cs = a.b_cs, b_sn = a.b_sn;
+    const long long a_ks = a.a_ks, b_cs = a.b_cs, b_sn = a.b_sn;
     const int b_pitch = a.b_pitch;
     const int n0 = (lid % nt) * BN; lid /= nt;
     const int m0 = (lid % mt) * BM;
@@ -166,9 +172,9 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
         const int f = tid + i * 256;
         if (AROW) {                                                // slot f of the [64 rows][8 pieces] tile: row f / 8, swizzled piece
             const int row = f >> 3, pc = (f & 7) ^ ((row >> 1) & 7);
-            aoff[i] = (long long)(m0 + row) * lda + 4 * pc;
+            aoff[i] = (long long)(m0 + row) * a_ks + 4 * pc;
         } else
-        aoff[i] = (long long)(f / (BM / 4)) * lda + m0 + 4 * (f % (BM / 4));
+        aoff[i] = (long long)(f / (BM / 4)) * a_ks + m0 + 4 * (f % (BM / 4));
         adst[i] = (wave * 64 + i * 256) * 4;
     }
 #pragma unroll
@@ -185,7 +191,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
         float* base = smem + buf * STAGE;
         const int k0 = kbase + stage_k * GK;
         const int t = k0 / Cb, c0 = k0 - t * Cb;                  // (a stage lies inside one tap: Cb % 32 == 0)
-        const float* ab = AROW ? A + (long long)cl.atap[t] * a.M * lda + c0 : A + (long long)k0 * lda;
+        const float* ab = AROW ? A + cl.aoff[t] + c0 : A + cl.aoff[t] + (long long)c0 * a_ks;
         const float* bb = Bp + cl.boff[t] + (long long)c0 * b_cs;
 #pragma unroll
         for (int i = 0; i < NA; ++i) glds16(ab + aoff[i], base + adst[i]);
@@ -201,28 +207,48 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
         if (s < nst) issue(s, s);
     const int a_lane = half * BM + wm * 32 + l31;                  // A[k = 2p + half][m]
     const int b_lane = SA + half * BN + wn * 32 + l31;             // B[k = 2p + half][n]
+    // 1-D convolutions over DENSE rows of zw columns (the trunk, sgemm.h): a tap's window shifted by -1 / +1 column reads the neighbouring row's
+    // last / first element at a row's first / last column -- this lane's B values of such a tap are replaced by the zero the padding holds
+    int zpos = 0;                                                  // 1: first column of a row, 2: last, 0: neither (or no fix)
+    if (ZFIX) { const int w = (n0 + wn * 32 + l31) % a.zw; zpos = (w == 0) ? 1 : (w == a.zw - 1 ? 2 : 0); }
     for (int st = 0; st < nst; ++st) {
         const int newer = (nst - 1 - st) < (ST - 2) ? (nst - 1 - st) : (ST - 2);
         if (newer >= 2) wait_vm<2 * ND>(); else if (newer == 1) wait_vm<ND>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         if (st + ST - 1 < nst) issue(st + ST - 1, (st + ST - 1) % ST);
         const float* sb = smem + (st % ST) * STAGE;
+        // (ZFIX) this stage's tap: 1 = window shifted by -1 column, 2 = by +1; a lane at that end of a row multiplies by 0 instead of the
+        // neighbouring row's element -- a scale, not a branch: the loads stay unconditional
+        float zsc = 1.f;
+        if (ZFIX) { const int zt = cl.zs[(kbase + st * GK) / Cb]; zsc = (zpos != 0 && zt == zpos) ? 0.f : 1.f; }
         if (AROW) {
+            // operand reads one group of four MFMAs ahead (one ds_read_b128 of A + four ds_read_b32 of B per group), order pinned
             const float* ar = sb + (wm * 32 + l31) * GK;
             const int sw = (l31 >> 1) & 7;
-            float4 av[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const float4*>(ar + (((4 * half + q) ^ sw) << 2));
             const float* br = sb + SA + (16 * half) * BN + wn * 32 + l31;
-            float bv[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) bv[j] = br[j * BN];
+            // (all operand reads of this branch are inline assembly -- see lds_read16 -- with their own waits: a group's reads are requested
+            //  in front of the previous group's four MFMAs and awaited behind them)
+            const unsigned a_addr = lds_addr(ar), b_addr = lds_addr(br);
+            f32x4 av, an; float b0, b1, b2, b3, n0_, n1_, n2_, n3_;
+            asm volatile("ds_read_b128 %0, %1" : "=&v"(av) : "v"(a_addr + ((((4 * half) ^ sw)) << 4)));
+            asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:256\n\tds_read_b32 %2, %4 offset:512\n\tds_read_b32 %3, %4 offset:768"
+                         : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(b_addr));
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[4 * q + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bv[4 * q + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bv[4 * q + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[4 * q + 3], acc, 0, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+                if (q < 3) {
+                    asm volatile("ds_read_b128 %0, %1" : "=&v"(an) : "v"(a_addr + ((((4 * half + q + 1) ^ sw)) << 4)));
+                    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:256\n\tds_read_b32 %2, %4 offset:512\n\tds_read_b32 %3, %4 offset:768"
+                                 : "=&v"(n0_), "=&v"(n1_), "=&v"(n2_), "=&v"(n3_) : "v"(b_addr + (q + 1) * 1024));
+                }
+                __builtin_amdgcn_sched_barrier(0);        // (the four MFMAs below stay BEHIND the next group's requests)
+                if (ZFIX) { b0 *= zsc; b1 *= zsc; b2 *= zsc; b3 *= zsc; }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);        // (... and the next group's wait stays behind them)
+                if (q < 3) { av = an; b0 = n0_; b1 = n1_; b2 = n2_; b3 = n3_; }
             }
             continue;
         }
@@ -231,6 +257,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
         for (int p = 0; p < GK / 2; ++p) {
             const int q = (p + 1 < GK / 2) ? p + 1 : p;
             const float na0 = sb[a_lane + q * 2 * BM], nb0 = sb[b_lane + q * 2 * BN];
+            if (ZFIX) b0 *= zsc;
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -269,115 +296,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
     }
 }
 
-// ---- staging of the 1-D trunk's GEMM forms ----------------------------------------------------------------------------------------
-// Yt[n][c] from y[b][c][p]
-__global__ void __launch_bounds__(256) planes_t_kernel(const Twin<StageArgs> tw)
-{
-    const StageArgs a = tw.v[blockIdx.z];
-    __shared__ float tile[32][33];
-    const int P = a.H * a.W;
-    const long long NT = (long long)a.NB * P;
-    const long long n0 = (long long)blockIdx.x * 32;
-    const int c0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const long long n = n0 + tx;
-    int b = 0, p = 0;
-    if (n < NT) { b = (int)(n / P); p = (int)(n - (long long)b * P); }
-    const int h = p / a.W, w = p - h * a.W;
-    for (int cl = ty; cl < 32; cl += 8) {
-        const int c = c0 + cl;
-        tile[cl][tx] = (n < NT && c < a.C) ? a.x[(long long)b * a.x_sb + (long long)c * a.x_sc + (long long)h * a.x_sh + w] : 0.f;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8)
-        if (n0 + r < a.rows_pad && c0 + tx < a.C) a.out[(n0 + r) * a.ld + c0 + tx] = tile[tx][r];
-}
-
-// ---- 1 x KW convolutions along w (stride 1, padding (KW-1)/2) over rows (b, h): the 1-D trunk run as an image of B rows -------------
-// Xcol[KW*ci + tap][n] = x[b][ci][h][w + tap - pw],  n = (b*H + h)*W + w
-template <int KW>
-__global__ void __launch_bounds__(256) im2col_1d_kernel(const Twin<StageArgs> tw)
-{
-    const StageArgs a = tw.v[blockIdx.z];
-    constexpr int PW = (KW - 1) / 2;
-    const int P = a.H * a.W;
-    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int ci = blockIdx.y;
-    if (n >= (long long)a.NB * P) return;
-    const int b = (int)(n / P), p = (int)(n - (long long)b * P);
-    const int h = p / a.W, w = p - h * a.W;
-    const float* xp = a.x + (long long)b * a.x_sb + (long long)ci * a.x_sc + (long long)h * a.x_sh;
-    float* o = a.out + (long long)ci * KW * a.ld + n;
-#pragma unroll
-    for (int t = 0; t < KW; ++t) {
-        const int iw = w + t - PW;
-        o[(long long)t * a.ld] = (iw >= 0 && iw < a.W) ? xp[iw] : 0.f;
-    }
-}
-
-// XcolT[n][KW*ci + tap]
-template <int KW>
-__global__ void __launch_bounds__(256) im2col_1d_t_kernel(const Twin<StageArgs> tw)
-{
-    const StageArgs a = tw.v[blockIdx.z];
-    constexpr int PW = (KW - 1) / 2;
-    __shared__ float tile[32][32 * KW + 1];
-    const int P = a.H * a.W;
-    const long long NT = (long long)a.NB * P;
-    const long long n0 = (long long)blockIdx.x * 32;
-    const int c0 = blockIdx.y * 32;
-    const int nl = threadIdx.x & 31, cw = threadIdx.x >> 5;
-    const long long n = n0 + nl;
-    const bool live = n < NT;
-    int b = 0, h = 0, w = 0;
-    if (live) { b = (int)(n / P); const int p = (int)(n - (long long)b * P); h = p / a.W; w = p - h * a.W; }
-    for (int cl = cw; cl < 32; cl += 8) {
-        const int ci = c0 + cl;
-        const float* xp = a.x + (long long)b * a.x_sb + (long long)ci * a.x_sc + (long long)h * a.x_sh;
-#pragma unroll
-        for (int t = 0; t < KW; ++t) {
-            const int iw = w + t - PW;
-            tile[nl][cl * KW + t] = (live && ci < a.C && iw >= 0 && iw < a.W) ? xp[iw] : 0.f;
-        }
-    }
-    __syncthreads();
-    const int kmax = (a.C - c0 < 32 ? a.C - c0 : 32) * KW;
-    for (int e = threadIdx.x; e < 32 * 32 * KW; e += 256) {
-        const int r = e / (32 * KW), k = e - r * (32 * KW);
-        if (n0 + r < a.rows_pad && k < kmax) a.out[(n0 + r) * a.ld + (long long)c0 * KW + k] = tile[r][k];
-    }
-}
-
-// dx[b][ci][h][w] (=|+=) sum_tap dXcol[KW*ci + tap][(b, h, w - tap + pw)], summed over the K-split slabs
-struct Col2im1dKArgs { StageArgs a; int nslab; long long slab_stride; int accumulate; };
-template <int KW>
-__global__ void __launch_bounds__(256) col2im_1d_kernel(const Twin<Col2im1dKArgs> tw)
-{
-    const Col2im1dKArgs ka_ = tw.v[blockIdx.z];
-    const StageArgs& a = ka_.a;
-    int nslab = ka_.nslab;
-    long long slab_stride = ka_.slab_stride;
-    int accumulate = ka_.accumulate;
-    constexpr int PW = (KW - 1) / 2;
-    const int P = a.H * a.W;
-    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int ci = blockIdx.y;
-    if (n >= (long long)a.NB * P) return;
-    const int b = (int)(n / P), p = (int)(n - (long long)b * P);
-    const int h = p / a.W, w = p - h * a.W;
-    const float* col = a.out + (long long)ci * KW * a.ld + n;
-    float s = 0.f;
-#pragma unroll
-    for (int t = 0; t < KW; ++t) {
-        const int ow = w - t + PW;
-        if (ow < 0 || ow >= a.W) continue;
-        const float* cp = col + (long long)t * a.ld + (ow - w);
-        for (int k = 0; k < nslab; ++k) s += cp[(long long)k * slab_stride];
-    }
-    float* d = const_cast<float*>(a.x) + (long long)b * a.x_sb + (long long)ci * a.x_sc + (long long)h * a.x_sh + w;
-    *d = accumulate ? *d + s : s;
-}
-
+// ---- the weight gradients' K-split slabs ----------------------------------------------------------------------------------------------
 struct DwAccumKArgs { const float* slabs; int nslab; long long slab_stride; float* g0; float* g1; int Cout; int rows; int K9; };
 __global__ void __launch_bounds__(256) dw_accum_kernel(const Twin<DwAccumKArgs> tw)
 {
@@ -479,7 +398,7 @@ int mcvc_igemm_launch(const IGemmArgs& a0, hipStream_t s)
 {
     IGemmArgs a = a0;
     if (a.nsplit < 1) a.nsplit = 1;
-    if (a.ncls < 1 || a.ncls > 4 || (a.M % BM) != 0 || (a.N & 3) || a.N < 4 || (a.lda & 3) || (a.Cb % GK) != 0 || (a.OW & 3) || a.P < a.OW || (a.P % a.OW) != 0 ||
+    if (a.ncls < 1 || a.ncls > 4 || (a.M % BM) != 0 || (a.N & 3) || a.N < 4 || (a.a_ks & 3) || (a.Cb % GK) != 0 || (a.OW & 3) || a.P < a.OW || (a.P % a.OW) != 0 ||
         (a.nsplit > 1 && !a.c_slab))
         return MCVC_ERR_INVALID;
     double flops = 0.0, bytes = 0.0;
@@ -495,53 +414,22 @@ int mcvc_igemm_launch(const IGemmArgs& a0, hipStream_t s)
     constexpr size_t lds = (size_t)ST * STAGE * sizeof(float);
     static bool done = false;
     if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         done = true;
     }
     TraceScope ts(K_SGEMM, s, flops, bytes);
-    if (a.arow) mcvc_launch(igemm_kernel<true>, dim3((unsigned)(a.nt * a.mt * a.nsplit), (unsigned)a.ncls), dim3(256), lds, s, a);
-    else mcvc_launch(igemm_kernel<false>, dim3((unsigned)(a.nt * a.mt * a.nsplit), (unsigned)a.ncls), dim3(256), lds, s, a);
-    return (int)hipGetLastError();
-}
-
-int mcvc_planes_t_launch(const StageArgs& a, hipStream_t s)
-{
-    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.NB * a.C * a.H * a.W + (double)a.C * a.rows_pad));
-    mcvc_launch(planes_t_kernel, dim3((unsigned)((a.rows_pad + 31) / 32), (unsigned)cdiv_i(a.C, 32)), dim3(256), 0, s, a);
-    return (int)hipGetLastError();
-}
-
-int mcvc_im2col_1d_launch(const StageArgs& a, int KW, hipStream_t s)
-{
-    const long long NT = (long long)a.NB * a.H * a.W;
-    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * (1.0 + KW) * a.C * NT);
-    const dim3 grid((unsigned)((NT + 255) / 256), (unsigned)a.C);
-    if (KW == 3) mcvc_launch(im2col_1d_kernel<3>, grid, dim3(256), 0, s, a);
-    else if (KW == 1) mcvc_launch(im2col_1d_kernel<1>, grid, dim3(256), 0, s, a);
-    else return MCVC_ERR_INVALID;
-    return (int)hipGetLastError();
-}
-
-int mcvc_im2col_1d_t_launch(const StageArgs& a, int KW, hipStream_t s)
-{
-    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((double)a.NB * a.C * a.H * a.W + (double)KW * a.C * a.rows_pad));
-    const dim3 grid((unsigned)((a.rows_pad + 31) / 32), (unsigned)cdiv_i(a.C, 32));
-    if (KW == 3) mcvc_launch(im2col_1d_t_kernel<3>, grid, dim3(256), 0, s, a);
-    else if (KW == 1) mcvc_launch(im2col_1d_t_kernel<1>, grid, dim3(256), 0, s, a);
-    else return MCVC_ERR_INVALID;
-    return (int)hipGetLastError();
-}
-
-int mcvc_col2im_1d_launch(const StageArgs& a, int KW, int nslab, long long slab_stride, int accumulate, hipStream_t s)
-{
-    const long long NT = (long long)a.NB * a.H * a.W;
-    TraceScope ts(K_ELEMENTWISE, s, 0.0, 4.0 * ((accumulate ? 2.0 : 1.0) + (double)KW * nslab) * a.C * NT);
-    const dim3 grid((unsigned)((NT + 255) / 256), (unsigned)a.C);
-    if (KW == 3) mcvc_launch(col2im_1d_kernel<3>, grid, dim3(256), 0, s, Col2im1dKArgs{a, nslab, slab_stride, accumulate});
-    else if (KW == 1) mcvc_launch(col2im_1d_kernel<1>, grid, dim3(256), 0, s, Col2im1dKArgs{a, nslab, slab_stride, accumulate});
-    else return MCVC_ERR_INVALID;
+    const dim3 grid((unsigned)(a.nt * a.mt * a.nsplit), (unsigned)a.ncls);
+    if (a.zw > 0) {
+        if (a.arow) mcvc_launch(igemm_kernel<true, true>, grid, dim3(256), lds, s, a);
+        else mcvc_launch(igemm_kernel<false, true>, grid, dim3(256), lds, s, a);
+    } else {
+        if (a.arow) mcvc_launch(igemm_kernel<true, false>, grid, dim3(256), lds, s, a);
+        else mcvc_launch(igemm_kernel<false, false>, grid, dim3(256), lds, s, a);
+    }
     return (int)hipGetLastError();
 }
 

@@ -62,19 +62,17 @@ __global__ void __launch_bounds__(256) wgemm_kernel(const Twin<WGemmArgs> tw)
     const long long a_cs = a.a_cs, b_cs = a.b_cs;
     const float* const Ap = a.a + (long long)(m0 + r8) * a_cs;
     const float* const Bp = a.b + (long long)(n0 + r8) * b_cs;
-    const float* const Zp = a.zero;
     auto issue = [&](int s, int buf) {
         float* base = smem + buf * STAGE;
         const int n = (st0 + s) * WGK + 4 * p;
-        const bool valid = n < NPIX;                   // (pixels beyond the last: a zero dY piece; x may be anything finite)
-        const int nn = valid ? n : 0;
+        const int nn = n < NPIX ? n : 0;               // (pixels beyond the last: any valid piece -- the dY operand is zeroed at the read)
         const int bb = nn / P, rem = nn - bb * P;
         const int ii = rem / OW, jj = rem - ii * OW;
         const long long offA = (long long)bb * a.a_sn + (long long)ii * a.a_pitch + jj;
         const long long offB = (long long)bb * a.b_sn + (long long)ii * a.b_pitch + jj;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            glds16(valid ? Ap + (long long)(32 * i) * a_cs + offA : Zp, base + (wave * 64 + i * 256) * 4);
+            glds16(Ap + (long long)(32 * i) * a_cs + offA, base + (wave * 64 + i * 256) * 4);
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -100,11 +98,35 @@ __global__ void __launch_bounds__(256) wgemm_kernel(const Twin<WGemmArgs> tw)
         float4 av[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const float4*>(sb + a_row + (((4 * half + q) ^ sw) << 2));
+        const int k_first = (st0 + st) * WGK + 16 * half;          // the first of this lane's 16 pixels
+        if (k_first + 16 > NPIX) {                                 // the last stage's tail: pixels that do not exist contribute nothing
+            float* af = reinterpret_cast<float*>(av);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (k_first + j >= NPIX) af[j] = 0.f;
+        }
+        // 1-D convolutions over DENSE rows of zw columns (the trunk): the window of tap 0 / tap 2 is shifted by -1 / +1 column and reads the
+        // neighbouring row's element at a row's first / last column, where the padding holds a zero -- those x values are dropped here
+        unsigned zfirst = 0, zlast = 0;                            // bit j: pixel j of this lane's 16 is a row's first / last column
+        if (TAPS == 3 && a.zw) {
+            int w = k_first % a.zw;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                zfirst |= (w == 0 ? 1u : 0u) << j;
+                zlast |= (w == a.zw - 1 ? 1u : 0u) << j;
+                w = (w + 1 == a.zw) ? 0 : w + 1;
+            }
+        }
 #pragma unroll
         for (int t = 0; t < NACC; ++t) {
             float4 bv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const float4*>(sb + b_row + t * SB1 + (((4 * half + q) ^ sw) << 2));
+            if (TAPS == 3 && a.zw && (t / NJ) != 1) {
+                const unsigned zm = (t / NJ) == 0 ? zfirst : zlast;
+                float* bf = reinterpret_cast<float*>(bv);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) if ((zm >> j) & 1u) bf[j] = 0.f;
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[q].x, acc[t], 0, 0, 0);
@@ -161,14 +183,14 @@ int wgemm_launch_t(const WGemmArgs& a, double flops, double bytes, hipStream_t s
 
 }  // namespace
 
-int mcvc_wgemm_cib(int taps) { return taps == 9 ? 32 : 64; }
+int mcvc_wgemm_cib(int taps) { return taps == 1 ? 64 : 32; }
 
 int mcvc_wgemm_launch(const WGemmArgs& a0, hipStream_t s)
 {
     WGemmArgs a = a0;
     if (a.nsplit < 1) a.nsplit = 1;
     const int cib = mcvc_wgemm_cib(a.ntaps);
-    if (!a.a || !a.b || !a.c || !a.zero || (a.M % WBM) != 0 || (a.Cin % cib) != 0 || (a.OW & 3) || a.P < a.OW || (a.P % a.OW) != 0 || a.NPIX < 4 || (a.NPIX & 3) ||
+    if (!a.a || !a.b || !a.c || (a.M % WBM) != 0 || (a.Cin % cib) != 0 || (a.OW & 3) || a.P < a.OW || (a.P % a.OW) != 0 || a.NPIX < 4 || (a.NPIX & 3) ||
         (a.a_cs & 3) || (a.a_sn & 3) || (a.a_pitch & 3) || (a.nsplit > 1 && !a.c_slab) || (a.ntaps != 9 && a.ntaps != 3 && a.ntaps != 1))
         return MCVC_ERR_INVALID;
     if (!a.c2) { a.c2 = a.c; a.m_split = a.M; }
@@ -182,6 +204,6 @@ int mcvc_wgemm_launch(const WGemmArgs& a0, hipStream_t s)
     // operands once from HBM (dY; x with the taps' overlap in L2) + the gradient (read-modify-write) / the slabs
     const double bytes = 4.0 * (K * a.M + 2.25 * K * a.Cin + (double)a.M * a.Cin * a.ntaps * (a.nsplit > 1 ? a.nsplit : 2));
     if (a.ntaps == 9) return wgemm_launch_t<9, 32>(a, flops, bytes, s);
-    if (a.ntaps == 3) return wgemm_launch_t<3, 64>(a, flops, bytes, s);
+    if (a.ntaps == 3) return wgemm_launch_t<3, 32>(a, flops, bytes, s);
     return wgemm_launch_t<1, 64>(a, flops, bytes, s);
 }
