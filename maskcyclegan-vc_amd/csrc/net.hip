@@ -398,6 +398,8 @@ static bool conv_wino(Exec& ex, const ConvSpec& c, const float* packed, int dgra
 {
     if (!c.wino || !wino_enabled() || !ex.wv) return false;
     if (wino4_applies(ex, c, NB, H, W) && conv_wino4(ex, c, packed, dgrad, NB, H, W, x, y, shuffle, accumulate)) return true;
+    // (bit 128: the 36-point sets of the layers whose EVERY pass takes the 4 x 4 scheme were not refreshed -- gen_pack_cfg)
+    if (!ex.dry && (ex.pack_skips & 128) && (long long)(H / 4) * (W / 4) >= wino4_min_tiles()) { ex.fail(MCVC_ERR_INVALID); return true; }
     const int K = dgrad ? c.cout_tot : c.Cin, M = dgrad ? c.Cin : c.cout_tot;
     const int TH = (H + 1) / 2, TW = (W + 1) / 2;
     const int nbc = wino_chunk(NB, (long long)TH * TW);
@@ -1097,7 +1099,7 @@ static void add_job(PackTable& t, PackJob j, int gx, int gy)
 // igemm_only: the layer runs on the implicit-GEMM kernels in every pass (the discriminators' stride-2 layers): only the bias, the tap-major
 // forward copy and the per-class data-gradient copies are refreshed
 static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = false, bool wino_only = false, int sets = 3, bool w4 = true, bool w43 = true,
-                          bool igemm_only = false)
+                          bool igemm_only = false, bool w2 = true)
 {
     const int K = c.Cin * c.KH * c.KW;
     const bool fw = (sets & 1) != 0, bw = (sets & 2) != 0;
@@ -1175,7 +1177,7 @@ static void add_spec_jobs(PackTable& t, const ConvSpec& c, bool trunk_only = fal
             if (bw) add_job(t, wd, cdiv_i(c.Cin, 256), c.Cout);
             t.bytes += 4.0 * (fw + bw) * (25.0 + 64.0) * c.Cout * c.Cin; t.wbytes += 4.0 * (fw + bw) * 64.0 * c.Cout * c.Cin;
         }
-        if (c.wino) {
+        if (c.wino && w2) {
             PackJob wf{}; wf.kind = PACK_WINO_F; wf.param = c.wi[br]; wf.dst = c.off_wf; wf.Cout = c.Cout; wf.Cin = c.Cin; wf.ld = c.cout_pk;
             wf.xi_stride = c.wf_xi; wf.co_off = br * c.Cout;
             if (fw) add_job(t, wf, cdiv_i(c.Cout, 256), c.Cin);
@@ -1277,7 +1279,7 @@ static const DevUpdTable* dev_upd_table(int kind, Build&& build, const long long
             else if (o.taps == 1) ib = 128;
             else if (o.taps > 25) ib = 16;
             o.CB = cb < o.Cout ? cb : o.Cout; o.IB = ib < o.Cin ? ib : o.Cin;
-            if ((size_t)o.CB * (((o.IB * o.taps + 3) & ~3) + kUpdPitchPad) * sizeof(float) > kUpdLds) { *err = MCVC_ERR_INVALID; return nullptr; }
+            if ((size_t)o.CB * mcvc_upd_pitch(o.IB, o.taps) * sizeof(float) > kUpdLds) { *err = MCVC_ERR_INVALID; return nullptr; }
             o.vec4 = ((o.IB * o.taps) % 4 == 0 && (o.Cin % o.IB) == 0 && ((long long)o.Cin * o.taps) % 4 == 0) ? 1 : 0;
             o.gx = cdiv_i(o.Cin, o.IB);
             nblocks += o.gx * cdiv_i(o.Cout, o.CB);
@@ -2345,7 +2347,7 @@ int mcvc_gen_pack_sets(const float* const* params, float* packed, int max_batch,
 // ... restricted to the layers of some parameter ranges (bit 0: upSample1/2 + lastConvLayer = parameters [100,110); bit 1: the residual
 // blocks + conv1dto2d = [24,100); bit 2: conv1, downSample1/2, conv2dto1d = [0,24) -- the ranges whose gradients become final one after the
 // other during a backward pass, mcvc_gen_backward_overlap): the optimizer step + re-pack of a range can then run beside the rest of the pass
-struct GenPackCfg { bool fused, wino_only, w4, w43, up1_w4; int skipped; };
+struct GenPackCfg { bool fused, wino_only, w4, w43, up1_w4, up1_w2, up2_w2; int skipped; };
 static GenPackCfg gen_pack_cfg(int max_batch, int T)
 {
     GenPackCfg q{};
@@ -2362,7 +2364,13 @@ static GenPackCfg gen_pack_cfg(int max_batch, int T)
     q.w4 = knobs_default && wino4_min_nb() > 0 && max_batch >= wino4_min_nb() && (T % 16) == 0;
     q.w43 = knobs_default && wino43_min_nb() > 0 && max_batch >= wino43_min_nb() && (T % 16) == 0;      // (bit 32)
     q.up1_w4 = (long long)max_batch * 5 * (T / 16) >= wino4_min_tiles();             // upSample1 runs on 20 x T/4 images: 5 x T/16 tiles per sample
-    q.skipped = (q.fused ? (q.wino_only ? 3 : 1) : 0) | (q.w4 ? 0 : 16) | (q.w43 ? 0 : 32);
+    // the 36-point sets of a layer only where some pass still runs F(2x2,5x5): a layer with >= wino4_min_tiles() tiles PER SAMPLE (upSample2
+    // at 64 frames: 80) takes the 4 x 4 scheme in every pass, forward, data gradient and weight gradient (wino4_applies), so its 36-point
+    // sets -- 2 x 36/25 of its weights per step -- have no reader (bit 128; r5)
+    const bool all4 = q.w4 && wino4_min_nb() == 1;
+    q.up1_w2 = !(all4 && 5LL * (T / 16) >= wino4_min_tiles());
+    q.up2_w2 = !(all4 && 10LL * (T / 8) >= wino4_min_tiles());
+    q.skipped = (q.fused ? (q.wino_only ? 3 : 1) : 0) | (q.w4 ? 0 : 16) | (q.w43 ? 0 : 32) | ((q.up1_w2 && q.up2_w2) ? 0 : 128);
     return q;
 }
 // range_mask bits: 1 = parameters [100,110), 2 = [24,100), 4 = [0,24); r4: the head in three parts, in the order their gradients become final
@@ -2385,7 +2393,8 @@ static void gen_pack_build(PackTable& pt, const GenPackCfg& q, int sets, int ran
     if (range_mask & 1) {
         const ConvSpec* up[] = {&g.up1, &g.up2, &g.last};
         // (a layer whose largest pass has fewer than 64 F(4x4) tiles never takes that path, conv_wino4: its 64-point sets are not written)
-        for (const ConvSpec* c : up) add_spec_jobs(pt, *c, false, q.wino_only, sets, q.w4 && (c != &g.up1 || q.up1_w4), q.w43);
+        for (const ConvSpec* c : up) add_spec_jobs(pt, *c, false, q.wino_only, sets, q.w4 && (c != &g.up1 || q.up1_w4), q.w43, false,
+                                                   c == &g.up1 ? q.up1_w2 : (c == &g.up2 ? q.up2_w2 : true));
     }
     if (range_mask & 2) {
         add_spec_jobs(pt, g.c1d2d, q.fused, false, sets);
@@ -2394,7 +2403,8 @@ static void gen_pack_build(PackTable& pt, const GenPackCfg& q, int sets, int ran
 }
 static int gen_pack_key(const GenPackCfg& q, int sets, int range_mask)
 {
-    return 16 + 4 * sets + (q.fused ? (q.wino_only ? 3 : 2) : 0) + 64 * range_mask /* <= 63 */ + (q.w4 ? 4096 : 0) + (q.w43 ? 8192 : 0) + (q.up1_w4 ? 16384 : 0);
+    return 16 + 4 * sets + (q.fused ? (q.wino_only ? 3 : 2) : 0) + 64 * range_mask /* <= 63 */ + (q.w4 ? 4096 : 0) + (q.w43 ? 8192 : 0) + (q.up1_w4 ? 16384 : 0) +
+           (q.up1_w2 ? 0 : 32768) + (q.up2_w2 ? 0 : 65536);
 }
 
 int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batch, int T, int sets, int range_mask, void* stream)

@@ -61,7 +61,10 @@ struct UpdOwner {
     int vec4;              // 1: every tile row is a 16-byte-aligned run of a multiple of four floats
 };
 struct UpdAdam { long long d_g, d_g2, d_m, d_v; int has_g2, zero; AdamCoef c; };     // d_*: float offsets from a parameter to its gradient(s) / moments
-constexpr int kUpdPitchPad = 4;
+// LDS row pitch of an owner tile: the run of IB * taps floats rounded up to four, + 1 -- ODD, so that the emits that walk the output channels
+// (lane = co: the K-major forward copies, the forward Winograd sets) read 32 different banks; r4's pitch was a multiple of four (the Adam
+// phase stored float4s) and those reads were 4-way conflicts -- SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.71 (r4 PMC pass).
+static inline int mcvc_upd_pitch(int IB, int taps) { return ((IB * taps + 3) & ~3) + 1; }
 constexpr size_t kUpdLds = 52 * 1024;
 int mcvc_update_net_launch(const UpdOwner* d_owners, int nown, int nblocks, const PackJob* d_jobs, const PackDgradArgs* d_dga, const PackPtrs& ptrs,
                            float* packed, const UpdAdam& ad, double bytes, hipStream_t s);

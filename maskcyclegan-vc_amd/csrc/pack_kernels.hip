@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) update_net_kernel(const Twin<UpdNetKArgs>
     t.co0 = by * o.CB; t.ci0 = bx * o.IB;
     t.nc = min(o.CB, o.Cout - t.co0); t.ni = min(o.IB, o.Cin - t.ci0);
     const int run = t.ni * o.taps;                    // floats per tile row (contiguous in the OIHW tensor)
-    t.pitch = ((o.IB * o.taps + 3) & ~3) + kUpdPitchPad;
+    t.pitch = ((o.IB * o.taps + 3) & ~3) + 1;                 // (mcvc_upd_pitch: odd)
     const long long row_stride = (long long)o.Cin * o.taps;
     const long long base = (long long)t.co0 * row_stride + (long long)t.ci0 * o.taps;
     // ---- Adam on the tile; the new weights stay in LDS
@@ -308,7 +308,7 @@ __global__ void __launch_bounds__(256) update_net_kernel(const Twin<UpdNetKArgs>
                 *reinterpret_cast<float4*>(p + off[u]) = pp[u];
                 *reinterpret_cast<float4*>(m + off[u]) = mm[u];
                 *reinterpret_cast<float4*>(v + off[u]) = vv[u];
-                *reinterpret_cast<float4*>(lds + ldo[u]) = pp[u];
+                lds[ldo[u]] = pp[u].x; lds[ldo[u] + 1] = pp[u].y; lds[ldo[u] + 2] = pp[u].z; lds[ldo[u] + 3] = pp[u].w;      // (odd pitch: no 16-byte alignment)
             }
         }
     } else {
