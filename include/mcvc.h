@@ -45,10 +45,10 @@ int mcvc_version(void);
 int mcvc_set_deterministic(int on);
 int mcvc_get_deterministic(void);
 /* Small-batch generator passes (B * T/4 <= 32) run the 1-D trunk (six residual blocks + conv1dto2d, model.py:258-271) as ONE
- * persistent launch per direction instead of one fused launch per layer (default on; env MCVC_TRUNK_NET=0).  Results are
+ * persistent launch per direction instead of one fused launch per layer (default on).  Results are
  * bit-identical either way; the switch exists for A/B timing and tests.  Returns the previous setting.
  * The BACKWARD pass's data-gradient chain through the six blocks is one persistent launch as well (B * T/4 <= 16 at the 1024 staged
- * channels; env MCVC_TRUNK_BWD_NET=0): on = 1 both directions, 2 forward only, 0 neither.  The persistent backward sums every K range in a
+ * channels): on = 1 both directions, 2 forward only, 0 neither.  The persistent backward sums every K range in a
  * fixed order, so -- unlike the per-layer launches' atomic K-split -- its gradients are bit-reproducible in every mode; they agree with the
  * per-layer path to rounding.                                                                                  */
 int mcvc_set_trunk_persistent(int on);
@@ -97,12 +97,12 @@ int mcvc_gen_pack_sets(const float* const* params, float* packed, int max_batch,
  * rest of the backward pass.                                                                              */
 int mcvc_gen_pack_ranges(const float* const* params, float* packed, int max_batch, int T, int sets, int range_mask, void* stream);
 int mcvc_disc_pack(const float* const* params, float* packed, void* stream);
-/*      The same restricted to what passes at n_frames T read when the three stride-2 layers run as staged GEMMs (the default at every batch
- *      size): their K-major forward copies + biases only -- 4x fewer bytes than the full re-pack; falls back to it otherwise.  A pass that
- *      would need one of the stale copies returns MCVC_ERR_INVALID instead of reading it.                         */
+/*      The same restricted to what passes at n_frames T read when the three stride-2 layers run as implicit GEMMs (every batch size
+ *      since r5): their tap-major K-major forward copy + biases only -- it serves the forward pass and, read row-major, the data gradient;
+ *      the weight gradient reads no weights.  Falls back to the full re-pack when a layer would not take that path (planes whose width is
+ *      no multiple of 8).  A pass that would need one of the stale copies returns MCVC_ERR_INVALID instead of reading it.                 */
 int mcvc_disc_pack_small(const float* const* params, float* packed, int T, void* stream);
-/*      ... for passes of up to max_batch samples (r4): the discriminators' stride-2 layers run as implicit GEMMs (forward: a tap-major K-major
- *      copy; data gradient from MCVC_IGEMM_DGRAD_NB samples per pass: four per-parity-class copies) -- only the copies some pass reads.  */
+/*      ... for passes of up to max_batch samples (same copies at every max_batch since r5; the argument is kept for ABI 3).            */
 int mcvc_disc_pack_batch(const float* const* params, float* packed, int max_batch, int T, void* stream);
 
 /* ---- Generator: replaces Generator.forward (mask_cyclegan_vc/model.py:239-280) and its autograd
@@ -237,7 +237,7 @@ int mcvc_adam_step2(float* p, float* g, float* g2, int zero_grads, float* exp_av
 /*      optimizer.step() fused with the weight re-pack (reference train.py:242 / :299 are just `optimizer.step()`: the packed copies are this
  *      library's own, so their refresh belongs to the step): ONE launch in which a workgroup owns a tile of filters of one parameter tensor --
  *      it applies the Adam update above to the tile (bit-identical to mcvc_adam_step2), keeps the new weights in LDS and writes every packed
- *      copy derived from them (K-major / tap-major / per-class data-gradient / transposed trunk / Winograd U sets) from there.  No second
+ *      copy derived from them (K-major / tap-major / data-gradient / transposed trunk / Winograd U sets) from there.  No second
  *      pass over the OIHW tensors: the per-step `pack` kernel family is gone (it remains for load_state_dict: mcvc_*_pack*).
  *      numel[i]: elements of parameter tensor i (0: a parameter that is neither updated nor packed -- the unused downSample4 block);
  *      flat / grad / grad2 (nullable) / exp_avg / exp_avg_sq: flat buffers in which params[i], its gradient(s) and moments sit at EQUAL
@@ -281,15 +281,15 @@ int mcvc_conv2d_wgrad(const float* x, const float* dy, float* dw, float* slabs, 
                       int Cout, int KH, int KW, int stride, int pad_h, int pad_w, void* stream);
 /* ---- one convolution LAYER of the path, op by op (r4).  SURVEY.md section 8(b) asks for single-op entries of the kernels that are hot at
  *      the trainer's shapes: the 5x5 layers run as Winograd products (model.py:86-103 downSample: F(2x2,3x3) / F(4x4,3x3) over the four input
- *      phases; :226-237 upSample: F(2x2,5x5) / F(4x4,5x5)) and the discriminators' stride-2 3x3 layers (:298-314) as staged GEMMs.  These
+ *      phases; :226-237 upSample: F(2x2,5x5) / F(4x4,5x5)) and the discriminators' stride-2 3x3 layers (:298-314) as implicit GEMMs.  These
  *      entries run the planner the networks use (conv_fwd / conv_dgrad / conv_wgrad) on ONE layer of `branches` (1, or 2 = value | gate)
  *      convolutions Cin -> Cout:  x [N][Cin][H][W], y / dy [N][branches*Cout][OH][OW] (value rows first), dx like x, dw like the OIHW
  *      parameters (ACCUMULATED: pass zeros).  `packed` = mcvc_layer_pack of the parameters (every weight set the planner may read);
  *      `scratch` >= mcvc_layer_scratch_floats.  `scheme`: 0 the planner's choice at this shape, 1 Winograd with 2x2 output tiles, 2 Winograd
  *      with 4x4 output tiles (sample / tile thresholds lifted; image sides must be multiples of 4 -- 8 for the stride-2 layers),
- *      3 no Winograd (staged GEMM where it applies, else direct), 4 direct kernels only, 5 implicit GEMM (forward / dgrad of the 3x3
+ *      3 no Winograd (direct kernels for these layers since r5), 4 direct kernels only, 5 implicit GEMM (forward / dgrad / wgrad of the 3x3
  *      stride-2 layers: the kernels the discriminator passes run, sgemm.h; the dense operand is converted to their layout first).  w0 / w1 = the OIHW tensors themselves (the
- *      staged-GEMM data gradient multiplies them in place).  pixel_shuffle: the forward store of the up-sampling layers (model.py:232).   */
+ *      pre-r5 staged data gradient multiplied them in place; unused now).  pixel_shuffle: the forward store of the up-sampling layers (model.py:232).   */
 long long mcvc_layer_packed_floats(int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w);
 long long mcvc_layer_scratch_floats(int N, int H, int W, int Cin, int Cout, int branches, int KH, int KW, int stride, int pad_h, int pad_w);
 int mcvc_layer_pack(const float* w0, const float* b0, const float* w1, const float* b1, float* packed, int Cin, int Cout, int branches,

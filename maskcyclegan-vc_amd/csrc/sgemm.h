@@ -55,7 +55,7 @@ struct IGemmArgs {
     const float* bias; int accumulate; int arow;
     int M, N;                           // M % 64 == 0, N % 4 == 0
     int nsplit; float* c_slab; long long c_split;      // K split of every class: split s > 0 writes the C layout at c_slab + (s - 1) * c_split
-    int nt, mt;                         // (filled by the launcher)
+    int nt, mt, mgroup;                 // (filled by the launcher; mgroup: row tiles per L2-sized group, see igemm_kernel)
 };
 int mcvc_igemm_launch(const IGemmArgs& a, hipStream_t s);
 

@@ -159,9 +159,25 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
     const int nt = a.nt, mt = a.mt, nsplit = a.nsplit, Cb = a.Cb, OW = a.OW, P = a.P, N = a.N;
     const long long a_ks = a.a_ks, b_cs = a.b_cs, b_sn = a.b_sn;
     const int b_pitch = a.b_pitch;
-    const int n0 = (lid % nt) * BN; lid /= nt;
-    const int m0 = (lid % mt) * BM;
-    const int ks = lid / mt;
+    // Tile order inside a K split: groups of `mg` row tiles whose weight panels fit an XCD's L2 together; within a group the row tile is the
+    // fastest index, then the column tile -- the workgroups that share a B window (the gathered activation: the large operand at large
+    // batch) run side by side on one XCD and fetch it ONCE, instead of once per row tile (r5: FETCH_SIZE of this kernel at bs=32 was 4-16x
+    // the activation bytes with the column tile fastest).
+    const int mg = a.mgroup;
+    int m_t, n_t;
+    if (mg == 0) { n_t = lid % nt; lid /= nt; m_t = lid % mt; lid /= mt; }
+    else {
+        const int per = mt * nt;
+        int r = lid % per;
+        const int g = r / (mg * nt);                 // full groups first; the last group may be narrower
+        const int gm = (g + 1) * mg <= mt ? mg : mt - g * mg;
+        r -= g * mg * nt;
+        n_t = r / gm; m_t = g * mg + r % gm;
+        lid /= per;
+    }
+    const int n0 = n_t * BN;
+    const int m0 = m_t * BM;
+    const int ks = lid;
     const int Kc = cl.ntaps * Cb / nsplit;
     const int kbase = ks * Kc;
     const float* const A = cl.a;
@@ -411,6 +427,16 @@ int mcvc_igemm_launch(const IGemmArgs& a0, hipStream_t s)
     }
     bytes += 4.0 * (double)a.Cb * a.N * 2.25;            // (the gathered activation: read once from HBM, the taps' overlap hits in L2)
     a.nt = cdiv_i(a.N, BN); a.mt = a.M / BM;
+    {   // row tiles per group: their A panels (the longest class's K x 64 floats each) within ~2 MB of the 4 MB L2 of an XCD
+        int kmax = 0;
+        for (int c = 0; c < a.ncls; ++c) kmax = a.cls[c].ntaps * a.Cb > kmax ? a.cls[c].ntaps * a.Cb : kmax;
+        static const int l2kb = mcvc_knob("MCVC_IGEMM_GROUP_KB", 2048);          // (0: the column tile fastest, r4's order)
+        const long long panel = (long long)kmax * BM * 4;
+        long long mg = l2kb > 0 ? (long long)l2kb * 1024 / (panel > 0 ? panel : 1) : 0;
+        if (l2kb > 0 && mg < 1) mg = 1;
+        if (mg > a.mt) mg = a.mt;
+        a.mgroup = (int)mg;
+    }
     constexpr size_t lds = (size_t)ST * STAGE * sizeof(float);
     static bool done = false;
     if (!done) {

@@ -14,6 +14,8 @@ import sys
 
 
 def family(name):
+    """Kernel name -> the library's trace kind (csrc/trace.cpp kNames: what bench.py's per-launch trace and `roofline.kernel` call it), so
+    that the counters and the launchers' own byte counts are compared family by family."""
     n = name.replace("(anonymous namespace)::", "").replace("void ", "").replace(" ", "")
     m = re.match(r"conv_direct_kernel<(\d+),(\d+),(\d+),(\d+),", n)
     if m:
@@ -21,7 +23,30 @@ def family(name):
     m = re.match(r"conv_wgrad_kernel<(\d+),(\d+),", n)
     if m:
         return "conv_wgrad<%s,%s>" % m.groups()
-    return re.sub(r"_kernel.*$", "", re.sub(r"\(.*$", "", n))
+    base = re.sub(r"_kernel.*$", "", re.sub(r"\(.*$", "", n))
+    base = re.sub(r"<.*$", "", base)
+    table = (
+        (("gemm2", "wino_gemm"), "wino_gemm"),
+        (("sgemm", "igemm", "wgemm"), "sgemm"),
+        (("update_net", "adam"), "adam"),
+        (("pack_",), "pack"),
+        (("norm_fwd", "bf16_norm", "bf16_stats", "bf16_finalize", "bf16_apply"), "norm_fwd"),
+        (("norm_bwd",), "norm_bwd"),
+        (("act_fwd", "disc_conv1_fwd", "disc_out_fwd"), "act_fwd"),
+        (("act_bwd", "disc_out_dgrad"), "act_bwd"),
+        (("trunk_",), "trunk_layer"),
+        (("wgrad_smallk",), "wgrad_smallk"),
+        (("wgrad_cin", "wgrad_cout"), "conv_wgrad<1,5>"),
+        (("conv_fewout",), "conv_fewout"),
+        (("bias_grad",), "bias_grad"),
+        (("l1_loss", "lsgan_loss", "loss_combine"), "loss"),
+    )
+    for prefixes, kind in table:
+        if any(base.startswith(p) for p in prefixes):
+            return kind
+    if base.startswith(("wino", "xform", "dw_accum", "mask_grad", "prep_input", "copy", "zero_words", "layout_conv", "draw_batch")):
+        return "elementwise"
+    return base
 
 
 def dispatches(dbfile, counter):
