@@ -16,6 +16,7 @@
 #include "trace.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -28,6 +29,7 @@ __device__ __forceinline__ unsigned pack2bf(float a, float b)
     const bf16x2_ r = __builtin_convertvector(f32x2_{a, b}, bf16x2_);
     return __builtin_bit_cast(unsigned, r);
 }
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p; }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float((unsigned)h << 16); }
 // (bf16 path: the result is rounded to 8 mantissa bits -- hardware exp2 / reciprocal (1 ulp) instead of the correctly rounded expf and an IEEE
@@ -63,7 +65,7 @@ constexpr int kMaxWP = 10;          // 16-byte weight pieces per thread and stag
 template <int WM, int WN, int MT, int NT, int KWT, int PPT>
 __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvArgs a)
 {
-    constexpr int kMaxPP = PPT;
+    constexpr int kMaxPP = PPT > 0 ? PPT : 1;
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = WM * MT * 32;
     constexpr int BN = WN * NT * 32;
@@ -139,7 +141,10 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     const bool s2 = a.stride == 2;
     const int PWe = (a.PW + 1) >> 1;
     auto patch_col = [&](int j) { return s2 ? (j < PWe ? 2 * j : 2 * (j - PWe) + 1) : j; };
-    const bool p_pref = patch_pieces <= kMaxPP * kConvThreads;
+    // PPT > 0: the host guarantees patch_pieces <= PPT * 256 and the patch is ALWAYS prefetched; PPT == 0: always staged synchronously.  (One
+    // kernel with both paths behind a run-time test made the compiler treat the synchronous loop's load registers as possibly pending at the
+    // first operand read of every stage: an s_waitcnt vmcnt(0) there, i.e. in front of the MFMAs and behind the weight DMA just issued.)
+    constexpr bool p_pref = PPT > 0;
     int poff[kMaxPP];                         // element offset of the piece inside the image (without the chunk offset; an image is < 2^31 elements: host check); -1 = zero fill
 #pragma unroll
     for (int i = 0; i < kMaxPP; ++i) {
@@ -205,7 +210,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     issue_w(0, 0);
-    if (p_pref) load_patch(0);
+    if constexpr (p_pref) load_patch(0);
     for (int stage = 0; stage < nstage; ++stage) {
         const int cc = stage / a.KH, kh = stage - cc * a.KH;
         const int buf = stage & 1;
@@ -214,11 +219,11 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kh == 0) {
-            if (p_pref) store_patch(); else stage_patch_sync(cc);
+            if constexpr (p_pref) store_patch(); else stage_patch_sync(cc);
             __syncthreads();
         }
         if (stage + 1 < nstage) issue_w(stage + 1, buf ^ 1);          // in flight during the MFMAs below
-        if (p_pref && kh == a.KH - 1 && cc + 1 < ncc) load_patch(cc + 1);
+        if constexpr (p_pref) { if (kh == a.KH - 1 && cc + 1 < ncc) load_patch(cc + 1); }
         const unsigned char* Wb = Ws + buf * wbuf_bytes;
         const int pk = kh * a.PW;
         // one step = (tap, 16-channel half) = MT + NT operand reads (ds_read_b128) and MT * NT MFMAs
@@ -248,18 +253,68 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
         };
         if constexpr (KWT > 0) {
-            // software pipeline over the 2 * KW steps of the stage: the operands of step s+1 are read while step s multiplies, and the
-            // order is pinned (left alone the scheduler sinks reads next to their MFMAs: ds_read_b128 -> s_waitcnt lgkmcnt(0) -> v_mfma,
-            // an LDS round trip per few MFMAs, which a single wave per SIMD cannot hide)
-            bf16x8 av[2][MT], bv[2][NT];
-            load_step(0, av[0], bv[0]);
-            __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+            // Software pipeline over the 2 * KW steps of the stage: the operands of step s+1 are requested while step s multiplies.  The reads
+            // are inline assembly: hipcc cannot tell that the LDS-DMA of the NEXT stage's weights (global_load_lds above) does not write what a
+            // ds_read_b128 here reads, and put `s_waitcnt vmcnt(0)` in front of the stage's first operand read -- every stage then waited for the
+            // next stage's 40 KB weight copy (and the next chunk's patch loads) before its first MFMA, the copy never overlapped the matrix work
+            // (SQ: MFMA busy 0.31 - 0.53 on the large layers).  With the reads opaque the compiler keeps its hands off the counters: one explicit
+            // lgkmcnt(0) per step, placed before the next step's requests are issued, and sched_barrier(0) pins requests / MFMAs / wait in order.
+            const unsigned xs_addr = lds_addr(Xs), wb_addr = lds_addr(Wb);
+            unsigned aaddr[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) aaddr[mt][h2] = wb_addr + (unsigned)((((rowA[mt] * KW) << 2) + ((h2 * 2 + half) ^ gA[mt])) << 4);
+            // pixel operand of (nt, tap): patch pixel pp, 16-byte slot (h2 * 2 + half) ^ ((pp >> 2) & 3); the two 16-channel halves differ in bit 5
+            auto b_addr = [&](int tap, unsigned (&ad)[NT][2]) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int pp = ppB[nt] + pk + (s2 ? (tap >> 1) + (tap & 1) * PWe : tap);
+                    const unsigned slot = (unsigned)((half ^ ((pp >> 2) & 3)) << 4);
+                    const unsigned row = xs_addr + ((unsigned)pp << 6);
+                    ad[nt][0] = row + slot; ad[nt][1] = row + (slot ^ 32u);
+                }
+            };
+            u32x4 av[2][MT], bv[2][NT];
+            unsigned bad[2][NT][2];                                  // [tap & 1]
+            auto request = [&](int step, u32x4 (&a_)[MT], u32x4 (&b_)[NT]) __attribute__((always_inline)) {
+                const int tap = step >> 1, h2 = step & 1;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(a_[mt]) : "v"(aaddr[mt][h2]), "i"(tap * 64));
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    asm volatile("ds_read_b128 %0, %1" : "=&v"(b_[nt]) : "v"(bad[tap & 1][nt][h2]));
+            };
+            auto landed = [&](u32x4 (&a_)[MT], u32x4 (&b_)[NT]) __attribute__((always_inline)) {
+                if constexpr (MT == 4 && NT == 4)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_[0]), "+v"(a_[1]), "+v"(a_[2]), "+v"(a_[3]), "+v"(b_[0]), "+v"(b_[1]), "+v"(b_[2]), "+v"(b_[3]));
+                else if constexpr (MT == 2 && NT == 4)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_[0]), "+v"(a_[1]), "+v"(b_[0]), "+v"(b_[1]), "+v"(b_[2]), "+v"(b_[3]));
+                else if constexpr (MT == 2 && NT == 2)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_[0]), "+v"(a_[1]), "+v"(b_[0]), "+v"(b_[1]));
+                else if constexpr (MT == 2 && NT == 1)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_[0]), "+v"(a_[1]), "+v"(b_[0]));
+                else {
+                    static_assert(MT == 1 && NT == 1, "operand-wait variant missing for this tile");
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_[0]), "+v"(b_[0]));
+                }
+            };
+            b_addr(0, bad[0]);
+            request(0, av[0], bv[0]);
 #pragma unroll
             for (int step = 0; step < 2 * KWT; ++step) {
-                if (step + 1 < 2 * KWT) load_step(step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
-                mfma_step(av[step & 1], bv[step & 1]);
-                if (step + 1 < 2 * KWT) __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+                landed(av[step & 1], bv[step & 1]);
+                if (step + 1 < 2 * KWT) request(step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if ((step & 1) == 0 && step + 2 < 2 * KWT) b_addr((step >> 1) + 1, bad[((step >> 1) + 1) & 1]);   // next tap's addresses: VALU work among the MFMAs
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[step & 1][mt]), __builtin_bit_cast(bf16x8, bv[step & 1][nt]),
+                                                                              acc[mt][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
             for (int step = 0; step < 2 * KW; ++step) {
@@ -345,20 +400,32 @@ int conv_launch_t(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
 template <int WM, int WN, int MT, int NT>
 int conv_launch_kw(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
 {
-    const bool big_patch = a.PH * a.PW * 4 > 4 * kConvThreads;
-    // (the 512-pixel tiles of the large stride-1 layers stage 816 / 1056 patch pixels = 13 / 17 pieces per thread: with 12 they fell off the
-    //  register prefetch onto the synchronous staging loop -- four dependent rounds of global loads per channel chunk in front of 50 MFMA-bound
-    //  steps; r4, 16 x 512 frames: upSample2 1090 -> 938 us)
-    static const int ppt_knob = mcvc_knob("MCVC_BF16_PPT", 1);
-    if constexpr (WM == 1 && WN == 4 && MT == 4 && NT == 4) {
-        const int pieces = a.PH * a.PW * 4;
-        if (a.KW == 5 && ppt_knob && pieces > 12 * kConvThreads && pieces <= 13 * kConvThreads) return conv_launch_t<WM, WN, MT, NT, 5, 13>(a, lds, s);
-        if (a.KW == 5 && ppt_knob && pieces > 13 * kConvThreads && pieces <= 17 * kConvThreads) return conv_launch_t<WM, WN, MT, NT, 5, 17>(a, lds, s);
+    // register-prefetch depth = 16-byte patch pieces per thread, the smallest instantiated depth that holds the patch (4: small stride-1 tiles,
+    // 12: 128-pixel stride-2 tiles, 13 / 17: the 512-pixel tiles of the large stride-1 layers stage 816 / 1056 patch pixels, 20: 256-pixel
+    // stride-2 tiles); anything larger, and run-time kernel widths, use the synchronous staging loop (depth 0)
+    // (r4, 16 x 512 frames: with 12 the 512-pixel tiles fell onto the synchronous loop -- four dependent rounds of global loads per channel chunk in
+    //  front of 50 MFMA-bound steps; upSample2 1090 -> 938 us)
+    const int pieces = a.PH * a.PW * 4;
+    const int need = (pieces + kConvThreads - 1) / kConvThreads;
+    if (a.KW == 5) {
+        if (need <= 4) return conv_launch_t<WM, WN, MT, NT, 5, 4>(a, lds, s);
+        if (need <= 12) return conv_launch_t<WM, WN, MT, NT, 5, 12>(a, lds, s);
+        if constexpr (WM == 1 && WN == 4 && MT == 4 && NT == 4) {
+            if (need <= 13) return conv_launch_t<WM, WN, MT, NT, 5, 13>(a, lds, s);
+            if (need <= 17) return conv_launch_t<WM, WN, MT, NT, 5, 17>(a, lds, s);
+        }
+        if constexpr (WM == 2 && WN == 2 && MT == 2 && NT == 4) {
+            if (need <= 20) return conv_launch_t<WM, WN, MT, NT, 5, 20>(a, lds, s);
+        }
+        return conv_launch_t<WM, WN, MT, NT, 5, 0>(a, lds, s);
     }
-    if (a.KW == 5) return big_patch ? conv_launch_t<WM, WN, MT, NT, 5, 12>(a, lds, s) : conv_launch_t<WM, WN, MT, NT, 5, 4>(a, lds, s);
-    if (a.KW == 3) return big_patch ? conv_launch_t<WM, WN, MT, NT, 3, 12>(a, lds, s) : conv_launch_t<WM, WN, MT, NT, 3, 4>(a, lds, s);
-    if (a.KW == 1) return conv_launch_t<WM, WN, MT, NT, 1, 4>(a, lds, s);
-    return conv_launch_t<WM, WN, MT, NT, 0, 4>(a, lds, s);
+    if (a.KW == 3) {
+        if (need <= 4) return conv_launch_t<WM, WN, MT, NT, 3, 4>(a, lds, s);
+        if (need <= 12) return conv_launch_t<WM, WN, MT, NT, 3, 12>(a, lds, s);
+        return conv_launch_t<WM, WN, MT, NT, 3, 0>(a, lds, s);
+    }
+    if (a.KW == 1 && need <= 4) return conv_launch_t<WM, WN, MT, NT, 1, 4>(a, lds, s);
+    return conv_launch_t<WM, WN, MT, NT, 0, 0>(a, lds, s);
 }
 
 }  // namespace
@@ -379,6 +446,18 @@ static int conv_config(const Bf16ConvArgs& a)
     if (a.Cout_pad % 128 == 0 && a.stride == 1 && a.KW >= 3 && !a.glu && knob != 0 && knob != 4 && (knob == 5 || (a.Cout_pad / 128) * ((px + 511) / 512) >= 512))
         return 5;
     if (a.Cout_pad % 128 == 0 && a.stride == 1 && a.KW >= 3 && knob != 0 && (knob == 4 || (a.Cout_pad / 128) * ((px + 255) / 256) >= 1024)) return 4;
+    // stride-2 layers, 128 channels x 256 pixels: on 128-pixel tiles every (tap, 16-channel) step is 4 operand reads per 4 MFMAs and wave --
+    // 128 LDS cycles per 128 matrix cycles and CU before the weight DMA's writes, the LDS port saturated (SQ: MFMA busy 0.31); 64 x 128 per
+    // wave is 6 reads per 8 MFMAs.  The 19 x 67-pixel patch (81.5 KB) and the two 40 KB weight stages fit the 160 KB LDS with 256 bytes to spare.
+    static const int s2_knob = mcvc_knob("MCVC_BF16_S2_WIDE", 1);
+    if (s2_knob && a.stride == 2 && a.KW == 5 && a.KH == 5 && a.Cout_pad % 128 == 0 && !a.glu && (a.Cout_pad / 128) * ((px + 255) / 256) >= 512) {
+        int th = 0, twl = 0;
+        mcvc_bf16_conv_tile(a.OH, a.OW, a.KH, a.KW, a.stride, 256, &th, &twl);
+        if (th > 0) {
+            const size_t ph = (size_t)(th - 1) * 2 + a.KH, pw = (size_t)((1 << twl) - 1) * 2 + a.KW;
+            if (((ph * pw * 64 + 255) & ~(size_t)255) + 2 * (size_t)128 * a.KW * 64 <= 160 * 1024 && ph * pw * 4 <= 20 * kConvThreads) return 4;
+        }
+    }
     if (a.Cout_pad % 128 != 0 || a.glu == 0) {
         // small problems: 128 x 128 tiles would leave most of the 256 CUs idle
         const long long wg128 = (a.Cout_pad / 128) * ((px + 127) / 128);
