@@ -19,6 +19,7 @@ struct Bf16ConvArgs {
     int N, H, W, Cin, Cout, Cout_pad, OH, OW, KH, KW, stride, pad_h, pad_w;
     int TH, tw_log2, tiles_h, tiles_w;  // pixel tile = TH x (1 << tw_log2) = 128 or 64 pixels (chosen by the launcher)
     int PH, PW;                         // input patch of a tile: (TH-1)*stride + KH rows, (TW-1)*stride + KW columns
+    int patch_bytes;                    // LDS bytes reserved for the staged patch (>= PH*PW*64, and >= prefetch depth * 4096 so that every thread stores every piece)
     int wbufs;                          // LDS weight buffers (2 = double buffer; 1 when that lets two workgroups share a CU)
     int glu;                            // 1: rows [0, Cout_pad/2) are value channels, [Cout_pad/2, Cout_pad) their gates, interleaved per
                                         //    64-row block by the packer; the epilogue stores value * sigmoid(gate): Cout = Cout_pad / 2

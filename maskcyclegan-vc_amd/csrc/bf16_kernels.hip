@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     const int patch_pieces = patch_px * 4;
     unsigned char* Xs = smem;                                             // [patch_px][64 B]
     const int wbuf_bytes = BM * KW * 64;
-    unsigned char* Ws = smem + (((size_t)patch_px * 64 + 255) & ~(size_t)255);   // wbufs x [BM][KW][64 B]
+    unsigned char* Ws = smem + a.patch_bytes;                             // wbufs x [BM][KW][64 B]
 
     const int ncc = a.Cin >> 5;
     const int nstage = ncc * a.KH;                                        // stage = (cc, kh): KW taps x 32 input channels
@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     // clock showed 1.3 us of store + 4.8 us "MFMA" phase per stage for 1.1 us of MFMA work.)
     constexpr int NWP = KWT > 0 ? (BM * KWT * 4 + kConvThreads - 1) / kConvThreads : kMaxWP;
     // piece -> (weight row, tap, swizzled chunk) is stage-invariant: element offsets computed once
+    constexpr bool W_EXACT = KWT > 0 && (BM * KWT * 4) % kConvThreads == 0;      // every lane of every piece is a real piece: no exec masking
     int woff[NWP];
 #pragma unroll
     for (int i = 0; i < NWP; ++i) {
@@ -124,15 +125,17 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
         const int lc = pos ^ ((row >> 2) & 3);
         woff[i] = (q < w_pieces) ? ((co0 + row) * a.KH * ncc * KW + tap) * 32 + lc * 8 : -1;
     }
+    auto w_src = [&](int stage) { const int cc = stage / a.KH, kh = stage - cc * a.KH; return a.w + (long long)(kh * ncc + cc) * KW * 32; };
+    auto issue_piece = [&](const bf16_t* base, unsigned char* dst, int i) __attribute__((always_inline)) {
+        if (W_EXACT || woff[i] >= 0)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + woff[i]),
+                                             (__attribute__((address_space(3))) void*)(dst + (size_t)(wave * 64 + i * kConvThreads) * 16), 16, 0, 0);
+    };
     auto issue_w = [&](int stage, int buf) {
-        const int cc = stage / a.KH, kh = stage - cc * a.KH;
-        const bf16_t* base = a.w + (long long)(kh * ncc + cc) * KW * 32;
+        const bf16_t* base = w_src(stage);
         unsigned char* dst = Ws + buf * wbuf_bytes;
 #pragma unroll
-        for (int i = 0; i < NWP; ++i)
-            if (woff[i] >= 0)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + woff[i]),
-                                                 (__attribute__((address_space(3))) void*)(dst + (size_t)(wave * 64 + i * kConvThreads) * 16), 16, 0, 0);
+        for (int i = 0; i < NWP; ++i) issue_piece(base, dst, i);
     };
     // ---- input patch: small patches (<= kMaxPP pieces per thread) are prefetched through registers one chunk ahead; large ones
     //      (stride-2 layers) are staged synchronously, four loads in flight per thread
@@ -145,7 +148,9 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     // kernel with both paths behind a run-time test made the compiler treat the synchronous loop's load registers as possibly pending at the
     // first operand read of every stage: an s_waitcnt vmcnt(0) there, i.e. in front of the MFMAs and behind the weight DMA just issued.)
     constexpr bool p_pref = PPT > 0;
-    int poff[kMaxPP];                         // element offset of the piece inside the image (without the chunk offset; an image is < 2^31 elements: host check); -1 = zero fill
+    int poff[kMaxPP];                         // element offset of the piece inside the image (without the chunk offset; an image is < 2^31 elements: host check)
+    unsigned pvalid = 0;                      // bit i: piece i is inside the image (else it is loaded from offset 0 and replaced by zeros at the LDS store:
+                                              // loads and stores without exec-mask branches)
 #pragma unroll
     for (int i = 0; i < kMaxPP; ++i) {
         const int q = tid + i * kConvThreads;
@@ -153,20 +158,24 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
         const int pr = pp / a.PW, pc = pp - pr * a.PW;
         const int ih = ih0 + pr, iw = iw0 + patch_col(pc);
         const bool ok = p_pref && q < patch_pieces && ih >= 0 && ih < a.H && iw >= 0 && iw < a.W;
-        poff[i] = ok ? (int)((long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 2) & 3)) * 8) : -1;
+        poff[i] = ok ? (int)((long long)ih * a.x_sh + (long long)iw * a.x_sw + (pos ^ ((pp >> 2) & 3)) * 8) : 0;
+        pvalid |= ok ? (1u << i) : 0u;
     }
     const bf16_t* ximg = a.x + (long long)n_img * a.x_sn;
     uint4 preg[kMaxPP];
     auto load_patch = [&](int cc) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < kMaxPP; ++i)
-            preg[i] = (poff[i] >= 0) ? *reinterpret_cast<const uint4*>(ximg + cc * 32 + poff[i]) : make_uint4(0u, 0u, 0u, 0u);
+            preg[i] = *reinterpret_cast<const uint4*>(ximg + cc * 32 + poff[i]);
     };
     auto store_patch = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < kMaxPP; ++i) {
-            const int q = tid + i * kConvThreads;
-            if (q < patch_pieces) *reinterpret_cast<uint4*>(Xs + (size_t)q * 16) = preg[i];
+            const int q = tid + i * kConvThreads;                  // q * 16 < kMaxPP * 4096 <= patch_bytes (launcher)
+            const bool ok = (pvalid >> i) & 1u;
+            uint4 v = preg[i];
+            v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u; v.z = ok ? v.z : 0u; v.w = ok ? v.w : 0u;
+            *reinterpret_cast<uint4*>(Xs + (size_t)q * 16) = v;
         }
     };
     auto stage_patch_sync = [&](int cc) {
@@ -222,8 +231,13 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
             if constexpr (p_pref) store_patch(); else stage_patch_sync(cc);
             __syncthreads();
         }
-        if (stage + 1 < nstage) issue_w(stage + 1, buf ^ 1);          // in flight during the MFMAs below
-        if constexpr (p_pref) { if (kh == a.KH - 1 && cc + 1 < ncc) load_patch(cc + 1); }
+        // KWT > 0: the next stage's weight DMA and the next chunk's patch loads are issued from inside the step loop, behind the first MFMAs
+        // (issued here they sat in front of the stage's first operand reads: ten DMA instructions with their address arithmetic per stage while
+        // the matrix pipe idled)
+        if constexpr (KWT == 0) {
+            if (stage + 1 < nstage) issue_w(stage + 1, buf ^ 1);          // in flight during the MFMAs below
+            if constexpr (p_pref) { if (kh == a.KH - 1 && cc + 1 < ncc) load_patch(cc + 1); }
+        }
         const unsigned char* Wb = Ws + buf * wbuf_bytes;
         const int pk = kh * a.PW;
         // one step = (tap, 16-channel half) = MT + NT operand reads (ds_read_b128) and MT * NT MFMAs
@@ -300,21 +314,65 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a_[0]), "+v"(b_[0]));
                 }
             };
+            // The next stage's weights: NWP DMA instructions per wave, spread over the stage's first 2 * KWT - 2 steps, each in the middle of
+            // a step's MFMAs.  One LDS-DMA instruction occupies its wave's issue slot for 60 - 185 cycles (MI355X_MICROARCH.md), far more than
+            // the 32-cycle MFMA beside it hides, and four waves issuing ten each in one burst queue behind each other in the texture path:
+            // with all ten at the head of the stage the copy cost 21 % of the layer (832 us with, 655 us without, upSample2 at 16 x 512 frames).
+            // Unconditional (a branch would end the scheduling region): the block's final stage re-requests its own weights into the idle buffer.
+            const bf16_t* wnext = w_src(stage + 1 < nstage ? stage + 1 : stage);
+            unsigned char* dnext = Ws + (buf ^ 1) * wbuf_bytes;
+            constexpr int DSTEPS = 2 * KWT > 2 ? 2 * KWT - 2 : 1;
             b_addr(0, bad[0]);
             request(0, av[0], bv[0]);
+            // One step = MT * NT MFMAs.  The NEXT step's MT + NT operand reads go one per MFMA gap at the head of the step (eight reads in a
+            // burst in front of the MFMAs cost +14 % in tools/ubench_issue_cost.hip, one per gap costs nothing), then the next tap's pixel
+            // addresses (VALU), then this step's share of the weight DMA; a sched_barrier after every MFMA keeps that order.
+            auto request_one = [&](int step, int r, u32x4 (&a_)[MT], u32x4 (&b_)[NT]) __attribute__((always_inline)) {
+                const int tap = step >> 1, h2 = step & 1;
+                if (r < MT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(a_[r]) : "v"(aaddr[r][h2]), "i"(tap * 64));
+                else asm volatile("ds_read_b128 %0, %1" : "=&v"(b_[r - MT]) : "v"(bad[tap & 1][r - MT][h2]));
+            };
+            auto b_addr_one = [&](int tap, int nt) __attribute__((always_inline)) {
+                const int pp = ppB[nt] + pk + (s2 ? (tap >> 1) + (tap & 1) * PWe : tap);
+                const unsigned slot = (unsigned)((half ^ ((pp >> 2) & 3)) << 4);
+                const unsigned row = xs_addr + ((unsigned)pp << 6);
+                bad[tap & 1][nt][0] = row + slot; bad[tap & 1][nt][1] = row + (slot ^ 32u);
+            };
+            constexpr int MN = MT * NT, NR = MT + NT;
 #pragma unroll
             for (int step = 0; step < 2 * KWT; ++step) {
                 landed(av[step & 1], bv[step & 1]);
-                if (step + 1 < 2 * KWT) request(step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                if ((step & 1) == 0 && step + 2 < 2 * KWT) b_addr((step >> 1) + 1, bad[((step >> 1) + 1) & 1]);   // next tap's addresses: VALU work among the MFMAs
+                const bool more = step + 1 < 2 * KWT;
+                int piece = 0;                                   // DMA pieces of this step issued so far
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int m = 0; m < MN; ++m) {
+                    if (more) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[step & 1][mt]), __builtin_bit_cast(bf16x8, bv[step & 1][nt]),
-                                                                              acc[mt][nt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                        for (int r = 0; r < NR; ++r)
+                            if ((r < MN ? r : MN - 1) == m) request_one(step + 1, r, av[(step + 1) & 1], bv[(step + 1) & 1]);
+                    }
+                    acc[m / NT][m % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[step & 1][m / NT]),
+                                                                                  __builtin_bit_cast(bf16x8, bv[step & 1][m % NT]), acc[m / NT][m % NT], 0, 0, 0);
+                    if ((step & 1) == 0 && step + 2 < 2 * KWT) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            if ((NR + nt < MN ? NR + nt : MN - 1) == m) b_addr_one((step >> 1) + 1, nt);
+                    }
+#pragma unroll
+                    for (int i = 0; i < NWP; ++i)
+                        if (i * DSTEPS / NWP == step) {
+                            int k = 0;                            // index of piece i among this step's pieces
+#pragma unroll
+                            for (int j = 0; j < i; ++j) k += (j * DSTEPS / NWP == step) ? 1 : 0;
+                            const int at = NR + NT + 1 + 2 * k;
+                            if ((at < MN ? at : MN - 1) == m) issue_piece(wnext, dnext, i);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                (void)piece;
+                if constexpr (p_pref) {
+                    if (step == (2 * KWT > 4 ? 3 : 2 * KWT - 1)) { if (kh == a.KH - 1 && cc + 1 < ncc) load_patch(cc + 1); }
+                }
             }
         } else {
             for (int step = 0; step < 2 * KW; ++step) {
@@ -325,6 +383,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
         }
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the last stage's redundant weight request)
     // the tile's BM bias values go through LDS once (per-store global loads, each behind its own `bias != nullptr` branch and vmcnt(0), were
     // a latency chain of 64 round trips per workgroup)
     __syncthreads();
@@ -397,34 +456,47 @@ int conv_launch_t(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
     return (int)hipGetLastError();
 }
 
+// Register-prefetch depth of the input patch = 16-byte pieces per thread, the smallest instantiated depth that holds it (4: small stride-1
+// tiles, 12: 128-pixel stride-2 tiles, 13 / 17: the 512-pixel tiles of the large stride-1 layers stage 816 / 1056 patch pixels, 20: 256-pixel
+// stride-2 tiles); anything larger, and run-time kernel widths, use the synchronous staging loop (depth 0).
+// (r4, 16 x 512 frames: with 12 the 512-pixel tiles fell onto the synchronous loop -- four dependent rounds of global loads per channel chunk in
+//  front of 50 MFMA-bound steps; upSample2 1090 -> 938 us)
+int bf16_prefetch_depth(int pieces, int KW, int BM, int BN)
+{
+    const int need = (pieces + kConvThreads - 1) / kConvThreads;
+    if (KW != 5 && KW != 3 && KW != 1) return 0;
+    if (need <= 4) return 4;
+    if (KW == 1) return 0;
+    if (need <= 12) return 12;
+    if (KW == 5 && BM == 128 && BN == 512 && need <= 13) return 13;
+    if (KW == 5 && BM == 128 && BN == 512 && need <= 17) return 17;
+    if (KW == 5 && BM == 128 && BN == 256 && need <= 20) return 20;
+    return 0;
+}
+
 template <int WM, int WN, int MT, int NT>
 int conv_launch_kw(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
 {
-    // register-prefetch depth = 16-byte patch pieces per thread, the smallest instantiated depth that holds the patch (4: small stride-1 tiles,
-    // 12: 128-pixel stride-2 tiles, 13 / 17: the 512-pixel tiles of the large stride-1 layers stage 816 / 1056 patch pixels, 20: 256-pixel
-    // stride-2 tiles); anything larger, and run-time kernel widths, use the synchronous staging loop (depth 0)
-    // (r4, 16 x 512 frames: with 12 the 512-pixel tiles fell onto the synchronous loop -- four dependent rounds of global loads per channel chunk in
-    //  front of 50 MFMA-bound steps; upSample2 1090 -> 938 us)
-    const int pieces = a.PH * a.PW * 4;
-    const int need = (pieces + kConvThreads - 1) / kConvThreads;
+    constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+    const int depth = bf16_prefetch_depth(a.PH * a.PW * 4, a.KW, BM, BN);
     if (a.KW == 5) {
-        if (need <= 4) return conv_launch_t<WM, WN, MT, NT, 5, 4>(a, lds, s);
-        if (need <= 12) return conv_launch_t<WM, WN, MT, NT, 5, 12>(a, lds, s);
-        if constexpr (WM == 1 && WN == 4 && MT == 4 && NT == 4) {
-            if (need <= 13) return conv_launch_t<WM, WN, MT, NT, 5, 13>(a, lds, s);
-            if (need <= 17) return conv_launch_t<WM, WN, MT, NT, 5, 17>(a, lds, s);
+        if (depth == 4) return conv_launch_t<WM, WN, MT, NT, 5, 4>(a, lds, s);
+        if (depth == 12) return conv_launch_t<WM, WN, MT, NT, 5, 12>(a, lds, s);
+        if constexpr (BM == 128 && BN == 512) {
+            if (depth == 13) return conv_launch_t<WM, WN, MT, NT, 5, 13>(a, lds, s);
+            if (depth == 17) return conv_launch_t<WM, WN, MT, NT, 5, 17>(a, lds, s);
         }
-        if constexpr (WM == 2 && WN == 2 && MT == 2 && NT == 4) {
-            if (need <= 20) return conv_launch_t<WM, WN, MT, NT, 5, 20>(a, lds, s);
+        if constexpr (BM == 128 && BN == 256) {
+            if (depth == 20) return conv_launch_t<WM, WN, MT, NT, 5, 20>(a, lds, s);
         }
         return conv_launch_t<WM, WN, MT, NT, 5, 0>(a, lds, s);
     }
     if (a.KW == 3) {
-        if (need <= 4) return conv_launch_t<WM, WN, MT, NT, 3, 4>(a, lds, s);
-        if (need <= 12) return conv_launch_t<WM, WN, MT, NT, 3, 12>(a, lds, s);
+        if (depth == 4) return conv_launch_t<WM, WN, MT, NT, 3, 4>(a, lds, s);
+        if (depth == 12) return conv_launch_t<WM, WN, MT, NT, 3, 12>(a, lds, s);
         return conv_launch_t<WM, WN, MT, NT, 3, 0>(a, lds, s);
     }
-    if (a.KW == 1 && need <= 4) return conv_launch_t<WM, WN, MT, NT, 1, 4>(a, lds, s);
+    if (a.KW == 1 && depth == 4) return conv_launch_t<WM, WN, MT, NT, 1, 4>(a, lds, s);
     return conv_launch_t<WM, WN, MT, NT, 0, 0>(a, lds, s);
 }
 
@@ -455,7 +527,7 @@ static int conv_config(const Bf16ConvArgs& a)
         mcvc_bf16_conv_tile(a.OH, a.OW, a.KH, a.KW, a.stride, 256, &th, &twl);
         if (th > 0) {
             const size_t ph = (size_t)(th - 1) * 2 + a.KH, pw = (size_t)((1 << twl) - 1) * 2 + a.KW;
-            if (((ph * pw * 64 + 255) & ~(size_t)255) + 2 * (size_t)128 * a.KW * 64 <= 160 * 1024 && ph * pw * 4 <= 20 * kConvThreads) return 4;
+            if (ph * pw * 4 <= 20 * kConvThreads && (size_t)20 * 4096 + 2 * (size_t)128 * a.KW * 64 <= 160 * 1024) return 4;    // (patch area = 20 prefetch rounds)
         }
     }
     if (a.Cout_pad % 128 != 0 || a.glu == 0) {
@@ -540,7 +612,12 @@ int mcvc_bf16_conv_launch(const Bf16ConvArgs& a0, hipStream_t s)
         }
     }
     if (BM * a.KW * 4 > kMaxWP * kConvThreads) return MCVC_ERR_INVALID;
-    const size_t patch = ((size_t)a.PH * a.PW * 64 + 255) & ~(size_t)255, wb = (size_t)BM * a.KW * 64;
+    // the patch area holds whole prefetch rounds (depth * 256 threads * 16 bytes): every thread stores every piece, no bounds test
+    const int depth = bf16_prefetch_depth(a.PH * a.PW * 4, a.KW, BM, BN);
+    size_t patch = ((size_t)a.PH * a.PW * 64 + 255) & ~(size_t)255;
+    if (patch < (size_t)depth * 4096) patch = (size_t)depth * 4096;
+    const size_t wb = (size_t)BM * a.KW * 64;
+    a.patch_bytes = (int)patch;
     a.wbufs = 2;                    // weight stages alternate between two LDS buffers (DMA of the next one during the MFMAs)
     const size_t lds = patch + a.wbufs * wb;
     if (lds > 160 * 1024) return MCVC_ERR_INVALID;
