@@ -343,7 +343,6 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
             for (int step = 0; step < 2 * KWT; ++step) {
                 landed(av[step & 1], bv[step & 1]);
                 const bool more = step + 1 < 2 * KWT;
-                int piece = 0;                                   // DMA pieces of this step issued so far
 #pragma unroll
                 for (int m = 0; m < MN; ++m) {
                     if (more) {
@@ -369,7 +368,6 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
                         }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                (void)piece;
                 if constexpr (p_pref) {
                     if (step == (2 * KWT > 4 ? 3 : 2 * KWT - 1)) { if (kh == a.KH - 1 && cc + 1 < ncc) load_patch(cc + 1); }
                 }

@@ -24,6 +24,9 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)p; }
 
 __device__ __forceinline__ void glds16(const float* g, float* l)
 {
@@ -94,15 +97,32 @@ __global__ void __launch_bounds__(256) wgemm_kernel(const Twin<WGemmArgs> tw)
         if (newer >= 1) wait_vm<ND>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         if (st + WST - 1 < nst) issue(st + WST - 1, (st + WST - 1) % WST);
+        // Operand reads are inline assembly with an explicit lgkmcnt wait per accumulator group.  As plain C++ loads hipcc cannot tell that the
+        // LDS-DMA just issued (stage st + 2's buffer) does not write what a ds_read_b128 of stage st reads, and put `s_waitcnt vmcnt(0)` in front
+        // of the stage's first read: every stage then waited for the copy issued a few instructions earlier and the three-stage ring never
+        // overlapped anything (found in the ISA in r5; the same had been fixed in igemm_kernel<AROW> and the bf16 convolution).
         const float* sb = smem + (st % WST) * STAGE;
-        float4 av[4];
+        const unsigned sb_addr = lds_addr(sb);
+        unsigned slot[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) av[q] = *reinterpret_cast<const float4*>(sb + a_row + (((4 * half + q) ^ sw) << 2));
+        for (int q = 0; q < 4; ++q) slot[q] = (unsigned)(((4 * half + q) ^ sw) << 4);
+        f32x4 av[4], bvv[2][4];
+        {
+            const unsigned aa = sb_addr + (unsigned)a_row * 4u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("ds_read_b128 %0, %1" : "=&v"(av[q]) : "v"(aa + slot[q]));
+        }
+        auto request_b = [&](int t, f32x4 (&b_)[4]) __attribute__((always_inline)) {
+            const unsigned ba = sb_addr + (unsigned)(b_row + t * SB1) * 4u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("ds_read_b128 %0, %1" : "=&v"(b_[q]) : "v"(ba + slot[q]));
+        };
+        request_b(0, bvv[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(bvv[0][0]), "+v"(bvv[0][1]), "+v"(bvv[0][2]), "+v"(bvv[0][3]));
         const int k_first = (st0 + st) * WGK + 16 * half;          // the first of this lane's 16 pixels
         if (k_first + 16 > NPIX) {                                 // the last stage's tail: pixels that do not exist contribute nothing
-            float* af = reinterpret_cast<float*>(av);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) if (k_first + j >= NPIX) af[j] = 0.f;
+            for (int j = 0; j < 16; ++j) if (k_first + j >= NPIX) av[j >> 2][j & 3] = 0.f;
         }
         // 1-D convolutions over DENSE rows of zw columns (the trunk): the window of tap 0 / tap 2 is shifted by -1 / +1 column and reads the
         // neighbouring row's element at a row's first / last column, where the padding holds a zero -- those x values are dropped here
@@ -118,22 +138,23 @@ __global__ void __launch_bounds__(256) wgemm_kernel(const Twin<WGemmArgs> tw)
         }
 #pragma unroll
         for (int t = 0; t < NACC; ++t) {
-            float4 bv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const float4*>(sb + b_row + t * SB1 + (((4 * half + q) ^ sw) << 2));
+            f32x4 (&bv)[4] = bvv[t & 1];
+            if (t > 0) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+            if (t + 1 < NACC) request_b(t + 1, bvv[(t + 1) & 1]);            // the next group's window, in flight during this group's 16 MFMAs
+            __builtin_amdgcn_sched_barrier(0);
             if (TAPS == 3 && a.zw && (t / NJ) != 1) {
                 const unsigned zm = (t / NJ) == 0 ? zfirst : zlast;
-                float* bf = reinterpret_cast<float*>(bv);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) if ((zm >> j) & 1u) bf[j] = 0.f;
+                for (int j = 0; j < 16; ++j) if ((zm >> j) & 1u) bv[j >> 2][j & 3] = 0.f;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[q].x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bv[q].y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bv[q].z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[q].w, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][0], bv[q][0], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][1], bv[q][1], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][2], bv[q][2], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][3], bv[q][3], acc[t], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // ---- epilogue: the TAPS values of a filter (co, ci) are consecutive floats of the OIHW gradient
