@@ -337,12 +337,16 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
     reducer.time_waits = world > 1         # exposed (un-hidden) gradient-exchange time: an event pair around every wait for the communication stream
     t0 = time.perf_counter()
     sync_losses = bool(getattr(args, "sync_losses", False))
+    host_enq = host_wait = 0.0             # host seconds inside step() (enqueueing ~300 launches) and inside the loss readback (waiting for the GPU)
     for i in range(steps):
+        h0 = time.perf_counter()
         engine.step(*batches[(warmup + i) % len(batches)])
+        h1 = time.perf_counter()
         # the reference reads both losses every iteration (train.py:303).  So do we; with the pipelined step they are the losses of the
         # last COMPLETE iteration (the previous one: its discriminator phase runs beside this iteration's generator phase).
         # --sync-losses: the reference-exact readback -- THIS iteration's pair, which completes the iteration first
         engine.losses(lagged=not sync_losses)
+        host_enq += h1 - h0; host_wait += time.perf_counter() - h1
     engine.flush()                         # ... and the last one to the timed region: exactly K complete iterations
     if world > 1:
         dist.barrier()
@@ -369,6 +373,8 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
             for i, (k, ms, fl, by) in enumerate(raw):
                 fh.write("%4d %-24s %9.4f ms %10.4f GF %9.3f MB %8.2f TF/s %8.1f GB/s\n" % (
                     i, k, ms, fl / 1e9, by / 1e6, fl / 1e9 / max(ms, 1e-6), by / 1e6 / max(ms, 1e-6)))
+    host = {"enqueue_ms_per_step": 1e3 * host_enq / steps, "loss_wait_ms_per_step": 1e3 * host_wait / steps,
+            "note": "host wall time inside engine.step() / inside the loss readback; the step is GPU-bound while enqueue << ms_per_step"}
     schedule = {"grouped_launches": bool(engine._use_grouped()), "pipelined": bool(engine._use_pipeline()), "merged_forwards": bool(engine._use_merged()),
                 "queue_probe": getattr(engine, "queue_probe", None),
                 "loss_readback": ("both losses of the CURRENT iteration every step (reference-exact, train.py:302-304): the pipelined overlap of "
@@ -400,7 +406,7 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
         "mel_frames_per_s": sample_iters * T,
         "step_mfma_fraction": sample_iters * ALG_GFLOP_PER_SAMPLE_ITER / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world),
         "exposed_comm_ms_per_step": (exposed_ms / steps) if world > 1 else 0.0, "comm_waits_per_step": n_waits / steps,
-        "losses_finite": finite, "last_losses": final, "schedule": schedule, "n_batches": len(batches), "deterministic": bool(args.deterministic),
+        "losses_finite": finite, "last_losses": final, "schedule": schedule, "host": host, "n_batches": len(batches), "deterministic": bool(args.deterministic),
         "identity_loss_lambda": float(sched.identity_loss_lambda),
     }
     if config_id:

@@ -536,8 +536,13 @@ static int conv_config(const Bf16ConvArgs& a)
     return 0;
 }
 
+// the staged patch of a 128-channel tile must leave room for the two weight stages: a stride-2 256-pixel tile has 80 KB = 1280 patch pixels
+// (the 4 x 64 shape, fewest tiles on a 20 x 128 grid, needs 1441: the chooser then takes 8 x 32 -- three row tiles for 20 rows, still faster)
+static long long bf16_patch_limit(int KW, int stride, int bn) { return (stride == 2 && bn == 256) ? (160 * 1024 - 2 * 128 * KW * 64) / 64 : 96 * 1024 / 64; }
+
 void mcvc_bf16_conv_tile(int OH, int OW, int KH, int KW, int stride, int bn, int* TH, int* tw_log2)
 {
+    const long long limit = bf16_patch_limit(KW, stride, bn);
     // candidates TH x TW = bn pixels; fewest tiles (least overhang) first, then the smallest staged input patch
     long long best_cost = -1;
     int lmax = 0;
@@ -546,7 +551,7 @@ void mcvc_bf16_conv_tile(int OH, int OW, int KH, int KW, int stride, int bn, int
         const int tw = 1 << l, th = bn >> l;
         const long long tiles = (long long)cdiv_i(OH, th) * cdiv_i(OW, tw);
         const long long patch = (long long)((th - 1) * stride + KH) * ((tw - 1) * stride + KW);
-        if (patch * 64 > 96 * 1024) continue;
+        if (patch > limit) continue;
         const long long cost = tiles * 4096 + patch;
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; *tw_log2 = l; *TH = th; }
     }
@@ -691,7 +696,9 @@ __global__ void __launch_bounds__(256) bf16_stats_kernel(const Bf16NormArgs a)
     }
 }
 
-// stats[n][cn] = (mean, rstd) from the S partials and the shift (re-read from the first pixel)
+// stats[n][cn] = (scale, shift) of z = x * scale + shift = gamma * (x - mean) * rstd + beta, from the S partials and the sums' shift
+// (re-read from the first pixel).  The affine parameters are folded in HERE, once per (image, channel): the apply pass used to fetch
+// gamma / beta / mean / rstd per thread -- 64 scalar loads in front of ~5 pixels of work per thread on the gated layers.
 __global__ void __launch_bounds__(256) bf16_finalize_kernel(const Bf16NormArgs a)
 {
     const int Cn = a.shuffle ? a.Cx / 4 : a.Cx;
@@ -708,8 +715,13 @@ __global__ void __launch_bounds__(256) bf16_finalize_kernel(const Bf16NormArgs a
     const float m = s1 / cnt;
     float var = s2 / cnt - m * m;
     if (var < 0.f) var = 0.f;
-    a.stats[i * 2] = shift + m;
-    a.stats[i * 2 + 1] = 1.0f / sqrtf(var + a.eps);
+    const float mean = shift + m, rstd = 1.0f / sqrtf(var + a.eps);
+    // channel -> affine parameter: gated layers carry [C value | C gate] channels with their own InstanceNorms (gamma[0] / gamma[1])
+    const int Cv = (a.act == BF16_ACT_GLU && !a.shuffle) ? Cn / 2 : Cn;
+    const float g = cn < Cv ? a.gamma[0][cn] : a.gamma[1][cn - Cv], b = cn < Cv ? a.beta[0][cn] : a.beta[1][cn - Cv];
+    const float sc = rstd * g;
+    a.stats[i * 2] = sc;
+    a.stats[i * 2 + 1] = b - mean * sc;
 }
 
 // one thread = 8 OUTPUT channels (16-byte store) of a run of pixels: the launcher makes the grid stride a multiple of the octet count,
@@ -730,15 +742,15 @@ __global__ void __launch_bounds__(256) bf16_apply_kernel(const Bf16NormArgs a)
     const int Cs = (a.act == BF16_ACT_GLU) ? 2 * C : C;                                    // channels of the statistics table
     float sc0[8], sh0[8], sc1[8], sh1[8];                                                  // z = x * sc + sh
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float g0 = a.has_norm ? a.gamma[0][c0 + j] : 1.f, b0 = a.has_norm ? a.beta[0][c0 + j] : 0.f;
-        const float g1 = (a.has_norm && a.act == BF16_ACT_GLU) ? a.gamma[1][c0 + j] : 1.f;
-        const float b1 = (a.has_norm && a.act == BF16_ACT_GLU) ? a.beta[1][c0 + j] : 0.f;
-        sc0[j] = g0; sh0[j] = b0; sc1[j] = g1; sh1[j] = b1;
-        if (a.has_norm) {
-            const float* st = a.stats + ((long long)n * Cs + c0 + j) * 2;
-            sc0[j] = st[1] * g0; sh0[j] = b0 - st[0] * sc0[j];
-            if (a.act == BF16_ACT_GLU) { const float* sg = st + 2 * C; sc1[j] = sg[1] * g1; sh1[j] = b1 - sg[0] * sc1[j]; }
+    for (int j = 0; j < 8; ++j) { sc0[j] = 1.f; sh0[j] = 0.f; sc1[j] = 1.f; sh1[j] = 0.f; }
+    if (a.has_norm) {        // (scale, shift) pairs of 8 consecutive channels = 64 contiguous bytes of the finalize pass's table (c0 % 8 == 0: 16-byte aligned)
+        const float4* st = reinterpret_cast<const float4*>(a.stats + ((long long)n * Cs + c0) * 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 v = st[q]; sc0[2 * q] = v.x; sh0[2 * q] = v.y; sc0[2 * q + 1] = v.z; sh0[2 * q + 1] = v.w; }
+        if (a.act == BF16_ACT_GLU) {
+            const float4* sg = reinterpret_cast<const float4*>(a.stats + ((long long)n * Cs + C + c0) * 2);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float4 v = sg[q]; sc1[2 * q] = v.x; sh1[2 * q] = v.y; sc1[2 * q + 1] = v.z; sh1[2 * q + 1] = v.w; }
         }
     }
     for (int p = idx / noct; p < P; p += pstep) {
