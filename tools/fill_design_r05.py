@@ -76,4 +76,27 @@ path = os.path.join(ROOT, "DESIGN.md")
 s = open(path).read()
 i, j = s.index("<!-- r05-numbers-begin -->\n") + len("<!-- r05-numbers-begin -->\n"), s.index("<!-- r05-numbers-end -->")
 open(path, "w").write(s[:i] + block + s[j:])
+# README: the round-5 table between its markers
+readme = os.path.join(ROOT, "README.md")
+r = open(readme).read()
+table = (
+    "<!-- r05-readme-begin -->\n"
+    "| config (BASELINE.json) | default run / own process | roofline | note |\n|---|---|---|---|\n"
+    "| C1 bs=1 full G+D iteration | **%.2f ms (%.1f it/s)** / %.2f; %d launches | step = %.2f of its convolution-FLOP floor at the fp32 MFMA peak (`conv_roofline_ms` %.2f); dominant family (%s) %.2f; HBM %s GB by the counters / %s by the launchers vs %s algorithmic | after the identity cut-off **%.2f ms (%.1f it/s)**; with the reference-exact loss readback %.2f ms; round 4 driver run 6.08; %.0fx the CPU oracle on the same box (32 threads) |\n"
+    "| C2 bs=32 | **%.1f ms** / %.1f | %.2f of the conv floor; dominant family %.2f of the nominal peak, MFMA pipes 0.8 busy at the sustained clock | round 4 driver run 77.6 |\n"
+    "| C3 per-GPU shape bs=8 | **%.1f ms** / %.1f | %.2f of the conv floor; dominant family %.2f (contains the small trunk products) | round 4 driver run 22.5 |\n"
+    "| C4 generator inference bs=16 x 512 frames | bf16 **%.2f ms** (%.2f M mel-frames/s) / %.2f | bf16 convs %.2f of the dense peak at 2.4 GHz (the chip sustains 1.83-1.90 GHz under them) | round 4 driver run 3.72; bf16 vs fp32 oracle %.2e rel-L2 |\n"
+    "<!-- r05-readme-end -->" % (
+        d["ms_per_step"], d["value"], own[1]["ms_per_step"], d["kernel_launches_per_step"], d["frac_of_conv_roofline"], d["conv_roofline_ms"], d["roofline"]["kernel"],
+        d["roofline"]["frac"], gb(own[1].get("hbm_bytes_per_step_pmc")), gb(own[1].get("hbm_bytes_per_step_launcher")), gb(own[1].get("algorithmic_bytes_per_step")),
+        post.get("ms_per_step", 0.0), post.get("iters_per_s", 0.0), sc.get("sync_losses_ms_per_step", 0.0), d.get("speedup_vs_cpu", 0.0),
+        c2["ms_per_step"], own[32]["ms_per_step"], c2["frac_of_conv_roofline"], c2["roofline"]["frac"],
+        c3["ms_per_step"], own[8]["ms_per_step"], c3["frac_of_conv_roofline"], c3["roofline"]["frac"],
+        c4["ms_per_step"], c4["value"] / 1e6, inf["ms_per_step"], c4["roofline"]["frac"], inf.get("parity_vs_cpu_rel_l2") or 0.0))
+if "@@R05TABLE@@" in r:
+    r = r.replace("@@R05TABLE@@", table)
+else:
+    i, j = r.index("<!-- r05-readme-begin -->"), r.index("<!-- r05-readme-end -->") + len("<!-- r05-readme-end -->")
+    r = r[:i] + table + r[j:]
+open(readme, "w").write(r)
 print("filled from", pre)
