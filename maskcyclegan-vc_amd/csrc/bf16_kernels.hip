@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
     for (int nt = 0; nt < NT; ++nt) {
         const int n = (wn * NT + nt) * 32 + l31;
         const int pr = n >> a.tw_log2, pc = n & (TW - 1);
-        ppB[nt] = pr * a.stride * a.PW + pc;          // (stride 2: de-interleaved columns -> lane stride 1)
+        ppB[nt] = pr * a.stride * a.PW + (s2 ? pc : pc * a.stride);          // (stride 2: de-interleaved columns -> lane stride 1)
     }
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -1040,7 +1040,8 @@ __global__ void __launch_bounds__(256) bf16_pack_kernel(const Bf16PackArgs a)
                     const int skw = k / a.Cin_src, ci = k - skw * a.Cin_src;
                     if (skw < a.KW_src) v = a.w[br][(((long long)co * a.Cin_src + ci) * a.KH + kh) * a.KW_src + skw];
                 } else if (a.kind == BF16_PACK_HC_IN) {
-                    if (k < a.Cin_src) { const int ci = (k & 255) * 20 + (k >> 8); v = a.w[br][(long long)co * a.Cin_src + ci]; }
+                    const int kf = kw * a.Cin + k;               // (packed KW > 1: the 1 x 1 layer's channels in KW groups of Cin, see infer_bf16.hip)
+                    if (kf < a.Cin_src) { const int ci = (kf & 255) * 20 + (kf >> 8); v = a.w[br][(long long)co * a.Cin_src + ci]; }
                 } else {
                     if (k < a.Cin_src) v = a.w[br][(((long long)co * a.Cin_src + k) * a.KH + kh) * a.KW_src + kw];
                 }

@@ -7,7 +7,8 @@
 //     (xin[b][h][w][kw*2+ci]), so the layer is a 5x1 convolution over 32 channels -- no 16x zero padding of Cin = 2 -- and its gated GLU
 //     (model.py:242, no norm in between) is fused into the conv epilogue through an interleaved [32 value | 32 gate] row order.
 //   * the reference's view(B, 5120, 1, T/4) (model.py:249-251, channel = c*20 + h) is a permutation of the conv2dto1d weight's input
-//     channels (h*256 + c) plus an output stride choice of the InstanceNorm kernel in front of it; view(B, 256, 20, T/4) (:270-271) is
+//     channels (h*256 + c) plus an output stride choice of the InstanceNorm kernel in front of it (the 1 x 1 layer itself runs as a
+//     1 x 5 stride-5 convolution over 1024-channel "pixels": fewer, fatter pipeline stages); view(B, 256, 20, T/4) (:270-271) is
 //     the mirrored permutation of conv1dto2d's output rows.
 //   * the last conv (128 -> 1, 5x15) would use 1 of 32 MFMA rows: its 15 kernel columns become 15 output channels of a 5x1 conv and a
 //     small kernel adds the 15 shifted planes.
@@ -51,7 +52,7 @@ static NetB build_net()
     n.conv1 = mkl(BF16_PACK_FOLD_KW, 0, 1, 2, 3, 128, 2, 5, 15, 32, 1, 256, 1, 2, 0, 1);                  // model.py:116-126, 241-242
     n.ds1 = mkl(BF16_PACK_PLAIN, 4, 5, 8, 9, 256, 128, 5, 5, 128, 5, 512, 2, 2, 2);                       // :129-133
     n.ds2 = mkl(BF16_PACK_PLAIN, 12, 13, 16, 17, 256, 256, 5, 5, 256, 5, 512, 2, 2, 2);                   // :135-139
-    n.c2d1d = mkl(BF16_PACK_HC_IN, 20, 21, -1, -1, 256, 5120, 1, 1, 5120, 1, 256, 1, 0, 0);               // :142-146
+    n.c2d1d = mkl(BF16_PACK_HC_IN, 20, 21, -1, -1, 256, 5120, 1, 1, 1024, 5, 256, 5, 0, 0);               // :142-146 (as a 1 x 5 stride-5 conv over 1024 channels, see forward())
     for (int i = 0; i < 6; ++i) {                                                                          // :151-180
         const int b = 24 + 12 * i;
         n.res_vg[i] = mkl(BF16_PACK_PLAIN, b + 0, b + 1, b + 4, b + 5, 512, 256, 1, 3, 256, 3, 1024, 1, 0, 1);
@@ -169,8 +170,10 @@ static void forward(Run& r, const float* x, const float* mask, float* out, const
     conv(r, n.ds2, B16(w.y2), 40LL * W2 * 256, W2 * 256, 256, B, 40, W2, B16(w.c3), 20LL * W4 * 512, W4 * 512, 512, 512);
     norm(r, B16(w.c3), 20LL * W4 * 512, W4 * 512, 512, B, 20, W4, 512, 0, BF16_ACT_GLU, P[14], P[15], P[18], P[19], nullptr,
          B16(w.y3), (long long)W4 * 5120, 256, 5120);
-    // :254-255 1x1 5120 -> 256 + IN
-    conv(r, n.c2d1d, B16(w.y3), (long long)W4 * 5120, 0, 5120, B, 1, W4, B16(w.c4), (long long)W4 * 256, 0, 256, 256);
+    // :254-255 1x1 5120 -> 256 + IN.  K = 5120 in 32-channel stages of two MFMA steps each is 160 barrier-bound stages per workgroup; the
+    // same bytes read as [b][5 * W4 "pixels"][1024 channels] make it a 1 x 5 convolution with stride 5 (non-overlapping windows): 32 stages
+    // of ten steps, the weight pack groups the channels accordingly (r5: 122 -> see DESIGN 8b)
+    conv(r, n.c2d1d, B16(w.y3), (long long)W4 * 5120, 0, 1024, B, 1, 5 * W4, B16(w.c4), (long long)W4 * 256, 0, 256, 256);
     norm(r, B16(w.c4), (long long)W4 * 256, 0, 256, B, 1, W4, 256, 0, BF16_ACT_NONE, P[22], P[23], nullptr, nullptr, nullptr,
          B16(w.h[0]), (long long)W4 * 256, 0, 256);
     // :258-263 residual blocks
