@@ -22,6 +22,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "maskcyclegan-vc_amd"))
+# multi-process GPU work on this image needs dmabuf IPC (RCCL / cross-process tensors fail with hipIpcGetMemHandle otherwise); exported on
+# the boxes already -- set here, before the HIP runtime starts, in case a launcher's environment dropped it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

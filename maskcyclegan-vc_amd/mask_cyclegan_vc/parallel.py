@@ -22,6 +22,10 @@ import os
 import torch
 import torch.distributed as dist
 
+# dmabuf IPC for multi-process GPU work on this image (RCCL fails in hipIpcGetMemHandle without it); read when the HSA runtime starts,
+# i.e. at the first device call -- set on import in case the launcher's environment dropped it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
