@@ -288,6 +288,8 @@ def parse_args():
     ap.add_argument("--no-extra-configs", action="store_true", help="default single-GPU run: skip the nested records of BASELINE configs[2..4]")
     ap.add_argument("--sync-losses", action="store_true", help="read the CURRENT iteration's g_loss and d_loss on the host every step, as the "
                     "reference's .item() calls do (train.py:302-304): completes the iteration before the next one is issued (no pipelining)")
+    ap.add_argument("--loss-lag", type=int, default=2, help="the per-step loss readback returns the iteration issued this many step()s earlier "
+                    "(2 = the training loop's LOSS_LAG: never waits for work in flight; 1 = rounds 3-4: waits for the discriminator phase just queued)")
     ap.add_argument("--allow-degraded", action="store_true", help="--gpus N: do not fail when the ranks did not all take part in the collective or the "
                     "persistent trunk kernels fell back to per-layer launches (single-GPU choreography tests over gloo)")
     ap.add_argument("--serial", action="store_true", help="one stream: no lanes, no auxiliary weight-gradient stream (A/B comparison, per-kernel profiling)")
@@ -340,15 +342,18 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
     reducer.time_waits = world > 1         # exposed (un-hidden) gradient-exchange time: an event pair around every wait for the communication stream
     t0 = time.perf_counter()
     sync_losses = bool(getattr(args, "sync_losses", False))
+    loss_lag = max(1, int(getattr(args, "loss_lag", 2)))
     host_enq = host_wait = 0.0             # host seconds inside step() (enqueueing ~300 launches) and inside the loss readback (waiting for the GPU)
     for i in range(steps):
         h0 = time.perf_counter()
         engine.step(*batches[(warmup + i) % len(batches)])
         h1 = time.perf_counter()
-        # the reference reads both losses every iteration (train.py:303).  So do we; with the pipelined step they are the losses of the
-        # last COMPLETE iteration (the previous one: its discriminator phase runs beside this iteration's generator phase).
+        # the reference reads both losses every iteration (train.py:303).  So do we -- the losses of a COMPLETE iteration, two step()s
+        # behind, exactly as mask_cyclegan_vc/train.py's loop does (LOSS_LAG): the newest complete iteration's discriminator phase was
+        # queued by THIS step() (it runs beside this iteration's generator phase), so waiting for it drains the GPU before the host
+        # issues the next iteration (r4 / early r5: +0.3 ms per bs=1 step of idle GPU); the one before it was published a step() ago.
         # --sync-losses: the reference-exact readback -- THIS iteration's pair, which completes the iteration first
-        engine.losses(lagged=not sync_losses)
+        engine.losses(lagged=0 if sync_losses else loss_lag)
         host_enq += h1 - h0; host_wait += time.perf_counter() - h1
     engine.flush()                         # ... and the last one to the timed region: exactly K complete iterations
     if world > 1:
@@ -382,7 +387,9 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
                 "queue_probe": getattr(engine, "queue_probe", None),
                 "loss_readback": ("both losses of the CURRENT iteration every step (reference-exact, train.py:302-304): the pipelined overlap of "
                                   "iteration t's discriminator phase with iteration t+1's generator phase is given up") if sync_losses else
-                                 "both losses every iteration; with the pipelined step those of the last complete iteration (one step behind)",
+                                 ("both losses every iteration, those of the iteration issued two step()s earlier (complete; the read never waits "
+                                  "for work in flight) -- the same readback as the training loop's (train.py LOSS_LAG)" if loss_lag >= 2 else
+                                  "both losses every iteration, those of the last complete iteration (one step() behind: waits for the discriminator phase just queued)"),
                 "trunk_persistent": engine.L.mcvc_gen_trunk_persistent(B, T) if engine._use_grouped() else None,
                 "trunk_fallback": bool(engine.trunk_fallback)}
     # what the persistent trunk kernels would do with ONE pass in flight: tells "this shape has no persistent kernel" from "the residency

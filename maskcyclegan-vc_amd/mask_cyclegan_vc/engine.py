@@ -166,9 +166,9 @@ class TrainEngine:
         self.trunk_fallback = False            # a persistent trunk launch faulted in this process: per-layer launches from then on (check_faults)
         self._pending_D = None                  # (input set, discriminator lr) of the iteration whose discriminator phase is still to run
         self.slots_done = torch.zeros(2 * _BLOCK, device=dev)          # loss slots of the last COMPLETE iteration
-        self._done_host = torch.zeros(2 * _BLOCK).pin_memory()
-        self._done_event = torch.cuda.Event()
-        self._done_valid = False
+        self._done_ring = [(torch.zeros(2 * _BLOCK).pin_memory(), torch.cuda.Event()) for _ in range(4)]    # published loss slots (host) + events
+        self._done_count = 0                    # iterations published so far ...
+        self._done_base = 0                     # ... of which before the last synchronous read (losses() without a lag)
         self.split_d_min_batch = 4
         self._timeline = None
         # data parallel (plain schedules): start the discriminator gradient all-reduce at the end of an iteration and finish the update
@@ -907,13 +907,10 @@ class TrainEngine:
             [ identity: real_other(t+1) | ones ;  translation: real(t+1) | mask(t+1) ;  D-phase translation: real(t) | mask(t) ]
         and the cycle pass TWO: [ fake(t+1) ; generated(t) ] (contiguous rows of the first pass's output).  The backward passes run over the
         first two / the first sample of those stashes (mcvc_gen_backward_window).  Per-sample results are what the separate passes compute
-        (every op of the generator is per sample): parity tests in tests/test_hip_twin.py.  Two of the six grouped generator passes of an
-        iteration disappear; one persistent trunk pass is in flight at a time instead of two.
-            lane 0:  forward x3 -> cycle x2 -> ("d1", "d2") backward cycle -> backward translation + identity -> conv1's update
-            lane 1:  ("g") D_A | D_B of D-phase(t) -> update of their slice -> first-step adversarial pair of G-phase(t+1)   "d1";
-                     then the ranged generator update
-            lane 2:  ("c") D_A2 | D_B2 of D-phase(t) -> update -> second-step adversarial pair                             "d2"
-            lane 3:  the backward passes' weight gradients"""
+        (every op of the generator is per sample): tests/test_hip_twin.py.  Two of six grouped generator passes disappear; one persistent trunk pass in flight, not two.
+            lane 0: forward x3 -> cycle x2 -> backward cycle -> backward translation + identity -> conv1's update;  lanes 1 / 2: D_A | D_B
+            (D_A2 | D_B2) of D-phase(t) -> their update -> first- (second-) step adversarial pair of G-phase(t+1), lane 1 then the ranged
+            generator update;  lane 3: the backward passes' weight gradients"""
         cur = self.static_in
         prev, d_lr = self._pending_D if self._pending_D is not None else (None, None)
         B, B2, B3 = self.B, 2 * self.B, 3 * self.B
@@ -1017,9 +1014,10 @@ class TrainEngine:
 
     def _publish_done(self):
         """Losses of the last COMPLETE iteration to pinned host memory (asynchronous copy + event; ``losses(lagged=True)`` waits for it)."""
-        self._done_host.copy_(self.slots_done, non_blocking=True)
-        self._done_event.record()
-        self._done_valid = True
+        host, ev = self._done_ring[self._done_count % 4]
+        host.copy_(self.slots_done, non_blocking=True)
+        ev.record()
+        self._done_count += 1
 
     def generator_update(self):
         """All-reduce (data parallel) + optimizer step of both generators (train.py:242) behind a generator phase that ran without its own."""
@@ -1260,21 +1258,24 @@ class TrainEngine:
     def losses(self, lagged=False):
         """Host read of the loss slots, like the reference's ``.item()`` calls (train.py:303).  Default: the losses of the iteration
         just issued -- a pending pipelined discriminator phase is completed first, so calling this every iteration runs the two phases
-        back to back.  ``lagged=True`` (the pipelined training loop, bench.py): the losses of the last COMPLETE iteration -- after
-        ``step()`` number t+1 that is iteration t (None before there is one) -- waiting only for the small asynchronous copy that
-        published them, never for work still in flight."""
+        back to back.  ``lagged=n`` (True = 1; the pipelined training loop and bench.py use 2): the n-th newest COMPLETE iteration -- after
+        ``step()`` number t+1 that is iteration t+1-n (None before there is one) -- waiting only for the asynchronous copy that published
+        it.  n = 1 still waits for the discriminator phase queued by the last ``step()``, i.e. for the GPU to drain; n = 2 never waits."""
         if lagged:
+            k = self._done_count - max(1, int(lagged))
             if self._pending_D is None:
                 lagged = False                   # nothing in flight: the latest iteration is complete
-            elif not self._done_valid:
+            elif k < self._done_base:
                 return None
             else:
-                self._done_event.synchronize()
-                v = self._done_host.tolist()
+                host, ev = self._done_ring[k % 4]
+                ev.synchronize()
+                v = host.tolist()
                 return {"g_loss": v[SLOT_G], "d_loss": v[SLOT_D], "cycle_loss": v[SLOT_CYCLE], "identity_loss": v[SLOT_IDENT],
                         "adv_loss": v[SLOT_ADV_G]}
         if self._pending_D is not None:
             self.flush()
+        self._done_base = self._done_count      # (what was published so far is older than what this read returns)
         v = self.slots.tolist()      # device sync, like the reference's .item()
         return {"g_loss": v[SLOT_G], "d_loss": v[SLOT_D], "cycle_loss": v[SLOT_CYCLE], "identity_loss": v[SLOT_IDENT],
                 "adv_loss": v[SLOT_ADV_G]}

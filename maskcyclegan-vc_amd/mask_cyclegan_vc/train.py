@@ -30,6 +30,7 @@ from .schedule import StepSchedule
 from .utils import denormalize_mel
 
 NET_NAMES = G_NAMES + D_NAMES          # construction order of the reference (train.py:103-110)
+LOSS_LAG = 2                           # the per-iteration loss readback (reference train.py:302-304) returns the iteration issued two step()s ago
 
 
 def load_speaker(preprocessed_dir, speaker_id):
@@ -170,8 +171,8 @@ class MaskCycleGANVCTraining(object):
 
             def log_one(lo):
                 # A persistent trunk launch that gave up waiting poisons its pass with NaN (csrc/trunk.h): that reaches every loss term of
-                # the iteration, so the (already host-resident) losses are the per-iteration fault probe.  The losses are one step() behind
-                # (iteration t is checked after t + 1 has been issued), so the poisoned update may already be in the weights: what the
+                # the iteration, so the (already host-resident) losses are the per-iteration fault probe.  The losses are LOSS_LAG step()s
+                # behind (iteration t is checked after t + 2 has been issued), so the poisoned update may already be in the weights: what the
                 # abort guarantees is that no CHECKPOINT is written from them.  Data parallel: the losses are rank-local -- only the
                 # poisoned rank sees the NaN at once, the others one iteration later through the all-reduced gradients -- so the verdict is
                 # taken collectively (one integer over the gloo control group: no device work, no stream sync) and every rank leaves the
@@ -194,14 +195,20 @@ class MaskCycleGANVCTraining(object):
                 self.logger.start_iter()
                 run_step()                                                 # G phase, (previous) D phase, lr / lambda bookkeeping
                 owed += 1
-                lo = self.engine.losses(lagged=True)                       # host read of the last COMPLETE iteration
-                in_flight = 1 if self.engine._pending_D is not None else 0   # pipelined: this iteration's discriminator phase is still to run
+                # Host read of a COMPLETE iteration: the LOSS_LAG-th newest.  Reading the newest (lag 1) waits for the discriminator phase this
+                # step() has just queued -- the host then issues the next iteration into a drained GPU (0.3 - 0.5 ms of a 6 ms step at bs=1,
+                # DESIGN section 5); with lag 2 the copy being waited for was published one step() earlier and the host stays ahead.
+                lo = self.engine.losses(lagged=LOSS_LAG)
+                in_flight = LOSS_LAG if self.engine._pending_D is not None else 0   # pipelined: iterations issued whose losses are not readable yet
                 if lo is not None and owed > in_flight:
                     log_one(lo)
                     owed -= 1
                 done += 1
                 if self.args.max_iters and done >= self.args.max_iters:
                     break
+            while owed > 1:                                                # the epoch's tail: iterations published but not read yet, oldest first
+                log_one(self.engine.losses(lagged=owed - 1))
+                owed -= 1
             if owed:
                 log_one(self.engine.losses())                              # completes the epoch's last iteration (flush) and reads it
                 owed -= 1

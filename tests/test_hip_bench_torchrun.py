@@ -70,7 +70,7 @@ def test_default_single_gpu_bench_carries_every_baseline_config():
     # the two byte counts are named for what they are, and the reference-exact loss readback is priced in the same run
     assert res["hbm_bytes_per_step_launcher"] > 0 and "hbm_bytes_per_step_pmc" in res and "hbm_bytes_per_step" not in res
     sc = res["schedule"]
-    assert sc["sync_losses_ms_per_step"] > 0 and -0.2 < sc["sync_losses_cost"] < 1.0 and "one step behind" in sc["loss_readback"]
+    assert sc["sync_losses_ms_per_step"] > 0 and -0.2 < sc["sync_losses_cost"] < 1.0 and "two step()s earlier" in sc["loss_readback"]
     # ... and so is the regime after the identity cut-off (train.py:314-315), labelled, beside the headline (which stays the dearer regime)
     post = res["after_identity_cutoff"]
     assert post["identity_loss_lambda"] == 0 and 0 < post["ms_per_step"] < 1.1 * res["ms_per_step"] and res["identity_loss_lambda"] == 5

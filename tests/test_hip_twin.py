@@ -104,6 +104,29 @@ def test_pipelined_steps_equal_back_to_back_phases(deterministic_mode, B):
             assert torch.equal(a, b), (n, i)
 
 
+def test_loss_readback_two_steps_behind_returns_the_same_losses_without_waiting(deterministic_mode):
+    """``losses(lagged=2)`` -- what the training loop and bench.py read -- is the iteration issued two step()s earlier: the values
+    ``lagged=True`` returned one step() before, None until there is one, and after a synchronous read (``losses()``) the ring starts
+    over."""
+    B = 1
+    eng = TrainEngine(_nets(640), B, 64, schedule=StepSchedule(batch_size=B, n_samples=4 * B, num_epochs=3))
+    newest, two_behind = [], []
+    for it in range(5):
+        eng.step(*_batch(B, 90 + it))
+        lo2 = eng.losses(lagged=2)                 # first: must not depend on the lag-1 read having waited
+        lo1 = eng.losses(lagged=True)
+        assert (lo1 is None) == (it == 0) and (lo2 is None) == (it <= 1)
+        newest.append(lo1)
+        two_behind.append(lo2)
+    assert two_behind[2:] == newest[1:4]
+    last = eng.losses()                            # flush: completes iteration 4
+    assert eng._pending_D is None and np.isfinite(last["g_loss"]) and last != newest[4]
+    eng.step(*_batch(B, 99))
+    assert eng.losses(lagged=True) is None and eng.losses(lagged=2) is None
+    eng.flush()
+    eng.check_faults()
+
+
 def test_merged_forwards_equal_the_separate_passes(deterministic_mode):
     """The default bs=1 step batches iteration t's discriminator-phase generator forwards INTO iteration t+1's generator-phase passes
     (engine._merged_step: three / two samples per pass, backward over the first two / one).  Every op of the generator is per sample, so all

@@ -230,7 +230,7 @@ def test_reference_arithmetic_spread_after_four_adam_steps(golden_dir):
     """How far the REFERENCE's own arithmetic is from itself after the four iterations of the ``cutoff`` fixture when only the summation
     order changes (3 threads and the full autograd graph against the fixture's 8 threads): Adam's first steps move an element by
     ~lr * sign(g) whatever |g| is, so rounding-level gradients turn into +-lr parameter differences.  This spread -- not 1e-3 -- is what
-    bounds per-tensor parity of ANY implementation after several optimizer steps; tests/test_hip_engine.py gates the HIP engine at 1.5 x
+    bounds per-tensor parity of ANY implementation after several optimizer steps; tests/test_hip_engine.py gates the HIP engine at 2 x
     the upper bound asserted here, and at 1e-3 on everything that is well-posed (losses, norms, single-iteration gradients)."""
     js, bt = _load_step(golden_dir, "cutoff")
     was = torch.get_num_threads()
@@ -256,7 +256,7 @@ def test_reference_arithmetic_spread_after_four_adam_steps(golden_dir):
             errs.append(rel_l2(flat[torch.from_numpy(orc.sample_index(flat.numel()))].numpy(), ref))
     errs = np.asarray(errs)
     print("reference self-spread after 4 steps: worst %.2e, %d of %d sampled tensors beyond 1e-3" % (errs.max(), int((errs > 1e-3).sum()), errs.size))
-    assert errs.max() < 5e-3 / 1.5                 # the bound the GPU test scales
+    assert errs.max() < 7e-3 / 2                   # the bound the GPU test scales
     assert errs.max() > 1e-3                       # ... and the reason a 1e-3 per-tensor gate after several steps is not a property of the path
 
 

@@ -44,3 +44,22 @@ for t, kind, i in ev2:
 print("exclusive (un-overlapped) time by kernel:")
 for k, v in sorted(excl.items(), key=lambda kv: -kv[1])[:14]:
     print("  %-62s %7.2f ms (%.1f%%)" % (k, v / 1e6, 100 * v / tot))
+# idle gaps (no kernel in flight): total by (kernel that ended before, kernel that started after), and the gap-length histogram
+gaps = {}
+gh = {"<2us": 0, "2-5us": 0, "5-10us": 0, "10-20us": 0, ">20us": 0}
+ends = sorted(rows, key=lambda r: r[1])
+cur_end, prev_name = ends[0][2], ends[0][0]
+for n, s, e in ends[1:]:
+    if s > cur_end:
+        g = s - cur_end
+        key = (short(prev_name), short(n))
+        gaps[key] = gaps.get(key, (0, 0))
+        gaps[key] = (gaps[key][0] + g, gaps[key][1] + 1)
+        b = "<2us" if g < 2000 else "2-5us" if g < 5000 else "5-10us" if g < 10000 else "10-20us" if g < 20000 else ">20us"
+        gh[b] += g
+    if e > cur_end:
+        cur_end, prev_name = e, n
+print("idle time by gap length: " + ", ".join("%s %.2f ms" % (k, v / 1e6) for k, v in gh.items()))
+print("largest idle gaps by (kernel before -> kernel after):")
+for k, (v, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:16]:
+    print("  %-44s -> %-44s %6.3f ms in %4d gaps" % (k[0][:44], k[1][:44], v / 1e6, c))
