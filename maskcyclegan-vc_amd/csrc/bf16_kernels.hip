@@ -462,7 +462,7 @@ int conv_launch_t(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
 int bf16_prefetch_depth(int pieces, int KW, int BM, int BN)
 {
     const int need = (pieces + kConvThreads - 1) / kConvThreads;
-    if (KW != 5 && KW != 3 && KW != 1) return 0;
+    if (KW != 5 && KW != 3 && KW != 1 && KW != 6) return 0;
     if (need <= 4) return 4;
     if (KW == 1) return 0;
     if (need <= 12) return 12;
@@ -493,6 +493,10 @@ int conv_launch_kw(const Bf16ConvArgs& a, size_t lds, hipStream_t s)
         if (depth == 4) return conv_launch_t<WM, WN, MT, NT, 3, 4>(a, lds, s);
         if (depth == 12) return conv_launch_t<WM, WN, MT, NT, 3, 12>(a, lds, s);
         return conv_launch_t<WM, WN, MT, NT, 3, 0>(a, lds, s);
+    }
+    if constexpr (BM == 64 && BN == 64) {          // (the 1-D trunk of the inference forward: three taps x two channel groups, stride 2)
+        if (a.KW == 6 && depth == 4) return conv_launch_t<WM, WN, MT, NT, 6, 4>(a, lds, s);
+        if (a.KW == 6 && depth == 12) return conv_launch_t<WM, WN, MT, NT, 6, 12>(a, lds, s);
     }
     if (a.KW == 1 && depth == 4) return conv_launch_t<WM, WN, MT, NT, 1, 4>(a, lds, s);
     return conv_launch_t<WM, WN, MT, NT, 0, 0>(a, lds, s);
@@ -1043,7 +1047,11 @@ __global__ void __launch_bounds__(256) bf16_pack_kernel(const Bf16PackArgs a)
                     const int kf = kw * a.Cin + k;               // (packed KW > 1: the 1 x 1 layer's channels in KW groups of Cin, see infer_bf16.hip)
                     if (kf < a.Cin_src) { const int ci = (kf & 255) * 20 + (kf >> 8); v = a.w[br][(long long)co * a.Cin_src + ci]; }
                 } else {
-                    if (k < a.Cin_src) v = a.w[br][(((long long)co * a.Cin_src + k) * a.KH + kh) * a.KW_src + kw];
+                    // packed KW = G * KW_src: G channel groups of Cin as extra positions of a stride-G window (infer_bf16.hip, the 1-D trunk):
+                    // window position kw = kw_src * G + g holds source channel g * Cin + k
+                    int ks = k, kws = kw;
+                    if (a.KW > a.KW_src) { const int G = a.KW / a.KW_src; kws = kw / G; ks = (kw % G) * a.Cin + k; }
+                    if (ks < a.Cin_src) v = a.w[br][(((long long)co * a.Cin_src + ks) * a.KH + kh) * a.KW_src + kws];
                 }
             }
         }

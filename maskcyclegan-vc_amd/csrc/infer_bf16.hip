@@ -53,10 +53,16 @@ static NetB build_net()
     n.ds1 = mkl(BF16_PACK_PLAIN, 4, 5, 8, 9, 256, 128, 5, 5, 128, 5, 512, 2, 2, 2);                       // :129-133
     n.ds2 = mkl(BF16_PACK_PLAIN, 12, 13, 16, 17, 256, 256, 5, 5, 256, 5, 512, 2, 2, 2);                   // :135-139
     n.c2d1d = mkl(BF16_PACK_HC_IN, 20, 21, -1, -1, 256, 5120, 1, 1, 1024, 5, 256, 5, 0, 0);               // :142-146 (as a 1 x 5 stride-5 conv over 1024 channels, see forward())
+    // The residual blocks' 1 x 3 convolutions have 8 / 16 pipeline stages of six MFMA steps: barrier-bound.  Read as [b][2 * W4 positions]
+    // [Cin / 2 channels] (the same bytes) they are 1 x 6 convolutions with stride 2 and padding 2 -- position 2 * w + g holds channel group g
+    // of pixel w, so the window of output w covers positions 2 * (w - 1) .. 2 * (w - 1) + 5 = (kw, g) of the three taps: half the stages,
+    // twice the steps each (knob MCVC_BF16_TRUNK_FOLD for the A/B).
+    static const int fold = mcvc_knob("MCVC_BF16_TRUNK_FOLD", 1);
+    const int G = fold ? 2 : 1;
     for (int i = 0; i < 6; ++i) {                                                                          // :151-180
         const int b = 24 + 12 * i;
-        n.res_vg[i] = mkl(BF16_PACK_PLAIN, b + 0, b + 1, b + 4, b + 5, 512, 256, 1, 3, 256, 3, 1024, 1, 0, 1);
-        n.res_out[i] = mkl(BF16_PACK_PLAIN, b + 8, b + 9, -1, -1, 256, 512, 1, 3, 512, 3, 256, 1, 0, 1);
+        n.res_vg[i] = mkl(BF16_PACK_PLAIN, b + 0, b + 1, b + 4, b + 5, 512, 256, 1, 3, 256 / G, 3 * G, 1024, G, 0, G);
+        n.res_out[i] = mkl(BF16_PACK_PLAIN, b + 8, b + 9, -1, -1, 256, 512, 1, 3, 512 / G, 3 * G, 256, G, 0, G);
     }
     n.c1d2d = mkl(BF16_PACK_HC_OUT, 96, 97, -1, -1, 5120, 256, 1, 1, 256, 1, 5120, 1, 0, 0);              // :183-187
     n.up1 = mkl(BF16_PACK_PLAIN, 104, 105, -1, -1, 1024, 256, 5, 5, 256, 5, 1024, 1, 2, 2);               // :192-196
@@ -180,10 +186,11 @@ static void forward(Run& r, const float* x, const float* mask, float* out, const
     int cur = 0;
     for (int i = 0; i < 6; ++i) {
         const int b = 24 + 12 * i;
-        conv(r, n.res_vg[i], B16(w.h[cur]), (long long)W4 * 256, 0, 256, B, 1, W4, B16(w.ca), (long long)W4 * 1024, 0, 1024, 1024);
+        const int G = n.res_vg[i].stride;                   // channel groups folded into the position axis (build_net)
+        conv(r, n.res_vg[i], B16(w.h[cur]), (long long)W4 * 256, 0, 256 / G, B, 1, G * W4, B16(w.ca), (long long)W4 * 1024, 0, 1024, 1024);
         norm(r, B16(w.ca), (long long)W4 * 1024, 0, 1024, B, 1, W4, 1024, 0, BF16_ACT_GLU, P[b + 2], P[b + 3], P[b + 6], P[b + 7], nullptr,
              B16(w.ya), (long long)W4 * 512, 0, 512);
-        conv(r, n.res_out[i], B16(w.ya), (long long)W4 * 512, 0, 512, B, 1, W4, B16(w.cb), (long long)W4 * 256, 0, 256, 256);
+        conv(r, n.res_out[i], B16(w.ya), (long long)W4 * 512, 0, 512 / G, B, 1, G * W4, B16(w.cb), (long long)W4 * 256, 0, 256, 256);
         norm(r, B16(w.cb), (long long)W4 * 256, 0, 256, B, 1, W4, 256, 0, BF16_ACT_NONE, P[b + 10], P[b + 11], nullptr, nullptr, B16(w.h[cur]),
              B16(w.h[cur ^ 1]), (long long)W4 * 256, 0, 256);
         cur ^= 1;
