@@ -578,6 +578,8 @@ class TrainEngine:
         g_lr = sc.g_opt_lr
         P = {}
 
+        copies = ([self.in_A2B[:B], self.in_A2B[B:], self.in_B2A[:B], self.in_B2A[B:], self.mask_A2B[:B], self.mask_B2A[:B]],
+                  [real_A, real_B, real_B, real_A, mask_A, mask_B])                    # (the masks' second halves stay all-ones)
         def pre(zero_grads=True):              # on the caller's stream, before the lanes fork
             self.slots[:_BLOCK].zero_()
             if zero_grads:
@@ -585,8 +587,7 @@ class TrainEngine:
                     self._g_grad_clean = False
                 else:
                     self.g_group.grad.zero_()
-            torch._foreach_copy_([self.in_A2B[:B], self.in_A2B[B:], self.in_B2A[:B], self.in_B2A[B:], self.mask_A2B[:B], self.mask_B2A[:B]],
-                                 [real_A, real_B, real_B, real_A, mask_A, mask_B])     # one launch; the masks' second halves stay all-ones
+            torch._foreach_copy_(*copies)      # one launch
 
         def fwd2(ln):                                                                                       # :203, :205, :207-210
             self._twin(lambda: self._G(A2B, self.in_A2B, self.mask_A2B, self.out_A2B, self.g_stash2[0], nbt, 0),
@@ -666,7 +667,7 @@ class TrainEngine:
             self._g_fwd_packed = bool(fuse_update)
             self._combine(0, self._comb_g)
         P.update(update_range=update_range, pre=pre, fwd2=fwd2, cycle=cycle, adv1=adv1, adv2=adv2, bwd_cycle=bwd_cycle, bwd_final=bwd_final,
-                 queue_reduce=queue_reduce, update=update, post=post, ov=ov)
+                 queue_reduce=queue_reduce, update=update, post=post, ov=ov, copies=copies)
         return P
 
     def generator_phase_grouped(self, real_A, mask_A, real_B, mask_B, fuse_update=False):
@@ -706,6 +707,7 @@ class TrainEngine:
         s0, s1 = (0, 1) if gi == 0 else (4, 5)
         P = {}
 
+        copies = ([di["discriminator_A"][:B], di["discriminator_A2"][:B], di["discriminator_B"][:B], di["discriminator_B2"][:B]], [real_A, real_A, real_B, real_B])
         def pre(zero_grads=True):
             self.slots[_BLOCK:].zero_()
             if zero_grads:
@@ -713,8 +715,7 @@ class TrainEngine:
                     self._d_grad_clean = False
                 else:
                     self.d_group.grad.zero_()
-            torch._foreach_copy_([di["discriminator_A"][:B], di["discriminator_A2"][:B], di["discriminator_B"][:B], di["discriminator_B2"][:B]],
-                                 [real_A, real_A, real_B, real_B])
+            torch._foreach_copy_(*copies)
 
         def disc_full(name):
             i = idx[name]
@@ -748,7 +749,7 @@ class TrainEngine:
 
         def post():
             self._combine(8, self._comb_d)
-        P.update(pre=pre, gen_fwd=gen_fwd, cycles=cycles, repack_full=repack_full, post=post,
+        P.update(pre=pre, gen_fwd=gen_fwd, cycles=cycles, repack_full=repack_full, post=post, copies=copies,
                  full1=pair(disc_full, "discriminator_A", "discriminator_B"), full2=pair(disc_full, "discriminator_A2", "discriminator_B2"),
                  real1=pair(disc_half, "discriminator_A", "discriminator_B", False), real2=pair(disc_half, "discriminator_A2", "discriminator_B2", False),
                  fake1=pair(disc_half, "discriminator_A", "discriminator_B", True), fake2=pair(disc_half, "discriminator_A2", "discriminator_B2", True))
@@ -837,13 +838,14 @@ class TrainEngine:
             self._g_grad_clean = True          # (cleared by the update launch that consumed them)
             g["post"]()
             return
-        self.slots_done[:_BLOCK].copy_(self.slots[:_BLOCK])           # g_loss and its terms of iteration t, before the block is reused
         d = self._d_parts(prev, gi=2, aux2=self._sides[1])            # (lane 2's stream: idle until "dupd1")
-        g["pre"](zero_grads=False)             # (all gradient buffers were cleared by the update launches that consumed them)
-        d["pre"](zero_grads=False)
+        # caller's stream, before the lanes fork, TWO launches (five until r5, ~15 us of idle GPU each at the head of the chain): iteration t's g_loss
+        # terms saved + both phases' input copies; both loss blocks cleared (the gradients were cleared by the updates that consumed them)
+        torch._foreach_copy_([self.slots_done[:_BLOCK]] + g["copies"][0] + d["copies"][0], [self.slots[:_BLOCK]] + g["copies"][1] + d["copies"][1])
+        self.slots.zero_()
         packed = self._g_fwd_packed
         d_step = self.d_group.step + 1
-        split = self.B >= self.split_d_min_batch
+        split, tail = self.B >= self.split_d_min_batch, self.concurrent and not self._serial
         serial = self._serial_fwd()            # (data-parallel ranks: one grouped persistent trunk pass in flight at a time)
         tasks = [
             (1, (lambda ln: (None if packed else d["repack_full"](ln), d["gen_fwd"](ln))), (), "gen"),
@@ -859,10 +861,11 @@ class TrainEngine:
             (1, d["fake2"] if split else d["full2"], ("r2",) if split else (), None),
             (1, self._d_pair_update(("discriminator_A2", "discriminator_B2"), d_lr, d_step), (), "dupd2"),
             (2, g["adv1"], ("g", "dupd1"), "d1"),
+        ] + ([(2, lambda ln: (d["post"](), self.slots_done[_BLOCK:].copy_(self.slots[_BLOCK:]), self._publish_done()), ("dupd2",), None)] if tail else []) + [
             (0, g["adv2"], ("dupd2",), None),
             (0, g["bwd_cycle"], ("d1",), None),
             (0, g["bwd_final"], (), "f"),
-        ] + ([(3, g["queue_reduce"], (), None)] if ov else [])
+        ] + ([(2, lambda ln: g["post"](), ("f",), None)] if tail else []) + ([(3, g["queue_reduce"], (), None)] if ov else [])
         if ranged:
             # the generator update range by range: the up-sampling blocks', the trunk's and most of the head's optimizer step + re-pack run
             # on lane 1 (idle since "dupd2" -- lane 3's stream carries the backward rounds' weight gradients) beside the rest of the last
@@ -876,10 +879,8 @@ class TrainEngine:
         self._run_tasks(tasks)
         self.d_group.step = d_step
         self._g_grad_clean = self._d_grad_clean = True
-        g["post"]()
-        d["post"]()
-        self.slots_done[_BLOCK:].copy_(self.slots[_BLOCK:])           # d_loss and its terms of iteration t: the iteration is complete
-        self._publish_done()
+        if not tail:      # (tail: the loss sums and the publish of iteration t's losses ride on lanes 1 / 2 instead of the end of the chain)
+            g["post"](), d["post"](), self.slots_done[_BLOCK:].copy_(self.slots[_BLOCK:]), self._publish_done()
 
     # ---- merged forwards (r4) ---------------------------------------------------------------------------------------------------------
     def _merged_ok(self, B):
@@ -908,9 +909,8 @@ class TrainEngine:
         and the cycle pass TWO: [ fake(t+1) ; generated(t) ] (contiguous rows of the first pass's output).  The backward passes run over the
         first two / the first sample of those stashes (mcvc_gen_backward_window).  Per-sample results are what the separate passes compute
         (every op of the generator is per sample): tests/test_hip_twin.py.  Two of six grouped generator passes disappear; one persistent trunk pass in flight, not two.
-            lane 0: forward x3 -> cycle x2 -> backward cycle -> backward translation + identity -> conv1's update;  lanes 1 / 2: D_A | D_B
-            (D_A2 | D_B2) of D-phase(t) -> their update -> first- (second-) step adversarial pair of G-phase(t+1), lane 1 then the ranged
-            generator update;  lane 3: the backward passes' weight gradients"""
+            lane 0: forward x3 -> cycle x2 -> the two backward passes -> conv1's update;  lanes 1 / 2: D_A | D_B (D_A2 | D_B2) of D-phase(t) ->
+            their update -> first- (second-) step adversarial pair of G-phase(t+1), lane 1 then the ranged generator update;  lane 3: weight gradients"""
         cur = self.static_in
         prev, d_lr = self._pending_D if self._pending_D is not None else (None, None)
         B, B2, B3 = self.B, 2 * self.B, 3 * self.B

@@ -23,7 +23,7 @@ for rep in range(3):
         eng.flush(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            eng.step(*batches[(4 + i) % 16]); eng.losses(lagged=True)
+            eng.step(*batches[(4 + i) % 16]); eng.losses(lagged=2)
         eng.flush(); torch.cuda.synchronize()
         print("bs=%d %s=%d: %.3f ms" % (B, attr, v, 1e3 * (time.perf_counter() - t0) / steps), flush=True)
         del eng, nets
