@@ -169,7 +169,7 @@ class TrainEngine:
         self._done_ring = [(torch.zeros(2 * _BLOCK).pin_memory(), torch.cuda.Event()) for _ in range(4)]    # published loss slots (host) + events
         self._done_count = 0                    # iterations published so far ...
         self._done_base = 0                     # ... of which before the last synchronous read (losses() without a lag)
-        self.split_d_min_batch = 4
+        self.split_d_min_batch = 8                  # (r5 same-box A/B: bs=4 12.94 -> 12.85 ms unsplit, bs=8 21.42 split vs 21.52)
         self._timeline = None
         # data parallel (plain schedules): start the discriminator gradient all-reduce at the end of an iteration and finish the update
         # where the discriminators are next used, i.e. after the next generator forwards -- the exchange hides behind them.  On one GPU
