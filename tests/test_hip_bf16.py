@@ -37,6 +37,10 @@ CONV_CASES = [
     (1, 80, 64, 128, 32, 5, 1, 1, 2, 0),     # last conv after the kw -> channel fold (32-row tile config)
     (1, 13, 37, 64, 36, 3, 3, 1, 1, 1),      # ragged: overhanging tiles, Cout not a multiple of 32
     (1, 21, 45, 32, 128, 5, 5, 2, 2, 2),     # ragged stride 2
+    (2, 1, 80, 1024, 256, 1, 5, 5, 0, 0),    # conv2dto1d as the forward runs it since r5: 1 x 5, stride 5 over [5 * W4 positions][1024 channels]
+    (3, 1, 32, 128, 1024, 1, 6, 2, 0, 2),    # residual value | gate as the forward runs it: 1 x 6, stride 2, two channel groups as positions
+    (3, 1, 32, 256, 256, 1, 6, 2, 0, 2),     # residual out, the same fold
+    (1, 9, 31, 32, 64, 3, 3, 3, 1, 1),       # a stride the generator does not use (general stride in the pixel addressing), ragged
 ]
 
 
