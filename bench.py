@@ -292,6 +292,8 @@ def parse_args():
                     "(2 = the training loop's LOSS_LAG: never waits for work in flight; 1 = rounds 3-4: waits for the discriminator phase just queued)")
     ap.add_argument("--allow-degraded", action="store_true", help="--gpus N: do not fail when the ranks did not all take part in the collective or the "
                     "persistent trunk kernels fell back to per-layer launches (single-GPU choreography tests over gloo)")
+    ap.add_argument("--test-force-residency", type=int, default=None, help=argparse.SUPPRESS)    # tests: engines claim this many persistent passes in flight
+    ap.add_argument("--test-distinct-gpus", action="store_true", help=argparse.SUPPRESS)         # tests: skip the ranks-share-a-GPU switch
     ap.add_argument("--serial", action="store_true", help="one stream: no lanes, no auxiliary weight-gradient stream (A/B comparison, per-kernel profiling)")
     ap.add_argument("--dump-trace", default=None, help="write one traced step's per-launch records (launch order) to this file")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")
@@ -473,7 +475,13 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
 
 def main():
     args = parse_args()
+    from mask_cyclegan_vc import parallel
     from mask_cyclegan_vc.parallel import init_from_env
+    if args.test_distinct_gpus:
+        parallel.ASSUME_DISTINCT_GPUS = True
+    if args.test_force_residency is not None:
+        from mask_cyclegan_vc.engine import TrainEngine
+        TrainEngine.FORCE_INFLIGHT = args.test_force_residency
 
     rank, world, local_rank = init_from_env()
     if world != args.gpus and world > 1:

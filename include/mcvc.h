@@ -44,6 +44,14 @@ int mcvc_version(void);
  * reference's CPU path.  Workspaces are always sized for both modes.  Returns the previous setting.             */
 int mcvc_set_deterministic(int on);
 int mcvc_get_deterministic(void);
+/* Precise mode (default: env MCVC_PRECISE, else off; r6).  When on, the generators' 5x5 convolutions (model.py:86-99 downSample1/2,
+ * :192-204 upSample1/2) run on the direct im2col-free kernels in every pass -- no Winograd scheme -- so the step's rounding is that of
+ * plain fp32 sums, the reference's own (F.conv2d): against an fp64 run of the same four iterations the parameters then sit as close as
+ * the reference's CPU fp32 arithmetic does (tests/test_hip_parity_fp64.py).  The default (fast) mode is 2-3x noisier on that measure and
+ * inside 1e-3 on every single-iteration quantity.  Process-wide; set it before packing networks / building engines.  Returns the
+ * previous setting.                                                                                                              */
+int mcvc_set_precise(int on);
+int mcvc_get_precise(void);
 /* Small-batch generator passes (B * T/4 <= 32) run the 1-D trunk (six residual blocks + conv1dto2d, model.py:258-271) as ONE
  * persistent launch per direction instead of one fused launch per layer (default on).  Results are
  * bit-identical either way; the switch exists for A/B timing and tests.  Returns the previous setting.

@@ -286,7 +286,12 @@ static bool wino_env_enabled()
     return en != 0;
 }
 static thread_local int t_no_wino = 0;          // (op-level entries that ask for the direct / staged-GEMM kernels)
-static bool wino_enabled() { return wino_env_enabled() && !t_no_wino; }
+// Precise mode (mcvc_set_precise / env MCVC_PRECISE): every 5x5 layer on the direct kernels -- no Winograd scheme anywhere.  The fast default
+// trades rounding for multiplies (after four Adam steps its parameters sit 2-3x further from an fp64 run than the
+// reference's own fp32 arithmetic does; precise mode sits where the reference sits).  Process-wide; set it BEFORE networks are packed and
+// engines are built (workspaces and packed copies are planned for the mode in force; a later switch fails loudly on a stale copy).
+static int g_precise = [] { const char* e = getenv("MCVC_PRECISE"); return (e && atoi(e) != 0) ? 1 : 0; }();
+static bool wino_enabled() { return wino_env_enabled() && !t_no_wino && !g_precise; }
 
 // tile of the 36 batched products: 128 channels x 64 tiles measured best on all four shapes (128x128 wastes the ragged
 // tile count of upSample1, 256x32 re-reads V too often); knob: MCVC_WINO_CFG = planner index + 1
@@ -2263,6 +2268,8 @@ int mcvc_twin_launches(void) { return (int)t_twin_ctx.recs.size(); }
 
 int mcvc_set_deterministic(int on) { const int was = g_deterministic; g_deterministic = on ? 1 : 0; return was; }
 int mcvc_get_deterministic(void) { return g_deterministic; }
+int mcvc_set_precise(int on) { const int was = g_precise; g_precise = on ? 1 : 0; return was; }
+int mcvc_get_precise(void) { return g_precise; }
 int mcvc_set_trunk_persistent(int on) { const int was = g_trunk_net; g_trunk_net = (on == 2) ? 2 : (on ? 1 : 0); return was; }
 
 long long mcvc_gen_packed_floats(void) { return gen_net().packed_floats; }
@@ -2359,10 +2366,11 @@ static GenPackCfg gen_pack_cfg(int max_batch, int T)
     // off through the MCVC_WINO* knobs: then their direct K-major copies are not refreshed either
     static const bool knobs_default = !mcvc_knob_set("MCVC_WINO") && !mcvc_knob_set("MCVC_WINO3") && !mcvc_knob_set("MCVC_WINO3_FWD") && !mcvc_knob_set("MCVC_WINO_GEMM");
     const GenDims dm = gen_dims(max_batch, T);
-    q.wino_only = q.fused && knobs_default && (T % 4) == 0 && T >= 32 && (long long)max_batch * 20 * dm.W4 <= 16384;
+    const bool wino_default = knobs_default && !g_precise;
+    q.wino_only = q.fused && wino_default && (T % 4) == 0 && T >= 32 && (long long)max_batch * 20 * dm.W4 <= 16384;
     // the 64-point weight sets of upSample1/2 only when some pass can take the F(4x4,5x5) path (wino4_applies); otherwise marked absent (bit 16)
-    q.w4 = knobs_default && wino4_min_nb() > 0 && max_batch >= wino4_min_nb() && (T % 16) == 0;
-    q.w43 = knobs_default && wino43_min_nb() > 0 && max_batch >= wino43_min_nb() && (T % 16) == 0;      // (bit 32)
+    q.w4 = wino_default && wino4_min_nb() > 0 && max_batch >= wino4_min_nb() && (T % 16) == 0;
+    q.w43 = wino_default && wino43_min_nb() > 0 && max_batch >= wino43_min_nb() && (T % 16) == 0;      // (bit 32)
     q.up1_w4 = (long long)max_batch * 5 * (T / 16) >= wino4_min_tiles();             // upSample1 runs on 20 x T/4 images: 5 x T/16 tiles per sample
     // the 36-point sets of a layer only where some pass still runs F(2x2,5x5): a layer with >= wino4_min_tiles() tiles PER SAMPLE (upSample2
     // at 64 frames: 80) takes the 4 x 4 scheme in every pass, forward, data gradient and weight gradient (wino4_applies), so its 36-point

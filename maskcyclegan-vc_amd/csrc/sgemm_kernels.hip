@@ -12,6 +12,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l)
 {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
+__device__ __forceinline__ float zmasked(float v, unsigned m) { return __uint_as_float(__float_as_uint(v) & m); }
 template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
 // A 16-byte LDS read the compiler does not see as a memory access: hipcc puts `s_waitcnt vmcnt(0)` in front of a ds_read_b128 that follows
 // global_load_lds instructions (it cannot tell the ring's stages apart) -- which would drain the whole LDS-DMA pipeline every stage; the
@@ -233,10 +234,11 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
         __builtin_amdgcn_s_barrier();
         if (st + ST - 1 < nst) issue(st + ST - 1, (st + ST - 1) % ST);
         const float* sb = smem + (st % ST) * STAGE;
-        // (ZFIX) this stage's tap: 1 = window shifted by -1 column, 2 = by +1; a lane at that end of a row multiplies by 0 instead of the
-        // neighbouring row's element -- a scale, not a branch: the loads stay unconditional
-        float zsc = 1.f;
-        if (ZFIX) { const int zt = cl.zs[(kbase + st * GK) / Cb]; zsc = (zpos != 0 && zt == zpos) ? 0.f : 1.f; }
+        // (ZFIX) this stage's tap: 1 = window shifted by -1 column, 2 = by +1; a lane at that end of a row takes 0 instead of the
+        // neighbouring row's element -- a bit mask on the LOADED value (v_and_b32), not a branch and not a scale: the loads stay
+        // unconditional, and the float beyond the tensor's first / last row may be anything (NaN, Inf: 0 * NaN would be NaN -- ADVICE r5)
+        unsigned zmask = 0xffffffffu;
+        if (ZFIX) { const int zt = cl.zs[(kbase + st * GK) / Cb]; zmask = (zpos != 0 && zt == zpos) ? 0u : 0xffffffffu; }
         if (AROW) {
             // operand reads one group of four MFMAs ahead (one ds_read_b128 of A + four ds_read_b32 of B per group), order pinned
             const float* ar = sb + (wm * 32 + l31) * GK;
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
                                  : "=&v"(n0_), "=&v"(n1_), "=&v"(n2_), "=&v"(n3_) : "v"(b_addr + (q + 1) * 1024));
                 }
                 __builtin_amdgcn_sched_barrier(0);        // (the four MFMAs below stay BEHIND the next group's requests)
-                if (ZFIX) { b0 *= zsc; b1 *= zsc; b2 *= zsc; b3 *= zsc; }
+                if (ZFIX) { b0 = zmasked(b0, zmask); b1 = zmasked(b1, zmask); b2 = zmasked(b2, zmask); b3 = zmasked(b3, zmask); }
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
@@ -273,7 +275,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const Twin<IGemmArgs> tw)
         for (int p = 0; p < GK / 2; ++p) {
             const int q = (p + 1 < GK / 2) ? p + 1 : p;
             const float na0 = sb[a_lane + q * 2 * BM], nb0 = sb[b_lane + q * 2 * BN];
-            if (ZFIX) b0 *= zsc;
+            if (ZFIX) b0 = zmasked(b0, zmask);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

@@ -523,6 +523,10 @@ __global__ void __launch_bounds__(256) wino_output_kernel(const Twin<WinoOutArgs
 // s_waitcnt vmcnt(n) that leaves the newer stages outstanding, so a stage has three stages of MFMA work (~2.5 us) to land.
 constexpr int kGK = 16;                 // k per stage
 constexpr int kGStages = 4;
+#ifndef MCVC_FOLDK
+#define MCVC_FOLDK 32
+#endif
+constexpr int kFoldK = MCVC_FOLDK;              // k per first-level accumulation chain of the batched GEMMs (two-level sums: wino_gemm_kernel)
 constexpr int kGA = kGK * 128;          // floats of A per stage
 
 __device__ __forceinline__ void wg_glds16(const float* g, float* l)
@@ -582,11 +586,16 @@ __global__ void __launch_bounds__(256, (BN == 64 ? 3 : 4)) wino_gemm_kernel(cons
         wg_glds16(a_src1 + stage_k * a_step, base + (wave * 64 + 256) * 4);
         wg_glds16(b_src + stage_k * b_step, base + kGA + (bw * 64) * 4);
     };
-    f32x16 acc[NACC];
+    // Two-level accumulation (r6): `acc` runs over kFoldK k, then folds into `tot`.  An fp32 chain of L fused multiply-adds carries a
+    // rounding error ~ eps * L / sqrt(2) of one term; in the Winograd domain that error is amplified by the cancellation of the output
+    // transform, and the K-long chain was 97 % of the schemes' error (tools/wino_error_model.py).  Chains of 32 + a chain of c = K / 32 partial
+    // sums: error ~ sqrt(L^2 / c + L c) instead of L: 2.5x smaller at K = 256, 3.3x at 512, 4x at 1024 (the optimum is c = sqrt(L)).
+    f32x16 acc[NACC], tot[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; tot[i][r] = 0.f; }
+    constexpr int kFoldSt = kFoldK / kGK;
     const int nst = a.K / kGK;
 #pragma unroll
     for (int s = 0; s < kGStages - 1; ++s)
@@ -601,6 +610,12 @@ __global__ void __launch_bounds__(256, (BN == 64 ? 3 : 4)) wino_gemm_kernel(cons
         else __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
         __builtin_amdgcn_s_barrier();                                 // everyone's part of stage st is in LDS; buffer (st-1)%4 is free
         if (st + kGStages - 1 < nst) issue(st + kGStages - 1, (st + kGStages - 1) % kGStages);
+        if (st != 0 && (st % kFoldSt) == 0) {                         // (behind the barrier: the chunk's last MFMAs have retired by now)
+#pragma unroll
+            for (int i = 0; i < NACC; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { tot[i][r] += acc[i][r]; acc[i][r] = 0.f; }
+        }
         const float* sb = smem + (st % kGStages) * kGStage;
         // operand reads run one k-pair ahead of the MFMAs (pinned: the scheduler otherwise sinks them below the MFMAs)
         if constexpr (BN == 64) {
@@ -638,7 +653,7 @@ __global__ void __launch_bounds__(256, (BN == 64 ? 3 : 4)) wino_gemm_kernel(cons
 #pragma unroll
         for (int i = 0; i < NACC; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) C[(long long)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc] = acc[i][r];
+            for (int r = 0; r < 16; ++r) C[(long long)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc] = tot[i][r] + acc[i][r];
     }
 }
 
@@ -698,11 +713,12 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const Twin<WinoGemmArgs> tw)
 #pragma unroll
         for (int i = 0; i < NB; ++i) wg_glds16(bsrc[i] + stage_k * b_step, base + bdst[i]);
     };
-    f32x16 acc[NACC];
+    f32x16 acc[NACC], tot[NACC];                 // two-level accumulation: see wino_gemm_kernel
 #pragma unroll
     for (int i = 0; i < NACC; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) { acc[i][r] = 0.f; tot[i][r] = 0.f; }
+    constexpr int kFoldSt = kFoldK / GK;
     const int nst = a.K / GK;
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
@@ -714,6 +730,12 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const Twin<WinoGemmArgs> tw)
         if (newer >= 2) wait_vm<2 * ND>(); else if (newer == 1) wait_vm<ND>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         if (st + ST - 1 < nst) issue(st + ST - 1, (st + ST - 1) % ST);
+        if (st != 0 && (st % kFoldSt) == 0) {
+#pragma unroll
+            for (int i = 0; i < NACC; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { tot[i][r] += acc[i][r]; acc[i][r] = 0.f; }
+        }
         const float* sb = smem + (st % ST) * STAGE;
         float av[NBM], bv[NBN];
 #pragma unroll
@@ -751,7 +773,7 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const Twin<WinoGemmArgs> tw)
 #pragma unroll
         for (int i = 0; i < NBM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) C[(long long)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc] = acc[i * NBN + j][r];
+            for (int r = 0; r < 16; ++r) C[(long long)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldc] = tot[i * NBN + j][r] + acc[i * NBN + j][r];
     }
 }
 

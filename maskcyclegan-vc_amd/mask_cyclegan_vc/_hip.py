@@ -29,6 +29,8 @@ _SIGS = {
     "mcvc_version": (c_int, []),
     "mcvc_set_deterministic": (c_int, [c_int]),
     "mcvc_get_deterministic": (c_int, []),
+    "mcvc_set_precise": (c_int, [c_int]),
+    "mcvc_get_precise": (c_int, []),
     "mcvc_set_trunk_persistent": (c_int, [c_int]),
     "mcvc_twin_begin": (c_int, []),
     "mcvc_twin_switch": (c_int, []),

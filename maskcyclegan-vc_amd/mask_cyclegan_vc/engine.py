@@ -162,7 +162,7 @@ class TrainEngine:
         # more sample (_merged_step).  Slower than the separate passes on one GPU (6.20-6.26 vs 6.00-6.16 ms at bs=1: DESIGN section 5);
         # default on data-parallel ranks only -- there one grouped persistent trunk pass in flight instead of two leaves half the compute
         # units to RCCL's kernels (csrc/trunk.h residency rule).
-        self.merged = self.reducer.world > 1
+        self.merged = self.reducer.active
         self.trunk_fallback = False            # a persistent trunk launch faulted in this process: per-layer launches from then on (check_faults)
         self._pending_D = None                  # (input set, discriminator lr) of the iteration whose discriminator phase is still to run
         self.slots_done = torch.zeros(2 * _BLOCK, device=dev)          # loss slots of the last COMPLETE iteration
@@ -174,11 +174,11 @@ class TrainEngine:
         # data parallel (plain schedules): start the discriminator gradient all-reduce at the end of an iteration and finish the update
         # where the discriminators are next used, i.e. after the next generator forwards -- the exchange hides behind them.  On one GPU
         # the same deferral measured slower (6.91 -> 7.26 ms at bs=1: the update's 0.7 GB of traffic beside the generator forwards).
-        self.defer_d_update = self.reducer.world > 1
+        self.defer_d_update = self.reducer.active
         self._pending_d_lr = None
         # ... and the generator gradient all-reduce starts per parameter range while the last backward passes are still
         # running: the library records an event when a range's gradients are complete (mcvc_gen_backward_overlap)
-        self.overlap_g_reduce = self.reducer.world > 1 and dev.type == "cuda"
+        self.overlap_g_reduce = self.reducer.active and dev.type == "cuda"
         self._ms = {}
         for n in G_NAMES:
             evs = [torch.cuda.Event() for _ in range(4)]        # ([2], [3]: the head's finer milestones, MCVC_BWD_FINE_MILESTONES)
@@ -264,6 +264,7 @@ class TrainEngine:
         for k, v in ws.items():
             setattr(self, k, v)
         self._resid = None
+        self.force_inflight = getattr(TrainEngine, "FORCE_INFLIGHT", None)   # test hook: see _set_residency (class attribute = default for new engines)
         self._set_residency()
         self._cur_set = 0
         self.static_in = self.static_sets[0]
@@ -277,8 +278,9 @@ class TrainEngine:
             inflight = 4 if (not self._use_merged() and not self._serial_fwd()) else 2
         else:
             inflight = 2
-        inflight += 1 if self.reducer.world > 1 else 0
-        inflight = int(os.environ.get("MCVC_TEST_FORCE_RESIDENCY", inflight))     # (tests: force the residency bound to fail)
+        inflight += 1 if self.reducer.active else 0
+        if self.force_inflight is not None:                        # (tests set this attribute to drive the residency bound into failure)
+            inflight = int(self.force_inflight)
         self.L.mcvc_set_trunk_passes_in_flight(inflight)          # (process-wide in the library: re-stated every step, another engine may have changed it)
         if self._resid == (inflight, self.B):
             return
@@ -800,7 +802,7 @@ class TrainEngine:
         lo, hi = self._d_ranges[pair[0]][0], self._d_ranges[pair[1]][1]
 
         def run(ln):
-            if self.reducer.world > 1:
+            if self.reducer.active:
                 self.reducer.reduce_range_after_(self.d_group.grad, lo, hi, None)
                 self.reducer.wait(self.device)
             self._twin(lambda: self._update_disc(pair[0], d_lr, d_step), lambda: self._update_disc(pair[1], d_lr, d_step))
@@ -826,7 +828,7 @@ class TrainEngine:
         (``losses(lagged=True)``); ``flush()`` / ``losses()`` complete a pending phase."""
         cur = self.static_in
         prev, d_lr = self._pending_D if self._pending_D is not None else (None, None)
-        ranged = self.reducer.world == 1
+        ranged = not self.reducer.active
         g = self._g_parts(cur, True, own_d_update=prev is None, zeroing_update=True, ranged=ranged)
         ov = g["ov"]
         if prev is None:                       # first iteration (or the first after a flush): there is no discriminator phase to run beside it
@@ -893,7 +895,7 @@ class TrainEngine:
         flight at a time, like on the merged schedule: 2 + 1 (RCCL's share) x 64 workgroups fit the 256 compute units, where the free-running
         4 + 1 do not and every pass would fall back to per-layer trunk launches.  The D-phase chain is the critical one; the
         G-phase forwards have ~0.7 ms of slack behind it."""
-        return self.reducer.world > 1 and self._use_pipeline() and not self._use_merged()
+        return self.reducer.active and self._use_pipeline() and not self._use_merged()
 
     def _use_merged(self):
         # (after the identity cut-off the merged passes would carry a dead sample: the separate passes skip it)
@@ -917,7 +919,7 @@ class TrainEngine:
         A2B, B2A = G_NAMES
         sc = self.sched
         cl, il = sc.cycle_loss_lambda, sc.identity_loss_lambda
-        ranged = self.reducer.world == 1
+        ranged = not self.reducer.active
         g = self._g_parts(cur, True, own_d_update=False, zeroing_update=True, ranged=ranged)     # (update / reduce / post closures)
         ov = g["ov"]
         ms_on = ov or ranged
@@ -1149,7 +1151,7 @@ class TrainEngine:
         self._update_discs(lr)
 
     def _use_pipeline(self):
-        return self.pipelined and self._use_grouped() and self.concurrent and (self.reducer.world == 1 or self.overlap_g_reduce)
+        return self.pipelined and self._use_grouped() and self.concurrent and (not self.reducer.active or self.overlap_g_reduce)
 
     def _next_input_set(self):
         """The static input buffers the coming iteration writes its minibatch into: the other set while the previous iteration's
@@ -1210,7 +1212,7 @@ class TrainEngine:
             return self.slots
         if self._pending_D is not None:
             self.flush()
-        if self.reducer.world == 1 or self.overlap_g_reduce:
+        if not self.reducer.active or self.overlap_g_reduce:
             phase = self.generator_phase_grouped if self._use_grouped() else self.generator_phase
             phase(*self.static_in, fuse_update=True)                      # includes the generator update (no join of the lanes)
         else:

@@ -22,9 +22,11 @@ import os
 import torch
 import torch.distributed as dist
 
-# dmabuf IPC for multi-process GPU work on this image (RCCL fails in hipIpcGetMemHandle without it); read when the HSA runtime starts,
-# i.e. at the first device call -- set on import in case the launcher's environment dropped it
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# Multi-process GPU work on this image needs dmabuf IPC: export HSA_ENABLE_IPC_MODE_LEGACY=0 in the LAUNCHER's environment (RCCL fails in
+# hipIpcGetMemHandle without it; the HSA runtime reads it when it starts, so setting it here would be too late -- INTEGRATION.md).
+
+
+ASSUME_DISTINCT_GPUS = False      # test hook (bench.py --test-distinct-gpus): skip the shared-device switch below
 
 
 def init_from_env(backend=None):
@@ -48,7 +50,7 @@ def init_from_env(backend=None):
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-            if torch.cuda.is_available() and _ranks_share_a_gpu(local_rank) and os.environ.get("MCVC_TEST_DISTINCT_GPUS") != "1":
+            if torch.cuda.is_available() and _ranks_share_a_gpu(local_rank) and not ASSUME_DISTINCT_GPUS:
                 # Ranks SHARING a GPU (the single-GPU choreography tests only): the persistent trunk kernels wait inside the kernel for
                 # workgroups that must all be resident (csrc/trunk.h) -- that holds for the passes one process keeps in flight, not for
                 # two processes' worth of them on one device.  Run the trunk as per-layer launches there.
@@ -94,9 +96,13 @@ def _ranks_share_a_gpu(local_rank):
 class FlatGradReducer:
     """Sum-all-reduce a flat gradient buffer in place, in buckets, optionally on a side stream."""
 
-    def __init__(self, bucket_bytes=64 << 20, group=None, use_side_stream=True):
+    def __init__(self, bucket_bytes=64 << 20, group=None, use_side_stream=True, force=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # ``active``: the exchange is really issued.  ``force`` keeps it on in a ONE-rank group (tests/test_hip_rccl_one_rank.py: real RCCL
+        # kernels on the communication stream beside the persistent trunk kernels, the data-parallel schedule and its residency budget, on
+        # the single GPU of a dev box -- a 1-rank all-reduce is the identity, so the result must equal the run without a reducer bit for bit)
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
         self.bucket_elems = max(1, bucket_bytes // 4)
         self._stream = None
         self._use_side_stream = use_side_stream
@@ -111,7 +117,7 @@ class FlatGradReducer:
 
     def reduce_(self, flat: torch.Tensor):
         """In-place SUM over ranks (scale by ``grad_scale`` downstream). No-op for world size 1."""
-        if self.world == 1:
+        if not self.active:
             return flat
         n = flat.numel()
         if flat.is_cuda and self._use_side_stream:
@@ -132,7 +138,7 @@ class FlatGradReducer:
         """Start the bucketed SUM all-reduce of ``flat`` on the communication stream and return immediately; the caller's
         stream keeps computing.  ``wait()`` makes the current stream wait for it.  (The engine uses this to hide the
         discriminator gradient exchange behind the next iteration's generator forwards.)"""
-        if self.world == 1:
+        if not self.active:
             return flat
         if not (flat.is_cuda and self._use_side_stream):
             return self.reduce_(flat)
@@ -149,7 +155,7 @@ class FlatGradReducer:
     def reduce_range_after_(self, flat: torch.Tensor, lo: int, hi: int, event=None):
         """Queue the SUM all-reduce of ``flat[lo:hi]`` on the communication stream, to start once ``event`` (recorded by the
         producer of that range; None = everything queued on the current stream so far) has completed.  Pair with ``wait()``."""
-        if self.world == 1 or hi <= lo:
+        if not self.active or hi <= lo:
             return
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=flat.device)
@@ -188,6 +194,6 @@ class FlatGradReducer:
 
     def broadcast_(self, flat: torch.Tensor, src=0):
         """Make every rank start from rank ``src``'s parameters."""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(flat, src=src, group=self.group)
         return flat

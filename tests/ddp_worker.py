@@ -105,7 +105,7 @@ def main():
     if rank == 0:
         both = batch_of(all_seeds[0] + all_seeds[1])
         solo = FlatGradReducer()
-        solo.world = 1                  # the single-process reference must not issue collectives
+        solo.world, solo.active = 1, False      # the single-process reference must not issue collectives
         ref = TrainEngine(nets_for(700), 2 * PER_RANK, 64, schedule=StepSchedule(batch_size=2 * PER_RANK, n_samples=64), reducer=solo)
         for dst, src in zip(ref.static_in, both):
             dst.copy_(src)
@@ -144,7 +144,7 @@ def main():
     # agree -- exactly the arithmetic before the first update, and closely after two (Adam's first steps amplify rounding)
     if rank == 0:
         solo = FlatGradReducer()
-        solo.world = 1
+        solo.world, solo.active = 1, False
         ref = TrainEngine(nets_for(800), 2 * PER_RANK, 64, schedule=StepSchedule(batch_size=2 * PER_RANK, n_samples=64, stop_identity_after=STOP_ID),
                           reducer=solo)
         for it in range(N_IT):

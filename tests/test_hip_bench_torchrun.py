@@ -34,13 +34,14 @@ def test_bench_under_torchrun_two_ranks():
 
 def test_multi_gpu_bench_fails_when_the_ranks_are_silently_degraded():
     """a SCALE line must not be quietly degraded.  Here the persistent trunk kernels are forced off their residency
-    bound on both ranks (MCVC_TEST_FORCE_RESIDENCY: the engine claims 9 passes in flight = 576 workgroups > 256 compute units, what five
+    bound on both ranks (bench.py --test-force-residency 9: the engine claims 9 passes in flight = 576 workgroups > 256 compute units, what five
     free-running grouped passes did on data-parallel ranks after the identity cut-off before r5) while the ranks do NOT share a GPU as
-    far as the job can tell (MCVC_TEST_DISTINCT_GPUS=1 skips the shared-device switch): bench.py must print its line, say why, and exit
+    far as the job can tell (--test-distinct-gpus skips the shared-device switch): bench.py must print its line, say why, and exit
     non-zero; --allow-degraded turns that into a zero exit."""
-    env = dict(os.environ, MCVC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MCVC_TEST_FORCE_RESIDENCY="9", MCVC_TEST_DISTINCT_GPUS="1")
+    env = dict(os.environ, MCVC_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-            "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-trace"]
+            "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-trace",
+            "--test-force-residency", "9", "--test-distinct-gpus"]
     r = subprocess.run(base, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode != 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]

@@ -16,6 +16,15 @@ from mask_cyclegan_vc.model import Discriminator, Generator  # noqa: E402
 from mask_cyclegan_vc.schedule import StepSchedule  # noqa: E402
 
 
+@pytest.fixture
+def deterministic_mode():
+    from mask_cyclegan_vc import _hip
+    L = _hip.lib()
+    was = L.mcvc_set_deterministic(1)
+    yield
+    L.mcvc_set_deterministic(was)
+
+
 def _nets(seeds):
     nets = {}
     for i, (n, s) in enumerate(zip(orc.NET_ORDER, seeds)):
@@ -71,14 +80,14 @@ def _run_against_golden(golden_dir, tag, n_it):
     return eng, js
 
 
-def test_three_iterations_match_unmodified_reference_train(golden_dir):
+def test_three_iterations_match_unmodified_reference_train(golden_dir, deterministic_mode):
     eng, js = _run_against_golden(golden_dir, "plain", 3)
     sd = eng.optimizer_state_dict("D")
     assert sorted(sd["state"].keys()) == js["adam_state_keys_D"]
     assert sorted(eng.optimizer_state_dict("G")["state"].keys()) == js["adam_state_keys_G"]
 
 
-def test_lr_decay_bug_and_identity_cutoff_match_reference(golden_dir):
+def test_lr_decay_bug_and_identity_cutoff_match_reference(golden_dir, deterministic_mode):
     eng, js = _run_against_golden(golden_dir, "decay", 2)
     fin = js["final"]
     assert eng.sched.identity_loss_lambda == fin["identity_loss_lambda"] == 0
@@ -86,7 +95,7 @@ def test_lr_decay_bug_and_identity_cutoff_match_reference(golden_dir):
     assert abs(eng.sched.generator_lr - fin["generator_lr_attr"]) < 1e-12
 
 
-def test_four_iterations_past_the_identity_cutoff_pipelined_and_unflushed(golden_dir):
+def test_four_iterations_past_the_identity_cutoff_pipelined_and_unflushed(golden_dir, deterministic_mode):
     """The regime a canonical run spends > 97 % of its life in (train.py:314-315: identity_loss_lambda = 0 from then on; :207-210 keeps
     computing the identity forwards, which the engine drops as dead work -- ``ident_dead`` in engine._g_parts), pinned to the REFERENCE:
     the ``cutoff`` fixture is four iterations of the unmodified train() at bs=2 whose iterations 2 and 3 run with lambda_id == 0.
@@ -328,15 +337,6 @@ def _three_steps(defer, seeds, B=1):
     eng.flush()
     sd = eng.optimizer_state_dict("D")
     return losses, {n: [p.detach().clone() for p in nets[n].parameters()] for n in G_NAMES + D_NAMES}, sd["state"][0]["step"]
-
-
-@pytest.fixture
-def deterministic_mode():
-    from mask_cyclegan_vc import _hip
-    L = _hip.lib()
-    was = L.mcvc_set_deterministic(1)
-    yield
-    L.mcvc_set_deterministic(was)
 
 
 def test_deferred_discriminator_update_matches_the_immediate_one(deterministic_mode):
