@@ -101,8 +101,8 @@ def test_four_iterations_past_the_identity_cutoff_pipelined_and_unflushed(golden
     the ``cutoff`` fixture is four iterations of the unmodified train() at bs=2 whose iterations 2 and 3 run with lambda_id == 0.
     Replayed through the DEFAULT schedule -- grouped launches, iteration t's discriminator phase pipelined beside iteration t+1's
     generator phase -- with NO flush() between the steps: losses are read the way the training loop reads them (``lagged=True``), the
-    parameters after the single flush at the end.  Gates: losses 1e-3; per parameter tensor the norm (fixture trace), the fixture's
-    element samples and the full tensor against the oracle (itself pinned to the same fixture in test_oracle_golden.py), rel-L2 <= 1e-3."""
+    parameters after the single flush at the end.  Gates: losses 1e-3; per parameter tensor the norm (fixture trace) 1e-3, the fixture's
+    element samples and the full tensor against the oracle (itself pinned to the same fixture in test_oracle_golden.py): see below."""
     skip = _zero_grad_bias_names(golden_dir)
     js = json.load(open(os.path.join(golden_dir, "step_cutoff.json")))
     bt = np.load(os.path.join(golden_dir, "step_cutoff_batches.npz"))
@@ -135,15 +135,13 @@ def test_four_iterations_past_the_identity_cutoff_pipelined_and_unflushed(golden
         assert abs(lo["g_loss"] - ref["g_loss"]) < 1e-3 * abs(ref["g_loss"]), (it, lo, ref)
         assert abs(lo["d_loss"] - ref["d_loss"]) < 1e-3 * abs(ref["d_loss"]), (it, lo, ref)
     assert got[2]["identity_loss"] == 0.0 and got[3]["identity_loss"] == 0.0 and got[1]["identity_loss"] > 0.0
-    # Per-tensor bound after FOUR Adam steps.  Adam's first steps move every element by ~lr * sign(g) whatever |g| is, so elements whose
-    # gradient is at rounding level move by +-lr on the toss of a summation order: the REFERENCE's own CPU arithmetic at another thread count
-    # differs from this fixture by up to 3.3e-3 rel-L2 per tensor, 63 of 232 tensors beyond 1e-3
-    # (tests/test_oracle_golden.py::test_reference_arithmetic_spread_after_four_adam_steps measures exactly that, every run).  The gate for
-    # the well-posed quantities -- losses, norms, single-iteration gradients (test_step_full_tensor_parity_vs_oracle at lam_id = 0) -- is the
-    # north star's 1e-3; the multi-step tensors are gated at 7e-3 = 2 x the reference's own spread, and most must still be inside 1e-3.
-    # (Measured over eight runs of the final r5 binary: worst tensor 4.2e-3 - 4.6e-3 -- downSample2 / upSample1 weights, the layers whose
-    # forward and gradients go through the F(4x4, 5x5) Winograd products, whose fp32 rounding is an order above a direct sum's and flips
-    # more rounding-level gradient signs -- 63 - 65 of 232 tensors beyond 1e-3; r5's first gate of 5e-3 failed once in ~10 runs.)
+    # Per-tensor distance after FOUR Adam steps, in DETERMINISTIC mode: one number per binary.  What bounds it is stated against an fp64
+    # anchor in tests/test_hip_parity_fp64.py (HIP and the reference's fp32 arithmetic each sit ~1e-3 at worst from the float64 result:
+    # Adam's first steps turn rounding-level gradients into +-lr parameter differences); here the HIP step is compared with the reference's
+    # fp32 result directly -- the fixture's element samples (fixed numbers: the gate is the measured worst x 1.25) and the oracle's full
+    # tensors (the oracle runs on this host's CPU, whose thread count moves its own result by up to ~1e-3: gate 2e-3).
+    # r6 binary (two-level accumulation in the Winograd GEMMs): worst sample distance 1.383e-3, worst full-tensor distance < 1e-3, 0 of 232
+    # tensors beyond 1e-3.  (r5: 4.2e-3 - 4.6e-3, 63-65 tensors beyond 1e-3, gate 7e-3: profiles/r06_parity_probe_before.log has the why.)
     worst, n_t, n_over, bad, top = 0.0, 0, 0, [], []
     for name in orc.NET_ORDER:
         for j, ((pn, p), rn) in enumerate(zip(nets[name].named_parameters(), js["trace"][-1]["norms"][name])):
@@ -163,12 +161,12 @@ def test_four_iterations_past_the_identity_cutoff_pipelined_and_unflushed(golden
             top.append((max(e_s, e_f), name, pn, p.numel()))
             n_t += 1
             n_over += int(e_f > 1e-3)
-            if not (e_s < 7e-3 and e_f < 7e-3):
+            if not (e_s < 1.383e-3 * 1.25 and e_f < 2e-3):
                 bad.append((name, pn, e_s, e_f))
     print("cutoff fixture, 4 un-flushed pipelined iterations: worst per-tensor rel-L2 %.3e, %d of %d tensors beyond 1e-3" % (worst, n_over, n_t))
     print("  largest: " + "; ".join("%s.%s (%d) %.2e" % (n, q, k, e) for e, n, q, k in sorted(top, reverse=True)[:6]))
     assert not bad, bad
-    assert n_over <= 0.4 * n_t, (n_over, n_t)
+    assert n_over <= 0.05 * n_t, (n_over, n_t)
 
 
 def _kink_free_batch(onets, B, T=64):
