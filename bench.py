@@ -292,6 +292,9 @@ def parse_args():
                     "(2 = the training loop's LOSS_LAG: never waits for work in flight; 1 = rounds 3-4: waits for the discriminator phase just queued)")
     ap.add_argument("--allow-degraded", action="store_true", help="--gpus N: do not fail when the ranks did not all take part in the collective or the "
                     "persistent trunk kernels fell back to per-layer launches (single-GPU choreography tests over gloo)")
+    ap.add_argument("--rccl-one-rank", action="store_true", help="single-GPU self-check of the data-parallel path: a ONE-rank nccl (= RCCL) group with the "
+                    "gradient exchange forced on -- real RCCL kernels on the communication stream beside the rank schedule; reports "
+                    "exposed_comm_ms_per_step like a --gpus N run (n_gpus stays 1)")
     ap.add_argument("--test-force-residency", type=int, default=None, help=argparse.SUPPRESS)    # tests: engines claim this many persistent passes in flight
     ap.add_argument("--test-distinct-gpus", action="store_true", help=argparse.SUPPRESS)         # tests: skip the ranks-share-a-GPU switch
     ap.add_argument("--serial", action="store_true", help="one stream: no lanes, no auxiliary weight-gradient stream (A/B comparison, per-kernel profiling)")
@@ -300,10 +303,10 @@ def parse_args():
     return ap.parse_args()
 
 
-def dist_info(world, device):
+def dist_info(world, device, force=False):
     """What the gradient exchange actually ran on: an all-reduce of ones proves that `world` ranks took part in a collective on the
     benchmark's own backend (RCCL when one GPU per rank is visible)."""
-    if world <= 1:
+    if world <= 1 and not force:
         return {"backend": None, "world": 1, "rccl_ranks_seen": 1}
     ones = torch.ones(1, device=device)
     dist.all_reduce(ones)
@@ -322,7 +325,9 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
     nets = build_nets(device)
     sched = StepSchedule(generator_lr=2e-4, discriminator_lr=1e-4, num_epochs=6172, n_samples=81, batch_size=B,
                          decay_after=2e5, stop_identity_after=stop_identity_after, world_size=world)     # bash_scripts/mask_cyclegan_train.sh
-    reducer = FlatGradReducer()
+    one_rank = bool(getattr(args, "rccl_one_rank", False))
+    dist_on = world > 1 or one_rank
+    reducer = FlatGradReducer(force=one_rank)
     engine = TrainEngine(nets, B, T, schedule=sched, reducer=reducer)
     engine.concurrent = not args.serial
     if args.serial:
@@ -337,11 +342,11 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
             lo = engine.losses()
             first = (lo["g_loss"], lo["d_loss"])
     engine.flush()                         # a deferred (data-parallel) discriminator update belongs to the warm-up
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     log("timing %d steps" % steps)
-    reducer.time_waits = world > 1         # exposed (un-hidden) gradient-exchange time: an event pair around every wait for the communication stream
+    reducer.time_waits = dist_on         # exposed (un-hidden) gradient-exchange time: an event pair around every wait for the communication stream
     t0 = time.perf_counter()
     sync_losses = bool(getattr(args, "sync_losses", False))
     loss_lag = max(1, int(getattr(args, "loss_lag", 2)))
@@ -358,11 +363,11 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
         engine.losses(lagged=0 if sync_losses else loss_lag)
         host_enq += h1 - h0; host_wait += time.perf_counter() - h1
     engine.flush()                         # ... and the last one to the timed region: exactly K complete iterations
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -370,7 +375,7 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
     log("timed region done: %.2f ms/step" % (1e3 * dt / steps))
     reducer.time_waits = False
     exposed_ms, n_waits = reducer.exposed_ms()
-    if world > 1:
+    if dist_on:
         t = torch.tensor([exposed_ms], device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         exposed_ms = float(t.item())
@@ -417,7 +422,7 @@ def train_record(args, rank, world, device, B, T, steps, warmup, cpu_iters, n_ba
                    "global_batch": world * B, "parallelism": "dp%d" % world},
         "mel_frames_per_s": sample_iters * T,
         "step_mfma_fraction": sample_iters * ALG_GFLOP_PER_SAMPLE_ITER / 1e3 / (PEAK_FP32_MFMA_TFLOPS * world),
-        "exposed_comm_ms_per_step": (exposed_ms / steps) if world > 1 else 0.0, "comm_waits_per_step": n_waits / steps,
+        "exposed_comm_ms_per_step": (exposed_ms / steps) if dist_on else 0.0, "comm_waits_per_step": n_waits / steps,
         "losses_finite": finite, "last_losses": final, "schedule": schedule, "host": host, "n_batches": len(batches), "deterministic": bool(args.deterministic),
         "identity_loss_lambda": float(sched.identity_loss_lambda),
     }
@@ -492,6 +497,12 @@ def main():
     if args.deterministic:
         from mask_cyclegan_vc import _hip
         _hip.lib().mcvc_set_deterministic(1)
+    if args.rccl_one_rank:
+        if world != 1 or args.mode != "train":
+            raise SystemExit("--rccl-one-rank is a single-process training self-check")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29571")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        args.no_extra_configs = True
     if args.mode == "infer":
         res = infer_record(args, rank, world, device, args.dtype or "bf16", args.batch_size if args.batch_size != 1 else 16,
                            args.frames if args.frames != 64 else 512, args.steps, args.warmup)
@@ -535,7 +546,7 @@ def main():
             if res is not None and rec is not None:
                 res["after_identity_cutoff"] = {"ms_per_step": rec["ms_per_step"], "iters_per_s": rec["value"], "identity_loss_lambda": rec["identity_loss_lambda"],
                                                 "note": "same config with identity_loss_lambda = 0 (train.py:314-315): > 97 % of a canonical run's iterations"}
-    info = dist_info(world, device)
+    info = dist_info(world, device, force=args.rccl_one_rank)
     degraded = []
     if world > 1 and args.mode == "train":
         if info["rccl_ranks_seen"] != world:
@@ -548,6 +559,9 @@ def main():
         if degraded:
             res["degraded"] = degraded
         print(json.dumps(res))
+    if args.rccl_one_rank:
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
     if world > 1:
         flag = torch.tensor([1.0 if degraded else 0.0], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)

@@ -403,8 +403,10 @@ static bool conv_wino(Exec& ex, const ConvSpec& c, const float* packed, int dgra
 {
     if (!c.wino || !wino_enabled() || !ex.wv) return false;
     if (wino4_applies(ex, c, NB, H, W) && conv_wino4(ex, c, packed, dgrad, NB, H, W, x, y, shuffle, accumulate)) return true;
-    // (bit 128: the 36-point sets of the layers whose EVERY pass takes the 4 x 4 scheme were not refreshed -- gen_pack_cfg)
-    if (!ex.dry && (ex.pack_skips & 128) && (long long)(H / 4) * (W / 4) >= wino4_min_tiles()) { ex.fail(MCVC_ERR_INVALID); return true; }
+    // (bits 128 / 256: the 36-point sets of upSample1 / upSample2 were not refreshed -- gen_pack_cfg skips them for a layer whose EVERY pass at
+    //  the engine's frame count takes the 4 x 4 scheme; recorded per LAYER, so a pass at another frame count on the same packed buffer that
+    //  does reach this path reads no stale set: ADVICE r5)
+    if (!ex.dry && (ex.pack_skips & (c.Cout == 1024 ? 128 : 256))) { ex.fail(MCVC_ERR_INVALID); return true; }
     const int K = dgrad ? c.cout_tot : c.Cin, M = dgrad ? c.Cin : c.cout_tot;
     const int TH = (H + 1) / 2, TW = (W + 1) / 2;
     const int nbc = wino_chunk(NB, (long long)TH * TW);
@@ -2378,7 +2380,7 @@ static GenPackCfg gen_pack_cfg(int max_batch, int T)
     const bool all4 = q.w4 && wino4_min_nb() == 1;
     q.up1_w2 = !(all4 && 5LL * (T / 16) >= wino4_min_tiles());
     q.up2_w2 = !(all4 && 10LL * (T / 8) >= wino4_min_tiles());
-    q.skipped = (q.fused ? (q.wino_only ? 3 : 1) : 0) | (q.w4 ? 0 : 16) | (q.w43 ? 0 : 32) | ((q.up1_w2 && q.up2_w2) ? 0 : 128);
+    q.skipped = (q.fused ? (q.wino_only ? 3 : 1) : 0) | (q.w4 ? 0 : 16) | (q.w43 ? 0 : 32) | (q.up1_w2 ? 0 : 128) | (q.up2_w2 ? 0 : 256);
     return q;
 }
 // range_mask bits: 1 = parameters [100,110), 2 = [24,100), 4 = [0,24); r4: the head in three parts, in the order their gradients become final

@@ -217,7 +217,7 @@ int mcvc_wgemm_launch(const WGemmArgs& a0, hipStream_t s)
     if (!a.c2) { a.c2 = a.c; a.m_split = a.M; }
     if (a.m_split & 31) return MCVC_ERR_INVALID;                 // (a wave's 32 rows lie on one side of it)
     a.nstages = cdiv_i(a.NPIX, WGK);
-    if (a.nsplit > a.nstages) a.nsplit = a.nstages;
+    if (a.nsplit > a.nstages) return MCVC_ERR_INVALID;            // (the caller sums ITS slab count with dw_accum: never clamp behind its back -- ADVICE r5)
     a.nt = a.Cin / cib; a.mt = a.M / WBM;
     a.ldc = (long long)a.Cin * a.ntaps;
     const double K = (double)a.NPIX;

@@ -193,6 +193,7 @@ class TrainEngine:
             self._g_ranges[n] = [(off[100], off[110]), (off[24], off[100]), (off[0], off[24])]
         self._workspaces = {}
         self._max_B = batch_size
+        self.force_inflight = getattr(TrainEngine, "FORCE_INFLIGHT", None)   # test hook: see _set_residency (class attribute = default for new engines)
         self._use(batch_size)
         self.reducer.broadcast_(self.g_group.flat)
         self.reducer.broadcast_(self.d_group.flat)
@@ -264,7 +265,6 @@ class TrainEngine:
         for k, v in ws.items():
             setattr(self, k, v)
         self._resid = None
-        self.force_inflight = getattr(TrainEngine, "FORCE_INFLIGHT", None)   # test hook: see _set_residency (class attribute = default for new engines)
         self._set_residency()
         self._cur_set = 0
         self.static_in = self.static_sets[0]

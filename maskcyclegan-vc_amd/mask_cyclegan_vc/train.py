@@ -161,9 +161,11 @@ class MaskCycleGANVCTraining(object):
 
     def train(self):
         """The reference's loop (train.py:175-315).  The engine's pipelined step completes an iteration's discriminator phase beside the
-        NEXT iteration's generator phase, so an iteration's losses reach the host one ``step()`` later: the logger is fed iteration t's
-        losses (both of them, like the reference's ``.item()`` reads at :303) right after iteration t+1 has been issued, and the last
-        iteration of an epoch after the epoch's flush -- the log lines are the reference's, line for line."""
+        NEXT iteration's generator phase, and the host reads a COMPLETE iteration LOSS_LAG = 2 ``step()``s behind so that it never waits for
+        work it has just queued: the logger is fed iteration t's losses (both of them, like the reference's ``.item()`` reads at :303) right
+        after iteration t+2 has been issued, the epoch's last iterations after the epoch's flush -- the log lines are the reference's, line for
+        line, two iterations late (the NaN probe below lags by the same two iterations; ``bench.py --sync-losses`` prices the reference-exact
+        readback at +15 %: INTEGRATION.md)."""
         done = 0
         for epoch in range(self.start_epoch, self.num_epochs + 1):
             self.logger.start_epoch()
@@ -193,7 +195,15 @@ class MaskCycleGANVCTraining(object):
                 self.logger.end_iter()
             for run_step in self._epoch_batches():
                 self.logger.start_iter()
-                run_step()                                                 # G phase, (previous) D phase, lr / lambda bookkeeping
+                try:
+                    run_step()                                             # G phase, (previous) D phase, lr / lambda bookkeeping
+                except Exception:
+                    # any other failure on this rank (data error, out of memory): publish it through the same control collective the other
+                    # ranks enter in log_one, so they abort with this rank instead of blocking in gloo until its timeout
+                    if self._ctl_group is not None:
+                        import torch.distributed as dist
+                        dist.all_reduce(torch.tensor([1], dtype=torch.int32), op=dist.ReduceOp.MAX, group=self._ctl_group)
+                    raise
                 owed += 1
                 # Host read of a COMPLETE iteration: the LOSS_LAG-th newest.  Reading the newest (lag 1) waits for the discriminator phase this
                 # step() has just queued -- the host then issues the next iteration into a drained GPU (0.3 - 0.5 ms of a 6 ms step at bs=1,
@@ -207,7 +217,10 @@ class MaskCycleGANVCTraining(object):
                 if self.args.max_iters and done >= self.args.max_iters:
                     break
             while owed > 1:                                                # the epoch's tail: iterations published but not read yet, oldest first
-                log_one(self.engine.losses(lagged=owed - 1))
+                lo = self.engine.losses(lagged=owed - 1) if self.engine._pending_D is not None else None
+                if lo is None:                                             # (nothing pending / read before: only the newest is left to report)
+                    break
+                log_one(lo)
                 owed -= 1
             if owed:
                 log_one(self.engine.losses())                              # completes the epoch's last iteration (flush) and reads it
