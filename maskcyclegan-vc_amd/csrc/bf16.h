@@ -53,6 +53,9 @@ int mcvc_bf16_norm_splits(int N, int P, int Cn);
 // ---- edges -----------------------------------------------------------------------------------------------------------
 // xin[b][h][w][kw*2 + ci] = (ci == 0 ? x*mask : mask)[b][h][w + kw - 7]  (kw < 15; zero outside the image; channels 30, 31 zero)
 int mcvc_bf16_prep_launch(const float* x, const float* mask, bf16_t* xin, int B, int H, int W, hipStream_t s);
+// conv1 + its input preparation + its gated GLU in one launch (model.py:241-242): y[b][h][w][128] bf16 from x, mask fp32 [B][H][W] (mask may
+// be null = ones); w / bias = the FOLD_KW pack of conv1 | conv1_gates with glu_interleave ([256][5][32] bf16, [256] fp32)
+int mcvc_bf16_conv1_fused_launch(const float* x, const float* mask, const bf16_t* w, const float* bias, bf16_t* y, int B, int H, int W, hipStream_t s);
 // out[b][h][w] = bias + sum_kw z[b][h][w + kw - 7][kw]      (z: [B][H][W][32] bf16, kw < 15) -- the last 5x15 conv's kw reduction
 int mcvc_bf16_last_launch(const bf16_t* z, const float* bias, float* out, int B, int H, int W, hipStream_t s);
 

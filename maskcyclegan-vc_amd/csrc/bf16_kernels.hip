@@ -998,6 +998,96 @@ __global__ void __launch_bounds__(256) bf16_prep_kernel(const float* __restrict_
     }
 }
 
+// ---- conv1 of the inference forward, fused with its input preparation and its gated GLU (r6) -----------------------------------------
+// model.py:241-242  conv1(stack(x * mask, mask)) * sigmoid(conv1_gates(...)),  2 -> 128 | 128 channels, 5 x 15, padding (2, 7).
+// As a generic tile (bf16_conv_kernel<2,2,2,2,1,4> over the folded input of bf16_prep_kernel) the layer was 10 240 workgroups of FIVE
+// pipeline stages each -- prologue, weight DMA and epilogue latency around 10 MFMA steps -- and ran at 1.6 TB/s, a third of what its
+// 210 MB of traffic allow (133 + 16 us of a 2.93 ms forward).  Here a workgroup owns a strip of 32 output columns x SH rows of one sample:
+//   * the strip's (x * mask, mask) pairs with halo -- (SH + 4) rows x 46 columns, 4 bytes per pixel -- are built ONCE in LDS straight from
+//     the fp32 inputs: the folded 32-channel tensor (42 MB written + 42 MB read per forward) and its kernel no longer exist;
+//   * the layer's whole weight slice of a wave (64 packed rows = 32 value + their 32 gate channels, K = 5 x 32) lives in REGISTERS
+//     (2 x 10 x 4 VGPRs), read once per workgroup; the four waves split the 128 output channels and share the staged strip;
+//   * per output row: 10 k-steps x 2 MFMAs per wave, the pixel operand of a k-step = 4 consecutive staged pixels (kw = 8 h2 + 4 half + j)
+//     of row r + kh; accumulators start from the bias; GLU + bf16 store as in the generic epilogue.
+// Same arithmetic as prep + conv (bf16 products of the same operands, fp32 accumulation; only the summation order inside the MFMA chain
+// differs: kh-major here as there).
+constexpr int kC1W = 32, kC1Halo = 14, kC1Pitch = kC1W + kC1Halo + 1;      // staged row pitch 47 words (odd: the two lane halves' windows spread over the banks)
+template <int SH>
+__global__ void __launch_bounds__(256) bf16_conv1_fused_kernel(const float* __restrict__ x, const float* __restrict__ mask, const bf16_t* __restrict__ w,
+                                                               const float* __restrict__ bias, bf16_t* __restrict__ y, int H, int W, int segs)
+{
+    __shared__ unsigned xs[(SH + 4) * kC1Pitch];
+    __shared__ __attribute__((aligned(16))) float sbias[256];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int strips = (W + kC1W - 1) / kC1W;
+    int b = blockIdx.x;
+    const int strip = b % strips; b /= strips;
+    const int seg = b % segs; const int n = b / segs;
+    const int w0 = strip * kC1W, h0 = seg * SH;
+    // ---- weights -> registers: packed [256][5][32] bf16, rows in 64-row blocks [32 value | 32 gate] (Bf16PackArgs::glu_interleave)
+    u32x4 areg[2][10];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const bf16_t* wr = w + (long long)(wave * 64 + mt * 32 + l31) * 160 + 8 * half;
+#pragma unroll
+        for (int s = 0; s < 10; ++s) areg[mt][s] = *reinterpret_cast<const u32x4*>(wr + (s >> 1) * 32 + (s & 1) * 16);
+    }
+    sbias[tid] = bias ? bias[tid] : 0.f;
+    // ---- the strip: staged column c <-> image column w0 - 7 + c, staged row r <-> image row h0 - 2 + r; zero outside the image
+    const float* xn = x + (long long)n * H * W;
+    const float* mn = mask ? mask + (long long)n * H * W : nullptr;
+    for (int i = tid; i < (SH + 4) * kC1Pitch; i += 256) {       // (all 47 columns: the last one is read by the zero-weight tap kw = 15 and must be finite)
+        const int r = i / kC1Pitch, c = i - r * kC1Pitch;
+        const int ih = h0 - 2 + r, iw = w0 - 7 + c;
+        float xv = 0.f, mv = 0.f;
+        if (ih >= 0 && ih < H && iw >= 0 && iw < W) {
+            mv = mn ? mn[(long long)ih * W + iw] : 1.0f;
+            xv = xn[(long long)ih * W + iw] * mv;
+        }
+        xs[r * kC1Pitch + c] = pack2bf(xv, mv);
+    }
+    __syncthreads();
+    const int ow = w0 + l31;
+    const unsigned* xl = xs + l31 + 4 * half;
+    for (int r = 0; r < SH; ++r) {
+        const int oh = h0 + r;
+        if (oh >= H) break;
+        f32x16 acc[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bv = *reinterpret_cast<const float4*>(sbias + wave * 64 + mt * 32 + 8 * q + 4 * half);
+                acc[mt][4 * q] = bv.x; acc[mt][4 * q + 1] = bv.y; acc[mt][4 * q + 2] = bv.z; acc[mt][4 * q + 3] = bv.w;
+            }
+#pragma unroll
+        for (int s = 0; s < 10; ++s) {
+            const unsigned* p = xl + (r + (s >> 1)) * kC1Pitch + 8 * (s & 1);
+            u32x4 bv;
+            bv.x = p[0]; bv.y = p[1]; bv.z = p[2]; bv.w = p[3];
+            const bf16x8 bb = __builtin_bit_cast(bf16x8, bv);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, areg[0][s]), bb, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, areg[1][s]), bb, acc[1], 0, 0, 0);
+        }
+        if (ow < W) {
+            bf16_t* yp = y + (((long long)n * H + oh) * W + ow) * 128 + wave * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = acc[0][4 * q + j] * sigmoidf_(acc[1][4 * q + j]);
+                uint2 pk2;
+                pk2.x = pack2bf(o[0], o[1]);
+                pk2.y = pack2bf(o[2], o[3]);
+                *reinterpret_cast<uint2*>(yp + 8 * q + 4 * half) = pk2;
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) bf16_last_kernel(const bf16_t* __restrict__ z, const float* __restrict__ bias, float* __restrict__ out,
                                                         int B, int H, int W)
 {
@@ -1093,6 +1183,16 @@ int mcvc_bf16_prep_launch(const float* x, const float* mask, bf16_t* xin, int B,
 {
     TraceScope ts(K_ELEMENTWISE, s, 0.0, (double)B * H * W * (8.0 + 64.0));
     hipLaunchKernelGGL(bf16_prep_kernel, dim3(ew_blocks((long long)B * H * W * 4)), dim3(256), 0, s, x, mask, xin, B, H, W);
+    return (int)hipGetLastError();
+}
+
+int mcvc_bf16_conv1_fused_launch(const float* x, const float* mask, const bf16_t* w, const float* bias, bf16_t* y, int B, int H, int W, hipStream_t s)
+{
+    constexpr int SH = 20;
+    const int strips = cdiv_i(W, kC1W), segs = cdiv_i(H, SH);
+    const double px = (double)B * H * W;
+    TraceScope ts(K_CONV_L, s, 2.0 * px * 256 * 160, px * (8.0 + 2.0 * 128) + 2.0 * 256 * 160);
+    hipLaunchKernelGGL(bf16_conv1_fused_kernel<SH>, dim3((unsigned)(B * segs * strips)), dim3(256), 0, s, x, mask, w, bias, y, H, W, segs);
     return (int)hipGetLastError();
 }
 

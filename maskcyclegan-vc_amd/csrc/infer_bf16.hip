@@ -166,8 +166,16 @@ static void forward(Run& r, const float* x, const float* mask, float* out, const
     auto B16 = [&](long long off) { return reinterpret_cast<bf16_t*>(r.ws + off); };
     const int B = d.B, T = d.T, W2 = d.W2, W4 = d.W4, Wu1 = d.Wu1, Wu2 = d.Wu2;
     // model.py:241-242: stack(x*mask, mask), the 15 kernel columns folded into the channel axis; gated 5x15 conv, GLU in the epilogue
-    r.fail(mcvc_bf16_prep_launch(x, mask, B16(w.xin), B, 80, T, r.s));
-    conv(r, n.conv1, B16(w.xin), 80LL * T * 32, T * 32, 32, B, 80, T, B16(w.y1), 80LL * T * 128, T * 128, 128, 128);
+    // (r6: one launch -- the folded tensor is built in LDS, the weights live in registers; MCVC_BF16_CONV1_FUSED=0 in the experiments build
+    //  restores input-prep kernel + generic tile for the A/B)
+    static const int c1_fused = mcvc_knob("MCVC_BF16_CONV1_FUSED", 1);
+    if (c1_fused) {
+        r.fail(mcvc_bf16_conv1_fused_launch(x, mask, reinterpret_cast<const bf16_t*>(r.pk + n.conv1.off_w), reinterpret_cast<const float*>(r.pk + n.conv1.off_bias),
+                                            B16(w.y1), B, 80, T, r.s));
+    } else {
+        r.fail(mcvc_bf16_prep_launch(x, mask, B16(w.xin), B, 80, T, r.s));
+        conv(r, n.conv1, B16(w.xin), 80LL * T * 32, T * 32, 32, B, 80, T, B16(w.y1), 80LL * T * 128, T * 128, 128, 128);
+    }
     // :245 downSample1
     conv(r, n.ds1, B16(w.y1), 80LL * T * 128, T * 128, 128, B, 80, T, B16(w.c2), 40LL * W2 * 512, W2 * 512, 512, 512);
     norm(r, B16(w.c2), 40LL * W2 * 512, W2 * 512, 512, B, 40, W2, 512, 0, BF16_ACT_GLU, P[6], P[7], P[10], P[11], nullptr,

@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(256, (BN == 64 ? 3 : 4)) wino_gemm_kernel(cons
     };
     // Two-level accumulation (r6): `acc` runs over kFoldK k, then folds into `tot`.  An fp32 chain of L fused multiply-adds carries a
     // rounding error ~ eps * L / sqrt(2) of one term; in the Winograd domain that error is amplified by the cancellation of the output
-    // transform, and the K-long chain was 97 % of the schemes' error (tools/wino_error_model.py).  Chains of 32 + a chain of c = K / 32 partial
+    // transform, and the K-long chain was most of the schemes' error (tools/parity_probe.py ops: profiles/r06_parity_ops_{before,after}_fold.log).  Chains of 32 + a chain of c = K / 32 partial
     // sums: error ~ sqrt(L^2 / c + L c) instead of L: 2.5x smaller at K = 256, 3.3x at 512, 4x at 1024 (the optimum is c = sqrt(L)).
     f32x16 acc[NACC], tot[NACC];
 #pragma unroll

@@ -363,6 +363,31 @@ def test_step_is_bit_reproducible_in_deterministic_mode(deterministic_mode, B):
             assert torch.equal(a, b), n
 
 
+@pytest.mark.parametrize("B", [1, 8])
+def test_no_result_depends_on_a_float_the_step_did_not_write(deterministic_mode, B):
+    """the wide trunk's 1 x 3 implicit GEMMs (more than 64 columns per pass: B = 8) read shifted windows over DENSE rows,
+    and the element a window picks up beyond a row's end -- for the first / last row of a tensor a float in FRONT of / BEHIND the tensor,
+    i.e. in whatever the allocator handed the neighbouring stash / scratch region -- must contribute exactly 0 whatever it holds.  The
+    mask is a bit-and on the loaded value (csrc/sgemm_kernels.hip zmasked; a scale would turn NaN / Inf into NaN).  Here every free block
+    of the caching allocator is filled with NaN before the engine allocates its workspaces (torch.empty: the engine's stashes and scratch
+    then START as NaN wherever a kernel has not written yet): three iterations must equal the un-poisoned run bit for bit."""
+    seeds = [540 + i for i in range(6)]
+    l0, p0, _ = _three_steps(False, seeds, B)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    junk = [torch.full((128 * 1024 * 1024,), float("nan"), device="cuda") for _ in range(24)]       # 12 GiB of NaN (bs=8 state + workspaces: 8.3 GB)
+    small = [torch.full((n,), float("nan"), device="cuda") for n in (64, 1024, 16384, 262144) for _ in range(64)]   # the small-block pool too
+    torch.cuda.synchronize()
+    del junk, small
+    l1, p1, _ = _three_steps(False, seeds, B)
+    assert all(np.isfinite(v) for pair in l1 for v in pair), l1
+    assert l0 == l1, (l0, l1)
+    for n in p0:
+        for a, b in zip(p0[n], p1[n]):
+            assert torch.isfinite(b).all(), n
+            assert torch.equal(a, b), n
+
+
 def test_default_mode_stays_close_run_to_run():
     """Default (fast) mode: a few K-split accumulations use atomics, so runs agree to rounding, not bitwise."""
     seeds = [500 + i for i in range(6)]

@@ -46,13 +46,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--compute-ms", type=float, default=1.7, help="length of the stand-in for the last generator backward passes")
+    ap.add_argument("--one-rank", action="store_true", help="single-GPU self-run: a ONE-rank nccl (= RCCL) group with the reducer forced on -- "
+                    "proves library load (HSA_ENABLE_IPC_MODE_LEGACY=0), the communication stream and the event ordering; the 'bandwidth' of a "
+                    "1-rank all-reduce is RCCL's launch + local copy cost, not xGMI")
     args = ap.parse_args()
-    rank, world, local_rank = init_from_env()
-    if world < 2:
-        raise SystemExit("run under torch.distributed.run with at least 2 ranks")
+    if args.one_rank:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29573")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        rank, world, local_rank = 0, 1, 0
+    else:
+        rank, world, local_rank = init_from_env()
+        if world < 2:
+            raise SystemExit("run under torch.distributed.run with at least 2 ranks (or --one-rank on a single GPU)")
     dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(dev)
-    red = FlatGradReducer()
+    red = FlatGradReducer(force=args.one_rank)
     out = {"backend": dist.get_backend(), "world": world, "buckets": [], "iteration": {}}
     ring = 2.0 * (world - 1) / world
     for mb in sorted(set(G_RANGES_MB) | {64.0, 25.0, 34.6}):
