@@ -202,6 +202,16 @@ int mcvc_gen_infer_bf16(const float* const* params, const void* packed, const fl
 long long mcvc_bf16_conv2d_pack_bytes(int Cout, int Cin, int KH, int KW);
 int mcvc_bf16_conv2d(const void* x, const float* w, const float* bias, void* y, void* wpack, int N, int H, int W, int Cin, int Cout,
                      int KH, int KW, int stride, int pad_h, int pad_w, void* stream);
+/*      conv1 of the bf16 forward with its input preparation and gated GLU fused (r6; model.py:241-242):
+ *      y[B][80][T][128] bf16 NHWC = conv2d(stack(x * mask, mask), w, b, padding (2, 7)) * sigmoid(conv2d(..., wg, bg)); x, mask fp32 [B][80][T]
+ *      (mask NULL = ones), w / wg [128][2][5][15], b / bg [128] fp32; wpack: mcvc_bf16_conv1_glu_pack_bytes() bytes, 16-byte aligned.     */
+long long mcvc_bf16_conv1_glu_pack_bytes(void);
+int mcvc_bf16_conv1_glu(const float* x, const float* mask, const float* w, const float* b, const float* wg, const float* bg, void* y, void* wpack,
+                        int B, int T, void* stream);
+/*      the generator's last conv (r6; model.py:207-211, 278-279) through the fused kernel of the bf16 forward: out[B][80][T] fp32 =
+ *      conv2d(x[B][80][T][128] bf16 NHWC, w[1][128][5][15], b[1], padding (2, 7)); wpack: mcvc_bf16_last_conv_pack_bytes() bytes, 16-byte aligned. */
+long long mcvc_bf16_last_conv_pack_bytes(void);
+int mcvc_bf16_last_conv(const void* x, const float* w, const float* b, float* out, void* wpack, int B, int T, void* stream);
 /*      y = act(InstanceNorm(x)) (+ residual): act 0 none, 1 gated GLU (Cx = 2C: value | gate), 2 x*sigmoid(x); pixel_shuffle != 0:
  *      the normalised tensor is PixelShuffle(2)(x), output [N][2H][2W][Cx/4].  scratch: N * 65 * Cx * 2 floats.      */
 int mcvc_bf16_instnorm_act(const void* x, const float* gamma, const float* beta, const float* gamma_gate, const float* beta_gate,

@@ -59,6 +59,10 @@ int mcvc_bf16_conv1_fused_launch(const float* x, const float* mask, const bf16_t
 // out[b][h][w] = bias + sum_kw z[b][h][w + kw - 7][kw]      (z: [B][H][W][32] bf16, kw < 15) -- the last 5x15 conv's kw reduction
 int mcvc_bf16_last_launch(const bf16_t* z, const float* bias, float* out, int B, int H, int W, hipStream_t s);
 
+// the last conv (128 -> 1, 5 x 15) + its kernel-column sum + bias in one launch: out[b][h][w] fp32 from x [B][H][W][128] bf16; w = the KW_OUT
+// pack ([32][5][4][32] bf16: row = kernel column), bias = the layer's scalar bias (device pointer) or null
+int mcvc_bf16_last_fused_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* out, int B, int H, int W, hipStream_t s);
+
 // ---- weight packing (fp32 OIHW parameters -> bf16 [Cout_pad][KH][Cin/32][KW][32]) -------------------------------------
 enum Bf16PackKind {
     BF16_PACK_PLAIN = 0,       // k index = ci (Cin_src % 32 == 0)

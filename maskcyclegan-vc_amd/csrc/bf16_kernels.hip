@@ -1106,6 +1106,109 @@ __global__ void __launch_bounds__(256) bf16_last_kernel(const bf16_t* __restrict
     }
 }
 
+// ---- the last conv of the inference forward (128 -> 1, 5 x 15, padding (2, 7): model.py:207-211, 278-279) in ONE launch (r6) -----------
+// The generic form computed the 15 kernel columns as 15 (of 32) output channels of a 5 x 1 conv -- z[b][h][w][32] bf16, 42 MB written and
+// re-read -- and a second kernel summed the shifted planes (73.8 + 34.5 us; the 168 MB activation read allows ~35).  Here:
+//   * Z[kw][w'] = sum_{kh, ci} W[ci][kh][kw] x[ci][h + kh - 2][w'] per INPUT column w' on v_mfma_f32_16x16x32_bf16 (16 rows = 15 taps + a zero
+//     row: no wasted half tile), the whole weight tensor (16 x 640 bf16) in REGISTERS (5 x 4 operands), the pixel operand straight from
+//     global memory (a lane's 8 k = 8 consecutive channels of its pixel: one 16-byte load), next row's loads in flight during this row's MFMAs;
+//   * every input row is loaded ONCE and feeds the five output rows it reaches (kh = 0..4) -- five rotating accumulator sets, the row loop
+//     unrolled by five so that the rotation is a compile-time renaming; an output row is complete after its kh = 4 contribution;
+//   * y[h][w] = bias + sum_kw Z[kw][w + kw - 7]: the finished 16 x 128 fp32 tile goes through LDS (double-buffered: one barrier per row),
+//     114 threads sum their anti-diagonal.  fp32 all the way (the two-kernel form rounded Z to bf16 in between).
+constexpr int kLastCols = 128, kLastOut = kLastCols - 14, kLastPitch = kLastCols + 4;
+template <int SH>
+__global__ void __launch_bounds__(256) bf16_last_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ out, int H, int W, int segs)
+{
+    __shared__ float Zs[2][16][kLastPitch];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int strips = (W + kLastOut - 1) / kLastOut;
+    int b = blockIdx.x;
+    const int strip = b % strips; b /= strips;
+    const int seg = b % segs; const int n = b / segs;
+    const int c0 = strip * kLastOut - 7, h0 = seg * SH;
+    // weights: packed [32][5][4][32] bf16 (BF16_PACK_KW_OUT: row = kernel column, rows >= 15 zero); lane: row l15, k = 8 kg .. 8 kg + 7 of a 32-k step
+    u32x4 areg[5][4];
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) areg[kh][cc] = *reinterpret_cast<const u32x4*>(w + ((l15 * 5 + kh) * 4 + cc) * 32 + 8 * kg);
+    const float bs = bias ? bias[0] : 0.f;
+    int col[2]; bool cok[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) { col[nt] = c0 + wave * 32 + nt * 16 + l15; cok[nt] = col[nt] >= 0 && col[nt] < W; }
+    auto load_row = [&](int i, u32x4 (&bv)[2][4]) __attribute__((always_inline)) {
+        const int ih = h0 - 2 + i;
+        const bool rok = ih >= 0 && ih < H;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const bf16_t* p = x + (((long long)n * H + (rok ? ih : 0)) * W + (cok[nt] ? col[nt] : 0)) * 128 + 8 * kg;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                u32x4 v = *reinterpret_cast<const u32x4*>(p + cc * 32);
+                if (!(rok && cok[nt])) v = u32x4{0u, 0u, 0u, 0u};
+                bv[nt][cc] = v;
+            }
+        }
+    };
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    f32x4_ acc[5][2];
+#pragma unroll
+    for (int s = 0; s < 5; ++s)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[s][nt] = f32x4_{0.f, 0.f, 0.f, 0.f};
+    u32x4 bcur[2][4], bnxt[2][4];
+    load_row(0, bcur);
+    int buf = 0;
+    for (int i0 = 0; i0 < SH + 4; i0 += 5) {
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int i = i0 + u;
+            if (i < SH + 4) {                                       // (uniform)
+                if (i + 1 < SH + 4) load_row(i + 1, bnxt);
+#pragma unroll
+                for (int kh = 0; kh < 5; ++kh) {
+                    constexpr int kFive = 5;
+                    const int slot = (u + kFive - kh) % kFive;     // output row i - kh: compile-time after unrolling
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {
+                            const f32x4_ cin = (kh == 0 && cc == 0) ? f32x4_{0.f, 0.f, 0.f, 0.f} : acc[slot][nt];       // kh = 0 opens the output row
+                            acc[slot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, areg[kh][cc]),
+                                                                                    __builtin_bit_cast(bf16x8, bcur[nt][cc]), cin, 0, 0, 0);
+                        }
+                }
+                const int r = i - 4;                                 // the output row whose kh = 4 contribution was just added
+                if (r >= 0 && r < SH && h0 + r < H) {                // (uniform)
+                    const int slot = (u + 1) % 5;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Zs[buf][4 * kg + j][wave * 32 + nt * 16 + l15] = acc[slot][nt][j];
+                    __syncthreads();
+                    const int ow = strip * kLastOut + tid;
+                    if (tid < kLastOut && ow < W) {
+                        float s = bs;
+#pragma unroll
+                        for (int kw = 0; kw < 15; ++kw) s += Zs[buf][kw][tid + kw];
+                        out[((long long)n * H + h0 + r) * W + ow] = s;
+                    }
+                    buf ^= 1;
+                }
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) bcur[nt][cc] = bnxt[nt][cc];
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) bf16_pack_kernel(const Bf16PackArgs a)
 {
     const int ncc = a.Cin >> 5;
@@ -1200,6 +1303,16 @@ int mcvc_bf16_last_launch(const bf16_t* z, const float* bias, float* out, int B,
 {
     TraceScope ts(K_ELEMENTWISE, s, 0.0, (double)B * H * W * (64.0 + 4.0));
     hipLaunchKernelGGL(bf16_last_kernel, dim3(ew_blocks((long long)B * H * W)), dim3(256), 0, s, z, bias, out, B, H, W);
+    return (int)hipGetLastError();
+}
+
+int mcvc_bf16_last_fused_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* out, int B, int H, int W, hipStream_t s)
+{
+    constexpr int SH = 10;
+    const int strips = cdiv_i(W, kLastOut), segs = cdiv_i(H, SH);
+    const double px = (double)B * H * W;
+    TraceScope ts(K_CONV_L, s, 2.0 * px * 16 * 640, px * (256.0 + 4.0) + 2.0 * 32 * 640);
+    hipLaunchKernelGGL(bf16_last_fused_kernel<SH>, dim3((unsigned)(B * segs * strips)), dim3(256), 0, s, x, w, bias, out, H, W, segs);
     return (int)hipGetLastError();
 }
 

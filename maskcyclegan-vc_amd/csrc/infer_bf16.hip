@@ -216,8 +216,14 @@ static void forward(Run& r, const float* x, const float* mask, float* out, const
     norm(r, B16(w.c8), 40LL * Wu1 * 512, Wu1 * 512, 512, B, 40, Wu1, 512, 1, BF16_ACT_SILU, P[102], P[103], nullptr, nullptr, nullptr,
          B16(w.y8), 80LL * Wu2 * 128, Wu2 * 128, 128);
     // :278-279 last conv: 15 kernel columns as output channels, then the column sum (+ bias)
-    conv(r, n.last, B16(w.y8), 80LL * Wu2 * 128, Wu2 * 128, 128, B, 80, Wu2, B16(w.z), 80LL * Wu2 * 32, Wu2 * 32, 32, 32);
-    r.fail(mcvc_bf16_last_launch(B16(w.z), P[109], out, B, 80, Wu2, r.s));
+    // (r6: one launch, fp32 kernel-column sum in LDS; MCVC_BF16_LAST_FUSED=0 in the experiments build restores conv + shifted-plane sum)
+    static const int last_fused = mcvc_knob("MCVC_BF16_LAST_FUSED", 1);
+    if (last_fused) {
+        r.fail(mcvc_bf16_last_fused_launch(B16(w.y8), reinterpret_cast<const bf16_t*>(r.pk + n.last.off_w), P[109], out, B, 80, Wu2, r.s));
+    } else {
+        conv(r, n.last, B16(w.y8), 80LL * Wu2 * 128, Wu2 * 128, 128, B, 80, Wu2, B16(w.z), 80LL * Wu2 * 32, Wu2 * 32, 32, 32);
+        r.fail(mcvc_bf16_last_launch(B16(w.z), P[109], out, B, 80, Wu2, r.s));
+    }
 }
 
 static void pack_layer(Run& r, const LayerB& l, unsigned char* pk)
@@ -302,6 +308,46 @@ int mcvc_bf16_conv2d(const void* x, const float* w, const float* bias, void* y, 
     const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
     conv(r, l, static_cast<const bf16_t*>(x), (long long)H * W * Cin, W * Cin, Cin, N, H, W, static_cast<bf16_t*>(y), (long long)OH * OW * Cout,
          OW * Cout, Cout, Cout);
+    return r.err;
+}
+
+// y[B][80][T][128] (bf16 NHWC) = conv1(stack(x * mask, mask)) * sigmoid(conv1_gates(...)) -- model.py:241-242 -- through the fused kernel the
+// forward uses: w / wg [128][2][5][15], b / bg [128] fp32; x, mask fp32 [B][80][T] (mask NULL = ones); wpack: mcvc_bf16_conv1_glu_pack_bytes()
+long long mcvc_bf16_conv1_glu_pack_bytes(void) { return 2LL * 256 * 5 * 32 + 4LL * 256 + 512; }
+
+int mcvc_bf16_conv1_glu(const float* x, const float* mask, const float* w, const float* b, const float* wg, const float* bg, void* y, void* wpack,
+                        int B, int T, void* stream)
+{
+    if (!x || !w || !b || !wg || !bg || !y || !wpack || B < 1 || T < 1) return MCVC_ERR_INVALID;
+    if (reinterpret_cast<uintptr_t>(wpack) & 15) return MCVC_ERR_INVALID;
+    LayerB l = net().conv1;
+    l.w0 = 0; l.b0 = 1; l.w1 = 2; l.b1 = 3;
+    l.off_w = 0; l.off_bias = (2LL * 256 * 5 * 32 + 255) & ~255LL;
+    const float* P[4] = {w, b, wg, bg};
+    Run r{}; r.s = (hipStream_t)stream; r.P = P;
+    unsigned char* pk = static_cast<unsigned char*>(wpack);
+    pack_layer(r, l, pk);
+    r.fail(mcvc_bf16_conv1_fused_launch(x, mask, reinterpret_cast<const bf16_t*>(pk + l.off_w), reinterpret_cast<const float*>(pk + l.off_bias),
+                                        static_cast<bf16_t*>(y), B, 80, T, r.s));
+    return r.err;
+}
+
+// out[B][80][T] fp32 = conv2d(x, w, b, padding (2, 7)) for the generator's last layer (model.py:207-211): x [B][80][T][128] bf16 NHWC,
+// w [1][128][5][15], b [1] fp32 -- through the fused kernel the forward uses; wpack: mcvc_bf16_last_conv_pack_bytes()
+long long mcvc_bf16_last_conv_pack_bytes(void) { return 2LL * 32 * 5 * 128 + 4LL * 32 + 512; }
+
+int mcvc_bf16_last_conv(const void* x, const float* w, const float* b, float* out, void* wpack, int B, int T, void* stream)
+{
+    if (!x || !w || !out || !wpack || B < 1 || T < 1) return MCVC_ERR_INVALID;
+    if (reinterpret_cast<uintptr_t>(wpack) & 15) return MCVC_ERR_INVALID;
+    LayerB l = net().last;
+    l.w0 = 0; l.b0 = 1;
+    l.off_w = 0; l.off_bias = (2LL * 32 * 5 * 128 + 255) & ~255LL;
+    const float* P[2] = {w, b};
+    Run r{}; r.s = (hipStream_t)stream; r.P = P;
+    unsigned char* pk = static_cast<unsigned char*>(wpack);
+    pack_layer(r, l, pk);
+    r.fail(mcvc_bf16_last_fused_launch(static_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(pk + l.off_w), b, out, B, 80, T, r.s));
     return r.err;
 }
 

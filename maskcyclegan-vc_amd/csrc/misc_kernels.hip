@@ -179,7 +179,7 @@ struct LossCombineArgs { int n; int loss_dst[16]; int term_dst[16]; };
 struct LossCombineKArgs { const float* pairs; float* slots; LossCombineArgs c; };
 __global__ void loss_combine_kernel(const Twin<LossCombineKArgs> tw)
 {
-    const LossCombineKArgs ka_ = tw.v[blockIdx.z];
+    const LossCombineKArgs& ka_ = tw.v[blockIdx.z];      // (by reference: the run-time indices c.*_dst[k] then read the argument segment, not a scratch copy)
     const float* __restrict__ pairs = ka_.pairs;
     float* __restrict__ slots = ka_.slots;
     const LossCombineArgs& c = ka_.c;

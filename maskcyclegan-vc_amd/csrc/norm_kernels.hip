@@ -144,7 +144,11 @@ __global__ void __launch_bounds__(256) norm_bwd_kernel(const Twin<NormBwdArgs> t
     const int nbr = (a.act == ACT_GLU) ? 2 : 1;
     const int Cx = a.C * nbr;
     float gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f};
-    for (int br = 0; br < nbr; ++br) { gam[br] = a.gamma[br][c]; bet[br] = a.beta[br][c]; }
+    // (constant indices only: a run-time index into the by-value argument struct -- a.gamma[br] -- made the compiler keep ALL 216 bytes of it in
+    //  scratch memory: every thread wrote its copy and read the fields back, 54 KB of private-segment traffic per workgroup -- the '6x its own
+    //  bytes' the PMC passes reported for this family (r6: profiles/r06_norm_bwd_probe.log, tools/isa_scan.py `scratch` column))
+    gam[0] = a.gamma[0][c]; bet[0] = a.beta[0][c];
+    if (nbr == 2) { gam[1] = a.gamma[1][c]; bet[1] = a.beta[1][c]; }
     float dgam[2] = {0.f, 0.f}, dbet[2] = {0.f, 0.f};
     const int oh_w = a.W >> 1;   // conv-grid width when un-shuffling
     (void)oh_w;
@@ -225,9 +229,11 @@ __global__ void __launch_bounds__(256) norm_bwd_kernel(const Twin<NormBwdArgs> t
             for (int br = 0; br < nbr; ++br) dyp_zero_borders<G>(a.dx + (long long)n * a.dx_sn + (long long)(c + br * a.C) * a.dx_sc, a.H, a.W, a.dx_pitch, l);
     }
     if (l == 0) {
-        for (int br = 0; br < nbr; ++br) {
-            if (a.dgamma[br]) a.dgamma[br][c] += dgam[br];
-            if (a.dbeta[br]) a.dbeta[br][c] += dbet[br];
+        if (a.dgamma[0]) a.dgamma[0][c] += dgam[0];
+        if (a.dbeta[0]) a.dbeta[0][c] += dbet[0];
+        if (nbr == 2) {
+            if (a.dgamma[1]) a.dgamma[1][c] += dgam[1];
+            if (a.dbeta[1]) a.dbeta[1][c] += dbet[1];
         }
     }
 }
@@ -337,7 +343,8 @@ __global__ void __launch_bounds__(256) norm_bwd_reg_kernel(const Twin<NormBwdArg
     const int nbr = (a.act == ACT_GLU) ? 2 : 1;
     const int Cx = a.C * nbr;
     float gam[2] = {0.f, 0.f}, bet[2] = {0.f, 0.f};
-    for (int br = 0; br < nbr; ++br) { gam[br] = a.gamma[br][c]; bet[br] = a.beta[br][c]; }
+    gam[0] = a.gamma[0][c]; bet[0] = a.beta[0][c];        // (constant indices: see norm_bwd_kernel)
+    if (nbr == 2) { gam[1] = a.gamma[1][c]; bet[1] = a.beta[1][c]; }
     float dgam[2] = {0.f, 0.f}, dbet[2] = {0.f, 0.f};
     // blockIdx.y = a chunk of samples (large batches: the per-sample work is independent, only dgamma / dbeta are sums over samples;
     // with more than one chunk they are added with atomics -- the launcher uses one chunk in deterministic mode)
@@ -430,13 +437,18 @@ __global__ void __launch_bounds__(256) norm_bwd_reg_kernel(const Twin<NormBwdArg
             for (int br = 0; br < nbr; ++br) dyp_zero_borders<G>(a.dx + (long long)n * a.dx_sn + (long long)(c + br * a.C) * a.dx_sc, a.H, a.W, a.dx_pitch, l);
     }
     if (l == 0 && n_begin < n_end) {
-        for (int br = 0; br < nbr; ++br) {
-            if (nchunk > 1) {
-                if (a.dgamma[br]) unsafeAtomicAdd(&a.dgamma[br][c], dgam[br]);
-                if (a.dbeta[br]) unsafeAtomicAdd(&a.dbeta[br][c], dbet[br]);
-            } else {
-                if (a.dgamma[br]) a.dgamma[br][c] += dgam[br];
-                if (a.dbeta[br]) a.dbeta[br][c] += dbet[br];
+        float* const dgp[2] = {a.dgamma[0], a.dgamma[1]};
+        float* const dbp[2] = {a.dbeta[0], a.dbeta[1]};
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+            if (br < nbr) {
+                if (nchunk > 1) {
+                    if (dgp[br]) unsafeAtomicAdd(&dgp[br][c], dgam[br]);
+                    if (dbp[br]) unsafeAtomicAdd(&dbp[br][c], dbet[br]);
+                } else {
+                    if (dgp[br]) dgp[br][c] += dgam[br];
+                    if (dbp[br]) dbp[br][c] += dbet[br];
+                }
             }
         }
     }

@@ -73,6 +73,10 @@ _SIGS = {
     "mcvc_bf16_conv2d_pack_bytes": (c_longlong, [c_int, c_int, c_int, c_int]),
     "mcvc_bf16_conv2d": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
     "mcvc_bf16_instnorm_act": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
+    "mcvc_bf16_last_conv_pack_bytes": (c_longlong, []),
+    "mcvc_bf16_last_conv": (c_int, [c_void_p] * 5 + [c_int] * 2 + [c_void_p]),
+    "mcvc_bf16_conv1_glu_pack_bytes": (c_longlong, []),
+    "mcvc_bf16_conv1_glu": (c_int, [c_void_p] * 8 + [c_int] * 2 + [c_void_p]),
     "mcvc_disc_forward": (c_int, [_PP, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p]),
     "mcvc_disc_backward": (c_int, [_PP, c_void_p, _PP, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p]),
     "mcvc_l1_loss": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

@@ -62,6 +62,56 @@ def test_bf16_conv_matches_fp32_conv_on_the_same_rounded_operands(N, H, W, Cin, 
     assert e < 4e-3, e
 
 
+@pytest.mark.parametrize("B,T,masked", [(2, 64, True), (1, 65, False), (3, 40, True), (1, 512, True), (2, 20, False)])
+def test_bf16_fused_conv1_matches_fp32_on_the_same_rounded_operands(B, T, masked):
+    """r6: conv1 + its input preparation + its gated GLU in ONE launch (bf16_conv1_fused_kernel: the (x * mask, mask) strip built in LDS from the
+    fp32 inputs, the layer's weights in registers) -- model.py:241-242.  Reference: F.conv2d on the bf16-rounded stack(x * mask, mask) with
+    the bf16-rounded weights, fp32 bias, value * sigmoid(gate); ragged T (strips of 32 columns overhang), T < 32, mask = None (ones)."""
+    L = lib()
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(B, 80, T, generator=g).cuda()
+    mask = None
+    if masked:
+        mask = torch.ones(B, 80, T)
+        for b in range(B):
+            s0 = int(torch.randint(0, max(T - 12, 1), (1,), generator=g)); mask[b, :, s0:s0 + min(12, T // 2)] = 0.0
+        mask = mask.cuda()
+    w = (torch.randn(128, 2, 5, 15, generator=g) / 150 ** 0.5).cuda(); wg = (torch.randn(128, 2, 5, 15, generator=g) / 150 ** 0.5).cuda()
+    bv, bg = torch.randn(128, generator=g).cuda(), torch.randn(128, generator=g).cuda()
+    y = torch.full((B, 80, T, 128), float("nan"), dtype=torch.bfloat16, device="cuda")
+    wpack = torch.zeros(L.mcvc_bf16_conv1_glu_pack_bytes(), dtype=torch.uint8, device="cuda")
+    check(L.mcvc_bf16_conv1_glu(ptr(x), ptr(mask), ptr(w), ptr(bv), ptr(wg), ptr(bg), ptr(y), ptr(wpack), B, T, stream()), "bf16_conv1_glu")
+    m = mask if mask is not None else torch.ones_like(x)
+    xin = torch.stack((x * m, m), dim=1).to(torch.bfloat16).float()
+    v = F.conv2d(xin, w.to(torch.bfloat16).float(), bv, 1, (2, 7))
+    gt = F.conv2d(xin, wg.to(torch.bfloat16).float(), bg, 1, (2, 7))
+    ref = v * torch.sigmoid(gt)
+    got = y.float().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    e = rel(got, ref)
+    assert e < 4e-3, e
+
+
+@pytest.mark.parametrize("B,T", [(2, 64), (1, 65), (1, 512), (3, 20), (1, 240)])
+def test_bf16_fused_last_conv_matches_fp32_on_the_same_rounded_operands(B, T):
+    """r6: the generator's last conv (128 -> 1, 5 x 15; model.py:207-211) in ONE launch (bf16_last_fused_kernel: 15 kernel columns as MFMA rows,
+    weights in registers, every input row loaded once for its five output rows, fp32 kernel-column sum through LDS).  Reference: F.conv2d on
+    the bf16 activations with bf16-rounded weights in fp32.  The output is fp32 (no output rounding): 1e-3.  T = 65 / 240 / 20: ragged strips
+    of 114 output columns, a strip narrower than one tile."""
+    L = lib()
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(B, 128, 80, T, generator=g).cuda().to(torch.bfloat16)
+    w = (torch.randn(1, 128, 5, 15, generator=g) / (128 * 75) ** 0.5).cuda()
+    b = torch.randn(1, generator=g).cuda()
+    out = torch.full((B, 80, T), float("nan"), device="cuda")
+    wpack = torch.zeros(L.mcvc_bf16_last_conv_pack_bytes(), dtype=torch.uint8, device="cuda")
+    check(L.mcvc_bf16_last_conv(ptr(x.permute(0, 2, 3, 1).contiguous()), ptr(w), ptr(b), ptr(out), ptr(wpack), B, T, stream()), "bf16_last_conv")
+    ref = F.conv2d(x.float(), w.to(torch.bfloat16).float(), b, 1, (2, 7))[:, 0]
+    assert torch.isfinite(out).all()
+    e = rel(out, ref)
+    assert e < 1e-3, e
+
+
 @pytest.mark.parametrize("N,H,W,Cx,act,shuffle,res", [(2, 40, 32, 512, 1, 0, False), (3, 1, 16, 1024, 1, 0, False), (3, 1, 16, 256, 0, 0, True),
                                                       (2, 20, 16, 1024, 2, 1, False), (1, 40, 128, 512, 2, 1, False), (2, 1, 128, 5120, 0, 0, False)])
 def test_bf16_instnorm_act_matches_fp32(N, H, W, Cx, act, shuffle, res):
