@@ -212,6 +212,13 @@ int mcvc_bf16_conv1_glu(const float* x, const float* mask, const float* w, const
  *      conv2d(x[B][80][T][128] bf16 NHWC, w[1][128][5][15], b[1], padding (2, 7)); wpack: mcvc_bf16_last_conv_pack_bytes() bytes, 16-byte aligned. */
 long long mcvc_bf16_last_conv_pack_bytes(void);
 int mcvc_bf16_last_conv(const void* x, const float* w, const float* b, float* out, void* wpack, int B, int T, void* stream);
+/*      one layer of a residual block (r6; model.py:47-76) through the fused kernel of the bf16 forward -- Conv1d(k = 3, padding 1) + InstanceNorm1d
+ *      (affine) + {value * sigmoid(gate) when w_gate != NULL | + residual}: x [B][W][Cin], y / residual [B][W][C] bf16 (channel-innermost);
+ *      w / w_gate [C][Cin][3], gamma / beta (+ the gate's) [C] fp32.  W <= 128, Cin = 256 or 512, C % 32 == 0, else MCVC_ERR_INVALID
+ *      (the forward then runs conv + norm as two launches).  wpack: mcvc_bf16_trunk_layer_pack_bytes() bytes, 16-byte aligned.               */
+long long mcvc_bf16_trunk_layer_pack_bytes(int Cin, int C, int gated);
+int mcvc_bf16_trunk_layer(const void* x, const float* w, const float* w_gate, const float* gamma, const float* beta, const float* gamma_gate,
+                          const float* beta_gate, const void* residual, void* y, void* wpack, int B, int W, int Cin, int C, void* stream);
 /*      y = act(InstanceNorm(x)) (+ residual): act 0 none, 1 gated GLU (Cx = 2C: value | gate), 2 x*sigmoid(x); pixel_shuffle != 0:
  *      the normalised tensor is PixelShuffle(2)(x), output [N][2H][2W][Cx/4].  scratch: N * 65 * Cx * 2 floats.      */
 int mcvc_bf16_instnorm_act(const void* x, const float* gamma, const float* beta, const float* gamma_gate, const float* beta_gate,

@@ -63,6 +63,14 @@ int mcvc_bf16_last_launch(const bf16_t* z, const float* bias, float* out, int B,
 // pack ([32][5][4][32] bf16: row = kernel column), bias = the layer's scalar bias (device pointer) or null
 int mcvc_bf16_last_fused_launch(const bf16_t* x, const bf16_t* w, const float* bias, float* out, int B, int H, int W, hipStream_t s);
 
+// ---- a residual-block layer in one launch (r6): y = {IN(conv1d_3(x; w0)) * sigmoid(IN(conv1d_3(x; w1))) | IN(conv1d_3(x; w0)) + res} on [B][W][C] bf16 rows,
+// W <= 128 (T <= 512 frames), Cin in {256, 512}, C % 32 == 0.  w: mcvc_bf16_trunk_pack_launch's operand-order copy (elems() bf16).
+bool mcvc_bf16_trunk_layer_applies(int W, int Cin, int C);
+long long mcvc_bf16_trunk_pack_elems(int Cin, int C, int glu);
+int mcvc_bf16_trunk_pack_launch(const float* w0, const float* w1, bf16_t* dst, int Cin, int C, int glu, hipStream_t s);
+int mcvc_bf16_trunk_layer_launch(const bf16_t* x, long long x_sn, const bf16_t* w, const float* g0, const float* b0, const float* g1, const float* b1,
+                                 const bf16_t* res, bf16_t* y, long long y_sn, int B, int W, int Cin, int C, int glu, float eps, hipStream_t s);
+
 // ---- weight packing (fp32 OIHW parameters -> bf16 [Cout_pad][KH][Cin/32][KW][32]) -------------------------------------
 enum Bf16PackKind {
     BF16_PACK_PLAIN = 0,       // k index = ci (Cin_src % 32 == 0)

@@ -1209,6 +1209,223 @@ __global__ void __launch_bounds__(256) bf16_last_fused_kernel(const bf16_t* __re
     }
 }
 
+// ---- a residual-block layer of the inference forward in ONE launch (r6) ---------------------------------------------------------------
+// model.py:47-76 at inference: Conv1d(k = 3, padding 1) + InstanceNorm1d(affine) + {value * sigmoid(gate) | + residual}.  Until r6 each of the
+// 12 layers was a 64 x 64-tile convolution (8-16 barrier-bound stages, 14.3 us) + a one-launch InstanceNorm (9.7 us) that re-read the
+// conv output.  InstanceNorm needs a whole (sample, channel) row; at T <= 512 frames that row is W = T/4 <= 128 columns = ONE MFMA tile
+// width, so the convolution's own workgroup can finish the layer:
+//   * a workgroup owns 32 output channels of ONE sample across all W columns.  GLU layers: 64 MFMA rows = per 32-row tile [16 value | their
+//     16 gate] rows -- accumulator registers r and r + 8 of a lane are then the value and the gate of the SAME channel and column, the GLU
+//     needs no exchange; waves 2 (row tiles) x 2 (column halves).  Plain layers: one 32-row tile, waves 1 x 4.
+//   * the sample's input row block [W + 2][Cin] (zero halo) is staged ONCE in LDS (pixel pitch Cin * 2 + 16 bytes: the 32 pixels of an
+//     operand read hit distinct 16-byte bank slots); tap kw reads the window shifted by kw pixels.
+//   * the weights are packed in operand order -- [row tile][k-step][64 lanes][8 bf16], k = kw * Cin + ci -- so a wave's A operand of a
+//     k-step is ONE coalesced 1 KB load straight into registers (ring of eight steps in flight; no LDS, no barrier in the K loop).
+//   * epilogue in registers: per-row sum / sum of squares over the valid columns (lane butterfly + one LDS hand-over between the waves that
+//     share rows), scale / shift from gamma, beta (the conv bias cancels under the norm and is never read), GLU or residual, bf16 store.
+// Statistics are taken on the fp32 accumulators (the two-launch form took them on the bf16-rounded conv output).
+struct Bf16TrunkArgs {
+    const bf16_t* x; long long x_sn;          // [B][W][Cin]
+    const bf16_t* w;                          // [row tile][k-step][64][8] (bf16_trunk_pack_kernel)
+    const float* g0; const float* b0; const float* g1; const float* b1;       // affine of the value (| gate) InstanceNorm, [C]
+    const bf16_t* res;                        // residual [B][W][C] or null
+    bf16_t* y; long long y_sn;                // [B][W][C]
+    int W, Cin, C;
+    float eps;
+};
+constexpr int kTrunkMaxW = 128;
+
+template <bool GLU, int CIN>
+__global__ void __launch_bounds__(256) bf16_trunk_layer_kernel(const Bf16TrunkArgs a)
+{
+    // (CIN is a template parameter so that the K loop unrolls COMPLETELY: with a loop back edge the compiler copies the weight ring's registers
+    //  there and waits vmcnt(0) for them -- the ring then drained every eight steps, 12 L2 round trips per layer)
+    constexpr int WN = GLU ? 2 : 4, NT = GLU ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = GLU ? (wave >> 1) : 0, wn = GLU ? (wave & 1) : wave;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n = blockIdx.y;
+    const int wgt = blockIdx.x;                                  // 32 output channels
+    const int tile = GLU ? (wgt * 2 + wm) : wgt;                 // 32-row tile of the packed weights
+    constexpr int S = 3 * CIN / 16;                              // k-steps (k = kw * Cin + ci)
+    constexpr int pitch = CIN * 2 + 16;                          // bytes per staged pixel
+    unsigned char* Xs = smem;                                    // [kTrunkMaxW + 2][pitch]
+    float* red = reinterpret_cast<float*>(smem + (size_t)(kTrunkMaxW + 2) * pitch);      // [2][WN][32][2]
+    // ---- A ring: the first eight k-steps are requested before anything else
+    const u32x4* wp = reinterpret_cast<const u32x4*>(a.w) + (long long)tile * S * 64 + lane;
+    u32x4 aq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) aq[u] = wp[(long long)u * 64];
+    // ---- stage the sample's rows: staged pixel p' <-> image pixel p' - 1; zero outside [0, W)
+    {
+        constexpr int c8n = CIN >> 3;                            // 16-byte pieces per pixel
+        const int total = (kTrunkMaxW + 2) * c8n;
+        const bf16_t* xb = a.x + (long long)n * a.x_sn;
+        // (17 pieces per thread in flight at once: the whole 256-channel block in one round of loads, the 512-channel block in two --
+        //  eight at a time made this staging five dependent L2 round trips, 10 us of a 46 us layer)
+        constexpr int SB = 17;
+        for (int i0 = tid; i0 < total; i0 += 256 * SB) {
+            u32x4 v[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int i = i0 + u * 256;
+                const int pp = i / c8n, c8 = i - pp * c8n, px = pp - 1;
+                v[u] = u32x4{0u, 0u, 0u, 0u};
+                if (i < total && px >= 0 && px < a.W) v[u] = *reinterpret_cast<const u32x4*>(xb + (long long)px * CIN + c8 * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int i = i0 + u * 256;
+                const int pp = i / c8n, c8 = i - pp * c8n;
+                if (i < total) *reinterpret_cast<u32x4*>(Xs + (size_t)pp * pitch + c8 * 16) = v[u];
+            }
+        }
+    }
+    __syncthreads();
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    const int col0 = wn * (32 * NT) + l31;                       // this lane's column of n-tile 0
+    const unsigned xs0 = lds_addr(Xs) + (unsigned)col0 * (unsigned)pitch + (unsigned)half * 16u;
+    // K loop: the pixel operand of step s + 1 is requested BEFORE step s waits (LDS returns in order: lgkmcnt(NT) = "everything but the newest NT
+    // reads has landed"), so a step costs its MFMAs, not an LDS round trip; two operand sets alternate by the step's parity (eight steps per
+    // block: the parity is a compile-time property of the unrolled body, nothing is copied at the loop's back edge)
+    auto blk_addr = [&](int s0) __attribute__((always_inline)) {
+        const int k0 = s0 * 16, kw = k0 / CIN, ci0 = k0 - kw * CIN;                // (eight steps = 128 channels of one tap: Cin % 128 == 0)
+        return xs0 + (unsigned)kw * (unsigned)pitch + (unsigned)ci0 * 2u;
+    };
+    u32x4 bv[2][NT];
+    auto request = [&](unsigned base, int u, u32x4 (&b_)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(b_[nt]) : "v"(base + (unsigned)(nt * 32) * (unsigned)pitch), "i"(u * 32));
+    };
+    unsigned xb_ = blk_addr(0);
+    request(xb_, 0, bv[0]);
+#pragma unroll
+    for (int s0 = 0; s0 < S; s0 += 8) {
+        const unsigned xnext = blk_addr(s0 + 8 < S ? s0 + 8 : s0);
+        // (branch-free body: past the end the ring re-requests the last step's weights and the first operand of this block -- a conditional
+        //  load ends the compiler's counter tracking, and it then waits vmcnt(0) after every weight load: the ring overlapped nothing)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u < 7) request(xb_, u + 1, bv[(u + 1) & 1]);
+            else request(xnext, 0, bv[0]);
+            const u32x4 av = aq[u];
+            const int sn = (s0 + 8 + u < S) ? (s0 + 8 + u) : (S - 1);
+            aq[u] = wp[(long long)sn * 64];
+            if constexpr (NT == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(bv[u & 1][0]), "+v"(bv[u & 1][1]));
+            else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bv[u & 1][0]));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv[u & 1][nt]), acc[nt], 0, 0, 0);
+        }
+        xb_ = xnext;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (the dangling request of the last step)
+    // ---- statistics of every MFMA row over the valid columns.  Register r <-> row (r & 3) + 8 (r >> 2) + 4 half.
+    float s1[16], s2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const bool ok = col0 + nt * 32 < a.W;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float v = ok ? acc[nt][r] : 0.f; s1[r] += v; s2[r] += v * v; }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+    if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float* q = red + (((wm * WN + wn) * 32 + row) << 1);
+            q[0] = s1[r]; q[1] = s2[r];
+        }
+    }
+    __syncthreads();
+    const float invW = 1.0f / (float)a.W;
+    float sc[16], sh[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) { const float* q = red + (((wm * WN + j) * 32 + row) << 1); t1 += q[0]; t2 += q[1]; }
+        const float mean = t1 * invW;
+        float var = t2 * invW - mean * mean;
+        if (var < 0.f) var = 0.f;
+        const float rstd = 1.0f / sqrtf(var + a.eps);
+        float g, b;
+        if (GLU) { const int c = tile * 16 + (row & 15); g = (row < 16) ? a.g0[c] : a.g1[c]; b = (row < 16) ? a.b0[c] : a.b1[c]; }
+        else { const int c = tile * 32 + row; g = a.g0[c]; b = a.b0[c]; }
+        sc[r] = rstd * g; sh[r] = b - mean * sc[r];
+    }
+    // ---- normalise, GLU / residual, store (4 consecutive channels per register quad: 8-byte stores)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int px = col0 + nt * 32;
+        if (px >= a.W) continue;
+        const long long po = (long long)n * a.y_sn + (long long)px * a.C;
+        if constexpr (GLU) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 4 * q + j;
+                    const float z0 = acc[nt][r] * sc[r] + sh[r], z1 = acc[nt][r + 8] * sc[r + 8] + sh[r + 8];
+                    o[j] = z0 * sigmoidf_(z1);
+                }
+                uint2 pk2; pk2.x = pack2bf(o[0], o[1]); pk2.y = pack2bf(o[2], o[3]);
+                *reinterpret_cast<uint2*>(a.y + po + tile * 16 + 8 * q + 4 * half) = pk2;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = tile * 32 + 8 * q + 4 * half;
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = acc[nt][4 * q + j] * sc[4 * q + j] + sh[4 * q + j];
+                if (a.res) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(a.res + po + c);
+                    o[0] += __uint_as_float(rv.x << 16); o[1] += __uint_as_float(rv.x & 0xffff0000u);
+                    o[2] += __uint_as_float(rv.y << 16); o[3] += __uint_as_float(rv.y & 0xffff0000u);
+                }
+                uint2 pk2; pk2.x = pack2bf(o[0], o[1]); pk2.y = pack2bf(o[2], o[3]);
+                *reinterpret_cast<uint2*>(a.y + po + c) = pk2;
+            }
+        }
+    }
+}
+
+// weights of a trunk layer in operand order: dst[((tile * S + s) * 64 + lane) * 8 + j] = W[row(tile, lane & 31)][k = 16 s + 8 (lane >> 5) + j],
+// k = kw * Cin + ci; GLU: tile rows 0-15 = value channels 16 tile .. 16 tile + 15 (w0), rows 16-31 = their gates (w1); source OIHW [Cout][Cin][1][3]
+__global__ void __launch_bounds__(256) bf16_trunk_pack_kernel(const float* __restrict__ w0, const float* __restrict__ w1, bf16_t* __restrict__ dst,
+                                                              int Cin, int tiles, int glu)
+{
+    const int S = 3 * Cin / 16;
+    const long long total = (long long)tiles * S * 64 * 8;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const long long ts = idx >> 9;
+        const int s = (int)(ts % S), tile = (int)(ts / S);
+        const int row = lane & 31, k = 16 * s + 8 * (lane >> 5) + j;
+        const int kw = k / Cin, ci = k - kw * Cin;
+        const float* src = w0; int co;
+        if (glu) { co = tile * 16 + (row & 15); if (row >= 16) src = w1; }
+        else co = tile * 32 + row;
+        dst[idx] = f2bf(src[((long long)co * Cin + ci) * 3 + kw]);
+    }
+}
+
 __global__ void __launch_bounds__(256) bf16_pack_kernel(const Bf16PackArgs a)
 {
     const int ncc = a.Cin >> 5;
@@ -1313,6 +1530,45 @@ int mcvc_bf16_last_fused_launch(const bf16_t* x, const bf16_t* w, const float* b
     const double px = (double)B * H * W;
     TraceScope ts(K_CONV_L, s, 2.0 * px * 16 * 640, px * (256.0 + 4.0) + 2.0 * 32 * 640);
     hipLaunchKernelGGL(bf16_last_fused_kernel<SH>, dim3((unsigned)(B * segs * strips)), dim3(256), 0, s, x, w, bias, out, H, W, segs);
+    return (int)hipGetLastError();
+}
+
+// ---- fused residual-block layer (bf16_trunk_layer_kernel): applies when a sample row fits one tile width and the channel counts fit the tiles
+bool mcvc_bf16_trunk_layer_applies(int W, int Cin, int C) { return W >= 1 && W <= kTrunkMaxW && (Cin == 256 || Cin == 512) && (C % 32) == 0; }
+long long mcvc_bf16_trunk_pack_elems(int Cin, int C, int glu) { return (long long)(glu ? 2 * C : C) * 3 * Cin; }
+
+int mcvc_bf16_trunk_pack_launch(const float* w0, const float* w1, bf16_t* dst, int Cin, int C, int glu, hipStream_t s)
+{
+    const int tiles = (glu ? 2 * C : C) / 32;
+    const long long total = (long long)tiles * (3 * Cin / 16) * 512;
+    hipLaunchKernelGGL(bf16_trunk_pack_kernel, dim3(ew_blocks(total)), dim3(256), 0, s, w0, w1, dst, Cin, tiles, glu);
+    return (int)hipGetLastError();
+}
+
+int mcvc_bf16_trunk_layer_launch(const bf16_t* x, long long x_sn, const bf16_t* w, const float* g0, const float* b0, const float* g1, const float* b1,
+                                 const bf16_t* res, bf16_t* y, long long y_sn, int B, int W, int Cin, int C, int glu, float eps, hipStream_t s)
+{
+    if (!mcvc_bf16_trunk_layer_applies(W, Cin, C)) return MCVC_ERR_INVALID;
+    Bf16TrunkArgs a{};
+    a.x = x; a.x_sn = x_sn; a.w = w; a.g0 = g0; a.b0 = b0; a.g1 = g1; a.b1 = b1; a.res = res; a.y = y; a.y_sn = y_sn;
+    a.W = W; a.Cin = Cin; a.C = C; a.eps = eps;
+    const size_t lds = (size_t)(kTrunkMaxW + 2) * (Cin * 2 + 16) + 2 * 4 * 32 * 2 * sizeof(float);
+    const double rows = glu ? 2.0 * C : (double)C;
+    TraceScope ts(K_CONV_L, s, 2.0 * B * W * rows * 3 * Cin, 2.0 * ((double)B * W * Cin * (C / 32) + (double)B * W * C * (res ? 2 : 1) + rows * 3 * Cin * B));
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipSuccess;
+#define MCVC_TRUNK_ATTR(G, CI) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_trunk_layer_kernel<G, CI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        MCVC_TRUNK_ATTR(true, 256) MCVC_TRUNK_ATTR(true, 512) MCVC_TRUNK_ATTR(false, 256) MCVC_TRUNK_ATTR(false, 512)
+#undef MCVC_TRUNK_ATTR
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    const dim3 grid((unsigned)(C / 32), (unsigned)B);
+    if (glu && Cin == 256) hipLaunchKernelGGL((bf16_trunk_layer_kernel<true, 256>), grid, dim3(256), lds, s, a);
+    else if (glu) hipLaunchKernelGGL((bf16_trunk_layer_kernel<true, 512>), grid, dim3(256), lds, s, a);
+    else if (Cin == 256) hipLaunchKernelGGL((bf16_trunk_layer_kernel<false, 256>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((bf16_trunk_layer_kernel<false, 512>), grid, dim3(256), lds, s, a);
     return (int)hipGetLastError();
 }
 

@@ -34,6 +34,7 @@ struct LayerB {
 struct NetB {
     LayerB conv1, ds1, ds2, c2d1d, res_vg[6], res_out[6], c1d2d, up1, up2, last;
     long long off_g6, off_b6;      // permuted affine of conv1dto2dLayer_tfan
+    long long off_tvg[6], off_tout[6];   // operand-order weight copies of the residual blocks for the fused layer kernel (r6)
     long long bytes;
 };
 
@@ -78,6 +79,7 @@ static NetB build_net()
     for (LayerB* l : all) place(*l);
     for (int i = 0; i < 6; ++i) { place(n.res_vg[i]); place(n.res_out[i]); }
     n.off_g6 = take(4LL * 5120); n.off_b6 = take(4LL * 5120);
+    for (int i = 0; i < 6; ++i) { n.off_tvg[i] = take(2 * mcvc_bf16_trunk_pack_elems(256, 512, 1)); n.off_tout[i] = take(2 * mcvc_bf16_trunk_pack_elems(512, 256, 0)); }
     n.bytes = cur;
     return n;
 }
@@ -192,7 +194,19 @@ static void forward(Run& r, const float* x, const float* mask, float* out, const
          B16(w.h[0]), (long long)W4 * 256, 0, 256);
     // :258-263 residual blocks
     int cur = 0;
-    for (int i = 0; i < 6; ++i) {
+    // (r6) T <= 512 frames: a sample's row is one tile wide, conv + InstanceNorm + GLU / residual of a layer are ONE launch (12 launches for the
+    // six blocks instead of 24); longer inputs, or MCVC_BF16_TRUNK_FUSED=0 in the experiments build, take the two-launch form below
+    static const int trunk_fused = mcvc_knob("MCVC_BF16_TRUNK_FUSED", 1);
+    const bool fused = trunk_fused && mcvc_bf16_trunk_layer_applies(W4, 256, 512) && mcvc_bf16_trunk_layer_applies(W4, 512, 256);
+    for (int i = 0; i < 6 && fused; ++i) {
+        const int b = 24 + 12 * i;
+        r.fail(mcvc_bf16_trunk_layer_launch(B16(w.h[cur]), (long long)W4 * 256, reinterpret_cast<const bf16_t*>(r.pk + n.off_tvg[i]), P[b + 2], P[b + 3], P[b + 6],
+                                            P[b + 7], nullptr, B16(w.ya), (long long)W4 * 512, B, W4, 256, 512, 1, kEps, r.s));
+        r.fail(mcvc_bf16_trunk_layer_launch(B16(w.ya), (long long)W4 * 512, reinterpret_cast<const bf16_t*>(r.pk + n.off_tout[i]), P[b + 10], P[b + 11], nullptr,
+                                            nullptr, B16(w.h[cur]), B16(w.h[cur ^ 1]), (long long)W4 * 256, B, W4, 512, 256, 0, kEps, r.s));
+        cur ^= 1;
+    }
+    for (int i = 0; i < 6 && !fused; ++i) {
         const int b = 24 + 12 * i;
         const int G = n.res_vg[i].stride;                   // channel groups folded into the position axis (build_net)
         conv(r, n.res_vg[i], B16(w.h[cur]), (long long)W4 * 256, 0, 256 / G, B, 1, G * W4, B16(w.ca), (long long)W4 * 1024, 0, 1024, 1024);
@@ -262,6 +276,11 @@ int mcvc_gen_bf16_pack(const float* const* params, void* packed, void* stream)
     const LayerB* all[] = {&n.conv1, &n.ds1, &n.ds2, &n.c2d1d, &n.c1d2d, &n.up1, &n.up2, &n.last};
     for (const LayerB* l : all) pack_layer(r, *l, pk);
     for (int i = 0; i < 6; ++i) { pack_layer(r, n.res_vg[i], pk); pack_layer(r, n.res_out[i], pk); }
+    for (int i = 0; i < 6; ++i) {
+        const int b = 24 + 12 * i;
+        r.fail(mcvc_bf16_trunk_pack_launch(params[b + 0], params[b + 4], reinterpret_cast<bf16_t*>(pk + n.off_tvg[i]), 256, 512, 1, r.s));
+        r.fail(mcvc_bf16_trunk_pack_launch(params[b + 8], nullptr, reinterpret_cast<bf16_t*>(pk + n.off_tout[i]), 512, 256, 0, r.s));
+    }
     r.fail(mcvc_bf16_vec_launch(params[98], nullptr, reinterpret_cast<float*>(pk + n.off_g6), 5120, 5120, BF16_PACK_HC_OUT, r.s));
     r.fail(mcvc_bf16_vec_launch(params[99], nullptr, reinterpret_cast<float*>(pk + n.off_b6), 5120, 5120, BF16_PACK_HC_OUT, r.s));
     return r.err;
@@ -349,6 +368,23 @@ int mcvc_bf16_last_conv(const void* x, const float* w, const float* b, float* ou
     pack_layer(r, l, pk);
     r.fail(mcvc_bf16_last_fused_launch(static_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(pk + l.off_w), b, out, B, 80, T, r.s));
     return r.err;
+}
+
+// one residual-block layer through the fused kernel (model.py:47-76): x [B][W][Cin] bf16, w / w_gate [C][Cin][3] fp32 (w_gate NULL: plain layer with
+// optional residual [B][W][C]), gamma / beta (+ gate's) [C]; y [B][W][C] bf16; wpack: mcvc_bf16_trunk_layer_pack_bytes(Cin, C, gated) bytes
+long long mcvc_bf16_trunk_layer_pack_bytes(int Cin, int C, int gated) { return 2 * mcvc_bf16_trunk_pack_elems(Cin, C, gated) + 256; }
+
+int mcvc_bf16_trunk_layer(const void* x, const float* w, const float* w_gate, const float* gamma, const float* beta, const float* gamma_gate,
+                          const float* beta_gate, const void* residual, void* y, void* wpack, int B, int W, int Cin, int C, void* stream)
+{
+    if (!x || !w || !gamma || !beta || !y || !wpack || B < 1) return MCVC_ERR_INVALID;
+    if (w_gate && (!gamma_gate || !beta_gate)) return MCVC_ERR_INVALID;
+    if (!mcvc_bf16_trunk_layer_applies(W, Cin, C) || (reinterpret_cast<uintptr_t>(wpack) & 15)) return MCVC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int e = mcvc_bf16_trunk_pack_launch(w, w_gate, static_cast<bf16_t*>(wpack), Cin, C, w_gate ? 1 : 0, s);
+    if (e) return e;
+    return mcvc_bf16_trunk_layer_launch(static_cast<const bf16_t*>(x), (long long)W * Cin, static_cast<const bf16_t*>(wpack), gamma, beta, gamma_gate, beta_gate,
+                                        static_cast<const bf16_t*>(residual), static_cast<bf16_t*>(y), (long long)W * C, B, W, Cin, C, w_gate ? 1 : 0, kEps, s);
 }
 
 // y = act(InstanceNorm(x)) on NHWC bf16.  x: [N][H][W][Cx]; act 0 none, 1 gated GLU (Cx = 2C: value | gate), 2 x*sigmoid(x);

@@ -92,6 +92,37 @@ def test_bf16_fused_conv1_matches_fp32_on_the_same_rounded_operands(B, T, masked
     assert e < 4e-3, e
 
 
+@pytest.mark.parametrize("B,W,Cin,C,gated,res", [(3, 16, 256, 512, True, False), (3, 16, 512, 256, False, True), (2, 128, 256, 512, True, False),
+                                                  (2, 128, 512, 256, False, True), (1, 17, 256, 512, True, False), (2, 100, 512, 256, False, False),
+                                                  (1, 2, 256, 32, False, True), (2, 33, 512, 64, True, False)])
+def test_bf16_fused_trunk_layer_matches_fp32_on_the_same_rounded_operands(B, W, Cin, C, gated, res):
+    """r6: a residual-block layer (model.py:47-76) in ONE launch at inference -- conv1d(k = 3) + InstanceNorm1d + GLU / residual
+    (bf16_trunk_layer_kernel: the sample's row block staged once in LDS, weights streamed in MFMA operand order, statistics on the fp32
+    accumulators).  Reference: F.conv1d on the bf16-rounded x with bf16-rounded weights, F.instance_norm, fp32; W = 16 (64 frames), 128 (512
+    frames: the benchmark shape), ragged widths, a single column."""
+    L = lib()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(B, Cin, W, generator=g).cuda().to(torch.bfloat16)
+    w = (torch.randn(C, Cin, 3, generator=g) / (3 * Cin) ** 0.5).cuda()
+    wg = (torch.randn(C, Cin, 3, generator=g) / (3 * Cin) ** 0.5).cuda() if gated else None
+    ga, be = (1 + 0.2 * torch.randn(C, generator=g)).cuda(), (0.3 * torch.randn(C, generator=g)).cuda()
+    gg, bg = ((1 + 0.2 * torch.randn(C, generator=g)).cuda(), (0.3 * torch.randn(C, generator=g)).cuda()) if gated else (None, None)
+    r = torch.randn(B, W, C, generator=g).cuda().to(torch.bfloat16) if res else None
+    y = torch.full((B, W, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    wpack = torch.zeros(L.mcvc_bf16_trunk_layer_pack_bytes(Cin, C, 1 if gated else 0), dtype=torch.uint8, device="cuda")
+    check(L.mcvc_bf16_trunk_layer(ptr(x.permute(0, 2, 1).contiguous()), ptr(w), ptr(wg), ptr(ga), ptr(be), ptr(gg), ptr(bg), ptr(r), ptr(y), ptr(wpack),
+                                  B, W, Cin, C, stream()), "bf16_trunk_layer")
+    xf = x.float()
+    z = F.instance_norm(F.conv1d(xf, w.to(torch.bfloat16).float(), None, 1, 1), weight=ga, bias=be, eps=1e-5)
+    if gated:
+        z = z * torch.sigmoid(F.instance_norm(F.conv1d(xf, wg.to(torch.bfloat16).float(), None, 1, 1), weight=gg, bias=bg, eps=1e-5))
+    if res:
+        z = z + r.float().permute(0, 2, 1)
+    got = y.float().permute(0, 2, 1)
+    assert torch.isfinite(got).all()
+    assert rel(got, z) < 4e-3, rel(got, z)
+
+
 @pytest.mark.parametrize("B,T", [(2, 64), (1, 65), (1, 512), (3, 20), (1, 240)])
 def test_bf16_fused_last_conv_matches_fp32_on_the_same_rounded_operands(B, T):
     """r6: the generator's last conv (128 -> 1, 5 x 15; model.py:207-211) in ONE launch (bf16_last_fused_kernel: 15 kernel columns as MFMA rows,
