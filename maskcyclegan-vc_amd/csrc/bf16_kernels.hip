@@ -1141,18 +1141,16 @@ __global__ void __launch_bounds__(256) bf16_last_fused_kernel(const bf16_t* __re
     int col[2]; bool cok[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) { col[nt] = c0 + wave * 32 + nt * 16 + l15; cok[nt] = col[nt] >= 0 && col[nt] < W; }
+    // every load is unconditional (row / column clamped into the image, the value zeroed by a select where it lies outside): a conditional load
+    // ends the compiler's vmcnt bookkeeping and it then drains the queue after each one (r6: the first form had 50 `vmcnt(0)` in its row loop)
     auto load_row = [&](int i, u32x4 (&bv)[2][4]) __attribute__((always_inline)) {
-        const int ih = h0 - 2 + i;
-        const bool rok = ih >= 0 && ih < H;
+        int ih = h0 - 2 + i;
+        ih = ih < 0 ? 0 : (ih >= H ? H - 1 : ih);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const bf16_t* p = x + (((long long)n * H + (rok ? ih : 0)) * W + (cok[nt] ? col[nt] : 0)) * 128 + 8 * kg;
+            const bf16_t* p = x + (((long long)n * H + ih) * W + (cok[nt] ? col[nt] : 0)) * 128 + 8 * kg;
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                u32x4 v = *reinterpret_cast<const u32x4*>(p + cc * 32);
-                if (!(rok && cok[nt])) v = u32x4{0u, 0u, 0u, 0u};
-                bv[nt][cc] = v;
-            }
+            for (int cc = 0; cc < 4; ++cc) bv[nt][cc] = *reinterpret_cast<const u32x4*>(p + cc * 32);
         }
     };
     typedef float f32x4_ __attribute__((ext_vector_type(4)));
@@ -1161,50 +1159,51 @@ __global__ void __launch_bounds__(256) bf16_last_fused_kernel(const bf16_t* __re
     for (int s = 0; s < 5; ++s)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[s][nt] = f32x4_{0.f, 0.f, 0.f, 0.f};
-    u32x4 bcur[2][4], bnxt[2][4];
-    load_row(0, bcur);
+    // rows fully unrolled (SH + 4 input rows): the five rotating accumulator sets and the three-deep operand ring are compile-time
+    // renamings, no register is copied at a loop's back edge (which would wait for the loads in flight); two rows of loads stay in flight
+    constexpr int NR = SH + 4;
+    u32x4 bq[3][2][4];
+    load_row(0, bq[0]);
+    load_row(1, bq[1]);
     int buf = 0;
-    for (int i0 = 0; i0 < SH + 4; i0 += 5) {
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int i = i0 + u;
-            if (i < SH + 4) {                                       // (uniform)
-                if (i + 1 < SH + 4) load_row(i + 1, bnxt);
+    for (int i = 0; i < NR; ++i) {
+        if (i + 2 < NR) load_row(i + 2, bq[(i + 2) % 3]);
+        const int ih = h0 - 2 + i;
+        const bool rok = ih >= 0 && ih < H;                          // (uniform)
+        u32x4 bm[2][4];
 #pragma unroll
-                for (int kh = 0; kh < 5; ++kh) {
-                    constexpr int kFive = 5;
-                    const int slot = (u + kFive - kh) % kFive;     // output row i - kh: compile-time after unrolling
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
+            for (int cc = 0; cc < 4; ++cc) bm[nt][cc] = (rok && cok[nt]) ? bq[i % 3][nt][cc] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) {
-                            const f32x4_ cin = (kh == 0 && cc == 0) ? f32x4_{0.f, 0.f, 0.f, 0.f} : acc[slot][nt];       // kh = 0 opens the output row
-                            acc[slot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, areg[kh][cc]),
-                                                                                    __builtin_bit_cast(bf16x8, bcur[nt][cc]), cin, 0, 0, 0);
-                        }
+        for (int kh = 0; kh < 5; ++kh) {
+            const int slot = (i + 10 - kh) % 5;                      // output row i - kh
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const f32x4_ cin = (kh == 0 && cc == 0) ? f32x4_{0.f, 0.f, 0.f, 0.f} : acc[slot][nt];       // kh = 0 opens the output row
+                    acc[slot][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, areg[kh][cc]),
+                                                                            __builtin_bit_cast(bf16x8, bm[nt][cc]), cin, 0, 0, 0);
                 }
-                const int r = i - 4;                                 // the output row whose kh = 4 contribution was just added
-                if (r >= 0 && r < SH && h0 + r < H) {                // (uniform)
-                    const int slot = (u + 1) % 5;
+        }
+        const int r = i - 4;                                         // the output row whose kh = 4 contribution was just added
+        if (r >= 0 && r < SH && h0 + r < H) {                        // (compile-time && uniform)
+            const int slot = (i + 1) % 5;
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) Zs[buf][4 * kg + j][wave * 32 + nt * 16 + l15] = acc[slot][nt][j];
-                    __syncthreads();
-                    const int ow = strip * kLastOut + tid;
-                    if (tid < kLastOut && ow < W) {
-                        float s = bs;
+                for (int j = 0; j < 4; ++j) Zs[buf][4 * kg + j][wave * 32 + nt * 16 + l15] = acc[slot][nt][j];
+            __syncthreads();
+            const int ow = strip * kLastOut + tid;
+            if (tid < kLastOut && ow < W) {
+                float s_ = bs;
 #pragma unroll
-                        for (int kw = 0; kw < 15; ++kw) s += Zs[buf][kw][tid + kw];
-                        out[((long long)n * H + h0 + r) * W + ow] = s;
-                    }
-                    buf ^= 1;
-                }
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int cc = 0; cc < 4; ++cc) bcur[nt][cc] = bnxt[nt][cc];
+                for (int kw = 0; kw < 15; ++kw) s_ += Zs[buf][kw][tid + kw];
+                out[((long long)n * H + h0 + r) * W + ow] = s_;
             }
+            buf ^= 1;
         }
     }
 }

@@ -64,7 +64,13 @@ __global__ void mask_grad_kernel(const Twin<MaskGradKArgs> tw)
         const int i = (int)(idx - n * P);
         const long long so = (n * C) * P + i;
         float v = dxin[so];
-        for (int sl = 1; sl < nslab; ++sl) v += dxin_slabs[(long long)(sl - 1) * slab_stride + so];
+        for (int sl = 1; sl < nslab; sl += 4) {      // four slabs' loads in flight (a `v += slab[sl]` loop waits for each load: norm_kernels.hip slab_sum4); same order
+            float u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int s_ = (sl + k < nslab) ? sl + k : nslab - 1; u[k] = dxin_slabs[(long long)(s_ - 1) * slab_stride + so]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (sl + k < nslab) v += u[k];
+        }
         if (mask) v *= mask[idx];
         dx[idx] = accumulate ? dx[idx] + v : v;
     }

@@ -265,17 +265,24 @@ __global__ void __launch_bounds__(256) norm_fwd_reg_kernel(const Twin<NormArgs> 
         if (br < nbr) {
             const long long poff = (long long)n * a.x_sn + (long long)(c + br * a.C) * a.x_sc;
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int i = l + e * G;
-                float v = 0.f;
-                if (i < P) {
-                    v = a.x[poff + i];
-#pragma unroll 8
-                    for (int sl = 1; sl < a.nslab; ++sl) v += a.x_slabs[(long long)(sl - 1) * a.slab_stride + poff + i];
-                }
-                xv[br][e] = v;
-            }
+            for (int e = 0; e < E; ++e) { const int i = l + e * G; xv[br][e] = (i < P) ? a.x[poff + i] : 0.f; }
         }
+    }
+    // K-split slabs of the producing convolution, summed in slab order (x + s1 + s2 + ...: the order of the per-element loop this replaces, bit
+    // for bit).  SLAB-major with every element's load of a round independent: written per element (`v += slab[sl][i]` in a loop) the compiler
+    // kept one register for the loaded value and waited vmcnt(0) after EVERY load -- E x (nslab - 1) dependent memory round trips per thread
+    // (r6, tools/isa_scan.py `loop ld|vm0`).
+    for (int sl = 1; sl < a.nslab; ++sl) {
+        const float* sp = a.x_slabs + (long long)(sl - 1) * a.slab_stride + (long long)n * a.x_sn + (long long)c * a.x_sc;
+        float t[2][E];
+#pragma unroll
+        for (int br = 0; br < 2; ++br)
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const int i = l + e * G; t[br][e] = (br < nbr && i < P) ? sp[(long long)br * a.C * a.x_sc + i] : 0.f; }
+#pragma unroll
+        for (int br = 0; br < 2; ++br)
+#pragma unroll
+            for (int e = 0; e < E; ++e) xv[br][e] += t[br][e];
     }
     const long long yoff0 = (long long)n * a.y_sn + (long long)c * a.y_sc;
 #pragma unroll
@@ -372,17 +379,20 @@ __global__ void __launch_bounds__(256) norm_bwd_reg_kernel(const Twin<NormBwdArg
             const int i = l + e * G;
             const int h = i / a.W, w = i - h * a.W;
             hh[e] = h; ww[e] = w;
-            float v = 0.f;
-            if (i < P) {
-                const long long yo = yoff0 + (long long)h * a.y_sh + w;
-                v = a.dy[yo];
-                if (a.nslab > 1) {
-#pragma unroll 8
-                    for (int sl = 1; sl < a.nslab; ++sl) v += a.dy_slabs[(long long)(sl - 1) * a.slab_stride + yo];
-                    a.dy[yo] = v;                  // the residual path re-reads the reduced gradient
-                }
+            dyv[e] = (i < P) ? a.dy[yoff0 + (long long)h * a.y_sh + w] : 0.f;
+        }
+        if (a.nslab > 1) {                     // slab-major, a round's loads independent (see norm_fwd_reg_kernel); same summation order
+            for (int sl = 1; sl < a.nslab; ++sl) {
+                const float* sp = a.dy_slabs + (long long)(sl - 1) * a.slab_stride + yoff0;
+                float t[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) t[e] = (l + e * G < P) ? sp[(long long)hh[e] * a.y_sh + ww[e]] : 0.f;
+#pragma unroll
+                for (int e = 0; e < E; ++e) dyv[e] += t[e];
             }
-            dyv[e] = v;
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (l + e * G < P) a.dy[yoff0 + (long long)hh[e] * a.y_sh + ww[e]] = dyv[e];      // the residual path re-reads the reduced gradient
         }
         float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
 #pragma unroll
@@ -524,6 +534,20 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const Twin<ActBwdArgs> tw)
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 add4(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// t + slab 1 + slab 2 + ... (that order), four slabs' loads in flight at a time: `t = add4(t, ld4(slab sl))` in a loop made every load wait for
+// the previous one (one register for the loaded value, vmcnt(0) behind each load -- r6, tools/isa_scan.py); past the last slab the load
+// repeats the last one and its add is skipped
+__device__ __forceinline__ float4 slab_sum4(float4 t, const float* slabs, long long stride, long long off, int nslab)
+{
+    for (int sl = 1; sl < nslab; sl += 4) {
+        float4 u[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int s_ = (sl + k < nslab) ? sl + k : nslab - 1; u[k] = ld4(slabs + (long long)(s_ - 1) * stride + off); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (sl + k < nslab) t = add4(t, u[k]);
+    }
+    return t;
+}
 
 __global__ void __launch_bounds__(256) act_fwd_vec_kernel(const Twin<ActArgs> tw)
 {
@@ -542,8 +566,7 @@ __global__ void __launch_bounds__(256) act_fwd_vec_kernel(const Twin<ActArgs> tw
                 const long long xo = ((long long)(n * nbr * a.C + c + br * a.C)) * a.P + 4 * i4;
                 float4 t = ld4(a.x + xo);
                 if (a.nslab > 1) {
-#pragma unroll 4
-                    for (int sl = 1; sl < a.nslab; ++sl) t = add4(t, ld4(a.x_slabs + (long long)(sl - 1) * a.slab_stride + xo));
+                    t = slab_sum4(t, a.x_slabs, a.slab_stride, xo, a.nslab);
                     st4(a.x + xo, t);
                 }
                 v[br] = t;
@@ -569,8 +592,7 @@ __global__ void __launch_bounds__(256) act_bwd_vec_kernel(const Twin<ActBwdArgs>
         const unsigned n = nc / (unsigned)a.C, c = nc - n * (unsigned)a.C;
         float4 d = ld4(a.dy + 4LL * q);
         if (a.nslab > 1) {
-#pragma unroll 4
-            for (int sl = 1; sl < a.nslab; ++sl) d = add4(d, ld4(a.dy_slabs + (long long)(sl - 1) * a.slab_stride + 4LL * q));
+            d = slab_sum4(d, a.dy_slabs, a.slab_stride, 4LL * q, a.nslab);
             st4(a.dy + 4LL * q, d);
         }
         const long long xo0 = ((long long)(n * nbr * a.C + c)) * a.P + 4 * i4;
