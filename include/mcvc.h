@@ -219,13 +219,6 @@ int mcvc_bf16_last_conv(const void* x, const float* w, const float* b, float* ou
 long long mcvc_bf16_trunk_layer_pack_bytes(int Cin, int C, int gated);
 int mcvc_bf16_trunk_layer(const void* x, const float* w, const float* w_gate, const float* gamma, const float* beta, const float* gamma_gate,
                           const float* beta_gate, const void* residual, void* y, void* wpack, int B, int W, int Cin, int C, void* stream);
-/*      conv2d + InstanceNorm + activation as the bf16 forward runs its four large layers since r6 (model.py:86-103, 226-237): the convolution's
- *      epilogue writes the InstanceNorm statistics (sum / sum of squares per tile and channel, shifted by the bias), the statistics pass over the
- *      conv output is gone.  yc = the conv output [N][OH][OW][Cout], y = mcvc_bf16_instnorm_act(yc, ...); Cout % 128 == 0 or % 32 == 0 as packed;
- *      scratch: N * 65 * Cout * 2 floats; MCVC_ERR_WORKSPACE when an image has more than 64 tiles.                                        */
-int mcvc_bf16_conv2d_instnorm_act(const void* x, const float* w, const float* bias, const float* gamma, const float* beta, const float* gamma_gate,
-                                  const float* beta_gate, void* yc, void* y, void* wpack, float* scratch, int N, int H, int W, int Cin, int Cout,
-                                  int KH, int KW, int stride, int pad_h, int pad_w, int act, int pixel_shuffle, void* stream);
 /*      y = act(InstanceNorm(x)) (+ residual): act 0 none, 1 gated GLU (Cx = 2C: value | gate), 2 x*sigmoid(x); pixel_shuffle != 0:
  *      the normalised tensor is PixelShuffle(2)(x), output [N][2H][2W][Cx/4].  scratch: N * 65 * Cx * 2 floats.      */
 int mcvc_bf16_instnorm_act(const void* x, const float* gamma, const float* beta, const float* gamma_gate, const float* beta_gate,

@@ -21,16 +21,10 @@ struct Bf16ConvArgs {
     int PH, PW;                         // input patch of a tile: (TH-1)*stride + KH rows, (TW-1)*stride + KW columns
     int patch_bytes;                    // LDS bytes reserved for the staged patch (>= PH*PW*64, and >= prefetch depth * 4096 so that every thread stores every piece)
     int wbufs;                          // LDS weight buffers (2 = double buffer; 1 when that lets two workgroups share a CU)
-    // (r6) InstanceNorm statistics in the epilogue: when stat_partial != null every workgroup also writes, per output channel of its tile, the sum
-    // and the sum of squares of (stored bf16 value - shift) over the tile's valid pixels: stat_partial[((n * S + tile) * Cout_pad + co) * 2 + {0, 1}],
-    // S = tiles per image (returned by the launcher), shift = bias[co] (stat_group4: bias[co & ~3], the shift common to the four conv channels
-    // of one PixelShuffle output channel).  bf16_finalize_kernel reads them instead of bf16_stats_kernel's partials: the statistics pass -- a
-    // full re-read of the conv output -- disappears.  stat_cap = floats available behind stat_partial (the launcher refuses what does not fit).
-    float* stat_partial; long long stat_cap; int stat_group4;
     int glu;                            // 1: rows [0, Cout_pad/2) are value channels, [Cout_pad/2, Cout_pad) their gates, interleaved per
                                         //    64-row block by the packer; the epilogue stores value * sigmoid(gate): Cout = Cout_pad / 2
 };
-int mcvc_bf16_conv_launch(const Bf16ConvArgs& a, hipStream_t s, int* stat_tiles = nullptr);     // *stat_tiles = S when the statistics were written, else 0
+int mcvc_bf16_conv_launch(const Bf16ConvArgs& a, hipStream_t s);
 // pixel-tile shape for an OH x OW output grid (TH * TW = bn)
 void mcvc_bf16_conv_tile(int OH, int OW, int KH, int KW, int stride, int bn, int* TH, int* tw_log2);
 
@@ -47,8 +41,6 @@ struct Bf16NormArgs {
     float* partial;                     // [N][S][Cn][2] shifted (sum, sumsq) partials; Cn = number of normalised channels
     float* stats;                       // [N][Cn][2] mean, rstd
     int S;                              // pixel splits of the statistics pass
-    const float* conv_bias;             // (r6) != null: `partial` holds the producing convolution's epilogue statistics -- [N][S][Cx][2] per CONV channel,
-                                        // shifted by conv_bias[cx] (shuffle: conv_bias[cx & ~3]) -- and no statistics pass runs
     const bf16_t* res;                  // optional residual, addressed like y
     bf16_t* y; long long y_sn; int y_sh, y_sw;        // output element (n, h', w', c) at y + n*y_sn + h'*y_sh + w'*y_sw + (c / y_csplit)*y_sc2 + c % y_csplit
     int y_csplit, y_sc2;                // channel split of the output address (0 = none)

@@ -436,52 +436,6 @@ __global__ void __launch_bounds__(kConvThreads) bf16_conv_kernel(const Bf16ConvA
             }
         }
     }
-    // ---- (r6) InstanceNorm statistics of this tile, on the values as stored (bf16-rounded), shifted by the channel's bias
-    if (a.stat_partial != nullptr && !a.glu) {
-        float* sred = reinterpret_cast<float*>(smem) + BM;           // [WN][BM][2] behind the bias values
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            float s1[16], s2[16], shf[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                s1[r] = 0.f; s2[r] = 0.f; shf[r] = sbias[a.stat_group4 ? (row & ~3) : row];
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int n = (wn * NT + nt) * 32 + l31;
-                const int oh = oh0 + (n >> a.tw_log2), ow = ow0 + (n & (TW - 1));
-                const bool ok = oh < a.OH && ow < a.OW;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int r = 2 * q;
-                    const int row = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const unsigned pk = pack2bf(acc[mt][nt][r] + sbias[row], acc[mt][nt][r + 1] + sbias[row + 1]);
-                    const float d0 = ok ? __uint_as_float(pk << 16) - shf[r] : 0.f, d1 = ok ? __uint_as_float(pk & 0xffff0000u) - shf[r + 1] : 0.f;
-                    s1[r] += d0; s2[r] += d0 * d0; s1[r + 1] += d1; s2[r + 1] += d1 * d1;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int o = 16; o > 0; o >>= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
-            if (l31 == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    sred[(wn * BM + row) * 2] = s1[r]; sred[(wn * BM + row) * 2 + 1] = s2[r];
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < BM && co0 + tid < a.Cout_pad) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < WN; ++j) { t1 += sred[(j * BM + tid) * 2]; t2 += sred[(j * BM + tid) * 2 + 1]; }
-            float* q = a.stat_partial + (((long long)n_img * (a.tiles_h * a.tiles_w) + trem) * a.Cout_pad + co0 + tid) * 2;
-            q[0] = t1; q[1] = t2;
-        }
-    }
 }
 
 template <int WM, int WN, int MT, int NT, int KWT, int PPT>
@@ -638,10 +592,9 @@ static double bf16_patch_conflicts(int tw_log2, int pw, int stride, int KH, int 
     return (double)extra / (double)n;
 }
 
-int mcvc_bf16_conv_launch(const Bf16ConvArgs& a0, hipStream_t s, int* stat_tiles)
+int mcvc_bf16_conv_launch(const Bf16ConvArgs& a0, hipStream_t s)
 {
     Bf16ConvArgs a = a0;
-    if (stat_tiles) *stat_tiles = 0;
     if ((a.Cin & 31) || (a.Cout & 3) || a.KW < 1 || a.KH < 1) return MCVC_ERR_INVALID;
     const int cfg = conv_config(a);
     const int BM = (cfg == 0 || cfg == 3 || cfg == 4 || cfg == 5) ? 128 : (cfg == 1 ? 64 : 32);
@@ -666,11 +619,6 @@ int mcvc_bf16_conv_launch(const Bf16ConvArgs& a0, hipStream_t s, int* stat_tiles
         }
     }
     if (BM * a.KW * 4 > kMaxWP * kConvThreads) return MCVC_ERR_INVALID;
-    if (a.stat_partial) {                                            // epilogue statistics only when every tile's partials fit the caller's buffer
-        const long long need = (long long)a.N * a.tiles_h * a.tiles_w * a.Cout_pad * 2;
-        if (a.glu || need > a.stat_cap) a.stat_partial = nullptr;
-        else if (stat_tiles) *stat_tiles = a.tiles_h * a.tiles_w;
-    }
     // the patch area holds whole prefetch rounds (depth * 256 threads * 16 bytes): every thread stores every piece, no bounds test
     const int depth = bf16_prefetch_depth(a.PH * a.PW * 4, a.KW, BM, BN);
     size_t patch = ((size_t)a.PH * a.PW * 64 + 255) & ~(size_t)255;
@@ -762,22 +710,12 @@ __global__ void __launch_bounds__(256) bf16_finalize_kernel(const Bf16NormArgs a
     if (i >= (long long)a.N * Cn) return;
     const int n = (int)(i / Cn), cn = (int)(i - (long long)n * Cn);
     float s1 = 0.f, s2 = 0.f;
-    float shift;
-    if (a.conv_bias) {             // (r6) the producing convolution's epilogue statistics: per conv channel and tile, shifted by the (group's) bias
-        const int g = a.shuffle ? 4 : 1;
-        for (int s = 0; s < a.S; ++s) {
-            const float* p = a.partial + (((long long)n * a.S + s) * a.Cx + g * cn) * 2;
-            for (int j = 0; j < g; ++j) { s1 += p[2 * j]; s2 += p[2 * j + 1]; }
-        }
-        shift = a.conv_bias[g * cn];
-    } else {
-        for (int s = 0; s < a.S; ++s) {
-            const float* p = a.partial + (((long long)n * a.S + s) * Cn + cn) * 2;
-            s1 += p[0]; s2 += p[1];
-        }
-        shift = bf2f(a.x[(long long)n * a.x_sn + (a.shuffle ? 4 * cn : cn)]);
+    for (int s = 0; s < a.S; ++s) {
+        const float* p = a.partial + (((long long)n * a.S + s) * Cn + cn) * 2;
+        s1 += p[0]; s2 += p[1];
     }
     const float cnt = (float)a.H * a.W * (a.shuffle ? 4.f : 1.f);
+    const float shift = bf2f(a.x[(long long)n * a.x_sn + (a.shuffle ? 4 * cn : cn)]);
     const float m = s1 / cnt;
     float var = s2 / cnt - m * m;
     if (var < 0.f) var = 0.f;
@@ -1006,7 +944,7 @@ int mcvc_bf16_norm_launch(const Bf16NormArgs& a, hipStream_t s)
     }
     if (a.has_norm) {
         if (a.S < 1) return MCVC_ERR_INVALID;
-        if (!a.conv_bias) {
+        {
             TraceScope ts(K_NORM_FWD, s, 0.0, 2.0 * el);
             hipLaunchKernelGGL(bf16_stats_kernel, dim3((unsigned)cdiv_i(a.Cx, 64), (unsigned)a.S, (unsigned)a.N), dim3(256), 0, s, a);
         }

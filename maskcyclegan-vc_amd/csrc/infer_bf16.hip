@@ -130,9 +130,8 @@ struct Run {
 };
 
 // y[n][oh][ow][co] = conv(x) (+bias)
-// returns S > 0 when the convolution also wrote its InstanceNorm statistics (stat_group4: PixelShuffle layers) into the partial buffer
-static int conv(Run& r, const LayerB& l, const bf16_t* x, long long x_sn, int x_sh, int x_sw, int N, int H, int W, bf16_t* y, long long y_sn,
-                int y_sh, int y_sw, int Cout_store, int stats = 0, int stat_group4 = 0)
+static void conv(Run& r, const LayerB& l, const bf16_t* x, long long x_sn, int x_sh, int x_sw, int N, int H, int W, bf16_t* y, long long y_sn,
+                 int y_sh, int y_sw, int Cout_store)
 {
     Bf16ConvArgs a{};
     a.x = x; a.x_sn = x_sn; a.x_sh = x_sh; a.x_sw = x_sw;
@@ -143,18 +142,12 @@ static int conv(Run& r, const LayerB& l, const bf16_t* x, long long x_sn, int x_
     a.KH = l.KH; a.KW = l.KW; a.stride = l.stride; a.pad_h = l.pad_h; a.pad_w = l.pad_w;
     a.OH = conv_out(H, l.KH, l.stride, l.pad_h); a.OW = conv_out(W, l.KW, l.stride, l.pad_w);
     a.glu = l.glu_fused;
-    static const int epi_stats = mcvc_knob("MCVC_BF16_EPI_STATS", 1);
-    if (stats && epi_stats && r.w) {
-        a.stat_partial = reinterpret_cast<float*>(r.ws + r.w->partial); a.stat_cap = (long long)N * 64 * 5120 * 2; a.stat_group4 = stat_group4;
-    }
-    int tiles = 0;
-    r.fail(mcvc_bf16_conv_launch(a, r.s, &tiles));
-    return tiles;
+    r.fail(mcvc_bf16_conv_launch(a, r.s));
 }
 
 static void norm(Run& r, const bf16_t* x, long long x_sn, int x_sh, int x_sw, int N, int H, int W, int Cx, int shuffle, int act,
                  const float* g0, const float* b0, const float* g1, const float* b1, const bf16_t* res, bf16_t* y, long long y_sn, int y_sh,
-                 int y_sw, int y_csplit = 0, int y_sc2 = 0, int conv_S = 0, const float* conv_bias = nullptr)
+                 int y_sw, int y_csplit = 0, int y_sc2 = 0)
 {
     Bf16NormArgs a{};
     a.x = x; a.x_sn = x_sn; a.x_sh = x_sh; a.x_sw = x_sw; a.N = N; a.H = H; a.W = W; a.Cx = Cx;
@@ -163,7 +156,6 @@ static void norm(Run& r, const bf16_t* x, long long x_sn, int x_sh, int x_sw, in
     a.partial = reinterpret_cast<float*>(r.ws + r.w->partial); a.stats = reinterpret_cast<float*>(r.ws + r.w->stats);
     const int Cn = shuffle ? Cx / 4 : Cx;
     a.S = mcvc_bf16_norm_splits(N, H * W, Cn);
-    if (conv_S > 0) { a.S = conv_S; a.conv_bias = conv_bias; }      // statistics came out of the convolution's epilogue
     a.res = res; a.y = y; a.y_sn = y_sn; a.y_sh = y_sh; a.y_sw = y_sw; a.y_csplit = y_csplit; a.y_sc2 = y_sc2; a.eps = kEps;
     r.fail(mcvc_bf16_norm_launch(a, r.s));
 }
@@ -187,14 +179,13 @@ static void forward(Run& r, const float* x, const float* mask, float* out, const
         conv(r, n.conv1, B16(w.xin), 80LL * T * 32, T * 32, 32, B, 80, T, B16(w.y1), 80LL * T * 128, T * 128, 128, 128);
     }
     // :245 downSample1
-    auto biasp = [&](const LayerB& l) { return reinterpret_cast<const float*>(r.pk + l.off_bias); };
-    int S = conv(r, n.ds1, B16(w.y1), 80LL * T * 128, T * 128, 128, B, 80, T, B16(w.c2), 40LL * W2 * 512, W2 * 512, 512, 512, 1, 0);
+    conv(r, n.ds1, B16(w.y1), 80LL * T * 128, T * 128, 128, B, 80, T, B16(w.c2), 40LL * W2 * 512, W2 * 512, 512, 512);
     norm(r, B16(w.c2), 40LL * W2 * 512, W2 * 512, 512, B, 40, W2, 512, 0, BF16_ACT_GLU, P[6], P[7], P[10], P[11], nullptr,
-         B16(w.y2), 40LL * W2 * 256, W2 * 256, 256, 0, 0, S, biasp(n.ds1));
+         B16(w.y2), 40LL * W2 * 256, W2 * 256, 256);
     // :246 downSample2; output written as [b][w][h*256 + c]  (:249-251)
-    S = conv(r, n.ds2, B16(w.y2), 40LL * W2 * 256, W2 * 256, 256, B, 40, W2, B16(w.c3), 20LL * W4 * 512, W4 * 512, 512, 512, 1, 0);
+    conv(r, n.ds2, B16(w.y2), 40LL * W2 * 256, W2 * 256, 256, B, 40, W2, B16(w.c3), 20LL * W4 * 512, W4 * 512, 512, 512);
     norm(r, B16(w.c3), 20LL * W4 * 512, W4 * 512, 512, B, 20, W4, 512, 0, BF16_ACT_GLU, P[14], P[15], P[18], P[19], nullptr,
-         B16(w.y3), (long long)W4 * 5120, 256, 5120, 0, 0, S, biasp(n.ds2));
+         B16(w.y3), (long long)W4 * 5120, 256, 5120);
     // :254-255 1x1 5120 -> 256 + IN.  K = 5120 in 32-channel stages of two MFMA steps each is 160 barrier-bound stages per workgroup; the
     // same bytes read as [b][5 * W4 "pixels"][1024 channels] make it a 1 x 5 convolution with stride 5 (non-overlapping windows): 32 stages
     // of ten steps, the weight pack groups the channels accordingly (r5: 122 -> see DESIGN 8b)
@@ -231,13 +222,13 @@ static void forward(Run& r, const float* x, const float* mask, float* out, const
     norm(r, B16(w.c6), (long long)W4 * 5120, 0, 5120, B, 1, W4, 5120, 0, BF16_ACT_NONE, reinterpret_cast<const float*>(r.pk + n.off_g6),
          reinterpret_cast<const float*>(r.pk + n.off_b6), nullptr, nullptr, nullptr, B16(w.y6), 20LL * W4 * 256, 0, 256, 256, W4 * 256);
     // :274 upSample1: conv -> PixelShuffle -> IN -> x*sigmoid(x)
-    S = conv(r, n.up1, B16(w.y6), 20LL * W4 * 256, W4 * 256, 256, B, 20, W4, B16(w.c7), 20LL * W4 * 1024, W4 * 1024, 1024, 1024, 1, 1);
+    conv(r, n.up1, B16(w.y6), 20LL * W4 * 256, W4 * 256, 256, B, 20, W4, B16(w.c7), 20LL * W4 * 1024, W4 * 1024, 1024, 1024);
     norm(r, B16(w.c7), 20LL * W4 * 1024, W4 * 1024, 1024, B, 20, W4, 1024, 1, BF16_ACT_SILU, P[106], P[107], nullptr, nullptr, nullptr,
-         B16(w.y7), 40LL * Wu1 * 256, Wu1 * 256, 256, 0, 0, S, biasp(n.up1));
+         B16(w.y7), 40LL * Wu1 * 256, Wu1 * 256, 256);
     // :275 upSample2
-    S = conv(r, n.up2, B16(w.y7), 40LL * Wu1 * 256, Wu1 * 256, 256, B, 40, Wu1, B16(w.c8), 40LL * Wu1 * 512, Wu1 * 512, 512, 512, 1, 1);
+    conv(r, n.up2, B16(w.y7), 40LL * Wu1 * 256, Wu1 * 256, 256, B, 40, Wu1, B16(w.c8), 40LL * Wu1 * 512, Wu1 * 512, 512, 512);
     norm(r, B16(w.c8), 40LL * Wu1 * 512, Wu1 * 512, 512, B, 40, Wu1, 512, 1, BF16_ACT_SILU, P[102], P[103], nullptr, nullptr, nullptr,
-         B16(w.y8), 80LL * Wu2 * 128, Wu2 * 128, 128, 0, 0, S, biasp(n.up2));
+         B16(w.y8), 80LL * Wu2 * 128, Wu2 * 128, 128);
     // :278-279 last conv: 15 kernel columns as output channels, then the column sum (+ bias)
     // (r6: one launch, fp32 kernel-column sum in LDS; MCVC_BF16_LAST_FUSED=0 in the experiments build restores conv + shifted-plane sum)
     static const int last_fused = mcvc_knob("MCVC_BF16_LAST_FUSED", 1);
@@ -394,51 +385,6 @@ int mcvc_bf16_trunk_layer(const void* x, const float* w, const float* w_gate, co
     if (e) return e;
     return mcvc_bf16_trunk_layer_launch(static_cast<const bf16_t*>(x), (long long)W * Cin, static_cast<const bf16_t*>(wpack), gamma, beta, gamma_gate, beta_gate,
                                         static_cast<const bf16_t*>(residual), static_cast<bf16_t*>(y), (long long)W * C, B, W, Cin, C, w_gate ? 1 : 0, kEps, s);
-}
-
-// conv2d followed by InstanceNorm (+ activation) the way the forward runs its large layers since r6: the convolution's epilogue writes the
-// statistics partials, no statistics pass.  yc [N][OH][OW][Cout] = the conv output (bf16), y = act(IN(yc)) as mcvc_bf16_instnorm_act would
-// give; scratch: N * 65 * Cout * 2 floats.  Returns MCVC_ERR_WORKSPACE when the tile count does not fit the scratch (the forward then runs the
-// statistics pass).
-int mcvc_bf16_conv2d_instnorm_act(const void* x, const float* w, const float* bias, const float* gamma, const float* beta, const float* gamma_gate,
-                                  const float* beta_gate, void* yc, void* y, void* wpack, float* scratch, int N, int H, int W, int Cin, int Cout,
-                                  int KH, int KW, int stride, int pad_h, int pad_w, int act, int pixel_shuffle, void* stream)
-{
-    if ((Cin & 31) || (Cout & 3) || !x || !w || !yc || !y || !wpack || !scratch || !gamma || !beta) return MCVC_ERR_INVALID;
-    const int cout_pad = (Cout % 128 == 0) ? Cout : ((Cout + 31) / 32) * 32;
-    if (cout_pad != Cout) return MCVC_ERR_INVALID;                   // (the statistics table is indexed by conv channel)
-    LayerB l = mkl(BF16_PACK_PLAIN, 0, 1, -1, -1, Cout, Cin, KH, KW, Cin, KW, cout_pad, stride, pad_h, pad_w);
-    l.off_w = 0; l.off_bias = ((2LL * cout_pad * KH * Cin * KW) + 255) & ~255LL;
-    const float* P[2] = {w, bias};
-    Run r{}; r.s = (hipStream_t)stream; r.P = P; r.pk = static_cast<const unsigned char*>(wpack);
-    Bf16PackArgs pa{};
-    pa.w[0] = w; pa.dst = reinterpret_cast<bf16_t*>(wpack); pa.kind = BF16_PACK_PLAIN; pa.nbr = 1; pa.Cout_src = Cout; pa.Cin_src = Cin; pa.KH = KH; pa.KW_src = KW;
-    pa.Cout_pad = cout_pad; pa.KW = KW; pa.Cin = Cin;
-    r.fail(mcvc_bf16_pack_launch(pa, r.s));
-    float* pbias = reinterpret_cast<float*>(static_cast<unsigned char*>(wpack) + l.off_bias);
-    r.fail(mcvc_bf16_vec_launch(bias, nullptr, pbias, bias ? Cout : 0, cout_pad, BF16_PACK_PLAIN, r.s));
-    const int OH = conv_out(H, KH, stride, pad_h), OW = conv_out(W, KW, stride, pad_w);
-    Bf16ConvArgs a{};
-    a.x = static_cast<const bf16_t*>(x); a.x_sn = (long long)H * W * Cin; a.x_sh = W * Cin; a.x_sw = Cin;
-    a.w = reinterpret_cast<const bf16_t*>(wpack); a.bias = pbias;
-    a.y = static_cast<bf16_t*>(yc); a.y_sn = (long long)OH * OW * Cout; a.y_sh = OW * Cout; a.y_sw = Cout;
-    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Cout_pad = cout_pad; a.KH = KH; a.KW = KW; a.stride = stride; a.pad_h = pad_h; a.pad_w = pad_w;
-    a.OH = OH; a.OW = OW;
-    a.stat_partial = scratch; a.stat_cap = (long long)N * 64 * Cout * 2; a.stat_group4 = pixel_shuffle ? 1 : 0;
-    int S = 0;
-    r.fail(mcvc_bf16_conv_launch(a, r.s, &S));
-    if (r.err) return r.err;
-    if (S <= 0) return MCVC_ERR_WORKSPACE;
-    const int C = pixel_shuffle ? Cout / 4 : (act == BF16_ACT_GLU ? Cout / 2 : Cout);
-    Bf16NormArgs nb{};
-    nb.x = static_cast<const bf16_t*>(yc); nb.x_sn = a.y_sn; nb.x_sh = a.y_sh; nb.x_sw = a.y_sw; nb.N = N; nb.H = OH; nb.W = OW; nb.Cx = Cout;
-    nb.shuffle = pixel_shuffle ? 1 : 0; nb.act = act; nb.has_norm = 1;
-    nb.gamma[0] = gamma; nb.beta[0] = beta; nb.gamma[1] = gamma_gate; nb.beta[1] = beta_gate;
-    nb.S = S; nb.conv_bias = pbias; nb.partial = scratch; nb.stats = scratch + (long long)N * 64 * Cout * 2;
-    nb.y = static_cast<bf16_t*>(y);
-    const int OHn = pixel_shuffle ? 2 * OH : OH, OWn = pixel_shuffle ? 2 * OW : OW;
-    nb.y_sn = (long long)OHn * OWn * C; nb.y_sh = OWn * C; nb.y_sw = C; nb.eps = kEps;
-    return mcvc_bf16_norm_launch(nb, r.s);
 }
 
 // y = act(InstanceNorm(x)) on NHWC bf16.  x: [N][H][W][Cx]; act 0 none, 1 gated GLU (Cx = 2C: value | gate), 2 x*sigmoid(x);

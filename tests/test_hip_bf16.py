@@ -92,58 +92,6 @@ def test_bf16_fused_conv1_matches_fp32_on_the_same_rounded_operands(B, T, masked
     assert e < 4e-3, e
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout,K,stride,act,shuffle", [
-    (2, 80, 64, 128, 512, 5, 2, 1, 0),      # downSample1: stride 2, gated GLU (value | gate statistics per conv channel)
-    (2, 40, 32, 256, 512, 5, 2, 1, 0),      # downSample2
-    (2, 20, 16, 256, 1024, 5, 1, 2, 1),     # upSample1: PixelShuffle -- four conv channels per normalised channel, common shift
-    (1, 40, 32, 256, 512, 5, 1, 2, 1),      # upSample2
-    (2, 40, 128, 256, 512, 5, 1, 2, 1),     # upSample2 at 512 frames per sample: 128 x 512-pixel tiles, ten tiles per image
-    (1, 21, 45, 32, 128, 5, 2, 0, 0),       # ragged stride 2: overhanging tiles must not count
-    (2, 13, 37, 64, 128, 3, 1, 2, 1),       # ragged, shuffle
-])
-def test_bf16_conv_epilogue_statistics_match_the_statistics_pass(N, H, W, Cin, Cout, K, stride, act, shuffle):
-    """r6: the large convolutions of the bf16 forward write their InstanceNorm statistics in the epilogue (per tile and conv channel: sum and sum
-    of squares of the STORED bf16 values, shifted by the channel's bias; PixelShuffle layers share the group's first bias) and bf16_finalize_kernel
-    reads those -- no statistics pass.  conv + norm + activation through that path must equal mcvc_bf16_instnorm_act on the same conv output
-    (the three-launch form) to rounding, and the fp32 reference on the bf16-rounded operands at the single-op tolerance."""
-    L = lib()
-    g = torch.Generator().manual_seed(37)
-    x = torch.randn(N, Cin, H, W, generator=g).cuda().to(torch.bfloat16)
-    w = (torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5).cuda()
-    b = (2.0 * torch.randn(Cout, generator=g)).cuda()                 # (a bias well off zero: the shift matters)
-    p = K // 2
-    OH, OW = (H + 2 * p - K) // stride + 1, (W + 2 * p - K) // stride + 1
-    C = Cout // 4 if shuffle else (Cout // 2 if act == 1 else Cout)
-    ga, be = (1 + 0.2 * torch.randn(C, generator=g)).cuda(), (0.3 * torch.randn(C, generator=g)).cuda()
-    gg, bg = (1 + 0.2 * torch.randn(C, generator=g)).cuda(), (0.3 * torch.randn(C, generator=g)).cuda()
-    OHn, OWn = (2 * OH, 2 * OW) if shuffle else (OH, OW)
-    yc = torch.empty(N, OH, OW, Cout, dtype=torch.bfloat16, device="cuda")
-    y = torch.full((N, OHn, OWn, C), float("nan"), dtype=torch.bfloat16, device="cuda")
-    y3 = torch.empty_like(y)
-    wpack = torch.zeros(L.mcvc_bf16_conv2d_pack_bytes(Cout, Cin, K, K), dtype=torch.uint8, device="cuda")
-    scratch = torch.full((N * 65 * Cout * 2,), float("nan"), device="cuda")
-    check(L.mcvc_bf16_conv2d_instnorm_act(ptr(x.permute(0, 2, 3, 1).contiguous()), ptr(w), ptr(b), ptr(ga), ptr(be), ptr(gg), ptr(bg), ptr(yc), ptr(y),
-                                          ptr(wpack), ptr(scratch), N, H, W, Cin, Cout, K, K, stride, p, p, act, 1 if shuffle else 0, stream()),
-          "bf16_conv2d_instnorm_act")
-    scratch2 = torch.zeros(N * 65 * Cout * 2, device="cuda")
-    check(L.mcvc_bf16_instnorm_act(ptr(yc), ptr(ga), ptr(be), ptr(gg), ptr(bg), None, ptr(y3), ptr(scratch2), N, OH, OW, Cout, act, 1 if shuffle else 0,
-                                   stream()), "bf16_instnorm_act")
-    assert torch.isfinite(y.float()).all()
-    e3 = rel(y.float(), y3.float())
-    assert e3 < 2e-3, e3                        # same conv output, same arithmetic up to the order of the partial sums: bf16 output rounding flips only
-    conv = F.conv2d(x.float(), w.to(torch.bfloat16).float(), b, stride, p).to(torch.bfloat16).float()
-    if shuffle:
-        z = F.instance_norm(F.pixel_shuffle(conv, 2), weight=ga, bias=be, eps=1e-5)
-    elif act == 1:
-        z = F.instance_norm(conv[:, :C], weight=ga, bias=be, eps=1e-5) * torch.sigmoid(F.instance_norm(conv[:, C:], weight=gg, bias=bg, eps=1e-5))
-    else:
-        z = F.instance_norm(conv, weight=ga, bias=be, eps=1e-5)
-    if act == 2:
-        z = z * torch.sigmoid(z)
-    e = rel(y.float().permute(0, 3, 1, 2), z)
-    assert e < 6e-3, e
-
-
 @pytest.mark.parametrize("B,W,Cin,C,gated,res", [(3, 16, 256, 512, True, False), (3, 16, 512, 256, False, True), (2, 128, 256, 512, True, False),
                                                   (2, 128, 512, 256, False, True), (1, 17, 256, 512, True, False), (2, 100, 512, 256, False, False),
                                                   (1, 2, 256, 32, False, True), (2, 33, 512, 64, True, False)])
