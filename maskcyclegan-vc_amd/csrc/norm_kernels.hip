@@ -265,24 +265,20 @@ __global__ void __launch_bounds__(256) norm_fwd_reg_kernel(const Twin<NormArgs> 
         if (br < nbr) {
             const long long poff = (long long)n * a.x_sn + (long long)(c + br * a.C) * a.x_sc;
 #pragma unroll
-            for (int e = 0; e < E; ++e) { const int i = l + e * G; xv[br][e] = (i < P) ? a.x[poff + i] : 0.f; }
+            for (int e = 0; e < E; ++e) {
+                const int i = l + e * G;
+                float v = 0.f;
+                if (i < P) {
+                    v = a.x[poff + i];
+                    // (kept per element: the slab-major form of norm_bwd_reg_kernel below is the same arithmetic, but with it hipcc contracts
+                    //  `x - s * invP` of the statistics differently -- a 1e-7 change per element that four Adam steps amplify to 1e-3 on single
+                    //  tensors and that moved the deterministic fp64-anchor numbers of tests/test_hip_parity_fp64.py; neutral in time either way)
+#pragma unroll 8
+                    for (int sl = 1; sl < a.nslab; ++sl) v += a.x_slabs[(long long)(sl - 1) * a.slab_stride + poff + i];
+                }
+                xv[br][e] = v;
+            }
         }
-    }
-    // K-split slabs of the producing convolution, summed in slab order (x + s1 + s2 + ...: the order of the per-element loop this replaces, bit
-    // for bit).  SLAB-major with every element's load of a round independent: written per element (`v += slab[sl][i]` in a loop) the compiler
-    // kept one register for the loaded value and waited vmcnt(0) after EVERY load -- E x (nslab - 1) dependent memory round trips per thread
-    // (r6, tools/isa_scan.py `loop ld|vm0`).
-    for (int sl = 1; sl < a.nslab; ++sl) {
-        const float* sp = a.x_slabs + (long long)(sl - 1) * a.slab_stride + (long long)n * a.x_sn + (long long)c * a.x_sc;
-        float t[2][E];
-#pragma unroll
-        for (int br = 0; br < 2; ++br)
-#pragma unroll
-            for (int e = 0; e < E; ++e) { const int i = l + e * G; t[br][e] = (br < nbr && i < P) ? sp[(long long)br * a.C * a.x_sc + i] : 0.f; }
-#pragma unroll
-        for (int br = 0; br < 2; ++br)
-#pragma unroll
-            for (int e = 0; e < E; ++e) xv[br][e] += t[br][e];
     }
     const long long yoff0 = (long long)n * a.y_sn + (long long)c * a.y_sc;
 #pragma unroll
