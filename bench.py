@@ -275,7 +275,9 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before the timed region (default 10; --mode infer: 100 -- the HIP runtime "
+                    "stalls ONCE for 10-50 ms somewhere between ~400 and ~3000 launches into a process, and with 34 launches per forward a 10-forward "
+                    "warm-up put that stall inside or outside the 50 timed forwards depending on the launch count: measured r6, profiles/r06_c2d1d_warmup_sweep.log)")
     ap.add_argument("--mode", choices=("train", "infer"), default="train", help="train: full G+D iteration (BASELINE metric); "
                     "infer: generator_A2B forward, bs=16 x 512 frames (BASELINE configs[4])")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default=None, help="infer mode arithmetic (default bf16); training is fp32")
@@ -300,7 +302,10 @@ def parse_args():
     ap.add_argument("--serial", action="store_true", help="one stream: no lanes, no auxiliary weight-gradient stream (A/B comparison, per-kernel profiling)")
     ap.add_argument("--dump-trace", default=None, help="write one traced step's per-launch records (launch order) to this file")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(host cores, 32))")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.warmup is None:
+        a.warmup = 100 if a.mode == "infer" else 10
+    return a
 
 
 def dist_info(world, device, force=False):

@@ -212,6 +212,11 @@ int mcvc_bf16_conv1_glu(const float* x, const float* mask, const float* w, const
  *      conv2d(x[B][80][T][128] bf16 NHWC, w[1][128][5][15], b[1], padding (2, 7)); wpack: mcvc_bf16_last_conv_pack_bytes() bytes, 16-byte aligned. */
 long long mcvc_bf16_last_conv_pack_bytes(void);
 int mcvc_bf16_last_conv(const void* x, const float* w, const float* b, float* out, void* wpack, int B, int T, void* stream);
+/*      conv2dto1d (Conv1d 5120 -> 256, k = 1) + conv2dto1dLayer_tfan (r6; model.py:142-146, 254-255) through the fused kernel of the bf16 forward:
+ *      x [B][W][5120] bf16 whose memory channel h * 256 + c holds the reference's channel c * 20 + h (the view(B, 5120, 1, -1) of :249-251 as the
+ *      forward lays it out), w [256][5120] fp32 in the reference's order, gamma / beta [256]; y [B][W][256] bf16.  W <= 128 else MCVC_ERR_INVALID.  */
+long long mcvc_bf16_c2d1d_pack_bytes(void);
+int mcvc_bf16_c2d1d_norm(const void* x, const float* w, const float* gamma, const float* beta, void* y, void* wpack, int B, int W, void* stream);
 /*      one layer of a residual block (r6; model.py:47-76) through the fused kernel of the bf16 forward -- Conv1d(k = 3, padding 1) + InstanceNorm1d
  *      (affine) + {value * sigmoid(gate) when w_gate != NULL | + residual}: x [B][W][Cin], y / residual [B][W][C] bf16 (channel-innermost);
  *      w / w_gate [C][Cin][3], gamma / beta (+ the gate's) [C] fp32.  W <= 128, Cin = 256 or 512, C % 32 == 0, else MCVC_ERR_INVALID

@@ -71,6 +71,13 @@ int mcvc_bf16_trunk_pack_launch(const float* w0, const float* w1, bf16_t* dst, i
 int mcvc_bf16_trunk_layer_launch(const bf16_t* x, long long x_sn, const bf16_t* w, const float* g0, const float* b0, const float* g1, const float* b1,
                                  const bf16_t* res, bf16_t* y, long long y_sn, int B, int W, int Cin, int C, int glu, float eps, hipStream_t s);
 
+// ---- conv2dto1d (5120 -> 256, k = 1) + its InstanceNorm in one launch (r6): x [B][W][5120] bf16 (channel h * 256 + c), y [B][W][256]; W <= 128
+bool mcvc_bf16_c2d1d_applies(int W);
+long long mcvc_bf16_c2d1d_pack_elems(void);
+int mcvc_bf16_c2d1d_pack_launch(const float* w, bf16_t* dst, hipStream_t s);
+int mcvc_bf16_c2d1d_launch(const bf16_t* x, long long x_sn, const bf16_t* w, const float* gamma, const float* beta, bf16_t* y, long long y_sn,
+                           int B, int W, float eps, hipStream_t s);
+
 // ---- weight packing (fp32 OIHW parameters -> bf16 [Cout_pad][KH][Cin/32][KW][32]) -------------------------------------
 enum Bf16PackKind {
     BF16_PACK_PLAIN = 0,       // k index = ci (Cin_src % 32 == 0)

@@ -1425,6 +1425,137 @@ __global__ void __launch_bounds__(256) bf16_trunk_pack_kernel(const float* __res
     }
 }
 
+// ---- conv2dto1d of the inference forward + its InstanceNorm in ONE launch (r6) ---------------------------------------------------------
+// model.py:142-146, 254-255: Conv1d(5120 -> 256, k = 1) + InstanceNorm1d over a sample's W = T/4 <= 128 columns.  As a 64 x 64-tile convolution
+// (1 x 5 stride 5 over 1024-channel "pixels") the layer was 32 barrier-bound stages per workgroup on 128 of the 256 compute units: 73 us for
+// 5.4 GF, + 8 us for the norm.  Here a workgroup owns 32 output channels x all columns of one sample (the norm's row is in the tile):
+//   * X [W][5120] streams through a FOUR-stage LDS-DMA ring in chunks of 128 channels (32 KB: 128 pixel rows of 256 bytes; piece p of row r at
+//     slot p ^ (r & 15) -- the DMA writes lane L to slot L, so lane L simply fetches the piece that belongs there -- conflict-free 16-byte
+//     operand reads); three chunks in flight, one barrier per chunk;
+//   * weights in MFMA operand order, an eight-step register ring (as bf16_trunk_layer_kernel); the four waves split the columns;
+//   * the K loop is fully unrolled and EVERY memory instruction of it is issued in a fixed order (inline assembly), so the `vmcnt` immediates
+//     are compile-time counts: 15 operations behind a weight load when it is used, 40 behind a chunk's DMA when it is read;
+//   * epilogue = the plain trunk layer's (statistics on the fp32 accumulators, affine, bf16 store); the conv bias cancels under the norm.
+// The eight channel tiles of a sample are mapped onto ONE XCD (workgroup id & 7 = XCD), so a sample's 1.3 MB are fetched into one L2.
+constexpr int kC2K = 5120, kC2Steps = kC2K / 16, kC2Chunks = kC2K / 128, kC2StageB = 128 * 256;
+template <int N> __device__ __forceinline__ void c2_wait_vm() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
+
+__global__ void __launch_bounds__(256) bf16_c2d1d_kernel(const Bf16TrunkArgs a, int B)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int lin = blockIdx.x, slot = lin & 7, q = lin >> 3;
+    const int tile = q & 7, n = (q >> 3) * 8 + slot;
+    if (n >= B) return;
+    float* red = reinterpret_cast<float*>(smem + 4 * kC2StageB);          // [4 waves][32 rows][2]
+    // DMA sources: piece index i * 256 + tid of a chunk = (row i * 16 + (tid >> 4), slot tid & 15); the lane fetches logical piece slot ^ (row & 15)
+    const bf16_t* xb = a.x + (long long)n * a.x_sn;
+    const int prow = tid >> 4, pp = (tid & 15) ^ (prow & 15);
+    const bf16_t* src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { int r = i * 16 + prow; r = r < a.W ? r : a.W - 1; src[i] = xb + (long long)r * kC2K + pp * 8; }
+    auto dma = [&](int chunk, int stage) __attribute__((always_inline)) {
+        unsigned char* dst = smem + stage * kC2StageB + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + chunk * 128),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+    };
+    const u32x4* wp = reinterpret_cast<const u32x4*>(a.w) + (long long)tile * kC2Steps * 64 + lane;
+    u32x4 aq[8];
+    auto a_load = [&](int s, u32x4& dstv) __attribute__((always_inline)) {
+        const u32x4* p = wp + (long long)s * 64;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dstv) : "v"(p) : "memory");
+    };
+    dma(0, 0); dma(1, 1); dma(2, 2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a_load(u, aq[u]);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int px = wave * 32 + l31;
+    const unsigned xs0 = lds_addr(smem) + (unsigned)px * 256u;
+    const unsigned sw = (unsigned)(px & 15);
+    u32x4 bv[2];
+#pragma unroll
+    for (int c = 0; c < kC2Chunks; ++c) {
+        // chunk c has landed: operations issued behind its DMA = 24 / 32 / 40 / 40 / ... (fixed issue order: see the header)
+        if (c == 0) c2_wait_vm<24>(); else if (c == 1) c2_wait_vm<32>(); else c2_wait_vm<40>();
+        __builtin_amdgcn_s_barrier();                                 // ... for every wave's part; the stage chunk c - 1 used is free
+        dma(c + 3 < kC2Chunks ? c + 3 : kC2Chunks - 1, (c + 3) & 3);  // (past the end: a harmless re-fetch into the free stage keeps the counts uniform)
+        const unsigned cb = xs0 + (unsigned)((c & 3) * kC2StageB);
+        asm volatile("ds_read_b128 %0, %1" : "=&v"(bv[0]) : "v"(cb + (((unsigned)half ^ sw) << 4)));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u < 7) asm volatile("ds_read_b128 %0, %1" : "=&v"(bv[(u + 1) & 1]) : "v"(cb + (((unsigned)(2 * (u + 1) + half) ^ sw) << 4)));
+            asm volatile("s_waitcnt vmcnt(15)" : "+v"(aq[u]));       // the weight operand of this step (requested eight steps ago)
+            const u32x4 av = aq[u];
+            const int sn = c * 8 + u + 8;
+            a_load(sn < kC2Steps ? sn : kC2Steps - 1, aq[u]);
+            if (u < 7) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(bv[u & 1])); else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[u & 1]));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv[u & 1]), acc, 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- statistics over the valid columns, affine, store (as bf16_trunk_layer_kernel<false, .>)
+    float s1[16], s2[16];
+    const bool ok = px < a.W;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float v = ok ? acc[r] : 0.f; s1[r] = v; s2[r] = v * v; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+    if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            red[((wave * 32 + row) << 1)] = s1[r]; red[((wave * 32 + row) << 1) + 1] = s2[r];
+        }
+    }
+    __syncthreads();
+    const float invW = 1.0f / (float)a.W;
+    if (ok) {
+        bf16_t* yp = a.y + (long long)n * a.y_sn + (long long)px * a.C + tile * 32;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * qd + j, row = j + 8 * qd + 4 * half;
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) { t1 += red[((w4 * 32 + row) << 1)]; t2 += red[((w4 * 32 + row) << 1) + 1]; }
+                const float mean = t1 * invW;
+                float var = t2 * invW - mean * mean;
+                if (var < 0.f) var = 0.f;
+                const float sc = a.g0[tile * 32 + row] / sqrtf(var + a.eps);
+                o[j] = (acc[r] - mean) * sc + a.b0[tile * 32 + row];
+            }
+            uint2 pk2; pk2.x = pack2bf(o[0], o[1]); pk2.y = pack2bf(o[2], o[3]);
+            *reinterpret_cast<uint2*>(yp + 8 * qd + 4 * half) = pk2;
+        }
+    }
+}
+
+// conv2dto1d's weight in operand order: dst[((tile * 320 + s) * 64 + lane) * 8 + j] = W[32 tile + (lane & 31)][source channel of memory channel
+// kf = 16 s + 8 (lane >> 5) + j], memory channel kf = h * 256 + c <-> source channel c * 20 + h (model.py:249-251 as the forward lays y3 out)
+__global__ void __launch_bounds__(256) bf16_c2d1d_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst)
+{
+    const long long total = 8LL * kC2Steps * 512;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+        const long long ts = idx >> 9;
+        const int s_ = (int)(ts % kC2Steps), tile = (int)(ts / kC2Steps);
+        const int co = tile * 32 + (lane & 31), kf = 16 * s_ + 8 * (lane >> 5) + j;
+        const int ci = (kf & 255) * 20 + (kf >> 8);
+        dst[idx] = f2bf(w[(long long)co * kC2K + ci]);
+    }
+}
+
 __global__ void __launch_bounds__(256) bf16_pack_kernel(const Bf16PackArgs a)
 {
     const int ncc = a.Cin >> 5;
@@ -1568,6 +1699,33 @@ int mcvc_bf16_trunk_layer_launch(const bf16_t* x, long long x_sn, const bf16_t* 
     else if (glu) hipLaunchKernelGGL((bf16_trunk_layer_kernel<true, 512>), grid, dim3(256), lds, s, a);
     else if (Cin == 256) hipLaunchKernelGGL((bf16_trunk_layer_kernel<false, 256>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((bf16_trunk_layer_kernel<false, 512>), grid, dim3(256), lds, s, a);
+    return (int)hipGetLastError();
+}
+
+// ---- conv2dto1d + InstanceNorm (bf16_c2d1d_kernel): a sample row of at most 128 columns
+bool mcvc_bf16_c2d1d_applies(int W) { return W >= 1 && W <= kTrunkMaxW; }
+long long mcvc_bf16_c2d1d_pack_elems(void) { return 256LL * kC2K; }
+int mcvc_bf16_c2d1d_pack_launch(const float* w, bf16_t* dst, hipStream_t s)
+{
+    hipLaunchKernelGGL(bf16_c2d1d_pack_kernel, dim3(ew_blocks(8LL * kC2Steps * 512)), dim3(256), 0, s, w, dst);
+    return (int)hipGetLastError();
+}
+int mcvc_bf16_c2d1d_launch(const bf16_t* x, long long x_sn, const bf16_t* w, const float* gamma, const float* beta, bf16_t* y, long long y_sn,
+                           int B, int W, float eps, hipStream_t s)
+{
+    if (!mcvc_bf16_c2d1d_applies(W)) return MCVC_ERR_INVALID;
+    Bf16TrunkArgs a{};
+    a.x = x; a.x_sn = x_sn; a.w = w; a.g0 = gamma; a.b0 = beta; a.y = y; a.y_sn = y_sn; a.W = W; a.Cin = kC2K; a.C = 256; a.eps = eps;
+    const size_t lds = 4 * (size_t)kC2StageB + 4 * 32 * 2 * sizeof(float);
+    TraceScope ts(K_CONV_L, s, 2.0 * B * W * 256.0 * kC2K, 2.0 * ((double)B * W * kC2K * 8 + (double)B * W * 256 + 256.0 * kC2K * B));
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_c2d1d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    const int groups = cdiv_i(B, 8);
+    hipLaunchKernelGGL(bf16_c2d1d_kernel, dim3((unsigned)(groups * 64)), dim3(256), lds, s, a, B);
     return (int)hipGetLastError();
 }
 

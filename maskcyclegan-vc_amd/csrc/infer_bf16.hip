@@ -35,6 +35,7 @@ struct NetB {
     LayerB conv1, ds1, ds2, c2d1d, res_vg[6], res_out[6], c1d2d, up1, up2, last;
     long long off_g6, off_b6;      // permuted affine of conv1dto2dLayer_tfan
     long long off_tvg[6], off_tout[6];   // operand-order weight copies of the residual blocks for the fused layer kernel (r6)
+    long long off_c2;                    // ... of conv2dto1d for bf16_c2d1d_kernel
     long long bytes;
 };
 
@@ -80,6 +81,7 @@ static NetB build_net()
     for (int i = 0; i < 6; ++i) { place(n.res_vg[i]); place(n.res_out[i]); }
     n.off_g6 = take(4LL * 5120); n.off_b6 = take(4LL * 5120);
     for (int i = 0; i < 6; ++i) { n.off_tvg[i] = take(2 * mcvc_bf16_trunk_pack_elems(256, 512, 1)); n.off_tout[i] = take(2 * mcvc_bf16_trunk_pack_elems(512, 256, 0)); }
+    n.off_c2 = take(2 * mcvc_bf16_c2d1d_pack_elems());
     n.bytes = cur;
     return n;
 }
@@ -189,9 +191,17 @@ static void forward(Run& r, const float* x, const float* mask, float* out, const
     // :254-255 1x1 5120 -> 256 + IN.  K = 5120 in 32-channel stages of two MFMA steps each is 160 barrier-bound stages per workgroup; the
     // same bytes read as [b][5 * W4 "pixels"][1024 channels] make it a 1 x 5 convolution with stride 5 (non-overlapping windows): 32 stages
     // of ten steps, the weight pack groups the channels accordingly (r5: 122 -> see DESIGN 8b)
-    conv(r, n.c2d1d, B16(w.y3), (long long)W4 * 5120, 0, 1024, B, 1, 5 * W4, B16(w.c4), (long long)W4 * 256, 0, 256, 256);
-    norm(r, B16(w.c4), (long long)W4 * 256, 0, 256, B, 1, W4, 256, 0, BF16_ACT_NONE, P[22], P[23], nullptr, nullptr, nullptr,
-         B16(w.h[0]), (long long)W4 * 256, 0, 256);
+    // (r6) T <= 512 frames: conv + norm in ONE launch (operand-order weights, X through a four-stage LDS-DMA ring); MCVC_BF16_C2D1D_FUSED=0 in the
+    // experiments build restores the two-launch form
+    static const int c2_fused = mcvc_knob("MCVC_BF16_C2D1D_FUSED", 1);
+    if (c2_fused && mcvc_bf16_c2d1d_applies(W4)) {
+        r.fail(mcvc_bf16_c2d1d_launch(B16(w.y3), (long long)W4 * 5120, reinterpret_cast<const bf16_t*>(r.pk + n.off_c2), P[22], P[23], B16(w.h[0]),
+                                      (long long)W4 * 256, B, W4, kEps, r.s));
+    } else {
+        conv(r, n.c2d1d, B16(w.y3), (long long)W4 * 5120, 0, 1024, B, 1, 5 * W4, B16(w.c4), (long long)W4 * 256, 0, 256, 256);
+        norm(r, B16(w.c4), (long long)W4 * 256, 0, 256, B, 1, W4, 256, 0, BF16_ACT_NONE, P[22], P[23], nullptr, nullptr, nullptr,
+             B16(w.h[0]), (long long)W4 * 256, 0, 256);
+    }
     // :258-263 residual blocks
     int cur = 0;
     // (r6) T <= 512 frames: a sample's row is one tile wide, conv + InstanceNorm + GLU / residual of a layer are ONE launch (12 launches for the
@@ -276,6 +286,7 @@ int mcvc_gen_bf16_pack(const float* const* params, void* packed, void* stream)
     const LayerB* all[] = {&n.conv1, &n.ds1, &n.ds2, &n.c2d1d, &n.c1d2d, &n.up1, &n.up2, &n.last};
     for (const LayerB* l : all) pack_layer(r, *l, pk);
     for (int i = 0; i < 6; ++i) { pack_layer(r, n.res_vg[i], pk); pack_layer(r, n.res_out[i], pk); }
+    r.fail(mcvc_bf16_c2d1d_pack_launch(params[20], reinterpret_cast<bf16_t*>(pk + n.off_c2), r.s));
     for (int i = 0; i < 6; ++i) {
         const int b = 24 + 12 * i;
         r.fail(mcvc_bf16_trunk_pack_launch(params[b + 0], params[b + 4], reinterpret_cast<bf16_t*>(pk + n.off_tvg[i]), 256, 512, 1, r.s));
@@ -368,6 +379,22 @@ int mcvc_bf16_last_conv(const void* x, const float* w, const float* b, float* ou
     pack_layer(r, l, pk);
     r.fail(mcvc_bf16_last_fused_launch(static_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(pk + l.off_w), b, out, B, 80, T, r.s));
     return r.err;
+}
+
+// conv2dto1d + its InstanceNorm through the fused kernel (model.py:142-146, 254-255): x [B][W][5120] bf16 with memory channel h * 256 + c = the
+// reference's channel c * 20 + h (how the forward lays out downSample2's output), w [256][5120] fp32 in the REFERENCE's channel order, gamma /
+// beta [256]; y [B][W][256] bf16; W <= 128; wpack: mcvc_bf16_c2d1d_pack_bytes()
+long long mcvc_bf16_c2d1d_pack_bytes(void) { return 2 * mcvc_bf16_c2d1d_pack_elems() + 256; }
+
+int mcvc_bf16_c2d1d_norm(const void* x, const float* w, const float* gamma, const float* beta, void* y, void* wpack, int B, int W, void* stream)
+{
+    if (!x || !w || !gamma || !beta || !y || !wpack || B < 1 || !mcvc_bf16_c2d1d_applies(W)) return MCVC_ERR_INVALID;
+    if (reinterpret_cast<uintptr_t>(wpack) & 15) return MCVC_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    int e = mcvc_bf16_c2d1d_pack_launch(w, static_cast<bf16_t*>(wpack), s);
+    if (e) return e;
+    return mcvc_bf16_c2d1d_launch(static_cast<const bf16_t*>(x), (long long)W * 5120, static_cast<const bf16_t*>(wpack), gamma, beta, static_cast<bf16_t*>(y),
+                                  (long long)W * 256, B, W, kEps, s);
 }
 
 // one residual-block layer through the fused kernel (model.py:47-76): x [B][W][Cin] bf16, w / w_gate [C][Cin][3] fp32 (w_gate NULL: plain layer with

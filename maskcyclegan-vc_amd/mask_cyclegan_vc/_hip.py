@@ -73,6 +73,8 @@ _SIGS = {
     "mcvc_bf16_conv2d_pack_bytes": (c_longlong, [c_int, c_int, c_int, c_int]),
     "mcvc_bf16_conv2d": (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
     "mcvc_bf16_instnorm_act": (c_int, [c_void_p] * 8 + [c_int] * 6 + [c_void_p]),
+    "mcvc_bf16_c2d1d_pack_bytes": (c_longlong, []),
+    "mcvc_bf16_c2d1d_norm": (c_int, [c_void_p] * 6 + [c_int] * 2 + [c_void_p]),
     "mcvc_bf16_trunk_layer_pack_bytes": (c_longlong, [c_int] * 3),
     "mcvc_bf16_trunk_layer": (c_int, [c_void_p] * 10 + [c_int] * 4 + [c_void_p]),
     "mcvc_bf16_last_conv_pack_bytes": (c_longlong, []),

@@ -92,6 +92,27 @@ def test_bf16_fused_conv1_matches_fp32_on_the_same_rounded_operands(B, T, masked
     assert e < 4e-3, e
 
 
+@pytest.mark.parametrize("B,W", [(3, 16), (16, 128), (1, 17), (9, 100), (2, 2)])
+def test_bf16_fused_conv2dto1d_norm_matches_fp32_on_the_same_rounded_operands(B, W):
+    """r6: conv2dto1d (5120 -> 256, k = 1) + its InstanceNorm in ONE launch (bf16_c2d1d_kernel: X through a four-stage LDS-DMA ring with swizzled
+    16-byte pieces, operand-order weights in a register ring, hand-counted vmcnt waits) -- model.py:142-146, 249-255.  The kernel reads the
+    layout the forward produces (memory channel h * 256 + c = reference channel c * 20 + h) and the weight in the reference's order.
+    B = 9 / 16: more than one group of eight samples (the workgroup -> (sample, channel tile) map); ragged W; W = 2."""
+    L = lib()
+    g = torch.Generator().manual_seed(41)
+    xr = torch.randn(B, 5120, W, generator=g).cuda().to(torch.bfloat16)               # the reference's channel order c * 20 + h
+    w = (torch.randn(256, 5120, generator=g) / 5120 ** 0.5).cuda()
+    ga, be = (1 + 0.2 * torch.randn(256, generator=g)).cuda(), (0.3 * torch.randn(256, generator=g)).cuda()
+    xm = xr.view(B, 256, 20, W).permute(0, 3, 2, 1).contiguous().view(B, W, 5120)       # [b][w][h * 256 + c]
+    y = torch.full((B, W, 256), float("nan"), dtype=torch.bfloat16, device="cuda")
+    wpack = torch.zeros(L.mcvc_bf16_c2d1d_pack_bytes(), dtype=torch.uint8, device="cuda")
+    check(L.mcvc_bf16_c2d1d_norm(ptr(xm), ptr(w), ptr(ga), ptr(be), ptr(y), ptr(wpack), B, W, stream()), "bf16_c2d1d_norm")
+    z = F.instance_norm(F.conv1d(xr.float(), w.to(torch.bfloat16).float().unsqueeze(2)), weight=ga, bias=be, eps=1e-5)
+    got = y.float().permute(0, 2, 1)
+    assert torch.isfinite(got).all()
+    assert rel(got, z) < 4e-3, rel(got, z)
+
+
 @pytest.mark.parametrize("B,W,Cin,C,gated,res", [(3, 16, 256, 512, True, False), (3, 16, 512, 256, False, True), (2, 128, 256, 512, True, False),
                                                   (2, 128, 512, 256, False, True), (1, 17, 256, 512, True, False), (2, 100, 512, 256, False, False),
                                                   (1, 2, 256, 32, False, True), (2, 33, 512, 64, True, False)])

@@ -78,7 +78,7 @@ readme = """<!-- r06-readme-begin -->
 | C1 bs=1 full G+D iteration | **%.2f ms (%.1f it/s)** / %.2f; %d launches; %.2f ms after the identity cut-off | step = %.2f of its convolution-FLOP floor at the fp32 MFMA peak (`conv_roofline_ms` %.2f); dominant family (%s) %.2f; HBM %s GB by the counters = %.2f× algorithmic | round 5 driver run 5.87 |
 | C2 bs=32 | **%.1f ms** / %.1f | %.2f of the conv floor; dominant family %.2f of the nominal peak | round 5 driver run 70.7 |
 | C3 per-GPU shape bs=8 | **%.1f ms** / %.1f | %.2f of the conv floor; dominant family %.2f (contains the small trunk products) | round 5 driver run 21.5 |
-| C4 generator inference bs=16 x 512 frames | bf16 **%.2f ms** (%.2f M mel-frames/s) / %.2f | bf16 convs %.2f of the dense peak at 2.4 GHz | round 5 driver run 2.93; 34 launches per forward (48) |
+| C4 generator inference bs=16 x 512 frames | bf16 **%.2f ms** (%.2f M mel-frames/s) / %.2f | bf16 convs %.2f of the dense peak at 2.4 GHz | round 5 driver run 2.93; 33 launches per forward (48) |
 <!-- r06-readme-end -->""" % (
     d["ms_per_step"], d["value"], own[1]["ms_per_step"], d.get("kernel_launches_per_step", 0), post.get("ms_per_step", 0.0),
     own[1]["frac_of_conv_roofline"], own[1]["conv_roofline_ms"], own[1]["roofline"]["kernel"], own[1]["roofline"]["frac"],
