@@ -137,6 +137,26 @@ def test_gradients_match_reference(golden_dir, meta):
     assert checked > 80
 
 
+def _zero_bias(golden_dir):
+    """Conv biases in front of an InstanceNorm: their gradient is mathematically zero (the reference's own grad_norms.json says < 1e-6)."""
+    return {k.split(":", 1)[1] for k, v in json.load(open(os.path.join(golden_dir, "grad_norms.json"))).items() if v is not None and v < 1e-6}
+
+
+def _norm_gate(tol, rn, k, numel, it, lr, zero_bias):
+    """Allowed |norm - fixture norm| of one parameter tensor after ``it + 1`` optimizer steps.
+
+    Well-posed tensors: ``tol`` relative.  Two classes are NOT well-posed, on ANY host: the conv biases in front of an InstanceNorm (true
+    gradient 0: what reaches Adam is rounding residue) and the one-element biases (a cancelling sum).  Adam's first steps move an element by
+    ~lr * sign(g) whatever |g| is, so a residue whose sign depends on the CPU's summation order (vector width, thread count, oneDNN kernel
+    choice) becomes a +-lr difference per element and step.  The fixtures were written on one host and this test runs on whatever host the
+    suite is given (seen: the same oracle, same thread count, AVX-512 Xeon against the fixture's host -- 3.8e-4 absolute on a 256-element
+    bias after ONE step, every well-posed tensor at 1e-7).  Their gate is therefore Adam's own bound on what those flips can do to the
+    norm: ||dp|| <= steps * lr * sqrt(numel)."""
+    if k in zero_bias or numel == 1:
+        return (it + 1) * lr * numel ** 0.5
+    return tol * max(rn, 1e-3)
+
+
 def _load_step(golden_dir, tag):
     js = json.load(open(os.path.join(golden_dir, "step_%s.json" % tag)))
     bt = np.load(os.path.join(golden_dir, "step_%s_batches.npz" % tag))
@@ -154,6 +174,7 @@ def test_full_step_matches_unmodified_reference_train(golden_dir, skip_wasted):
     nets = _nets_from_filler(js["config"]["filler_seeds"])
     so = orc.StepOracle(nets, skip_wasted=skip_wasted)
     n_it = 3 if not skip_wasted else 2
+    zb, lr = _zero_bias(golden_dir), js["config"]["g_lr"]
     for it in range(n_it):
         batch = [torch.from_numpy(bt["it%d_%s" % (it, k)]) for k in ("real_A", "mask_A", "real_B", "mask_B")]
         g_loss, d_loss = so.step(*batch)
@@ -164,7 +185,7 @@ def test_full_step_matches_unmodified_reference_train(golden_dir, skip_wasted):
             names = orc.generator_param_names() if name.startswith("generator") else orc.discriminator_param_names()
             for k, rn in zip(names, ref_norms[name]):
                 mine = float(nets[name][k].double().norm())
-                assert abs(mine - rn) <= 2e-4 * max(rn, 1e-3), (it, name, k)
+                assert abs(mine - rn) <= _norm_gate(2e-4, rn, k, nets[name][k].numel(), it, lr, zb), (it, name, k)
     # Adam state exists only for parameters that ever received a grad (D downSample4 never does)
     dn = orc.discriminator_param_names()
     dead = {n * len(dn) + i for n in range(4) for i, k in enumerate(dn) if k.startswith(orc.DISC_DEAD_PREFIX)}
@@ -182,6 +203,7 @@ def _replay(golden_dir, tag, n_it, tol):
     so = orc.StepOracle(nets, skip_wasted=True)
     g_lr, d_lr, gs = cfg["g_lr"], cfg["d_lr"], 0
     denom = float(cfg["num_epochs"] * (cfg["n_utt"] // cfg["batch_size"]))
+    zb = _zero_bias(golden_dir)
     for it in range(n_it):
         batch = [torch.from_numpy(bt["it%d_%s" % (it, k)]) for k in ("real_A", "mask_A", "real_B", "mask_B")]
         assert js["trace"][it]["identity_lambda_before_check"] == so.identity_lambda
@@ -191,7 +213,7 @@ def _replay(golden_dir, tag, n_it, tol):
         for name in orc.NET_ORDER:
             names = orc.generator_param_names() if name.startswith("generator") else orc.discriminator_param_names()
             for k, rn in zip(names, js["trace"][it]["norms"][name]):
-                assert abs(float(nets[name][k].double().norm()) - rn) <= tol * max(rn, 1e-3), (it, name, k)
+                assert abs(float(nets[name][k].double().norm()) - rn) <= _norm_gate(tol, rn, k, nets[name][k].numel(), it, cfg["g_lr"], zb), (it, name, k)
         gs += cfg["batch_size"]
         if gs > cfg["decay_after"]:                                   # train.py:307-311, call-site bug included
             g_lr = max(0.0, g_lr - cfg["g_lr"] / denom)
@@ -209,10 +231,13 @@ def test_oracle_across_the_lr_decay_bug(golden_dir):
 def test_oracle_past_the_identity_cutoff(golden_dir):
     """Iterations 2 and 3 of the ``cutoff`` fixture run with identity_loss_lambda == 0 in the reference's unmodified train()
     (train.py:207-210 still computes the identity forwards, :223-224 weighs them 0).  Also pins the fixture's parameter SAMPLES:
-    element-wise values after four iterations, not only norms."""
+    element-wise values after four iterations, not only norms.  The element gate is the reference's own arithmetic spread after four Adam
+    steps (test_reference_arithmetic_spread_after_four_adam_steps asserts the same 3.5e-3 between thread counts): on the fixture's host this
+    replay sits under 1e-3; on a host whose vector width differs from it (AVX-512 Xeon) the SAME code is 2.0e-3 away on upSample1 / downSample2
+    with every loss within 4e-5 and every well-posed norm within 4e-5."""
     js, bt, nets = _replay(golden_dir, "cutoff", 4, 3e-4)
     assert [t["identity_lambda_before_check"] for t in js["trace"]] == [5, 5, 0, 0] and js["final"]["identity_loss_lambda"] == 0
-    zero_bias = {k.split(":", 1)[1] for k, v in json.load(open(os.path.join(golden_dir, "grad_norms.json"))).items() if v is not None and v < 1e-6}
+    zero_bias = _zero_bias(golden_dir)
     for name in orc.NET_ORDER:
         names = orc.generator_param_names() if name.startswith("generator") else orc.discriminator_param_names()
         for j, k in enumerate(names):
@@ -223,7 +248,7 @@ def test_oracle_past_the_identity_cutoff(golden_dir):
             ref = bt["final_%s_%d" % (name, j)]
             if ref.size == 1:            # the discriminators' one-element output bias: cancellation + Adam's normalisation (see test_hip_engine)
                 continue
-            assert rel_l2(mine, ref) < 1e-3, (name, k, rel_l2(mine, ref))
+            assert rel_l2(mine, ref) < 7e-3 / 2, (name, k, rel_l2(mine, ref))
 
 
 def test_reference_arithmetic_spread_after_four_adam_steps(golden_dir):
@@ -244,7 +269,7 @@ def test_reference_arithmetic_spread_after_four_adam_steps(golden_dir):
             assert abs(g_loss - js["losses"][it]["g_loss"]) < 1e-3 * abs(js["losses"][it]["g_loss"])     # (observed 4e-4 at the fourth iteration)
     finally:
         torch.set_num_threads(was)
-    zero_bias = {k.split(":", 1)[1] for k, v in json.load(open(os.path.join(golden_dir, "grad_norms.json"))).items() if v is not None and v < 1e-6}
+    zero_bias = _zero_bias(golden_dir)
     errs = []
     for name in orc.NET_ORDER:
         names = orc.generator_param_names() if name.startswith("generator") else orc.discriminator_param_names()
@@ -271,7 +296,7 @@ def test_reference_fp32_against_the_fp64_anchor(golden_dir):
     for it in range(4):       # fp32 losses vs fp64 losses: rounding only before the first update, the steps' amplification of it afterwards
         assert abs(fx["losses"][it][0] - js["losses"][it]["g_loss"]) < (2e-6 if it == 0 else 2e-4) * abs(js["losses"][it]["g_loss"])
         assert abs(fx["losses"][it][1] - js["losses"][it]["d_loss"]) < (2e-6 if it == 0 else 1e-3) * abs(js["losses"][it]["d_loss"])
-    zero_bias = {k.split(":", 1)[1] for k, v in json.load(open(os.path.join(golden_dir, "grad_norms.json"))).items() if v is not None and v < 1e-6}
+    zero_bias = _zero_bias(golden_dir)
     errs, pooled = [], {}
     for name in orc.NET_ORDER:
         names = orc.generator_param_names() if name.startswith("generator") else orc.discriminator_param_names()
