@@ -436,6 +436,8 @@ int mcvc_igemm_launch(const IGemmArgs& a0, hipStream_t s)
         const long long panel = (long long)kmax * BM * 4;
         long long mg = l2kb > 0 ? (long long)l2kb * 1024 / (panel > 0 ? panel : 1) : 0;
         if (l2kb > 0 && mg < 1) mg = 1;
+        static const int mgmax = mcvc_knob("MCVC_IGEMM_GROUP_MAX", 1 << 20);
+        if (mg > mgmax) mg = mgmax;
         if (mg > a.mt) mg = a.mt;
         a.mgroup = (int)mg;
     }

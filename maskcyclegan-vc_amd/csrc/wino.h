@@ -106,6 +106,7 @@ struct WinoGemmArgs {
     int M, N, K;                                 // N = valid columns (multiple of 32)
     int nxi;                                     // transform points: 36 (F(2x2,5x5)) or 16 (F(2x2,3x3)); 0 = 36
     int nt, mt;                                  // (filled by the launcher) tiles along n and m
+    int mgroup;                                  // (filled by the launcher) gemm2_kernel: row tiles per group of its tile order; 0 = column tile fastest
 };
 int mcvc_wino_gemm_launch(const WinoGemmArgs& a, hipStream_t s);
 

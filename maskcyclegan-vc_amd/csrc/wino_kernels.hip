@@ -683,9 +683,22 @@ __global__ void __launch_bounds__(256) gemm2_kernel(const Twin<WinoGemmArgs> tw)
         const int q = total >> 3, r = total & 7, xcd = linear & 7, k = linear >> 3;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
-    const int n0 = (lid % a.nt) * BN; lid /= a.nt;
-    const int m0 = (lid % a.mt) * BM;
-    const int xi = lid / a.mt;
+    // Tile order inside a point (r6): with `mgroup` row tiles per group the ROW tile is the fastest index inside a group, then the column tile
+    // (igemm_kernel's order) -- the ~64 workgroups an XCD holds at a time are then mgroup x (64 / mgroup) tiles that sweep k side by side, so
+    // a stage's A chunk is fetched once for 64 / mgroup of them and its B chunk once for mgroup (the reuse is SIMULTANEOUS: it needs no L2
+    // capacity), against 1 x 64 tiles -- B fetched once per row tile -- with the column tile fastest (mgroup = 0).
+    int n_t, m_t, xi;
+    if (a.mgroup == 0) { n_t = lid % a.nt; lid /= a.nt; m_t = lid % a.mt; xi = lid / a.mt; }
+    else {
+        const int mg = a.mgroup, per = a.mt * a.nt;
+        int r = lid % per;
+        xi = lid / per;
+        const int g = r / (mg * a.nt);
+        const int gm = (g + 1) * mg <= a.mt ? mg : a.mt - g * mg;
+        r -= g * mg * a.nt;
+        n_t = r / gm; m_t = g * mg + r % gm;
+    }
+    const int n0 = n_t * BN, m0 = m_t * BM;
     const float* A = a.a + (long long)xi * a.a_xi + m0;
     const float* B = a.b + (long long)xi * a.b_xi + n0;
     constexpr int A4R = BM / 4, B4R = BN / 4;                     // float4 per row
@@ -782,6 +795,11 @@ static int gemm2_launch(WinoGemmArgs b, int nxi, hipStream_t s)
 {
     if ((b.M % BM) != 0 || (b.K % GK) != 0) return MCVC_ERR_INVALID;
     b.nt = cdiv_i(b.N, BN); b.mt = b.M / BM;
+    {   // row tiles per group (see gemm2_kernel): only where a point has enough column tiles for the order to matter
+        static const int mgk = mcvc_knob("MCVC_GEMM_MGROUP", 0);
+        static const int mgn = mcvc_knob("MCVC_GEMM_MGROUP_MINNT", 8);
+        b.mgroup = (mgk > 0 && b.nt >= mgn) ? (mgk < b.mt ? mgk : b.mt) : 0;
+    }
     constexpr size_t lds = (size_t)ST * (GK * BM + GK * BN) * sizeof(float);
     static bool done = false;
     if (!done) {

@@ -138,11 +138,16 @@ def test_four_iterations_past_the_identity_cutoff_pipelined_and_unflushed(golden
     # Per-tensor distance after FOUR Adam steps, in DETERMINISTIC mode: one number per binary.  What bounds it is stated against an fp64
     # anchor in tests/test_hip_parity_fp64.py (HIP and the reference's fp32 arithmetic each sit ~1e-3 at worst from the float64 result:
     # Adam's first steps turn rounding-level gradients into +-lr parameter differences); here the HIP step is compared with the reference's
-    # fp32 result directly -- the fixture's element samples (fixed numbers: the gate is the measured worst x 1.25) and the oracle's full
-    # tensors (the oracle runs on this host's CPU, whose thread count moves its own result by up to ~1e-3: gate 2e-3).
-    # r6 binary (two-level accumulation in the Winograd GEMMs): worst sample distance 1.383e-3, worst full-tensor distance < 1e-3, 0 of 232
-    # tensors beyond 1e-3.  (r5: 4.2e-3 - 4.6e-3, 63-65 tensors beyond 1e-3, gate 7e-3: profiles/r06_parity_probe_before.log has the why.)
-    worst, n_t, n_over, bad, top = 0.0, 0, 0, [], []
+    # fp32 result directly:
+    #   e_s  against the fixture's element samples -- fixed numbers on both sides, so the gate is the measured worst x 1.25 and the count of
+    #        tensors beyond 1e-3 is gated on THIS distance (host-independent);
+    #   e_f  against the oracle's full tensors.  The oracle runs on this host's CPU, and its result is a property of that CPU: the same oracle
+    #        on an AVX-512 Xeon / 8 threads sits 2.0e-3 from the fixture on upSample1 / downSample2 with 15 of 232 tensors beyond 1e-3
+    #        (tests/test_oracle_golden.py::test_oracle_past_the_identity_cutoff), on the MI355X boxes' EPYC 9575F under 1e-3.  Its gate is the
+    #        reference's asserted self-spread (7e-3 / 2, test_reference_arithmetic_spread_after_four_adam_steps), not a number tuned on one host.
+    # r6 binary (two-level accumulation in the Winograd GEMMs): worst sample distance 1.383e-3 with 9 of 232 tensors beyond 1e-3 (gate 5 % = 11);
+    # against the EPYC boxes' oracle worst full-tensor distance < 1e-3, 0 beyond (profiles/r06b_parity_host_independent.log).  (r5: 4.2e-3 - 4.6e-3, 63-65 tensors beyond 1e-3, gate 7e-3: profiles/r06_parity_probe_before.log has the why.)
+    worst, n_t, n_over_s, n_over_f, bad, top = 0.0, 0, 0, 0, [], []
     for name in orc.NET_ORDER:
         for j, ((pn, p), rn) in enumerate(zip(nets[name].named_parameters(), js["trace"][-1]["norms"][name])):
             if pn in skip:
@@ -160,13 +165,15 @@ def test_four_iterations_past_the_identity_cutoff_pipelined_and_unflushed(golden
             worst = max(worst, e_s, e_f)
             top.append((max(e_s, e_f), name, pn, p.numel()))
             n_t += 1
-            n_over += int(e_f > 1e-3)
-            if not (e_s < 1.383e-3 * 1.25 and e_f < 2e-3):
+            n_over_s += int(e_s > 1e-3)
+            n_over_f += int(e_f > 1e-3)
+            if not (e_s < 1.383e-3 * 1.25 and e_f < 7e-3 / 2):
                 bad.append((name, pn, e_s, e_f))
-    print("cutoff fixture, 4 un-flushed pipelined iterations: worst per-tensor rel-L2 %.3e, %d of %d tensors beyond 1e-3" % (worst, n_over, n_t))
+    print("cutoff fixture, 4 un-flushed pipelined iterations: worst per-tensor rel-L2 %.3e; of %d tensors beyond 1e-3: %d (fixture samples), %d (this host's oracle)"
+          % (worst, n_t, n_over_s, n_over_f))
     print("  largest: " + "; ".join("%s.%s (%d) %.2e" % (n, q, k, e) for e, n, q, k in sorted(top, reverse=True)[:6]))
     assert not bad, bad
-    assert n_over <= 0.05 * n_t, (n_over, n_t)
+    assert n_over_s <= 0.05 * n_t, (n_over_s, n_t)
 
 
 def _kink_free_batch(onets, B, T=64):

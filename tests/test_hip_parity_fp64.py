@@ -115,19 +115,35 @@ def _report(tag, rows, pooled):
     return eh, er
 
 
+# The reference's OWN distance to the anchor is a property of the host the oracle runs on (oneDNN / MKL pick their kernels by CPU vendor and
+# vector width, the summation order follows the thread count), measured on this fixture:
+#     EPYC 9575F, 32 threads (the MI355X boxes):   pooled 5.92e-4, worst tensor 1.08e-3, median 4.89e-5,  4 of 216 tensors beyond 1e-3
+#     Xeon (AVX-512), 8 threads (build container): pooled 8.29e-4, worst tensor 1.42e-3, median 6.82e-5, 11 of 216
+# (profiles/r06_parity_repeat3.log, profiles/r06_reference_distance_by_host.log).  The HIP side is deterministic -- one number per binary -- so a
+# comparison against the LIVE reference alone would pass or fail with the host.  Each reference figure below is therefore the live one
+# floored at the MOST ACCURATE reference host measured so far (the first row): on such a host nothing changes, on a host where the reference
+# happens to land closer to the anchor the claim stays "as accurate as the reference on the best host we have seen", and on a host where
+# it lands further away the live (larger) figure is the honest same-host comparison.
+REF_BEST_HOST = {"pooled": {"generator_A2B": 2.300e-4, "generator_B2A": 2.541e-4, "discriminator_A": 2.838e-4, "discriminator_B": 1.344e-4,
+                            "discriminator_A2": 1.427e-4, "discriminator_B2": 3.384e-4},
+                 "all": 5.924e-4, "worst": 1.078e-3, "median": 4.891e-5, "beyond": 4}
+
+
 def _as_accurate_as_the_reference(eh, er, pooled):
     """The statement "as accurate as the reference's fp32 step", on one fixture.  The quantity is chaotic (a flipped rounding-level sign in
     iteration 1 changes which signs flip in iteration 2), so single networks scatter by ~2x either way between arithmetically equivalent
-    implementations -- the reference at another thread count included; the gates are on the whole step, with that scatter allowed per network."""
+    implementations -- the reference at another thread count or on another CPU included; the gates are on the whole step, with that scatter
+    allowed per network, and the reference's figures are floored as REF_BEST_HOST says."""
     num = sum(h * h for h, _ in pooled.values()) ** 0.5
-    den = sum(r * r for _, r in pooled.values()) ** 0.5
-    print("   all networks: HIP %.3e reference %.3e ratio %.2f" % (num, den, num / den))
-    assert num <= 1.5 * den, (num, den)
+    den_live = sum(r * r for _, r in pooled.values()) ** 0.5
+    den = max(den_live, REF_BEST_HOST["all"])
+    print("   all networks: HIP %.3e reference %.3e ratio %.2f" % (num, den_live, num / den_live))
+    assert num <= 1.5 * den, (num, den_live)
     for n, (h, r) in pooled.items():
-        assert h <= 3.0 * r, (n, h, r)
-    assert eh.max() <= 1.5 * er.max(), (eh.max(), er.max())
-    assert np.median(eh) <= 1.5 * np.median(er), (np.median(eh), np.median(er))
-    assert int((eh > 1e-3).sum()) <= int((er > 1e-3).sum()) + 2
+        assert h <= 3.0 * max(r, REF_BEST_HOST["pooled"][n]), (n, h, r)
+    assert eh.max() <= 1.5 * max(er.max(), REF_BEST_HOST["worst"]), (eh.max(), er.max())
+    assert np.median(eh) <= 1.5 * max(np.median(er), REF_BEST_HOST["median"]), (np.median(eh), np.median(er))
+    assert int((eh > 1e-3).sum()) <= max(int((er > 1e-3).sum()), REF_BEST_HOST["beyond"]) + 2
 
 
 def test_precise_mode_is_as_accurate_as_the_reference_fp32(golden_dir, anchors):
