@@ -76,6 +76,7 @@ struct WGemmArgs {
     float* c; float* c2; int m_split; int accumulate;
     int nsplit; float* c_slab; long long c_split;
     long long ldc; int nstages, nt, mt;  // (filled by the launcher)
+    int xcd_order;                       // (filled by the launcher) 1: every XCD gets one contiguous range of tiles (see wgemm_kernel)
 };
 int mcvc_wgemm_launch(const WGemmArgs& a, hipStream_t s);
 int mcvc_wgemm_cib(int taps);            // input channels per workgroup tile

@@ -429,15 +429,24 @@ int mcvc_igemm_launch(const IGemmArgs& a0, hipStream_t s)
     }
     bytes += 4.0 * (double)a.Cb * a.N * 2.25;            // (the gathered activation: read once from HBM, the taps' overlap hits in L2)
     a.nt = cdiv_i(a.N, BN); a.mt = a.M / BM;
-    {   // row tiles per group: their A panels (the longest class's K x 64 floats each) within ~2 MB of the 4 MB L2 of an XCD
+    {   // Row tiles per group of the tile order (igemm_kernel).  Two kinds of reuse decide what an XCD fetches through its L2:
+        //  * over TIME -- a group's A panels (the longest class's K x 64 floats each) stay in L2 while the group's column tiles pass by: needs
+        //    the panels within ~2 MB of the 4 MB (r5's rule; right for the short grids: a whole XCD's share is resident at once and A dominates);
+        //  * SIMULTANEOUS -- the ~64 workgroups an XCD holds (2 per CU) sweep k side by side, so a stage's A chunk is fetched once for all the
+        //    column tiles of its row among them and its B chunk once for all the rows of its column: gm x (64 / gm) tiles fetch
+        //    (gm + 64 / gm) chunks per stage -- 16 at gm = 8 against 65 at gm = 1 -- and need no capacity at all.  r5's rule gives gm = 1 exactly
+        //    where it matters (downSample3: 1.2 MB panels) and the gathered activation was fetched once per ROW tile: FETCH_SIZE per launch at
+        //    32 samples 626 -> 252 MB (forward), 338 -> 262 MB (data gradient) with 8 rows per group; at 8 samples (an XCD's share is 20-80
+        //    tiles, all resident at once) the data gradient went 42 -> 82 MB, so the grid must hold at least one full resident round per XCD
+        //    (profiles/r06b_pmc_order.log; the step time does not move either way: r06b_ab_tile_order.log).
         int kmax = 0;
         for (int c = 0; c < a.ncls; ++c) kmax = a.cls[c].ntaps * a.Cb > kmax ? a.cls[c].ntaps * a.Cb : kmax;
         static const int l2kb = mcvc_knob("MCVC_IGEMM_GROUP_KB", 2048);          // (0: the column tile fastest, r4's order)
+        static const int simul = mcvc_knob("MCVC_IGEMM_GROUP_ROWS", 8);          // (0: r5's rule alone)
         const long long panel = (long long)kmax * BM * 4;
         long long mg = l2kb > 0 ? (long long)l2kb * 1024 / (panel > 0 ? panel : 1) : 0;
         if (l2kb > 0 && mg < 1) mg = 1;
-        static const int mgmax = mcvc_knob("MCVC_IGEMM_GROUP_MAX", 1 << 20);
-        if (mg > mgmax) mg = mgmax;
+        if (l2kb > 0 && simul > mg && (long long)a.nt * a.mt * a.nsplit >= 8 * 64) mg = simul;
         if (mg > a.mt) mg = a.mt;
         a.mgroup = (int)mg;
     }

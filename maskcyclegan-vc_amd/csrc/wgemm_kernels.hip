@@ -49,7 +49,15 @@ __global__ void __launch_bounds__(256) wgemm_kernel(const Twin<WGemmArgs> tw)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
+    // Tile ids run input-channel tile fastest, then output-channel tile, then pixel split.  The hardware deals consecutive workgroup ids
+    // round-robin to the 8 XCDs, so with lid = blockIdx.x the nt workgroups that multiply the SAME dY tile sat behind up to 8 different L2s and
+    // dY was fetched once per XCD.  With one contiguous range of ids per XCD (r6; the remap of gemm2_kernel / igemm_kernel) an XCD's workgroups
+    // are neighbours in (n, m) of the same pixel split -- and the splits partition the pixels, so the XCDs share almost nothing
     int lid = (int)blockIdx.x;
+    if (a.xcd_order) {
+        const int total = (int)gridDim.x, q = total >> 3, r = total & 7, xcd = lid & 7, k = lid >> 3;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
     const int nt = a.nt, mt = a.mt;
     const int n0 = (lid % nt) * CIB; lid /= nt;        // first input channel
     const int m0 = (lid % mt) * WBM;                   // first output channel
@@ -219,6 +227,8 @@ int mcvc_wgemm_launch(const WGemmArgs& a0, hipStream_t s)
     a.nstages = cdiv_i(a.NPIX, WGK);
     if (a.nsplit > a.nstages) return MCVC_ERR_INVALID;            // (the caller sums ITS slab count with dw_accum: never clamp behind its back -- ADVICE r5)
     a.nt = a.Cin / cib; a.mt = a.M / WBM;
+    static const int xcd_order = mcvc_knob("MCVC_WGEMM_XCD", 1);
+    a.xcd_order = xcd_order;
     a.ldc = (long long)a.Cin * a.ntaps;
     const double K = (double)a.NPIX;
     const double flops = 2.0 * a.M * a.Cin * a.ntaps * K;

@@ -795,8 +795,10 @@ static int gemm2_launch(WinoGemmArgs b, int nxi, hipStream_t s)
 {
     if ((b.M % BM) != 0 || (b.K % GK) != 0) return MCVC_ERR_INVALID;
     b.nt = cdiv_i(b.N, BN); b.mt = b.M / BM;
-    {   // row tiles per group (see gemm2_kernel): only where a point has enough column tiles for the order to matter
-        static const int mgk = mcvc_knob("MCVC_GEMM_MGROUP", 0);
+    {   // row tiles per group (see gemm2_kernel): where a point has enough column tiles for the order to matter.  FETCH_SIZE per launch of the
+        // 128 x 128 products at 32 samples 720 -> 356 MB, at 8 samples 203 -> 164 MB (profiles/r06b_pmc_order.log); the one- and two-sample
+        // products (1-3 column tiles) keep the column tile fastest
+        static const int mgk = mcvc_knob("MCVC_GEMM_MGROUP", 8);
         static const int mgn = mcvc_knob("MCVC_GEMM_MGROUP_MINNT", 8);
         b.mgroup = (mgk > 0 && b.nt >= mgn) ? (mgk < b.mt ? mgk : b.mt) : 0;
     }
