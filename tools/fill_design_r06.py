@@ -47,7 +47,7 @@ def cpu(r):
 
 rev = own[1].get("hbm_bytes_per_step_pmc_source", "?")
 block = """<!-- r06-numbers-begin -->
-**Round-6 numbers (1× MI355X; `profiles/r06_*`: bench lines, traces, PMC / SQ passes and the GPU test log of ONE gpurun call, `tools/r06_final.sh`, at the
+**Round-6 numbers (1× MI355X; `profiles/r06_*`: bench lines, traces, PMC / SQ passes and the GPU test log of ONE gpurun call, `tools/r06_final2.sh` (the default-run line: the call right after it, with the refreshed counter files in place), at the
 revision inside `r06_pmc_traffic_bs*.json` (%s); default run = what the driver runs, the other configs nested under `"configs"`; boxes differ by ±2 %%:
 the same-box A/B numbers of §8b / §9 are the ones that compare states):**
 
@@ -60,8 +60,8 @@ the same-box A/B numbers of §8b / §9 are the ones that compare states):**
 | C3 per-GPU shape bs=8 | 21.5 ms | **%.1f ms** | %.1f | %s | %s | %s |
 | C4 inference bs=16×512, bf16 | 2.93 ms | **%.2f ms** (%.2f M mel-frames/s) | %.2f | dominant conv %.0f TF/s = %.2f of the dense bf16 peak | — | %s |
 
-The counter-measured bytes fell with the InstanceNorm-backward fix (bs=1 15.62 → %s GB, bs=8 56.86 → %s, bs=32 198.5 → %s); what is left above the
-launchers' counts is the implicit GEMMs' gathered operand (per family: `hbm_bytes_per_step_by_family` in the bench line).
+The counter-measured bytes fell twice this round: with the InstanceNorm-backward fix (bs=1 15.62 → 14.33 GB, bs=8 56.86 → 49.48, bs=32 198.5 → 183.65) and with
+the GEMM families' tile orders (→ %s / %s / %s GB; below: "tile ORDER, not L2 capacity"); per family: `hbm_bytes_per_step_by_family` in the bench line.
 <!-- r06-numbers-end -->""" % (
     rev,
     d["ms_per_step"], d["value"], d.get("kernel_launches_per_step", 0), own[1]["ms_per_step"], roof(own[1]), bytes_cell(own[1]), cpu(d),
