@@ -244,10 +244,15 @@ def test_fused_trunk_layer_matches_torch(B, T4, Cin, Cout, KW, kind):
 
 
 @pytest.mark.parametrize("nb,M,N,K", [(36, 1024, 96, 256), (36, 1024, 160, 256), (36, 512, 320, 256), (16, 512, 96, 1024), (16, 512, 640, 512),
-                                      (36, 256, 1024, 96), (3, 128, 64, 16), (2, 256, 200, 48)])
+                                      (36, 256, 1024, 96), (3, 128, 64, 16), (2, 256, 200, 48),
+                                      (16, 768, 640, 512), (36, 1536, 1400, 64), (12, 640, 3000, 32)])
 def test_batched_winograd_gemm_matches_torch(nb, M, N, K):
     """Isolated parity of wino_gemm_kernel (both tile widths) -- the 36 / 16 per-point products of the Winograd convolutions, in the
-    shapes the generator produces at B = 1, 2, 4 (incl. the ragged 96- and 160-column cases that take the 32-column tile)."""
+    shapes the generator produces at B = 1, 2, 4 (incl. the ragged 96- and 160-column cases that take the 32-column tile).  The last three
+    shapes take gemm2_kernel's row-group tile order (r6: 8 row tiles per group where a point has >= 8 column tiles) with a row-tile count
+    that is NOT a multiple of the group -- 12 tiles of 64 rows (64 x 64 tiles, K >= 512), 12 of 128 rows with a ragged last column tile (the
+    128 x 128 tiles of the large grids), 5 of 128 rows (one short group, 12 points) -- so a tile the order skipped or visited twice shows as NaN / a
+    wrong block (c is pre-filled with NaN)."""
     from mask_cyclegan_vc._hip import check, lib, ptr, stream
     L = lib()
     g = torch.Generator().manual_seed(3)
@@ -289,6 +294,7 @@ LAYER_CASES = [
     ("d.ds1.small", 128, 256, 1, 3, 3, 2, 1, 1, 1, 12, 16, False, (5,)),
     ("d.ds1.B4", 128, 256, 1, 3, 3, 2, 1, 1, 4, 80, 64, False, (5,)),              # K split of the implicit weight gradient over 160 pixel stages
     ("d.ds3.B8", 512, 1024, 1, 3, 3, 2, 1, 1, 8, 20, 16, False, (5,)),             # 128 tiles, no split: straight into the gradient
+    ("d.rows12.B9", 256, 768, 1, 3, 3, 2, 1, 1, 9, 40, 32, False, (5,)),           # 12 x 45 forward tiles: igemm's 8-row groups (r6) with a ragged last group of 4
 ]
 _LAYER_IDS = ["%s-s%d" % (c[0], s) for c in LAYER_CASES for s in c[-1]]
 _LAYER_PARAMS = [(c, s) for c in LAYER_CASES for s in c[-1]]
